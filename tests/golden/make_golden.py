@@ -1,0 +1,352 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz by RUNNING THE REFERENCE's own model files.
+
+Run in the authoring container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+What it does
+------------
+* writes a throw-away stand-in for the packages the reference imports but this image lacks
+  (``torch_geometric``, ``torch_sparse``, ``learningHelper``) into a temp dir and puts it first on
+  sys.path.  The stand-in is OUR code and states our reading of PyG 2.0.2 / torch_scatter 2.0.9
+  (SURVEY.md Appendix B): ``MessagePassing.propagate`` for a dense LongTensor edge_index =
+  index_select -> message -> scatter-add by destination -> count -> clamp(min 1) -> divide.
+* imports ``/root/reference/learning/surfaceNet{Static,Updated}EdgeFilters.py`` UNMODIFIED from
+  where they lie, builds ``SurfaceNet`` from ``configs/pretrained/reconbench.yaml``, loads the
+  shipped checkpoint ``data/models/kf96/model_best.ptm`` and runs the reference methods.
+* stores inputs + reference outputs (fp32, and an fp64 re-evaluation) as small npz fixtures, and
+  the checkpoint's tensors as ``kf96_weights.npz`` (data only; no reference source is copied).
+
+Nothing here travels to the GPU box except the resulting .npz data files.
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import tempfile
+import textwrap
+
+import numpy as np
+import torch
+import yaml
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+STANDIN = {
+    "torch_geometric/__init__.py": "",
+    "torch_geometric/typing.py": """
+        from typing import Optional, Tuple, Union
+        from torch import Tensor
+        OptPairTensor = Tuple[Tensor, Optional[Tensor]]
+        Adj = Union[Tensor, object]
+        Size = Optional[Tuple[int, int]]
+    """,
+    "torch_geometric/nn/__init__.py": "",
+    "torch_geometric/nn/conv/__init__.py": """
+        import torch
+        from torch import Tensor
+
+        class _Inspector:
+            def __init__(self, mp): self.mp = mp
+            def distribute(self, name, d):
+                if name == 'message':   return {'x_j': d['x_j'], 'edge_attr': d['edge_attr']}
+                if name == 'aggregate': return {'index': d['index'], 'dim_size': d['dim_size']}
+                return {}
+
+        class MessagePassing(torch.nn.Module):
+            # PyG 2.0.2 semantics for a dense LongTensor edge_index, flow source_to_target, node_dim=-2
+            def __init__(self, aggr='add', flow='source_to_target', node_dim=-2):
+                super().__init__()
+                assert aggr == 'mean' and flow == 'source_to_target'
+                self.aggr, self.flow, self.node_dim = aggr, flow, node_dim
+                self.fuse = False
+                self.__explain__ = False
+                self.__user_args__ = ['x_j', 'edge_attr']
+                self.inspector = _Inspector(self)
+            def __check_input__(self, edge_index, size):
+                assert isinstance(edge_index, Tensor) and edge_index.dtype == torch.long and edge_index.dim() == 2
+                return [None, None] if size is None else list(size)
+            def __collect__(self, args, edge_index, size, kwargs):
+                x = kwargs['x']
+                return {'x_j': x[0].index_select(0, edge_index[0]), 'edge_attr': kwargs['edge_attr'],
+                        'index': edge_index[1], 'dim_size': x[1].size(0)}
+            def aggregate(self, inputs, index, dim_size):
+                # torch_scatter.scatter(inputs, index, dim=0, dim_size=dim_size, reduce='mean')
+                out = torch.zeros((dim_size, inputs.size(1)), dtype=inputs.dtype)
+                out.index_add_(0, index, inputs)
+                cnt = torch.zeros(dim_size, dtype=inputs.dtype)
+                cnt.index_add_(0, index, torch.ones_like(index, dtype=inputs.dtype))
+                cnt[cnt < 1] = 1
+                return out / cnt.unsqueeze(1)
+            def update(self, inputs): return inputs
+            def propagate(self, edge_index, size=None, **kwargs):
+                size = self.__check_input__(edge_index, size)
+                d = self.__collect__(self.__user_args__, edge_index, size, kwargs)
+                out = self.message(**self.inspector.distribute('message', d))
+                out = self.aggregate(out, **self.inspector.distribute('aggregate', d))
+                return self.update(out)
+
+        class SAGEConv(MessagePassing):  # imported by the reference, never instantiated on this path
+            pass
+    """,
+    "torch_geometric/nn/norm/__init__.py": """
+        import torch
+        class BatchNorm(torch.nn.Module):
+            def __init__(self, in_channels, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
+                super().__init__()
+                self.module = torch.nn.BatchNorm1d(in_channels, eps, momentum, affine, track_running_stats)
+            def forward(self, x): return self.module(x)
+        class LayerNorm(torch.nn.Module):
+            def __init__(self, *a, **k): raise NotImplementedError
+    """,
+    "torch_sparse/__init__.py": """
+        class SparseTensor: pass
+        def matmul(*a, **k): raise NotImplementedError
+    """,
+    "learningHelper.py": "def get_gpu_memory(*a, **k): return 0\n",
+}
+
+
+class AD(dict):
+    """5-line attribute dict standing in for munch.Munch (run.py:291)."""
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+    __setattr__ = dict.__setitem__
+
+    @staticmethod
+    def wrap(o):
+        if isinstance(o, dict):
+            return AD({k: AD.wrap(v) for k, v in o.items()})
+        return o
+
+
+def load_ref():
+    d = tempfile.mkdtemp(prefix="pyg_standin_")
+    for rel, src in STANDIN.items():
+        p = os.path.join(d, rel)
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+        with open(p, "w") as f:
+            f.write(textwrap.dedent(src))
+    sys.path.insert(0, d)
+    mods = {}
+    for name in ("surfaceNetStaticEdgeFilters", "surfaceNetUpdatedEdgeFilters"):
+        spec = importlib.util.spec_from_file_location("ref_" + name, os.path.join(REF, "learning", name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        mods[name] = m
+    return mods
+
+
+def static_clf():
+    with open(os.path.join(REF, "configs/pretrained/reconbench.yaml")) as f:
+        clf = AD.wrap(yaml.safe_load(f))
+    clf.temp = AD(device="cpu", num_node_features=28, num_edge_features=20)
+    return clf
+
+
+def four_regular_random(n, rng):
+    """Seeded symmetric 4-regular graph without self loops / duplicates, reference layout [4n,2]."""
+    while True:
+        nb = [set() for _ in range(n)]
+        ok = True
+        for _ in range(2):  # two random Hamiltonian cycles -> degree 4
+            p = rng.permutation(n)
+            for a, b in zip(p, np.roll(p, 1)):
+                if a == b or b in nb[a]:
+                    ok = False
+                nb[a].add(int(b)); nb[b].add(int(a))
+        if ok and all(len(s) == 4 for s in nb):
+            break
+    adj = np.empty((4 * n, 2), np.int32)
+    for i in range(n):
+        adj[4 * i:4 * i + 4, 0] = i
+        adj[4 * i:4 * i + 4, 1] = rng.permutation(sorted(nb[i]))
+    return adj
+
+
+def ignatius_block(n_keep=768):
+    """F1: BFS ball of the real Ignatius adjacency closed under 4-regularity by a sink node, with
+    the real per-scene-standardised node features and 16 real edge columns (+4 seeded N(0,1)
+    columns standing in for the missing 99_fgeom.npz), produced by the reference's own loader."""
+    sys.path.insert(0, REF)
+    from processing.data import dataLoader  # reference loader, run here only
+    clf = static_clf()
+    clf.features.edge_features = [f for f in clf.features.edge_features if f != "shape"]
+    clf.inference.has_label = 0
+    dl = dataLoader(clf, verbosity=0)
+    dl.run(dict(path=os.path.join(REF, "data/Ignatius"), filename="99", category="", id="", scan_conf="",
+                gtfile="gt/99", ioufile=""))
+    x, ea, ei = dl.features, dl.edge_features, dl.edge_lists
+    assert x.shape[1] == 29 and ea.shape[1] == 16
+    n = x.shape[0]
+    dst = ei[1].numpy().reshape(n, 4)
+    seen = {1000: 0}
+    queue = [1000]
+    while queue and len(seen) < n_keep:
+        u = queue.pop(0)
+        for v in dst[u]:
+            v = int(v)
+            if v not in seen and len(seen) < n_keep:
+                seen[v] = len(seen)
+                queue.append(v)
+    keep = np.array(sorted(seen, key=seen.get))
+    sink = len(keep)
+    loc = np.full(n, sink, np.int64)
+    loc[keep] = np.arange(len(keep))
+    # directed edges of kept nodes (their 4 out-rows, dst re-wired to sink when cut) and the
+    # matching in-edges sink->node are NOT added: the block is used as a bipartite-free directed
+    # graph; in-degree then varies (0..4) which exercises the count-clamp path on real data.
+    rows = (keep[:, None] * 4 + np.arange(4)[None]).reshape(-1)
+    e_src = loc[ei[0].numpy()[rows]]
+    e_dst = loc[ei[1].numpy()[rows]]
+    g = torch.Generator().manual_seed(7)
+    xs = torch.cat([x[keep], torch.zeros(1, 29)], 0)
+    eas = torch.cat([torch.randn(len(rows), 4, generator=g), ea[rows]], 1)
+    return xs.float(), eas.float(), torch.from_numpy(np.stack([e_src, e_dst])).long()
+
+
+def run_static(ref, sd, x, ea, ei, dtype):
+    clf = static_clf()
+    net = ref["surfaceNetStaticEdgeFilters"].SurfaceNet(clf)
+    msg = net.load_state_dict(sd)
+    assert str(msg) == "<All keys matched successfully>", msg
+    net = net.to(dtype).eval()
+    data = AD(x=x.to(dtype), edge_attr=ea.to(dtype), edge_index=ei)
+    acts = {}
+    with torch.no_grad():
+        # same calls as SurfaceNet.inference_layer, hooks capture the per-layer tensors
+        hooks = []
+        for i, blk in enumerate(net.convs):
+            hooks.append(blk[0].register_forward_hook(lambda m, a, o, i=i: acts.__setitem__("conv%d" % i, o.clone())))
+            hooks.append(blk[1].register_forward_hook(lambda m, a, o, i=i: acts.__setitem__("norm%d" % i, o.clone())))
+            hooks.append(blk[2].register_forward_hook(lambda m, a, o, i=i: acts.__setitem__("relu%d" % i, o.clone())))
+        logits = net.inference_layer(data)
+        for h in hooks:
+            h.remove()
+    return logits, acts, net
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(1)
+    ref = load_ref()
+    sd = torch.load(os.path.join(REF, "data/models/kf96/model_best.ptm"), map_location="cpu")
+    np.savez(os.path.join(HERE, "kf96_weights.npz"), **{k: v.numpy() for k, v in sd.items()})
+
+    rng = np.random.default_rng(1)
+    g = torch.Generator().manual_seed(1)
+
+    # ---- F2: seeded random 4-regular symmetric graph, N=256, all intermediates ---------------
+    n = 256
+    adj = four_regular_random(n, rng)
+    ei = torch.from_numpy(adj.T.astype(np.int64))
+    x = torch.randn(n, 29, generator=g)
+    ea = torch.randn(4 * n, 20, generator=g)
+    logits, acts, net = run_static(ref, sd, x, ea, ei, torch.float32)
+    logits64, _, _ = run_static(ref, sd, x, ea, ei, torch.float64)
+    out = dict(x=x.numpy(), edge_attr=ea.numpy(), adjacencies=adj, logits=logits.numpy(), logits64=logits64.numpy())
+    out.update({k: v.numpy() for k, v in acts.items()})
+    # stable-sort property: dst-stable-sorted edge list gives bit-identical logits
+    perm = torch.from_numpy(np.argsort(adj[:, 1], kind="stable"))
+    l_sorted, _, _ = run_static(ref, sd, x, ea[perm], ei[:, perm], torch.float32)
+    assert torch.equal(l_sorted, logits), "stable dst sort changed reference logits"
+    np.savez_compressed(os.path.join(HERE, "static_f2_regular256.npz"), **out)
+    print("F2", logits.shape, float((logits - logits64.float()).abs().max()))
+
+    # ---- F1: real Ignatius sub-block (irregular in-degree after the cut) ----------------------
+    x1, ea1, ei1 = ignatius_block()
+    logits, acts, _ = run_static(ref, sd, x1, ea1, ei1, torch.float32)
+    logits64, _, _ = run_static(ref, sd, x1, ea1, ei1, torch.float64)
+    np.savez_compressed(os.path.join(HERE, "static_f1_ignatius.npz"), x=x1.numpy(), edge_attr=ea1.numpy(),
+                        edge_index=ei1.numpy().astype(np.int32), logits=logits.numpy(), logits64=logits64.numpy(),
+                        conv0=acts["conv0"].numpy(), relu3=acts["relu3"].numpy())
+    print("F1", logits.shape, float((logits - logits64.float()).abs().max()))
+
+    # ---- F3: sampled bipartite blocks (train forward, BN train mode, grads) -------------------
+    from dgnn_amd.synthetic import delaunay_tet_graph
+    from oracle.pyg_semantics import neighbor_sampler_full  # restated NeighborSampler (see its docstring)
+    adj3, _, _ = delaunay_tet_graph(400, seed=3)
+    n3 = adj3.shape[0] // 4
+    ei3 = adj3.T.astype(np.int64)
+    batch = rng.choice(n3, size=24, replace=False)
+    n_id, adjs = neighbor_sampler_full(ei3, n3, batch, 4)
+    x3 = torch.randn(n3, 29, generator=g)
+    x3[:, 0] = x3[:, 0].abs() + 0.1  # col 0 = volume weight
+    ea3 = torch.randn(4 * n3, 20, generator=g)
+    clf = static_clf()
+    net = ref["surfaceNetStaticEdgeFilters"].SurfaceNet(clf)
+    net.load_state_dict(sd)
+    net.train()
+    data = AD(all=AD(x=x3, edge_attr=ea3), batch_n_id=torch.from_numpy(n_id),
+              batch_adjs=[(torch.from_numpy(a), torch.from_numpy(e), s) for a, e, s in adjs])
+    logits = net(data)  # SurfaceNet.forward, BN in train mode
+    G = torch.randn(logits.shape, generator=g)
+    (logits * G).sum().backward()
+    out = dict(x=x3.numpy(), edge_attr=ea3.numpy(), adjacencies=adj3, batch=batch.astype(np.int64), n_id=n_id,
+               G=G.numpy(), logits=logits.detach().numpy())
+    for i, (a, e, s) in enumerate(adjs):
+        out["adj%d_edge_index" % i] = a
+        out["adj%d_e_id" % i] = e
+        out["adj%d_size" % i] = np.asarray(s, np.int64)
+    for k, p in net.named_parameters():
+        out["grad." + k] = p.grad.numpy()
+    for k, b in net.named_buffers():
+        out["buf." + k] = b.detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "static_f3_train_blocks.npz"), **out)
+    print("F3 n_src per layer", [s[0] for _, _, s in adjs], "n_dst", [s[1] for _, _, s in adjs])
+    # eval-mode batch_layer inference on the same blocks (reference inference_batch_layer)
+    net2 = ref["surfaceNetStaticEdgeFilters"].SurfaceNet(clf)
+    net2.load_state_dict(sd)
+    net2.eval()
+    with torch.no_grad():
+        loader = [(len(batch), torch.from_numpy(n_id), data.batch_adjs)]
+        xo = net2.inference_batch_layer(AD(x=x3, edge_attr=ea3), loader)
+    np.savez_compressed(os.path.join(HERE, "static_f3_batch_layer.npz"), logits_rows=xo[torch.from_numpy(batch)].numpy())
+
+    # ---- Updated variant on sampled blocks --------------------------------------------------
+    # (a) "+" head: forward only -- the reference's own backward raises there (out_net starts with an
+    #     in-place ReLU applied to the output of F.relu, :245-246 + :210).
+    # (b) no head, last width 2: forward + grads of every parameter.
+    _cuda_empty = torch.cuda.empty_cache
+    torch.cuda.empty_cache = lambda: None  # reference calls it every layer (:243); no-op on CPU
+    udata = AD(x=x3, edge_attr=ea3, n_id=torch.from_numpy(n_id),
+               adjs=[(torch.from_numpy(a), torch.from_numpy(e), s) for a, e, s in adjs])
+    out = {}
+    for tag, params, name in (("plus", [32, 48, 48, 32], "sage+"), ("plain", [32, 48, 40, 2], "sage")):
+        uclf = AD(training=AD(model_params=params, model_name=name, loss="kl"),
+                  features=AD(normalization_feature=1, keep_normalization_feature=0), temp=AD(device="cpu"))
+        torch.manual_seed(5)
+        unet = ref["surfaceNetUpdatedEdgeFilters"].SurfaceNet(28, uclf)
+        phis = []
+        hooks = [c.register_forward_hook(lambda m, a, o: phis.append(o[1].detach().clone())) for c in unet.convs]
+        if tag == "plus":
+            with torch.no_grad():
+                ulog = unet(udata)
+        else:
+            ulog = unet(udata)
+            (ulog * G).sum().backward()
+        for h in hooks:
+            h.remove()
+        out[tag + ".logits"] = ulog.detach().numpy()
+        out[tag + ".model_params"] = np.asarray(params)
+        for i, ph in enumerate(phis):
+            out[tag + ".phi%d_sum" % i] = np.asarray([ph.double().sum().item(), ph.double().abs().sum().item()])
+        for k, p in unet.named_parameters():
+            out[tag + ".param." + k] = p.detach().numpy()
+            if p.grad is not None:
+                out[tag + ".grad." + k] = p.grad.numpy()
+        print("Updated", tag, ulog.shape, sum(p.numel() for p in unet.parameters()))
+    torch.cuda.empty_cache = _cuda_empty
+    np.savez_compressed(os.path.join(HERE, "updated_f3_blocks.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()
