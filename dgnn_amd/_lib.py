@@ -1,0 +1,79 @@
+"""ctypes binding of libdgnn_hip.so (the C ABI declared in include/dgnn_hip.h).
+
+There is NO fallback: if the library has not been built (`python -c "import __graft_entry__ as g;
+g.build()"` or `make -C dgnn_amd/csrc`) importing a symbol raises; calling into it without a GPU
+raises from the HIP runtime.  The product never routes through `oracle/` or any CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdgnn_hip.so")
+
+i64, i32, f32, vp = C.c_int64, C.c_int, C.c_float, C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/dgnn_hip.h one to one
+SIGNATURES = {
+    "dgnn_version": (i32, []),
+    "dgnn_last_error_string": (C.c_char_p, []),
+    "dgnn_plan_scratch_elems": (i64, [i64, i64]),
+    "dgnn_plan_build": (i32, [vp, i64, i64, i32, vp, vp, vp, vp, vp]),
+    "dgnn_gather_rows_f32": (i32, [vp, i64, vp, i64, i32, vp, i64, vp]),
+    "dgnn_scatter_rows_f32": (i32, [vp, i64, vp, i64, i32, vp, i64, vp]),
+    "dgnn_relu": (i32, [vp, i64, vp, vp]),
+    "dgnn_sage_aggregate_fwd": (i32, [vp, vp, vp, i64, vp, i64, i32, vp, i64, i32, vp, vp, vp, i64, vp, i64, vp, i64, vp]),
+    "dgnn_linear_fwd": (i32, [vp, i64, i32, vp, i64, vp, i64, i32, vp, i64, vp, vp, vp, i32, i64, i32, vp, i64, vp]),
+    "dgnn_linear_wgrad_scratch_elems": (i64, [i64, i32, i32]),
+    "dgnn_linear_wgrad": (i32, [vp, i64, i32, vp, i64, i32, i64, vp, i64, i32, vp, vp]),
+    "dgnn_bn_fold": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp]),
+    "dgnn_colstats_scratch_elems": (i64, [i64, i32]),
+    "dgnn_bn_batch_stats": (i32, [vp, i64, i64, i32, vp, vp, vp, vp, f32, vp, vp]),
+    "dgnn_scale_shift_act": (i32, [vp, i64, vp, vp, i32, i64, i32, vp, i64, vp]),
+    "dgnn_bn_relu_bwd": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, vp, f32, i32, i32, i64, i32, vp, i64, vp, vp, vp, vp]),
+    "dgnn_colsum": (i32, [vp, i64, i64, i32, vp, i32, vp, vp]),
+    "dgnn_sage_aggregate_bwd_scratch_elems": (i64, [i64, i32, i32]),
+    "dgnn_sage_aggregate_bwd": (i32, [vp, vp, vp, i64, vp, vp, i64, i32, vp, i64, i32, vp, vp, vp, i64, vp, i64, vp, i64,
+                                      vp, vp, vp, i64, vp, vp]),
+    "dgnn_sage_layer_fused_fwd": (i32, [vp, vp, i64, vp, i64, i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp,
+                                        i64, vp]),
+}
+
+_lib = None
+
+
+class DgnnError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libdgnn_hip.so once and attaches argtypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DgnnError("%s is missing: build it with `make -C dgnn_amd/csrc` (hipcc, gfx950); "
+                            "dgnn_amd has no CPU fallback" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(code: int, what: str = ""):
+    if code != 0:
+        msg = lib().dgnn_last_error_string().decode()
+        raise DgnnError("%s failed (%d): %s" % (what or "dgnn call", code, msg))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,337 @@
+// Edge-filtered mean aggregation, forward and backward (general CSR, any width).
+//
+//   forward : a_i = ( sum_{k in seg(i)} x_src[src_k] * phi_k ) / max(deg_i,1)
+//   phi_k   = We . A_e + be (FE > 0, recomputed in registers, never written unless asked)
+//           | phi[e]        (FE == 0, "given": Updated variant / 2-layer edge MLP)
+//           | 1             (FE < 0, lin_e is None)
+//
+// Mapping: one wavefront owns one destination at a time; the 64 lanes own CPL consecutive channels
+// each (a [c_in] row is one coalesced 256/512-byte access).  Everything indexed by the destination
+// (rowptr, src, eid, the 20 edge features) is wave-uniform, so it is read through the scalar cache
+// into SGPRs and the filter MLP is 20 v_fma with an SGPR operand per channel -- no LDS, no shuffles.
+// Wide layers are tiled over blockIdx.y in chunks of 64*CPL channels.
+//
+// Numerics: multiply and add are rounded separately (__fmul_rn/__fadd_rn) and the segment is summed
+// in plan order starting from 0, i.e. the order of torch_scatter's CPU scatter_add_ that the
+// reference runs (surfaceNetStaticEdgeFilters.py:80 -> aggr='mean').  Division is IEEE.
+#include "common.h"
+
+namespace {
+
+template <int CPL>
+struct Vec;
+template <>
+struct Vec<1> {
+    float v[1];
+    __device__ __forceinline__ void load(const float* p) { v[0] = *p; }
+    __device__ __forceinline__ void store(float* p) const { *p = v[0]; }
+};
+template <>
+struct Vec<2> {
+    float v[2];
+    __device__ __forceinline__ void load(const float* p) {
+        float2 t = *reinterpret_cast<const float2*>(p);
+        v[0] = t.x;
+        v[1] = t.y;
+    }
+    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]); }
+};
+
+template <int CPL, int FE>
+__global__ void __launch_bounds__(256) k_agg_fwd(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
+                                                 const int32_t* __restrict__ eid, int64_t n_dst,
+                                                 const float* __restrict__ x, int64_t ldx, int c_in,
+                                                 const float* __restrict__ ea, int64_t lde,
+                                                 const float* __restrict__ We, const float* __restrict__ be,
+                                                 const float* __restrict__ phi, int64_t ldphi,
+                                                 float* __restrict__ phi_out, int64_t ldphi_out,
+                                                 float* __restrict__ a, int64_t lda) {
+    constexpr int NW = FE > 0 ? FE : 1;
+    const int lane = lane_id();
+    const int c0 = (blockIdx.y * 64 + lane) * CPL;
+    const bool on = c0 < c_in;  // c_in is a multiple of CPL on this path
+    float w[CPL][NW], b[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        b[j] = 0.f;
+#pragma unroll
+        for (int f = 0; f < NW; ++f) w[j][f] = 0.f;
+        if (FE > 0 && on) {
+            b[j] = be[c0 + j];
+#pragma unroll
+            for (int f = 0; f < NW; ++f) w[j][f] = We[(int64_t)(c0 + j) * FE + f];
+        }
+    }
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wave_id_uniform();
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t d = wave; d < n_dst; d += nwaves) {
+        const int beg = rowptr[d], end = rowptr[d + 1];
+        float acc[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) acc[j] = 0.f;
+        for (int k = beg; k < end; ++k) {
+            const int s = src[k];
+            const int64_t e = eid ? eid[k] : k;
+            Vec<CPL> xr;
+            if (on) xr.load(x + (int64_t)s * ldx + c0);
+            float p[CPL];
+            if (FE > 0) {
+                const float* ar = ea + e * lde;
+                float A[NW];
+#pragma unroll
+                for (int f = 0; f < NW; ++f) A[f] = ar[f];
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    float t = b[j];
+#pragma unroll
+                    for (int f = 0; f < NW; ++f) t = __fmaf_rn(w[j][f], A[f], t);
+                    p[j] = t;
+                }
+                if (phi_out && on) {
+                    Vec<CPL> po;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) po.v[j] = p[j];
+                    po.store(phi_out + e * ldphi_out + c0);
+                }
+            } else if (FE == 0) {
+                Vec<CPL> pr;
+                if (on) pr.load(phi + e * ldphi + c0);
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) p[j] = pr.v[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) p[j] = 1.f;
+            }
+            if (on) {
+#pragma unroll
+                for (int j = 0; j < CPL; ++j)
+                    acc[j] = __fadd_rn(acc[j], FE < 0 ? xr.v[j] : __fmul_rn(xr.v[j], p[j]));
+            }
+        }
+        if (on) {
+            const float cnt = (float)max(end - beg, 1);
+            Vec<CPL> o;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) o.v[j] = __fdiv_rn(acc[j], cnt);
+            o.store(a + d * lda + c0);
+        }
+    }
+}
+
+// Backward over the transposed plan: one wavefront per SOURCE tet, so dx_src[s] is a register
+// accumulation (no atomics) in ascending edge position -- the order of autograd's index_add_ for
+// x_j = x.index_select(0, edge_index[0]).  Filter-weight gradients are kept per lane (CPL x (FE+1)
+// registers), reduced across the block's 4 waves through LDS in a fixed order and written as one
+// slab per block; k_reduce_slabs sums the slabs in block order (deterministic).
+template <int CPL, int FE>
+__global__ void __launch_bounds__(256) k_agg_bwd(const int32_t* __restrict__ t_rowptr, const int32_t* __restrict__ t_dst,
+                                                 const int32_t* __restrict__ t_eid, int64_t n_src,
+                                                 const int32_t* __restrict__ rowptr_dst, const float* __restrict__ x,
+                                                 int64_t ldx, int c_in, const float* __restrict__ ea, int64_t lde,
+                                                 const float* __restrict__ We, const float* __restrict__ be,
+                                                 const float* __restrict__ phi, int64_t ldphi,
+                                                 const float* __restrict__ da, int64_t ldda, float* __restrict__ dx,
+                                                 int64_t lddx, float* __restrict__ dphi_out, int64_t lddphi,
+                                                 float* __restrict__ slabs) {
+    constexpr int NW = FE > 0 ? FE : 1;
+    __shared__ float red[FE > 0 ? 4 * 64 * CPL * (FE + 1) : 1];
+    const int lane = lane_id();
+    const int c0 = (blockIdx.y * 64 + lane) * CPL;
+    const bool on = c0 < c_in;
+    float w[CPL][NW], b[CPL], gw[CPL][NW], gb[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        b[j] = 0.f;
+        gb[j] = 0.f;
+#pragma unroll
+        for (int f = 0; f < NW; ++f) {
+            w[j][f] = 0.f;
+            gw[j][f] = 0.f;
+        }
+        if (FE > 0 && on) {
+            b[j] = be[c0 + j];
+#pragma unroll
+            for (int f = 0; f < NW; ++f) w[j][f] = We[(int64_t)(c0 + j) * FE + f];
+        }
+    }
+    const int wv = wave_id_uniform();
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t s = wave; s < n_src; s += nwaves) {
+        const int beg = t_rowptr[s], end = t_rowptr[s + 1];
+        Vec<CPL> xs;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) xs.v[j] = 0.f;
+        if (on && dx) {
+            // rows of x_src without out-edges still get dx = 0
+        }
+        if (on && end > beg) xs.load(x + s * ldx + c0);
+        float acc[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) acc[j] = 0.f;
+        for (int k = beg; k < end; ++k) {
+            const int d = t_dst[k];
+            const int64_t e = t_eid[k];
+            const float cnt = (float)max(rowptr_dst[d + 1] - rowptr_dst[d], 1);
+            Vec<CPL> g;
+            if (on) g.load(da + (int64_t)d * ldda + c0);
+            float p[CPL];
+            float A[NW];
+            if (FE > 0) {
+                const float* ar = ea + e * lde;
+#pragma unroll
+                for (int f = 0; f < NW; ++f) A[f] = ar[f];
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    float t = b[j];
+#pragma unroll
+                    for (int f = 0; f < NW; ++f) t = __fmaf_rn(w[j][f], A[f], t);
+                    p[j] = t;
+                }
+            } else if (FE == 0) {
+                Vec<CPL> pr;
+                if (on) pr.load(phi + e * ldphi + c0);
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) p[j] = pr.v[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) p[j] = 1.f;
+            }
+            if (on) {
+                Vec<CPL> dph;
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    const float dm = __fdiv_rn(g.v[j], cnt);
+                    acc[j] = __fadd_rn(acc[j], __fmul_rn(dm, p[j]));
+                    dph.v[j] = __fmul_rn(dm, xs.v[j]);
+                    if (FE > 0) {
+                        gb[j] += dph.v[j];
+#pragma unroll
+                        for (int f = 0; f < NW; ++f) gw[j][f] = __fmaf_rn(dph.v[j], A[f], gw[j][f]);
+                    }
+                }
+                if (FE == 0 && dphi_out) dph.store(dphi_out + e * lddphi + c0);
+            }
+        }
+        if (on && dx) {
+            Vec<CPL> o;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) o.v[j] = acc[j];
+            o.store(dx + s * lddx + c0);
+        }
+    }
+    if (FE > 0) {
+        // red[wave][channel-in-chunk][FE+1]
+        float* mine = red + ((wv * 64 + lane) * CPL) * (FE + 1);
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+#pragma unroll
+            for (int f = 0; f < NW; ++f) mine[j * (FE + 1) + f] = gw[j][f];
+            mine[j * (FE + 1) + FE] = gb[j];
+        }
+        __syncthreads();
+        constexpr int PER = 64 * CPL * (FE + 1);
+        float* slab = slabs + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * PER;
+        for (int i = threadIdx.x; i < PER; i += 256)
+            slab[i] = ((red[i] + red[PER + i]) + red[2 * PER + i]) + red[3 * PER + i];
+    }
+}
+
+// out[chunk][i] (+)= sum_b slabs[b][chunk][i]; one thread per output, fixed order.
+__global__ void k_reduce_slabs(const float* __restrict__ slabs, int nblocks, int nchunks, int per, int c_in, int fe,
+                               int cpl, float* __restrict__ dWe, float* __restrict__ dbe) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nchunks * per) return;
+    const int chunk = i / per, r = i - chunk * per;
+    const int c = chunk * 64 * cpl + r / (fe + 1), f = r % (fe + 1);
+    if (c >= c_in) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += slabs[((int64_t)b * nchunks + chunk) * per + r];
+    if (f < fe)
+        dWe[(int64_t)c * fe + f] += s;
+    else
+        dbe[c] += s;
+}
+
+constexpr int BWD_BLOCKS = 512;  // persistent-ish: 2 blocks per CU keeps the slab array small
+
+template <int CPL>
+bool aligned_for(const void* p, int64_t ld) {
+    return CPL == 1 || (((uintptr_t)p % (sizeof(float) * CPL)) == 0 && ld % CPL == 0);
+}
+
+}  // namespace
+
+extern "C" int dgnn_sage_aggregate_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst,
+                                       const float* x_src, int64_t ldx, int c_in, const float* edge_attr, int64_t lde,
+                                       int f_e, const float* We, const float* be, const float* phi, int64_t ldphi,
+                                       float* phi_out, int64_t ldphi_out, float* a, int64_t lda, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DGNN_REQUIRE(n_dst >= 0 && c_in > 0, DGNN_E_INVALID, "aggregate_fwd: bad sizes n_dst=%lld c_in=%d", (long long)n_dst, c_in);
+    if (n_dst == 0) return DGNN_OK;
+    DGNN_REQUIRE(rowptr && src && x_src && a, DGNN_E_INVALID, "aggregate_fwd: null pointer");
+    const bool fused = We != nullptr;
+    DGNN_REQUIRE(!fused || (be && edge_attr), DGNN_E_INVALID, "aggregate_fwd: fused mode needs be and edge_attr");
+    DGNN_REQUIRE(!fused || f_e == 20 || f_e == 2, DGNN_E_UNSUPPORTED,
+                 "aggregate_fwd: fused filter supports f_e in {2,20} (got %d); materialise phi with dgnn_linear_fwd", f_e);
+    const bool given = !fused && phi != nullptr;
+    bool v2 = (c_in % 2 == 0) && c_in > 64 && aligned_for<2>(x_src, ldx) && aligned_for<2>(a, lda) &&
+              (!given || aligned_for<2>(phi, ldphi)) && (!phi_out || aligned_for<2>(phi_out, ldphi_out));
+    const int cpl = v2 ? 2 : 1;
+    const int chunks = (int)dgnn_cdiv(c_in, 64 * cpl);
+    dim3 grid(dgnn_grid_cap(dgnn_cdiv(n_dst, 4), 8), chunks), block(256);
+#define LAUNCH(CPL, FE)                                                                                               \
+    hipLaunchKernelGGL((k_agg_fwd<CPL, FE>), grid, block, 0, stream, rowptr, src, eid, n_dst, x_src, ldx, c_in, edge_attr, \
+                       lde, We, be, phi, ldphi, phi_out, ldphi_out, a, lda)
+    if (fused && f_e == 20) { if (v2) LAUNCH(2, 20); else LAUNCH(1, 20); }
+    else if (fused && f_e == 2) { if (v2) LAUNCH(2, 2); else LAUNCH(1, 2); }
+    else if (given) { if (v2) LAUNCH(2, 0); else LAUNCH(1, 0); }
+    else { if (v2) LAUNCH(2, -1); else LAUNCH(1, -1); }
+#undef LAUNCH
+    return dgnn_check_launch("aggregate_fwd");
+}
+
+extern "C" int64_t dgnn_sage_aggregate_bwd_scratch_elems(int64_t n_src, int c_in, int f_e) {
+    (void)n_src;
+    if (c_in <= 0 || f_e <= 0) return 1;
+    // chunks * 64*cpl >= c_in; cpl in {1,2}: bound with cpl = 1 chunk count * per(cpl=2)
+    const int64_t chunks = dgnn_cdiv(c_in, 64);
+    return (int64_t)BWD_BLOCKS * chunks * 128 * (f_e + 1);
+}
+
+extern "C" int dgnn_sage_aggregate_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid,
+                                       int64_t n_src, const int32_t* rowptr_dst, const float* x_src, int64_t ldx, int c_in,
+                                       const float* edge_attr, int64_t lde, int f_e, const float* We, const float* be,
+                                       const float* phi, int64_t ldphi, const float* da, int64_t ldda, float* dx_src,
+                                       int64_t lddx, float* dWe, float* dbe, float* dphi_out, int64_t lddphi,
+                                       float* partials, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DGNN_REQUIRE(n_src >= 0 && c_in > 0, DGNN_E_INVALID, "aggregate_bwd: bad sizes");
+    if (n_src == 0) return DGNN_OK;
+    DGNN_REQUIRE(t_rowptr && t_dst && t_eid && rowptr_dst && x_src && da, DGNN_E_INVALID, "aggregate_bwd: null pointer");
+    const bool fused = We != nullptr;
+    DGNN_REQUIRE(!fused || (be && edge_attr && dWe && dbe && partials), DGNN_E_INVALID, "aggregate_bwd: fused mode needs be, edge_attr, dWe, dbe, partials");
+    DGNN_REQUIRE(!fused || f_e == 20 || f_e == 2, DGNN_E_UNSUPPORTED, "aggregate_bwd: fused filter supports f_e in {2,20} (got %d)", f_e);
+    const bool given = !fused && phi != nullptr;
+    bool v2 = (c_in % 2 == 0) && c_in > 64 && aligned_for<2>(x_src, ldx) && aligned_for<2>(da, ldda) &&
+              (!dx_src || aligned_for<2>(dx_src, lddx)) && (!given || aligned_for<2>(phi, ldphi)) &&
+              (!dphi_out || aligned_for<2>(dphi_out, lddphi));
+    const int cpl = v2 ? 2 : 1;
+    const int chunks = (int)dgnn_cdiv(c_in, 64 * cpl);
+    const int nblocks = (int)(dgnn_cdiv(n_src, 4) < BWD_BLOCKS ? dgnn_cdiv(n_src, 4) : BWD_BLOCKS);
+    dim3 grid(nblocks, chunks), block(256);
+#define LAUNCH(CPL, FE)                                                                                               \
+    hipLaunchKernelGGL((k_agg_bwd<CPL, FE>), grid, block, 0, stream, t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, ldx, \
+                       c_in, edge_attr, lde, We, be, phi, ldphi, da, ldda, dx_src, lddx, dphi_out, lddphi, partials)
+    if (fused && f_e == 20) { if (v2) LAUNCH(2, 20); else LAUNCH(1, 20); }
+    else if (fused && f_e == 2) { if (v2) LAUNCH(2, 2); else LAUNCH(1, 2); }
+    else if (given) { if (v2) LAUNCH(2, 0); else LAUNCH(1, 0); }
+    else { if (v2) LAUNCH(2, -1); else LAUNCH(1, -1); }
+#undef LAUNCH
+    if (fused) {
+        const int per = 64 * cpl * (f_e + 1);
+        hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)dgnn_cdiv((int64_t)chunks * per, 256)), dim3(256), 0, stream, partials,
+                           nblocks, chunks, per, c_in, f_e, cpl, dWe, dbe);
+    }
+    return dgnn_check_launch("aggregate_bwd");
+}

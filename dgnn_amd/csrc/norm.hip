@@ -1,0 +1,223 @@
+// BatchNorm1d pieces and column reductions (HBM-bound streaming kernels).
+//
+// Reference: torch_geometric.nn.norm.BatchNorm -> torch.nn.BatchNorm1d(eps=1e-5, momentum=0.1)
+// (surfaceNetStaticEdgeFilters.py:116-123, applied :218,263,305,345).
+//   eval : y = x*scale + shift, scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale
+//   train: batch mean / biased batch variance normalise; running stats take momentum*(mean, unbiased var)
+// Column reductions run in two deterministic stages (per-block fp64 partials, then a fixed-order sum).
+#include "common.h"
+
+namespace {
+
+constexpr int RED_BLOCKS = 1024;
+
+// MODE 0: (x, x*x)   MODE 1: (g, g*xhat) with g = dy*[y>0]   MODE 2: (x, 0)
+template <int MODE>
+__global__ void __launch_bounds__(256) k_colreduce(const float* __restrict__ x, int64_t ldx, const float* __restrict__ y,
+                                                   int64_t ldy, const float* __restrict__ dy, int64_t lddy,
+                                                   const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                                   int relu, int64_t M, int c, int64_t rows_per_block,
+                                                   double* __restrict__ partials) {
+    __shared__ double red[2][4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(M, r0 + rows_per_block);
+    for (int cb = 0; cb < c; cb += 64) {
+        const int col = cb + tx;
+        double s0 = 0.0, s1 = 0.0;
+        if (col < c) {
+            float mu = 0.f, is = 1.f;
+            if (MODE == 1) {
+                mu = mean[col];
+                is = 1.0f / sqrtf(var[col] + eps);
+            }
+            for (int64_t r = r0 + ty; r < r1; r += 4) {
+                if (MODE == 0) {
+                    const float v = x[r * ldx + col];
+                    s0 += v;
+                    s1 += (double)v * v;
+                } else if (MODE == 1) {
+                    float g = dy[r * lddy + col];
+                    if (relu && !(y[r * ldy + col] > 0.f)) g = 0.f;
+                    const float xh = (x[r * ldx + col] - mu) * is;
+                    s0 += g;
+                    s1 += (double)g * xh;
+                } else {
+                    s0 += x[r * ldx + col];
+                }
+            }
+        }
+        red[0][ty][tx] = s0;
+        red[1][ty][tx] = s1;
+        __syncthreads();
+        if (ty == 0 && col < c) {
+            partials[((int64_t)blockIdx.x * 2 + 0) * c + col] = ((red[0][0][tx] + red[0][1][tx]) + red[0][2][tx]) + red[0][3][tx];
+            partials[((int64_t)blockIdx.x * 2 + 1) * c + col] = ((red[1][0][tx] + red[1][1][tx]) + red[1][2][tx]) + red[1][3][tx];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_stats_finalize(const double* __restrict__ partials, int nblk, int64_t M, int c, float* __restrict__ mean,
+                                 float* __restrict__ var, float* __restrict__ rmean, float* __restrict__ rvar, float momentum) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= c) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s += partials[((int64_t)b * 2 + 0) * c + col];
+        q += partials[((int64_t)b * 2 + 1) * c + col];
+    }
+    const double m = s / (double)M;
+    double v = q / (double)M - m * m;
+    if (v < 0.0) v = 0.0;
+    mean[col] = (float)m;
+    var[col] = (float)v;
+    if (rmean) rmean[col] = (1.f - momentum) * rmean[col] + momentum * (float)m;
+    if (rvar) {
+        const double unb = M > 1 ? v * (double)M / (double)(M - 1) : v;
+        rvar[col] = (1.f - momentum) * rvar[col] + momentum * (float)unb;
+    }
+}
+
+// sums[0][c] = first quantity, sums[1][c] = second (float), optional accumulate into out0/out1
+__global__ void k_sum_finalize(const double* __restrict__ partials, int nblk, int c, float* __restrict__ out0,
+                               float* __restrict__ out1, int accumulate) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= c) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s += partials[((int64_t)b * 2 + 0) * c + col];
+        q += partials[((int64_t)b * 2 + 1) * c + col];
+    }
+    if (out0) out0[col] = accumulate ? out0[col] + (float)s : (float)s;
+    if (out1) out1[col] = accumulate ? out1[col] + (float)q : (float)q;
+}
+
+__global__ void k_bn_fold(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                          const float* __restrict__ var, float eps, int c, float* __restrict__ scale,
+                          float* __restrict__ shift) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    const float invstd = 1.0f / sqrtf(var[i] + eps);
+    const float s = (gamma ? gamma[i] : 1.f) * invstd;
+    scale[i] = s;
+    shift[i] = (beta ? beta[i] : 0.f) - mean[i] * s;
+}
+
+__global__ void k_scale_shift_act(const float* __restrict__ x, int64_t ldx, const float* __restrict__ scale,
+                                  const float* __restrict__ shift, int relu, int64_t M, int c, float* __restrict__ y,
+                                  int64_t ldy) {
+    const int64_t total = M * c;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / c;
+        const int col = (int)(t - r * c);
+        float v = __fmaf_rn(x[r * ldx + col], scale[col], shift[col]);
+        if (relu) v = fmaxf(v, 0.f);
+        y[r * ldy + col] = v;
+    }
+}
+
+// dx for y = relu(bn(x)).  sums: [0][c] = sum g, [1][c] = sum g*xhat (already final floats in dbeta/dgamma)
+__global__ void k_bn_relu_bwd_apply(const float* __restrict__ x, int64_t ldx, const float* __restrict__ y, int64_t ldy,
+                                    const float* __restrict__ dy, int64_t lddy, const float* __restrict__ gamma,
+                                    const float* __restrict__ mean, const float* __restrict__ var, float eps, int train,
+                                    int relu, int64_t M, int c, const float* __restrict__ sum_g,
+                                    const float* __restrict__ sum_gx, float* __restrict__ dx, int64_t lddx) {
+    const int64_t total = M * c;
+    const float invM = 1.0f / (float)M;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / c;
+        const int col = (int)(t - r * c);
+        float g = dy[r * lddy + col];
+        if (relu && !(y[r * ldy + col] > 0.f)) g = 0.f;
+        const float is = 1.0f / sqrtf(var[col] + eps);
+        const float gs = (gamma ? gamma[col] : 1.f) * is;
+        float o;
+        if (train) {
+            const float xh = (x[r * ldx + col] - mean[col]) * is;
+            o = gs * (g - invM * sum_g[col] - xh * invM * sum_gx[col]);
+        } else {
+            o = g * gs;
+        }
+        dx[r * lddx + col] = o;
+    }
+}
+
+int red_blocks(int64_t M) {
+    int64_t b = dgnn_cdiv(M, 64);
+    if (b > RED_BLOCKS) b = RED_BLOCKS;
+    return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+// scratch (floats): partials as doubles [blocks][2][c] -> 4*blocks*c floats, + 2*c floats of sums
+extern "C" int64_t dgnn_colstats_scratch_elems(int64_t M, int c) {
+    if (c <= 0) return 2;
+    return (int64_t)red_blocks(M < 0 ? 0 : M) * 4 * c + 2 * c + 2;
+}
+
+static double* as_f64(float* scratch) { return reinterpret_cast<double*>(((uintptr_t)scratch + 7) & ~(uintptr_t)7); }
+
+extern "C" int dgnn_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int c,
+                            float* scale, float* shift, void* stream) {
+    DGNN_REQUIRE(c > 0 && mean && var && scale && shift, DGNN_E_INVALID, "bn_fold: bad args");
+    hipLaunchKernelGGL(k_bn_fold, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, mean, var, eps, c, scale, shift);
+    return dgnn_check_launch("bn_fold");
+}
+
+extern "C" int dgnn_bn_batch_stats(const float* x, int64_t ldx, int64_t M, int c, float* mean, float* var,
+                                   float* running_mean, float* running_var, float momentum, float* scratch, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DGNN_REQUIRE(M > 0 && c > 0 && x && mean && var && scratch, DGNN_E_INVALID, "bn_batch_stats: bad args (M=%lld c=%d)", (long long)M, c);
+    const int nblk = red_blocks(M);
+    const int64_t rpb = dgnn_cdiv(M, nblk);
+    double* P = as_f64(scratch);
+    hipLaunchKernelGGL((k_colreduce<0>), dim3(nblk), dim3(256), 0, stream, x, ldx, nullptr, (int64_t)0, nullptr, (int64_t)0, nullptr,
+                       nullptr, 0.f, 0, M, c, rpb, P);
+    hipLaunchKernelGGL(k_stats_finalize, dim3((c + 255) / 256), dim3(256), 0, stream, P, nblk, M, c, mean, var, running_mean,
+                       running_var, momentum);
+    return dgnn_check_launch("bn_batch_stats");
+}
+
+extern "C" int dgnn_scale_shift_act(const float* x, int64_t ldx, const float* scale, const float* shift, int relu, int64_t M,
+                                    int c, float* y, int64_t ldy, void* stream) {
+    DGNN_REQUIRE(M >= 0 && c > 0, DGNN_E_INVALID, "scale_shift_act: bad sizes");
+    if (M == 0) return DGNN_OK;
+    DGNN_REQUIRE(x && scale && shift && y, DGNN_E_INVALID, "scale_shift_act: null pointer");
+    hipLaunchKernelGGL(k_scale_shift_act, dim3(dgnn_grid_cap(dgnn_cdiv(M * c, 256))), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       scale, shift, relu, M, c, y, ldy);
+    return dgnn_check_launch("scale_shift_act");
+}
+
+extern "C" int dgnn_bn_relu_bwd(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* dy, int64_t lddy,
+                                const float* gamma, const float* mean, const float* var, float eps, int train, int relu,
+                                int64_t M, int c, float* dx, int64_t lddx, float* dgamma, float* dbeta, float* scratch,
+                                void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DGNN_REQUIRE(M > 0 && c > 0 && x && dy && mean && var && dx && scratch && (!relu || y), DGNN_E_INVALID, "bn_relu_bwd: bad args");
+    const int nblk = red_blocks(M);
+    const int64_t rpb = dgnn_cdiv(M, nblk);
+    double* P = as_f64(scratch);
+    float* sums = reinterpret_cast<float*>(P + (int64_t)nblk * 2 * c);
+    hipLaunchKernelGGL((k_colreduce<1>), dim3(nblk), dim3(256), 0, stream, x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, rpb, P);
+    hipLaunchKernelGGL(k_sum_finalize, dim3((c + 255) / 256), dim3(256), 0, stream, P, nblk, c, sums, sums + c, 0);
+    hipLaunchKernelGGL(k_bn_relu_bwd_apply, dim3(dgnn_grid_cap(dgnn_cdiv(M * c, 256))), dim3(256), 0, stream, x, ldx, y, ldy, dy,
+                       lddy, gamma, mean, var, eps, train, relu, M, c, sums, sums + c, dx, lddx);
+    if (dbeta) (void)hipMemcpyAsync(dbeta, sums, sizeof(float) * c, hipMemcpyDeviceToDevice, stream);
+    if (dgamma) (void)hipMemcpyAsync(dgamma, sums + c, sizeof(float) * c, hipMemcpyDeviceToDevice, stream);
+    return dgnn_check_launch("bn_relu_bwd");
+}
+
+extern "C" int dgnn_colsum(const float* x, int64_t ldx, int64_t M, int c, float* out, int accumulate, float* scratch,
+                           void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DGNN_REQUIRE(M > 0 && c > 0 && x && out && scratch, DGNN_E_INVALID, "colsum: bad args");
+    const int nblk = red_blocks(M);
+    const int64_t rpb = dgnn_cdiv(M, nblk);
+    double* P = as_f64(scratch);
+    hipLaunchKernelGGL((k_colreduce<2>), dim3(nblk), dim3(256), 0, stream, x, ldx, nullptr, (int64_t)0, nullptr, (int64_t)0, nullptr,
+                       nullptr, 0.f, 0, M, c, rpb, P);
+    hipLaunchKernelGGL(k_sum_finalize, dim3((c + 255) / 256), dim3(256), 0, stream, P, nblk, c, out, nullptr, accumulate);
+    return dgnn_check_launch("colsum");
+}

@@ -1,0 +1,275 @@
+// Graph plan: stable destination-sorted CSR of the reference's int64 [2,E] edge_index.
+//
+// Reference semantics being reproduced: torch_scatter's CPU scatter_add_
+// accumulates, for every destination, in ascending edge position.  The plan stores exactly that
+// order, so the aggregation kernels are deterministic and can be compared with the oracle.
+//
+// Pipeline (all on the caller's stream, no host sync, no allocation):
+//   count   deg[key[e]]++                         (int atomics; 4 MB of counters at 1M tets: L2)
+//   scan    rowptr = exclusive_scan(deg)          (3 small kernels)
+//   fill    slot = rowptr[d] + --deg[d]; tmp[slot] = e     (unordered inside the segment)
+//   emit    sort every segment by edge position   (4-regular tet graphs: a 5-comparator network in
+//           registers; up to 32: insertion sort; longer segments: block-wide rank sort) and write
+//           eid[k], other[k] = edge_index[other_row][eid[k]].
+#include <stdarg.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "ok";
+void dgnn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* dgnn_last_error_string(void) { return g_err; }
+extern "C" int dgnn_version(void) { return DGNN_VERSION; }
+
+namespace {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;  // per thread
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+__global__ void k_zero_i32(int32_t* p, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0;
+}
+
+__global__ void k_plan_count(const int64_t* __restrict__ key, int64_t E, int32_t* __restrict__ deg) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd(&deg[key[e]], 1);
+}
+
+// block-local exclusive scan of SCAN_TILE items; block total -> sums[blockIdx.x]
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_tile(const int32_t* __restrict__ in, int64_t n,
+                                                            int32_t* __restrict__ out, int32_t* __restrict__ sums) {
+    __shared__ int32_t wsum[SCAN_THREADS / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int32_t v[SCAN_ITEMS];
+    int32_t t = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        v[i] = (base + i < n) ? in[base + i] : 0;
+        t += v[i];
+    }
+    // inclusive scan of t across the wave
+    int32_t incl = t;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int32_t o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    const int w = threadIdx.x >> 6;
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int32_t woff = 0;
+    for (int i = 0; i < w; ++i) woff += wsum[i];
+    int32_t run = woff + incl - t;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        if (base + i < n) out[base + i] = run;
+        run += v[i];
+    }
+    if (threadIdx.x == SCAN_THREADS - 1) sums[blockIdx.x] = run;
+}
+
+// single block: exclusive scan of the tile sums in place; total -> sums[nb]
+__global__ void __launch_bounds__(1024) k_scan_sums(int32_t* __restrict__ sums, int nb) {
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int base = 0; base < nb; base += 1024) {
+        int i = base + threadIdx.x;
+        int32_t t = i < nb ? sums[i] : 0;
+        int32_t incl = t;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int32_t o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int32_t woff = carry;
+        for (int k = 0; k < w; ++k) woff += wsum[k];
+        if (i < nb) sums[i] = woff + incl - t;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[nb] = carry;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_add(int32_t* __restrict__ out, int64_t n,
+                                                           const int32_t* __restrict__ sums, int nb) {
+    const int32_t add = sums[blockIdx.x];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (base + i < n) out[base + i] += add;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = sums[nb];
+}
+
+__global__ void k_plan_fill(const int64_t* __restrict__ key, int64_t E, const int32_t* __restrict__ rowptr,
+                            int32_t* __restrict__ deg, int32_t* __restrict__ tmp) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t d = key[e];
+        const int32_t slot = rowptr[d] + atomicSub(&deg[d], 1) - 1;
+        tmp[slot] = (int32_t)e;
+    }
+}
+
+__device__ __forceinline__ void cswap(int32_t& a, int32_t& b) {
+    int32_t lo = min(a, b), hi = max(a, b);
+    a = lo;
+    b = hi;
+}
+
+// one thread per key: sort its segment of `tmp` ascending and emit eid/other.
+// Segments longer than 32 are queued for k_plan_emit_big.
+__global__ void k_plan_emit(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ tmp,
+                            const int64_t* __restrict__ other_row, int64_t n_key, int32_t* __restrict__ eid,
+                            int32_t* __restrict__ other, int32_t* __restrict__ big_count,
+                            int32_t* __restrict__ big_list) {
+    for (int64_t d = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; d < n_key; d += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t beg = rowptr[d], n = rowptr[d + 1] - beg;
+        if (n <= 4) {
+            int32_t v0 = n > 0 ? tmp[beg] : INT32_MAX, v1 = n > 1 ? tmp[beg + 1] : INT32_MAX;
+            int32_t v2 = n > 2 ? tmp[beg + 2] : INT32_MAX, v3 = n > 3 ? tmp[beg + 3] : INT32_MAX;
+            cswap(v0, v1); cswap(v2, v3); cswap(v0, v2); cswap(v1, v3); cswap(v1, v2);
+            if (n > 0) { eid[beg] = v0; other[beg] = (int32_t)other_row[v0]; }
+            if (n > 1) { eid[beg + 1] = v1; other[beg + 1] = (int32_t)other_row[v1]; }
+            if (n > 2) { eid[beg + 2] = v2; other[beg + 2] = (int32_t)other_row[v2]; }
+            if (n > 3) { eid[beg + 3] = v3; other[beg + 3] = (int32_t)other_row[v3]; }
+        } else if (n <= 32) {
+            int32_t v[32];
+            for (int i = 0; i < n; ++i) {
+                int32_t x = tmp[beg + i];
+                int j = i;
+                while (j > 0 && v[j - 1] > x) { v[j] = v[j - 1]; --j; }
+                v[j] = x;
+            }
+            for (int i = 0; i < n; ++i) { eid[beg + i] = v[i]; other[beg + i] = (int32_t)other_row[v[i]]; }
+        } else {
+            big_list[atomicAdd(big_count, 1)] = (int32_t)d;
+        }
+    }
+}
+
+// one block per queued long segment: rank sort (edge positions are distinct)
+__global__ void __launch_bounds__(256) k_plan_emit_big(const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ tmp,
+                                                       const int64_t* __restrict__ other_row,
+                                                       int32_t* __restrict__ eid, int32_t* __restrict__ other,
+                                                       const int32_t* __restrict__ big_count,
+                                                       const int32_t* __restrict__ big_list) {
+    const int nbig = *big_count;
+    for (int b = blockIdx.x; b < nbig; b += gridDim.x) {
+        const int32_t d = big_list[b];
+        const int32_t beg = rowptr[d], n = rowptr[d + 1] - beg;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int32_t x = tmp[beg + i];
+            int32_t rank = 0;
+            for (int j = 0; j < n; ++j) rank += tmp[beg + j] < x;
+            eid[beg + rank] = x;
+            other[beg + rank] = (int32_t)other_row[x];
+        }
+    }
+}
+
+__global__ void k_gather_rows(const float* __restrict__ in, int64_t ld_in, const int32_t* __restrict__ idx, int64_t n,
+                              int cols, float* __restrict__ out, int64_t ld_out) {
+    // one thread per (row, col); consecutive threads walk a row -> coalesced on both sides
+    const int64_t total = n * cols;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / cols;
+        const int c = (int)(t - r * cols);
+        out[r * ld_out + c] = in[(int64_t)idx[r] * ld_in + c];
+    }
+}
+
+__global__ void k_scatter_rows(const float* __restrict__ in, int64_t ld_in, const int64_t* __restrict__ idx, int64_t n,
+                               int cols, float* __restrict__ out, int64_t ld_out) {
+    const int64_t total = n * cols;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / cols;
+        const int c = (int)(t - r * cols);
+        out[idx[r] * ld_out + c] = in[r * ld_in + c];
+    }
+}
+
+__global__ void k_relu(const float* __restrict__ x, int64_t n, float* __restrict__ y) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = fmaxf(x[i], 0.0f);
+}
+
+}  // namespace
+
+// scratch layout (int32): deg[n_key] | tmp[E] | sums[nb+1] | big_count[1] | big_list[n_key/33+1]
+extern "C" int64_t dgnn_plan_scratch_elems(int64_t E, int64_t n_key) {
+    if (E < 0 || n_key < 0) return 0;
+    return n_key + E + (dgnn_cdiv(n_key, SCAN_TILE) + 2) + 1 + (E / 33 + 2);
+}
+
+extern "C" int dgnn_plan_build(const int64_t* edge_index, int64_t E, int64_t n_key, int by, int32_t* rowptr,
+                               int32_t* other, int32_t* eid, int32_t* scratch, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DGNN_REQUIRE(E >= 0 && n_key >= 0 && (by == 0 || by == 1), DGNN_E_INVALID, "plan_build: bad sizes E=%lld n=%lld by=%d",
+                 (long long)E, (long long)n_key, by);
+    DGNN_REQUIRE(E < INT32_MAX && n_key < INT32_MAX, DGNN_E_UNSUPPORTED, "plan_build: E and n must fit int32");
+    DGNN_REQUIRE(rowptr && scratch && (E == 0 || (edge_index && other && eid)), DGNN_E_INVALID, "plan_build: null pointer");
+    const int64_t* key = edge_index + (by ? E : 0);
+    const int64_t* oth = edge_index + (by ? 0 : E);
+    int32_t* deg = scratch;
+    int32_t* tmp = deg + n_key;
+    const int nb = (int)dgnn_cdiv(n_key, SCAN_TILE);
+    int32_t* sums = tmp + E;
+    int32_t* big_count = sums + nb + 2;
+    int32_t* big_list = big_count + 1;
+
+    // zero deg, sums, big_count in one go would touch tmp too; two small launches instead
+    hipLaunchKernelGGL(k_zero_i32, dim3(dgnn_grid_cap(dgnn_cdiv(n_key, 256))), dim3(256), 0, stream, deg, n_key);
+    hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, big_count, (int64_t)1);
+    if (n_key == 0) {
+        hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, rowptr, (int64_t)1);
+        return dgnn_check_launch("plan_build");
+    }
+    if (E > 0) hipLaunchKernelGGL(k_plan_count, dim3(dgnn_grid_cap(dgnn_cdiv(E, 256))), dim3(256), 0, stream, key, E, deg);
+    hipLaunchKernelGGL(k_scan_tile, dim3(nb), dim3(SCAN_THREADS), 0, stream, deg, n_key, rowptr, sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums, nb);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_THREADS), 0, stream, rowptr, n_key, sums, nb);
+    if (E > 0) {
+        hipLaunchKernelGGL(k_plan_fill, dim3(dgnn_grid_cap(dgnn_cdiv(E, 256))), dim3(256), 0, stream, key, E, rowptr, deg, tmp);
+        hipLaunchKernelGGL(k_plan_emit, dim3(dgnn_grid_cap(dgnn_cdiv(n_key, 256))), dim3(256), 0, stream, rowptr, tmp, oth,
+                           n_key, eid, other, big_count, big_list);
+        hipLaunchKernelGGL(k_plan_emit_big, dim3(256), dim3(256), 0, stream, rowptr, tmp, oth, eid, other, big_count, big_list);
+    }
+    return dgnn_check_launch("plan_build");
+}
+
+extern "C" int dgnn_gather_rows_f32(const float* in, int64_t ld_in, const int32_t* idx, int64_t n, int cols, float* out,
+                                    int64_t ld_out, void* stream) {
+    DGNN_REQUIRE(n >= 0 && cols >= 0 && (n == 0 || cols == 0 || (in && idx && out)), DGNN_E_INVALID, "gather_rows: bad args");
+    if (n == 0 || cols == 0) return DGNN_OK;
+    hipLaunchKernelGGL(k_gather_rows, dim3(dgnn_grid_cap(dgnn_cdiv(n * cols, 256))), dim3(256), 0, (hipStream_t)stream, in,
+                       ld_in, idx, n, cols, out, ld_out);
+    return dgnn_check_launch("gather_rows");
+}
+
+extern "C" int dgnn_scatter_rows_f32(const float* in, int64_t ld_in, const int64_t* idx, int64_t n, int cols, float* out,
+                                     int64_t ld_out, void* stream) {
+    DGNN_REQUIRE(n >= 0 && cols >= 0 && (n == 0 || cols == 0 || (in && idx && out)), DGNN_E_INVALID, "scatter_rows: bad args");
+    if (n == 0 || cols == 0) return DGNN_OK;
+    hipLaunchKernelGGL(k_scatter_rows, dim3(dgnn_grid_cap(dgnn_cdiv(n * cols, 256))), dim3(256), 0, (hipStream_t)stream, in,
+                       ld_in, idx, n, cols, out, ld_out);
+    return dgnn_check_launch("scatter_rows");
+}
+
+extern "C" int dgnn_relu(const float* x, int64_t n, float* y, void* stream) {
+    DGNN_REQUIRE(n >= 0 && (n == 0 || (x && y)), DGNN_E_INVALID, "relu: bad args");
+    if (n == 0) return DGNN_OK;
+    hipLaunchKernelGGL(k_relu, dim3(dgnn_grid_cap(dgnn_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream, x, n, y);
+    return dgnn_check_launch("relu");
+}

@@ -1,0 +1,153 @@
+"""Differentiable building blocks (torch.autograd.Function over the HIP kernels).
+
+These replace what autograd records for the reference's op chain (learning/runModel.py:279 runs
+``loss.backward()`` through lin_e -> index_select -> mul -> scatter-mean -> lin_j/lin_i -> BatchNorm
+-> ReLU).  The filter phi is recomputed in the backward kernel instead of being saved, so a layer
+saves x_src and the aggregate only -- not the three [E, C_in] tensors PyTorch keeps.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .graph import GraphPlan
+
+
+class _Aggregate(torch.autograd.Function):
+    """a = mean_{e -> i}( x_src[src_e] * (We.A_e + be) )    (fused filter)"""
+
+    @staticmethod
+    def forward(ctx, x_src, edge_attr, We, be, plan: GraphPlan):
+        a = ops.aggregate_fwd(plan.rowptr, plan.src, plan.eid, plan.n_dst, x_src, edge_attr, We, be)
+        ctx.plan = plan
+        ctx.save_for_backward(x_src, edge_attr, We, be)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        x_src, edge_attr, We, be = ctx.saved_tensors
+        plan = ctx.plan
+        t_rowptr, t_dst, t_eid = plan.transposed
+        da = da.contiguous()
+        dx, dWe, dbe, _ = ops.aggregate_bwd(t_rowptr, t_dst, t_eid, plan.n_src, plan.rowptr, x_src, da, edge_attr, We, be,
+                                            need_dx=ctx.needs_input_grad[0])
+        return dx, None, dWe, dbe, None
+
+
+class _AggregatePhi(torch.autograd.Function):
+    """a = mean_{e -> i}( x_src[src_e] * phi_e ), phi given per edge row (Updated variant, edge MLPs)"""
+
+    @staticmethod
+    def forward(ctx, x_src, phi, plan: GraphPlan):
+        a = ops.aggregate_fwd(plan.rowptr, plan.src, plan.eid, plan.n_dst, x_src, phi=phi)
+        ctx.plan = plan
+        ctx.save_for_backward(x_src, phi)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        x_src, phi = ctx.saved_tensors
+        plan = ctx.plan
+        t_rowptr, t_dst, t_eid = plan.transposed
+        dx, _, _, dphi = ops.aggregate_bwd(t_rowptr, t_dst, t_eid, plan.n_src, plan.rowptr, x_src, da.contiguous(), phi=phi,
+                                           need_dx=ctx.needs_input_grad[0])
+        return dx, dphi, None
+
+
+class _AggregatePlain(torch.autograd.Function):
+    """a = mean_{e -> i} x_src[src_e]   (lin_e is None: model.edge_convs == 0)"""
+
+    @staticmethod
+    def forward(ctx, x_src, plan: GraphPlan):
+        ctx.plan = plan
+        ctx.save_for_backward(x_src)
+        return ops.aggregate_fwd(plan.rowptr, plan.src, plan.eid, plan.n_dst, x_src)
+
+    @staticmethod
+    def backward(ctx, da):
+        (x_src,) = ctx.saved_tensors
+        plan = ctx.plan
+        t_rowptr, t_dst, t_eid = plan.transposed
+        dx, _, _, _ = ops.aggregate_bwd(t_rowptr, t_dst, t_eid, plan.n_src, plan.rowptr, x_src, da.contiguous())
+        return dx, None
+
+
+class _Linear2(torch.autograd.Function):
+    """out = A1.W1^T + A2.W2^T + bias   (A2/W2/bias optional)"""
+
+    @staticmethod
+    def forward(ctx, A1, W1, A2, W2, bias):
+        ctx.save_for_backward(A1, W1, A2, W2)
+        ctx.has_bias = bias is not None
+        return ops.linear_fwd(A1, W1, A2, W2, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        A1, W1, A2, W2 = ctx.saved_tensors
+        g = g.contiguous()
+        need = ctx.needs_input_grad
+        dA1 = ops.linear_fwd(g, W1.t().contiguous()) if need[0] else None
+        dW1 = ops.linear_wgrad(g, A1) if need[1] else None
+        dA2 = ops.linear_fwd(g, W2.t().contiguous()) if (A2 is not None and need[2]) else None
+        dW2 = ops.linear_wgrad(g, A2) if (A2 is not None and need[3]) else None
+        db = ops.colsum(g) if (ctx.has_bias and need[4]) else None
+        return dA1, dW1, dA2, dW2, db
+
+
+class _BatchNormAct(torch.autograd.Function):
+    """y = act(BatchNorm1d(x)); train mode uses batch statistics and updates the running buffers."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+        if training:
+            mean, var = ops.bn_batch_stats(x, running_mean, running_var, momentum)
+        else:
+            mean, var = running_mean, running_var
+        scale, shift = ops.bn_fold(gamma, beta, mean, var, eps)
+        y = ops.scale_shift_act(x, scale, shift, relu)
+        ctx.save_for_backward(x, y, gamma, mean, var)
+        ctx.cfg = (bool(training), float(eps), bool(relu))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, mean, var = ctx.saved_tensors
+        training, eps, relu = ctx.cfg
+        dx, dgamma, dbeta = ops.bn_relu_bwd(x, y, dy.contiguous(), gamma, mean, var, eps, training, relu)
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def aggregate(x_src, plan, edge_attr=None, We=None, be=None, phi=None):
+    if We is not None:
+        return _Aggregate.apply(x_src, edge_attr, We, be, plan)
+    if phi is not None:
+        return _AggregatePhi.apply(x_src, phi, plan)
+    return _AggregatePlain.apply(x_src, plan)
+
+
+def linear2(A1, W1, A2=None, W2=None, bias=None):
+    return _Linear2.apply(A1, W1, A2, W2, bias)
+
+
+def batch_norm_act(x, bn: torch.nn.BatchNorm1d, relu: bool):
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training,
+                               bn.momentum if bn.momentum is not None else 0.1, bn.eps, relu)
+
+
+class _ReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = ops.relu(x)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return g * (y > 0).to(g.dtype)
+
+
+def relu(x):
+    return _ReLU.apply(x)

@@ -1,0 +1,282 @@
+"""MI355X drop-in for the reference's learning/surfaceNetStaticEdgeFilters.py.
+
+Same public surface: ``SAGEConv(lin_i, lin_j, lin_e)`` callable as
+``conv((x_src, x_dst), edge_attr, edge_index)`` (reference :66-87) and ``SurfaceNet(clf)`` with
+``forward(data)`` (:196-227), ``inference_layer`` (:323-355), ``inference_batch_layer`` (:232-275),
+``inference_layer_batch`` (:279-320), ``.convs / .decoder / .num_layers`` and the checkpoint keys
+of data/models/kf96/model_best.ptm (``convs.N.conv.lin_{i,j,e}.*``, ``convs.N.norm.module.*``,
+``decoder.{0,3}.*``, ``decoder.1.module.*``).  The nn.Linear / BatchNorm1d sub-modules are parameter
+containers only -- their ``forward`` is never called; all arithmetic runs in libdgnn_hip.so.
+
+Ownership and errors follow the reference: inputs are never mutated, logits are returned on the
+device, config errors ``print`` and ``sys.exit(1)`` (learning/runModel.py:190-191), everything else
+raises.  There is no CPU execution path.
+"""
+from __future__ import annotations
+
+import sys
+
+import torch
+import torch.nn as nn
+from torch.nn import Linear
+
+from .. import functional as Fn
+from .. import ops
+from ..graph import GraphPlan, plan_for
+
+
+class BatchNorm(nn.Module):
+    """Key-compatible stand-in for torch_geometric.nn.norm.BatchNorm (wraps BatchNorm1d as .module)."""
+
+    def __init__(self, in_channels: int):
+        super().__init__()
+        self.module = nn.BatchNorm1d(in_channels, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True)
+
+    def forward(self, x, relu: bool = False):
+        return Fn.batch_norm_act(x, self.module, relu)
+
+
+def _dev_f32(t: torch.Tensor, device) -> torch.Tensor:
+    """H2D copy as the reference's ``.to(self.clf.temp.device)`` does; keeps views of resident data."""
+    if t.device != torch.device(device) or t.dtype != torch.float32:
+        t = t.to(device=device, dtype=torch.float32)
+    return t if (t.dim() != 2 or t.stride(1) == 1) else t.contiguous()
+
+
+class SAGEConv(nn.Module):
+    """Edge-filtered GraphSAGE conv (reference :20-109): out = lin_j(mean_j x_j * lin_e(e_ji)) + lin_i(x_i)."""
+
+    def __init__(self, lin_i, lin_j, lin_e, **kwargs):
+        super().__init__()
+        self.lin_i = lin_i
+        self.lin_j = lin_j
+        self.lin_e = lin_e
+
+    def _filter_args(self, edge_attr):
+        """lin_e as (edge_attr, We, be) for the fused kernel, or a materialised phi for edge MLPs."""
+        le = self.lin_e
+        if le is None:
+            return dict()
+        if isinstance(le, Linear):
+            if le.in_features in (2, 20):
+                return dict(edge_attr=edge_attr, We=le.weight, be=le.bias)
+            return dict(phi=Fn.linear2(edge_attr, le.weight, bias=le.bias))
+        # edge_convs == 2 (:131-136): Linear -> norm -> ReLU -> Linear, materialised per edge
+        h = Fn.linear2(edge_attr, le[0].weight, bias=le[0].bias)
+        h = le[1](h, relu=True) if le[1] is not None else Fn.relu(h)
+        return dict(phi=Fn.linear2(h, le[3].weight, bias=le[3].bias))
+
+    def forward(self, x, edge_attr, edge_index, size=None, plan: GraphPlan = None):
+        if isinstance(x, torch.Tensor):
+            x = (x, x)
+        x_src, x_dst = x
+        if plan is None:
+            plan = plan_for(edge_index, x_src.size(0), x_dst.size(0))
+        a = Fn.aggregate(x_src, plan, **self._filter_args(edge_attr))
+        if x_dst is not None:
+            return Fn.linear2(a, self.lin_j.weight, x_dst, self.lin_i.weight, self.lin_j.bias)
+        return Fn.linear2(a, self.lin_j.weight, bias=self.lin_j.bias)
+
+    def __repr__(self):
+        return '{}:\nW1: {}\nW2: {}\nΦ: {}'.format(self.__class__.__name__, self.lin_i, self.lin_j, self.lin_e)
+
+
+class SurfaceNet(nn.Module):
+
+    def normLayer(self, size):
+        if self.norm_type == 'b':
+            return BatchNorm(size)
+        elif self.norm_type == 'l':
+            print("normalization 'l' (graph LayerNorm) is not supported by the MI355X path")
+            sys.exit(1)
+        return None
+
+    def sageLayer(self, input, output):
+        li = Linear(input, output, bias=False)
+        lj = Linear(input, output, bias=True)
+        if self.clf.model.edge_convs == 1:
+            le = Linear(self.n_edge_feat, input, bias=True)
+        elif self.clf.model.edge_convs == 2:
+            le = nn.Sequential()
+            le.add_module("0", Linear(self.n_edge_feat, int(self.n_edge_feat * 2)))
+            le.add_module("1", self.normLayer(int(self.n_edge_feat * 2)))
+            le.add_module("2", nn.ReLU(True))
+            le.add_module("3", Linear(int(self.n_edge_feat * 2), input))
+        else:
+            le = None
+        return SAGEConv(li, lj, le)
+
+    def __init__(self, clf):
+        super().__init__()
+        self.clf = clf
+        self.n_classes = 2
+        self.n_node_feat = clf.temp.num_node_features
+        self.n_edge_feat = clf.temp.num_edge_features
+        self.norm_type = clf.model.normalization
+        self.output_dim = 2 if clf.training.loss == "kl" else 1
+
+        self.convs = nn.ModuleList()
+        widths = [self.n_node_feat] + list(clf.model.convs)
+        for cin, cout in zip(widths[:-1], widths[1:]):
+            layer = nn.Sequential()
+            layer.add_module("conv", self.sageLayer(cin, cout))
+            layer.add_module("norm", self.normLayer(cout))
+            layer.add_module("relu", nn.ReLU(True))
+            self.convs.append(layer)
+        self.num_layers = len(self.convs)
+
+        self.decoder = nn.Sequential()
+        last = clf.model.convs[-1]
+        if clf.model.decoder == 1:
+            self.decoder.add_module("0", nn.Linear(last, self.output_dim))
+        elif clf.model.decoder == 2:
+            self.decoder.add_module("0", nn.Linear(last, int(last / 2)))
+            self.decoder.add_module("1", self.normLayer(int(last / 2)))
+            self.decoder.add_module("2", nn.ReLU(True))
+            self.decoder.add_module("3", nn.Linear(int(last / 2), self.output_dim))
+
+    # ------------------------------------------------------------------------------------------
+    def _device(self):
+        dev = self.clf.temp.device
+        if not str(dev).startswith("cuda"):
+            raise RuntimeError("clf.temp.device=%r: dgnn_amd.SurfaceNet runs on a GPU only (no CPU fallback)" % (dev,))
+        return dev
+
+    def _norm_act(self, layer, x):
+        """convs[i][1] then convs[i][2] (reference :218-219): BatchNorm (if any) + ReLU, one kernel chain."""
+        norm = layer[1] if len(layer) > 1 and isinstance(layer[1], BatchNorm) else None
+        if norm is not None:
+            return norm(x, relu=True)
+        return Fn.relu(x)
+
+    def _decode(self, x):
+        dec = self.decoder
+        if len(dec) == 0:
+            return x
+        if len(dec) == 1:
+            return Fn.linear2(x, dec[0].weight, bias=dec[0].bias)
+        h = Fn.linear2(x, dec[0].weight, bias=dec[0].bias)
+        h = dec[1](h, relu=True) if dec[1] is not None else Fn.relu(h)
+        return Fn.linear2(h, dec[3].weight, bias=dec[3].bias)
+
+    # ---- TRAIN FORWARD (reference :196-227) ---------------------------------------------------
+    def forward(self, data):
+        dev = self._device()
+        x_all = data.all.x
+        n_id = data.batch_n_id.to(x_all.device)
+        x = _dev_f32(x_all[n_id, 1:] if self.clf.regularization.cell_type else x_all[n_id, :], dev)
+        for i in range(self.num_layers):
+            edge_index, e_id, size = data.batch_adjs[i]
+            ea = _dev_f32(data.all.edge_attr[e_id.to(data.all.edge_attr.device)], dev)
+            edge_index = edge_index.to(dev)
+            x = self.convs[i][0]((x, x[:size[1]]), ea, edge_index)
+            x = self._norm_act(self.convs[i], x)
+        if self.clf.model.decoder:
+            x = self._decode(x)
+        return x
+
+    # ---- INFERENCE, whole graph (reference :323-355; the benchmarked path) ---------------------
+    @torch.no_grad()
+    def inference_layer(self, data_all, plan: GraphPlan = None):
+        dev = self._device()
+        x = _dev_f32(data_all.x, dev)
+        x = x[:, 1:] if self.clf.regularization.cell_type else x
+        xe = _dev_f32(data_all.edge_attr, dev)
+        xe = xe[:, 1:] if self.clf.regularization.edge_type else xe
+        edge_index = data_all.edge_index.to(dev)
+        if plan is None:
+            plan = plan_for(edge_index, x.size(0), x.size(0))
+        x = self._eval_layers(x, x.size(0), xe, [plan] * self.num_layers, sorted_attr=True)
+        return self._eval_decoder(x)
+
+    def _fold(self, norm, c, device):
+        if norm is None:
+            return None, None
+        bn = norm.module
+        return ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+
+    def _eval_layers(self, x, n_dst0, xe, plans, sorted_attr):
+        """Eval-mode conv stack: per layer one fused launch when the widths allow it, else the
+        aggregate + linear pair; BatchNorm(eval) and ReLU always ride in the GEMM epilogue."""
+        for i in range(self.num_layers):
+            layer, plan = self.convs[i], plans[i]
+            conv = layer[0]
+            norm = layer[1] if isinstance(layer[1], BatchNorm) else None
+            scale, shift = self._fold(norm, conv.lin_j.out_features, x.device)
+            le = conv.lin_e
+            x_dst = x[:plan.n_dst]
+            simple = isinstance(le, Linear) and le.in_features in (2, 20)
+            if simple and le.in_features == 20 and ops.fused_layer_supported(x.size(1), conv.lin_j.out_features, 20):
+                ea = plan.sorted_edge_attr(xe) if sorted_attr else xe
+                x = ops.sage_layer_fused_fwd(plan.rowptr, plan.src, plan.n_dst, x, ea, le.weight, le.bias, conv.lin_j.weight,
+                                             conv.lin_j.bias, conv.lin_i.weight, scale, shift, True)
+                continue
+            if simple:
+                ea = plan.sorted_edge_attr(xe) if sorted_attr else xe
+                a = ops.aggregate_fwd(plan.rowptr, plan.src, None if sorted_attr else plan.eid, plan.n_dst, x, ea, le.weight, le.bias)
+            else:
+                a = Fn.aggregate(x, plan, **conv._filter_args(xe))
+            x = ops.linear_fwd(a, conv.lin_j.weight, x_dst, conv.lin_i.weight, conv.lin_j.bias, scale, shift, True)
+        return x
+
+    def _eval_decoder(self, x):
+        dec = self.decoder
+        if not self.clf.model.decoder or len(dec) == 0:
+            return x
+        if len(dec) == 1:
+            return ops.linear_fwd(x, dec[0].weight, bias=dec[0].bias)
+        scale, shift = self._fold(dec[1] if isinstance(dec[1], BatchNorm) else None, dec[0].out_features, x.device)
+        h = ops.linear_fwd(x, dec[0].weight, bias=dec[0].bias, scale=scale, shift=shift, relu=True)
+        return ops.linear_fwd(h, dec[3].weight, bias=dec[3].bias)
+
+    # ---- INFERENCE, batch-major k-hop blocks (reference :232-275) ------------------------------
+    @torch.no_grad()
+    def inference_batch_layer(self, data_all, batch_loader):
+        dev = self._device()
+        x_out = torch.zeros([data_all.x.size(0), 2 if self.clf.training.loss == "kl" else 1], dtype=torch.float32, device=dev)
+        x_all = _dev_f32(data_all.x, dev)
+        x_all = x_all[:, 1:] if self.clf.regularization.cell_type else x_all
+        xe_all = _dev_f32(data_all.edge_attr, dev)
+        xe_all = xe_all[:, 1:] if self.clf.regularization.edge_type else xe_all
+        for batch_size, n_id, adjs in batch_loader:
+            n_id = n_id.to(dev)
+            x = ops.gather_rows(x_all, n_id.to(torch.int32))
+            for i in range(self.num_layers):
+                edge_index, e_id, size = adjs[i]
+                plan = plan_for(edge_index.to(dev), size[0], size[1], cache=False)
+                ea = ops.gather_rows(xe_all, e_id.to(dev).to(torch.int32))
+                x = self._eval_layers_one(i, x, ea, plan)
+            x = self._eval_decoder(x)
+            ops.scatter_rows_(x_out, n_id[:batch_size], x)
+        return x_out
+
+    def _eval_layers_one(self, i, x, ea, plan):
+        layer = self.convs[i]
+        conv = layer[0]
+        norm = layer[1] if isinstance(layer[1], BatchNorm) else None
+        scale, shift = self._fold(norm, conv.lin_j.out_features, x.device)
+        le = conv.lin_e
+        if isinstance(le, Linear) and le.in_features in (2, 20):
+            a = ops.aggregate_fwd(plan.rowptr, plan.src, plan.eid, plan.n_dst, x, ea, le.weight, le.bias)
+        else:
+            a = Fn.aggregate(x, plan, **conv._filter_args(ea))
+        return ops.linear_fwd(a, conv.lin_j.weight, x[:plan.n_dst], conv.lin_i.weight, conv.lin_j.bias, scale, shift, True)
+
+    # ---- INFERENCE, layer-major 1-hop blocks (reference :279-320) -------------------------------
+    @torch.no_grad()
+    def inference_layer_batch(self, data_all, batch_loader):
+        dev = self._device()
+        x_all = _dev_f32(data_all.x, dev)
+        x_all = x_all[:, 1:] if self.clf.regularization.cell_type else x_all
+        xe_all = _dev_f32(data_all.edge_attr, dev)
+        xe_all = xe_all[:, 1:] if self.clf.regularization.edge_type else xe_all
+        for i in range(self.num_layers):
+            xs = []
+            for batch_size, n_id, adj in batch_loader:
+                edge_index, e_id, size = adj
+                x = ops.gather_rows(x_all, n_id.to(dev).to(torch.int32))
+                plan = plan_for(edge_index.to(dev), size[0], size[1], cache=False)
+                ea = ops.gather_rows(xe_all, e_id.to(dev).to(torch.int32))
+                xs.append(self._eval_layers_one(i, x, ea, plan))  # activations stay in HBM (no host round trip)
+            x_all = torch.cat(xs, dim=0)
+        return self._eval_decoder(x_all)

@@ -1,0 +1,242 @@
+"""Tensor-level wrappers over the C ABI (PyTorch is used for device memory and streams only).
+
+Every function takes CUDA(ROCm) float32 tensors whose last dimension is contiguous, launches on the
+current torch stream and returns torch tensors.  No CPU path exists: a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import DgnnError, check, lib, ptr, stream_ptr
+
+
+def _req(t: torch.Tensor, name: str, dtype=torch.float32, dim=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a tensor" % name)
+    if not t.is_cuda:
+        raise DgnnError("%s is on %s: dgnn_amd runs on the GPU only (no CPU fallback)" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if dim is not None and t.dim() != dim:
+        raise ValueError("%s must be %d-D, got shape %s" % (name, dim, tuple(t.shape)))
+    if t.dim() == 2 and t.numel() and t.stride(1) != 1:
+        raise ValueError("%s must have a contiguous last dimension (stride %s)" % (name, t.stride()))
+    return t
+
+
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.size(0) > 1 or t.stride(0) >= t.size(1) else t.size(1)
+
+
+def rows2d(t: torch.Tensor, name: str) -> torch.Tensor:
+    """Returns `t` as a 2-D fp32 tensor with unit column stride (copies only when it must)."""
+    _req(t, name, dim=2)
+    return t
+
+
+def _f32(n, device):
+    return torch.empty(int(max(n, 1)), dtype=torch.float32, device=device)
+
+
+# ---- plan ---------------------------------------------------------------------------------------
+def plan_build(edge_index: torch.Tensor, n_key: int, by: int):
+    """-> (rowptr int32 [n_key+1], other int32 [E], eid int32 [E]); see dgnn_plan_build."""
+    _req(edge_index, "edge_index", torch.int64, 2)
+    if edge_index.size(0) != 2 or not edge_index.is_contiguous():
+        raise ValueError("edge_index must be a contiguous int64 [2,E] tensor")
+    E = edge_index.size(1)
+    dev = edge_index.device
+    rowptr = torch.empty(n_key + 1, dtype=torch.int32, device=dev)
+    other = torch.empty(max(E, 1), dtype=torch.int32, device=dev)[:E]
+    eid = torch.empty(max(E, 1), dtype=torch.int32, device=dev)[:E]
+    scratch = torch.empty(int(lib().dgnn_plan_scratch_elems(E, n_key)), dtype=torch.int32, device=dev)
+    check(lib().dgnn_plan_build(ptr(edge_index), E, n_key, by, ptr(rowptr), ptr(other), ptr(eid), ptr(scratch), stream_ptr()),
+          "dgnn_plan_build")
+    return rowptr, other, eid
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    _req(src, "src", dim=2)
+    _req(idx, "idx", torch.int32, 1)
+    out = torch.empty((idx.numel(), src.size(1)), dtype=torch.float32, device=src.device)
+    check(lib().dgnn_gather_rows_f32(ptr(src), _ld(src), ptr(idx), idx.numel(), src.size(1), ptr(out), out.size(1), stream_ptr()),
+          "dgnn_gather_rows_f32")
+    return out
+
+
+def scatter_rows_(out: torch.Tensor, idx: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    _req(src, "src", dim=2)
+    _req(out, "out", dim=2)
+    _req(idx, "idx", torch.int64, 1)
+    check(lib().dgnn_scatter_rows_f32(ptr(src), _ld(src), ptr(idx), idx.numel(), src.size(1), ptr(out), _ld(out), stream_ptr()),
+          "dgnn_scatter_rows_f32")
+    return out
+
+
+def relu(x: torch.Tensor) -> torch.Tensor:
+    _req(x, "x")
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    check(lib().dgnn_relu(ptr(x), x.numel(), ptr(y), stream_ptr()), "dgnn_relu")
+    return y
+
+
+# ---- aggregation --------------------------------------------------------------------------------
+def aggregate_fwd(rowptr, src, eid, n_dst, x_src, edge_attr=None, We=None, be=None, phi=None, want_phi=False):
+    _req(x_src, "x_src", dim=2)
+    c_in = x_src.size(1)
+    a = torch.empty((n_dst, c_in), dtype=torch.float32, device=x_src.device)
+    phi_out = None
+    f_e = 0
+    if We is not None:
+        _req(edge_attr, "edge_attr", dim=2)
+        _req(We, "We", dim=2)
+        We = We.contiguous()
+        be = _req(be, "be").contiguous()
+        f_e = We.size(1)
+        if We.size(0) != c_in or edge_attr.size(1) < f_e:
+            raise ValueError("lin_e weight %s does not match c_in=%d / edge_attr %s" % (tuple(We.shape), c_in, tuple(edge_attr.shape)))
+        if want_phi:
+            phi_out = torch.empty((edge_attr.size(0), c_in), dtype=torch.float32, device=x_src.device)
+    elif phi is not None:
+        _req(phi, "phi", dim=2)
+    check(lib().dgnn_sage_aggregate_fwd(
+        ptr(rowptr), ptr(src), ptr(eid), n_dst, ptr(x_src), _ld(x_src), c_in,
+        ptr(edge_attr) if We is not None else None, _ld(edge_attr) if We is not None else 0, f_e,
+        ptr(We), ptr(be), ptr(phi), _ld(phi) if phi is not None else 0,
+        ptr(phi_out), c_in, ptr(a), c_in, stream_ptr()), "dgnn_sage_aggregate_fwd")
+    return (a, phi_out) if want_phi else a
+
+
+def aggregate_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, da, edge_attr=None, We=None, be=None, phi=None,
+                  need_dx=True):
+    """-> (dx_src | None, dWe | None, dbe | None, dphi | None)"""
+    _req(x_src, "x_src", dim=2)
+    _req(da, "da", dim=2)
+    c_in = x_src.size(1)
+    dev = x_src.device
+    dx = torch.empty((n_src, c_in), dtype=torch.float32, device=dev) if need_dx else None
+    dWe = dbe = dphi = None
+    f_e = 0
+    partials = None
+    if We is not None:
+        We = We.contiguous()
+        be = be.contiguous()
+        f_e = We.size(1)
+        dWe = torch.zeros_like(We)
+        dbe = torch.zeros_like(be)
+        partials = _f32(lib().dgnn_sage_aggregate_bwd_scratch_elems(n_src, c_in, f_e), dev)
+    elif phi is not None:
+        dphi = torch.zeros((phi.size(0), c_in), dtype=torch.float32, device=dev)
+    check(lib().dgnn_sage_aggregate_bwd(
+        ptr(t_rowptr), ptr(t_dst), ptr(t_eid), n_src, ptr(rowptr_dst), ptr(x_src), _ld(x_src), c_in,
+        ptr(edge_attr) if We is not None else None, _ld(edge_attr) if We is not None else 0, f_e, ptr(We), ptr(be),
+        ptr(phi), _ld(phi) if phi is not None else 0, ptr(da), _ld(da), ptr(dx), c_in, ptr(dWe), ptr(dbe), ptr(dphi), c_in,
+        ptr(partials), stream_ptr()), "dgnn_sage_aggregate_bwd")
+    return dx, dWe, dbe, dphi
+
+
+# ---- dense --------------------------------------------------------------------------------------
+def linear_fwd(A1, W1, A2=None, W2=None, bias=None, scale=None, shift=None, relu=False):
+    _req(A1, "A1", dim=2)
+    W1 = _req(W1, "W1", dim=2).contiguous()
+    M, n_out = A1.size(0), W1.size(0)
+    if W1.size(1) != A1.size(1):
+        raise ValueError("W1 %s does not match A1 %s" % (tuple(W1.shape), tuple(A1.shape)))
+    if A2 is not None:
+        _req(A2, "A2", dim=2)
+        W2 = _req(W2, "W2", dim=2).contiguous()
+        if A2.size(0) != M or W2.size(0) != n_out or W2.size(1) != A2.size(1):
+            raise ValueError("second operand shapes do not match")
+    out = torch.empty((M, n_out), dtype=torch.float32, device=A1.device)
+    check(lib().dgnn_linear_fwd(
+        ptr(A1), _ld(A1), A1.size(1), ptr(W1), W1.size(1),
+        ptr(A2), _ld(A2) if A2 is not None else 0, A2.size(1) if A2 is not None else 0, ptr(W2), W2.size(1) if W2 is not None else 0,
+        ptr(bias), ptr(scale), ptr(shift), int(bool(relu)), M, n_out, ptr(out), n_out, stream_ptr()), "dgnn_linear_fwd")
+    return out
+
+
+def linear_wgrad(A, B):
+    """dW[n_a,n_b] = A^T . B  (A [M,n_a], B [M,n_b])"""
+    _req(A, "A", dim=2)
+    _req(B, "B", dim=2)
+    M, na, nb = A.size(0), A.size(1), B.size(1)
+    dW = torch.empty((na, nb), dtype=torch.float32, device=A.device)
+    if M == 0:
+        return dW.zero_()
+    partials = _f32(lib().dgnn_linear_wgrad_scratch_elems(M, na, nb), A.device)
+    check(lib().dgnn_linear_wgrad(ptr(A), _ld(A), na, ptr(B), _ld(B), nb, M, ptr(dW), nb, 0, ptr(partials), stream_ptr()),
+          "dgnn_linear_wgrad")
+    return dW
+
+
+def colsum(x):
+    _req(x, "x", dim=2)
+    out = torch.empty(x.size(1), dtype=torch.float32, device=x.device)
+    if x.size(0) == 0:
+        return out.zero_()
+    scratch = _f32(lib().dgnn_colstats_scratch_elems(x.size(0), x.size(1)), x.device)
+    check(lib().dgnn_colsum(ptr(x), _ld(x), x.size(0), x.size(1), ptr(out), 0, ptr(scratch), stream_ptr()), "dgnn_colsum")
+    return out
+
+
+# ---- batch norm ---------------------------------------------------------------------------------
+def bn_fold(gamma, beta, mean, var, eps):
+    c = mean.numel()
+    scale = torch.empty(c, dtype=torch.float32, device=mean.device)
+    shift = torch.empty(c, dtype=torch.float32, device=mean.device)
+    check(lib().dgnn_bn_fold(ptr(gamma), ptr(beta), ptr(mean), ptr(var), float(eps), c, ptr(scale), ptr(shift), stream_ptr()),
+          "dgnn_bn_fold")
+    return scale, shift
+
+
+def bn_batch_stats(x, running_mean=None, running_var=None, momentum=0.1):
+    _req(x, "x", dim=2)
+    M, c = x.shape
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    var = torch.empty(c, dtype=torch.float32, device=x.device)
+    scratch = _f32(lib().dgnn_colstats_scratch_elems(M, c), x.device)
+    check(lib().dgnn_bn_batch_stats(ptr(x), _ld(x), M, c, ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
+                                    float(momentum), ptr(scratch), stream_ptr()), "dgnn_bn_batch_stats")
+    return mean, var
+
+
+def scale_shift_act(x, scale, shift, relu):
+    _req(x, "x", dim=2)
+    y = torch.empty((x.size(0), x.size(1)), dtype=torch.float32, device=x.device)
+    check(lib().dgnn_scale_shift_act(ptr(x), _ld(x), ptr(scale), ptr(shift), int(bool(relu)), x.size(0), x.size(1), ptr(y),
+                                     x.size(1), stream_ptr()), "dgnn_scale_shift_act")
+    return y
+
+
+def bn_relu_bwd(x, y, dy, gamma, mean, var, eps, train, relu):
+    _req(x, "x", dim=2)
+    _req(dy, "dy", dim=2)
+    M, c = x.shape
+    dx = torch.empty((M, c), dtype=torch.float32, device=x.device)
+    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+    scratch = _f32(lib().dgnn_colstats_scratch_elems(M, c), x.device)
+    check(lib().dgnn_bn_relu_bwd(ptr(x), _ld(x), ptr(y), _ld(y) if y is not None else 0, ptr(dy), _ld(dy), ptr(gamma), ptr(mean),
+                                 ptr(var), float(eps), int(bool(train)), int(bool(relu)), M, c, ptr(dx), c, ptr(dgamma), ptr(dbeta),
+                                 ptr(scratch), stream_ptr()), "dgnn_bn_relu_bwd")
+    return dx, dgamma, dbeta
+
+
+# ---- fused inference layer ----------------------------------------------------------------------
+def fused_layer_supported(c_in: int, c_out: int, f_e: int) -> bool:
+    return f_e == 20 and c_in <= 128 and c_out in (64, 128) and FUSED_ENABLED
+
+
+FUSED_ENABLED = False  # flipped on when csrc/fused.hip carries the real kernel
+
+
+def sage_layer_fused_fwd(rowptr, src, n_dst, x_src, edge_attr_sorted, We, be, Wj, bj, Wi, scale, shift, relu):
+    _req(x_src, "x_src", dim=2)
+    c_in, c_out = x_src.size(1), Wj.size(0)
+    out = torch.empty((n_dst, c_out), dtype=torch.float32, device=x_src.device)
+    check(lib().dgnn_sage_layer_fused_fwd(
+        ptr(rowptr), ptr(src), n_dst, ptr(x_src), _ld(x_src), c_in, ptr(edge_attr_sorted), _ld(edge_attr_sorted), We.size(1),
+        ptr(We), ptr(be), ptr(Wj), ptr(bj), ptr(Wi), ptr(scale), ptr(shift), int(bool(relu)), c_out, ptr(out), c_out,
+        stream_ptr()), "dgnn_sage_layer_fused_fwd")
+    return out

@@ -1,0 +1,171 @@
+/*
+ * dgnn_hip.h -- C ABI of libdgnn_hip.so: the MI355X (gfx950) kernels behind the hot path of
+ * raphaelsulzer/dgnn (edge-filtered GraphSAGE over the tetrahedron-adjacency graph).
+ *
+ * The reference has no FFI / operator registry: its seam is the Python module API
+ * (learning/surfaceNetStaticEdgeFilters.py, learning/surfaceNetUpdatedEdgeFilters.py).  The Python
+ * mirror in dgnn_amd/ keeps that API and binds these entry points with ctypes;
+ * each entry point below cites the reference lines (relative to the reference root) it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (e.g. torch.Tensor.data_ptr()); sizes are element counts;
+ *    `ld*` are row strides in elements; all float data is fp32 row-major, all indices int32 unless
+ *    stated (the reference's edge_index is int64 [2,E] and is consumed as such by the plan builder);
+ *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *  - nothing here allocates, frees or synchronises: the caller owns every buffer, including the
+ *    plan arrays and scratch; calls are asynchronous on `stream`;
+ *  - return value: 0 = ok, negative = DGNN_E_*; dgnn_last_error_string() describes the last
+ *    failure on the calling thread.  Functions never throw.
+ *  - thread safety: no global mutable state except the thread-local error string; calls on
+ *    distinct streams may run concurrently.
+ */
+#ifndef DGNN_HIP_H
+#define DGNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGNN_VERSION 100 /* major*10000 + minor*100 + patch */
+
+#define DGNN_OK 0
+#define DGNN_E_INVALID -1     /* bad argument (null pointer, negative size, unsupported width) */
+#define DGNN_E_UNSUPPORTED -2 /* shape outside what the kernel family handles */
+#define DGNN_E_LAUNCH -3      /* hipGetLastError() after launch */
+
+int dgnn_version(void);
+const char* dgnn_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Graph plan: destination-sorted CSR of an edge list, STABLE in edge position.
+ *
+ * Replaces the implicit per-call work of PyG `MessagePassing.propagate` + torch_scatter
+ * `scatter(reduce='mean')` (call site surfaceNetStaticEdgeFilters.py:80): there the aggregation
+ * index is edge_index[1] and CPU accumulation runs in ascending edge position per destination.  The
+ * plan makes that order explicit: for destination i, sorted edges rowptr[i]..rowptr[i+1]-1 are its
+ * in-edges in ascending original position; src[k] = edge_index[0][eid[k]].
+ *
+ * `by` selects the sort key row of edge_index: 1 = by destination (forward), 0 = by source
+ * (the transposed plan used by the backward pass; then `src` receives the OTHER endpoint,
+ * i.e. the destination, and n_key = number of sources).
+ *
+ *   edge_index : int64 [2,E] (reference layout, processing/data.py:434-438), row0=src row1=dst
+ *   rowptr     : int32 [n_key+1]   out
+ *   other      : int32 [E]         out  (src for by=1, dst for by=0)
+ *   eid        : int32 [E]         out  original edge position of the k-th sorted edge
+ *   scratch    : int32 [dgnn_plan_scratch_elems(E,n_key)]
+ * ---------------------------------------------------------------------------------------------- */
+int64_t dgnn_plan_scratch_elems(int64_t E, int64_t n_key);
+int dgnn_plan_build(const int64_t* edge_index, int64_t E, int64_t n_key, int by, int32_t* rowptr, int32_t* other,
+                    int32_t* eid, int32_t* scratch, void* stream);
+
+/* out[k, 0:cols] = in[idx[k], 0:cols]  -- stages edge_attr rows into plan order once per scene
+ * (the reference gathers them implicitly: `xe[e_id]` at surfaceNetStaticEdgeFilters.py:262,304). */
+int dgnn_gather_rows_f32(const float* in, int64_t ld_in, const int32_t* idx, int64_t n, int cols, float* out,
+                         int64_t ld_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Edge-filtered mean aggregation (forward).  Replaces surfaceNetStaticEdgeFilters.py:75-80 + :89-96
+ * (lin_e -> index_select -> x_j * phi -> scatter mean) and surfaceNetUpdatedEdgeFilters.py:156-158.
+ *
+ *   a[i,:] = ( sum_{k in rowptr[i]..rowptr[i+1]} x_src[src[k],:] * phi_k ) / max(deg_i,1)
+ *   phi_k  = We . edge_attr[e,:] + be          (mode "fused": We != NULL, F_e <= 32)
+ *          = phi[e,:]                           (mode "given": We == NULL, phi != NULL)
+ *          = 1                                  (both NULL: plain mean, lin_e is None at :77-78)
+ *   e      = eid ? eid[k] : k                   (eid == NULL: edge rows already in plan order)
+ *
+ * The sum runs in plan order with separately rounded multiply and add, i.e. the CPU order of
+ * torch_scatter.  phi_out (optional, fused mode) receives phi rows at index e: the Updated variant
+ * returns them (surfaceNetUpdatedEdgeFilters.py:170).
+ * ---------------------------------------------------------------------------------------------- */
+int dgnn_sage_aggregate_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst,
+                            const float* x_src, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e,
+                            const float* We, const float* be, const float* phi, int64_t ldphi, float* phi_out,
+                            int64_t ldphi_out, float* a, int64_t lda, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * out = act( (A1 . W1^T + A2 . W2^T + bias) * scale + shift )      [M, n_out]
+ *
+ * Replaces lin_j(out) + lin_i(x_r) (surfaceNetStaticEdgeFilters.py:81-86; lin_l/lin_r at
+ * surfaceNetUpdatedEdgeFilters.py:159-165), eval-mode BatchNorm folded to scale/shift (:218) and
+ * ReLU (:219); also the decoder Linears (:180-187) and lin_e of the Updated variant when its input
+ * is wide.  W1 [n_out,K1], W2 [n_out,K2] are torch.nn.Linear weights (row-major).  A2/W2, bias,
+ * scale/shift may be NULL.  relu != 0 applies max(0,.).  fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * ---------------------------------------------------------------------------------------------- */
+int dgnn_linear_fwd(const float* A1, int64_t lda1, int k1, const float* W1, int64_t ldw1, const float* A2,
+                    int64_t lda2, int k2, const float* W2, int64_t ldw2, const float* bias, const float* scale,
+                    const float* shift, int relu, int64_t M, int n_out, float* out, int64_t ldo, void* stream);
+
+/* dW[n_a, n_b] (+)= A^T . B over M rows (weight gradients of the Linears above: autograd of :81-86).
+ * Deterministic two-stage reduction; `partials` holds dgnn_linear_wgrad_scratch_elems floats. */
+int64_t dgnn_linear_wgrad_scratch_elems(int64_t M, int n_a, int n_b);
+int dgnn_linear_wgrad(const float* A, int64_t lda, int n_a, const float* B, int64_t ldb, int n_b, int64_t M,
+                      float* dW, int64_t lddw, int accumulate, float* partials, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm1d pieces (torch_geometric BatchNorm -> torch.nn.BatchNorm1d, eps 1e-5, momentum 0.1;
+ * used at surfaceNetStaticEdgeFilters.py:165,173,185; applied :218,263,305,345).
+ * ---------------------------------------------------------------------------------------------- */
+/* eval fold: scale = gamma/sqrt(var+eps), shift = beta - mean*scale */
+int dgnn_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int c,
+                 float* scale, float* shift, void* stream);
+/* column sums and sums of squares (fp64 accumulation inside) -> mean[c], biased var[c]; when
+ * running_* != NULL updates them with momentum and the UNBIASED variance, as BatchNorm1d.train(). */
+int64_t dgnn_colstats_scratch_elems(int64_t M, int c);
+int dgnn_bn_batch_stats(const float* x, int64_t ldx, int64_t M, int c, float* mean, float* var, float* running_mean,
+                        float* running_var, float momentum, float* scratch, void* stream);
+/* y = act(x*scale + shift) elementwise over [M,c] (train-mode BN apply + ReLU; in place allowed) */
+int dgnn_scale_shift_act(const float* x, int64_t ldx, const float* scale, const float* shift, int relu, int64_t M,
+                         int c, float* y, int64_t ldy, void* stream);
+/* backward of y = relu(bn(x)):  given y, dy (and x_hat recomputed from x, mean, invstd) produce
+ * dx, dgamma, dbeta.  train != 0 uses the batch-statistics formula, else dx = dy*mask*scale. */
+int dgnn_bn_relu_bwd(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* dy, int64_t lddy,
+                     const float* gamma, const float* mean, const float* var, float eps, int train, int relu,
+                     int64_t M, int c, float* dx, int64_t lddx, float* dgamma, float* dbeta, float* scratch,
+                     void* stream);
+/* out[c] (+)= sum over rows (bias gradients) */
+int dgnn_colsum(const float* x, int64_t ldx, int64_t M, int c, float* out, int accumulate, float* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Aggregation backward (autograd of :75-80,:89-96, invoked at learning/runModel.py:279).
+ * Runs over the TRANSPOSED plan (edges grouped by source) so dx_src needs no atomics:
+ *   dm_e   = da[dst_e,:] / max(deg_dst,1)
+ *   dphi_e = dm_e * x_src[s,:]          dx_src[s,:] = sum_e dm_e * phi_e
+ *   fused mode (We != NULL): phi recomputed; dWe += dphi_e (x) edge_attr[e]; dbe += dphi_e
+ *   given mode (phi != NULL): dphi written to dphi_out[e,:]
+ *   t_rowptr/t_dst/t_eid : transposed plan (dgnn_plan_build with by=0); deg_dst from rowptr_dst.
+ * dWe [c_in,f_e], dbe [c_in] are accumulated deterministically via `partials`.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t dgnn_sage_aggregate_bwd_scratch_elems(int64_t n_src, int c_in, int f_e);
+int dgnn_sage_aggregate_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, int64_t n_src,
+                            const int32_t* rowptr_dst, const float* x_src, int64_t ldx, int c_in,
+                            const float* edge_attr, int64_t lde, int f_e, const float* We, const float* be,
+                            const float* phi, int64_t ldphi, const float* da, int64_t ldda, float* dx_src,
+                            int64_t lddx, float* dWe, float* dbe, float* dphi_out, int64_t lddphi, float* partials,
+                            void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused inference layer (the timed path, surfaceNetStaticEdgeFilters.py:343-346, one call per
+ * layer): aggregate + lin_j + lin_i + BN(eval) + ReLU in one persistent launch; the aggregate
+ * never leaves the CU.  Requires c_in <= 128, c_out in {64,128}, f_e == 20, edge rows in plan
+ * order (edge_attr_sorted).  Returns DGNN_E_UNSUPPORTED otherwise (callers fall back to the
+ * aggregate + linear pair above).
+ * ---------------------------------------------------------------------------------------------- */
+int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* src, int64_t n_dst, const float* x_src,
+                              int64_t ldx, int c_in, const float* edge_attr_sorted, int64_t lde, int f_e,
+                              const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
+                              const float* scale, const float* shift, int relu, int c_out, float* out, int64_t ldo,
+                              void* stream);
+
+/* elementwise helpers used by the Updated variant (F.relu at surfaceNetUpdatedEdgeFilters.py:239-241
+ * and the scatter of phi rows into the zero [E_all,C] buffer at :236-237) */
+int dgnn_relu(const float* x, int64_t n, float* y, void* stream);
+int dgnn_scatter_rows_f32(const float* in, int64_t ld_in, const int64_t* idx, int64_t n, int cols, float* out,
+                          int64_t ld_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGNN_HIP_H */

@@ -1,0 +1,285 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the committed golden
+vectors.  Bar: bit-exact for integer/index work; fp32 logits within 1e-4 abs (the
+reference differs from its own fp64 evaluation by 4e-6; the downstream graph cut rounds logit*10)."""
+import numpy as np
+import pytest
+import torch
+
+from dgnn_amd.config import Config, reconbench_pretrained
+from helpers import f3_data, gold, kf96_state_dict, oracle_static
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+TOL_LOGIT = 1e-4
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def hip_static(train=False, convs=(64, 128, 128, 128), sd=None):
+    from dgnn_amd.learning.surfaceNetStaticEdgeFilters import SurfaceNet
+    net = SurfaceNet(reconbench_pretrained(device=DEV, convs=convs))
+    net.load_state_dict(kf96_state_dict() if sd is None else sd)
+    net = net.to(DEV)
+    return net.train() if train else net.eval()
+
+
+# ---- plan: bit-exact index work -------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["regular", "ragged", "empty_rows", "star", "empty"])
+def test_plan_matches_stable_sort(case):
+    from dgnn_amd import ops
+    rng = np.random.default_rng(0)
+    if case == "regular":
+        from dgnn_amd.synthetic import delaunay_tet_graph
+        adj, _, _ = delaunay_tet_graph(3000, seed=2)
+        ei = adj.T.astype(np.int64)
+        n_src = n_dst = adj.shape[0] // 4
+    elif case == "ragged":
+        n_src, n_dst, E = 5000, 3000, 40000
+        ei = np.stack([rng.integers(0, n_src, E), rng.integers(0, n_dst, E)])
+    elif case == "empty_rows":
+        n_src, n_dst, E = 100, 1000, 300
+        ei = np.stack([rng.integers(0, n_src, E), rng.integers(0, n_dst, E)])
+    elif case == "star":  # one destination with a very long segment + some medium ones
+        n_src, n_dst = 4000, 50
+        dst = np.concatenate([np.zeros(3000, np.int64), rng.integers(1, 5, 200), rng.integers(5, 50, 500)])
+        ei = np.stack([rng.integers(0, n_src, dst.shape[0]), rng.permutation(dst)])
+    else:
+        n_src, n_dst = 7, 5
+        ei = np.zeros((2, 0), np.int64)
+    t = torch.from_numpy(np.ascontiguousarray(ei)).to(DEV)
+    for by, n_key in ((1, n_dst), (0, n_src)):
+        rowptr, other, eid = ops.plan_build(t, n_key, by)
+        key, oth = ei[by], ei[1 - by]
+        order = np.argsort(key, kind="stable")
+        ref_rowptr = np.concatenate([[0], np.cumsum(np.bincount(key, minlength=n_key))])
+        assert np.array_equal(rowptr.cpu().numpy(), ref_rowptr)
+        assert np.array_equal(eid.cpu().numpy(), order)
+        assert np.array_equal(other.cpu().numpy(), oth[order])
+
+
+# ---- aggregate: given phi is bit-exact against the oracle's propagate ------------------------------
+@pytest.mark.parametrize("c_in", [28, 64, 128, 200])
+def test_aggregate_phi_given_bit_exact(c_in):
+    from dgnn_amd import ops
+    from oracle.pyg_semantics import propagate_mean
+    g = torch.Generator().manual_seed(c_in)
+    n_src, n_dst, E = 700, 500, 2600
+    ei = torch.stack([torch.randint(0, n_src, (E,), generator=g), torch.randint(0, n_dst + 40, (E,), generator=g).clamp_max(n_dst - 1)])
+    x = torch.randn(n_src, c_in, generator=g)
+    phi = torch.randn(E, c_in, generator=g)
+    ref = propagate_mean(x, n_dst, ei, phi)
+    rowptr, src, eid = ops.plan_build(ei.to(DEV), n_dst, 1)
+    a = ops.aggregate_fwd(rowptr, src, eid, n_dst, x.to(DEV), phi=phi.to(DEV))
+    assert torch.equal(a.cpu(), ref)
+    ref_plain = propagate_mean(x, n_dst, ei, None)
+    a = ops.aggregate_fwd(rowptr, src, eid, n_dst, x.to(DEV))
+    assert torch.equal(a.cpu(), ref_plain)
+
+
+@pytest.mark.parametrize("c_in,f_e", [(28, 20), (64, 20), (128, 20), (48, 2)])
+def test_aggregate_fused_filter(c_in, f_e):
+    from dgnn_amd import ops
+    from oracle.pyg_semantics import propagate_mean
+    g = torch.Generator().manual_seed(7)
+    n_src, n_dst, E = 900, 600, 3000
+    ei = torch.stack([torch.randint(0, n_src, (E,), generator=g), torch.randint(0, n_dst, (E,), generator=g)])
+    x = torch.randn(n_src, c_in + 1, generator=g)[:, 1:]  # unaligned view, row stride c_in+1
+    ea = torch.randn(E, f_e, generator=g)
+    We, be = torch.randn(c_in, f_e, generator=g) * 0.3, torch.randn(c_in, generator=g)
+    phi64 = ea.double() @ We.double().t() + be.double()
+    ref = propagate_mean(x.double(), n_dst, ei, phi64)
+    rowptr, src, eid = ops.plan_build(ei.to(DEV), n_dst, 1)
+    xd = torch.randn(1).to(DEV)  # noqa: F841 (touch the device)
+    x_dev = torch.empty(n_src, c_in + 1, device=DEV)
+    x_dev[:, 1:] = x.to(DEV)
+    a, phi = ops.aggregate_fwd(rowptr, src, eid, n_dst, x_dev[:, 1:], ea.to(DEV), We.to(DEV), be.to(DEV), want_phi=True)
+    assert rel_err(a, ref) < 2e-6
+    assert rel_err(phi, phi64) < 2e-6
+
+
+# ---- dense kernels ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,k1,k2,n_out", [(1000, 28, 28, 64), (777, 64, 64, 128), (2048, 128, 128, 128), (300, 128, 0, 2),
+                                          (130, 37, 5, 70), (1, 128, 0, 64)])
+def test_linear_fwd(M, k1, k2, n_out):
+    from dgnn_amd import ops
+    g = torch.Generator().manual_seed(M)
+    A1, W1 = torch.randn(M, k1, generator=g), torch.randn(n_out, k1, generator=g)
+    b = torch.randn(n_out, generator=g)
+    sc, sh = torch.rand(n_out, generator=g) + 0.5, torch.randn(n_out, generator=g)
+    ref = A1.double() @ W1.double().t() + b.double()
+    args = dict(A1=A1.to(DEV), W1=W1.to(DEV), bias=b.to(DEV))
+    if k2:
+        A2, W2 = torch.randn(M, k2, generator=g), torch.randn(n_out, k2, generator=g)
+        ref = ref + A2.double() @ W2.double().t()
+        args.update(A2=A2.to(DEV), W2=W2.to(DEV))
+    out = ops.linear_fwd(**args)
+    assert rel_err(out, ref) < 2e-6
+    out = ops.linear_fwd(**args, scale=sc.to(DEV), shift=sh.to(DEV), relu=True)
+    assert rel_err(out, torch.relu(ref * sc.double() + sh.double())) < 2e-6
+
+
+@pytest.mark.parametrize("M,na,nb", [(5000, 128, 128), (333, 64, 28), (70000, 2, 64), (64, 130, 37)])
+def test_linear_wgrad_and_colsum(M, na, nb):
+    from dgnn_amd import ops
+    g = torch.Generator().manual_seed(M)
+    A, B = torch.randn(M, na, generator=g), torch.randn(M, nb, generator=g)
+    dW = ops.linear_wgrad(A.to(DEV), B.to(DEV))
+    assert rel_err(dW, A.double().t() @ B.double()) < 1e-5
+    assert rel_err(ops.colsum(A.to(DEV)), A.double().sum(0)) < 1e-5
+
+
+def test_batchnorm_train_eval_and_backward():
+    from dgnn_amd import functional as Fn
+    g = torch.Generator().manual_seed(3)
+    M, c = 4321, 96
+    x = torch.randn(M, c, generator=g) * 2 + 0.5
+    for training in (True, False):
+        bn_ref = torch.nn.BatchNorm1d(c)
+        with torch.no_grad():
+            bn_ref.weight.copy_(torch.rand(c, generator=g) + 0.5)
+            bn_ref.bias.copy_(torch.randn(c, generator=g))
+            bn_ref.running_mean.copy_(torch.randn(c, generator=g) * 0.1)
+            bn_ref.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+        bn = torch.nn.BatchNorm1d(c)
+        bn.load_state_dict(bn_ref.state_dict())
+        bn = bn.to(DEV)
+        bn_ref.train(training)
+        bn.train(training)
+        xr = x.clone().requires_grad_(True)
+        xg = x.to(DEV).requires_grad_(True)
+        G = torch.randn(M, c, generator=g)
+        yr = torch.relu(bn_ref(xr))
+        (yr * G).sum().backward()
+        yg = Fn.batch_norm_act(xg, bn, relu=True)
+        (yg * G.to(DEV)).sum().backward()
+        assert rel_err(yg, yr) < 1e-5
+        assert rel_err(xg.grad, xr.grad) < 2e-5
+        assert rel_err(bn.weight.grad, bn_ref.weight.grad) < 2e-5
+        assert rel_err(bn.bias.grad, bn_ref.bias.grad) < 2e-5
+        assert rel_err(bn.running_mean, bn_ref.running_mean) < 1e-5
+        assert rel_err(bn.running_var, bn_ref.running_var) < 1e-5
+        assert int(bn.num_batches_tracked) == int(bn_ref.num_batches_tracked)
+
+
+# ---- whole model: golden vectors --------------------------------------------------------------------
+@pytest.mark.parametrize("fused", [True, False])
+def test_inference_layer_golden_f2(fused):
+    from dgnn_amd import ops
+    g = gold("static_f2_regular256.npz")
+    net = hip_static()
+    data = Config(x=torch.from_numpy(g["x"]).to(DEV), edge_attr=torch.from_numpy(g["edge_attr"]).to(DEV),
+                  edge_index=torch.from_numpy(g["adjacencies"].T.astype(np.int64)).to(DEV))
+    ops.FUSED_ENABLED = fused
+    try:
+        logits = net.inference_layer(data)
+    finally:
+        ops.FUSED_ENABLED = True
+    err = np.abs(logits.cpu().numpy() - g["logits"]).max()
+    assert err <= TOL_LOGIT, err
+    assert np.abs(logits.cpu().numpy().astype(np.float64) - g["logits64"]).max() <= TOL_LOGIT
+    # arg-max (the in/out label) agrees wherever the margin exceeds the tolerance
+    ref = g["logits"]
+    margin = np.abs(ref[:, 0] - ref[:, 1]) > TOL_LOGIT
+    assert np.array_equal(logits.cpu().numpy().argmax(1)[margin], ref.argmax(1)[margin])
+
+
+def test_inference_layer_golden_f1_real_block():
+    g = gold("static_f1_ignatius.npz")
+    net = hip_static()
+    data = Config(x=torch.from_numpy(g["x"]).to(DEV), edge_attr=torch.from_numpy(g["edge_attr"]).to(DEV),
+                  edge_index=torch.from_numpy(g["edge_index"].astype(np.int64)).to(DEV))
+    logits = net.inference_layer(data)
+    assert np.abs(logits.cpu().numpy() - g["logits"]).max() <= TOL_LOGIT
+
+
+def test_per_layer_activations_vs_oracle():
+    """Every layer's output (not only the logits) against the oracle, heavy-tailed inputs."""
+    from dgnn_amd.synthetic import delaunay_tet_graph
+    adj, _, _ = delaunay_tet_graph(1500, seed=5)
+    n = adj.shape[0] // 4
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(n, 29, generator=g)
+    x[::97] *= 40.0  # real standardised features reach 174 sigma
+    ea = torch.randn(4 * n, 20, generator=g)
+    ei = torch.from_numpy(adj.T.astype(np.int64))
+    onet = oracle_static(dtype=torch.float64)
+    trace = []
+    with torch.no_grad():
+        ref = onet.inference_layer(Config(x=x.double(), edge_attr=ea.double(), edge_index=ei), trace)
+    net = hip_static()
+    xs = x.to(DEV)[:, 1:]
+    from dgnn_amd.graph import plan_for
+    plan = plan_for(ei.to(DEV), n, n)
+    h = xs
+    t = dict(trace)
+    for i in range(4):
+        h = net._eval_layers_one(i, h, ea.to(DEV), plan)
+        assert rel_err(h, t["relu%d" % i]) < 1e-5, i
+    logits = net.inference_layer(Config(x=x.to(DEV), edge_attr=ea.to(DEV), edge_index=ei.to(DEV)))
+    assert (logits.double().cpu() - ref).abs().max().item() <= TOL_LOGIT * max(1.0, ref.abs().max().item() / 8)
+
+
+def test_train_forward_backward_golden_f3():
+    g = gold("static_f3_train_blocks.npz")
+    net = hip_static(train=True)
+    d = f3_data(g)
+    data = Config(all=Config(x=d.all.x.to(DEV), edge_attr=d.all.edge_attr.to(DEV)), batch_n_id=d.batch_n_id.to(DEV),
+                  batch_adjs=[(a.to(DEV), e.to(DEV), s) for a, e, s in d.batch_adjs])
+    logits = net(data)
+    assert np.abs(logits.detach().cpu().numpy() - g["logits"]).max() <= TOL_LOGIT
+    (logits * torch.from_numpy(g["G"]).to(DEV)).sum().backward()
+    for k, p in net.named_parameters():
+        ref = g["grad." + k]
+        err = np.abs(p.grad.cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-30)
+        assert err < 2e-4, (k, err)
+    for k, b in net.named_buffers():
+        ref = g["buf." + k]
+        err = np.abs(b.cpu().numpy().astype(np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30)
+        assert err < 1e-5, (k, err)
+
+
+def test_batch_layer_and_layer_batch_schedules():
+    g = gold("static_f3_train_blocks.npz")
+    gb = gold("static_f3_batch_layer.npz")
+    net = hip_static()
+    d = f3_data(g)
+    data_all = Config(x=d.all.x.to(DEV), edge_attr=d.all.edge_attr.to(DEV))
+    loader = [(len(g["batch"]), d.batch_n_id, d.batch_adjs)]
+    xo = net.inference_batch_layer(data_all, loader)
+    assert np.abs(xo[torch.from_numpy(g["batch"]).to(DEV)].cpu().numpy() - gb["logits_rows"]).max() <= TOL_LOGIT
+    # layer-major schedule on 1-hop blocks covering the whole graph == whole-graph inference_layer
+    from oracle.pyg_semantics import neighbor_sampler_full
+    ei = g["adjacencies"].T.astype(np.int64)
+    n = g["x"].shape[0]
+    loader1 = []
+    for s in range(0, n, 512):
+        b = np.arange(s, min(n, s + 512))
+        n_id, adjs = neighbor_sampler_full(ei, n, b, 1)
+        a, e, size = adjs[0]
+        loader1.append((len(b), torch.from_numpy(n_id), (torch.from_numpy(a), torch.from_numpy(e), size)))
+    full = net.inference_layer(Config(x=data_all.x, edge_attr=data_all.edge_attr, edge_index=torch.from_numpy(ei).to(DEV)))
+    lb = net.inference_layer_batch(data_all, loader1)
+    assert (full - lb).abs().max().item() <= TOL_LOGIT
+
+
+def test_other_widths_random_init():
+    """[64,128,256,512] (configs/aerial.yaml:57) exercises the non-fused path and wide channel tiling."""
+    from oracle.static_edge_filters import SurfaceNet as ONet
+    from dgnn_amd.synthetic import delaunay_tet_graph
+    convs = (64, 128, 256, 512)
+    torch.manual_seed(0)
+    onet = ONet(reconbench_pretrained(device="cpu", convs=convs)).eval()
+    net = hip_static(convs=convs, sd=onet.state_dict())
+    adj, _, _ = delaunay_tet_graph(500, seed=8)
+    n = adj.shape[0] // 4
+    g = torch.Generator().manual_seed(2)
+    x, ea = torch.randn(n, 29, generator=g), torch.randn(4 * n, 20, generator=g)
+    ei = torch.from_numpy(adj.T.astype(np.int64))
+    with torch.no_grad():
+        ref = onet.inference_layer(Config(x=x, edge_attr=ea, edge_index=ei))
+    logits = net.inference_layer(Config(x=x.to(DEV), edge_attr=ea.to(DEV), edge_index=ei.to(DEV)))
+    assert (logits.cpu() - ref).abs().max().item() <= TOL_LOGIT
