@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Benchmark of the dgnn hot path on MI355X: whole-graph in/out classification of a synthetic Delaunay
+tetrahedron graph (SurfaceNet.inference_layer equivalent: 4 x [edge-filtered SAGE conv + BN(eval) +
+ReLU] + decoder -> logits [N,2]), fp32, shipped kf96 weights.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over the graph, inputs resident in HBM in the reference's layout
+(x [N,29] fp32, edge_attr [4N,20] fp32, edge_index [2,4N] int64).  The step INCLUDES building the
+graph plan (stable destination sort) and staging edge_attr into plan order, because the reference
+takes a raw edge_index on every call.  N>1: the scene has gpus x 150k points and is partitioned
+spatially, one part per rank, with an RCCL halo exchange of boundary-tet features before conv
+layers 1..3 (weak scaling: ~1M tets per GPU).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_TET = 5048          # algorithmic HBM bytes per tet, whole path, fp32
+LAYER_BYTES = {(28, 64): 704, (64, 128): 1104, (128, 128): 1360}  # per tet, per fused layer launch
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def load_weights():
+    w = np.load(os.path.join(ROOT, "tests", "golden", "kf96_weights.npz"))
+    return {k: torch.from_numpy(w[k]) for k in w.files}
+
+
+def make_scene(points, seed):
+    from dgnn_amd.synthetic import delaunay_tet_graph
+    adj, cent, _ = delaunay_tet_graph(points, seed)
+    n = adj.shape[0] // 4
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(n, 29, generator=g)
+    ea = torch.randn(4 * n, 20, generator=g)
+    return adj, cent, x, ea
+
+
+def cpu_baseline(points, threads):
+    """Times the CPU oracle (plain-PyTorch restatement of the reference path) on a bounded sample of the
+    same workload: same generator, `points` points (~6.7 tets per point)."""
+    from dgnn_amd.config import Config, reconbench_pretrained
+    from oracle.static_edge_filters import SurfaceNet as OracleNet
+    adj, _, x, ea = make_scene(points, 0)
+    n = adj.shape[0] // 4
+    net = OracleNet(reconbench_pretrained(device="cpu"))
+    net.load_state_dict(load_weights())
+    net.eval()
+    data = Config(x=x, edge_attr=ea, edge_index=torch.from_numpy(adj.T.astype(np.int64)))
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    times = []
+    with torch.no_grad():
+        net.inference_layer(data)
+        for _ in range(3):
+            t0 = time.perf_counter()
+            net.inference_layer(data)
+            times.append(time.perf_counter() - t0)
+    torch.set_num_threads(old)
+    return n / float(np.median(times)), n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--points", type=int, default=150000, help="Delaunay points per GPU (150000 -> 1 010 078 tets)")
+    ap.add_argument("--cpu-points", type=int, default=30000, help="sample size of the CPU baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cached-plan", action="store_true", help="reuse the graph plan across steps (reported, not the metric)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    from dgnn_amd import ops
+    from dgnn_amd.config import Config, reconbench_pretrained
+    from dgnn_amd.graph import GraphPlan
+    from dgnn_amd.learning.surfaceNetStaticEdgeFilters import SurfaceNet
+
+    net = SurfaceNet(reconbench_pretrained(device=dev))
+    net.load_state_dict(load_weights())
+    net = net.to(dev).eval()
+
+    if world == 1:
+        adj, _, x, ea = make_scene(args.points, 0)
+        n_total = n_local = adj.shape[0] // 4
+        data = Config(x=x.to(dev), edge_attr=ea.to(dev), edge_index=torch.from_numpy(adj.T.astype(np.int64)).to(dev))
+        cached = {}
+
+        def step():
+            plan = cached.get("p")
+            if plan is None:
+                plan = GraphPlan(data.edge_index, n_local, n_local)
+                if args.cached_plan:
+                    cached["p"] = plan
+            return net.inference_layer(data, plan=plan)
+        workload = "synthetic Delaunay tet graph, %d points -> N=%d tets, E=%d, whole-graph inference_layer" % (args.points, n_total, 4 * n_total)
+    else:
+        from dgnn_amd.partition import PartitionedScene
+        scene = PartitionedScene.build_synthetic(args.points * world, 0, rank, world, dev)
+        n_total, n_local = scene.n_total, scene.n_own
+
+        def step():
+            return scene.inference_layer(net)
+        workload = "synthetic Delaunay scene, %d points -> N=%d tets, %d-way spatial partition + RCCL halo exchange" % (args.points * world, n_total, world)
+
+    def sync():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = n_total * args.steps / dt
+
+    # ---- roofline of the dominant kernel (fused 128->128 layer), HIP events on the launch stream ----
+    roof = None
+    breakdown = {}
+    if world == 1:
+        plan = GraphPlan(data.edge_index, n_local, n_local)
+        xs = data.x[:, 1:]
+        ea_sorted = plan.sorted_edge_attr(data.edge_attr)
+        # per-kernel timing: replay each layer 10x between events
+        def timed(fn, reps=10):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+        breakdown["plan_ms"] = timed(lambda: GraphPlan(data.edge_index, n_local, n_local), 5)
+        breakdown["edge_sort_ms"] = timed(lambda: ops.gather_rows(data.edge_attr, plan.eid), 5)
+        h = xs
+        for i in range(4):
+            conv = net.convs[i][0]
+            scale, shift = net._fold(net.convs[i][1], conv.lin_j.out_features, dev)
+            hin = h
+            if ops.fused_layer_supported(hin.size(1), conv.lin_j.out_features, 20):
+                fn = lambda hin=hin, conv=conv, scale=scale, shift=shift: ops.sage_layer_fused_fwd(
+                    plan.rowptr, plan.src, n_local, hin, ea_sorted, conv.lin_e.weight, conv.lin_e.bias, conv.lin_j.weight,
+                    conv.lin_j.bias, conv.lin_i.weight, scale, shift, True)
+            else:
+                fn = lambda hin=hin, i=i: net._eval_layers_one(i, hin, data.edge_attr, plan)
+            breakdown["layer%d_ms" % i] = timed(fn)
+            h = fn()
+        breakdown["decoder_ms"] = timed(lambda: net._eval_decoder(h))
+        dom_ms = breakdown["layer3_ms"]
+        algo = LAYER_BYTES[(128, 128)] * n_local
+        achieved = algo / (dom_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "k_sage_fused<128,128> (layer 3)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(dom_ms, 4),
+                "whole_path_frac": round(value * BYTES_PER_TET / 1e9 / HBM_PEAK_GBS, 4)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cores = os.cpu_count() or 1
+        v, n_s = cpu_baseline(args.cpu_points, cores)
+        cpu = {"value": round(v, 1), "unit": "tets/s", "cores": cores, "kind": "port",
+               "sample": "oracle (PyTorch-CPU restatement of inference_layer), same generator at %d points -> %d tets, "
+                         "1 warm-up + median of 3" % (args.cpu_points, n_s)}
+
+    if rank == 0:
+        out = {
+            "metric": "tetrahedra/sec (in/out classified), 1M-tet graph at 1/2/4/8 MI355X",
+            "value": round(value, 1), "unit": "tets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "tets_per_gpu": n_local, "weights": "kf96 checkpoint [64,128,128,128]",
+                       "plan_in_step": not args.cached_plan, "breakdown_ms": {k: round(v, 4) for k, v in breakdown.items()}},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

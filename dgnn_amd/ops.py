@@ -228,7 +228,7 @@ def fused_layer_supported(c_in: int, c_out: int, f_e: int) -> bool:
     return f_e == 20 and c_in <= 128 and c_out in (64, 128) and FUSED_ENABLED
 
 
-FUSED_ENABLED = False  # flipped on when csrc/fused.hip carries the real kernel
+FUSED_ENABLED = True
 
 
 def sage_layer_fused_fwd(rowptr, src, n_dst, x_src, edge_attr_sorted, We, be, Wj, bj, Wi, scale, shift, relu):

@@ -232,10 +232,14 @@ def test_train_forward_backward_golden_f3():
     logits = net(data)
     assert np.abs(logits.detach().cpu().numpy() - g["logits"]).max() <= TOL_LOGIT
     (logits * torch.from_numpy(g["G"]).to(DEV)).sum().backward()
+    # biases feeding a train-mode BatchNorm have an analytically zero gradient (the reference holds
+    # rounding noise there), so the error is measured against the tensor's own scale plus a floor
+    # tied to the largest gradient in the model
+    gmax = max(np.abs(g[k]).max() for k in g.files if k.startswith("grad."))
     for k, p in net.named_parameters():
         ref = g["grad." + k]
-        err = np.abs(p.grad.cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-30)
-        assert err < 2e-4, (k, err)
+        err = np.abs(p.grad.cpu().numpy() - ref).max()
+        assert err <= 2e-4 * np.abs(ref).max() + 2e-6 * gmax, (k, err, np.abs(ref).max(), gmax)
     for k, b in net.named_buffers():
         ref = g["buf." + k]
         err = np.abs(b.cpu().numpy().astype(np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30)
