@@ -79,3 +79,28 @@ def check_four_regular(adj: np.ndarray) -> bool:
     fwd = np.sort(src * n + dst)
     rev = np.sort(dst * n + src)
     return bool(np.array_equal(fwd, rev))
+
+
+def hashed_normal(rows, ncols: int, seed: int = 0, device="cpu"):
+    """Deterministic N(0,1) float32 tensor [len(rows), ncols] where entry (i, c) depends only on
+    (rows[i], c, seed): splitmix64 hash -> Box-Muller, evaluated with torch integer ops on `device`.
+    Lets every rank of a partitioned scene materialise exactly the feature rows it owns (or holds
+    as halo) without generating the whole scene, while all ranks agree on shared rows."""
+    import torch
+
+    def s64(v):  # python uint64 constant -> wrapped int64
+        v &= (1 << 64) - 1
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    def lsr(z, k):  # logical shift right on int64
+        return (z >> k) & ((1 << (64 - k)) - 1)
+
+    r = torch.as_tensor(np.asarray(rows, dtype=np.int64) if not isinstance(rows, torch.Tensor) else rows, device=device).to(torch.int64)
+    z = r.reshape(-1, 1) * ncols + torch.arange(ncols, dtype=torch.int64, device=device).reshape(1, -1)
+    z = z + s64(seed * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019)
+    z = (z ^ lsr(z, 30)) * s64(0xBF58476D1CE4E5B9)
+    z = (z ^ lsr(z, 27)) * s64(0x94D049BB133111EB)
+    z = z ^ lsr(z, 31)
+    u1 = (lsr(z, 40).to(torch.float32) + 0.5) / float(1 << 24)
+    u2 = ((z & 0xFFFFFF).to(torch.float32) + 0.5) / float(1 << 24)
+    return torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(6.283185307179586 * u2)
