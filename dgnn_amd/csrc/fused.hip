@@ -7,56 +7,92 @@
 // (phi, x_j, x_j*phi: 6 GB at 1M tets / C=128); this kernel reads x, edge_attr and the indices once
 // and writes y once (1360 B/tet at 128->128).
 //
-// Work decomposition (512-thread workgroup = 8 wavefronts, one workgroup per CU, persistent):
-//   * wavefronts 4..7  PRODUCERS (VALU + memory): each owns TILE/4 destination tets of the tile.
-//     All loads of the tile are issued up front -- the 4 gathered source rows and the own row of every
-//     tet (one coalesced row per wave instruction, CPL floats per lane) and the tile's edge-attribute
-//     block (contiguous, edges are in plan order) -- so one HBM round trip covers the tile.  The
-//     filter phi = We.A + be is 20 FMAs per channel with We held in registers and A broadcast from LDS;
-//     products and the in-order 4-term sum reproduce the reference's scatter order.  The mean row and
-//     the tet's own row are written side by side into the LDS A-tile [TILE][2*CIN_PAD].
-//   * wavefronts 0..3  CONSUMERS (matrix cores): [a | x_i] . [Wj | Wi]^T on v_mfma_f32_32x32x2_f32.
-//     Each consumer keeps its 32 output columns of the concatenated weight matrix in REGISTERS for the
-//     whole launch (K/2 VGPRs), so the only per-tile LDS traffic is one ds_read_b128 of the A-tile per
-//     4 MFMAs.  BatchNorm(eval) scale/shift and ReLU are applied on the accumulators and the tile is
-//     stored straight to HBM (128-byte row segments per half-wave).
-//   * the A-tile is double buffered; producers fill tile t+1 while consumers multiply tile t; one
-//     workgroup barrier per tile.  fp32 MFMA runs at the fp32 vector rate (MI355X guide), so the matrix
-//     pipe is the critical resource and VALU/memory work hides beside it.
-//   * tile -> workgroup map is XCD-aware: workgroup b runs on XCD b%8 (observed placement; used for L2
-//     locality only), and each XCD walks one contiguous eighth of the tets so that gathered neighbour
-//     rows are mostly resident in that XCD's L2.
+// Measured facts that shape the design (tools/ubench_pipes.hip, tools/ubench_interleave.hip on MI355X):
+// fp32 MFMA and fp32 VALU work on one SIMD do NOT overlap -- their times add, from different waves and
+// from one wave alike -- and a wave that wants VALU issue while another wave streams dependent MFMAs
+// advances about one instruction per MFMA.  So wave specialisation (gather waves beside MFMA waves)
+// only starves the gather waves; what matters is (1) every SIMD always has VALU or MFMA work, (2) HBM
+// latency sits behind the MFMA phase, (3) one barrier per tile.
+//
+// Structure (512-thread workgroup = 8 wavefronts = 2 per SIMD, one workgroup per CU, persistent).
+// Every wavefront runs the same two-phase loop over the workgroup's tiles of TILE destination tets:
+//   P  gather/filter phase (VALU): the wave owns TILE/8 tets.  Their 4 neighbour rows, own rows and the
+//      contiguous edge-attribute block were requested one tile ahead, so they are (mostly) resident.
+//      phi = We.A + be is 20 FMAs per channel with We in registers and A broadcast from a private LDS
+//      strip; products and the in-order 4-term sum reproduce the reference's scatter order.  The mean
+//      row and the tet's own row go side by side into the LDS A-tile [TILE][2*CIN_PAD].  Then the wave
+//      issues all loads of its tets of the NEXT tile (indices were prefetched as scalars) and hits
+//      the workgroup barrier.
+//   C  matrix phase (MFMA): [a | x_i] . [Wj | Wi]^T on v_mfma_f32_32x32x2_f32.  The 8 waves split the
+//      tile as (32-column slice) x (K half: the `a` half with Wj, the `x_i` half with Wi) [x row group],
+//      so a wave keeps only CIN_PAD/2 weight VGPRs for the whole launch and streams its A operand from
+//      LDS with one ds_read_b128 per 4 MFMAs.  The two K-halves exchange half of their accumulators
+//      through LDS; each finishes 8 of the 16 accumulator rows (bias, BatchNorm scale/shift, ReLU) and
+//      stores them -- one tile later, right after the next barrier, so that one barrier per tile
+//      orders both the A-tile hand-off and the partial-sum exchange.
+// HBM latency of tile t+1 is therefore covered by the whole matrix phase of tile t.
+//
+// tile -> workgroup map is XCD-aware: workgroup b runs on XCD b%8 (observed placement; used for L2
+// locality only) and each XCD walks one contiguous eighth of the tets, so gathered neighbour rows are
+// mostly resident in that XCD's L2.
 //
 // LDS A-tile row stride is K+4 floats: the 16-lane groups of ds_read_b128 then hit 16 distinct 16-byte
 // slots (conflict free) and rows stay 16-byte aligned.
 #include "common.h"
 
+// Optional phase tracing (debug): workgroup 0 stamps wall_clock64() at phase boundaries into a caller
+// buffer registered with dgnn_debug_trace_buffer(); NULL (default) disables it.
+static int64_t* g_trace_buf = nullptr;
+static int64_t g_trace_cap = 0;
+extern "C" int dgnn_debug_trace_buffer(int64_t* dev_buf, int64_t n) {
+    g_trace_buf = dev_buf;
+    g_trace_cap = n;
+    return DGNN_OK;
+}
+
 namespace {
 
 constexpr int FE = 20;
+constexpr int NWAVE = 8;
+
+// slot layout: trace[(it * 12 + wave) * 8 + phase]
+__device__ __forceinline__ void stamp(int64_t* trace, int64_t cap, int64_t it, int w, int phase) {
+    if (trace && blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
+        const int64_t i = (it * 12 + w) * 8 + phase;
+        if (i < cap) trace[i] = (int64_t)wall_clock64();
+    }
+}
 
 template <int CIN_PAD, int COUT>
 struct FusedCfg {
     static constexpr int K = 2 * CIN_PAD;
-    static constexpr int NSLICE = COUT / 32;  // column slices of 32
-    static constexpr int RG = 4 / NSLICE;     // row groups per tile
-    static constexpr int TILE = 32 * RG;      // destination tets per tile
+    static constexpr int NSLICE = COUT / 32;           // column slices of 32
+    static constexpr int RG = NWAVE / (2 * NSLICE);    // row groups per tile (K is split in 2)
+    static constexpr int TILE = 32 * RG;               // destination tets per tile
     static constexpr int LDA = K + 4;
-    static constexpr int TPW = TILE / 4;                  // tets per producer wave
-    static constexpr int CPL = CIN_PAD > 64 ? 2 : 1;      // channels per lane in the producer
-    static constexpr int EA_FLOATS = TPW * 4 * FE;        // edge-attribute floats per producer wave
-    static constexpr int EA_PAD = (EA_FLOATS + 255) / 256 * 256;
-    static constexpr int SMEM_FLOATS = 2 * TILE * LDA + 4 * EA_PAD;
+    static constexpr int TPW = TILE / NWAVE;           // tets gathered per wave
+    static constexpr int CPL = CIN_PAD > 64 ? 2 : 1;   // channels per lane in the gather phase
+    static constexpr int NQ = TPW * 4;                 // neighbour rows per wave
+    static constexpr int EA_FLOATS = NQ * FE;          // edge-attribute floats per wave and tile
+    static constexpr int NV4 = EA_FLOATS / 4;
+    static constexpr int NEV = (NV4 + 63) / 64;        // float4 loads per lane for the attribute block
+    static constexpr int EA_PAD = NEV * 256;
+    static constexpr int S_STEPS = CIN_PAD / 8;        // k-steps of 8 per K half
+    static constexpr int RED_FLOATS = NWAVE * 8 * 64;  // one partial-sum exchange buffer
+    static constexpr int SMEM_FLOATS = 2 * TILE * LDA + NWAVE * EA_PAD + 2 * RED_FLOATS;
 };
 
+// Row fragment load.  The caller passes an address that is valid for every lane (inactive lanes are
+// clamped to channel 0), so the load is unconditional -- no exec-mask branch around it -- and inactive
+// lanes are zeroed by a select at the point of use.
 template <int CPL>
-__device__ __forceinline__ void ld_row(float (&v)[CPL], const float* p, bool on) {
+__device__ __forceinline__ void ld_row(float (&v)[CPL], const float* p) {
     if (CPL == 2) {
-        float2 t = on ? *reinterpret_cast<const float2*>(p) : make_float2(0.f, 0.f);
+        const float2 t = *reinterpret_cast<const float2*>(p);
         v[0] = t.x;
         v[CPL - 1] = t.y;
     } else {
-        v[0] = on ? *p : 0.f;
+        v[0] = *p;
     }
 }
 
@@ -66,12 +102,14 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
              const float* __restrict__ x, int64_t ldx, int c_in, const float* __restrict__ ea, int64_t lde,
              const float* __restrict__ We, const float* __restrict__ be, const float* __restrict__ Wj,
              const float* __restrict__ bj, const float* __restrict__ Wi, const float* __restrict__ scale,
-             const float* __restrict__ shift, int relu, float* __restrict__ out, int64_t ldo, int64_t ntiles) {
+             const float* __restrict__ shift, int relu, float* __restrict__ out, int64_t ldo, int64_t ntiles,
+             int64_t* __restrict__ trace, int64_t trace_cap) {
     using C = FusedCfg<CIN_PAD, COUT>;
-    constexpr int K = C::K, LDA = C::LDA, TILE = C::TILE, TPW = C::TPW, CPL = C::CPL;
+    constexpr int LDA = C::LDA, TILE = C::TILE, TPW = C::TPW, CPL = C::CPL, NQ = C::NQ, NEV = C::NEV, NV4 = C::NV4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const abuf = smem;                       // [2][TILE][LDA]
-    float* const eabuf = smem + 2 * TILE * LDA;     // [4 producer waves][EA_PAD]
+    float* const abuf = smem;                                  // [2][TILE][LDA]
+    float* const eabuf = smem + 2 * TILE * LDA;                // [NWAVE][EA_PAD]
+    float* const redbuf = eabuf + NWAVE * C::EA_PAD;           // [2][NWAVE][8][64]
 
     const int lane = lane_id(), w = wave_id_uniform();
     const int h = lane >> 5, l31 = lane & 31;
@@ -80,189 +118,254 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
     const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wg_per_xcd = (nwg + 7 - xcd) >> 3;
     const int64_t per = (ntiles + 7) / 8;
     const int64_t t_lo = xcd * per, t_hi = min(ntiles, t_lo + per);
-    // number of tiles this workgroup processes (identical trip count for all 8 waves -> barriers match)
-    int64_t my_n = 0;
+    int64_t my_n = 0;  // tiles of this workgroup (same for all 8 waves -> barrier counts match)
     if (t_lo + slot < t_hi) my_n = (t_hi - t_lo - slot + wg_per_xcd - 1) / wg_per_xcd;
 
-    if (w < 4) {
-        // ------------------------------------------------------------------ consumer (MFMA)
-        const int cs = w % C::NSLICE, rg = w / C::NSLICE;
-        const int col = cs * 32 + l31;
-        float wr[K / 2];
+    // ---- matrix-phase role: (column slice cs, K half kh, row group rg)
+    const int cs = w % C::NSLICE, kh = (w / C::NSLICE) & 1, rg = w / (2 * C::NSLICE);
+    const int col = cs * 32 + l31;
+    const int partner = w ^ C::NSLICE;  // same cs and rg, other K half
+    float wr[C::S_STEPS * 4];
+    {
+        const float* Wsrc = kh ? Wi : Wj;
 #pragma unroll
-        for (int S = 0; S < K / 8; ++S) {
+        for (int S = 0; S < C::S_STEPS; ++S) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int k = 8 * S + 4 * h + j;  // k-permutation shared with the A-tile read below
-                float v = 0.f;
-                if (k < CIN_PAD) {
-                    if (k < c_in) v = Wj[(int64_t)col * c_in + k];
-                } else {
-                    if (k - CIN_PAD < c_in) v = Wi[(int64_t)col * c_in + (k - CIN_PAD)];
-                }
-                wr[S * 4 + j] = v;
+                const int k = 8 * S + 4 * h + j;  // k-permutation shared with the A-tile read
+                const float v = Wsrc[(int64_t)col * c_in + (k < c_in ? k : 0)];
+                wr[S * 4 + j] = k < c_in ? v : 0.f;
             }
         }
-        const float bb = bj ? bj[col] : 0.f;
-        const float sc = scale ? scale[col] : 1.f;
-        const float sh = scale ? shift[col] : 0.f;
-        const bool has_scale = scale != nullptr;
+    }
+    const float bb = bj ? bj[col] : 0.f;
+    const float sc = scale ? scale[col] : 1.f;
+    const float sh = scale ? shift[col] : 0.f;
+    const bool has_scale = scale != nullptr;
 
-        for (int64_t it = 0; it < my_n; ++it) {
-            const int64_t tile = t_lo + slot + it * wg_per_xcd;
-            __syncthreads();  // tile `it` is complete in abuf[it&1]
-            const float* A = abuf + (it & 1) * TILE * LDA + (rg * 32 + l31) * LDA + 4 * h;
-            f32x16 acc;
+    // ---- gather-phase role: this wave owns tets [w*TPW, (w+1)*TPW) of every tile
+    const int c0 = lane * CPL;
+    const bool on = c0 < c_in;    // c_in is a multiple of CPL (host-checked)
+    const int c0l = on ? c0 : 0;  // clamped channel offset: loads stay in bounds for inactive lanes
+    float wl[CPL][FE], bl[CPL];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int j = 0; j < CPL; ++j) {
+        const float bv = be[c0l + j];
+        bl[j] = on ? bv : 0.f;
 #pragma unroll
-            for (int S = 0; S < K / 8; ++S) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(A + 8 * S);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], wr[S * 4 + j], acc, 0, 0, 0);
-            }
-            const int64_t row0 = tile * TILE + rg * 32 + 4 * h;
-            float* o = out + row0 * ldo + col;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = (r & 3) + 8 * (r >> 2);
-                if (row0 + rr < n_dst) {
-                    float v = acc[r] + bb;
-                    if (has_scale) v = __fmaf_rn(v, sc, sh);
-                    if (relu) v = fmaxf(v, 0.f);
-                    o[(int64_t)rr * ldo] = v;
-                }
-            }
+        for (int f = 0; f < FE; ++f) {
+            const float wv = We[(int64_t)(c0l + j) * FE + f];
+            wl[j][f] = on ? wv : 0.f;
         }
-        __syncthreads();  // matches the producers' final barrier
-    } else {
-        // ------------------------------------------------------------------ producer (gather + filter + mean)
-        const int pw = w - 4;
-        const int c0 = lane * CPL;
-        const bool on = c0 < c_in;  // c_in is a multiple of CPL (host-checked)
-        float wl[CPL][FE], bl[CPL];
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-            bl[j] = on ? be[c0 + j] : 0.f;
-#pragma unroll
-            for (int f = 0; f < FE; ++f) wl[j][f] = on ? We[(int64_t)(c0 + j) * FE + f] : 0.f;
-        }
-        float* const myea = eabuf + pw * C::EA_PAD;
+    }
+    float* const myea = eabuf + w * C::EA_PAD;
 
-        for (int64_t it = 0; it <= my_n; ++it) {
-            if (it < my_n) {
-                const int64_t tile = t_lo + slot + it * wg_per_xcd;
-                const int64_t i0 = tile * TILE + pw * TPW;  // first tet of this wave
-                float* const Arow = abuf + (it & 1) * TILE * LDA + (pw * TPW) * LDA;
-                // ---- indices (wave-uniform -> scalar loads)
-                int beg[TPW + 1];
-                bool regular = (i0 + TPW <= n_dst);
-                if (regular) {
+    // state of the tile in flight
+    float xd[TPW][CPL], xr[NQ][CPL];
+    f32x4 ev[NEV];
+    bool regular = false;        // loads for the current tile are in flight (4-regular fast path)
+    // Index prefetch runs two tiles deep so that no scalar round trip sits in front of the row loads:
+    //   beg2  rowptr entries of tile it+2 (requested during P(it))
+    //   beg1  rowptr entries of tile it+1 (arrived during P(it-1)),  sidx1 its 4*TPW source ids
+    int beg1[TPW + 1], beg2[TPW + 1], sidx1[NQ];
+    bool ok1 = false, ok2 = false;  // tile exists, is complete and (for ok1) 4-regular
+
+    auto tile_of = [&](int64_t it) { return t_lo + slot + it * wg_per_xcd; };
+    auto load_rowptr = [&](int64_t it, int (&b)[TPW + 1]) -> bool {
+        if (it >= my_n) return false;
+        const int64_t i0 = tile_of(it) * TILE + w * TPW;
+        if (i0 + TPW > n_dst) return false;
 #pragma unroll
-                    for (int r = 0; r <= TPW; ++r) beg[r] = rowptr[i0 + r];
+        for (int r = 0; r <= TPW; ++r) b[r] = rowptr[i0 + r];
+        return true;
+    };
+    // beg1 is resident: decide regularity and request the source ids (wave-uniform -> scalar loads)
+    auto load_src = [&]() {
+        if (ok1) {
 #pragma unroll
-                    for (int r = 0; r < TPW; ++r) regular = regular && (beg[r + 1] - beg[r] == 4);
+            for (int r = 0; r < TPW; ++r) ok1 = ok1 && (beg1[r + 1] - beg1[r] == 4);
+        }
+        if (ok1) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) sidx1[q] = src[beg1[0] + q];
+        }
+    };
+    // issue every load of this wave's tets of tile `it` (uses beg1/sidx1)
+    auto issue_loads = [&](int64_t it) {
+        regular = ok1;
+        if (regular) {
+            const int64_t i0 = tile_of(it) * TILE + w * TPW;
+            const float* eab = ea + (int64_t)beg1[0] * lde;
+#pragma unroll
+            for (int q = 0; q < NEV; ++q) {
+                const int idx = q * 64 + lane;
+                ev[q] = *reinterpret_cast<const f32x4*>(eab + 4 * (idx < NV4 ? idx : 0));
+            }
+#pragma unroll
+            for (int r = 0; r < TPW; ++r) ld_row<CPL>(xd[r], x + (i0 + r) * ldx + c0l);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) ld_row<CPL>(xr[q], x + (int64_t)sidx1[q] * ldx + c0l);
+        }
+    };
+    // shift the index pipeline by one tile: (beg2 -> beg1, request sidx1), request beg2 for tile it+2
+    auto advance_idx = [&](int64_t it_next) {
+        ok1 = ok2;
+#pragma unroll
+        for (int r = 0; r <= TPW; ++r) beg1[r] = beg2[r];
+        load_src();
+        ok2 = load_rowptr(it_next + 1, beg2);
+    };
+
+    ok1 = load_rowptr(0, beg1);
+    load_src();
+    ok2 = load_rowptr(1, beg2);
+    issue_loads(0);
+    float mine[8];  // own half of the accumulators of the previous tile, finished after the next barrier
+#pragma unroll
+    for (int r = 0; r < 8; ++r) mine[r] = 0.f;
+
+    for (int64_t it = 0; it <= my_n; ++it) {
+        if (it < my_n) {
+            // ================================================================ P: gather / filter / mean
+            const int64_t i0 = tile_of(it) * TILE + w * TPW;
+            float* const Arow = abuf + (it & 1) * TILE * LDA + (w * TPW) * LDA;
+            stamp(trace, trace_cap, it, w, 0);
+            const bool was_regular = regular;
+            if (was_regular) {
+                // attribute block -> this wave's private LDS strip (read back as broadcasts)
+#pragma unroll
+                for (int q = 0; q < NEV; ++q) {
+                    const int idx = q * 64 + lane;
+                    if (idx < NV4) *reinterpret_cast<f32x4*>(myea + 4 * idx) = ev[q];
                 }
-                if (regular) {
-                    const int e0 = beg[0];
-                    // ---- issue every load of this wave's TPW tets: edge-attribute block, own rows, 4 neighbours
-                    constexpr int NV4 = C::EA_FLOATS / 4;  // float4 count of the attribute block (lde == FE here)
-                    const float* eab = ea + (int64_t)e0 * lde;
-                    f32x4 ev[(NV4 + 63) / 64];
+            }
+            advance_idx(it + 1);  // index scalar loads fly under the VALU work below
+            stamp(trace, trace_cap, it, w, 1);
+            if (was_regular) {
 #pragma unroll
-                    for (int q = 0; q < (NV4 + 63) / 64; ++q) {
-                        const int idx = q * 64 + lane;
-                        ev[q] = idx < NV4 ? *reinterpret_cast<const f32x4*>(eab + 4 * idx) : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int r = 0; r < TPW; ++r) {
+                    float acc[CPL];
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) acc[j] = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float* ap = myea + (r * 4 + e) * FE;
+                        float A[FE];
+#pragma unroll
+                        for (int f = 0; f < FE; f += 4) {
+                            const f32x4 t = *reinterpret_cast<const f32x4*>(ap + f);
+                            A[f] = t[0]; A[f + 1] = t[1]; A[f + 2] = t[2]; A[f + 3] = t[3];
+                        }
+#pragma unroll
+                        for (int j = 0; j < CPL; ++j) {
+                            float p = bl[j];
+#pragma unroll
+                            for (int f = 0; f < FE; ++f) p = __fmaf_rn(wl[j][f], A[f], p);
+                            acc[j] = __fadd_rn(acc[j], __fmul_rn(on ? xr[r * 4 + e][j] : 0.f, p));
+                        }
                     }
-                    int sidx[TPW * 4];
-#pragma unroll
-                    for (int q = 0; q < TPW * 4; ++q) sidx[q] = src[e0 + q];
-                    float xd[TPW][CPL], xr[TPW * 4][CPL];
-#pragma unroll
-                    for (int r = 0; r < TPW; ++r) ld_row<CPL>(xd[r], x + (i0 + r) * ldx + c0, on);
-#pragma unroll
-                    for (int q = 0; q < TPW * 4; ++q) ld_row<CPL>(xr[q], x + (int64_t)sidx[q] * ldx + c0, on);
-                    // attribute block -> this wave's LDS staging area (read back as broadcasts)
-#pragma unroll
-                    for (int q = 0; q < (NV4 + 63) / 64; ++q) {
-                        const int idx = q * 64 + lane;
-                        if (idx < NV4) *reinterpret_cast<f32x4*>(myea + 4 * idx) = ev[q];
+                    float* dst = Arow + r * LDA;
+                    if (CPL == 2) {
+                        if (lane < CIN_PAD / 2) {
+                            *reinterpret_cast<float2*>(dst + c0) = make_float2(acc[0] * 0.25f, acc[CPL - 1] * 0.25f);
+                            *reinterpret_cast<float2*>(dst + CIN_PAD + c0) =
+                                make_float2(on ? xd[r][0] : 0.f, on ? xd[r][CPL - 1] : 0.f);
+                        }
+                    } else {
+                        if (lane < CIN_PAD) {
+                            dst[c0] = acc[0] * 0.25f;
+                            dst[CIN_PAD + c0] = on ? xd[r][0] : 0.f;
+                        }
                     }
-                    // ---- filter, multiply, in-order mean; write [a | x_i] rows of the A-tile
+                }
+            } else {
+                // generic path: any in-degree, tile tail; one edge at a time (rare)
+                for (int r = 0; r < TPW; ++r) {
+                    const int64_t i = i0 + r;
+                    float acc[CPL], xdv[CPL];
 #pragma unroll
-                    for (int r = 0; r < TPW; ++r) {
-                        float acc[CPL];
-#pragma unroll
-                        for (int j = 0; j < CPL; ++j) acc[j] = 0.f;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float* ap = myea + (r * 4 + e) * FE;
-                            float A[FE];
-#pragma unroll
-                            for (int f = 0; f < FE; f += 4) {
-                                const f32x4 t = *reinterpret_cast<const f32x4*>(ap + f);
-                                A[f] = t[0]; A[f + 1] = t[1]; A[f + 2] = t[2]; A[f + 3] = t[3];
-                            }
+                    for (int j = 0; j < CPL; ++j) acc[j] = xdv[j] = 0.f;
+                    if (i < n_dst) {
+                        const int b = rowptr[i], e_end = rowptr[i + 1];
+                        ld_row<CPL>(xdv, x + i * ldx + c0l);
+                        for (int k = b; k < e_end; ++k) {
+                            const int s = src[k];
+                            const float* ar = ea + (int64_t)k * lde;
+                            float xv[CPL];
+                            ld_row<CPL>(xv, x + (int64_t)s * ldx + c0l);
 #pragma unroll
                             for (int j = 0; j < CPL; ++j) {
                                 float p = bl[j];
 #pragma unroll
-                                for (int f = 0; f < FE; ++f) p = __fmaf_rn(wl[j][f], A[f], p);
-                                acc[j] = __fadd_rn(acc[j], __fmul_rn(xr[r * 4 + e][j], p));
+                                for (int f = 0; f < FE; ++f) p = __fmaf_rn(wl[j][f], ar[f], p);
+                                acc[j] = __fadd_rn(acc[j], __fmul_rn(on ? xv[j] : 0.f, p));
                             }
                         }
-                        float* dst = Arow + r * LDA;
-                        if (CPL == 2) {
-                            if (lane < CIN_PAD / 2) {
-                                *reinterpret_cast<float2*>(dst + c0) = make_float2(acc[0] * 0.25f, acc[CPL - 1] * 0.25f);
-                                *reinterpret_cast<float2*>(dst + CIN_PAD + c0) = make_float2(xd[r][0], xd[r][CPL - 1]);
-                            }
-                        } else {
-                            if (lane < CIN_PAD) {
-                                dst[c0] = acc[0] * 0.25f;
-                                dst[CIN_PAD + c0] = xd[r][0];
-                            }
-                        }
+                        const float cnt = (float)max(e_end - b, 1);
+#pragma unroll
+                        for (int j = 0; j < CPL; ++j) acc[j] = __fdiv_rn(acc[j], cnt);
                     }
-                } else {
-                    // ---- generic path: any in-degree, tile tail; one edge at a time (rare)
-                    for (int r = 0; r < TPW; ++r) {
-                        const int64_t i = i0 + r;
-                        float acc[CPL], xdv[CPL];
+                    float* dst = Arow + r * LDA;
+                    if (lane * CPL < CIN_PAD) {
 #pragma unroll
-                        for (int j = 0; j < CPL; ++j) acc[j] = xdv[j] = 0.f;
-                        if (i < n_dst) {
-                            const int b = rowptr[i], e_end = rowptr[i + 1];
-                            ld_row<CPL>(xdv, x + i * ldx + c0, on);
-                            for (int k = b; k < e_end; ++k) {
-                                const int s = src[k];
-                                const float* ar = ea + (int64_t)k * lde;
-                                float xv[CPL];
-                                ld_row<CPL>(xv, x + (int64_t)s * ldx + c0, on);
-#pragma unroll
-                                for (int j = 0; j < CPL; ++j) {
-                                    float p = bl[j];
-#pragma unroll
-                                    for (int f = 0; f < FE; ++f) p = __fmaf_rn(wl[j][f], ar[f], p);
-                                    acc[j] = __fadd_rn(acc[j], __fmul_rn(xv[j], p));
-                                }
-                            }
-                            const float cnt = (float)max(e_end - b, 1);
-#pragma unroll
-                            for (int j = 0; j < CPL; ++j) acc[j] = __fdiv_rn(acc[j], cnt);
-                        }
-                        float* dst = Arow + r * LDA;
-                        if (lane * CPL < CIN_PAD) {
-#pragma unroll
-                            for (int j = 0; j < CPL; ++j) {
-                                dst[c0 + j] = acc[j];
-                                dst[CIN_PAD + c0 + j] = xdv[j];
-                            }
+                        for (int j = 0; j < CPL; ++j) {
+                            dst[c0 + j] = acc[j];
+                            dst[CIN_PAD + c0 + j] = on ? xdv[j] : 0.f;
                         }
                     }
                 }
             }
-            __syncthreads();  // publishes tile `it`; consumers are done with the other buffer
+            stamp(trace, trace_cap, it, w, 2);
+            issue_loads(it + 1);  // in flight during the barrier wait and the whole matrix phase
+            stamp(trace, trace_cap, it, w, 3);
+        }
+        __syncthreads();  // A-tile `it` complete; partial sums of tile `it-1` complete
+        stamp(trace, trace_cap, it, w, 4);
+
+        if (it > 0) {
+            // ============================================================ delayed epilogue of tile it-1
+            const int64_t tile = tile_of(it - 1);
+            const float* red = redbuf + ((it - 1) & 1) * C::RED_FLOATS + partner * 512 + lane;
+            const int64_t row0 = tile * TILE + rg * 32 + 4 * h + 16 * kh;  // kh=0: acc regs 0..7, kh=1: regs 8..15
+            float* o = out + row0 * ldo + col;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                v[r] = (mine[r] + red[r * 64]) + bb;
+                if (has_scale) v[r] = __fmaf_rn(v[r], sc, sh);
+                if (relu) v[r] = fmaxf(v[r], 0.f);
+            }
+            if ((tile + 1) * TILE <= n_dst) {  // full tile (wave-uniform): unconditional row stores
+#pragma unroll
+                for (int r = 0; r < 8; ++r) o[(int64_t)((r & 3) + 8 * (r >> 2)) * ldo] = v[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int rr = (r & 3) + 8 * (r >> 2);
+                    if (row0 + rr < n_dst) o[(int64_t)rr * ldo] = v[r];
+                }
+            }
+        }
+        if (it < my_n) {
+            // ================================================================ C: matrix phase
+            const float* A = abuf + (it & 1) * TILE * LDA + (rg * 32 + l31) * LDA + kh * CIN_PAD + 4 * h;
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int S = 0; S < C::S_STEPS; ++S) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(A + 8 * S);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], wr[S * 4 + j], acc, 0, 0, 0);
+            }
+            // keep the half this wave finishes, hand the other half to the partner
+            float* red = redbuf + (it & 1) * C::RED_FLOATS + w * 512 + lane;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                mine[r] = kh ? acc[8 + r] : acc[r];
+                red[r * 64] = kh ? acc[r] : acc[8 + r];
+            }
+            stamp(trace, trace_cap, it, w, 5);
         }
     }
 }
@@ -284,7 +387,7 @@ int launch_fused(const int32_t* rowptr, const int32_t* src, int64_t n_dst, const
     int grid = (int)(ntiles < DGNN_NUM_CU ? ntiles : DGNN_NUM_CU);
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL((k_sage_fused<CIN_PAD, COUT>), dim3(grid), dim3(512), smem, stream, rowptr, src, n_dst, x, ldx, c_in,
-                       ea, lde, We, be, Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles);
+                       ea, lde, We, be, Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles, g_trace_buf, g_trace_cap);
     return dgnn_check_launch("sage_layer_fused_fwd");
 }
 

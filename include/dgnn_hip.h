@@ -159,6 +159,10 @@ int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* src, int64_t
                               const float* scale, const float* shift, int relu, int c_out, float* out, int64_t ldo,
                               void* stream);
 
+/* Debug only: register a device buffer of n int64 slots; workgroup 0 of the fused kernel then stamps
+ * wall_clock64() at phase boundaries (slot = (tile_iter*12 + wave)*8 + phase).  NULL disables. */
+int dgnn_debug_trace_buffer(int64_t* dev_buf, int64_t n);
+
 /* elementwise helpers used by the Updated variant (F.relu at surfaceNetUpdatedEdgeFilters.py:239-241
  * and the scatter of phi rows into the zero [E_all,C] buffer at :236-237) */
 int dgnn_relu(const float* x, int64_t n, float* y, void* stream);
