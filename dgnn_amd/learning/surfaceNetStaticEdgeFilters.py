@@ -195,10 +195,11 @@ class SurfaceNet(nn.Module):
         bn = norm.module
         return ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
 
-    def _eval_layers(self, x, n_dst0, xe, plans, sorted_attr):
+    def _eval_layers(self, x, n_dst0, xe, plans, sorted_attr, only=None):
         """Eval-mode conv stack: per layer one fused launch when the widths allow it, else the
-        aggregate + linear pair; BatchNorm(eval) and ReLU always ride in the GEMM epilogue."""
-        for i in range(self.num_layers):
+        aggregate + linear pair; BatchNorm(eval) and ReLU always ride in the GEMM epilogue.
+        `only=i` runs just layer i (the partitioned forward exchanges halos between layers)."""
+        for i in (range(self.num_layers) if only is None else [only]):
             layer, plan = self.convs[i], plans[i]
             conv = layer[0]
             norm = layer[1] if isinstance(layer[1], BatchNorm) else None
