@@ -23,6 +23,7 @@ SIGNATURES = {
     "dgnn_gather_rows_f32": (i32, [vp, i64, vp, i64, i32, vp, i64, vp]),
     "dgnn_scatter_rows_f32": (i32, [vp, i64, vp, i64, i32, vp, i64, vp]),
     "dgnn_relu": (i32, [vp, i64, vp, vp]),
+    "dgnn_relu_bwd": (i32, [vp, vp, i64, vp, vp]),
     "dgnn_sage_aggregate_fwd": (i32, [vp, vp, vp, i64, vp, i64, i32, vp, i64, i32, vp, vp, vp, i64, vp, i64, vp, i64, vp]),
     "dgnn_linear_fwd": (i32, [vp, i64, i32, vp, i64, vp, i64, i32, vp, i64, vp, vp, vp, i32, i64, i32, vp, i64, vp]),
     "dgnn_linear_wgrad_scratch_elems": (i64, [i64, i32, i32]),

@@ -205,7 +205,19 @@ __global__ void k_relu(const float* __restrict__ x, int64_t n, float* __restrict
         y[i] = fmaxf(x[i], 0.0f);
 }
 
+__global__ void k_relu_bwd(const float* __restrict__ y, const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = y[i] > 0.f ? g[i] : 0.f;
+}
+
 }  // namespace
+
+extern "C" int dgnn_relu_bwd(const float* y, const float* g, int64_t n, float* out, void* stream) {
+    DGNN_REQUIRE(n >= 0 && (n == 0 || (y && g && out)), DGNN_E_INVALID, "relu_bwd: bad args");
+    if (n == 0) return DGNN_OK;
+    hipLaunchKernelGGL(k_relu_bwd, dim3(dgnn_grid_cap(dgnn_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream, y, g, n, out);
+    return dgnn_check_launch("relu_bwd");
+}
 
 // scratch layout (int32): deg[n_key] | tmp[E] | sums[nb+1] | big_count[1] | big_list[n_key/33+1]
 extern "C" int64_t dgnn_plan_scratch_elems(int64_t E, int64_t n_key) {

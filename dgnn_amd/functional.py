@@ -146,8 +146,47 @@ class _ReLU(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (y,) = ctx.saved_tensors
-        return g * (y > 0).to(g.dtype)
+        return ops.relu_bwd(y, g)
 
 
 def relu(x):
     return _ReLU.apply(x)
+
+
+class _GatherRows(torch.autograd.Function):
+    """out = src[idx]  (rows; idx unique)"""
+
+    @staticmethod
+    def forward(ctx, src, idx):
+        ctx.save_for_backward(idx)
+        ctx.n = src.size(0)
+        return ops.gather_rows(src, idx.to(torch.int32))
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        out = torch.zeros((ctx.n, g.size(1)), dtype=g.dtype, device=g.device)
+        return ops.scatter_rows_(out, idx, g.contiguous()), None
+
+
+class _ScatterRows(torch.autograd.Function):
+    """out = zeros[n_rows, C]; out[idx] = src  (idx unique)"""
+
+    @staticmethod
+    def forward(ctx, src, idx, n_rows):
+        ctx.save_for_backward(idx)
+        out = torch.zeros((n_rows, src.size(1)), dtype=src.dtype, device=src.device)
+        return ops.scatter_rows_(out, idx, src)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return ops.gather_rows(g.contiguous(), idx.to(torch.int32)), None, None
+
+
+def gather_rows(src, idx):
+    return _GatherRows.apply(src, idx)
+
+
+def scatter_rows(src, idx, n_rows):
+    return _ScatterRows.apply(src, idx, n_rows)

@@ -1,0 +1,120 @@
+"""MI355X drop-in for the coherent part of the reference's learning/surfaceNetUpdatedEdgeFilters.py.
+
+``SAGEConv(in_channels, out_channels, edge_in_channels)`` returns ``(out, phi)`` (reference :147-170)
+and ``SurfaceNet(n_node_features, clf).forward(data_all)`` chains the edge embeddings from layer to
+layer (:216-251).  State-dict keys: ``convs.N.lin_l.{weight,bias}``, ``convs.N.lin_r.weight``,
+``convs.N.lin_e.{weight,bias}``, ``out_net.{1,3}.{weight,bias}``.
+
+phi feeds both this layer's aggregation and the next layer's lin_e, so it is materialised
+([E_l, C_in], written once, read twice) and differentiated through both uses; the dense lin_e runs on
+the fp32 MFMA GEMM (its K is 2, F or h_{k-2}) and the aggregation kernel takes phi rows as given.
+
+The reference's three ``inference_*`` methods of this file call the conv without ``edge_attr``
+(:281,:317,:352) and raise there; they are not part of the path and raise here too.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+from torch.nn import Linear
+
+from .. import functional as Fn
+from ..graph import GraphPlan, plan_for
+
+
+def _dev_f32(t, device):
+    if t.device != torch.device(device) or t.dtype != torch.float32:
+        t = t.to(device=device, dtype=torch.float32)
+    return t
+
+
+class SAGEConv(nn.Module):
+
+    def __init__(self, in_channels, out_channels, edge_in_channels, normalize=False, bias=True, **kwargs):
+        super().__init__()
+        self.in_channels = in_channels
+        self.edge_in_channels = edge_in_channels
+        self.out_channels = out_channels
+        self.normalize = normalize
+        if isinstance(in_channels, int):
+            in_channels = (in_channels, in_channels)
+        self.lin_l = Linear(in_channels[0], out_channels, bias=bias)
+        self.lin_r = Linear(in_channels[1], out_channels, bias=False)
+        self.lin_e = Linear(edge_in_channels, in_channels[0], bias=bias)
+
+    def reset_parameters(self):
+        self.lin_l.reset_parameters()
+        self.lin_r.reset_parameters()
+        self.lin_e.reset_parameters()
+
+    def forward(self, x, edge_attr, edge_index, size=None, plan: GraphPlan = None):
+        if isinstance(x, torch.Tensor):
+            x = (x, x)
+        x_src, x_dst = x
+        if plan is None:
+            plan = plan_for(edge_index, x_src.size(0), x_dst.size(0))
+        phi = Fn.linear2(edge_attr, self.lin_e.weight, bias=self.lin_e.bias)        # :156
+        a = Fn.aggregate(x_src, plan, phi=phi)                                       # :158 (mean of x_j * phi)
+        out = Fn.linear2(a, self.lin_l.weight, x_dst, self.lin_r.weight, self.lin_l.bias)  # :159-165
+        if self.normalize:
+            out = torch.nn.functional.normalize(out, p=2., dim=-1)                   # :167-168 (never enabled by a config)
+        return out, phi
+
+    def __repr__(self):
+        return '{}(in:{}, edge_in:{}, edge_out:{}, out:{})'.format(self.__class__.__name__, self.in_channels,
+                                                                   self.edge_in_channels, self.in_channels, self.out_channels)
+
+
+class SurfaceNet(nn.Module):
+
+    def __init__(self, n_node_features, clf):
+        super().__init__()
+        self.clf = clf
+        self.n_classes = 2
+        self.n_node_feat = n_node_features
+        p = clf.training.model_params
+        self.convs = nn.ModuleList()
+        self.convs.append(SAGEConv(self.n_node_feat, p[0], 2))
+        self.convs.append(SAGEConv(p[0], p[1], self.n_node_feat))
+        for i in range(len(p) - 2):
+            self.convs.append(SAGEConv(p[i + 1], p[i + 2], p[i], normalize=False))
+        self.num_layers = len(self.convs)
+        if clf.training.model_name[-1] == "+":
+            self.out_net = nn.Sequential(nn.ReLU(True), nn.Linear(p[-1], 128), nn.ReLU(True), nn.Linear(128, 2))
+
+    def forward(self, data_all):
+        dev = self.clf.temp.device
+        if not str(dev).startswith("cuda"):
+            raise RuntimeError("clf.temp.device=%r: dgnn_amd runs on a GPU only (no CPU fallback)" % (dev,))
+        f = self.clf.features
+        x_all = data_all.x
+        n_id = data_all.n_id.to(x_all.device)
+        if f.normalization_feature and not f.keep_normalization_feature:
+            x = _dev_f32(x_all[n_id, 1:], dev)
+        else:
+            x = _dev_f32(x_all[n_id, :], dev)
+        edge_attr = _dev_f32(data_all.edge_attr, dev)
+        n_edges = edge_attr.size(0)
+        for i in range(self.num_layers):
+            edge_index, e_id, size = data_all.adjs[i]
+            e_id = e_id.to(dev)
+            conv = self.convs[i]
+            ea = Fn.gather_rows(edge_attr, e_id)[:, :conv.edge_in_channels]          # :237 edge_attr[e_id, :edge_in]
+            x, phi = conv((x, x[:size[1]]), ea, edge_index.to(dev))
+            edge_attr = Fn.scatter_rows(phi, e_id, n_edges)                           # :236-237 zeros[E_all,C]; [e_id] = phi
+            if i != self.num_layers - 1:                                              # :239-241
+                x = Fn.relu(x)
+                edge_attr = Fn.relu(edge_attr)
+        if self.clf.training.model_name[-1] == "+":                                   # :245-247
+            x = Fn.relu(x)
+            x = Fn.relu(x)  # out_net[0] is another ReLU (idempotent)
+            x = Fn.linear2(x, self.out_net[1].weight, bias=self.out_net[1].bias)
+            x = Fn.relu(x)
+            x = Fn.linear2(x, self.out_net[3].weight, bias=self.out_net[3].bias)
+        return x
+
+    def _unsupported(self, *a, **k):
+        raise NotImplementedError("the reference's surfaceNetUpdatedEdgeFilters.inference_* methods call the conv without "
+                                  "edge_attr and cannot run (reference :281,:317,:352); use forward(data_all)")
+
+    inference_batch_layer = inference_layer_batch = inference_layer = _unsupported

@@ -81,6 +81,15 @@ def relu(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def relu_bwd(y: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    _req(y, "y")
+    _req(g, "g")
+    y, g = y.contiguous(), g.contiguous()
+    out = torch.empty_like(g)
+    check(lib().dgnn_relu_bwd(ptr(y), ptr(g), g.numel(), ptr(out), stream_ptr()), "dgnn_relu_bwd")
+    return out
+
+
 # ---- aggregation --------------------------------------------------------------------------------
 def aggregate_fwd(rowptr, src, eid, n_dst, x_src, edge_attr=None, We=None, be=None, phi=None, want_phi=False):
     _req(x_src, "x_src", dim=2)

@@ -166,6 +166,7 @@ int dgnn_debug_trace_buffer(int64_t* dev_buf, int64_t n);
 /* elementwise helpers used by the Updated variant (F.relu at surfaceNetUpdatedEdgeFilters.py:239-241
  * and the scatter of phi rows into the zero [E_all,C] buffer at :236-237) */
 int dgnn_relu(const float* x, int64_t n, float* y, void* stream);
+int dgnn_relu_bwd(const float* y, const float* g, int64_t n, float* out, void* stream); /* out = g * [y > 0] */
 int dgnn_scatter_rows_f32(const float* in, int64_t ld_in, const int64_t* idx, int64_t n, int cols, float* out,
                           int64_t ld_out, void* stream);
 

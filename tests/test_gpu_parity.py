@@ -321,3 +321,42 @@ def test_partitioned_hip_forward_equals_whole_graph(world):
     for r in range(world):
         logits[torch.from_numpy(lps[r].own_gid).to(DEV)] = net._eval_decoder(hs[r][:lps[r].n_own])
     assert torch.equal(logits, full)
+
+
+def test_updated_variant_forward_backward_golden():
+    from dgnn_amd.learning.surfaceNetUpdatedEdgeFilters import SurfaceNet
+    g = gold("static_f3_train_blocks.npz")
+    u = gold("updated_f3_blocks.npz")
+    d = f3_data(g)
+    for tag, name in (("plus", "sage+"), ("plain", "sage")):
+        clf = Config.wrap(dict(training=dict(model_params=[int(v) for v in u[tag + ".model_params"]], model_name=name, loss="kl"),
+                               features=dict(normalization_feature=1, keep_normalization_feature=0), temp=dict(device=DEV)))
+        net = SurfaceNet(28, clf)
+        net.load_state_dict({k[len(tag) + 7:]: torch.from_numpy(u[k]) for k in u.files if k.startswith(tag + ".param.")})
+        net = net.to(DEV)
+        data = Config(x=d.all.x.to(DEV), edge_attr=d.all.edge_attr.to(DEV), n_id=d.batch_n_id.to(DEV),
+                      adjs=[(a.to(DEV), e.to(DEV), s) for a, e, s in d.batch_adjs])
+        logits = net(data)
+        ref = u[tag + ".logits"]
+        assert np.abs(logits.detach().cpu().numpy() - ref).max() <= TOL_LOGIT * max(1.0, np.abs(ref).max())
+        # our "+" head is also differentiable (the reference's raises there); grads are checked on "plain"
+        (logits * torch.from_numpy(g["G"]).to(DEV)).sum().backward()
+        if tag == "plain":
+            gmax = max(np.abs(u[k]).max() for k in u.files if k.startswith("plain.grad."))
+            for k, p in net.named_parameters():
+                r = u["plain.grad." + k]
+                err = np.abs(p.grad.cpu().numpy() - r).max()
+                assert err <= 2e-4 * np.abs(r).max() + 2e-6 * gmax, (k, err, np.abs(r).max())
+
+
+def test_partitioned_scene_world1_matches_inference_layer():
+    from dgnn_amd.partition import PartitionedScene
+    from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal
+    net = hip_static()
+    scene = PartitionedScene.build_synthetic(1500, 3, 0, 1, DEV)
+    logits = scene.inference_layer(net)
+    adj, _, _ = delaunay_tet_graph(1500, 3)
+    n = adj.shape[0] // 4
+    data = Config(x=hashed_normal(np.arange(n), 29, seed=1, device=DEV), edge_attr=hashed_normal(np.arange(4 * n), 20, seed=2, device=DEV),
+                  edge_index=torch.from_numpy(adj.T.astype(np.int64)).to(DEV))
+    assert torch.equal(logits, net.inference_layer(data))
