@@ -192,7 +192,9 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cores = os.cpu_count() or 1
+        # 16 threads is where this op chain peaks on the GPU host (tools/cpu_sweep.py: 1 -> 9.7e4, 16 -> 1.6e5,
+        # 64 -> 1.1e5, 128 -> 6.7e4 tets/s on a 256-core box): more threads only add contention
+        cores = min(os.cpu_count() or 1, 16)
         v, n_s = cpu_baseline(args.cpu_points, cores)
         cpu = {"value": round(v, 1), "unit": "tets/s", "cores": cores, "kind": "port",
                "sample": "oracle (PyTorch-CPU restatement of inference_layer), same generator at %d points -> %d tets, "
