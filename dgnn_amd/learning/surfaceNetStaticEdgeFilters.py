@@ -227,6 +227,8 @@ class SurfaceNet(nn.Module):
         if len(dec) == 1:
             return ops.linear_fwd(x, dec[0].weight, bias=dec[0].bias)
         scale, shift = self._fold(dec[1] if isinstance(dec[1], BatchNorm) else None, dec[0].out_features, x.device)
+        if ops.decoder_fused_supported(dec[0].in_features, dec[0].out_features, dec[3].out_features):
+            return ops.decoder_fused_fwd(x, dec[0].weight, dec[0].bias, scale, shift, dec[3].weight, dec[3].bias)
         h = ops.linear_fwd(x, dec[0].weight, bias=dec[0].bias, scale=scale, shift=shift, relu=True)
         return ops.linear_fwd(h, dec[3].weight, bias=dec[3].bias)
 

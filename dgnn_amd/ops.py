@@ -249,3 +249,17 @@ def sage_layer_fused_fwd(rowptr, src, n_dst, x_src, edge_attr_sorted, We, be, Wj
         ptr(We), ptr(be), ptr(Wj), ptr(bj), ptr(Wi), ptr(scale), ptr(shift), int(bool(relu)), c_out, ptr(out), c_out,
         stream_ptr()), "dgnn_sage_layer_fused_fwd")
     return out
+
+
+def decoder_fused_supported(k: int, hidden: int, n_out: int) -> bool:
+    return k == 128 and hidden == 64 and n_out in (1, 2)
+
+
+def decoder_fused_fwd(y, W0, b0, scale, shift, W3, b3):
+    _req(y, "y", dim=2)
+    M, n_out = y.size(0), W3.size(0)
+    out = torch.empty((M, n_out), dtype=torch.float32, device=y.device)
+    check(lib().dgnn_decoder_fused_fwd(ptr(y), _ld(y), M, y.size(1), ptr(W0.contiguous()), ptr(b0), ptr(scale), ptr(shift),
+                                       W0.size(0), ptr(W3.contiguous()), ptr(b3), n_out, ptr(out), n_out, stream_ptr()),
+          "dgnn_decoder_fused_fwd")
+    return out

@@ -159,6 +159,13 @@ int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* src, int64_t
                               const float* scale, const float* shift, int relu, int c_out, float* out, int64_t ldo,
                               void* stream);
 
+/* Fused decoder, eval mode (reference :180-187 applied at :350-351):
+ *   logits = W3 . relu((W0 . y + b0) * scale + shift) + b3,   y [M,k] -> out [M,n_out]
+ * Supports k == 128, hidden == 64, n_out in {1,2}; DGNN_E_UNSUPPORTED otherwise (use dgnn_linear_fwd twice). */
+int dgnn_decoder_fused_fwd(const float* y, int64_t ldy, int64_t M, int k, const float* W0, const float* b0,
+                           const float* scale, const float* shift, int hidden, const float* W3, const float* b3, int n_out,
+                           float* out, int64_t ldo, void* stream);
+
 /* Debug only: register a device buffer of n int64 slots; workgroup 0 of the fused kernel then stamps
  * wall_clock64() at phase boundaries (slot = (tile_iter*12 + wave)*8 + phase).  NULL disables. */
 int dgnn_debug_trace_buffer(int64_t* dev_buf, int64_t n);

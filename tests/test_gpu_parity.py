@@ -360,3 +360,16 @@ def test_partitioned_scene_world1_matches_inference_layer():
     data = Config(x=hashed_normal(np.arange(n), 29, seed=1, device=DEV), edge_attr=hashed_normal(np.arange(4 * n), 20, seed=2, device=DEV),
                   edge_index=torch.from_numpy(adj.T.astype(np.int64)).to(DEV))
     assert torch.equal(logits, net.inference_layer(data))
+
+
+@pytest.mark.parametrize("M,n_out", [(1000, 2), (64, 2), (4097, 1), (1, 2)])
+def test_decoder_fused(M, n_out):
+    from dgnn_amd import ops
+    g = torch.Generator().manual_seed(M + n_out)
+    y = torch.randn(M, 128, generator=g)
+    W0, b0 = torch.randn(64, 128, generator=g) * 0.2, torch.randn(64, generator=g)
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    W3, b3 = torch.randn(n_out, 64, generator=g) * 0.3, torch.randn(n_out, generator=g)
+    ref = torch.relu((y.double() @ W0.double().t() + b0.double()) * sc.double() + sh.double()) @ W3.double().t() + b3.double()
+    out = ops.decoder_fused_fwd(*(t.to(DEV) for t in (y, W0, b0, sc, sh, W3, b3)))
+    assert rel_err(out, ref) < 3e-6
