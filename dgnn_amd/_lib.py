@@ -40,7 +40,7 @@ SIGNATURES = {
     "dgnn_debug_trace_buffer": (i32, [vp, i64]),
     "dgnn_decoder_fused_fwd": (i32, [vp, i64, i64, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, i64, vp]),
     "dgnn_sage_layer_fused_fwd": (i32, [vp, vp, i64, vp, i64, i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp,
-                                        i64, vp]),
+                                        i64, i32, vp]),
 }
 
 _lib = None

@@ -63,13 +63,39 @@ __device__ __forceinline__ void stamp(int64_t* trace, int64_t cap, int64_t it, i
     }
 }
 
-template <int CIN_PAD, int COUT>
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// Exact 3-way split of two fp32 values into packed bf16 pairs: x = hi + mid + lo with each part a bf16
+// (8 significant bits, same exponent range), rounding to nearest at every step (v_cvt_pk_bf16_f32).
+// Residuals are exact in fp32, so the three parts carry all 24 significand bits.
+__device__ __forceinline__ void split3(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    const bf16x2_t h = __builtin_convertvector(f32x2_t{x0, x1}, bf16x2_t);
+    hi = __builtin_bit_cast(uint32_t, h);
+    const float r0 = x0 - __builtin_bit_cast(float, hi << 16), r1 = x1 - __builtin_bit_cast(float, hi & 0xFFFF0000u);
+    const bf16x2_t m = __builtin_convertvector(f32x2_t{r0, r1}, bf16x2_t);
+    mid = __builtin_bit_cast(uint32_t, m);
+    const float s0 = r0 - __builtin_bit_cast(float, mid << 16), s1 = r1 - __builtin_bit_cast(float, mid & 0xFFFF0000u);
+    const bf16x2_t l = __builtin_convertvector(f32x2_t{s0, s1}, bf16x2_t);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// MODE 0: fp32 MFMA (v_mfma_f32_32x32x2_f32), bit-faithful fp32 fmaf chains.
+// MODE 1: split-bf16 MFMA (v_mfma_f32_32x32x16_bf16): both operands are split exactly into 3 bf16 parts and the
+//         6 partial products of relative weight >= 2^-18 are accumulated in fp32 (dropped: mid*lo, lo*mid, lo*lo
+//         <= 2^-25 relative, below fp32 rounding).  Same fp32-class result at 6/16 of the matrix-pipe time.
+template <int CIN_PAD, int COUT, int MODE>
 struct FusedCfg {
     static constexpr int K = 2 * CIN_PAD;
     static constexpr int NSLICE = COUT / 32;           // column slices of 32
     static constexpr int RG = NWAVE / (2 * NSLICE);    // row groups per tile (K is split in 2)
     static constexpr int TILE = 32 * RG;               // destination tets per tile
     static constexpr int LDA = K + 4;
+    // MODE 1 A-tile: per row K/8 octets of 48 bytes [hi 8 x bf16 | mid | lo] + 16 pad bytes (row stride = odd
+    // number of 16-byte slots -> conflict-free ds_read_b128); counted in floats for the carve-up below
+    static constexpr int ROWB = (K / 8) * 48 + 16;
+    static constexpr int A_FLOATS = MODE == 0 ? TILE * LDA : TILE * ROWB / 4;
     static constexpr int TPW = TILE / NWAVE;           // tets gathered per wave
     static constexpr int CPL = CIN_PAD > 64 ? 2 : 1;   // channels per lane in the gather phase
     static constexpr int NQ = TPW * 4;                 // neighbour rows per wave
@@ -79,7 +105,7 @@ struct FusedCfg {
     static constexpr int EA_PAD = NEV * 256;
     static constexpr int S_STEPS = CIN_PAD / 8;        // k-steps of 8 per K half
     static constexpr int RED_FLOATS = NWAVE * 8 * 64;  // one partial-sum exchange buffer
-    static constexpr int SMEM_FLOATS = 2 * TILE * LDA + NWAVE * EA_PAD + 2 * RED_FLOATS;
+    static constexpr int SMEM_FLOATS = 2 * A_FLOATS + NWAVE * EA_PAD + 2 * RED_FLOATS;
 };
 
 // Row fragment load.  The caller passes an address that is valid for every lane (inactive lanes are
@@ -96,7 +122,7 @@ __device__ __forceinline__ void ld_row(float (&v)[CPL], const float* p) {
     }
 }
 
-template <int CIN_PAD, int COUT>
+template <int CIN_PAD, int COUT, int MODE>
 __global__ void __launch_bounds__(512, 2)
 k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, int64_t n_dst,
              const float* __restrict__ x, int64_t ldx, int c_in, const float* __restrict__ ea, int64_t lde,
@@ -104,11 +130,12 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
              const float* __restrict__ bj, const float* __restrict__ Wi, const float* __restrict__ scale,
              const float* __restrict__ shift, int relu, float* __restrict__ out, int64_t ldo, int64_t ntiles,
              int64_t* __restrict__ trace, int64_t trace_cap) {
-    using C = FusedCfg<CIN_PAD, COUT>;
+    using C = FusedCfg<CIN_PAD, COUT, MODE>;
     constexpr int LDA = C::LDA, TILE = C::TILE, TPW = C::TPW, CPL = C::CPL, NQ = C::NQ, NEV = C::NEV, NV4 = C::NV4;
+    constexpr int ROWB = C::ROWB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const abuf = smem;                                  // [2][TILE][LDA]
-    float* const eabuf = smem + 2 * TILE * LDA;                // [NWAVE][EA_PAD]
+    float* const abuf = smem;                                  // [2][A_FLOATS]
+    float* const eabuf = smem + 2 * C::A_FLOATS;               // [NWAVE][EA_PAD]
     float* const redbuf = eabuf + NWAVE * C::EA_PAD;           // [2][NWAVE][8][64]
 
     const int lane = lane_id(), w = wave_id_uniform();
@@ -125,16 +152,39 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
     const int cs = w % C::NSLICE, kh = (w / C::NSLICE) & 1, rg = w / (2 * C::NSLICE);
     const int col = cs * 32 + l31;
     const int partner = w ^ C::NSLICE;  // same cs and rg, other K half
-    float wr[C::S_STEPS * 4];
+    constexpr int NWR = MODE == 0 ? C::S_STEPS * 4 : 1;
+    constexpr int NWB = MODE == 1 ? CIN_PAD / 16 : 1;   // k-steps of 16 per K half
+    float wr[NWR];
+    bf16x8 wb[NWB][3];                                   // [k-step][hi, mid, lo] 8 bf16 each
     {
         const float* Wsrc = kh ? Wi : Wj;
+        if (MODE == 0) {
 #pragma unroll
-        for (int S = 0; S < C::S_STEPS; ++S) {
+            for (int S = 0; S < C::S_STEPS; ++S) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = 8 * S + 4 * h + j;  // k-permutation shared with the A-tile read
-                const float v = Wsrc[(int64_t)col * c_in + (k < c_in ? k : 0)];
-                wr[S * 4 + j] = k < c_in ? v : 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 8 * S + 4 * h + j;  // k-permutation shared with the A-tile read
+                    const float v = Wsrc[(int64_t)col * c_in + (k < c_in ? k : 0)];
+                    wr[S * 4 + j] = k < c_in ? v : 0.f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int S = 0; S < NWB; ++S) {
+                uint32_t ph[4], pm[4], pl[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int k = 16 * S + 8 * h + 2 * d;  // lane half h holds k = 16S+8h .. +7, as the A-tile read does
+                    const float v0 = Wsrc[(int64_t)col * c_in + (k < c_in ? k : 0)];
+                    const float v1 = Wsrc[(int64_t)col * c_in + (k + 1 < c_in ? k + 1 : 0)];
+                    split3(k < c_in ? v0 : 0.f, k + 1 < c_in ? v1 : 0.f, ph[d], pm[d], pl[d]);
+                }
+                wb[S][0] = __builtin_bit_cast(bf16x8, f32x4{__builtin_bit_cast(float, ph[0]), __builtin_bit_cast(float, ph[1]),
+                                                            __builtin_bit_cast(float, ph[2]), __builtin_bit_cast(float, ph[3])});
+                wb[S][1] = __builtin_bit_cast(bf16x8, f32x4{__builtin_bit_cast(float, pm[0]), __builtin_bit_cast(float, pm[1]),
+                                                            __builtin_bit_cast(float, pm[2]), __builtin_bit_cast(float, pm[3])});
+                wb[S][2] = __builtin_bit_cast(bf16x8, f32x4{__builtin_bit_cast(float, pl[0]), __builtin_bit_cast(float, pl[1]),
+                                                            __builtin_bit_cast(float, pl[2]), __builtin_bit_cast(float, pl[3])});
             }
         }
     }
@@ -216,6 +266,51 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
         ok2 = load_rowptr(it_next + 1, beg2);
     };
 
+    // write one finished tet into the A-tile: columns [0,CIN_PAD) = mean row, [CIN_PAD,2*CIN_PAD) = own row
+    auto put_row = [&](int buf, int row, const float (&av)[CPL], const float (&xv)[CPL]) {
+        if (MODE == 0) {
+            float* dst = abuf + buf * C::A_FLOATS + row * LDA;
+            if (CPL == 2) {
+                if (lane < CIN_PAD / 2) {
+                    *reinterpret_cast<float2*>(dst + c0) = make_float2(av[0], av[CPL - 1]);
+                    *reinterpret_cast<float2*>(dst + CIN_PAD + c0) = make_float2(xv[0], xv[CPL - 1]);
+                }
+            } else if (lane < CIN_PAD) {
+                dst[c0] = av[0];
+                dst[CIN_PAD + c0] = xv[0];
+            }
+        } else {
+            char* dst = reinterpret_cast<char*>(abuf + buf * C::A_FLOATS) + row * ROWB;
+            if (CPL == 2) {
+                // channels (c0, c0+1) = one packed bf16 pair per part: octet c0/8, dword (c0%8)/2
+                if (lane < CIN_PAD / 2) {
+                    uint32_t hh, mm, ll;
+                    char* pa = dst + (c0 >> 3) * 48 + (c0 & 7) * 2;
+                    split3(av[0], av[CPL - 1], hh, mm, ll);
+                    *reinterpret_cast<uint32_t*>(pa) = hh;
+                    *reinterpret_cast<uint32_t*>(pa + 16) = mm;
+                    *reinterpret_cast<uint32_t*>(pa + 32) = ll;
+                    char* px = pa + (CIN_PAD / 8) * 48;
+                    split3(xv[0], xv[CPL - 1], hh, mm, ll);
+                    *reinterpret_cast<uint32_t*>(px) = hh;
+                    *reinterpret_cast<uint32_t*>(px + 16) = mm;
+                    *reinterpret_cast<uint32_t*>(px + 32) = ll;
+                }
+            } else if (lane < CIN_PAD) {
+                uint32_t hh, mm, ll;
+                char* pa = dst + (c0 >> 3) * 48 + (c0 & 7) * 2;
+                split3(av[0], xv[0], hh, mm, ll);  // low halves: mean value, high halves: own-row value
+                *reinterpret_cast<uint16_t*>(pa) = (uint16_t)hh;
+                *reinterpret_cast<uint16_t*>(pa + 16) = (uint16_t)mm;
+                *reinterpret_cast<uint16_t*>(pa + 32) = (uint16_t)ll;
+                char* px = pa + (CIN_PAD / 8) * 48;
+                *reinterpret_cast<uint16_t*>(px) = (uint16_t)(hh >> 16);
+                *reinterpret_cast<uint16_t*>(px + 16) = (uint16_t)(mm >> 16);
+                *reinterpret_cast<uint16_t*>(px + 32) = (uint16_t)(ll >> 16);
+            }
+        }
+    };
+
     ok1 = load_rowptr(0, beg1);
     load_src();
     ok2 = load_rowptr(1, beg2);
@@ -228,7 +323,6 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
         if (it < my_n) {
             // ================================================================ P: gather / filter / mean
             const int64_t i0 = tile_of(it) * TILE + w * TPW;
-            float* const Arow = abuf + (it & 1) * TILE * LDA + (w * TPW) * LDA;
             stamp(trace, trace_cap, it, w, 0);
             const bool was_regular = regular;
             if (was_regular) {
@@ -264,19 +358,13 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
                             acc[j] = __fadd_rn(acc[j], __fmul_rn(on ? xr[r * 4 + e][j] : 0.f, p));
                         }
                     }
-                    float* dst = Arow + r * LDA;
-                    if (CPL == 2) {
-                        if (lane < CIN_PAD / 2) {
-                            *reinterpret_cast<float2*>(dst + c0) = make_float2(acc[0] * 0.25f, acc[CPL - 1] * 0.25f);
-                            *reinterpret_cast<float2*>(dst + CIN_PAD + c0) =
-                                make_float2(on ? xd[r][0] : 0.f, on ? xd[r][CPL - 1] : 0.f);
-                        }
-                    } else {
-                        if (lane < CIN_PAD) {
-                            dst[c0] = acc[0] * 0.25f;
-                            dst[CIN_PAD + c0] = on ? xd[r][0] : 0.f;
-                        }
+                    float xv[CPL];
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        acc[j] *= 0.25f;
+                        xv[j] = on ? xd[r][j] : 0.f;
                     }
+                    put_row((int)(it & 1), w * TPW + r, acc, xv);
                 }
             } else {
                 // generic path: any in-degree, tile tail; one edge at a time (rare)
@@ -305,14 +393,9 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
 #pragma unroll
                         for (int j = 0; j < CPL; ++j) acc[j] = __fdiv_rn(acc[j], cnt);
                     }
-                    float* dst = Arow + r * LDA;
-                    if (lane * CPL < CIN_PAD) {
 #pragma unroll
-                        for (int j = 0; j < CPL; ++j) {
-                            dst[c0 + j] = acc[j];
-                            dst[CIN_PAD + c0 + j] = on ? xdv[j] : 0.f;
-                        }
-                    }
+                    for (int j = 0; j < CPL; ++j) xdv[j] = on ? xdv[j] : 0.f;
+                    put_row((int)(it & 1), w * TPW + r, acc, xdv);
                 }
             }
             stamp(trace, trace_cap, it, w, 2);
@@ -348,15 +431,33 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
         }
         if (it < my_n) {
             // ================================================================ C: matrix phase
-            const float* A = abuf + (it & 1) * TILE * LDA + (rg * 32 + l31) * LDA + kh * CIN_PAD + 4 * h;
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            if (MODE == 0) {
+                const float* A = abuf + (it & 1) * C::A_FLOATS + (rg * 32 + l31) * LDA + kh * CIN_PAD + 4 * h;
 #pragma unroll
-            for (int S = 0; S < C::S_STEPS; ++S) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(A + 8 * S);
+                for (int S = 0; S < C::S_STEPS; ++S) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(A + 8 * S);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], wr[S * 4 + j], acc, 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], wr[S * 4 + j], acc, 0, 0, 0);
+                }
+            } else {
+                const char* A = reinterpret_cast<const char*>(abuf + (it & 1) * C::A_FLOATS) + (rg * 32 + l31) * ROWB +
+                                (kh * (CIN_PAD / 8) + h) * 48;
+#pragma unroll
+                for (int S = 0; S < NWB; ++S) {
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(A + S * 96);
+                    const bf16x8 am = *reinterpret_cast<const bf16x8*>(A + S * 96 + 16);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(A + S * 96 + 32);
+                    // smallest partial products first
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wb[S][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wb[S][2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wb[S][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wb[S][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wb[S][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wb[S][0], acc, 0, 0, 0);
+                }
             }
             // keep the half this wave finishes, hand the other half to the partner
             float* red = redbuf + (it & 1) * C::RED_FLOATS + w * 512 + lane;
@@ -370,23 +471,23 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
     }
 }
 
-template <int CIN_PAD, int COUT>
+template <int CIN_PAD, int COUT, int MODE>
 int launch_fused(const int32_t* rowptr, const int32_t* src, int64_t n_dst, const float* x, int64_t ldx, int c_in,
                  const float* ea, int64_t lde, const float* We, const float* be, const float* Wj, const float* bj,
                  const float* Wi, const float* scale, const float* shift, int relu, float* out, int64_t ldo,
                  hipStream_t stream) {
-    using C = FusedCfg<CIN_PAD, COUT>;
+    using C = FusedCfg<CIN_PAD, COUT, MODE>;
     const int64_t ntiles = dgnn_cdiv(n_dst, C::TILE);
     const size_t smem = sizeof(float) * C::SMEM_FLOATS;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sage_fused<CIN_PAD, COUT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sage_fused<CIN_PAD, COUT, MODE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
     int grid = (int)(ntiles < DGNN_NUM_CU ? ntiles : DGNN_NUM_CU);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((k_sage_fused<CIN_PAD, COUT>), dim3(grid), dim3(512), smem, stream, rowptr, src, n_dst, x, ldx, c_in,
+    hipLaunchKernelGGL((k_sage_fused<CIN_PAD, COUT, MODE>), dim3(grid), dim3(512), smem, stream, rowptr, src, n_dst, x, ldx, c_in,
                        ea, lde, We, be, Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles, g_trace_buf, g_trace_cap);
     return dgnn_check_launch("sage_layer_fused_fwd");
 }
@@ -397,9 +498,10 @@ extern "C" int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* s
                                          int64_t ldx, int c_in, const float* edge_attr_sorted, int64_t lde, int f_e,
                                          const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
                                          const float* scale, const float* shift, int relu, int c_out, float* out, int64_t ldo,
-                                         void* stream_) {
+                                         int gemm_mode, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DGNN_REQUIRE(n_dst >= 0 && c_in > 0 && c_out > 0, DGNN_E_INVALID, "sage_layer_fused_fwd: bad sizes");
+    DGNN_REQUIRE(gemm_mode == DGNN_GEMM_F32 || gemm_mode == DGNN_GEMM_BF16X3, DGNN_E_INVALID, "sage_layer_fused_fwd: bad gemm_mode %d", gemm_mode);
     if (n_dst == 0) return DGNN_OK;
     DGNN_REQUIRE(rowptr && src && x_src && edge_attr_sorted && We && be && Wj && Wi && out, DGNN_E_INVALID,
                  "sage_layer_fused_fwd: null pointer");
@@ -408,8 +510,14 @@ extern "C" int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* s
     DGNN_REQUIRE(((uintptr_t)edge_attr_sorted % 16) == 0, DGNN_E_UNSUPPORTED, "sage_layer_fused_fwd: edge_attr must be 16-byte aligned");
     DGNN_REQUIRE(c_in <= 128 && (c_out == 64 || c_out == 128), DGNN_E_UNSUPPORTED,
                  "sage_layer_fused_fwd: supports c_in <= 128 and c_out in {64,128} (got %d -> %d)", c_in, c_out);
-#define GO(CP, CO) return launch_fused<CP, CO>(rowptr, src, n_dst, x_src, ldx, c_in, edge_attr_sorted, lde, We, be, Wj, bj, Wi, \
-                                               scale, shift, relu, out, ldo, stream)
+#define GO(CP, CO)                                                                                                              \
+    do {                                                                                                                        \
+        if (gemm_mode == DGNN_GEMM_F32)                                                                                         \
+            return launch_fused<CP, CO, 0>(rowptr, src, n_dst, x_src, ldx, c_in, edge_attr_sorted, lde, We, be, Wj, bj, Wi, scale, \
+                                           shift, relu, out, ldo, stream);                                                      \
+        return launch_fused<CP, CO, 1>(rowptr, src, n_dst, x_src, ldx, c_in, edge_attr_sorted, lde, We, be, Wj, bj, Wi, scale,     \
+                                       shift, relu, out, ldo, stream);                                                          \
+    } while (0)
     if (c_in <= 32) { if (c_out == 64) GO(32, 64); else GO(32, 128); }
     if (c_in <= 64) { if (c_out == 64) GO(64, 64); else GO(64, 128); }
     DGNN_REQUIRE(c_in % 2 == 0 && ldx % 2 == 0 && ((uintptr_t)x_src % 8) == 0, DGNN_E_UNSUPPORTED,

@@ -238,16 +238,19 @@ def fused_layer_supported(c_in: int, c_out: int, f_e: int) -> bool:
 
 
 FUSED_ENABLED = True
+GEMM_F32, GEMM_BF16X3 = 0, 1
+# how the fused layer runs its dense part: exact-fp32 MFMA or the 3-way split-bf16 MFMA (fp32-class accuracy)
+GEMM_MODE = GEMM_BF16X3 if __import__("os").environ.get("DGNN_GEMM_MODE", "bf16x3") == "bf16x3" else GEMM_F32
 
 
-def sage_layer_fused_fwd(rowptr, src, n_dst, x_src, edge_attr_sorted, We, be, Wj, bj, Wi, scale, shift, relu):
+def sage_layer_fused_fwd(rowptr, src, n_dst, x_src, edge_attr_sorted, We, be, Wj, bj, Wi, scale, shift, relu, gemm_mode=None):
     _req(x_src, "x_src", dim=2)
     c_in, c_out = x_src.size(1), Wj.size(0)
     out = torch.empty((n_dst, c_out), dtype=torch.float32, device=x_src.device)
     check(lib().dgnn_sage_layer_fused_fwd(
         ptr(rowptr), ptr(src), n_dst, ptr(x_src), _ld(x_src), c_in, ptr(edge_attr_sorted), _ld(edge_attr_sorted), We.size(1),
         ptr(We), ptr(be), ptr(Wj), ptr(bj), ptr(Wi), ptr(scale), ptr(shift), int(bool(relu)), c_out, ptr(out), c_out,
-        stream_ptr()), "dgnn_sage_layer_fused_fwd")
+        GEMM_MODE if gemm_mode is None else gemm_mode, stream_ptr()), "dgnn_sage_layer_fused_fwd")
     return out
 
 

@@ -151,13 +151,16 @@ int dgnn_sage_aggregate_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const
  * layer): aggregate + lin_j + lin_i + BN(eval) + ReLU in one persistent launch; the aggregate
  * never leaves the CU.  Requires c_in <= 128, c_out in {64,128}, f_e == 20, edge rows in plan
  * order (edge_attr_sorted).  Returns DGNN_E_UNSUPPORTED otherwise (callers fall back to the
- * aggregate + linear pair above).
+ * aggregate + linear pair above).  gemm_mode selects how the dense part runs on the matrix cores.
  * ---------------------------------------------------------------------------------------------- */
+#define DGNN_GEMM_F32 0    /* v_mfma_f32_32x32x2_f32: bit-faithful fp32 fmaf chains */
+#define DGNN_GEMM_BF16X3 1 /* operands split exactly into 3 bf16 parts, 6 partial products on v_mfma_f32_32x32x16_bf16,
+                              fp32 accumulate: fp32-class accuracy (dropped terms <= 2^-25 relative) at 6/16 of the time */
 int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* src, int64_t n_dst, const float* x_src,
                               int64_t ldx, int c_in, const float* edge_attr_sorted, int64_t lde, int f_e,
                               const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
                               const float* scale, const float* shift, int relu, int c_out, float* out, int64_t ldo,
-                              void* stream);
+                              int gemm_mode, void* stream);
 
 /* Fused decoder, eval mode (reference :180-187 applied at :350-351):
  *   logits = W3 . relu((W0 . y + b0) * scale + shift) + b3,   y [M,k] -> out [M,n_out]

@@ -166,18 +166,20 @@ def test_batchnorm_train_eval_and_backward():
 
 
 # ---- whole model: golden vectors --------------------------------------------------------------------
-@pytest.mark.parametrize("fused", [True, False])
-def test_inference_layer_golden_f2(fused):
+@pytest.mark.parametrize("fused,mode", [(True, 0), (True, 1), (False, 0)])
+def test_inference_layer_golden_f2(fused, mode):
     from dgnn_amd import ops
     g = gold("static_f2_regular256.npz")
     net = hip_static()
     data = Config(x=torch.from_numpy(g["x"]).to(DEV), edge_attr=torch.from_numpy(g["edge_attr"]).to(DEV),
                   edge_index=torch.from_numpy(g["adjacencies"].T.astype(np.int64)).to(DEV))
     ops.FUSED_ENABLED = fused
+    old_mode, ops.GEMM_MODE = ops.GEMM_MODE, mode
     try:
         logits = net.inference_layer(data)
     finally:
         ops.FUSED_ENABLED = True
+        ops.GEMM_MODE = old_mode
     err = np.abs(logits.cpu().numpy() - g["logits"]).max()
     assert err <= TOL_LOGIT, err
     assert np.abs(logits.cpu().numpy().astype(np.float64) - g["logits64"]).max() <= TOL_LOGIT
@@ -373,3 +375,34 @@ def test_decoder_fused(M, n_out):
     ref = torch.relu((y.double() @ W0.double().t() + b0.double()) * sc.double() + sh.double()) @ W3.double().t() + b3.double()
     out = ops.decoder_fused_fwd(*(t.to(DEV) for t in (y, W0, b0, sc, sh, W3, b3)))
     assert rel_err(out, ref) < 3e-6
+
+
+@pytest.mark.parametrize("c_in,c_out", [(28, 64), (64, 128), (128, 128), (20, 128), (64, 64)])
+def test_fused_layer_gemm_modes_vs_fp64(c_in, c_out):
+    """The fused layer in exact-fp32 MFMA mode and in split-bf16 (3x3 -> 6 products) mode against an fp64
+    evaluation: both must sit at fp32 rounding level (the split mode drops only terms <= 2^-25 relative)."""
+    from dgnn_amd import ops
+    from dgnn_amd.graph import GraphPlan
+    from dgnn_amd.synthetic import delaunay_tet_graph
+    from oracle.pyg_semantics import propagate_mean
+    adj, _, _ = delaunay_tet_graph(1200, seed=c_in)
+    n = adj.shape[0] // 4
+    ei = torch.from_numpy(adj.T.astype(np.int64))
+    g = torch.Generator().manual_seed(c_out)
+    x = torch.randn(n, c_in, generator=g) * torch.exp(torch.randn(n, 1, generator=g))  # wide dynamic range
+    ea = torch.randn(4 * n, 20, generator=g)
+    We, be = torch.randn(c_in, 20, generator=g) * 0.3, torch.randn(c_in, generator=g)
+    Wj, Wi, bj = torch.randn(c_out, c_in, generator=g) * 0.2, torch.randn(c_out, c_in, generator=g) * 0.2, torch.randn(c_out, generator=g)
+    sc, sh = torch.rand(c_out, generator=g) + 0.5, torch.randn(c_out, generator=g)
+    phi = ea.double() @ We.double().t() + be.double()
+    a = propagate_mean(x.double(), n, ei, phi)
+    ref = torch.relu((a @ Wj.double().t() + bj.double() + x.double() @ Wi.double().t()) * sc.double() + sh.double())
+    plan = GraphPlan(ei.to(DEV), n, n)
+    eas = plan.sorted_edge_attr(ea.to(DEV))
+    errs = {}
+    for mode in (ops.GEMM_F32, ops.GEMM_BF16X3):
+        out = ops.sage_layer_fused_fwd(plan.rowptr, plan.src, n, x.to(DEV), eas, We.to(DEV), be.to(DEV), Wj.to(DEV), bj.to(DEV),
+                                       Wi.to(DEV), sc.to(DEV), sh.to(DEV), True, gemm_mode=mode)
+        errs[mode] = rel_err(out, ref)
+        assert errs[mode] < 3e-6, (mode, errs)
+    assert errs[ops.GEMM_BF16X3] < 3 * errs[ops.GEMM_F32] + 2e-7, errs
