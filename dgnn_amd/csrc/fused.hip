@@ -122,6 +122,21 @@ __device__ __forceinline__ void ld_row(float (&v)[CPL], const float* p) {
     }
 }
 
+// 16 bytes per lane, global -> LDS without a VGPR landing (LDS destination = wave-uniform base + lane*16).
+// The issuing wave must cover it with s_waitcnt vmcnt before reading the strip (hipcc does not track it).
+__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() would also drain vmcnt,
+// i.e. the next tile's loads that are meant to fly across the barrier (LDS-DMA counts as a pending LDS write).
+__device__ __forceinline__ void tile_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 template <int CIN_PAD, int COUT, int MODE>
 __global__ void __launch_bounds__(512, 2)
 k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, int64_t n_dst,
@@ -140,6 +155,7 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
 
     const int lane = lane_id(), w = wave_id_uniform();
     const int h = lane >> 5, l31 = lane & 31;
+    const int ldx32 = (int)ldx;  // host guarantees n * ldx < 2^31: row offsets in 32-bit scalar arithmetic
 
     // XCD-aware persistent schedule: XCD x owns tiles [x*per, (x+1)*per); its workgroups walk them together
     const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wg_per_xcd = (nwg + 7 - xcd) >> 3;
@@ -212,60 +228,61 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
 
     // state of the tile in flight
     float xd[TPW][CPL], xr[NQ][CPL];
-    f32x4 ev[NEV];
     bool regular = false;        // loads for the current tile are in flight (4-regular fast path)
-    // Index prefetch runs two tiles deep so that no scalar round trip sits in front of the row loads:
-    //   beg2  rowptr entries of tile it+2 (requested during P(it))
-    //   beg1  rowptr entries of tile it+1 (arrived during P(it-1)),  sidx1 its 4*TPW source ids
-    int beg1[TPW + 1], beg2[TPW + 1], sidx1[NQ];
+    // Index prefetch runs two tiles deep so that no index round trip sits in front of the row loads.  The
+    // indices live in VGPRs, one entry per lane (a single coalesced load each), and are turned into scalar row
+    // offsets with v_readlane when the row loads are issued -- no long-lived SGPR arrays, no SGPR spills.
+    //   vbeg2  lane r <= TPW : rowptr[i0(it+2) + r]      (requested during P(it))
+    //   vbeg1  same for tile it+1 (arrived during P(it-1));  vsrc1  lane q < NQ : src[beg1_0 + q]
+    int vbeg1 = 0, vbeg2 = 0, vsrc1 = 0;
     bool ok1 = false, ok2 = false;  // tile exists, is complete and (for ok1) 4-regular
 
     auto tile_of = [&](int64_t it) { return t_lo + slot + it * wg_per_xcd; };
-    auto load_rowptr = [&](int64_t it, int (&b)[TPW + 1]) -> bool {
+    auto load_rowptr = [&](int64_t it, int& vb) -> bool {
         if (it >= my_n) return false;
         const int64_t i0 = tile_of(it) * TILE + w * TPW;
         if (i0 + TPW > n_dst) return false;
-#pragma unroll
-        for (int r = 0; r <= TPW; ++r) b[r] = rowptr[i0 + r];
+        vb = rowptr[i0 + (lane < TPW ? lane : TPW)];
         return true;
     };
-    // beg1 is resident: decide regularity and request the source ids (wave-uniform -> scalar loads)
     auto load_src = [&]() {
         if (ok1) {
-#pragma unroll
-            for (int r = 0; r < TPW; ++r) ok1 = ok1 && (beg1[r + 1] - beg1[r] == 4);
-        }
-        if (ok1) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) sidx1[q] = src[beg1[0] + q];
+            const int b0 = __builtin_amdgcn_readfirstlane(vbeg1);
+            ok1 = __all(lane > TPW || vbeg1 == b0 + 4 * lane) != 0;  // every in-degree of this wave's tets is 4
+            if (ok1) vsrc1 = src[b0 + (lane < NQ ? lane : NQ - 1)];
         }
     };
-    // issue every load of this wave's tets of tile `it` (uses beg1/sidx1)
+    // issue every load of this wave's tets of tile `it` (uses vbeg1/vsrc1)
     auto issue_loads = [&](int64_t it) {
         regular = ok1;
         if (regular) {
-            const int64_t i0 = tile_of(it) * TILE + w * TPW;
-            const float* eab = ea + (int64_t)beg1[0] * lde;
+            const int i0 = (int)(tile_of(it) * TILE) + w * TPW;
+            const float* eab = ea + (int64_t)__builtin_amdgcn_readfirstlane(vbeg1) * lde;
+#pragma unroll
+            for (int r = 0; r < TPW; ++r) ld_row<CPL>(xd[r], x + (uint32_t)((i0 + r) * ldx32) + c0l);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                ld_row<CPL>(xr[q], x + (uint32_t)(__builtin_amdgcn_readlane(vsrc1, q) * ldx32) + c0l);
+            // edge-attribute block of this wave's tets: async DMA straight into its private LDS strip (issued last:
+            // hipcc answers any later wait on an ordinary load with vmcnt(0) while an LDS-DMA is in flight)
 #pragma unroll
             for (int q = 0; q < NEV; ++q) {
                 const int idx = q * 64 + lane;
-                ev[q] = *reinterpret_cast<const f32x4*>(eab + 4 * (idx < NV4 ? idx : 0));
+                glds16(eab + 4 * (idx < NV4 ? idx : 0), myea + q * 256);
             }
-#pragma unroll
-            for (int r = 0; r < TPW; ++r) ld_row<CPL>(xd[r], x + (i0 + r) * ldx + c0l);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) ld_row<CPL>(xr[q], x + (int64_t)sidx1[q] * ldx + c0l);
         }
     };
-    // shift the index pipeline by one tile: (beg2 -> beg1, request sidx1), request beg2 for tile it+2
+    // shift the index pipeline by one tile
     auto advance_idx = [&](int64_t it_next) {
         ok1 = ok2;
-#pragma unroll
-        for (int r = 0; r <= TPW; ++r) beg1[r] = beg2[r];
+        vbeg1 = vbeg2;
         load_src();
-        ok2 = load_rowptr(it_next + 1, beg2);
+        ok2 = load_rowptr(it_next + 1, vbeg2);
     };
 
+    ok1 = load_rowptr(0, vbeg1);
+    load_src();
+    ok2 = load_rowptr(1, vbeg2);
     // write one finished tet into the A-tile: columns [0,CIN_PAD) = mean row, [CIN_PAD,2*CIN_PAD) = own row
     auto put_row = [&](int buf, int row, const float (&av)[CPL], const float (&xv)[CPL]) {
         if (MODE == 0) {
@@ -311,9 +328,6 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
         }
     };
 
-    ok1 = load_rowptr(0, beg1);
-    load_src();
-    ok2 = load_rowptr(1, beg2);
     issue_loads(0);
     float mine[8];  // own half of the accumulators of the previous tile, finished after the next barrier
 #pragma unroll
@@ -325,14 +339,8 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
             const int64_t i0 = tile_of(it) * TILE + w * TPW;
             stamp(trace, trace_cap, it, w, 0);
             const bool was_regular = regular;
-            if (was_regular) {
-                // attribute block -> this wave's private LDS strip (read back as broadcasts)
-#pragma unroll
-                for (int q = 0; q < NEV; ++q) {
-                    const int idx = q * 64 + lane;
-                    if (idx < NV4) *reinterpret_cast<f32x4*>(myea + 4 * idx) = ev[q];
-                }
-            }
+            // rows and the LDS-DMA'd attribute strip of this tile: the wave's own counted wait orders the reads below
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             advance_idx(it + 1);  // index scalar loads fly under the VALU work below
             stamp(trace, trace_cap, it, w, 1);
             if (was_regular) {
@@ -399,10 +407,16 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
                 }
             }
             stamp(trace, trace_cap, it, w, 2);
+            // every read of the attribute strip must have returned before the next tile's LDS-DMA is issued (the DMA
+            // is not ordered against this wave's LDS queue and the compiler models it as touching 16 bytes only)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // the index loads issued at the start of this phase are consumed HERE (they landed long ago); otherwise the
+            // compiler waits for them later with vmcnt(0), draining the row loads that must fly across the barrier
+            asm volatile("" : "+v"(vbeg2), "+v"(vsrc1), "+v"(vbeg1));
             issue_loads(it + 1);  // in flight during the barrier wait and the whole matrix phase
             stamp(trace, trace_cap, it, w, 3);
         }
-        __syncthreads();  // A-tile `it` complete; partial sums of tile `it-1` complete
+        tile_barrier();  // A-tile `it` complete; partial sums of tile `it-1` complete
         stamp(trace, trace_cap, it, w, 4);
 
         if (it > 0) {
@@ -508,6 +522,7 @@ extern "C" int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* s
     DGNN_REQUIRE((scale == nullptr) == (shift == nullptr), DGNN_E_INVALID, "sage_layer_fused_fwd: scale/shift must come together");
     DGNN_REQUIRE(f_e == FE && lde == FE, DGNN_E_UNSUPPORTED, "sage_layer_fused_fwd: needs f_e == 20 and packed edge rows (lde == 20)");
     DGNN_REQUIRE(((uintptr_t)edge_attr_sorted % 16) == 0, DGNN_E_UNSUPPORTED, "sage_layer_fused_fwd: edge_attr must be 16-byte aligned");
+    DGNN_REQUIRE(n_dst * ldx < ((int64_t)1 << 31), DGNN_E_UNSUPPORTED, "sage_layer_fused_fwd: activations beyond 2^31 elements");
     DGNN_REQUIRE(c_in <= 128 && (c_out == 64 || c_out == 128), DGNN_E_UNSUPPORTED,
                  "sage_layer_fused_fwd: supports c_in <= 128 and c_out in {64,128} (got %d -> %d)", c_in, c_out);
 #define GO(CP, CO)                                                                                                              \
