@@ -347,23 +347,54 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
 #pragma unroll
                 for (int r = 0; r < TPW; ++r) {
                     float acc[CPL];
+                    // ILP form: the 4 edges of a tet advance together -> 4*CPL independent FMA chains (a single chain
+                    // issues at half rate because of the 4-cycle dependent latency).  The register-tight configuration
+                    // (bf16x3 at C=128) keeps the edge-serial form.  Either way each chain runs f-ascending and the
+                    // 4 products are summed in edge order, so the two forms are bit-identical.
+                    constexpr bool ILP = !(MODE == 1 && CIN_PAD == 128);
+                    if (ILP) {
+                        float p[4][CPL];
 #pragma unroll
-                    for (int j = 0; j < CPL; ++j) acc[j] = 0.f;
+                        for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float* ap = myea + (r * 4 + e) * FE;
-                        float A[FE];
+                            for (int j = 0; j < CPL; ++j) p[e][j] = bl[j];
 #pragma unroll
                         for (int f = 0; f < FE; f += 4) {
-                            const f32x4 t = *reinterpret_cast<const f32x4*>(ap + f);
-                            A[f] = t[0]; A[f + 1] = t[1]; A[f + 2] = t[2]; A[f + 3] = t[3];
+                            f32x4 Aq[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) Aq[e] = *reinterpret_cast<const f32x4*>(myea + (r * 4 + e) * FE + f);
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                                    for (int j = 0; j < CPL; ++j) p[e][j] = __fmaf_rn(wl[j][f + t], Aq[e][t], p[e][j]);
                         }
 #pragma unroll
                         for (int j = 0; j < CPL; ++j) {
-                            float p = bl[j];
+                            acc[j] = 0.f;
 #pragma unroll
-                            for (int f = 0; f < FE; ++f) p = __fmaf_rn(wl[j][f], A[f], p);
-                            acc[j] = __fadd_rn(acc[j], __fmul_rn(on ? xr[r * 4 + e][j] : 0.f, p));
+                            for (int e = 0; e < 4; ++e) acc[j] = __fadd_rn(acc[j], __fmul_rn(on ? xr[r * 4 + e][j] : 0.f, p[e][j]));
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < CPL; ++j) acc[j] = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float* ap = myea + (r * 4 + e) * FE;
+                            float A[FE];
+#pragma unroll
+                            for (int f = 0; f < FE; f += 4) {
+                                const f32x4 t = *reinterpret_cast<const f32x4*>(ap + f);
+                                A[f] = t[0]; A[f + 1] = t[1]; A[f + 2] = t[2]; A[f + 3] = t[3];
+                            }
+#pragma unroll
+                            for (int j = 0; j < CPL; ++j) {
+                                float p = bl[j];
+#pragma unroll
+                                for (int f = 0; f < FE; ++f) p = __fmaf_rn(wl[j][f], A[f], p);
+                                acc[j] = __fadd_rn(acc[j], __fmul_rn(on ? xr[r * 4 + e][j] : 0.f, p));
+                            }
                         }
                     }
                     float xv[CPL];
