@@ -189,8 +189,16 @@ def main():
         dom_ms = breakdown["layer3_ms"]
         algo = LAYER_BYTES[(128, 128)] * n_local
         achieved = algo / (dom_ms * 1e-3) / 1e9
+        # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
+        # gfx950 note + WRITE_SIZE); scaled by tets when the bench graph differs from the profiled one
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01b_traffic.json")))
+            traffic = round(tj["traffic_bytes_per_launch"] * n_local / 1010078)
+        except Exception:
+            pass
         roof = {"bound": "hbm", "kernel": "k_sage_fused<128,128> (layer 3)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(dom_ms, 4),
                 "whole_path_frac": round(value * BYTES_PER_TET / 1e9 / HBM_PEAK_GBS, 4)}
 

@@ -1,10 +1,14 @@
+# rocprofv3 passes for the round-1 bench (run on the GPU box through gpurun; outputs under gpurun_out/)
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-rocprofv3 -L 2>/dev/null | grep -E "^\s*(Name|name)|SQ_|TCC_|GRBM|FETCH|WRITE_SIZE|TCP_" | head -150 > gpurun_out/counters.txt
+T=${1:-r1b}
 B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r1_trace -- $B > gpurun_out/r1_trace.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d gpurun_out/r1_pmc1 -- $B > gpurun_out/r1_pmc1.log 2>&1
-rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS --output-format csv -d gpurun_out/r1_pmc2 -- $B > gpurun_out/r1_pmc2.log 2>&1
-rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/r1_pmc3 -- $B > gpurun_out/r1_pmc3.log 2>&1
-rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/r1_pmc4 -- $B > gpurun_out/r1_pmc4.log 2>&1
-ls -R gpurun_out | head -50
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${T}_trace -- $B > gpurun_out/${T}_trace.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d gpurun_out/${T}_pmc1 -- $B > gpurun_out/${T}_pmc1.log 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS --output-format csv -d gpurun_out/${T}_pmc2 -- $B > gpurun_out/${T}_pmc2.log 2>&1
+rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${T}_pmc3 -- $B > gpurun_out/${T}_pmc3.log 2>&1
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/${T}_pmc4 -- $B > gpurun_out/${T}_pmc4.log 2>&1
+python3 bench.py --steps 20 --warmup 5 > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
+python3 bench.py --steps 20 --warmup 5 --gemm-mode f32 --no-cpu-baseline > gpurun_out/${T}_bench_f32.json 2>> gpurun_out/${T}_bench.err
+python3 bench.py --steps 20 --warmup 5 --cached-plan --no-cpu-baseline > gpurun_out/${T}_bench_cachedplan.json 2>> gpurun_out/${T}_bench.err
+tail -c 600 gpurun_out/${T}_bench.json
