@@ -195,10 +195,11 @@ class SurfaceNet(nn.Module):
         bn = norm.module
         return ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
 
-    def _eval_layers(self, x, n_dst0, xe, plans, sorted_attr, only=None):
+    def _eval_layers(self, x, n_dst0, xe, plans, sorted_attr, only=None, out=None):
         """Eval-mode conv stack: per layer one fused launch when the widths allow it, else the
         aggregate + linear pair; BatchNorm(eval) and ReLU always ride in the GEMM epilogue.
-        `only=i` runs just layer i (the partitioned forward exchanges halos between layers)."""
+        `only=i` runs just layer i (the partitioned forward exchanges halos between layers), `out` then
+        optionally names the [>= n_dst, C_out] buffer to write into."""
         for i in (range(self.num_layers) if only is None else [only]):
             layer, plan = self.convs[i], plans[i]
             conv = layer[0]
@@ -210,14 +211,14 @@ class SurfaceNet(nn.Module):
             if simple and le.in_features == 20 and ops.fused_layer_supported(x.size(1), conv.lin_j.out_features, 20):
                 ea = plan.sorted_edge_attr(xe) if sorted_attr else xe
                 x = ops.sage_layer_fused_fwd(plan.rowptr, plan.src, plan.n_dst, x, ea, le.weight, le.bias, conv.lin_j.weight,
-                                             conv.lin_j.bias, conv.lin_i.weight, scale, shift, True)
+                                             conv.lin_j.bias, conv.lin_i.weight, scale, shift, True, out=out)
                 continue
             if simple:
                 ea = plan.sorted_edge_attr(xe) if sorted_attr else xe
                 a = ops.aggregate_fwd(plan.rowptr, plan.src, None if sorted_attr else plan.eid, plan.n_dst, x, ea, le.weight, le.bias)
             else:
                 a = Fn.aggregate(x, plan, **conv._filter_args(xe))
-            x = ops.linear_fwd(a, conv.lin_j.weight, x_dst, conv.lin_i.weight, conv.lin_j.bias, scale, shift, True)
+            x = ops.linear_fwd(a, conv.lin_j.weight, x_dst, conv.lin_i.weight, conv.lin_j.bias, scale, shift, True, out=out)
         return x
 
     def _eval_decoder(self, x):

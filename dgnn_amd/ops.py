@@ -146,7 +146,7 @@ def aggregate_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, da, edge_att
 
 
 # ---- dense --------------------------------------------------------------------------------------
-def linear_fwd(A1, W1, A2=None, W2=None, bias=None, scale=None, shift=None, relu=False):
+def linear_fwd(A1, W1, A2=None, W2=None, bias=None, scale=None, shift=None, relu=False, out=None):
     _req(A1, "A1", dim=2)
     W1 = _req(W1, "W1", dim=2).contiguous()
     M, n_out = A1.size(0), W1.size(0)
@@ -157,7 +157,10 @@ def linear_fwd(A1, W1, A2=None, W2=None, bias=None, scale=None, shift=None, relu
         W2 = _req(W2, "W2", dim=2).contiguous()
         if A2.size(0) != M or W2.size(0) != n_out or W2.size(1) != A2.size(1):
             raise ValueError("second operand shapes do not match")
-    out = torch.empty((M, n_out), dtype=torch.float32, device=A1.device)
+    if out is None:
+        out = torch.empty((M, n_out), dtype=torch.float32, device=A1.device)
+    elif out.size(0) < M or out.size(1) != n_out or out.stride(0) != n_out:
+        raise ValueError("out must be a contiguous [>= M, n_out] buffer")
     check(lib().dgnn_linear_fwd(
         ptr(A1), _ld(A1), A1.size(1), ptr(W1), W1.size(1),
         ptr(A2), _ld(A2) if A2 is not None else 0, A2.size(1) if A2 is not None else 0, ptr(W2), W2.size(1) if W2 is not None else 0,
@@ -243,10 +246,18 @@ GEMM_F32, GEMM_BF16X3 = 0, 1
 GEMM_MODE = GEMM_BF16X3 if __import__("os").environ.get("DGNN_GEMM_MODE", "bf16x3") == "bf16x3" else GEMM_F32
 
 
-def sage_layer_fused_fwd(rowptr, src, n_dst, x_src, edge_attr_sorted, We, be, Wj, bj, Wi, scale, shift, relu, gemm_mode=None):
+def sage_layer_fused_fwd(rowptr, src, n_dst, x_src, edge_attr_sorted, We, be, Wj, bj, Wi, scale, shift, relu, gemm_mode=None,
+                         out=None):
+    """`out` (optional): a [>= n_dst, c_out] buffer whose first n_dst rows receive the result (the partitioned
+    forward passes the next layer's [n_own + n_halo, C] activation buffer, so no copy is needed)."""
     _req(x_src, "x_src", dim=2)
     c_in, c_out = x_src.size(1), Wj.size(0)
-    out = torch.empty((n_dst, c_out), dtype=torch.float32, device=x_src.device)
+    if out is None:
+        out = torch.empty((n_dst, c_out), dtype=torch.float32, device=x_src.device)
+    else:
+        _req(out, "out", dim=2)
+        if out.size(0) < n_dst or out.size(1) != c_out or out.stride(0) != c_out:
+            raise ValueError("out must be a contiguous [>= n_dst, c_out] buffer")
     check(lib().dgnn_sage_layer_fused_fwd(
         ptr(rowptr), ptr(src), n_dst, ptr(x_src), _ld(x_src), c_in, ptr(edge_attr_sorted), _ld(edge_attr_sorted), We.size(1),
         ptr(We), ptr(be), ptr(Wj), ptr(bj), ptr(Wi), ptr(scale), ptr(shift), int(bool(relu)), c_out, ptr(out), c_out,

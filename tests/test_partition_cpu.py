@@ -67,7 +67,7 @@ def _worker(rank, world, port, out_dir):
     e_loc = torch.from_numpy(lp.edge_index)
     exchange = HaloExchange(lp, "cpu")
 
-    def layer_fn(i, h):
+    def layer_fn(i, h, out):
         blk = net.convs[i]
         return blk[2](blk[1](blk[0]((h, h[:lp.n_own]), ea_local, e_loc)))
 
@@ -99,3 +99,40 @@ def test_partitioned_oracle_forward_matches_single_process(world, tmp_path):
     assert not np.isnan(got).any()
     # same per-destination order; BLAS may pick different kernels for different row counts -> tiny tolerance
     assert np.abs(got - ref).max() <= 1e-5
+
+
+def _dp_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dgnn_amd.partition import allreduce_gradients
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 2))
+    g = torch.Generator().manual_seed(100 + rank)  # every rank sees its own shard
+    x, y = torch.randn(32, 8, generator=g), torch.randn(32, 2, generator=g)
+    ((net(x) - y) ** 2).mean().backward()
+    allreduce_gradients(net)
+    torch.save([p.grad.clone() for p in net.parameters()], os.path.join(out_dir, "g%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_dp_gradient_allreduce(tmp_path):
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_dp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    g0, g1 = (torch.load(os.path.join(str(tmp_path), "g%d.pt" % r)) for r in range(world))
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    # equals the mean of the per-shard gradients computed in one process
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 2))
+    acc = [torch.zeros_like(p) for p in net.parameters()]
+    for r in range(world):
+        net.zero_grad()
+        g = torch.Generator().manual_seed(100 + r)
+        x, y = torch.randn(32, 8, generator=g), torch.randn(32, 2, generator=g)
+        ((net(x) - y) ** 2).mean().backward()
+        for a, p in zip(acc, net.parameters()):
+            a += p.grad / world
+    for a, b in zip(acc, g0):
+        assert torch.allclose(a, b, atol=1e-7)

@@ -30,18 +30,10 @@ t = buf.cpu().numpy().reshape(NT, 12, 8).astype(np.float64)
 t0 = t[t > 0].min()
 t = np.where(t > 0, (t - t0) / 100.0, np.nan)  # wall_clock64 ticks at 100 MHz -> microseconds
 np.set_printoptions(linewidth=200, precision=2, suppress=True)
-# M waves (0..3): 0 at barrier, 1 released, 2 mfma done.  G waves (4..7): 0 start, 1 loads landed + idx advanced,
-# 2 rows written, 3 next loads issued, 4 released
-for it in range(8, 11):
-    print("iter", it)
-    print(" M w0: at_barrier %.2f released %.2f mfma_done %.2f" % tuple(t[it, 0, :3]))
-    for w in (4, 7):
-        print(" G w%d: start %.2f landed %.2f rows_done %.2f loads_issued %.2f released %.2f" % ((w,) + tuple(t[it, w, :5])))
+# uniform kernel phases: 0 P start, 1 loads landed + idx advanced, 2 rows written, 3 next loads issued, 4 barrier released, 5 MFMA done
 sl = slice(5, 35)
-print("tile period (us): %.2f" % np.nanmean(np.diff(t[sl, 0, 1])))
-print("M w0: barrier wait %.2f  mfma %.2f  epilogue(to next barrier arrival) %.2f" % (
-    np.nanmean(t[sl, 0, 1] - t[sl, 0, 0]), np.nanmean(t[sl, 0, 2] - t[sl, 0, 1]), np.nanmean(t[6:36, 0, 0] - t[5:35, 0, 2])))
-for w in (4, 7):
-    print("G w%d: wait-loads %.2f  gather-compute %.2f  issue-next %.2f  barrier wait %.2f" % (
+print("tile period (us): %.2f" % np.nanmean(np.diff(t[sl, 0, 4])))
+for w in (0, 3, 4, 7):
+    print("w%d: wait-loads %.2f  gather-compute %.2f  issue-next %.2f  barrier wait %.2f  epilogue+mfma %.2f" % (
         w, np.nanmean(t[sl, w, 1] - t[sl, w, 0]), np.nanmean(t[sl, w, 2] - t[sl, w, 1]), np.nanmean(t[sl, w, 3] - t[sl, w, 2]),
-        np.nanmean(t[sl, w, 4] - t[sl, w, 3])))
+        np.nanmean(t[sl, w, 4] - t[sl, w, 3]), np.nanmean(t[sl, w, 5] - t[sl, w, 4])))
