@@ -16,20 +16,23 @@
 //
 // Structure (512-thread workgroup = 8 wavefronts = 2 per SIMD, one workgroup per CU, persistent).
 // Every wavefront runs the same two-phase loop over the workgroup's tiles of TILE destination tets:
-//   P  gather/filter phase (VALU): the wave owns TILE/8 tets.  Their 4 neighbour rows, own rows and the
-//      contiguous edge-attribute block were requested one tile ahead, so they are (mostly) resident.
-//      phi = We.A + be is 20 FMAs per channel with We in registers and A broadcast from a private LDS
-//      strip; products and the in-order 4-term sum reproduce the reference's scatter order.  The mean
-//      row and the tet's own row go side by side into the LDS A-tile [TILE][2*CIN_PAD].  Then the wave
-//      issues all loads of its tets of the NEXT tile (indices were prefetched as scalars) and hits
-//      the workgroup barrier.
-//   C  matrix phase (MFMA): [a | x_i] . [Wj | Wi]^T on v_mfma_f32_32x32x2_f32.  The 8 waves split the
-//      tile as (32-column slice) x (K half: the `a` half with Wj, the `x_i` half with Wi) [x row group],
-//      so a wave keeps only CIN_PAD/2 weight VGPRs for the whole launch and streams its A operand from
-//      LDS with one ds_read_b128 per 4 MFMAs.  The two K-halves exchange half of their accumulators
-//      through LDS; each finishes 8 of the 16 accumulator rows (bias, BatchNorm scale/shift, ReLU) and
-//      stores them -- one tile later, right after the next barrier, so that one barrier per tile
-//      orders both the A-tile hand-off and the partial-sum exchange.
+//   P  gather/filter phase (VALU): the wave owns TILE/8 tets.  Their 4 neighbour rows and own rows were
+//      requested one tile ahead (indices two tiles ahead: one coalesced VGPR load each, turned into scalar
+//      row offsets by v_readlane), the contiguous edge-attribute block arrived by LDS-DMA in a private strip.
+//      phi = We.A + be is 20 FMAs per channel with We in registers and A broadcast from the strip;
+//      products and the in-order 4-term sum reproduce the reference's scatter order.  The mean row and the
+//      tet's own row go side by side into the LDS A-tile.  Then the wave issues all loads of its tets of
+//      the NEXT tile and hits the workgroup barrier (LDS traffic only; the loads fly across it).
+//   C  matrix phase (MFMA): [a | x_i] . [Wj | Wi]^T.  The 8 waves split the tile as (32-column slice) x
+//      (K half: the `a` half with Wj, the `x_i` half with Wi) [x row group], so a wave keeps only its half-K
+//      weights in registers for the whole launch and streams its A operand from LDS.  Two modes:
+//        MODE 0  v_mfma_f32_32x32x2_f32: bit-faithful fp32 fmaf chains;
+//        MODE 1  operands split exactly into 3 bf16 parts, the 6 partial products of weight >= 2^-18 on
+//                v_mfma_f32_32x32x16_bf16 with fp32 accumulation (dropped terms <= 2^-25: fp32-class result
+//                at 6/16 of the matrix time).
+//      The two K-halves exchange half of their accumulators through LDS; each finishes 8 of the 16
+//      accumulator rows (bias, BatchNorm scale/shift, ReLU) and stores them -- one tile later, right after
+//      the next barrier, so that one barrier per tile orders both the A-tile hand-off and the exchange.
 // HBM latency of tile t+1 is therefore covered by the whole matrix phase of tile t.
 //
 // tile -> workgroup map is XCD-aware: workgroup b runs on XCD b%8 (observed placement; used for L2

@@ -406,3 +406,33 @@ def test_fused_layer_gemm_modes_vs_fp64(c_in, c_out):
         errs[mode] = rel_err(out, ref)
         assert errs[mode] < 3e-6, (mode, errs)
     assert errs[ops.GEMM_BF16X3] < 3 * errs[ops.GEMM_F32] + 2e-7, errs
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_fused_layers_row_level_on_larger_graph(mode):
+    """Row-level check of every fused layer on a 134k-tet graph (thousands of tiles per launch, several
+    launches): no output row may deviate from the unfused aggregate + GEMM path.  This is the detector that
+    caught a rare single-row race in an abandoned wave-specialised variant (tools/dbg_rows.py)."""
+    from dgnn_amd import ops
+    from dgnn_amd.graph import GraphPlan
+    from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal
+    net = hip_static()
+    adj, _, _ = delaunay_tet_graph(20000, 3)
+    n = adj.shape[0] // 4
+    x = hashed_normal(np.arange(n), 29, seed=1, device=DEV)
+    ea = hashed_normal(np.arange(4 * n), 20, seed=2, device=DEV)
+    plan = GraphPlan(torch.from_numpy(adj.T.astype(np.int64)).to(DEV), n, n)
+    acts = [x[:, 1:]]
+    for i in range(4):
+        acts.append(net._eval_layers_one(i, acts[-1], ea, plan))
+    old, ops.GEMM_MODE = ops.GEMM_MODE, mode
+    try:
+        for i in range(4):
+            for rep in range(4):
+                hin = acts[i].clone() if i > 0 else acts[i]
+                o = net._eval_layers(hin, n, ea, [plan] * 4, True, only=i)
+                ref = acts[i + 1]
+                bad = ((o - ref).abs() > 2e-3 * ref.abs().max()).any(1).nonzero().flatten()
+                assert bad.numel() == 0, (i, rep, bad[:8].tolist())
+    finally:
+        ops.GEMM_MODE = old
