@@ -41,48 +41,18 @@
 //
 // LDS A-tile row stride is K+4 floats: the 16-lane groups of ds_read_b128 then hit 16 distinct 16-byte
 // slots (conflict free) and rows stay 16-byte aligned.
-#include "common.h"
+#include "fused_common.h"
 
-// Optional phase tracing (debug): workgroup 0 stamps wall_clock64() at phase boundaries into a caller
-// buffer registered with dgnn_debug_trace_buffer(); NULL (default) disables it.
-static int64_t* g_trace_buf = nullptr;
-static int64_t g_trace_cap = 0;
+int64_t* g_dgnn_trace_buf = nullptr;
+int64_t g_dgnn_trace_cap = 0;
 extern "C" int dgnn_debug_trace_buffer(int64_t* dev_buf, int64_t n) {
-    g_trace_buf = dev_buf;
-    g_trace_cap = n;
+    g_dgnn_trace_buf = dev_buf;
+    g_dgnn_trace_cap = n;
     return DGNN_OK;
 }
 
 namespace {
-
-constexpr int FE = 20;
-constexpr int NWAVE = 8;
-
-// slot layout: trace[(it * 12 + wave) * 8 + phase]
-__device__ __forceinline__ void stamp(int64_t* trace, int64_t cap, int64_t it, int w, int phase) {
-    if (trace && blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
-        const int64_t i = (it * 12 + w) * 8 + phase;
-        if (i < cap) trace[i] = (int64_t)wall_clock64();
-    }
-}
-
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-
-// Exact 3-way split of two fp32 values into packed bf16 pairs: x = hi + mid + lo with each part a bf16
-// (8 significant bits, same exponent range), rounding to nearest at every step (v_cvt_pk_bf16_f32).
-// Residuals are exact in fp32, so the three parts carry all 24 significand bits.
-__device__ __forceinline__ void split3(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
-    const bf16x2_t h = __builtin_convertvector(f32x2_t{x0, x1}, bf16x2_t);
-    hi = __builtin_bit_cast(uint32_t, h);
-    const float r0 = x0 - __builtin_bit_cast(float, hi << 16), r1 = x1 - __builtin_bit_cast(float, hi & 0xFFFF0000u);
-    const bf16x2_t m = __builtin_convertvector(f32x2_t{r0, r1}, bf16x2_t);
-    mid = __builtin_bit_cast(uint32_t, m);
-    const float s0 = r0 - __builtin_bit_cast(float, mid << 16), s1 = r1 - __builtin_bit_cast(float, mid & 0xFFFF0000u);
-    const bf16x2_t l = __builtin_convertvector(f32x2_t{s0, s1}, bf16x2_t);
-    lo = __builtin_bit_cast(uint32_t, l);
-}
+using namespace fused;
 
 // MODE 0: fp32 MFMA (v_mfma_f32_32x32x2_f32), bit-faithful fp32 fmaf chains.
 // MODE 1: split-bf16 MFMA (v_mfma_f32_32x32x16_bf16): both operands are split exactly into 3 bf16 parts and the
@@ -110,35 +80,6 @@ struct FusedCfg {
     static constexpr int RED_FLOATS = NWAVE * 8 * 64;  // one partial-sum exchange buffer
     static constexpr int SMEM_FLOATS = 2 * A_FLOATS + NWAVE * EA_PAD + 2 * RED_FLOATS;
 };
-
-// Row fragment load.  The caller passes an address that is valid for every lane (inactive lanes are
-// clamped to channel 0), so the load is unconditional -- no exec-mask branch around it -- and inactive
-// lanes are zeroed by a select at the point of use.
-template <int CPL>
-__device__ __forceinline__ void ld_row(float (&v)[CPL], const float* p) {
-    if (CPL == 2) {
-        const float2 t = *reinterpret_cast<const float2*>(p);
-        v[0] = t.x;
-        v[CPL - 1] = t.y;
-    } else {
-        v[0] = *p;
-    }
-}
-
-// 16 bytes per lane, global -> LDS without a VGPR landing (LDS destination = wave-uniform base + lane*16).
-// The issuing wave must cover it with s_waitcnt vmcnt before reading the strip (hipcc does not track it).
-__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-// workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() would also drain vmcnt,
-// i.e. the next tile's loads that are meant to fly across the barrier (LDS-DMA counts as a pending LDS write).
-__device__ __forceinline__ void tile_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
 
 template <int CIN_PAD, int COUT, int MODE>
 __global__ void __launch_bounds__(512, 2)
@@ -536,11 +477,16 @@ int launch_fused(const int32_t* rowptr, const int32_t* src, int64_t n_dst, const
     int grid = (int)(ntiles < DGNN_NUM_CU ? ntiles : DGNN_NUM_CU);
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL((k_sage_fused<CIN_PAD, COUT, MODE>), dim3(grid), dim3(512), smem, stream, rowptr, src, n_dst, x, ldx, c_in,
-                       ea, lde, We, be, Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles, g_trace_buf, g_trace_cap);
+                       ea, lde, We, be, Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles, g_dgnn_trace_buf, g_dgnn_trace_cap);
     return dgnn_check_launch("sage_layer_fused_fwd");
 }
 
 }  // namespace
+
+int dgnn_sage_layer_fused_mfma_try(const int32_t* rowptr, const int32_t* src, int64_t n_dst, const float* x_src, int64_t ldx,
+                                   int c_in, const float* edge_attr_sorted, int64_t lde, const float* We, const float* be,
+                                   const float* Wj, const float* bj, const float* Wi, const float* scale, const float* shift,
+                                   int relu, int c_out, float* out, int64_t ldo, hipStream_t stream);  // fused_mfma.hip
 
 extern "C" int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* src, int64_t n_dst, const float* x_src,
                                          int64_t ldx, int c_in, const float* edge_attr_sorted, int64_t lde, int f_e,
@@ -549,7 +495,8 @@ extern "C" int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* s
                                          int gemm_mode, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DGNN_REQUIRE(n_dst >= 0 && c_in > 0 && c_out > 0, DGNN_E_INVALID, "sage_layer_fused_fwd: bad sizes");
-    DGNN_REQUIRE(gemm_mode == DGNN_GEMM_F32 || gemm_mode == DGNN_GEMM_BF16X3, DGNN_E_INVALID, "sage_layer_fused_fwd: bad gemm_mode %d", gemm_mode);
+    DGNN_REQUIRE(gemm_mode >= DGNN_GEMM_F32 && gemm_mode <= DGNN_GEMM_BF16X3_FILTER, DGNN_E_INVALID,
+                 "sage_layer_fused_fwd: bad gemm_mode %d", gemm_mode);
     if (n_dst == 0) return DGNN_OK;
     DGNN_REQUIRE(rowptr && src && x_src && edge_attr_sorted && We && be && Wj && Wi && out, DGNN_E_INVALID,
                  "sage_layer_fused_fwd: null pointer");
@@ -559,6 +506,12 @@ extern "C" int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* s
     DGNN_REQUIRE(n_dst * ldx < ((int64_t)1 << 31), DGNN_E_UNSUPPORTED, "sage_layer_fused_fwd: activations beyond 2^31 elements");
     DGNN_REQUIRE(c_in <= 128 && (c_out == 64 || c_out == 128), DGNN_E_UNSUPPORTED,
                  "sage_layer_fused_fwd: supports c_in <= 128 and c_out in {64,128} (got %d -> %d)", c_in, c_out);
+    if (gemm_mode == DGNN_GEMM_BF16X3_FILTER) {
+        const int rc = dgnn_sage_layer_fused_mfma_try(rowptr, src, n_dst, x_src, ldx, c_in, edge_attr_sorted, lde, We, be, Wj, bj, Wi,
+                                                      scale, shift, relu, c_out, out, ldo, stream);
+        if (rc != DGNN_E_UNSUPPORTED) return rc;
+        gemm_mode = DGNN_GEMM_BF16X3;  // shape not covered by the all-MFMA variant
+    }
 #define GO(CP, CO)                                                                                                              \
     do {                                                                                                                        \
         if (gemm_mode == DGNN_GEMM_F32)                                                                                         \

@@ -1,0 +1,424 @@
+// Fused SAGE inference layer, "all matrix core" variant (gemm_mode DGNN_GEMM_BF16X3_FILTER):
+// the filter MLP phi = We.A + be runs on v_mfma_f32_16x16x32_bf16 as well, not on the VALU.
+//
+// Why: MFMA and VALU work serialise on a SIMD (fused.hip header), and in the split-bf16 variant the 20-tap
+// filter is ~70 % of the remaining VALU instructions.  As a matrix product it is tiny and cheap:
+//     PHI[16 edges x 16 channels] = A[16 edges x 32] . B[32 x 16 channels]
+// with A = the wave's 16 edge-attribute rows (k < 20 attributes, k = 20 the constant 1 that carries the bias,
+// rest 0) and B = We^T | be.  Both are split exactly into 3 bf16 parts and the 6 partial products of weight
+// >= 2^-18 are accumulated in fp32 -- the same fp32-class scheme as the dense part (fused.hip MODE 1).
+//
+// The MFMA accumulator layout does the segmented reduction for free: in v_mfma_f32_16x16x32_bf16 lane l holds
+// D[row = 4*(l>>4) + r][col = l&15] for r = 0..3 -- rows 4t..4t+3 are exactly the 4 in-edges of the wave's
+// t-th tet (edges are in plan order), so one lane owns all 4 messages of (tet t = l>>4, channel) and the
+// mean is an in-lane, in-order 4-term sum (the reference's scatter order), no shuffles.
+// Column block cb of lane column j is channel NB*j + cb (NB = C_in/16 blocks), so a lane's channels over
+// all blocks are NB contiguous floats: its x rows are fetched as one 16/32-byte piece per row, and its
+// outputs form whole 8-k octets of the split-bf16 A-tile (3 x ds_write_b128 per row segment).
+//
+// Everything else is fused.hip's uniform two-phase loop: loads of tile t+1 (neighbour rows, own rows,
+// LDS-DMA of the attribute block) are issued before the single per-tile barrier and land under the matrix
+// phase; the dense part is the K-split 32x32x16 split-bf16 product with the delayed epilogue.
+#include "fused_common.h"
+
+namespace {
+using namespace fused;
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int CIN_PAD, int COUT>
+struct Cfg2 {
+    static constexpr int K = 2 * CIN_PAD;
+    static constexpr int NSLICE = COUT / 32;
+    static constexpr int RG = NWAVE / (2 * NSLICE);
+    static constexpr int TILE = 32 * RG;
+    static constexpr int ROWB = (K / 8) * 48 + 16;       // A-tile row: K/8 octets of [hi|mid|lo] 16 B each + pad
+    static constexpr int A_BYTES = TILE * ROWB;
+    static constexpr int TPW = TILE / NWAVE;              // tets per wave (4 or 8)
+    static constexpr int RB = TPW / 4;                    // 16-edge row blocks per wave
+    static constexpr int NQ = TPW * 4;                    // edges per wave
+    static constexpr int NB = CIN_PAD / 16;               // column blocks = contiguous channels per lane (8, 4, 2)
+    static constexpr int EA_BYTES = NQ * FE * 4;          // 1280 or 2560: whole KiB by 16-B DMA, the rest by 4-B DMA
+    static constexpr int EA_FULL = EA_BYTES / 1024, EA_TAIL = (EA_BYTES % 1024) / 256;
+    static constexpr int BP_BYTES = NB * 3 * 768;         // [cb][part][g<3][j<16] x 16 B filter operand parts
+    static constexpr int RED_BYTES = NWAVE * 8 * 64 * 4;
+    static constexpr int SMEM_BYTES = 2 * A_BYTES + NWAVE * EA_BYTES + 2 * RED_BYTES + BP_BYTES;
+    static constexpr int NWB = CIN_PAD / 16;              // dense part: k-steps of 16 per K half
+    static_assert(EA_BYTES % 256 == 0, "attribute block must be DMA-able");
+};
+
+template <int NB>
+__device__ __forceinline__ void ld_vec(float (&v)[NB], const float* p, bool vec) {
+    if (NB == 8 && vec) {
+        const f32x4_t a = *reinterpret_cast<const f32x4_t*>(p), b = *reinterpret_cast<const f32x4_t*>(p + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[(4 + i) % NB] = b[i]; }
+    } else if (NB == 4 && vec) {
+        const f32x4_t a = *reinterpret_cast<const f32x4_t*>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i % NB] = a[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) v[i] = p[i];
+    }
+}
+
+template <int CIN_PAD, int COUT>
+__global__ void __launch_bounds__(512, 2)
+k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, int64_t n_dst,
+                  const float* __restrict__ x, int64_t ldx, int c_in, const float* __restrict__ ea, int64_t lde,
+                  const float* __restrict__ We, const float* __restrict__ be, const float* __restrict__ Wj,
+                  const float* __restrict__ bj, const float* __restrict__ Wi, const float* __restrict__ scale,
+                  const float* __restrict__ shift, int relu, float* __restrict__ out, int64_t ldo, int64_t ntiles,
+                  int xvec, int64_t* __restrict__ trace, int64_t trace_cap) {
+    using C = Cfg2<CIN_PAD, COUT>;
+    constexpr int ROWB = C::ROWB, TILE = C::TILE, TPW = C::TPW, RB = C::RB, NQ = C::NQ, NB = C::NB, NWB = C::NWB;
+    extern __shared__ __attribute__((aligned(16))) char smem2[];
+    char* const abuf = smem2;                                        // [2][A_BYTES]
+    char* const eabuf = smem2 + 2 * C::A_BYTES;                      // [NWAVE][EA_BYTES] fp32 attribute strips
+    float* const redbuf = reinterpret_cast<float*>(eabuf + NWAVE * C::EA_BYTES);  // [2][NWAVE][8][64]
+    char* const bpbuf = reinterpret_cast<char*>(redbuf) + 2 * C::RED_BYTES;       // filter operand parts
+
+    const int lane = lane_id(), w = wave_id_uniform();
+    const int h = lane >> 5, l31 = lane & 31;
+    const int jcol = lane & 15, tq = lane >> 4;  // filter phase: channel group / tet within a row block; also MFMA (col, k-group)
+    const int ldx32 = (int)ldx;
+    const bool vec = xvec != 0;
+
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wg_per_xcd = (nwg + 7 - xcd) >> 3;
+    const int64_t per = (ntiles + 7) / 8;
+    const int64_t t_lo = xcd * per, t_hi = min(ntiles, t_lo + per);
+    int64_t my_n = 0;
+    if (t_lo + slot < t_hi) my_n = (t_hi - t_lo - slot + wg_per_xcd - 1) / wg_per_xcd;
+    auto tile_of = [&](int64_t it) { return t_lo + slot + it * wg_per_xcd; };
+
+    // ---- filter operand B = [We^T ; be ; 0] split in 3 bf16 parts -> LDS, once per launch.
+    // entry (cb, g, j): channel c = NB*j + cb, k = 8g .. 8g+7 (g < 3; the k-group 3 of the MFMA is all zero)
+    for (int e = threadIdx.x; e < NB * 48; e += blockDim.x) {
+        const int cb = e / 48, gj = e - cb * 48, g = gj >> 4, j = gj & 15;
+        const int c = NB * j + cb;
+        uint32_t ph[4], pm[4], pl[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            float v[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = 8 * g + 2 * d + u;
+                v[u] = 0.f;
+                if (c < c_in) v[u] = k < FE ? We[(int64_t)c * FE + k] : (k == FE ? be[c] : 0.f);
+            }
+            split3(v[0], v[1], ph[d], pm[d], pl[d]);
+        }
+        uint4* dst = reinterpret_cast<uint4*>(bpbuf + ((cb * 3) * 48 + gj) * 16);
+        dst[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+        dst[48] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+        dst[96] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+    }
+
+    // ---- dense-phase role: (column slice cs, K half kh, row group rg); half-K weights resident as 3 bf16 parts
+    const int cs = w % C::NSLICE, kh = (w / C::NSLICE) & 1, rg = w / (2 * C::NSLICE);
+    const int col = cs * 32 + l31;
+    const int partner = w ^ C::NSLICE;
+    bf16x8 wb[NWB][3];
+    {
+        const float* Wsrc = kh ? Wi : Wj;
+#pragma unroll
+        for (int S = 0; S < NWB; ++S) {
+            uint32_t ph[4], pm[4], pl[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int k = 16 * S + 8 * h + 2 * d;
+                const float v0 = Wsrc[(int64_t)col * c_in + (k < c_in ? k : 0)];
+                const float v1 = Wsrc[(int64_t)col * c_in + (k + 1 < c_in ? k + 1 : 0)];
+                split3(k < c_in ? v0 : 0.f, k + 1 < c_in ? v1 : 0.f, ph[d], pm[d], pl[d]);
+            }
+            wb[S][0] = pack8(ph);
+            wb[S][1] = pack8(pm);
+            wb[S][2] = pack8(pl);
+        }
+    }
+    const float bb = bj ? bj[col] : 0.f;
+    const float sc = scale ? scale[col] : 1.f;
+    const float sh = scale ? shift[col] : 0.f;
+    const bool has_scale = scale != nullptr;
+    __syncthreads();  // filter operand parts visible
+
+    // ---- filter-phase role
+    const int c0 = NB * jcol;            // this lane's NB contiguous channels
+    const bool on = c0 < c_in;           // c_in is a multiple of NB (host-checked)
+    const int c0l = on ? c0 : 0;
+    float* const myea = reinterpret_cast<float*>(eabuf + w * C::EA_BYTES);
+
+    float xd[RB][NB], xr[RB][4][NB];
+    bool regular = false;
+    int vbeg1 = 0, vbeg2 = 0, vsrc1 = 0;  // index pipeline, see fused.hip
+    bool ok1 = false, ok2 = false;
+
+    auto load_rowptr = [&](int64_t it, int& vb) -> bool {
+        if (it >= my_n) return false;
+        const int64_t i0 = tile_of(it) * TILE + w * TPW;
+        if (i0 + TPW > n_dst) return false;
+        vb = rowptr[i0 + (lane < TPW ? lane : TPW)];
+        return true;
+    };
+    auto load_src = [&]() {
+        if (ok1) {
+            const int b0 = __builtin_amdgcn_readfirstlane(vbeg1);
+            ok1 = __all(lane > TPW || vbeg1 == b0 + 4 * lane) != 0;
+            if (ok1) vsrc1 = src[b0 + (lane < NQ ? lane : NQ - 1)];
+        }
+    };
+    auto issue_loads = [&](int64_t it) {
+        regular = ok1;
+        if (regular) {
+            const int i0 = (int)(tile_of(it) * TILE) + w * TPW;
+            const float* eab = ea + (int64_t)__builtin_amdgcn_readfirstlane(vbeg1) * lde;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int tl = rb * 4 + tq;  // this lane's tet within the wave
+                ld_vec<NB>(xd[rb], x + (uint32_t)((i0 + tl) * ldx32) + c0l, vec);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int s_ = __shfl(vsrc1, tl * 4 + r);
+                    ld_vec<NB>(xr[rb][r], x + (uint32_t)(s_ * ldx32) + c0l, vec);
+                }
+            }
+            // attribute block of this wave's tets: LDS-DMA into the private strip (issued last, see fused.hip)
+#pragma unroll
+            for (int q = 0; q < C::EA_FULL; ++q) glds16(eab + q * 256 + lane * 4, myea + q * 256);
+#pragma unroll
+            for (int q = 0; q < C::EA_TAIL; ++q) glds4(eab + C::EA_FULL * 256 + q * 64 + lane, myea + C::EA_FULL * 256 + q * 64);
+        }
+    };
+    auto advance_idx = [&](int64_t it_next) {
+        ok1 = ok2;
+        vbeg1 = vbeg2;
+        load_src();
+        ok2 = load_rowptr(it_next + 1, vbeg2);
+    };
+    // one finished (tet row, NB channels) segment -> A-tile: columns [c0, c0+NB) of the mean half and of the own-row half
+    auto put_seg = [&](int buf, int row, const float (&av)[NB], const float (&xv)[NB]) {
+        char* dst = abuf + buf * C::A_BYTES + row * ROWB + (c0 >> 3) * 48 + (c0 & 7) * 2;
+        char* dsx = dst + (CIN_PAD / 8) * 48;
+        uint32_t ph[NB / 2], pm[NB / 2], pl[NB / 2], qh[NB / 2], qm[NB / 2], ql[NB / 2];
+#pragma unroll
+        for (int d = 0; d < NB / 2; ++d) {
+            split3(av[2 * d], av[2 * d + 1], ph[d], pm[d], pl[d]);
+            split3(xv[2 * d], xv[2 * d + 1], qh[d], qm[d], ql[d]);
+        }
+        if (NB == 8) {
+            *reinterpret_cast<uint4*>(dst) = make_uint4(ph[0], ph[1], ph[2 % (NB / 2)], ph[3 % (NB / 2)]);
+            *reinterpret_cast<uint4*>(dst + 16) = make_uint4(pm[0], pm[1], pm[2 % (NB / 2)], pm[3 % (NB / 2)]);
+            *reinterpret_cast<uint4*>(dst + 32) = make_uint4(pl[0], pl[1], pl[2 % (NB / 2)], pl[3 % (NB / 2)]);
+            *reinterpret_cast<uint4*>(dsx) = make_uint4(qh[0], qh[1], qh[2 % (NB / 2)], qh[3 % (NB / 2)]);
+            *reinterpret_cast<uint4*>(dsx + 16) = make_uint4(qm[0], qm[1], qm[2 % (NB / 2)], qm[3 % (NB / 2)]);
+            *reinterpret_cast<uint4*>(dsx + 32) = make_uint4(ql[0], ql[1], ql[2 % (NB / 2)], ql[3 % (NB / 2)]);
+        } else if (NB == 4) {
+            *reinterpret_cast<uint2*>(dst) = make_uint2(ph[0], ph[1 % (NB / 2)]);
+            *reinterpret_cast<uint2*>(dst + 16) = make_uint2(pm[0], pm[1 % (NB / 2)]);
+            *reinterpret_cast<uint2*>(dst + 32) = make_uint2(pl[0], pl[1 % (NB / 2)]);
+            *reinterpret_cast<uint2*>(dsx) = make_uint2(qh[0], qh[1 % (NB / 2)]);
+            *reinterpret_cast<uint2*>(dsx + 16) = make_uint2(qm[0], qm[1 % (NB / 2)]);
+            *reinterpret_cast<uint2*>(dsx + 32) = make_uint2(ql[0], ql[1 % (NB / 2)]);
+        } else {
+            *reinterpret_cast<uint32_t*>(dst) = ph[0];
+            *reinterpret_cast<uint32_t*>(dst + 16) = pm[0];
+            *reinterpret_cast<uint32_t*>(dst + 32) = pl[0];
+            *reinterpret_cast<uint32_t*>(dsx) = qh[0];
+            *reinterpret_cast<uint32_t*>(dsx + 16) = qm[0];
+            *reinterpret_cast<uint32_t*>(dsx + 32) = ql[0];
+        }
+    };
+
+    ok1 = load_rowptr(0, vbeg1);
+    load_src();
+    ok2 = load_rowptr(1, vbeg2);
+    issue_loads(0);
+    float mine[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) mine[r] = 0.f;
+
+    for (int64_t it = 0; it <= my_n; ++it) {
+        if (it < my_n) {
+            // ================================================================ P: filter on the matrix cores + mean
+            const int64_t i0 = tile_of(it) * TILE + w * TPW;
+            stamp(trace, trace_cap, it, w, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // rows + LDS-DMA'd strip of this tile
+            const bool was_regular = regular;
+            advance_idx(it + 1);
+            stamp(trace, trace_cap, it, w, 1);
+            if (was_regular) {
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    // A operand: lane (edge i = lane&15, k-group g = lane>>4) holds attributes 8g..8g+7 of its edge;
+                    // k = 20 is the constant 1 multiplying the bias row, everything beyond is 0
+                    const float* er = myea + (rb * 16 + jcol) * FE;
+                    const f32x4_t q0 = *reinterpret_cast<const f32x4_t*>(er + 8 * (tq < 2 ? tq : 2));
+                    const f32x4_t q1 = *reinterpret_cast<const f32x4_t*>(er + 8 * (tq < 1 ? tq : 1) + 4);
+                    float av[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        av[i] = tq < 3 ? q0[i] : 0.f;
+                        av[4 + i] = tq < 2 ? q1[i] : 0.f;
+                    }
+                    if (tq == 2) av[4] = 1.0f;
+                    uint32_t ph[4], pm[4], pl[4];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) split3(av[2 * d], av[2 * d + 1], ph[d], pm[d], pl[d]);
+                    const bf16x8 ah = pack8(ph), am = pack8(pm), al = pack8(pl);
+
+                    float aout[NB], xv[NB];
+#pragma unroll
+                    for (int cb = 0; cb < NB; ++cb) {
+                        const char* bp = bpbuf + ((cb * 3) * 48 + (tq < 3 ? tq : 0) * 16 + jcol) * 16;
+                        uint4 u0 = *reinterpret_cast<const uint4*>(bp), u1 = *reinterpret_cast<const uint4*>(bp + 768),
+                              u2 = *reinterpret_cast<const uint4*>(bp + 1536);
+                        if (tq == 3) u0 = u1 = u2 = make_uint4(0, 0, 0, 0);
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, u0), bm = __builtin_bit_cast(bf16x8, u1),
+                                     bl = __builtin_bit_cast(bf16x8, u2);
+                        f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d, 0, 0, 0);
+                        // d[r] = phi of edge 4*tq + r (the r-th in-edge of this lane's tet), channel c0 + cb
+                        float a = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) a = __fadd_rn(a, __fmul_rn(xr[rb][r][cb], d[r]));
+                        aout[cb] = on ? a * 0.25f : 0.f;
+                        xv[cb] = on ? xd[rb][cb] : 0.f;
+                    }
+                    put_seg((int)(it & 1), w * TPW + rb * 4 + tq, aout, xv);
+                }
+            } else {
+                // generic path (any in-degree, tile tail): plain fp32 per lane, one edge at a time (rare)
+#pragma unroll 1
+                for (int rb = 0; rb < RB; ++rb) {
+                    const int64_t i = i0 + rb * 4 + tq;
+                    float aout[NB], xv[NB];
+#pragma unroll
+                    for (int cb = 0; cb < NB; ++cb) aout[cb] = xv[cb] = 0.f;
+                    if (i < n_dst && on) {
+                        const int b = rowptr[i], e_end = rowptr[i + 1];
+#pragma unroll
+                        for (int cb = 0; cb < NB; ++cb) xv[cb] = x[i * ldx + c0 + cb];
+                        for (int k = b; k < e_end; ++k) {
+                            const int s_ = src[k];
+                            const float* ar = ea + (int64_t)k * lde;
+#pragma unroll 1
+                            for (int cb = 0; cb < NB; ++cb) {
+                                float p = be[c0 + cb];
+                                for (int f = 0; f < FE; ++f) p = __fmaf_rn(We[(int64_t)(c0 + cb) * FE + f], ar[f], p);
+                                aout[cb] = __fadd_rn(aout[cb], __fmul_rn(x[(int64_t)s_ * ldx + c0 + cb], p));
+                            }
+                        }
+                        const float cnt = (float)max(e_end - b, 1);
+#pragma unroll
+                        for (int cb = 0; cb < NB; ++cb) aout[cb] = __fdiv_rn(aout[cb], cnt);
+                    }
+                    put_seg((int)(it & 1), w * TPW + rb * 4 + tq, aout, xv);
+                }
+            }
+            stamp(trace, trace_cap, it, w, 2);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // strip reads returned before the next DMA may land
+            asm volatile("" : "+v"(vbeg2), "+v"(vsrc1), "+v"(vbeg1));  // consume the index loads here (see fused.hip)
+            issue_loads(it + 1);
+            stamp(trace, trace_cap, it, w, 3);
+        }
+        tile_barrier();  // A-tile `it` complete; partial sums of tile `it-1` complete
+        stamp(trace, trace_cap, it, w, 4);
+
+        if (it > 0) {
+            // ============================================================ delayed epilogue of tile it-1
+            const int64_t tile = tile_of(it - 1);
+            const float* red = redbuf + ((it - 1) & 1) * (C::RED_BYTES / 4) + partner * 512 + lane;
+            const int64_t row0 = tile * TILE + rg * 32 + 4 * h + 16 * kh;
+            float* o = out + row0 * ldo + col;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                v[r] = (mine[r] + red[r * 64]) + bb;
+                if (has_scale) v[r] = __fmaf_rn(v[r], sc, sh);
+                if (relu) v[r] = fmaxf(v[r], 0.f);
+            }
+            if ((tile + 1) * TILE <= n_dst) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) o[(int64_t)((r & 3) + 8 * (r >> 2)) * ldo] = v[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int rr = (r & 3) + 8 * (r >> 2);
+                    if (row0 + rr < n_dst) o[(int64_t)rr * ldo] = v[r];
+                }
+            }
+        }
+        if (it < my_n) {
+            // ================================================================ C: dense part, split-bf16, K half
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            const char* A = abuf + (it & 1) * C::A_BYTES + (rg * 32 + l31) * ROWB + (kh * (CIN_PAD / 8) + h) * 48;
+#pragma unroll
+            for (int S = 0; S < NWB; ++S) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(A + S * 96);
+                const bf16x8 am = *reinterpret_cast<const bf16x8*>(A + S * 96 + 16);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(A + S * 96 + 32);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wb[S][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wb[S][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wb[S][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wb[S][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wb[S][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wb[S][0], acc, 0, 0, 0);
+            }
+            float* red = redbuf + (it & 1) * (C::RED_BYTES / 4) + w * 512 + lane;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                mine[r] = kh ? acc[8 + r] : acc[r];
+                red[r * 64] = kh ? acc[r] : acc[8 + r];
+            }
+            stamp(trace, trace_cap, it, w, 5);
+        }
+    }
+}
+
+template <int CIN_PAD, int COUT>
+int launch2(const int32_t* rowptr, const int32_t* src, int64_t n_dst, const float* x, int64_t ldx, int c_in, const float* ea,
+            int64_t lde, const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
+            const float* scale, const float* shift, int relu, float* out, int64_t ldo, int xvec, hipStream_t stream) {
+    using C = Cfg2<CIN_PAD, COUT>;
+    const int64_t ntiles = dgnn_cdiv(n_dst, C::TILE);
+    const size_t smem = C::SMEM_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sage_fused_mfma<CIN_PAD, COUT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    int grid = (int)(ntiles < DGNN_NUM_CU ? ntiles : DGNN_NUM_CU);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((k_sage_fused_mfma<CIN_PAD, COUT>), dim3(grid), dim3(512), smem, stream, rowptr, src, n_dst, x, ldx, c_in, ea,
+                       lde, We, be, Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles, xvec, g_dgnn_trace_buf, g_dgnn_trace_cap);
+    return dgnn_check_launch("sage_layer_fused_fwd(mfma filter)");
+}
+
+}  // namespace
+
+// Returns DGNN_E_UNSUPPORTED when the shape does not fit this variant (the caller then uses fused.hip MODE 1).
+int dgnn_sage_layer_fused_mfma_try(const int32_t* rowptr, const int32_t* src, int64_t n_dst, const float* x_src, int64_t ldx,
+                                   int c_in, const float* edge_attr_sorted, int64_t lde, const float* We, const float* be,
+                                   const float* Wj, const float* bj, const float* Wi, const float* scale, const float* shift,
+                                   int relu, int c_out, float* out, int64_t ldo, hipStream_t stream) {
+    const int cin_pad = c_in <= 32 ? 32 : (c_in <= 64 ? 64 : 128);
+    const int nb = cin_pad / 16;
+    if (c_in % nb != 0 || (c_out != 64 && c_out != 128) || (cin_pad == 128 && c_out != 128)) return DGNN_E_UNSUPPORTED;
+    const int xvec = (((uintptr_t)x_src % 16) == 0 && ldx % 4 == 0) ? 1 : 0;
+    if (nb >= 4 && !xvec) return DGNN_E_UNSUPPORTED;
+#define GO2(CP, CO) return launch2<CP, CO>(rowptr, src, n_dst, x_src, ldx, c_in, edge_attr_sorted, lde, We, be, Wj, bj, Wi, scale, \
+                                           shift, relu, out, ldo, xvec, stream)
+    if (cin_pad == 32) { if (c_out == 64) GO2(32, 64); else GO2(32, 128); }
+    if (cin_pad == 64) { if (c_out == 64) GO2(64, 64); else GO2(64, 128); }
+    GO2(128, 128);
+#undef GO2
+}

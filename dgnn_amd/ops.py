@@ -241,9 +241,11 @@ def fused_layer_supported(c_in: int, c_out: int, f_e: int) -> bool:
 
 
 FUSED_ENABLED = True
-GEMM_F32, GEMM_BF16X3 = 0, 1
-# how the fused layer runs its dense part: exact-fp32 MFMA or the 3-way split-bf16 MFMA (fp32-class accuracy)
-GEMM_MODE = GEMM_BF16X3 if __import__("os").environ.get("DGNN_GEMM_MODE", "bf16x3") == "bf16x3" else GEMM_F32
+GEMM_F32, GEMM_BF16X3, GEMM_BF16X3_FILTER = 0, 1, 2
+# how the fused layer uses the matrix cores: exact-fp32 MFMA for the dense part ("f32"), 3-way split-bf16 MFMA for the
+# dense part ("bf16x3"), or split-bf16 MFMA for the dense part AND the filter MLP ("bf16x3f"); all fp32-class accuracy
+GEMM_MODE = {"f32": GEMM_F32, "bf16x3": GEMM_BF16X3, "bf16x3f": GEMM_BF16X3_FILTER}[
+    __import__("os").environ.get("DGNN_GEMM_MODE", "bf16x3f")]
 
 
 def sage_layer_fused_fwd(rowptr, src, n_dst, x_src, edge_attr_sorted, We, be, Wj, bj, Wi, scale, shift, relu, gemm_mode=None,

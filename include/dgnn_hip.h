@@ -156,6 +156,9 @@ int dgnn_sage_aggregate_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const
 #define DGNN_GEMM_F32 0    /* v_mfma_f32_32x32x2_f32: bit-faithful fp32 fmaf chains */
 #define DGNN_GEMM_BF16X3 1 /* operands split exactly into 3 bf16 parts, 6 partial products on v_mfma_f32_32x32x16_bf16,
                               fp32 accumulate: fp32-class accuracy (dropped terms <= 2^-25 relative) at 6/16 of the time */
+#define DGNN_GEMM_BF16X3_FILTER 2 /* as BF16X3, and the 20-tap filter MLP runs on v_mfma_f32_16x16x32_bf16 too (same exact
+                                     3-part split, 6 products, fp32 accumulate); falls back to BF16X3 for shapes it
+                                     does not cover (c_in not a multiple of c_in_pad/16, unaligned wide rows) */
 int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* src, int64_t n_dst, const float* x_src,
                               int64_t ldx, int c_in, const float* edge_attr_sorted, int64_t lde, int f_e,
                               const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,

@@ -166,7 +166,7 @@ def test_batchnorm_train_eval_and_backward():
 
 
 # ---- whole model: golden vectors --------------------------------------------------------------------
-@pytest.mark.parametrize("fused,mode", [(True, 0), (True, 1), (False, 0)])
+@pytest.mark.parametrize("fused,mode", [(True, 0), (True, 1), (True, 2), (False, 0)])
 def test_inference_layer_golden_f2(fused, mode):
     from dgnn_amd import ops
     g = gold("static_f2_regular256.npz")
@@ -400,15 +400,16 @@ def test_fused_layer_gemm_modes_vs_fp64(c_in, c_out):
     plan = GraphPlan(ei.to(DEV), n, n)
     eas = plan.sorted_edge_attr(ea.to(DEV))
     errs = {}
-    for mode in (ops.GEMM_F32, ops.GEMM_BF16X3):
+    for mode in (ops.GEMM_F32, ops.GEMM_BF16X3, ops.GEMM_BF16X3_FILTER):
         out = ops.sage_layer_fused_fwd(plan.rowptr, plan.src, n, x.to(DEV), eas, We.to(DEV), be.to(DEV), Wj.to(DEV), bj.to(DEV),
                                        Wi.to(DEV), sc.to(DEV), sh.to(DEV), True, gemm_mode=mode)
         errs[mode] = rel_err(out, ref)
         assert errs[mode] < 3e-6, (mode, errs)
     assert errs[ops.GEMM_BF16X3] < 3 * errs[ops.GEMM_F32] + 2e-7, errs
+    assert errs[ops.GEMM_BF16X3_FILTER] < 3 * errs[ops.GEMM_F32] + 2e-7, errs
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_fused_layers_row_level_on_larger_graph(mode):
     """Row-level check of every fused layer on a 134k-tet graph (thousands of tiles per launch, several
     launches): no output row may deviate from the unfused aggregate + GEMM path.  This is the detector that
