@@ -21,6 +21,10 @@
 // phase; the dense part is the K-split 32x32x16 split-bf16 product with the delayed epilogue.
 #include "fused_common.h"
 
+#ifndef DGNN_YOUNG_PRIO
+#define DGNN_YOUNG_PRIO 0  // measured: it only swaps which wave of a SIMD waits at the barrier (zero-sum)
+#endif
+
 namespace {
 using namespace fused;
 
@@ -80,6 +84,11 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     char* const bpbuf = reinterpret_cast<char*>(redbuf) + 2 * C::RED_BYTES;       // filter operand parts
 
     const int lane = lane_id(), w = wave_id_uniform();
+#if DGNN_YOUNG_PRIO
+    // the second wave of every SIMD loses VALU/MFMA arbitration to the older one on every phase (priority, then age);
+    // one static priority bump evens the two out so neither idles long at the tile barrier
+    if (w >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     const int h = lane >> 5, l31 = lane & 31;
     const int jcol = lane & 15, tq = lane >> 4;  // filter phase: channel group / tet within a row block; also MFMA (col, k-group)
     const int ldx32 = (int)ldx;
