@@ -219,6 +219,19 @@ extern "C" int dgnn_relu_bwd(const float* y, const float* g, int64_t n, float* o
     return dgnn_check_launch("relu_bwd");
 }
 
+// out[0..n] = exclusive scan of in[0..n) (out[n] = total).  sums_scratch: cdiv(n, 2048) + 2 ints.  Used by sampler.hip.
+int dgnn_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, int32_t* sums_scratch, hipStream_t stream) {
+    if (n <= 0) {
+        hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, out, (int64_t)1);
+        return DGNN_OK;
+    }
+    const int nb = (int)dgnn_cdiv(n, SCAN_TILE);
+    hipLaunchKernelGGL(k_scan_tile, dim3(nb), dim3(SCAN_THREADS), 0, stream, in, n, out, sums_scratch);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums_scratch, nb);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_THREADS), 0, stream, out, n, sums_scratch, nb);
+    return DGNN_OK;
+}
+
 // scratch layout (int32): deg[n_key] | tmp[E] | sums[nb+1] | big_count[1] | big_list[n_key/33+1]
 extern "C" int64_t dgnn_plan_scratch_elems(int64_t E, int64_t n_key) {
     if (E < 0 || n_key < 0) return 0;

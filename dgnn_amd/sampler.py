@@ -1,0 +1,101 @@
+"""GPU k-hop full-neighbour block builder: drop-in for the CPU
+``torch_geometric.data.NeighborSampler(edge_index, sizes=[-1]*k, node_idx, batch_size, shuffle, drop_last,
+return_e_id=True)`` that the reference builds at run.py:72-74 (training) and run.py:221-223 (inference).
+
+Iterating yields ``(batch_size, n_id, adjs)`` exactly as PyG does: ``adjs`` is the list of
+``(edge_index [2,E_l] local ids, e_id [E_l], size=(n_src, n_dst))`` with the OUTERMOST hop first (a single
+triple when there is one hop, as consumed at surfaceNetStaticEdgeFilters.py:300-301); targets are always a prefix
+of sources.  Everything stays on the GPU (the reference samples on the CPU with torch_sparse and copies each block
+over PCIe).  Per destination, edges come in plan order = ascending edge position; for the reference's adjacency
+layout (4 rows per source tet, distinct neighbours) that is ascending source id, i.e. PyG's order, so blocks are
+identical to the CPU sampler's (tests/test_gpu_parity.py checks this against the oracle's restatement).
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import check, lib, ptr, stream_ptr
+from .graph import GraphPlan
+
+_I32_MAX = 2 ** 31 - 1
+
+
+class EdgeIndex(tuple):
+    """(edge_index, e_id, size) with attribute access like PyG's namedtuple (calcRegularization reads
+    ``batch_adjs[k].edge_index`` / ``.size``, learning/runModel.py:118-119)."""
+
+    def __new__(cls, edge_index, e_id, size):
+        return super().__new__(cls, (edge_index, e_id, size))
+
+    edge_index = property(lambda self: self[0])
+    e_id = property(lambda self: self[1])
+    size = property(lambda self: self[2])
+
+    def to(self, *a, **k):
+        return EdgeIndex(self[0].to(*a, **k), self[1].to(*a, **k) if self[1] is not None else None, self[2])
+
+
+class NeighborSampler:
+    def __init__(self, edge_index, sizes, node_idx=None, num_nodes=None, batch_size=1, shuffle=False, drop_last=False,
+                 return_e_id=True, plan: GraphPlan = None, generator=None, **kwargs):
+        if any(int(s) != -1 for s in sizes):
+            raise NotImplementedError("only full neighbourhoods (size -1) are used by the reference (clique_sizes: [-1])")
+        if not edge_index.is_cuda:
+            raise RuntimeError("dgnn_amd.sampler.NeighborSampler builds blocks on the GPU: pass a CUDA edge_index")
+        self.sizes = list(sizes)
+        self.device = edge_index.device
+        n = int(num_nodes) if num_nodes is not None else int(edge_index.max().item()) + 1
+        self.num_nodes = n
+        self.plan = plan if plan is not None else GraphPlan(edge_index, n, n)
+        if node_idx is None:
+            node_idx = torch.arange(n, device=self.device)
+        elif node_idx.dtype == torch.bool:
+            node_idx = node_idx.nonzero(as_tuple=False).view(-1)
+        self.node_idx = node_idx.to(self.device, torch.int64)
+        self.batch_size, self.shuffle, self.drop_last, self.return_e_id = int(batch_size), shuffle, drop_last, return_e_id
+        self.generator = generator
+        self._pos = torch.full((n,), -1, dtype=torch.int32, device=self.device)
+        self._first = torch.full((n,), _I32_MAX, dtype=torch.int32, device=self.device)
+
+    def __len__(self):
+        m = self.node_idx.numel()
+        return m // self.batch_size if self.drop_last else (m + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        idx = self.node_idx
+        if self.shuffle:
+            idx = idx[torch.randperm(idx.numel(), device=self.device, generator=self.generator)]
+        for s in range(0, idx.numel(), self.batch_size):
+            b = idx[s:s + self.batch_size]
+            if self.drop_last and b.numel() < self.batch_size:
+                break
+            yield self.sample(b)
+
+    def sample(self, batch: torch.Tensor):
+        L, st, p = lib(), stream_ptr(), self.plan
+        n_id = batch.to(self.device, torch.int64).contiguous()
+        batch_size = n_id.numel()
+        adjs = []
+        for hop in range(len(self.sizes)):
+            n_t = n_id.numel()
+            off = torch.empty(n_t + 1, dtype=torch.int32, device=self.device)
+            scratch = torch.empty(int(L.dgnn_khop_scratch_elems(n_t, 0)), dtype=torch.int32, device=self.device)
+            check(L.dgnn_khop_count(ptr(p.rowptr), ptr(n_id), n_t, int(hop == 0), ptr(self._pos), ptr(off), ptr(scratch), st),
+                  "dgnn_khop_count")
+            n_e = int(off[n_t].item())  # sizes the block tensors (the CPU sampler is synchronous as well)
+            e_src = torch.empty(n_e, dtype=torch.int64, device=self.device)
+            e_dst = torch.empty(n_e, dtype=torch.int64, device=self.device)
+            e_id = torch.empty(n_e, dtype=torch.int64, device=self.device)
+            n_id_out = torch.empty(n_t + n_e, dtype=torch.int64, device=self.device)
+            n_new = torch.zeros(1, dtype=torch.int32, device=self.device)
+            scratch = torch.empty(int(L.dgnn_khop_scratch_elems(n_t, n_e)), dtype=torch.int32, device=self.device)
+            check(L.dgnn_khop_expand(ptr(p.rowptr), ptr(p.src), ptr(p.eid), ptr(n_id), n_t, ptr(off), n_e, ptr(self._pos),
+                                     ptr(self._first), ptr(e_src), ptr(e_dst), ptr(e_id), ptr(n_id_out), ptr(n_new), ptr(scratch),
+                                     st), "dgnn_khop_expand")
+            n_all = n_t + int(n_new.item())
+            check(L.dgnn_khop_commit(ptr(n_id_out), n_t, n_all, ptr(self._pos), ptr(self._first), st), "dgnn_khop_commit")
+            n_id = n_id_out[:n_all]
+            adjs.append(EdgeIndex(torch.stack([e_src, e_dst]), e_id if self.return_e_id else None, (n_all, n_t)))
+        check(L.dgnn_khop_reset(ptr(n_id), n_id.numel(), ptr(self._pos), st), "dgnn_khop_reset")
+        adjs = adjs[0] if len(adjs) == 1 else adjs[::-1]
+        return batch_size, n_id, adjs

@@ -176,6 +176,25 @@ int dgnn_decoder_fused_fwd(const float* y, int64_t ldy, int64_t M, int k, const 
  * wall_clock64() at phase boundaries (slot = (tile_iter*12 + wave)*8 + phase).  NULL disables. */
 int dgnn_debug_trace_buffer(int64_t* dev_buf, int64_t n);
 
+/* ------------------------------------------------------------------------------------------------
+ * k-hop full-neighbour block builder: GPU replacement of the CPU
+ * torch_geometric NeighborSampler(edge_index, sizes=[-1]*k) the reference builds at run.py:72-74,221-223.
+ * One hop: dgnn_khop_count -> host reads off[n_t] (edge total) -> dgnn_khop_expand -> host reads *n_new ->
+ * dgnn_khop_commit; dgnn_khop_reset after the last hop of a batch.  `pos` int32 [n_nodes] all -1 and `first`
+ * int32 [n_nodes] all INT32_MAX between batches (dgnn_fill_i32).  rowptr/src/eid: the by-destination plan.
+ * Output of a hop: local edge list e_src/e_dst int64 [n_edges] (targets keep ids 0..n_t-1, new sources appended in
+ * first-appearance order), e_id int64 [n_edges] rows of edge_attr, n_id_out int64 [n_t + n_new].
+ * ---------------------------------------------------------------------------------------------- */
+int dgnn_fill_i32(int32_t* p, int64_t n, int32_t value, void* stream);
+int64_t dgnn_khop_scratch_elems(int64_t n_t, int64_t max_edges);
+int dgnn_khop_count(const int32_t* rowptr, const int64_t* n_id, int64_t n_t, int first_hop, int32_t* pos, int32_t* off,
+                    int32_t* scratch, void* stream);
+int dgnn_khop_expand(const int32_t* rowptr, const int32_t* src, const int32_t* eid, const int64_t* n_id, int64_t n_t,
+                     const int32_t* off, int64_t n_edges, int32_t* pos, int32_t* first, int64_t* e_src, int64_t* e_dst,
+                     int64_t* e_id, int64_t* n_id_out, int32_t* n_new_out, int32_t* scratch, void* stream);
+int dgnn_khop_commit(const int64_t* n_id_out, int64_t n_t, int64_t n_all, int32_t* pos, int32_t* first, void* stream);
+int dgnn_khop_reset(const int64_t* n_id, int64_t n, int32_t* pos, void* stream);
+
 /* elementwise helpers used by the Updated variant (F.relu at surfaceNetUpdatedEdgeFilters.py:239-241
  * and the scatter of phi rows into the zero [E_all,C] buffer at :236-237) */
 int dgnn_relu(const float* x, int64_t n, float* y, void* stream);
