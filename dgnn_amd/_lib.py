@@ -39,6 +39,10 @@ SIGNATURES = {
                                       vp, vp, vp, i64, vp, vp]),
     "dgnn_debug_trace_buffer": (i32, [vp, i64]),
     "dgnn_fill_i32": (i32, [vp, i64, i32, vp]),
+    "dgnn_argmax_rows": (i32, [vp, i64, i64, i32, vp, vp]),
+    "dgnn_compact_scratch_elems": (i64, [i64]),
+    "dgnn_compact_i32": (i32, [vp, vp, i32, i64, vp, vp, vp, vp]),
+    "dgnn_interface_flags": (i32, [vp, vp, i64, vp, vp]),
     "dgnn_khop_scratch_elems": (i64, [i64, i64]),
     "dgnn_khop_count": (i32, [vp, vp, i64, i32, vp, vp, vp, vp]),
     "dgnn_khop_expand": (i32, [vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

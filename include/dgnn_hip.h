@@ -195,6 +195,18 @@ int dgnn_khop_expand(const int32_t* rowptr, const int32_t* src, const int32_t* e
 int dgnn_khop_commit(const int64_t* n_id_out, int64_t n_t, int64_t n_all, int32_t* pos, int32_t* first, void* stream);
 int dgnn_khop_reset(const int64_t* n_id, int64_t n, int32_t* pos, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Logits -> labels -> interface facets (reference processing/generate_mesh.py:75 and :93-105).
+ *   dgnn_argmax_rows     labels[i] = argmax_c logits[i,c]             (log_softmax(...).argmax(1), ties -> 0)
+ *   dgnn_compact_i32     order-preserving stream compaction (finite-cell labels; interface facet ids)
+ *   dgnn_interface_flags flags[f] = label(nfacets[f,0]) != label(nfacets[f,1]), cell -1 = outside
+ * ---------------------------------------------------------------------------------------------- */
+int dgnn_argmax_rows(const float* logits, int64_t ld, int64_t n, int c, int32_t* labels, void* stream);
+int64_t dgnn_compact_scratch_elems(int64_t n);
+int dgnn_compact_i32(const int32_t* values, const int32_t* keep, int invert, int64_t n, int32_t* out, int32_t* count_out,
+                     int32_t* scratch, void* stream);
+int dgnn_interface_flags(const int32_t* nfacets, const int32_t* labels_finite, int64_t n_facets, int32_t* flags, void* stream);
+
 /* elementwise helpers used by the Updated variant (F.relu at surfaceNetUpdatedEdgeFilters.py:239-241
  * and the scatter of phi rows into the zero [E_all,C] buffer at :236-237) */
 int dgnn_relu(const float* x, int64_t n, float* y, void* stream);

@@ -521,3 +521,24 @@ def F_kl(logits, gt, vol):
     import torch.nn.functional as F
     cl = F.kl_div(F.log_softmax(logits, dim=-1), gt[:, :2], reduction='none').sum(1) * vol
     return float((cl.sum() / vol.sum()).detach())
+
+
+def test_interface_extraction_matches_reference_loops():
+    """Device label/interface extraction vs a direct restatement of processing/generate_mesh.py:75,93-105."""
+    from dgnn_amd.processing.generate_mesh import extract_interface
+    rng = np.random.default_rng(5)
+    n, nf_facets = 5000, 9000
+    infinite = (rng.random(n) < 0.05).astype(np.int32)
+    logits = rng.standard_normal((n, 2)).astype(np.float32)
+    logits[::50] = 0.25  # exact ties -> class 0, as argmax does
+    n_fin = int((infinite == 0).sum())
+    nfacets = rng.integers(-1, n_fin, size=(nf_facets, 2)).astype(np.int32)
+    # reference semantics
+    labels = torch.log_softmax(torch.from_numpy(logits)[torch.from_numpy(infinite) == 0], dim=-1).argmax(1).numpy()
+    edges = nfacets.copy()
+    edges[edges == -1] = labels.shape[0]
+    lab = np.append(labels, 1)
+    interfaces = [fi for fi, f in enumerate(edges) if lab[f[0]] != lab[f[1]]]
+    got_labels, got_if = extract_interface(torch.from_numpy(logits).to(DEV), torch.from_numpy(infinite).to(DEV), torch.from_numpy(nfacets).to(DEV))
+    assert np.array_equal(got_labels.cpu().numpy(), labels)
+    assert np.array_equal(got_if.cpu().numpy(), np.asarray(interfaces, dtype=np.int32))
