@@ -39,6 +39,8 @@ SIGNATURES = {
                                       vp, vp, vp, i64, vp, vp]),
     "dgnn_debug_trace_buffer": (i32, [vp, i64]),
     "dgnn_fill_i32": (i32, [vp, i64, i32, vp]),
+    "dgnn_standardize_scratch_doubles": (i64, [i32]),
+    "dgnn_standardize_f64": (i32, [vp, i64, i64, i32, i32, vp, i64, vp, vp]),
     "dgnn_argmax_rows": (i32, [vp, i64, i64, i32, vp, vp]),
     "dgnn_compact_scratch_elems": (i64, [i64]),
     "dgnn_compact_i32": (i32, [vp, vp, i32, i64, vp, vp, vp, vp]),

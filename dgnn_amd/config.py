@@ -42,9 +42,13 @@ def reconbench_pretrained(device: str = "cuda:0", convs=(64, 128, 128, 128)) -> 
     """The hot-path subset of configs/pretrained/reconbench.yaml (:19-20, :45, :53-61, :66-70) with
     the feature counts of the shipped checkpoint (28 node / 20 edge features)."""
     return Config.wrap(dict(
+        features=dict(scaling="s", normalization_range=[0, 1],
+                      node_features=["shape", "vertex", "facet", "count", "min", "max", "sum", "first", "second"],
+                      edge_features=["shape", "vertex", "facet", "count", "min", "max", "sum"],
+                      node_normalization_feature=None, edge_normalization_feature=None),
         model=dict(type="sage", convs=list(convs), edge_convs=1, decoder=2, normalization="b"),
         training=dict(loss="kl", learning_rate=0.005, adjust_lr_every=24, batch_size=2048),
-        inference=dict(batch_size=0, per_layer=1),
+        inference=dict(batch_size=0, per_layer=1, has_label=1),
         graph=dict(num_hops=4, additional_num_hops=1, clique_sizes=[-1], self_loops=0),
         regularization=dict(cell_type="vol", cell_norm=None, edge_type=None, edge_epoch=None, edge_weight=0.4),
         temp=dict(device=device, num_node_features=28, num_edge_features=20),

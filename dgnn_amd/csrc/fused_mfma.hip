@@ -76,7 +76,7 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                   const float* __restrict__ shift, int relu, float* __restrict__ out, int64_t ldo, int64_t ntiles,
                   int xvec, int64_t* __restrict__ trace, int64_t trace_cap) {
     using C = Cfg2<CIN_PAD, COUT>;
-    constexpr int ROWB = C::ROWB, TILE = C::TILE, TPW = C::TPW, RB = C::RB, NQ = C::NQ, NB = C::NB, NWB = C::NWB;
+    constexpr int ROWB = C::ROWB, TILE = C::TILE, TPW = C::TPW, RB = C::RB, NB = C::NB, NWB = C::NWB;
     extern __shared__ __attribute__((aligned(16))) char smem2[];
     char* const abuf = smem2;                                        // [2][A_BYTES]
     char* const eabuf = smem2 + 2 * C::A_BYTES;                      // [NWAVE][EA_BYTES] fp32 attribute strips
@@ -162,19 +162,24 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     bool regular = false;
     int vbeg1 = 0, vbeg2 = 0, vsrc1 = 0;  // index pipeline, see fused.hip
     bool ok1 = false, ok2 = false;
+    // nv = valid tets of this wave's group (TPW except in the last tile).  A short group still takes the matrix-core
+    // path with clamped (duplicated) rows so that a tet's result does not depend on where the tile grid cuts the
+    // graph: whole-graph and partitioned runs stay bit-identical on 4-regular scenes.
+    int nv1 = 0, nv2 = 0;
 
-    auto load_rowptr = [&](int64_t it, int& vb) -> bool {
+    auto load_rowptr = [&](int64_t it, int& vb, int& nv) -> bool {
         if (it >= my_n) return false;
         const int64_t i0 = tile_of(it) * TILE + w * TPW;
-        if (i0 + TPW > n_dst) return false;
-        vb = rowptr[i0 + (lane < TPW ? lane : TPW)];
+        if (i0 >= n_dst) return false;
+        nv = (int)(n_dst - i0 < TPW ? n_dst - i0 : TPW);
+        vb = rowptr[i0 + (lane < nv ? lane : nv)];
         return true;
     };
     auto load_src = [&]() {
         if (ok1) {
             const int b0 = __builtin_amdgcn_readfirstlane(vbeg1);
-            ok1 = __all(lane > TPW || vbeg1 == b0 + 4 * lane) != 0;
-            if (ok1) vsrc1 = src[b0 + (lane < NQ ? lane : NQ - 1)];
+            ok1 = __all(vbeg1 == b0 + 4 * (lane < nv1 ? lane : nv1)) != 0;
+            if (ok1) vsrc1 = src[b0 + (lane < 4 * nv1 ? lane : 4 * nv1 - 1)];
         }
     };
     auto issue_loads = [&](int64_t it) {
@@ -182,10 +187,11 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         if (regular) {
             const int i0 = (int)(tile_of(it) * TILE) + w * TPW;
             const float* eab = ea + (int64_t)__builtin_amdgcn_readfirstlane(vbeg1) * lde;
+            const int ea_last = nv1 * 4 * FE - 4;  // last 16-byte chunk of the group's attribute block
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const int tl = rb * 4 + tq;  // this lane's tet within the wave
-                ld_vec<NB>(xd[rb], x + (uint32_t)((i0 + tl) * ldx32) + c0l, vec);
+                ld_vec<NB>(xd[rb], x + (uint32_t)((i0 + (tl < nv1 ? tl : nv1 - 1)) * ldx32) + c0l, vec);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int s_ = __shfl(vsrc1, tl * 4 + r);
@@ -194,16 +200,18 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
             }
             // attribute block of this wave's tets: LDS-DMA into the private strip (issued last, see fused.hip)
 #pragma unroll
-            for (int q = 0; q < C::EA_FULL; ++q) glds16(eab + q * 256 + lane * 4, myea + q * 256);
+            for (int q = 0; q < C::EA_FULL; ++q) glds16(eab + min(q * 256 + lane * 4, ea_last), myea + q * 256);
 #pragma unroll
-            for (int q = 0; q < C::EA_TAIL; ++q) glds4(eab + C::EA_FULL * 256 + q * 64 + lane, myea + C::EA_FULL * 256 + q * 64);
+            for (int q = 0; q < C::EA_TAIL; ++q)
+                glds4(eab + min(C::EA_FULL * 256 + q * 64 + lane, ea_last + 3), myea + C::EA_FULL * 256 + q * 64);
         }
     };
     auto advance_idx = [&](int64_t it_next) {
         ok1 = ok2;
         vbeg1 = vbeg2;
+        nv1 = nv2;
         load_src();
-        ok2 = load_rowptr(it_next + 1, vbeg2);
+        ok2 = load_rowptr(it_next + 1, vbeg2, nv2);
     };
     // one finished (tet row, NB channels) segment -> A-tile: columns [c0, c0+NB) of the mean half and of the own-row half
     auto put_seg = [&](int buf, int row, const float (&av)[NB], const float (&xv)[NB]) {
@@ -239,9 +247,9 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         }
     };
 
-    ok1 = load_rowptr(0, vbeg1);
+    ok1 = load_rowptr(0, vbeg1, nv1);
     load_src();
-    ok2 = load_rowptr(1, vbeg2);
+    ok2 = load_rowptr(1, vbeg2, nv2);
     issue_loads(0);
     float mine[8];
 #pragma unroll
@@ -302,7 +310,7 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                     put_seg((int)(it & 1), w * TPW + rb * 4 + tq, aout, xv);
                 }
             } else {
-                // generic path (any in-degree, tile tail): plain fp32 per lane, one edge at a time (rare)
+                // generic path (a group with any in-degree other than 4, or past the end): plain fp32 per lane, one edge at a time (rare)
 #pragma unroll 1
                 for (int rb = 0; rb < RB; ++rb) {
                     const int64_t i = i0 + rb * 4 + tq;

@@ -207,6 +207,15 @@ int dgnn_compact_i32(const int32_t* values, const int32_t* keep, int invert, int
                      int32_t* scratch, void* stream);
 int dgnn_interface_flags(const int32_t* nfacets, const int32_t* labels_finite, int64_t n_facets, int32_t* flags, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Per-scene standardisation (reference processing/data.py:444-506 sklearn StandardScaler + :512-519
+ * float32 cast): out[i,c] = float((x[i,c] - mean_c) / std_c) for c >= c_first, plain cast for c < c_first;
+ * fp64 statistics (population variance, zero scale -> 1).  scratch: dgnn_standardize_scratch_doubles(c) doubles.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t dgnn_standardize_scratch_doubles(int c);
+int dgnn_standardize_f64(const double* x, int64_t ld, int64_t n, int c, int c_first, float* out, int64_t ldo, double* scratch,
+                         void* stream);
+
 /* elementwise helpers used by the Updated variant (F.relu at surfaceNetUpdatedEdgeFilters.py:239-241
  * and the scatter of phi rows into the zero [E_all,C] buffer at :236-237) */
 int dgnn_relu(const float* x, int64_t n, float* y, void* stream);

@@ -234,6 +234,60 @@ def run_static(ref, sd, x, ea, ei, dtype):
     return logits, acts, net
 
 
+def write_small_scene(root, rng):
+    """A tiny scene in the reference's on-disk schema (data/<scene>/gt/<id>_{labels,cgeom,cbvf,cbff,fgeom,fbvf,
+    fbff,adjacencies}.npz, same keys/dtypes/order as data/Ignatius/gt/99_*.npz; the 4 fgeom key names are ours,
+    the reference iterates whatever keys the file has).  Values are heavy-tailed like the real ones, one column
+    is constant (zero variance -> scale 1 in StandardScaler)."""
+    from dgnn_amd.synthetic import delaunay_tet_graph
+    adj, _, _ = delaunay_tet_graph(48, seed=11)
+    n, e = adj.shape[0] // 4, adj.shape[0]
+    os.makedirs(os.path.join(root, "gt"), exist_ok=True)
+    b = os.path.join(root, "gt", "0")
+    inside = rng.random(n)
+    np.savez(b + "_labels.npz", inside_perc=inside, outside_perc=1.0 - inside, infinite=(rng.random(n) < 0.1).astype(np.int32))
+    np.savez(b + "_cgeom.npz", radius=rng.lognormal(0, 1, n), vol=rng.lognormal(-2, 2, n),
+             longest_edge=rng.lognormal(0, 0.5, n) + 1, shortest_edge=rng.lognormal(-1, 0.5, n))
+
+    def stats(prefix, groups, m):
+        d = {}
+        for g_ in groups:
+            cnt = rng.poisson(3, m).astype(np.float64)
+            d["%s_%s_count" % (prefix, g_)] = cnt
+            d["%s_%s_dist_min" % (prefix, g_)] = rng.exponential(0.5, m) * (cnt > 0)
+            d["%s_%s_dist_max" % (prefix, g_)] = rng.exponential(5.0, m) * (cnt > 0)
+            d["%s_%s_dist_sum" % (prefix, g_)] = rng.exponential(20.0, m) * cnt
+        return d
+    cbvf = stats("cb_vertex", ["inside", "outside", "last"], n)
+    cbvf["cb_vertex_outside_count"][:] = 2.0          # constant column
+    np.savez(b + "_cbvf.npz", **cbvf)
+    np.savez(b + "_cbff.npz", **stats("cb_facet", ["inside_first", "inside_second", "outside_first", "outside_second",
+                                                    "last_first", "last_second"], n))
+    np.savez(b + "_fgeom.npz", area=rng.lognormal(0, 1, e), angle=rng.random(e) * 3.14, cc_dist=rng.lognormal(0, 1, e),
+             beta=rng.random(e))
+    np.savez(b + "_fbvf.npz", **stats("fb_vertex", ["inside", "outside", "last"], e))
+    np.savez(b + "_fbff.npz", **stats("fb_facet", ["inside", "outside", "last"], e))
+    np.savez(b + "_adjacencies.npz", adjacencies=adj.astype(np.int32))
+    return n
+
+
+def ingest_fixture(rng):
+    """Row 8f-3: the reference's own dataLoader.run on the small scene -> expected features / edge_features /
+    edge_lists / gt / infinite / feature names."""
+    sys.path.insert(0, REF)
+    from processing.data import dataLoader
+    root = os.path.join(HERE, "scene_small")
+    write_small_scene(root, rng)
+    clf = static_clf()
+    clf.inference.has_label = 1
+    dl = dataLoader(clf, verbosity=0)
+    dl.run(dict(path=root, filename="0", category="", id="", scan_conf="", gtfile="gt/0", ioufile=""))
+    np.savez_compressed(os.path.join(HERE, "ingest_small.npz"), features=dl.features.numpy(), edge_features=dl.edge_features.numpy(),
+                        edge_lists=dl.edge_lists.numpy(), gt=dl.gt.numpy(), infinite=dl.infinite.numpy(),
+                        node_feature_names=np.array(dl.node_feature_names), edge_feature_names=np.array(dl.edge_feature_names))
+    print("ingest", tuple(dl.features.shape), tuple(dl.edge_features.shape))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(1)
@@ -347,6 +401,11 @@ def main():
     torch.cuda.empty_cache = _cuda_empty
     np.savez_compressed(os.path.join(HERE, "updated_f3_blocks.npz"), **out)
 
+    ingest_fixture(np.random.default_rng(5))
+
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["ingest"]:      # only the 8f-3 fixture (independent seed)
+        ingest_fixture(np.random.default_rng(5))
+    else:
+        main()

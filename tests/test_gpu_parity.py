@@ -542,3 +542,37 @@ def test_interface_extraction_matches_reference_loops():
     got_labels, got_if = extract_interface(torch.from_numpy(logits).to(DEV), torch.from_numpy(infinite).to(DEV), torch.from_numpy(nfacets).to(DEV))
     assert np.array_equal(got_labels.cpu().numpy(), labels)
     assert np.array_equal(got_if.cpu().numpy(), np.asarray(interfaces, dtype=np.int32))
+
+
+def test_npz_ingest_matches_reference_loader_and_feeds_inference():
+    """8f-3: dgnn_amd.processing.data.dataLoader (device fp64 standardisation) == the reference dataLoader's tensors on
+    the small scene; the loaded scene then runs through inference_layer and matches the oracle on the fixture tensors."""
+    import os
+    from dgnn_amd.config import reconbench_pretrained
+    from dgnn_amd.processing.data import dataLoader, standardize
+    g = gold("ingest_small.npz")
+    clf = reconbench_pretrained()
+    dl = dataLoader(clf, verbosity=0)
+    root = os.path.join(os.path.dirname(__file__), "golden", "scene_small")
+    dl.run(dict(path=root, filename="0", category="", id="", scan_conf="", gtfile="gt/0", ioufile=""))
+    assert dl.features.is_cuda and dl.features.dtype == torch.float32
+    assert torch.equal(dl.features[:, 0].cpu(), torch.from_numpy(g["features"][:, 0]))
+    assert (dl.features.cpu() - torch.from_numpy(g["features"])).abs().max().item() <= 1e-6
+    assert (dl.edge_features.cpu() - torch.from_numpy(g["edge_features"])).abs().max().item() <= 1e-6
+    assert torch.equal(dl.edge_lists.cpu(), torch.from_numpy(g["edge_lists"]))
+    assert torch.equal(dl.gt.cpu(), torch.from_numpy(g["gt"]))
+    assert torch.equal(dl.infinite.cpu(), torch.from_numpy(g["infinite"]))
+    assert dl.node_feature_names == [str(s) for s in g["node_feature_names"]]
+    assert dl.getInfo() == g["features"].shape[0] and clf.temp.num_node_features == 28 and clf.temp.num_edge_features == 20
+    # large-magnitude column with tiny spread: the two-pass fp64 statistics keep it exact where fp32 would not
+    rng = np.random.default_rng(0)
+    big = np.stack([1e3 + rng.standard_normal(5000) * 1e-3, rng.standard_normal(5000)], 1)
+    ref = (big - big.mean(0)) / big.std(0)
+    assert (standardize(big, 0, "cuda:0").cpu().double().numpy() - ref).__abs__().max() <= 1e-6
+    # end to end from the files
+    net = hip_static()
+    logits = net.inference_layer(Config(x=dl.features, edge_attr=dl.edge_features, edge_index=dl.edge_lists))
+    with torch.no_grad():
+        want = oracle_static().inference_layer(Config(x=torch.from_numpy(g["features"]), edge_attr=torch.from_numpy(g["edge_features"]),
+                                                      edge_index=torch.from_numpy(g["edge_lists"])))
+    assert (logits.cpu() - want).abs().max().item() <= TOL_LOGIT * max(1.0, want.abs().max().item())

@@ -132,3 +132,28 @@ def test_checkpoint_keys_match_reference_layout():
     net = oracle_static(load=False)
     assert set(net.state_dict().keys()) == set(sd.keys())
     assert sum(v.numel() for v in net.state_dict().values()) == 103699
+
+
+def test_ingest_oracle_and_column_selection_match_reference_loader():
+    """8f-3: host column selection of dgnn_amd.processing.data + the numpy standardisation restatement reproduce the
+    reference dataLoader's tensors on the small scene (fixture made by the reference loader itself)."""
+    import os
+    from dgnn_amd.config import reconbench_pretrained
+    from dgnn_amd.processing.data import dataLoader
+    from oracle.ingest import standardize
+    g = gold("ingest_small.npz")
+    clf = reconbench_pretrained()
+    dl = dataLoader(clf, verbosity=0)
+    base = os.path.join(os.path.dirname(__file__), "golden", "scene_small", "gt", "0")
+    names, nodes = dl._node_columns(base)
+    enames, edges = dl._edge_columns(base)
+    assert names == [str(s) for s in g["node_feature_names"]]
+    assert enames == [str(s) for s in g["edge_feature_names"]]
+    f = standardize(nodes, 1)
+    assert np.array_equal(f[:, 0], g["features"][:, 0])
+    assert np.abs(f - g["features"]).max() <= 1e-6
+    assert np.abs(standardize(edges, 0) - g["edge_features"]).max() <= 1e-6
+    # a statistic left out of the facet groups fails in the reference (NpzFile has no .drop): same here
+    clf.features.edge_features = ["vertex", "count", "min", "max"]
+    with pytest.raises(AttributeError):
+        dl._edge_columns(base)
