@@ -158,7 +158,8 @@ def main():
     if world == 1:
         plan = GraphPlan(data.edge_index, n_local, n_local)
         xs = data.x[:, 1:]
-        ea_sorted = plan.sorted_edge_attr(data.edge_attr)
+        in_kernel = ops.EDGE_GATHER_IN_KERNEL  # fused layers gather edge rows by eid themselves: no staging pass
+        ea_l, eid_l = (data.edge_attr, plan.eid) if in_kernel else (plan.sorted_edge_attr(data.edge_attr), None)
         # per-kernel timing: replay each layer 10x between events
         def timed(fn, reps=10):
             fn()
@@ -171,7 +172,7 @@ def main():
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / reps
         breakdown["plan_ms"] = timed(lambda: GraphPlan(data.edge_index, n_local, n_local), 5)
-        breakdown["edge_sort_ms"] = timed(lambda: ops.gather_rows(data.edge_attr, plan.eid), 5)
+        breakdown["edge_sort_ms"] = 0.0 if in_kernel else timed(lambda: ops.gather_rows(data.edge_attr, plan.eid), 5)
         h = xs
         for i in range(4):
             conv = net.convs[i][0]
@@ -179,8 +180,8 @@ def main():
             hin = h
             if ops.fused_layer_supported(hin.size(1), conv.lin_j.out_features, 20):
                 fn = lambda hin=hin, conv=conv, scale=scale, shift=shift: ops.sage_layer_fused_fwd(
-                    plan.rowptr, plan.src, n_local, hin, ea_sorted, conv.lin_e.weight, conv.lin_e.bias, conv.lin_j.weight,
-                    conv.lin_j.bias, conv.lin_i.weight, scale, shift, True)
+                    plan.rowptr, plan.src, n_local, hin, ea_l, conv.lin_e.weight, conv.lin_e.bias, conv.lin_j.weight,
+                    conv.lin_j.bias, conv.lin_i.weight, scale, shift, True, eid=eid_l)
             else:
                 fn = lambda hin=hin, i=i: net._eval_layers_one(i, hin, data.edge_attr, plan)
             breakdown["layer%d_ms" % i] = timed(fn)

@@ -83,7 +83,7 @@ struct FusedCfg {
 
 template <int CIN_PAD, int COUT, int MODE>
 __global__ void __launch_bounds__(512, 2)
-k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, int64_t n_dst,
+k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid, int64_t n_dst,
              const float* __restrict__ x, int64_t ldx, int c_in, const float* __restrict__ ea, int64_t lde,
              const float* __restrict__ We, const float* __restrict__ be, const float* __restrict__ Wj,
              const float* __restrict__ bj, const float* __restrict__ Wi, const float* __restrict__ scale,
@@ -178,7 +178,7 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
     // offsets with v_readlane when the row loads are issued -- no long-lived SGPR arrays, no SGPR spills.
     //   vbeg2  lane r <= TPW : rowptr[i0(it+2) + r]      (requested during P(it))
     //   vbeg1  same for tile it+1 (arrived during P(it-1));  vsrc1  lane q < NQ : src[beg1_0 + q]
-    int vbeg1 = 0, vbeg2 = 0, vsrc1 = 0;
+    int vbeg1 = 0, vbeg2 = 0, vsrc1 = 0, veid1 = 0;
     bool ok1 = false, ok2 = false;  // tile exists, is complete and (for ok1) 4-regular
 
     auto tile_of = [&](int64_t it) { return t_lo + slot + it * wg_per_xcd; };
@@ -193,7 +193,10 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
         if (ok1) {
             const int b0 = __builtin_amdgcn_readfirstlane(vbeg1);
             ok1 = __all(lane > TPW || vbeg1 == b0 + 4 * lane) != 0;  // every in-degree of this wave's tets is 4
-            if (ok1) vsrc1 = src[b0 + (lane < NQ ? lane : NQ - 1)];
+            if (ok1) {
+                vsrc1 = src[b0 + (lane < NQ ? lane : NQ - 1)];
+                if (eid) veid1 = eid[b0 + (lane < NQ ? lane : NQ - 1)];
+            }
         }
     };
     // issue every load of this wave's tets of tile `it` (uses vbeg1/vsrc1)
@@ -209,10 +212,16 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
                 ld_row<CPL>(xr[q], x + (uint32_t)(__builtin_amdgcn_readlane(vsrc1, q) * ldx32) + c0l);
             // edge-attribute block of this wave's tets: async DMA straight into its private LDS strip (issued last:
             // hipcc answers any later wait on an ordinary load with vmcnt(0) while an LDS-DMA is in flight)
+            // eid == nullptr: rows already in plan order (one contiguous block); otherwise row k comes from edge_attr[eid[k]]
 #pragma unroll
             for (int q = 0; q < NEV; ++q) {
-                const int idx = q * 64 + lane;
-                glds16(eab + 4 * (idx < NV4 ? idx : 0), myea + q * 256);
+                const int idx = q * 64 + lane, ch = idx < NV4 ? idx : 0;  // 16-byte chunk of the strip: edge ch/5, part ch%5
+                if (eid) {
+                    const int e = (ch * 0x3334) >> 16;
+                    glds16(ea + (int64_t)__shfl(veid1, e) * FE + (ch - 5 * e) * 4, myea + q * 256);
+                } else {
+                    glds16(eab + 4 * ch, myea + q * 256);
+                }
             }
         }
     };
@@ -361,7 +370,7 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
                         ld_row<CPL>(xdv, x + i * ldx + c0l);
                         for (int k = b; k < e_end; ++k) {
                             const int s = src[k];
-                            const float* ar = ea + (int64_t)k * lde;
+                            const float* ar = ea + (int64_t)(eid ? eid[k] : k) * lde;
                             float xv[CPL];
                             ld_row<CPL>(xv, x + (int64_t)s * ldx + c0l);
 #pragma unroll
@@ -387,7 +396,7 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // the index loads issued at the start of this phase are consumed HERE (they landed long ago); otherwise the
             // compiler waits for them later with vmcnt(0), draining the row loads that must fly across the barrier
-            asm volatile("" : "+v"(vbeg2), "+v"(vsrc1), "+v"(vbeg1));
+            asm volatile("" : "+v"(vbeg2), "+v"(vsrc1), "+v"(vbeg1), "+v"(veid1));
             issue_loads(it + 1);  // in flight during the barrier wait and the whole matrix phase
             stamp(trace, trace_cap, it, w, 3);
         }
@@ -461,7 +470,7 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
 }
 
 template <int CIN_PAD, int COUT, int MODE>
-int launch_fused(const int32_t* rowptr, const int32_t* src, int64_t n_dst, const float* x, int64_t ldx, int c_in,
+int launch_fused(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x, int64_t ldx, int c_in,
                  const float* ea, int64_t lde, const float* We, const float* be, const float* Wj, const float* bj,
                  const float* Wi, const float* scale, const float* shift, int relu, float* out, int64_t ldo,
                  hipStream_t stream) {
@@ -476,20 +485,20 @@ int launch_fused(const int32_t* rowptr, const int32_t* src, int64_t n_dst, const
     }
     int grid = (int)(ntiles < DGNN_NUM_CU ? ntiles : DGNN_NUM_CU);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((k_sage_fused<CIN_PAD, COUT, MODE>), dim3(grid), dim3(512), smem, stream, rowptr, src, n_dst, x, ldx, c_in,
+    hipLaunchKernelGGL((k_sage_fused<CIN_PAD, COUT, MODE>), dim3(grid), dim3(512), smem, stream, rowptr, src, eid, n_dst, x, ldx, c_in,
                        ea, lde, We, be, Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles, g_dgnn_trace_buf, g_dgnn_trace_cap);
     return dgnn_check_launch("sage_layer_fused_fwd");
 }
 
 }  // namespace
 
-int dgnn_sage_layer_fused_mfma_try(const int32_t* rowptr, const int32_t* src, int64_t n_dst, const float* x_src, int64_t ldx,
-                                   int c_in, const float* edge_attr_sorted, int64_t lde, const float* We, const float* be,
+int dgnn_sage_layer_fused_mfma_try(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src, int64_t ldx,
+                                   int c_in, const float* edge_attr, int64_t lde, const float* We, const float* be,
                                    const float* Wj, const float* bj, const float* Wi, const float* scale, const float* shift,
                                    int relu, int c_out, float* out, int64_t ldo, hipStream_t stream);  // fused_mfma.hip
 
-extern "C" int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* src, int64_t n_dst, const float* x_src,
-                                         int64_t ldx, int c_in, const float* edge_attr_sorted, int64_t lde, int f_e,
+extern "C" int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src,
+                                         int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e,
                                          const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
                                          const float* scale, const float* shift, int relu, int c_out, float* out, int64_t ldo,
                                          int gemm_mode, void* stream_) {
@@ -498,16 +507,16 @@ extern "C" int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* s
     DGNN_REQUIRE(gemm_mode >= DGNN_GEMM_F32 && gemm_mode <= DGNN_GEMM_BF16X3_FILTER, DGNN_E_INVALID,
                  "sage_layer_fused_fwd: bad gemm_mode %d", gemm_mode);
     if (n_dst == 0) return DGNN_OK;
-    DGNN_REQUIRE(rowptr && src && x_src && edge_attr_sorted && We && be && Wj && Wi && out, DGNN_E_INVALID,
+    DGNN_REQUIRE(rowptr && src && x_src && edge_attr && We && be && Wj && Wi && out, DGNN_E_INVALID,
                  "sage_layer_fused_fwd: null pointer");
     DGNN_REQUIRE((scale == nullptr) == (shift == nullptr), DGNN_E_INVALID, "sage_layer_fused_fwd: scale/shift must come together");
     DGNN_REQUIRE(f_e == FE && lde == FE, DGNN_E_UNSUPPORTED, "sage_layer_fused_fwd: needs f_e == 20 and packed edge rows (lde == 20)");
-    DGNN_REQUIRE(((uintptr_t)edge_attr_sorted % 16) == 0, DGNN_E_UNSUPPORTED, "sage_layer_fused_fwd: edge_attr must be 16-byte aligned");
+    DGNN_REQUIRE(((uintptr_t)edge_attr % 16) == 0, DGNN_E_UNSUPPORTED, "sage_layer_fused_fwd: edge_attr must be 16-byte aligned");
     DGNN_REQUIRE(n_dst * ldx < ((int64_t)1 << 31), DGNN_E_UNSUPPORTED, "sage_layer_fused_fwd: activations beyond 2^31 elements");
     DGNN_REQUIRE(c_in <= 128 && (c_out == 64 || c_out == 128), DGNN_E_UNSUPPORTED,
                  "sage_layer_fused_fwd: supports c_in <= 128 and c_out in {64,128} (got %d -> %d)", c_in, c_out);
     if (gemm_mode == DGNN_GEMM_BF16X3_FILTER) {
-        const int rc = dgnn_sage_layer_fused_mfma_try(rowptr, src, n_dst, x_src, ldx, c_in, edge_attr_sorted, lde, We, be, Wj, bj, Wi,
+        const int rc = dgnn_sage_layer_fused_mfma_try(rowptr, src, eid, n_dst, x_src, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi,
                                                       scale, shift, relu, c_out, out, ldo, stream);
         if (rc != DGNN_E_UNSUPPORTED) return rc;
         gemm_mode = DGNN_GEMM_BF16X3;  // shape not covered by the all-MFMA variant
@@ -515,9 +524,9 @@ extern "C" int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* s
 #define GO(CP, CO)                                                                                                              \
     do {                                                                                                                        \
         if (gemm_mode == DGNN_GEMM_F32)                                                                                         \
-            return launch_fused<CP, CO, 0>(rowptr, src, n_dst, x_src, ldx, c_in, edge_attr_sorted, lde, We, be, Wj, bj, Wi, scale, \
+            return launch_fused<CP, CO, 0>(rowptr, src, eid, n_dst, x_src, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, \
                                            shift, relu, out, ldo, stream);                                                      \
-        return launch_fused<CP, CO, 1>(rowptr, src, n_dst, x_src, ldx, c_in, edge_attr_sorted, lde, We, be, Wj, bj, Wi, scale,     \
+        return launch_fused<CP, CO, 1>(rowptr, src, eid, n_dst, x_src, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale,     \
                                        shift, relu, out, ldo, stream);                                                          \
     } while (0)
     if (c_in <= 32) { if (c_out == 64) GO(32, 64); else GO(32, 128); }

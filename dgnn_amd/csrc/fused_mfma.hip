@@ -69,7 +69,7 @@ __device__ __forceinline__ void ld_vec(float (&v)[NB], const float* p, bool vec)
 
 template <int CIN_PAD, int COUT>
 __global__ void __launch_bounds__(512, 2)
-k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, int64_t n_dst,
+k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid, int64_t n_dst,
                   const float* __restrict__ x, int64_t ldx, int c_in, const float* __restrict__ ea, int64_t lde,
                   const float* __restrict__ We, const float* __restrict__ be, const float* __restrict__ Wj,
                   const float* __restrict__ bj, const float* __restrict__ Wi, const float* __restrict__ scale,
@@ -160,7 +160,7 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
 
     float xd[RB][NB], xr[RB][4][NB];
     bool regular = false;
-    int vbeg1 = 0, vbeg2 = 0, vsrc1 = 0;  // index pipeline, see fused.hip
+    int vbeg1 = 0, vbeg2 = 0, vsrc1 = 0, veid1 = 0;  // index pipeline, see fused.hip
     bool ok1 = false, ok2 = false;
     // nv = valid tets of this wave's group (TPW except in the last tile).  A short group still takes the matrix-core
     // path with clamped (duplicated) rows so that a tet's result does not depend on where the tile grid cuts the
@@ -179,7 +179,10 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         if (ok1) {
             const int b0 = __builtin_amdgcn_readfirstlane(vbeg1);
             ok1 = __all(vbeg1 == b0 + 4 * (lane < nv1 ? lane : nv1)) != 0;
-            if (ok1) vsrc1 = src[b0 + (lane < 4 * nv1 ? lane : 4 * nv1 - 1)];
+            if (ok1) {
+                vsrc1 = src[b0 + (lane < 4 * nv1 ? lane : 4 * nv1 - 1)];
+                if (eid) veid1 = eid[b0 + (lane < 4 * nv1 ? lane : 4 * nv1 - 1)];
+            }
         }
     };
     auto issue_loads = [&](int64_t it) {
@@ -198,12 +201,25 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                     ld_vec<NB>(xr[rb][r], x + (uint32_t)(s_ * ldx32) + c0l, vec);
                 }
             }
-            // attribute block of this wave's tets: LDS-DMA into the private strip (issued last, see fused.hip)
+            // attribute block of this wave's tets: LDS-DMA into the private strip (issued last, see fused.hip).
+            // eid == nullptr: the rows are in plan order, one contiguous block.  Otherwise every 80-byte row is
+            // fetched from its place in the caller's edge_attr (row eid[k]) -- no staging copy of the edge features.
+            if (eid) {
+                auto row_ptr = [&](int fi) -> const float* {     // float index within the strip -> global address
+                    const int e = (fi * 0xCCD) >> 16;             // fi / 20 for fi < 8192
+                    return ea + (int64_t)__shfl(veid1, e) * FE + (fi - e * FE);
+                };
 #pragma unroll
-            for (int q = 0; q < C::EA_FULL; ++q) glds16(eab + min(q * 256 + lane * 4, ea_last), myea + q * 256);
+                for (int q = 0; q < C::EA_FULL; ++q) glds16(row_ptr(q * 256 + lane * 4), myea + q * 256);
 #pragma unroll
-            for (int q = 0; q < C::EA_TAIL; ++q)
-                glds4(eab + min(C::EA_FULL * 256 + q * 64 + lane, ea_last + 3), myea + C::EA_FULL * 256 + q * 64);
+                for (int q = 0; q < C::EA_TAIL; ++q) glds4(row_ptr(C::EA_FULL * 256 + q * 64 + lane), myea + C::EA_FULL * 256 + q * 64);
+            } else {
+#pragma unroll
+                for (int q = 0; q < C::EA_FULL; ++q) glds16(eab + min(q * 256 + lane * 4, ea_last), myea + q * 256);
+#pragma unroll
+                for (int q = 0; q < C::EA_TAIL; ++q)
+                    glds4(eab + min(C::EA_FULL * 256 + q * 64 + lane, ea_last + 3), myea + C::EA_FULL * 256 + q * 64);
+            }
         }
     };
     auto advance_idx = [&](int64_t it_next) {
@@ -288,9 +304,9 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
 #pragma unroll
                     for (int cb = 0; cb < NB; ++cb) {
                         const char* bp = bpbuf + ((cb * 3) * 48 + (tq < 3 ? tq : 0) * 16 + jcol) * 16;
-                        uint4 u0 = *reinterpret_cast<const uint4*>(bp), u1 = *reinterpret_cast<const uint4*>(bp + 768),
-                              u2 = *reinterpret_cast<const uint4*>(bp + 1536);
-                        if (tq == 3) u0 = u1 = u2 = make_uint4(0, 0, 0, 0);
+                        // k-group 3 re-reads group 0: its A operand is all zero, so any finite B will do (saves 12 selects)
+                        const uint4 u0 = *reinterpret_cast<const uint4*>(bp), u1 = *reinterpret_cast<const uint4*>(bp + 768),
+                                    u2 = *reinterpret_cast<const uint4*>(bp + 1536);
                         const bf16x8 bh = __builtin_bit_cast(bf16x8, u0), bm = __builtin_bit_cast(bf16x8, u1),
                                      bl = __builtin_bit_cast(bf16x8, u2);
                         f32x4_t d = {0.f, 0.f, 0.f, 0.f};
@@ -301,11 +317,13 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                         d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, d, 0, 0, 0);
                         d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d, 0, 0, 0);
                         // d[r] = phi of edge 4*tq + r (the r-th in-edge of this lane's tet), channel c0 + cb
-                        float a = 0.f;
+                        // in-order sum over the tet's 4 in-edges.  Lanes past c_in need no masking: their filter
+                        // operand and their rows of Wj|Wi are zero, and what they loaded (channel 0..) is finite.
+                        float a = __fmul_rn(xr[rb][0][cb], d[0]);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) a = __fadd_rn(a, __fmul_rn(xr[rb][r][cb], d[r]));
-                        aout[cb] = on ? a * 0.25f : 0.f;
-                        xv[cb] = on ? xd[rb][cb] : 0.f;
+                        for (int r = 1; r < 4; ++r) a = __fmaf_rn(xr[rb][r][cb], d[r], a);
+                        aout[cb] = a * 0.25f;
+                        xv[cb] = xd[rb][cb];
                     }
                     put_seg((int)(it & 1), w * TPW + rb * 4 + tq, aout, xv);
                 }
@@ -323,7 +341,7 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                         for (int cb = 0; cb < NB; ++cb) xv[cb] = x[i * ldx + c0 + cb];
                         for (int k = b; k < e_end; ++k) {
                             const int s_ = src[k];
-                            const float* ar = ea + (int64_t)k * lde;
+                            const float* ar = ea + (int64_t)(eid ? eid[k] : k) * lde;
 #pragma unroll 1
                             for (int cb = 0; cb < NB; ++cb) {
                                 float p = be[c0 + cb];
@@ -340,7 +358,7 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
             }
             stamp(trace, trace_cap, it, w, 2);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // strip reads returned before the next DMA may land
-            asm volatile("" : "+v"(vbeg2), "+v"(vsrc1), "+v"(vbeg1));  // consume the index loads here (see fused.hip)
+            asm volatile("" : "+v"(vbeg2), "+v"(vsrc1), "+v"(vbeg1), "+v"(veid1));  // consume the index loads here (see fused.hip)
             issue_loads(it + 1);
             stamp(trace, trace_cap, it, w, 3);
         }
@@ -401,7 +419,7 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
 }
 
 template <int CIN_PAD, int COUT>
-int launch2(const int32_t* rowptr, const int32_t* src, int64_t n_dst, const float* x, int64_t ldx, int c_in, const float* ea,
+int launch2(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x, int64_t ldx, int c_in, const float* ea,
             int64_t lde, const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
             const float* scale, const float* shift, int relu, float* out, int64_t ldo, int xvec, hipStream_t stream) {
     using C = Cfg2<CIN_PAD, COUT>;
@@ -415,7 +433,7 @@ int launch2(const int32_t* rowptr, const int32_t* src, int64_t n_dst, const floa
     }
     int grid = (int)(ntiles < DGNN_NUM_CU ? ntiles : DGNN_NUM_CU);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((k_sage_fused_mfma<CIN_PAD, COUT>), dim3(grid), dim3(512), smem, stream, rowptr, src, n_dst, x, ldx, c_in, ea,
+    hipLaunchKernelGGL((k_sage_fused_mfma<CIN_PAD, COUT>), dim3(grid), dim3(512), smem, stream, rowptr, src, eid, n_dst, x, ldx, c_in, ea,
                        lde, We, be, Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles, xvec, g_dgnn_trace_buf, g_dgnn_trace_cap);
     return dgnn_check_launch("sage_layer_fused_fwd(mfma filter)");
 }
@@ -423,8 +441,8 @@ int launch2(const int32_t* rowptr, const int32_t* src, int64_t n_dst, const floa
 }  // namespace
 
 // Returns DGNN_E_UNSUPPORTED when the shape does not fit this variant (the caller then uses fused.hip MODE 1).
-int dgnn_sage_layer_fused_mfma_try(const int32_t* rowptr, const int32_t* src, int64_t n_dst, const float* x_src, int64_t ldx,
-                                   int c_in, const float* edge_attr_sorted, int64_t lde, const float* We, const float* be,
+int dgnn_sage_layer_fused_mfma_try(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src,
+                                   int64_t ldx, int c_in, const float* edge_attr, int64_t lde, const float* We, const float* be,
                                    const float* Wj, const float* bj, const float* Wi, const float* scale, const float* shift,
                                    int relu, int c_out, float* out, int64_t ldo, hipStream_t stream) {
     const int cin_pad = c_in <= 32 ? 32 : (c_in <= 64 ? 64 : 128);
@@ -432,7 +450,7 @@ int dgnn_sage_layer_fused_mfma_try(const int32_t* rowptr, const int32_t* src, in
     if (c_in % nb != 0 || (c_out != 64 && c_out != 128) || (cin_pad == 128 && c_out != 128)) return DGNN_E_UNSUPPORTED;
     const int xvec = (((uintptr_t)x_src % 16) == 0 && ldx % 4 == 0) ? 1 : 0;
     if (nb >= 4 && !xvec) return DGNN_E_UNSUPPORTED;
-#define GO2(CP, CO) return launch2<CP, CO>(rowptr, src, n_dst, x_src, ldx, c_in, edge_attr_sorted, lde, We, be, Wj, bj, Wi, scale, \
+#define GO2(CP, CO) return launch2<CP, CO>(rowptr, src, eid, n_dst, x_src, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, \
                                            shift, relu, out, ldo, xvec, stream)
     if (cin_pad == 32) { if (c_out == 64) GO2(32, 64); else GO2(32, 128); }
     if (cin_pad == 64) { if (c_out == 64) GO2(64, 64); else GO2(64, 128); }

@@ -209,9 +209,14 @@ class SurfaceNet(nn.Module):
             x_dst = x[:plan.n_dst]
             simple = isinstance(le, Linear) and le.in_features in (2, 20)
             if simple and le.in_features == 20 and ops.fused_layer_supported(x.size(1), conv.lin_j.out_features, 20):
-                ea = plan.sorted_edge_attr(xe) if sorted_attr else xe
+                # sorted_attr: xe is in the caller's edge order.  Either the kernel gathers each row by eid (no staging
+                # copy of the edge features), or the rows are staged into plan order once and reused by all layers.
+                if sorted_attr and ops.EDGE_GATHER_IN_KERNEL and xe.stride(0) == 20 and xe.data_ptr() % 16 == 0:
+                    ea, eid = xe, plan.eid
+                else:
+                    ea, eid = (plan.sorted_edge_attr(xe) if sorted_attr else xe), None
                 x = ops.sage_layer_fused_fwd(plan.rowptr, plan.src, plan.n_dst, x, ea, le.weight, le.bias, conv.lin_j.weight,
-                                             conv.lin_j.bias, conv.lin_i.weight, scale, shift, True, out=out)
+                                             conv.lin_j.bias, conv.lin_i.weight, scale, shift, True, out=out, eid=eid)
                 continue
             if simple:
                 ea = plan.sorted_edge_attr(xe) if sorted_attr else xe

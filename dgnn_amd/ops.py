@@ -246,11 +246,16 @@ GEMM_F32, GEMM_BF16X3, GEMM_BF16X3_FILTER = 0, 1, 2
 # dense part ("bf16x3"), or split-bf16 MFMA for the dense part AND the filter MLP ("bf16x3f"); all fp32-class accuracy
 GEMM_MODE = {"f32": GEMM_F32, "bf16x3": GEMM_BF16X3, "bf16x3f": GEMM_BF16X3_FILTER}[
     __import__("os").environ.get("DGNN_GEMM_MODE", "bf16x3f")]
+# whole-graph inference: fused layers read the caller's edge_attr in place (rows DMA-gathered by the plan's eid) instead of
+# staging a plan-ordered copy once per scene; DGNN_EDGE_STAGING=1 restores the staged copy
+EDGE_GATHER_IN_KERNEL = __import__("os").environ.get("DGNN_EDGE_STAGING", "0") != "1"
 
 
-def sage_layer_fused_fwd(rowptr, src, n_dst, x_src, edge_attr_sorted, We, be, Wj, bj, Wi, scale, shift, relu, gemm_mode=None,
-                         out=None):
-    """`out` (optional): a [>= n_dst, c_out] buffer whose first n_dst rows receive the result (the partitioned
+def sage_layer_fused_fwd(rowptr, src, n_dst, x_src, edge_attr, We, be, Wj, bj, Wi, scale, shift, relu, gemm_mode=None,
+                         out=None, eid=None):
+    """`eid` (the plan's edge ids): edge_attr is the caller's tensor in its own row order and rows are gathered inside the
+    kernel; eid=None: edge_attr is already in plan order.
+    `out` (optional): a [>= n_dst, c_out] buffer whose first n_dst rows receive the result (the partitioned
     forward passes the next layer's [n_own + n_halo, C] activation buffer, so no copy is needed)."""
     _req(x_src, "x_src", dim=2)
     c_in, c_out = x_src.size(1), Wj.size(0)
@@ -261,7 +266,7 @@ def sage_layer_fused_fwd(rowptr, src, n_dst, x_src, edge_attr_sorted, We, be, Wj
         if out.size(0) < n_dst or out.size(1) != c_out or out.stride(0) != c_out:
             raise ValueError("out must be a contiguous [>= n_dst, c_out] buffer")
     check(lib().dgnn_sage_layer_fused_fwd(
-        ptr(rowptr), ptr(src), n_dst, ptr(x_src), _ld(x_src), c_in, ptr(edge_attr_sorted), _ld(edge_attr_sorted), We.size(1),
+        ptr(rowptr), ptr(src), ptr(eid), n_dst, ptr(x_src), _ld(x_src), c_in, ptr(edge_attr), _ld(edge_attr), We.size(1),
         ptr(We), ptr(be), ptr(Wj), ptr(bj), ptr(Wi), ptr(scale), ptr(shift), int(bool(relu)), c_out, ptr(out), c_out,
         GEMM_MODE if gemm_mode is None else gemm_mode, stream_ptr()), "dgnn_sage_layer_fused_fwd")
     return out

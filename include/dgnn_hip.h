@@ -149,9 +149,11 @@ int dgnn_sage_aggregate_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const
 /* ------------------------------------------------------------------------------------------------
  * Fused inference layer (the timed path, surfaceNetStaticEdgeFilters.py:343-346, one call per
  * layer): aggregate + lin_j + lin_i + BN(eval) + ReLU in one persistent launch; the aggregate
- * never leaves the CU.  Requires c_in <= 128, c_out in {64,128}, f_e == 20, edge rows in plan
- * order (edge_attr_sorted).  Returns DGNN_E_UNSUPPORTED otherwise (callers fall back to the
- * aggregate + linear pair above).  gemm_mode selects how the dense part runs on the matrix cores.
+ * never leaves the CU.  Requires c_in <= 128, c_out in {64,128}, f_e == 20 with packed rows.
+ * Edge row of plan position k = edge_attr[eid ? eid[k] : k]: pass the plan's eid to read the
+ * caller's edge_attr in place (each 80-byte row is DMA-gathered into LDS; no staging copy), or
+ * eid == NULL with rows already in plan order (dgnn_gather_rows_f32).  Returns DGNN_E_UNSUPPORTED
+ * for other shapes (callers fall back to the aggregate + linear pair above).  gemm_mode selects how the dense part runs on the matrix cores.
  * ---------------------------------------------------------------------------------------------- */
 #define DGNN_GEMM_F32 0    /* v_mfma_f32_32x32x2_f32: bit-faithful fp32 fmaf chains */
 #define DGNN_GEMM_BF16X3 1 /* operands split exactly into 3 bf16 parts, 6 partial products on v_mfma_f32_32x32x16_bf16,
@@ -159,8 +161,8 @@ int dgnn_sage_aggregate_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const
 #define DGNN_GEMM_BF16X3_FILTER 2 /* as BF16X3, and the 20-tap filter MLP runs on v_mfma_f32_16x16x32_bf16 too (same exact
                                      3-part split, 6 products, fp32 accumulate); falls back to BF16X3 for shapes it
                                      does not cover (c_in not a multiple of c_in_pad/16, unaligned wide rows) */
-int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* src, int64_t n_dst, const float* x_src,
-                              int64_t ldx, int c_in, const float* edge_attr_sorted, int64_t lde, int f_e,
+int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src,
+                              int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e,
                               const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
                               const float* scale, const float* shift, int relu, int c_out, float* out, int64_t ldo,
                               int gemm_mode, void* stream);

@@ -405,6 +405,10 @@ def test_fused_layer_gemm_modes_vs_fp64(c_in, c_out):
                                        Wi.to(DEV), sc.to(DEV), sh.to(DEV), True, gemm_mode=mode)
         errs[mode] = rel_err(out, ref)
         assert errs[mode] < 3e-6, (mode, errs)
+        # same launch reading the caller's edge_attr in place (rows DMA-gathered by eid): identical bits
+        out_g = ops.sage_layer_fused_fwd(plan.rowptr, plan.src, n, x.to(DEV), ea.to(DEV), We.to(DEV), be.to(DEV), Wj.to(DEV),
+                                         bj.to(DEV), Wi.to(DEV), sc.to(DEV), sh.to(DEV), True, gemm_mode=mode, eid=plan.eid)
+        assert torch.equal(out_g, out), mode
     assert errs[ops.GEMM_BF16X3] < 3 * errs[ops.GEMM_F32] + 2e-7, errs
     assert errs[ops.GEMM_BF16X3_FILTER] < 3 * errs[ops.GEMM_F32] + 2e-7, errs
 
