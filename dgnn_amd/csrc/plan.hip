@@ -35,14 +35,22 @@ __global__ void k_zero_i32(int32_t* p, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0;
 }
 
-__global__ void k_plan_count(const int64_t* __restrict__ key, int64_t E, int32_t* __restrict__ deg) {
+// `need` (may be NULL): device flag written by k_plan_regular -- 0 = the regular fast path already produced the plan and
+// the generic kernels return at once, non-zero = run.  `sc` = element stride between consecutive edges of a row.
+__device__ __forceinline__ bool plan_skip(const int32_t* need) { return need != nullptr && *need == 0; }
+
+__global__ void k_plan_count(const int64_t* __restrict__ key, int64_t sc, int64_t E, int32_t* __restrict__ deg,
+                             const int32_t* __restrict__ need) {
+    if (plan_skip(need)) return;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x)
-        atomicAdd(&deg[key[e]], 1);
+        atomicAdd(&deg[key[e * sc]], 1);
 }
 
 // block-local exclusive scan of SCAN_TILE items; block total -> sums[blockIdx.x]
 __global__ void __launch_bounds__(SCAN_THREADS) k_scan_tile(const int32_t* __restrict__ in, int64_t n,
-                                                            int32_t* __restrict__ out, int32_t* __restrict__ sums) {
+                                                            int32_t* __restrict__ out, int32_t* __restrict__ sums,
+                                                            const int32_t* __restrict__ need) {
+    if (plan_skip(need)) return;
     __shared__ int32_t wsum[SCAN_THREADS / 64];
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     int32_t v[SCAN_ITEMS];
@@ -75,7 +83,8 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_tile(const int32_t* __res
 }
 
 // single block: exclusive scan of the tile sums in place; total -> sums[nb]
-__global__ void __launch_bounds__(1024) k_scan_sums(int32_t* __restrict__ sums, int nb) {
+__global__ void __launch_bounds__(1024) k_scan_sums(int32_t* __restrict__ sums, int nb, const int32_t* __restrict__ need) {
+    if (plan_skip(need)) return;
     __shared__ int32_t wsum[16];
     __shared__ int32_t carry;
     if (threadIdx.x == 0) carry = 0;
@@ -103,7 +112,9 @@ __global__ void __launch_bounds__(1024) k_scan_sums(int32_t* __restrict__ sums, 
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS) k_scan_add(int32_t* __restrict__ out, int64_t n,
-                                                           const int32_t* __restrict__ sums, int nb) {
+                                                           const int32_t* __restrict__ sums, int nb,
+                                                           const int32_t* __restrict__ need) {
+    if (plan_skip(need)) return;
     const int32_t add = sums[blockIdx.x];
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
 #pragma unroll
@@ -112,10 +123,11 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_add(int32_t* __restrict__
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = sums[nb];
 }
 
-__global__ void k_plan_fill(const int64_t* __restrict__ key, int64_t E, const int32_t* __restrict__ rowptr,
-                            int32_t* __restrict__ deg, int32_t* __restrict__ tmp) {
+__global__ void k_plan_fill(const int64_t* __restrict__ key, int64_t sc, int64_t E, const int32_t* __restrict__ rowptr,
+                            int32_t* __restrict__ deg, int32_t* __restrict__ tmp, const int32_t* __restrict__ need) {
+    if (plan_skip(need)) return;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t d = key[e];
+        const int64_t d = key[e * sc];
         const int32_t slot = rowptr[d] + atomicSub(&deg[d], 1) - 1;
         tmp[slot] = (int32_t)e;
     }
@@ -130,19 +142,20 @@ __device__ __forceinline__ void cswap(int32_t& a, int32_t& b) {
 // one thread per key: sort its segment of `tmp` ascending and emit eid/other.
 // Segments longer than 32 are queued for k_plan_emit_big.
 __global__ void k_plan_emit(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ tmp,
-                            const int64_t* __restrict__ other_row, int64_t n_key, int32_t* __restrict__ eid,
+                            const int64_t* __restrict__ other_row, int64_t sc, int64_t n_key, int32_t* __restrict__ eid,
                             int32_t* __restrict__ other, int32_t* __restrict__ big_count,
-                            int32_t* __restrict__ big_list) {
+                            int32_t* __restrict__ big_list, const int32_t* __restrict__ need) {
+    if (plan_skip(need)) return;
     for (int64_t d = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; d < n_key; d += (int64_t)gridDim.x * blockDim.x) {
         const int32_t beg = rowptr[d], n = rowptr[d + 1] - beg;
         if (n <= 4) {
             int32_t v0 = n > 0 ? tmp[beg] : INT32_MAX, v1 = n > 1 ? tmp[beg + 1] : INT32_MAX;
             int32_t v2 = n > 2 ? tmp[beg + 2] : INT32_MAX, v3 = n > 3 ? tmp[beg + 3] : INT32_MAX;
             cswap(v0, v1); cswap(v2, v3); cswap(v0, v2); cswap(v1, v3); cswap(v1, v2);
-            if (n > 0) { eid[beg] = v0; other[beg] = (int32_t)other_row[v0]; }
-            if (n > 1) { eid[beg + 1] = v1; other[beg + 1] = (int32_t)other_row[v1]; }
-            if (n > 2) { eid[beg + 2] = v2; other[beg + 2] = (int32_t)other_row[v2]; }
-            if (n > 3) { eid[beg + 3] = v3; other[beg + 3] = (int32_t)other_row[v3]; }
+            if (n > 0) { eid[beg] = v0; other[beg] = (int32_t)other_row[(int64_t)v0 * sc]; }
+            if (n > 1) { eid[beg + 1] = v1; other[beg + 1] = (int32_t)other_row[(int64_t)v1 * sc]; }
+            if (n > 2) { eid[beg + 2] = v2; other[beg + 2] = (int32_t)other_row[(int64_t)v2 * sc]; }
+            if (n > 3) { eid[beg + 3] = v3; other[beg + 3] = (int32_t)other_row[(int64_t)v3 * sc]; }
         } else if (n <= 32) {
             int32_t v[32];
             for (int i = 0; i < n; ++i) {
@@ -151,20 +164,86 @@ __global__ void k_plan_emit(const int32_t* __restrict__ rowptr, const int32_t* _
                 while (j > 0 && v[j - 1] > x) { v[j] = v[j - 1]; --j; }
                 v[j] = x;
             }
-            for (int i = 0; i < n; ++i) { eid[beg + i] = v[i]; other[beg + i] = (int32_t)other_row[v[i]]; }
+            for (int i = 0; i < n; ++i) { eid[beg + i] = v[i]; other[beg + i] = (int32_t)other_row[(int64_t)v[i] * sc]; }
         } else {
             big_list[atomicAdd(big_count, 1)] = (int32_t)d;
         }
     }
 }
 
+// ---- fast path for the reference's own graph layout -------------------------------------------------------------
+// processing/data.py:434-438 hands the model `adjacencies` [4N,2]: row 4t+r = (t, r-th neighbour of cell t), every
+// cell has exactly 4 rows and the relation is symmetric (cells share facets).  Then in-edges(t) = the reverse of its
+// out-edges, rowptr[t] = 4t, and the stable by-destination order is: neighbours ascending, and for a neighbour s the
+// slots r' of s's own rows that point back at t, ascending (edge id 4s + r').  One thread per cell builds its 4
+// entries from its own 4 rows and its neighbours' rows -- no atomics, no scan, no segment sort.
+// Everything is verified on the fly (other[k] == k/4, keys in range, count(s->t) == count(t->s) for every
+// neighbour; the last one, checked by every cell, is exactly global symmetry).  Any violation clears nothing but sets
+// *need = 1, and the generic kernels that follow in the stream then rebuild the plan from scratch.
+// BY_KEY_ROW = false is the transposed plan of the same layout (sorted by source): the identity.
+template <bool BY_DST>
+__global__ void __launch_bounds__(256) k_plan_regular(const int64_t* __restrict__ key, const int64_t* __restrict__ oth, int64_t sc,
+                                                      int64_t n_key, int32_t* __restrict__ rowptr, int32_t* __restrict__ other,
+                                                      int32_t* __restrict__ eid, int32_t* __restrict__ need) {
+    bool bad = false;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n_key; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t k4[4], o4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            k4[r] = key[(4 * t + r) * sc];
+            o4[r] = oth[(4 * t + r) * sc];
+        }
+        rowptr[t] = (int32_t)(4 * t);
+        if (t == n_key - 1) rowptr[n_key] = (int32_t)(4 * n_key);
+        if (!BY_DST) {
+            // sorted by source and the source row is k/4: already in order
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bad |= k4[r] != t;
+                eid[4 * t + r] = (int32_t)(4 * t + r);
+                other[4 * t + r] = (int32_t)o4[r];
+            }
+            continue;
+        }
+        int32_t d[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bad |= o4[r] != t || k4[r] < 0 || k4[r] >= n_key;
+            d[r] = (int32_t)(k4[r] < 0 ? 0 : (k4[r] >= n_key ? n_key - 1 : k4[r]));
+        }
+        cswap(d[0], d[1]); cswap(d[2], d[3]); cswap(d[0], d[2]); cswap(d[1], d[3]); cswap(d[1], d[2]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t s_ = d[i];
+            int occ = 0, mult = 0;  // which of the duplicates of s_ this is, and how many there are
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                mult += d[j] == d[i];
+                occ += (j < i) && d[j] == d[i];
+            }
+            int cnt = 0, slot = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool hit = key[(4 * s_ + r) * sc] == t;
+                if (hit && cnt == occ) slot = r;
+                cnt += hit;
+            }
+            bad |= cnt != mult;
+            other[4 * t + i] = (int32_t)s_;
+            eid[4 * t + i] = (int32_t)(4 * s_ + slot);
+        }
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(need, 1);
+}
+
 // one block per queued long segment: rank sort (edge positions are distinct)
 __global__ void __launch_bounds__(256) k_plan_emit_big(const int32_t* __restrict__ rowptr,
                                                        const int32_t* __restrict__ tmp,
-                                                       const int64_t* __restrict__ other_row,
+                                                       const int64_t* __restrict__ other_row, int64_t sc,
                                                        int32_t* __restrict__ eid, int32_t* __restrict__ other,
                                                        const int32_t* __restrict__ big_count,
-                                                       const int32_t* __restrict__ big_list) {
+                                                       const int32_t* __restrict__ big_list, const int32_t* __restrict__ need) {
+    if (plan_skip(need)) return;
     const int nbig = *big_count;
     for (int b = blockIdx.x; b < nbig; b += gridDim.x) {
         const int32_t d = big_list[b];
@@ -174,7 +253,7 @@ __global__ void __launch_bounds__(256) k_plan_emit_big(const int32_t* __restrict
             int32_t rank = 0;
             for (int j = 0; j < n; ++j) rank += tmp[beg + j] < x;
             eid[beg + rank] = x;
-            other[beg + rank] = (int32_t)other_row[x];
+            other[beg + rank] = (int32_t)other_row[(int64_t)x * sc];
         }
     }
 }
@@ -226,50 +305,68 @@ int dgnn_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, int32_t*
         return DGNN_OK;
     }
     const int nb = (int)dgnn_cdiv(n, SCAN_TILE);
-    hipLaunchKernelGGL(k_scan_tile, dim3(nb), dim3(SCAN_THREADS), 0, stream, in, n, out, sums_scratch);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums_scratch, nb);
-    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_THREADS), 0, stream, out, n, sums_scratch, nb);
+    const int32_t* none = nullptr;
+    hipLaunchKernelGGL(k_scan_tile, dim3(nb), dim3(SCAN_THREADS), 0, stream, in, n, out, sums_scratch, none);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums_scratch, nb, none);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_THREADS), 0, stream, out, n, sums_scratch, nb, none);
     return DGNN_OK;
 }
 
-// scratch layout (int32): deg[n_key] | tmp[E] | sums[nb+1] | big_count[1] | big_list[n_key/33+1]
+// scratch layout (int32): deg[n_key] | tmp[E] | sums[nb+2] | big_count[1] | big_list[E/33+2] | need[1]
 extern "C" int64_t dgnn_plan_scratch_elems(int64_t E, int64_t n_key) {
     if (E < 0 || n_key < 0) return 0;
-    return n_key + E + (dgnn_cdiv(n_key, SCAN_TILE) + 2) + 1 + (E / 33 + 2);
+    return n_key + E + (dgnn_cdiv(n_key, SCAN_TILE) + 2) + 1 + (E / 33 + 2) + 1;
 }
 
-extern "C" int dgnn_plan_build(const int64_t* edge_index, int64_t E, int64_t n_key, int by, int32_t* rowptr,
-                               int32_t* other, int32_t* eid, int32_t* scratch, void* stream_) {
+extern "C" int dgnn_plan_build(const int64_t* edge_index, int64_t stride_row, int64_t stride_col, int64_t E, int64_t n_key, int by,
+                               int32_t* rowptr, int32_t* other, int32_t* eid, int32_t* scratch, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DGNN_REQUIRE(E >= 0 && n_key >= 0 && (by == 0 || by == 1), DGNN_E_INVALID, "plan_build: bad sizes E=%lld n=%lld by=%d",
                  (long long)E, (long long)n_key, by);
     DGNN_REQUIRE(E < INT32_MAX && n_key < INT32_MAX, DGNN_E_UNSUPPORTED, "plan_build: E and n must fit int32");
     DGNN_REQUIRE(rowptr && scratch && (E == 0 || (edge_index && other && eid)), DGNN_E_INVALID, "plan_build: null pointer");
-    const int64_t* key = edge_index + (by ? E : 0);
-    const int64_t* oth = edge_index + (by ? 0 : E);
+    DGNN_REQUIRE(E <= 1 || stride_col != 0, DGNN_E_INVALID, "plan_build: zero column stride");
+    const int64_t* key = edge_index + (by ? stride_row : 0);
+    const int64_t* oth = edge_index + (by ? 0 : stride_row);
+    const int64_t sc = stride_col;
     int32_t* deg = scratch;
     int32_t* tmp = deg + n_key;
     const int nb = (int)dgnn_cdiv(n_key, SCAN_TILE);
     int32_t* sums = tmp + E;
     int32_t* big_count = sums + nb + 2;
     int32_t* big_list = big_count + 1;
+    int32_t* need = big_list + (E / 33 + 2);
 
-    // zero deg, sums, big_count in one go would touch tmp too; two small launches instead
+    // zero deg, sums, big_count in one go would touch tmp too; small launches instead
     hipLaunchKernelGGL(k_zero_i32, dim3(dgnn_grid_cap(dgnn_cdiv(n_key, 256))), dim3(256), 0, stream, deg, n_key);
     hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, big_count, (int64_t)1);
     if (n_key == 0) {
         hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, rowptr, (int64_t)1);
         return dgnn_check_launch("plan_build");
     }
-    if (E > 0) hipLaunchKernelGGL(k_plan_count, dim3(dgnn_grid_cap(dgnn_cdiv(E, 256))), dim3(256), 0, stream, key, E, deg);
-    hipLaunchKernelGGL(k_scan_tile, dim3(nb), dim3(SCAN_THREADS), 0, stream, deg, n_key, rowptr, sums);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums, nb);
-    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_THREADS), 0, stream, rowptr, n_key, sums, nb);
+    // candidate for the regular fast path: then the generic kernels are launched small (they are grid-stride loops
+    // and normally return on their first instruction) -- a wrong guess costs speed, never correctness
+    const bool try_regular = E == 4 * n_key && E > 0;
+    const int32_t* flag = nullptr;
+    if (try_regular) {
+        hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, need, (int64_t)1);
+        const dim3 g(dgnn_grid_cap(dgnn_cdiv(n_key, 256)));
+        if (by) hipLaunchKernelGGL((k_plan_regular<true>), g, dim3(256), 0, stream, key, oth, sc, n_key, rowptr, other, eid, need);
+        else hipLaunchKernelGGL((k_plan_regular<false>), g, dim3(256), 0, stream, key, oth, sc, n_key, rowptr, other, eid, need);
+        flag = need;
+    }
+    const int cap = try_regular ? 4 * DGNN_NUM_CU : (1 << 30);
+    auto grid_for = [&](int64_t n) { const int64_t g = dgnn_grid_cap(dgnn_cdiv(n, 256)); return dim3((unsigned)(g < cap ? g : cap)); };
+    if (E > 0) hipLaunchKernelGGL(k_plan_count, grid_for(E), dim3(256), 0, stream, key, sc, E, deg, flag);
+    hipLaunchKernelGGL(k_scan_tile, dim3(nb), dim3(SCAN_THREADS), 0, stream, deg, n_key, rowptr, sums, flag);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums, nb, flag);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_THREADS), 0, stream, rowptr, n_key, sums, nb, flag);
     if (E > 0) {
-        hipLaunchKernelGGL(k_plan_fill, dim3(dgnn_grid_cap(dgnn_cdiv(E, 256))), dim3(256), 0, stream, key, E, rowptr, deg, tmp);
-        hipLaunchKernelGGL(k_plan_emit, dim3(dgnn_grid_cap(dgnn_cdiv(n_key, 256))), dim3(256), 0, stream, rowptr, tmp, oth,
-                           n_key, eid, other, big_count, big_list);
-        hipLaunchKernelGGL(k_plan_emit_big, dim3(256), dim3(256), 0, stream, rowptr, tmp, oth, eid, other, big_count, big_list);
+        hipLaunchKernelGGL(k_plan_fill, grid_for(E), dim3(256), 0, stream, key, sc, E, rowptr, deg, tmp, flag);
+        hipLaunchKernelGGL(k_plan_emit, grid_for(n_key), dim3(256), 0, stream, rowptr, tmp, oth, sc, n_key, eid, other, big_count,
+                           big_list, flag);
+        hipLaunchKernelGGL(k_plan_emit_big, dim3(256), dim3(256), 0, stream, rowptr, tmp, oth, sc, eid, other, big_count, big_list,
+                           flag);
     }
     return dgnn_check_launch("plan_build");
 }

@@ -22,7 +22,7 @@ class GraphPlan:
     def __init__(self, edge_index: torch.Tensor, n_src: int, n_dst: int):
         if edge_index.dtype != torch.int64:
             edge_index = edge_index.to(torch.int64)  # inference_layer does the same (:339)
-        self.edge_index = edge_index.contiguous()
+        self.edge_index = edge_index  # any strides: the plan builder reads the (possibly transposed) view in place
         self.n_src, self.n_dst, self.E = int(n_src), int(n_dst), int(edge_index.size(1))
         self.rowptr, self.src, self.eid = ops.plan_build(self.edge_index, self.n_dst, by=1)
         self._t = None

@@ -10,7 +10,7 @@ import torch
 from ._lib import DgnnError, check, lib, ptr, stream_ptr
 
 
-def _req(t: torch.Tensor, name: str, dtype=torch.float32, dim=None):
+def _req(t: torch.Tensor, name: str, dtype=torch.float32, dim=None, any_stride=False):
     if not isinstance(t, torch.Tensor):
         raise TypeError("%s must be a tensor" % name)
     if not t.is_cuda:
@@ -19,7 +19,7 @@ def _req(t: torch.Tensor, name: str, dtype=torch.float32, dim=None):
         raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
     if dim is not None and t.dim() != dim:
         raise ValueError("%s must be %d-D, got shape %s" % (name, dim, tuple(t.shape)))
-    if t.dim() == 2 and t.numel() and t.stride(1) != 1:
+    if t.dim() == 2 and t.numel() and t.stride(1) != 1 and not any_stride:
         raise ValueError("%s must have a contiguous last dimension (stride %s)" % (name, t.stride()))
     return t
 
@@ -41,16 +41,16 @@ def _f32(n, device):
 # ---- plan ---------------------------------------------------------------------------------------
 def plan_build(edge_index: torch.Tensor, n_key: int, by: int):
     """-> (rowptr int32 [n_key+1], other int32 [E], eid int32 [E]); see dgnn_plan_build."""
-    _req(edge_index, "edge_index", torch.int64, 2)
-    if edge_index.size(0) != 2 or not edge_index.is_contiguous():
-        raise ValueError("edge_index must be a contiguous int64 [2,E] tensor")
+    _req(edge_index, "edge_index", torch.int64, 2, any_stride=True)
+    if edge_index.size(0) != 2:
+        raise ValueError("edge_index must be an int64 [2,E] tensor (any strides; the transposed [E,2] view is read in place)")
     E = edge_index.size(1)
     dev = edge_index.device
     rowptr = torch.empty(n_key + 1, dtype=torch.int32, device=dev)
     other = torch.empty(max(E, 1), dtype=torch.int32, device=dev)[:E]
     eid = torch.empty(max(E, 1), dtype=torch.int32, device=dev)[:E]
     scratch = torch.empty(int(lib().dgnn_plan_scratch_elems(E, n_key)), dtype=torch.int32, device=dev)
-    check(lib().dgnn_plan_build(ptr(edge_index), E, n_key, by, ptr(rowptr), ptr(other), ptr(eid), ptr(scratch), stream_ptr()),
+    check(lib().dgnn_plan_build(ptr(edge_index), edge_index.stride(0), edge_index.stride(1), E, n_key, by, ptr(rowptr), ptr(other), ptr(eid), ptr(scratch), stream_ptr()),
           "dgnn_plan_build")
     return rowptr, other, eid
 

@@ -51,14 +51,20 @@ const char* dgnn_last_error_string(void);
  * (the transposed plan used by the backward pass; then `src` receives the OTHER endpoint,
  * i.e. the destination, and n_key = number of sources).
  *
- *   edge_index : int64 [2,E] (reference layout, processing/data.py:434-438), row0=src row1=dst
+ *   edge_index : int64 [2,E] view, row0=src row1=dst: element (r,k) at edge_index[r*stride_row + k*stride_col].
+ *                The reference passes torch.transpose(adjacencies,1,0) (processing/data.py:434-438), i.e.
+ *                strides (1,2) over the [E,2] array; a contiguous [2,E] tensor has (E,1).  Read in place.
  *   rowptr     : int32 [n_key+1]   out
  *   other      : int32 [E]         out  (src for by=1, dst for by=0)
  *   eid        : int32 [E]         out  original edge position of the k-th sorted edge
  *   scratch    : int32 [dgnn_plan_scratch_elems(E,n_key)]
+ * When E == 4*n_key the reference's own layout is tried first (row 4t+r = r-th neighbour of cell t, symmetric
+ * relation): one verified pass without atomics/scan/sort; if the check fails on the device the generic
+ * count/scan/fill/sort kernels queued behind it rebuild the plan.  Same result either way.
  * ---------------------------------------------------------------------------------------------- */
 int64_t dgnn_plan_scratch_elems(int64_t E, int64_t n_key);
-int dgnn_plan_build(const int64_t* edge_index, int64_t E, int64_t n_key, int by, int32_t* rowptr, int32_t* other,
+int dgnn_plan_build(const int64_t* edge_index, int64_t stride_row, int64_t stride_col, int64_t E, int64_t n_key, int by,
+                    int32_t* rowptr, int32_t* other,
                     int32_t* eid, int32_t* scratch, void* stream);
 
 /* out[k, 0:cols] = in[idx[k], 0:cols]  -- stages edge_attr rows into plan order once per scene

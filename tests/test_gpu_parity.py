@@ -50,15 +50,56 @@ def test_plan_matches_stable_sort(case):
     else:
         n_src, n_dst = 7, 5
         ei = np.zeros((2, 0), np.int64)
-    t = torch.from_numpy(np.ascontiguousarray(ei)).to(DEV)
-    for by, n_key in ((1, n_dst), (0, n_src)):
-        rowptr, other, eid = ops.plan_build(t, n_key, by)
-        key, oth = ei[by], ei[1 - by]
-        order = np.argsort(key, kind="stable")
-        ref_rowptr = np.concatenate([[0], np.cumsum(np.bincount(key, minlength=n_key))])
-        assert np.array_equal(rowptr.cpu().numpy(), ref_rowptr)
-        assert np.array_equal(eid.cpu().numpy(), order)
-        assert np.array_equal(other.cpu().numpy(), oth[order])
+    _check_plan(ops, ei, n_src, n_dst)
+
+
+def _check_plan(ops, ei, n_src, n_dst):
+    # both memory layouts the reference produces: a contiguous [2,E] tensor and the transposed view of the [E,2] array
+    # (torch.transpose(adjacencies,1,0), processing/data.py:437-438); the builder reads either in place
+    views = [torch.from_numpy(np.ascontiguousarray(ei)).to(DEV), torch.from_numpy(np.ascontiguousarray(ei.T)).to(DEV).t()]
+    assert not views[1].is_contiguous() or ei.shape[1] <= 1
+    for t in views:
+        for by, n_key in ((1, n_dst), (0, n_src)):
+            rowptr, other, eid = ops.plan_build(t, n_key, by)
+            key, oth = ei[by], ei[1 - by]
+            order = np.argsort(key, kind="stable")
+            ref_rowptr = np.concatenate([[0], np.cumsum(np.bincount(key, minlength=n_key))])
+            assert np.array_equal(rowptr.cpu().numpy(), ref_rowptr)
+            assert np.array_equal(eid.cpu().numpy(), order)
+            assert np.array_equal(other.cpu().numpy(), oth[order])
+
+
+@pytest.mark.parametrize("case", ["delaunay", "duplicates_selfloops", "one_way", "wrong_group", "out_of_pattern_src", "perm_rows"])
+def test_plan_regular_fast_path_and_its_fallback(case):
+    """E == 4N graphs: the reference layout takes the verified single-pass builder; every near miss (asymmetric relation,
+    rows not grouped by source, ...) must be caught on the device and rebuilt by the generic kernels -- the result is
+    always the stable sort."""
+    from dgnn_amd import ops
+    from dgnn_amd.synthetic import delaunay_tet_graph
+    rng = np.random.default_rng(3)
+    adj, _, _ = delaunay_tet_graph(2500, seed=4)
+    n = adj.shape[0] // 4
+    ei = adj.T.astype(np.int64).copy()
+    if case == "duplicates_selfloops":
+        # symmetric multigraph in the reference layout: double links a<->b (two slots each way) and self loops
+        n = 64
+        nb = np.empty((n, 4), np.int64)
+        # even cells: a double link to the odd partner + a ring over the even cells; odd cells: the double link + 2 self loops
+        for a in range(0, n, 2):
+            nb[a] = [a + 1, a + 1, (a + 2) % n, (a - 2) % n]
+            nb[a + 1] = [a, a, a + 1, a + 1]
+        ei = np.stack([np.repeat(np.arange(n), 4), nb.reshape(-1)])
+    elif case == "one_way":
+        k = 4 * 17 + 2
+        ei[1, k] = (ei[1, k] + 7) % n                     # one link no longer has its reverse
+    elif case == "wrong_group":
+        ei[0, [5, 9]] = ei[0, [9, 5]]                      # sources 1 and 2 have 3 and 5 rows: still E == 4N
+    elif case == "out_of_pattern_src":
+        ei = ei[:, rng.permutation(ei.shape[1])]           # same graph, rows shuffled
+    elif case == "perm_rows":
+        p = (np.arange(n)[:, None] * 4 + np.array([2, 0, 3, 1])[None]).reshape(-1)
+        ei = ei[:, p]                                      # still grouped by source, slots permuted: fast path holds
+    _check_plan(ops, ei, n, n)
 
 
 # ---- aggregate: given phi is bit-exact against the oracle's propagate ------------------------------
