@@ -21,6 +21,9 @@
 // phase; the dense part is the K-split 32x32x16 split-bf16 product with the delayed epilogue.
 #include "fused_common.h"
 
+#ifndef DGNN_PHASE_PRIO
+#define DGNN_PHASE_PRIO 0  // measured: balances the barrier waits (0.6/0.4 us instead of 1.4/0.2) but the tile period does not move
+#endif
 #ifndef DGNN_YOUNG_PRIO
 #define DGNN_YOUNG_PRIO 0  // measured: it only swaps which wave of a SIMD waits at the barrier (zero-sum)
 #endif
@@ -364,6 +367,12 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         }
         tile_barrier();  // A-tile `it` complete; partial sums of tile `it-1` complete
         stamp(trace, trace_cap, it, w, 4);
+#if DGNN_PHASE_PRIO
+        // Arbitration between the two waves of a SIMD is oldest-first, so waves 0..3 win BOTH phases, reach the barrier
+        // early and leave their SIMD to a lone wave with nobody to hide its latencies.  Giving the younger four the
+        // dense phase and the older four (by age) the filter phase makes both reach the barrier together.
+        if (w >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 
         if (it > 0) {
             // ============================================================ delayed epilogue of tile it-1
@@ -415,6 +424,9 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
             }
             stamp(trace, trace_cap, it, w, 5);
         }
+#if DGNN_PHASE_PRIO
+        if (w >= 4) __builtin_amdgcn_s_setprio(0);
+#endif
     }
 }
 

@@ -2,6 +2,9 @@
 import sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dgnn_amd._lib as _L
+if len(sys.argv) > 2:
+    _L.LIB_PATH = os.path.abspath(sys.argv[2])   # e.g. a what-if build
 from dgnn_amd import ops
 from dgnn_amd._lib import lib, ptr
 from dgnn_amd.graph import GraphPlan
