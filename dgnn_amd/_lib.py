@@ -51,7 +51,7 @@ SIGNATURES = {
     "dgnn_khop_commit": (i32, [vp, i64, i64, vp, vp, vp]),
     "dgnn_khop_reset": (i32, [vp, i64, vp, vp]),
     "dgnn_decoder_fused_fwd": (i32, [vp, i64, i64, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, i64, vp]),
-    "dgnn_sage_layer_fused_fwd": (i32, [vp, vp, vp, i64, vp, i64, i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp,
+    "dgnn_sage_layer_fused_fwd": (i32, [vp, vp, vp, i64, vp, vp, i64, i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp,
                                         i64, i32, vp]),
 }
 

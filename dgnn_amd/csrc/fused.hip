@@ -84,7 +84,7 @@ struct FusedCfg {
 template <int CIN_PAD, int COUT, int MODE>
 __global__ void __launch_bounds__(512, 2)
 k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid, int64_t n_dst,
-             const float* __restrict__ x, int64_t ldx, int c_in, const float* __restrict__ ea, int64_t lde,
+             const float* __restrict__ x, const float* __restrict__ xdst, int64_t ldx, int c_in, const float* __restrict__ ea, int64_t lde,
              const float* __restrict__ We, const float* __restrict__ be, const float* __restrict__ Wj,
              const float* __restrict__ bj, const float* __restrict__ Wi, const float* __restrict__ scale,
              const float* __restrict__ shift, int relu, float* __restrict__ out, int64_t ldo, int64_t ntiles,
@@ -206,7 +206,7 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
             const int i0 = (int)(tile_of(it) * TILE) + w * TPW;
             const float* eab = ea + (int64_t)__builtin_amdgcn_readfirstlane(vbeg1) * lde;
 #pragma unroll
-            for (int r = 0; r < TPW; ++r) ld_row<CPL>(xd[r], x + (uint32_t)((i0 + r) * ldx32) + c0l);
+            for (int r = 0; r < TPW; ++r) ld_row<CPL>(xd[r], xdst + (uint32_t)((i0 + r) * ldx32) + c0l);
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
                 ld_row<CPL>(xr[q], x + (uint32_t)(__builtin_amdgcn_readlane(vsrc1, q) * ldx32) + c0l);
@@ -367,7 +367,7 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
                     for (int j = 0; j < CPL; ++j) acc[j] = xdv[j] = 0.f;
                     if (i < n_dst) {
                         const int b = rowptr[i], e_end = rowptr[i + 1];
-                        ld_row<CPL>(xdv, x + i * ldx + c0l);
+                        ld_row<CPL>(xdv, xdst + i * ldx + c0l);
                         for (int k = b; k < e_end; ++k) {
                             const int s = src[k];
                             const float* ar = ea + (int64_t)(eid ? eid[k] : k) * lde;
@@ -470,7 +470,8 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
 }
 
 template <int CIN_PAD, int COUT, int MODE>
-int launch_fused(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x, int64_t ldx, int c_in,
+int launch_fused(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x, const float* xdst,
+                 int64_t ldx, int c_in,
                  const float* ea, int64_t lde, const float* We, const float* be, const float* Wj, const float* bj,
                  const float* Wi, const float* scale, const float* shift, int relu, float* out, int64_t ldo,
                  hipStream_t stream) {
@@ -485,20 +486,21 @@ int launch_fused(const int32_t* rowptr, const int32_t* src, const int32_t* eid, 
     }
     int grid = (int)(ntiles < DGNN_NUM_CU ? ntiles : DGNN_NUM_CU);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((k_sage_fused<CIN_PAD, COUT, MODE>), dim3(grid), dim3(512), smem, stream, rowptr, src, eid, n_dst, x, ldx, c_in,
+    hipLaunchKernelGGL((k_sage_fused<CIN_PAD, COUT, MODE>), dim3(grid), dim3(512), smem, stream, rowptr, src, eid, n_dst, x, xdst, ldx, c_in,
                        ea, lde, We, be, Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles, g_dgnn_trace_buf, g_dgnn_trace_cap);
     return dgnn_check_launch("sage_layer_fused_fwd");
 }
 
 }  // namespace
 
-int dgnn_sage_layer_fused_mfma_try(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src, int64_t ldx,
+int dgnn_sage_layer_fused_mfma_try(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src,
+                                   const float* x_dst, int64_t ldx,
                                    int c_in, const float* edge_attr, int64_t lde, const float* We, const float* be,
                                    const float* Wj, const float* bj, const float* Wi, const float* scale, const float* shift,
                                    int relu, int c_out, float* out, int64_t ldo, hipStream_t stream);  // fused_mfma.hip
 
 extern "C" int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src,
-                                         int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e,
+                                         const float* x_dst, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e,
                                          const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
                                          const float* scale, const float* shift, int relu, int c_out, float* out, int64_t ldo,
                                          int gemm_mode, void* stream_) {
@@ -510,13 +512,14 @@ extern "C" int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* s
     DGNN_REQUIRE(rowptr && src && x_src && edge_attr && We && be && Wj && Wi && out, DGNN_E_INVALID,
                  "sage_layer_fused_fwd: null pointer");
     DGNN_REQUIRE((scale == nullptr) == (shift == nullptr), DGNN_E_INVALID, "sage_layer_fused_fwd: scale/shift must come together");
+    if (x_dst == nullptr) x_dst = x_src;  // the reference's (x, x[:n_dst]) pair
     DGNN_REQUIRE(f_e == FE && lde == FE, DGNN_E_UNSUPPORTED, "sage_layer_fused_fwd: needs f_e == 20 and packed edge rows (lde == 20)");
     DGNN_REQUIRE(((uintptr_t)edge_attr % 16) == 0, DGNN_E_UNSUPPORTED, "sage_layer_fused_fwd: edge_attr must be 16-byte aligned");
     DGNN_REQUIRE(n_dst * ldx < ((int64_t)1 << 31), DGNN_E_UNSUPPORTED, "sage_layer_fused_fwd: activations beyond 2^31 elements");
     DGNN_REQUIRE(c_in <= 128 && (c_out == 64 || c_out == 128), DGNN_E_UNSUPPORTED,
                  "sage_layer_fused_fwd: supports c_in <= 128 and c_out in {64,128} (got %d -> %d)", c_in, c_out);
     if (gemm_mode == DGNN_GEMM_BF16X3_FILTER) {
-        const int rc = dgnn_sage_layer_fused_mfma_try(rowptr, src, eid, n_dst, x_src, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi,
+        const int rc = dgnn_sage_layer_fused_mfma_try(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi,
                                                       scale, shift, relu, c_out, out, ldo, stream);
         if (rc != DGNN_E_UNSUPPORTED) return rc;
         gemm_mode = DGNN_GEMM_BF16X3;  // shape not covered by the all-MFMA variant
@@ -524,14 +527,14 @@ extern "C" int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* s
 #define GO(CP, CO)                                                                                                              \
     do {                                                                                                                        \
         if (gemm_mode == DGNN_GEMM_F32)                                                                                         \
-            return launch_fused<CP, CO, 0>(rowptr, src, eid, n_dst, x_src, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, \
+            return launch_fused<CP, CO, 0>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, \
                                            shift, relu, out, ldo, stream);                                                      \
-        return launch_fused<CP, CO, 1>(rowptr, src, eid, n_dst, x_src, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale,     \
+        return launch_fused<CP, CO, 1>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale,     \
                                        shift, relu, out, ldo, stream);                                                          \
     } while (0)
     if (c_in <= 32) { if (c_out == 64) GO(32, 64); else GO(32, 128); }
     if (c_in <= 64) { if (c_out == 64) GO(64, 64); else GO(64, 128); }
-    DGNN_REQUIRE(c_in % 2 == 0 && ldx % 2 == 0 && ((uintptr_t)x_src % 8) == 0, DGNN_E_UNSUPPORTED,
+    DGNN_REQUIRE(c_in % 2 == 0 && ldx % 2 == 0 && (((uintptr_t)x_src | (uintptr_t)x_dst) % 8) == 0, DGNN_E_UNSUPPORTED,
                  "sage_layer_fused_fwd: c_in > 64 needs even c_in / ldx and 8-byte aligned x");
     DGNN_REQUIRE(c_out == 128, DGNN_E_UNSUPPORTED, "sage_layer_fused_fwd: c_in > 64 supports c_out == 128 only");
     GO(128, 128);

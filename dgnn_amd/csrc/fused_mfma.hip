@@ -73,7 +73,7 @@ __device__ __forceinline__ void ld_vec(float (&v)[NB], const float* p, bool vec)
 template <int CIN_PAD, int COUT>
 __global__ void __launch_bounds__(512, 2)
 k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid, int64_t n_dst,
-                  const float* __restrict__ x, int64_t ldx, int c_in, const float* __restrict__ ea, int64_t lde,
+                  const float* __restrict__ x, const float* __restrict__ xdst, int64_t ldx, int c_in, const float* __restrict__ ea, int64_t lde,
                   const float* __restrict__ We, const float* __restrict__ be, const float* __restrict__ Wj,
                   const float* __restrict__ bj, const float* __restrict__ Wi, const float* __restrict__ scale,
                   const float* __restrict__ shift, int relu, float* __restrict__ out, int64_t ldo, int64_t ntiles,
@@ -197,7 +197,7 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const int tl = rb * 4 + tq;  // this lane's tet within the wave
-                ld_vec<NB>(xd[rb], x + (uint32_t)((i0 + (tl < nv1 ? tl : nv1 - 1)) * ldx32) + c0l, vec);
+                ld_vec<NB>(xd[rb], xdst + (uint32_t)((i0 + (tl < nv1 ? tl : nv1 - 1)) * ldx32) + c0l, vec);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int s_ = __shfl(vsrc1, tl * 4 + r);
@@ -341,7 +341,7 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                     if (i < n_dst && on) {
                         const int b = rowptr[i], e_end = rowptr[i + 1];
 #pragma unroll
-                        for (int cb = 0; cb < NB; ++cb) xv[cb] = x[i * ldx + c0 + cb];
+                        for (int cb = 0; cb < NB; ++cb) xv[cb] = xdst[i * ldx + c0 + cb];
                         for (int k = b; k < e_end; ++k) {
                             const int s_ = src[k];
                             const float* ar = ea + (int64_t)(eid ? eid[k] : k) * lde;
@@ -431,7 +431,7 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
 }
 
 template <int CIN_PAD, int COUT>
-int launch2(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x, int64_t ldx, int c_in, const float* ea,
+int launch2(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x, const float* xdst, int64_t ldx, int c_in, const float* ea,
             int64_t lde, const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
             const float* scale, const float* shift, int relu, float* out, int64_t ldo, int xvec, hipStream_t stream) {
     using C = Cfg2<CIN_PAD, COUT>;
@@ -445,7 +445,7 @@ int launch2(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64
     }
     int grid = (int)(ntiles < DGNN_NUM_CU ? ntiles : DGNN_NUM_CU);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((k_sage_fused_mfma<CIN_PAD, COUT>), dim3(grid), dim3(512), smem, stream, rowptr, src, eid, n_dst, x, ldx, c_in, ea,
+    hipLaunchKernelGGL((k_sage_fused_mfma<CIN_PAD, COUT>), dim3(grid), dim3(512), smem, stream, rowptr, src, eid, n_dst, x, xdst, ldx, c_in, ea,
                        lde, We, be, Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles, xvec, g_dgnn_trace_buf, g_dgnn_trace_cap);
     return dgnn_check_launch("sage_layer_fused_fwd(mfma filter)");
 }
@@ -454,15 +454,15 @@ int launch2(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64
 
 // Returns DGNN_E_UNSUPPORTED when the shape does not fit this variant (the caller then uses fused.hip MODE 1).
 int dgnn_sage_layer_fused_mfma_try(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src,
-                                   int64_t ldx, int c_in, const float* edge_attr, int64_t lde, const float* We, const float* be,
+                                   const float* x_dst, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, const float* We, const float* be,
                                    const float* Wj, const float* bj, const float* Wi, const float* scale, const float* shift,
                                    int relu, int c_out, float* out, int64_t ldo, hipStream_t stream) {
     const int cin_pad = c_in <= 32 ? 32 : (c_in <= 64 ? 64 : 128);
     const int nb = cin_pad / 16;
     if (c_in % nb != 0 || (c_out != 64 && c_out != 128) || (cin_pad == 128 && c_out != 128)) return DGNN_E_UNSUPPORTED;
-    const int xvec = (((uintptr_t)x_src % 16) == 0 && ldx % 4 == 0) ? 1 : 0;
+    const int xvec = ((((uintptr_t)x_src | (uintptr_t)x_dst) % 16) == 0 && ldx % 4 == 0) ? 1 : 0;
     if (nb >= 4 && !xvec) return DGNN_E_UNSUPPORTED;
-#define GO2(CP, CO) return launch2<CP, CO>(rowptr, src, eid, n_dst, x_src, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, \
+#define GO2(CP, CO) return launch2<CP, CO>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, \
                                            shift, relu, out, ldo, xvec, stream)
     if (cin_pad == 32) { if (c_out == 64) GO2(32, 64); else GO2(32, 128); }
     if (cin_pad == 64) { if (c_out == 64) GO2(64, 64); else GO2(64, 128); }

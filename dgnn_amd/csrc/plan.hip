@@ -31,13 +31,18 @@ constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 8;  // per thread
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 
+__global__ void k_fill2_i32(int32_t* p, int32_t a, int32_t b) {
+    if (threadIdx.x == 0) { p[0] = a; p[1] = b; }
+}
+
 __global__ void k_zero_i32(int32_t* p, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0;
 }
 
-// `need` (may be NULL): device flag written by k_plan_regular -- 0 = the regular fast path already produced the plan and
-// the generic kernels return at once, non-zero = run.  `sc` = element stride between consecutive edges of a row.
-__device__ __forceinline__ bool plan_skip(const int32_t* need) { return need != nullptr && *need == 0; }
+// `need` (may be NULL): device flags written by the fast-path kernels -- when one of them already produced the plan the
+// generic kernels return at once.  `sc` = element stride between consecutive edges of a row.
+// need[0] = 1: the "already grouped by key" pass failed; need[1] = 1: the "reference layout" pass failed or was not tried.
+__device__ __forceinline__ bool plan_skip(const int32_t* need) { return need != nullptr && (need[0] == 0 || need[1] == 0); }
 
 __global__ void k_plan_count(const int64_t* __restrict__ key, int64_t sc, int64_t E, int32_t* __restrict__ deg,
                              const int32_t* __restrict__ need) {
@@ -171,20 +176,41 @@ __global__ void k_plan_emit(const int32_t* __restrict__ rowptr, const int32_t* _
     }
 }
 
-// ---- fast path for the reference's own graph layout -------------------------------------------------------------
+// ---- fast path 1: the edge list is already grouped by key (ascending) -------------------------------------------
+// Then the stable sort is the identity: eid[k] = k, other[k] = the other endpoint, and rowptr[d] is the first position
+// whose key is >= d.  One pass, no atomics.  This is what k-hop sampled blocks look like (edges ordered by destination,
+// SURVEY App. B), what the by-source (transposed) plan of the reference layout is, and how dgnn_amd.partition lays out a
+// rank's local edge list.  Any inversion or out-of-range key sets need[0] and the next builder takes over.
+__global__ void __launch_bounds__(256) k_plan_sorted(const int64_t* __restrict__ key, const int64_t* __restrict__ oth, int64_t sc,
+                                                     int64_t E, int64_t n_key, int32_t* __restrict__ rowptr,
+                                                     int32_t* __restrict__ other, int32_t* __restrict__ eid,
+                                                     int32_t* __restrict__ need) {
+    bool bad = false;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < E; k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t kk = key[k * sc], kp = k > 0 ? key[(k - 1) * sc] : -1;
+        if (kk < kp || kk < 0 || kk >= n_key) { bad = true; continue; }
+        eid[k] = (int32_t)k;
+        other[k] = (int32_t)oth[k * sc];
+        for (int64_t d = kp + 1; d <= kk; ++d) rowptr[d] = (int32_t)k;
+        if (k == E - 1)
+            for (int64_t d = kk + 1; d <= n_key; ++d) rowptr[d] = (int32_t)E;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&need[0], 1);
+}
+
+// ---- fast path 2: the reference's own graph layout -----------------------------------------------------------------
 // processing/data.py:434-438 hands the model `adjacencies` [4N,2]: row 4t+r = (t, r-th neighbour of cell t), every
 // cell has exactly 4 rows and the relation is symmetric (cells share facets).  Then in-edges(t) = the reverse of its
 // out-edges, rowptr[t] = 4t, and the stable by-destination order is: neighbours ascending, and for a neighbour s the
 // slots r' of s's own rows that point back at t, ascending (edge id 4s + r').  One thread per cell builds its 4
 // entries from its own 4 rows and its neighbours' rows -- no atomics, no scan, no segment sort.
 // Everything is verified on the fly (other[k] == k/4, keys in range, count(s->t) == count(t->s) for every
-// neighbour; the last one, checked by every cell, is exactly global symmetry).  Any violation clears nothing but sets
-// *need = 1, and the generic kernels that follow in the stream then rebuild the plan from scratch.
-// BY_KEY_ROW = false is the transposed plan of the same layout (sorted by source): the identity.
-template <bool BY_DST>
+// neighbour; the last one, checked by every cell, is exactly global symmetry).  Any violation sets need[1], and the
+// generic kernels that follow in the stream then rebuild the plan from scratch.
 __global__ void __launch_bounds__(256) k_plan_regular(const int64_t* __restrict__ key, const int64_t* __restrict__ oth, int64_t sc,
                                                       int64_t n_key, int32_t* __restrict__ rowptr, int32_t* __restrict__ other,
                                                       int32_t* __restrict__ eid, int32_t* __restrict__ need) {
+    if (need[0] == 0) return;  // fast path 1 already produced the plan
     bool bad = false;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n_key; t += (int64_t)gridDim.x * blockDim.x) {
         int64_t k4[4], o4[4];
@@ -195,16 +221,6 @@ __global__ void __launch_bounds__(256) k_plan_regular(const int64_t* __restrict_
         }
         rowptr[t] = (int32_t)(4 * t);
         if (t == n_key - 1) rowptr[n_key] = (int32_t)(4 * n_key);
-        if (!BY_DST) {
-            // sorted by source and the source row is k/4: already in order
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                bad |= k4[r] != t;
-                eid[4 * t + r] = (int32_t)(4 * t + r);
-                other[4 * t + r] = (int32_t)o4[r];
-            }
-            continue;
-        }
         int32_t d[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -233,7 +249,7 @@ __global__ void __launch_bounds__(256) k_plan_regular(const int64_t* __restrict_
             eid[4 * t + i] = (int32_t)(4 * s_ + slot);
         }
     }
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(need, 1);
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&need[1], 1);
 }
 
 // one block per queued long segment: rank sort (edge positions are distinct)
@@ -312,10 +328,10 @@ int dgnn_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, int32_t*
     return DGNN_OK;
 }
 
-// scratch layout (int32): deg[n_key] | tmp[E] | sums[nb+2] | big_count[1] | big_list[E/33+2] | need[1]
+// scratch layout (int32): deg[n_key] | tmp[E] | sums[nb+2] | big_count[1] | big_list[E/33+2] | need[2]
 extern "C" int64_t dgnn_plan_scratch_elems(int64_t E, int64_t n_key) {
     if (E < 0 || n_key < 0) return 0;
-    return n_key + E + (dgnn_cdiv(n_key, SCAN_TILE) + 2) + 1 + (E / 33 + 2) + 1;
+    return n_key + E + (dgnn_cdiv(n_key, SCAN_TILE) + 2) + 1 + (E / 33 + 2) + 2;
 }
 
 extern "C" int dgnn_plan_build(const int64_t* edge_index, int64_t stride_row, int64_t stride_col, int64_t E, int64_t n_key, int by,
@@ -344,18 +360,22 @@ extern "C" int dgnn_plan_build(const int64_t* edge_index, int64_t stride_row, in
         hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, rowptr, (int64_t)1);
         return dgnn_check_launch("plan_build");
     }
-    // candidate for the regular fast path: then the generic kernels are launched small (they are grid-stride loops
-    // and normally return on their first instruction) -- a wrong guess costs speed, never correctness
-    const bool try_regular = E == 4 * n_key && E > 0;
+    // Fast paths first (see the kernels): 1. already grouped by key, 2. (by destination, E == 4N) the reference layout.
+    // The generic kernels are queued behind them with small grids (they are grid-stride loops and return on their first
+    // instruction when a fast path succeeded) -- a graph that fits neither costs a little time, never correctness.
     const int32_t* flag = nullptr;
-    if (try_regular) {
-        hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, need, (int64_t)1);
-        const dim3 g(dgnn_grid_cap(dgnn_cdiv(n_key, 256)));
-        if (by) hipLaunchKernelGGL((k_plan_regular<true>), g, dim3(256), 0, stream, key, oth, sc, n_key, rowptr, other, eid, need);
-        else hipLaunchKernelGGL((k_plan_regular<false>), g, dim3(256), 0, stream, key, oth, sc, n_key, rowptr, other, eid, need);
+    int cap = 1 << 30;
+    if (E > 0) {
+        const bool try_regular = by == 1 && E == 4 * n_key;
+        hipLaunchKernelGGL(k_fill2_i32, dim3(1), dim3(64), 0, stream, need, 0, try_regular ? 0 : 1);
+        hipLaunchKernelGGL(k_plan_sorted, dim3(dgnn_grid_cap(dgnn_cdiv(E, 256))), dim3(256), 0, stream, key, oth, sc, E, n_key, rowptr,
+                           other, eid, need);
+        if (try_regular)
+            hipLaunchKernelGGL(k_plan_regular, dim3(dgnn_grid_cap(dgnn_cdiv(n_key, 256))), dim3(256), 0, stream, key, oth, sc, n_key,
+                               rowptr, other, eid, need);
         flag = need;
+        cap = 4 * DGNN_NUM_CU;
     }
-    const int cap = try_regular ? 4 * DGNN_NUM_CU : (1 << 30);
     auto grid_for = [&](int64_t n) { const int64_t g = dgnn_grid_cap(dgnn_cdiv(n, 256)); return dim3((unsigned)(g < cap ? g : cap)); };
     if (E > 0) hipLaunchKernelGGL(k_plan_count, grid_for(E), dim3(256), 0, stream, key, sc, E, deg, flag);
     hipLaunchKernelGGL(k_scan_tile, dim3(nb), dim3(SCAN_THREADS), 0, stream, deg, n_key, rowptr, sums, flag);

@@ -195,18 +195,23 @@ class SurfaceNet(nn.Module):
         bn = norm.module
         return ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
 
-    def _eval_layers(self, x, n_dst0, xe, plans, sorted_attr, only=None, out=None):
+    def _eval_layers(self, x, n_dst0, xe, plans, sorted_attr, only=None, out=None, rows=None):
         """Eval-mode conv stack: per layer one fused launch when the widths allow it, else the
         aggregate + linear pair; BatchNorm(eval) and ReLU always ride in the GEMM epilogue.
-        `only=i` runs just layer i (the partitioned forward exchanges halos between layers), `out` then
-        optionally names the [>= n_dst, C_out] buffer to write into."""
+        `sorted_attr`: True = xe rows follow the caller's edge_index order (gathered by eid in the kernel or staged once),
+        False = xe rows are already in plan order.  `only=i` runs just layer i (the partitioned forward exchanges halos between layers), `out` then
+        optionally names the [>= n_dst, C_out] buffer to write into and `rows=(b, e)` restricts the launch to
+        the destinations [b, e) (written to out[b:e]; interior / boundary cells of a partition)."""
         for i in (range(self.num_layers) if only is None else [only]):
             layer, plan = self.convs[i], plans[i]
             conv = layer[0]
             norm = layer[1] if isinstance(layer[1], BatchNorm) else None
             scale, shift = self._fold(norm, conv.lin_j.out_features, x.device)
             le = conv.lin_e
-            x_dst = x[:plan.n_dst]
+            b, e = (0, plan.n_dst) if rows is None else rows
+            n, rowptr = e - b, (plan.rowptr if rows is None else plan.rowptr[b:e + 1])
+            x_dst = x[b:e]
+            out_v = out if (out is None or rows is None) else out[b:e]
             simple = isinstance(le, Linear) and le.in_features in (2, 20)
             if simple and le.in_features == 20 and ops.fused_layer_supported(x.size(1), conv.lin_j.out_features, 20):
                 # sorted_attr: xe is in the caller's edge order.  Either the kernel gathers each row by eid (no staging
@@ -215,15 +220,18 @@ class SurfaceNet(nn.Module):
                     ea, eid = xe, plan.eid
                 else:
                     ea, eid = (plan.sorted_edge_attr(xe) if sorted_attr else xe), None
-                x = ops.sage_layer_fused_fwd(plan.rowptr, plan.src, plan.n_dst, x, ea, le.weight, le.bias, conv.lin_j.weight,
-                                             conv.lin_j.bias, conv.lin_i.weight, scale, shift, True, out=out, eid=eid)
+                x = ops.sage_layer_fused_fwd(rowptr, plan.src, n, x, ea, le.weight, le.bias, conv.lin_j.weight,
+                                             conv.lin_j.bias, conv.lin_i.weight, scale, shift, True, out=out_v, eid=eid,
+                                             x_dst=x_dst if b else None)
                 continue
             if simple:
                 ea = plan.sorted_edge_attr(xe) if sorted_attr else xe
-                a = ops.aggregate_fwd(plan.rowptr, plan.src, None if sorted_attr else plan.eid, plan.n_dst, x, ea, le.weight, le.bias)
+                a = ops.aggregate_fwd(rowptr, plan.src, None, n, x, ea, le.weight, le.bias)
             else:
+                if rows is not None:
+                    raise NotImplementedError("destination sub-ranges need a Linear edge filter")
                 a = Fn.aggregate(x, plan, **conv._filter_args(xe))
-            x = ops.linear_fwd(a, conv.lin_j.weight, x_dst, conv.lin_i.weight, conv.lin_j.bias, scale, shift, True, out=out)
+            x = ops.linear_fwd(a, conv.lin_j.weight, x_dst, conv.lin_i.weight, conv.lin_j.bias, scale, shift, True, out=out_v)
         return x
 
     def _eval_decoder(self, x):

@@ -252,8 +252,9 @@ EDGE_GATHER_IN_KERNEL = __import__("os").environ.get("DGNN_EDGE_STAGING", "0") !
 
 
 def sage_layer_fused_fwd(rowptr, src, n_dst, x_src, edge_attr, We, be, Wj, bj, Wi, scale, shift, relu, gemm_mode=None,
-                         out=None, eid=None):
-    """`eid` (the plan's edge ids): edge_attr is the caller's tensor in its own row order and rows are gathered inside the
+                         out=None, eid=None, x_dst=None):
+    """`x_dst` (optional): own rows of the destinations when they are not x_src[:n_dst] (a destination sub-range).
+    `eid` (the plan's edge ids): edge_attr is the caller's tensor in its own row order and rows are gathered inside the
     kernel; eid=None: edge_attr is already in plan order.
     `out` (optional): a [>= n_dst, c_out] buffer whose first n_dst rows receive the result (the partitioned
     forward passes the next layer's [n_own + n_halo, C] activation buffer, so no copy is needed)."""
@@ -266,7 +267,7 @@ def sage_layer_fused_fwd(rowptr, src, n_dst, x_src, edge_attr, We, be, Wj, bj, W
         if out.size(0) < n_dst or out.size(1) != c_out or out.stride(0) != c_out:
             raise ValueError("out must be a contiguous [>= n_dst, c_out] buffer")
     check(lib().dgnn_sage_layer_fused_fwd(
-        ptr(rowptr), ptr(src), ptr(eid), n_dst, ptr(x_src), _ld(x_src), c_in, ptr(edge_attr), _ld(edge_attr), We.size(1),
+        ptr(rowptr), ptr(src), ptr(eid), n_dst, ptr(x_src), ptr(x_dst), _ld(x_src), c_in, ptr(edge_attr), _ld(edge_attr), We.size(1),
         ptr(We), ptr(be), ptr(Wj), ptr(bj), ptr(Wi), ptr(scale), ptr(shift), int(bool(relu)), c_out, ptr(out), c_out,
         GEMM_MODE if gemm_mode is None else gemm_mode, stream_ptr()), "dgnn_sage_layer_fused_fwd")
     return out

@@ -14,10 +14,15 @@ On an 8 x MI355X node the scene is instead cut into one part per rank:
   ncclSend/ncclRecv on RCCL; every pair of GPUs has a direct xGMI link, so this is a single-hop
   neighbour exchange, not a ring).  Layer 0 needs no exchange: halo input features are part of the
   rank's input.  BatchNorm(eval) is per-channel affine -> no communication.
-* local ids: owned tets 0..n_own-1 in ascending global id, halo rows n_own.. grouped by owner rank
-  (ascending global id inside a group) so each peer's rows land contiguously.  The local edge list
-  keeps the global edge order, therefore every destination sums its 4 messages in the same order as
-  the single-GPU run and the result is bit-identical to it.
+* local ids: owned tets first -- INTERIOR tets (no remote source, not needed by any peer) then BOUNDARY
+  tets, ascending global id inside each group -- then halo rows grouped by owner rank (ascending global
+  id inside a group) so each peer's rows land contiguously.  The local edge list is grouped by
+  destination and keeps the global edge order inside a destination, therefore every destination sums
+  its 4 messages in the same order as the single-GPU run and the result is bit-identical to it (and the
+  plan builder's "already grouped" fast path applies).
+* overlap: the halo exchange of layer l's output runs on its own HIP stream while the interior tets of
+  layer l+1 are computed (they read owned rows only); the boundary tets follow once the halo has landed,
+  and their outputs are exactly what the next exchange sends.
 
 `layer_fn(i, h, plan_like) -> [n_own, C_out]` and `decoder_fn(h)` are injected, so the same
 orchestration runs with the HIP layers on GPUs (product) and with the CPU oracle under gloo (tests).
@@ -59,10 +64,11 @@ class LocalPart:
     rank: int
     world: int
     n_total: int
-    own_gid: np.ndarray          # int64 [n_own] ascending global ids of owned tets
+    own_gid: np.ndarray          # int64 [n_own] global ids of owned tets: interior (ascending) then boundary (ascending)
+    n_interior: int              # owned tets that neither read a halo row nor are sent to a peer
     halo_gid: np.ndarray         # int64 [n_halo] global ids of halo rows, grouped by owner
-    edge_index: np.ndarray       # int64 [2, E_loc] local ids; dst < n_own, src < n_own + n_halo
-    edge_gid: np.ndarray         # int64 [E_loc] global edge positions (rows of the global edge_attr)
+    edge_index: np.ndarray       # int64 [2, E_loc] local ids, grouped by dst (ascending); dst < n_own, src < n_own + n_halo
+    edge_gid: np.ndarray         # int64 [E_loc] global edge positions (rows of the global edge_attr), ascending per dst
     send_idx: np.ndarray         # int64 [n_send] local ids of owned rows to send, grouped by destination rank
     send_counts: List[int]       # rows sent to each rank
     recv_counts: List[int]       # rows received from each rank (== sizes of the halo groups)
@@ -81,7 +87,6 @@ def build_local_part(edge_index: np.ndarray, part: np.ndarray, rank: int, world:
     src, dst = np.asarray(edge_index[0], np.int64), np.asarray(edge_index[1], np.int64)
     n = part.shape[0]
     p_src, p_dst = part[src], part[dst]
-    own_gid = np.nonzero(part == rank)[0].astype(np.int64)
     # cut edges s -> d (owner(s) != owner(d)): s is needed by owner(d).  unique (needer, owner, s) triples
     cut = p_src != p_dst
     key = np.unique((p_dst[cut].astype(np.int64) * world + p_src[cut]) * n + src[cut])
@@ -92,36 +97,47 @@ def build_local_part(edge_index: np.ndarray, part: np.ndarray, rank: int, world:
     theirs = owner == rank                      # rows I send, sorted by (needer, gid)
     send_gid = gid[theirs]
     send_counts = np.bincount(needer[theirs], minlength=world).astype(int).tolist()
+    # owned tets: interior first, then boundary = reads a halo row (cut in-edge) or is sent to a peer (cut out-edge)
+    boundary = np.zeros(n, dtype=bool)
+    boundary[dst[cut & (p_dst == rank)]] = True
+    boundary[send_gid] = True
+    owned = part == rank
+    own_gid = np.concatenate([np.nonzero(owned & ~boundary)[0], np.nonzero(owned & boundary)[0]]).astype(np.int64)
+    n_interior = int(np.count_nonzero(owned & ~boundary))
     # global -> local id map (only for ids this rank touches)
     loc = np.full(n, -1, dtype=np.int64)
     loc[own_gid] = np.arange(own_gid.shape[0])
     send_idx = loc[send_gid]
     loc[halo_gid] = own_gid.shape[0] + np.arange(halo_gid.shape[0])
-    e_sel = np.nonzero(p_dst == rank)[0]        # in-edges of owned tets, global order preserved
+    e_sel = np.nonzero(p_dst == rank)[0]        # in-edges of owned tets, ascending global position
+    e_sel = e_sel[np.argsort(loc[dst[e_sel]], kind="stable")]   # grouped by local destination, global order inside
     e_loc = np.stack([loc[src[e_sel]], loc[dst[e_sel]]])
     assert (e_loc >= 0).all()
-    return LocalPart(rank, world, n, own_gid, halo_gid, e_loc, e_sel.astype(np.int64), send_idx, send_counts, recv_counts)
+    return LocalPart(rank, world, n, own_gid, n_interior, halo_gid, e_loc, e_sel.astype(np.int64), send_idx, send_counts,
+                     recv_counts)
 
 
 class HaloExchange:
-    """Per-round exchange of boundary rows.  `pack(h, idx)` gathers rows (HIP gather kernel on GPU)."""
+    """Per-round exchange of boundary rows.  `pack(h, idx)` gathers rows (HIP gather kernel on GPU).
+
+    start(h) posts the exchange, wait() makes the caller's stream see the received rows; on a GPU the sends/receives are
+    issued on a side stream so kernels queued between start() and wait() overlap with the transfer.  __call__ = both."""
 
     def __init__(self, lp: LocalPart, device, pack: Optional[Callable] = None, group=None):
         self.lp = lp
-        self.device = device
+        self.device = torch.device(device)
         self.group = group
         self.send_idx = torch.from_numpy(lp.send_idx).to(device)
         self.send_idx32 = self.send_idx.to(torch.int32)
         self.pack = pack
         self.n_own = lp.n_own
+        self.active = lp.world > 1 and (sum(lp.send_counts) + sum(lp.recv_counts)) > 0
+        self.stream = torch.cuda.Stream(device=self.device) if (self.device.type == "cuda" and self.active) else None
+        self._pending = None
 
-    def __call__(self, h_full: torch.Tensor) -> torch.Tensor:
-        """h_full [n_own + n_halo, C] with owned rows valid: fills the halo rows in place."""
+    def _post(self, h_full, send):
         import torch.distributed as dist
         lp = self.lp
-        if lp.world == 1 or (sum(lp.send_counts) == 0 and sum(lp.recv_counts) == 0):
-            return h_full
-        send = self.pack(h_full, self.send_idx32) if self.pack is not None else h_full.index_select(0, self.send_idx)
         ops, so, ro = [], 0, self.n_own
         for peer in range(lp.world):
             ns, nr = lp.send_counts[peer], lp.recv_counts[peer]
@@ -133,30 +149,58 @@ class HaloExchange:
             ro += nr
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+
+    def start(self, h_full: torch.Tensor) -> None:
+        """h_full [n_own + n_halo, C] with the rows to send valid: begins filling the halo rows in place."""
+        if not self.active:
+            return
+        send = self.pack(h_full, self.send_idx32) if self.pack is not None else h_full.index_select(0, self.send_idx)
+        if self.stream is None:
+            self._post(h_full, send)
+            return
+        main = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(main)           # packed rows (and the buffer itself) are ready
+        with torch.cuda.stream(self.stream):
+            self._post(h_full, send)
+        send.record_stream(self.stream)
+        h_full.record_stream(self.stream)
+        self._pending = True
+
+    def wait(self) -> None:
+        if self._pending:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            self._pending = None
+
+    def __call__(self, h_full: torch.Tensor) -> torch.Tensor:
+        self.start(h_full)
+        self.wait()
         return h_full
 
 
 def run_partitioned_layers(lp: LocalPart, x_local: torch.Tensor, num_layers: int, layer_fn: Callable, decoder_fn: Callable,
-                           exchange: HaloExchange, alloc: Callable, widths=None) -> torch.Tensor:
-    """x_local [n_own + n_halo, F] (halo input rows included).  `layer_fn(i, h, out)` computes layer i for the
-    owned tets (into `out[:n_own]` when given).  `widths`: output width per layer, enables the copy-free path.
-    Returns logits of the owned tets."""
+                           exchange: HaloExchange, alloc: Callable, widths) -> torch.Tensor:
+    """x_local [n_own + n_halo, F] (halo input rows included).  `layer_fn(i, h, out, b, e)` computes layer i for the owned
+    tets [b, e) into out[b:e]; `widths[i]` = output width of layer i.  Returns logits of the owned tets.
+
+    Layer 0 needs no exchange.  For l >= 1 the halo of the layer's input is in flight when the layer starts: interior
+    tets first (owned rows only), then wait, then boundary tets -- whose outputs are what the next exchange sends."""
     h = x_local
+    n_own, n_int = lp.n_own, lp.n_interior
     for i in range(num_layers):
         last = i == num_layers - 1
-        if last or widths is None:
-            out = layer_fn(i, h, None)                        # [n_own, C_out]
-            if last:
-                h = out
-                break
-            buf = alloc(lp.n_own + lp.n_halo, out.size(1))
-            buf[:lp.n_own] = out
+        buf = alloc(n_own if last else n_own + lp.n_halo, widths[i])
+        if i == 0:
+            layer_fn(i, h, buf, 0, n_own)
         else:
-            # the layer writes its n_own rows straight into the next activation buffer; the exchange fills the tail
-            buf = alloc(lp.n_own + lp.n_halo, widths[i])
-            layer_fn(i, h, buf)
-        h = exchange(buf)
-    return decoder_fn(h[:lp.n_own])
+            if n_int:
+                layer_fn(i, h, buf, 0, n_int)
+            exchange.wait()
+            if n_own > n_int:
+                layer_fn(i, h, buf, n_int, n_own)
+        if not last:
+            exchange.start(buf)
+        h = buf
+    return decoder_fn(h[:n_own])
 
 
 class PartitionedScene:
@@ -199,8 +243,8 @@ class PartitionedScene:
         x = self.x_local[:, 1:] if net.clf.regularization.cell_type else self.x_local
         xe = self.edge_attr[:, 1:] if net.clf.regularization.edge_type else self.edge_attr
 
-        def layer_fn(i, h, out):
-            return net._eval_layers(h, self.n_own, xe, [plan] * net.num_layers, True, only=i, out=out)
+        def layer_fn(i, h, out, b, e):
+            net._eval_layers(h, self.n_own, xe, [plan] * net.num_layers, False, only=i, out=out, rows=(b, e))
 
         def alloc(r, c):
             return torch.empty((r, c), dtype=torch.float32, device=self.device)

@@ -159,7 +159,11 @@ int dgnn_sage_aggregate_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const
  * Edge row of plan position k = edge_attr[eid ? eid[k] : k]: pass the plan's eid to read the
  * caller's edge_attr in place (each 80-byte row is DMA-gathered into LDS; no staging copy), or
  * eid == NULL with rows already in plan order (dgnn_gather_rows_f32).  Returns DGNN_E_UNSUPPORTED
- * for other shapes (callers fall back to the aggregate + linear pair above).  gemm_mode selects how the dense part runs on the matrix cores.
+ * for other shapes (callers fall back to the aggregate + linear pair above).
+ * x_dst: own rows of the n_dst destinations (row stride ldx), the second element of the reference's
+ * (x_src, x_dst) pair (:66-72); NULL = x_src (x_dst is x_src[:n_dst] at every reference call site).
+ * A sub-range [b, b+n) of the destinations is one call with rowptr+b, x_dst = x_src + b*ldx, out + b*ldo
+ * (the partitioned forward runs interior and boundary cells as two such launches).  gemm_mode selects how the dense part runs on the matrix cores.
  * ---------------------------------------------------------------------------------------------- */
 #define DGNN_GEMM_F32 0    /* v_mfma_f32_32x32x2_f32: bit-faithful fp32 fmaf chains */
 #define DGNN_GEMM_BF16X3 1 /* operands split exactly into 3 bf16 parts, 6 partial products on v_mfma_f32_32x32x16_bf16,
@@ -168,7 +172,7 @@ int dgnn_sage_aggregate_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const
                                      3-part split, 6 products, fp32 accumulate); falls back to BF16X3 for shapes it
                                      does not cover (c_in not a multiple of c_in_pad/16, unaligned wide rows) */
 int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src,
-                              int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e,
+                              const float* x_dst, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e,
                               const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
                               const float* scale, const float* shift, int relu, int c_out, float* out, int64_t ldo,
                               int gemm_mode, void* stream);

@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the committed golden
 vectors.  Bar: bit-exact for integer/index work; fp32 logits within 1e-4 abs (the
 reference differs from its own fp64 evaluation by 4e-6; the downstream graph cut rounds logit*10)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -28,7 +30,7 @@ def hip_static(train=False, convs=(64, 128, 128, 128), sd=None):
 
 
 # ---- plan: bit-exact index work -------------------------------------------------------------------
-@pytest.mark.parametrize("case", ["regular", "ragged", "empty_rows", "star", "empty"])
+@pytest.mark.parametrize("case", ["regular", "ragged", "empty_rows", "star", "empty", "grouped", "grouped_but_one"])
 def test_plan_matches_stable_sort(case):
     from dgnn_amd import ops
     rng = np.random.default_rng(0)
@@ -40,6 +42,15 @@ def test_plan_matches_stable_sort(case):
     elif case == "ragged":
         n_src, n_dst, E = 5000, 3000, 40000
         ei = np.stack([rng.integers(0, n_src, E), rng.integers(0, n_dst, E)])
+    elif case in ("grouped", "grouped_but_one"):
+        # edge list already grouped by destination (sampled blocks, partition-local lists): the identity fast path,
+        # with empty rows at the start, in the middle and at the end; one inversion must send it to the generic kernels
+        n_src, n_dst, E = 3000, 2000, 9000
+        dst = np.sort(rng.integers(5, n_dst - 7, E))
+        dst[(dst > 700) & (dst < 760)] = 760
+        if case == "grouped_but_one":
+            dst[4000], dst[4001] = dst[4001] + 1, dst[4000]
+        ei = np.stack([rng.integers(0, n_src, E), dst])
     elif case == "empty_rows":
         n_src, n_dst, E = 100, 1000, 300
         ei = np.stack([rng.integers(0, n_src, E), rng.integers(0, n_dst, E)])
@@ -351,15 +362,25 @@ def test_partitioned_hip_forward_equals_whole_graph(world):
     part = rcb_partition(cent, world)
     lps = [build_local_part(ei, part, r, world) for r in range(world)]
     plans = [GraphPlan(torch.from_numpy(lp.edge_index).to(DEV), lp.n_own + lp.n_halo, lp.n_own) for lp in lps]
-    eas = [ea[torch.from_numpy(lp.edge_gid).to(DEV)] for lp in lps]
+    for lp, pl in zip(lps, plans):   # local lists are grouped by destination: the plan is the identity
+        assert torch.equal(pl.eid.cpu(), torch.arange(pl.E, dtype=torch.int32))
+    eas = [ea[torch.from_numpy(lp.edge_gid).to(DEV)] for lp in lps]     # already in plan order
     hs = [x[torch.from_numpy(np.concatenate([lp.own_gid, lp.halo_gid])).to(DEV)][:, 1:] for lp in lps]
-    glob = None
+    widths = [64, 128, 128, 128]
     for i in range(net.num_layers):
-        outs = [net._eval_layers(hs[r], lps[r].n_own, eas[r], [plans[r]] * 4, True, only=i) for r in range(world)]
-        glob = torch.empty(n, outs[0].size(1), device=DEV)
+        bufs = []
+        for r, lp in enumerate(lps):
+            # as run_partitioned_layers does: interior cells, then (after the halo landed) boundary cells, as two launches
+            buf = torch.full((lp.n_own + lp.n_halo, widths[i]), float("nan"), device=DEV)
+            for b, e in ((0, lp.n_interior), (lp.n_interior, lp.n_own)):
+                net._eval_layers(hs[r], lp.n_own, eas[r], [plans[r]] * 4, False, only=i, out=buf, rows=(b, e))
+            bufs.append(buf)
+        glob = torch.empty(n, widths[i], device=DEV)
         for r in range(world):
-            glob[torch.from_numpy(lps[r].own_gid).to(DEV)] = outs[r]
-        hs = [torch.cat([outs[r], glob[torch.from_numpy(lps[r].halo_gid).to(DEV)]]) for r in range(world)]
+            glob[torch.from_numpy(lps[r].own_gid).to(DEV)] = bufs[r][:lps[r].n_own]
+        for r in range(world):           # what the exchange delivers
+            bufs[r][lps[r].n_own:] = glob[torch.from_numpy(lps[r].halo_gid).to(DEV)]
+        hs = bufs
     logits = torch.empty(n, 2, device=DEV)
     for r in range(world):
         logits[torch.from_numpy(lps[r].own_gid).to(DEV)] = net._eval_decoder(hs[r][:lps[r].n_own])
@@ -403,6 +424,64 @@ def test_partitioned_scene_world1_matches_inference_layer():
     data = Config(x=hashed_normal(np.arange(n), 29, seed=1, device=DEV), edge_attr=hashed_normal(np.arange(4 * n), 20, seed=2, device=DEV),
                   edge_index=torch.from_numpy(adj.T.astype(np.int64)).to(DEV))
     assert torch.equal(logits, net.inference_layer(data))
+
+
+def _two_rank_worker(rank, world, port, out_dir):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dgnn_amd.partition import PartitionedScene
+    net = hip_static()
+    scene = PartitionedScene.build_synthetic(6000, 5, rank, world, DEV)
+    ex, lp = scene.exchange, scene.lp
+    assert ex.stream is not None and lp.n_interior > 0 and lp.n_halo > 0
+
+    def post(h_full, send):
+        # Test-only transport: both ranks share the box's single GPU (RCCL wants one GPU per rank), so the rows travel
+        # through host memory over gloo.  Stream choreography -- pack on the compute stream, transfer on the side
+        # stream, interior launch in between, boundary launch after wait() -- is the product's.
+        send_h = send.cpu()
+        recv_h = torch.empty(lp.n_halo, send.size(1))
+        ops_, so, ro = [], 0, 0
+        for peer in range(world):
+            ns, nr = lp.send_counts[peer], lp.recv_counts[peer]
+            if nr:
+                ops_.append(dist.P2POp(dist.irecv, recv_h[ro:ro + nr], peer))
+            if ns:
+                ops_.append(dist.P2POp(dist.isend, send_h[so:so + ns], peer))
+            so, ro = so + ns, ro + nr
+        for req in dist.batch_isend_irecv(ops_):
+            req.wait()
+        h_full[lp.n_own:].copy_(recv_h.to(h_full.device, non_blocking=True))
+
+    ex._post = post
+    for _ in range(3):  # several steps: buffers are recycled by the allocator across streams
+        logits = scene.inference_layer(net)
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), gid=lp.own_gid, logits=logits.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_partitioned_scene_two_processes_overlapped_exchange(tmp_path):
+    """PartitionedScene.inference_layer end to end in two processes (interior launch || exchange on a side stream,
+    boundary launch after the wait), union of the ranks' logits == whole-graph inference_layer, bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    adj, _, _ = delaunay_tet_graph(6000, 5)
+    n = adj.shape[0] // 4
+    data = Config(x=hashed_normal(np.arange(n), 29, seed=1, device=DEV), edge_attr=hashed_normal(np.arange(4 * n), 20, seed=2, device=DEV),
+                  edge_index=torch.from_numpy(adj.T.astype(np.int64)).to(DEV))
+    ref = hip_static().inference_layer(data).cpu().numpy()
+    got = np.full_like(ref, np.nan)
+    for r in range(2):
+        d = np.load(os.path.join(str(tmp_path), "r%d.npz" % r))
+        got[d["gid"]] = d["logits"]
+    assert np.array_equal(got, ref)
 
 
 @pytest.mark.parametrize("M,n_out", [(1000, 2), (64, 2), (4097, 1), (1, 2)])

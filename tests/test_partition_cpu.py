@@ -35,8 +35,16 @@ def test_rcb_and_local_part_structure():
         lps = [build_local_part(ei, part, r, world) for r in range(world)]
         assert sum(lp.n_own for lp in lps) == n
         for lp in lps:
-            # every owned tet keeps exactly its 4 in-edges, in global order
-            assert lp.edge_index.shape[1] == 4 * lp.n_own and np.all(np.diff(lp.edge_gid) > 0)
+            # every owned tet keeps exactly its 4 in-edges; the local list is grouped by destination with the global
+            # edge order inside a destination (so per-destination summation order == single-process order)
+            assert lp.edge_index.shape[1] == 4 * lp.n_own and np.array_equal(lp.edge_index[1], np.repeat(np.arange(lp.n_own), 4))
+            assert np.all(np.diff(lp.edge_gid.reshape(-1, 4), axis=1) > 0)
+            # interior cells first: they read no halo row and are sent to nobody; boundary cells are the rest
+            reads_halo = (lp.edge_index[0] >= lp.n_own).reshape(-1, 4).any(1)
+            is_sent = np.zeros(lp.n_own, bool); is_sent[lp.send_idx] = True
+            assert 0 < lp.n_interior < lp.n_own
+            assert not (reads_halo | is_sent)[:lp.n_interior].any() and (reads_halo | is_sent)[lp.n_interior:].all()
+            assert np.all(np.diff(lp.own_gid[:lp.n_interior]) > 0) and np.all(np.diff(lp.own_gid[lp.n_interior:]) > 0)
             assert lp.edge_index[1].max() < lp.n_own and lp.edge_index[0].max() < lp.n_own + lp.n_halo
             gl = np.concatenate([lp.own_gid, lp.halo_gid])
             assert np.array_equal(gl[lp.edge_index[0]], ei[0][lp.edge_gid]) and np.array_equal(gl[lp.edge_index[1]], ei[1][lp.edge_gid])
@@ -67,13 +75,21 @@ def _worker(rank, world, port, out_dir):
     e_loc = torch.from_numpy(lp.edge_index)
     exchange = HaloExchange(lp, "cpu")
 
-    def layer_fn(i, h, out):
+    calls = []
+
+    def layer_fn(i, h, out, b, e):
+        # destinations [b, e) only: their in-edges are the local rows 4b .. 4e-1 (list grouped by destination)
+        calls.append((i, b, e))
         blk = net.convs[i]
-        return blk[2](blk[1](blk[0]((h, h[:lp.n_own]), ea_local, e_loc)))
+        ei_sub = e_loc[:, 4 * b:4 * e].clone()
+        ei_sub[1] -= b
+        out[b:e] = blk[2](blk[1](blk[0]((h, h[b:e]), ea_local[4 * b:4 * e], ei_sub)))
 
     with torch.no_grad():
+        # NaN-poisoned buffers: a boundary row computed before its halo arrived would show up in the logits
         logits = run_partitioned_layers(lp, x_local, net.num_layers, layer_fn, net.decoder, exchange,
-                                        lambda r, c: torch.empty(r, c))
+                                        lambda r, c: torch.full((r, c), float("nan")), widths=[64, 128, 128, 128])
+    assert calls[0] == (0, 0, lp.n_own) and calls[1] == (1, 0, lp.n_interior) and calls[2] == (1, lp.n_interior, lp.n_own)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), gid=lp.own_gid, logits=logits.numpy())
     dist.barrier()
     dist.destroy_process_group()
