@@ -116,7 +116,7 @@ def main():
         def step():
             plan = cached.get("p")
             if plan is None:
-                plan = GraphPlan(data.edge_index, n_local, n_local)
+                plan = GraphPlan(data.edge_index, n_local, n_local, hint=ops.PLAN_HINT_REFERENCE)
                 if args.cached_plan:
                     cached["p"] = plan
             return net.inference_layer(data, plan=plan)
@@ -156,7 +156,7 @@ def main():
     roof = None
     breakdown = {}
     if world == 1:
-        plan = GraphPlan(data.edge_index, n_local, n_local)
+        plan = GraphPlan(data.edge_index, n_local, n_local, hint=ops.PLAN_HINT_REFERENCE)
         xs = data.x[:, 1:]
         in_kernel = ops.EDGE_GATHER_IN_KERNEL  # fused layers gather edge rows by eid themselves: no staging pass
         ea_l, eid_l = (data.edge_attr, plan.eid) if in_kernel else (plan.sorted_edge_attr(data.edge_attr), None)
@@ -171,7 +171,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / reps
-        breakdown["plan_ms"] = timed(lambda: GraphPlan(data.edge_index, n_local, n_local), 5)
+        breakdown["plan_ms"] = timed(lambda: GraphPlan(data.edge_index, n_local, n_local, hint=ops.PLAN_HINT_REFERENCE), 5)
         breakdown["edge_sort_ms"] = 0.0 if in_kernel else timed(lambda: ops.gather_rows(data.edge_attr, plan.eid), 5)
         h = xs
         for i in range(4):

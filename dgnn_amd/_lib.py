@@ -19,7 +19,7 @@ SIGNATURES = {
     "dgnn_version": (i32, []),
     "dgnn_last_error_string": (C.c_char_p, []),
     "dgnn_plan_scratch_elems": (i64, [i64, i64]),
-    "dgnn_plan_build": (i32, [vp, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp]),
+    "dgnn_plan_build": (i32, [vp, i64, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp]),
     "dgnn_gather_rows_f32": (i32, [vp, i64, vp, i64, i32, vp, i64, vp]),
     "dgnn_scatter_rows_f32": (i32, [vp, i64, vp, i64, i32, vp, i64, vp]),
     "dgnn_relu": (i32, [vp, i64, vp, vp]),

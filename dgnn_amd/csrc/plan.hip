@@ -31,8 +31,10 @@ constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 8;  // per thread
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 
-__global__ void k_fill2_i32(int32_t* p, int32_t a, int32_t b) {
-    if (threadIdx.x == 0) { p[0] = a; p[1] = b; }
+// deg[0..n) = 0, *big_count = 0, need = (a, b): one launch
+__global__ void k_plan_init(int32_t* deg, int64_t n, int32_t* big_count, int32_t* need, int32_t a, int32_t b) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) deg[i] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *big_count = 0; need[0] = a; need[1] = b; }
 }
 
 __global__ void k_zero_i32(int32_t* p, int64_t n) {
@@ -181,21 +183,33 @@ __global__ void k_plan_emit(const int32_t* __restrict__ rowptr, const int32_t* _
 // whose key is >= d.  One pass, no atomics.  This is what k-hop sampled blocks look like (edges ordered by destination,
 // SURVEY App. B), what the by-source (transposed) plan of the reference layout is, and how dgnn_amd.partition lays out a
 // rank's local edge list.  Any inversion or out-of-range key sets need[0] and the next builder takes over.
+// Two kernels: the check first -- the row-pointer fill below walks the gap between consecutive keys, which is only
+// bounded (n_key in total) when the keys really are ascending.
+__global__ void __launch_bounds__(256) k_plan_sorted_check(const int64_t* __restrict__ key, int64_t sc, int64_t E, int64_t n_key,
+                                                           int32_t* __restrict__ need) {
+    bool bad = false;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < E; k += (int64_t)gridDim.x * blockDim.x) {
+        if (*reinterpret_cast<volatile int32_t*>(&need[0])) return;  // somebody already found an inversion
+        const int64_t kk = key[k * sc], kp = k > 0 ? key[(k - 1) * sc] : 0;
+        bad |= kk < kp || kk < 0 || kk >= n_key;
+    }
+    // one store per wave at most, and none once the flag is up (thousands of same-address atomics serialise in L2)
+    if (__any(bad) && (threadIdx.x & 63) == 0 && *reinterpret_cast<volatile int32_t*>(&need[0]) == 0) atomicOr(&need[0], 1);
+}
+
 __global__ void __launch_bounds__(256) k_plan_sorted(const int64_t* __restrict__ key, const int64_t* __restrict__ oth, int64_t sc,
                                                      int64_t E, int64_t n_key, int32_t* __restrict__ rowptr,
                                                      int32_t* __restrict__ other, int32_t* __restrict__ eid,
-                                                     int32_t* __restrict__ need) {
-    bool bad = false;
+                                                     const int32_t* __restrict__ need) {
+    if (need[0] != 0) return;
     for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < E; k += (int64_t)gridDim.x * blockDim.x) {
         const int64_t kk = key[k * sc], kp = k > 0 ? key[(k - 1) * sc] : -1;
-        if (kk < kp || kk < 0 || kk >= n_key) { bad = true; continue; }
         eid[k] = (int32_t)k;
         other[k] = (int32_t)oth[k * sc];
         for (int64_t d = kp + 1; d <= kk; ++d) rowptr[d] = (int32_t)k;
         if (k == E - 1)
             for (int64_t d = kk + 1; d <= n_key; ++d) rowptr[d] = (int32_t)E;
     }
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&need[0], 1);
 }
 
 // ---- fast path 2: the reference's own graph layout -----------------------------------------------------------------
@@ -249,7 +263,7 @@ __global__ void __launch_bounds__(256) k_plan_regular(const int64_t* __restrict_
             eid[4 * t + i] = (int32_t)(4 * s_ + slot);
         }
     }
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&need[1], 1);
+    if (__any(bad) && (threadIdx.x & 63) == 0 && *reinterpret_cast<volatile int32_t*>(&need[1]) == 0) atomicOr(&need[1], 1);
 }
 
 // one block per queued long segment: rank sort (edge positions are distinct)
@@ -335,10 +349,11 @@ extern "C" int64_t dgnn_plan_scratch_elems(int64_t E, int64_t n_key) {
 }
 
 extern "C" int dgnn_plan_build(const int64_t* edge_index, int64_t stride_row, int64_t stride_col, int64_t E, int64_t n_key, int by,
-                               int32_t* rowptr, int32_t* other, int32_t* eid, int32_t* scratch, void* stream_) {
+                               int hint, int32_t* rowptr, int32_t* other, int32_t* eid, int32_t* scratch, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DGNN_REQUIRE(E >= 0 && n_key >= 0 && (by == 0 || by == 1), DGNN_E_INVALID, "plan_build: bad sizes E=%lld n=%lld by=%d",
                  (long long)E, (long long)n_key, by);
+    DGNN_REQUIRE(hint >= DGNN_PLAN_HINT_AUTO && hint <= DGNN_PLAN_HINT_REFERENCE, DGNN_E_INVALID, "plan_build: bad hint %d", hint);
     DGNN_REQUIRE(E < INT32_MAX && n_key < INT32_MAX, DGNN_E_UNSUPPORTED, "plan_build: E and n must fit int32");
     DGNN_REQUIRE(rowptr && scratch && (E == 0 || (edge_index && other && eid)), DGNN_E_INVALID, "plan_build: null pointer");
     DGNN_REQUIRE(E <= 1 || stride_col != 0, DGNN_E_INVALID, "plan_build: zero column stride");
@@ -353,26 +368,30 @@ extern "C" int dgnn_plan_build(const int64_t* edge_index, int64_t stride_row, in
     int32_t* big_list = big_count + 1;
     int32_t* need = big_list + (E / 33 + 2);
 
-    // zero deg, sums, big_count in one go would touch tmp too; small launches instead
-    hipLaunchKernelGGL(k_zero_i32, dim3(dgnn_grid_cap(dgnn_cdiv(n_key, 256))), dim3(256), 0, stream, deg, n_key);
-    hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, big_count, (int64_t)1);
     if (n_key == 0) {
         hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, rowptr, (int64_t)1);
         return dgnn_check_launch("plan_build");
     }
-    // Fast paths first (see the kernels): 1. already grouped by key, 2. (by destination, E == 4N) the reference layout.
-    // The generic kernels are queued behind them with small grids (they are grid-stride loops and return on their first
-    // instruction when a fast path succeeded) -- a graph that fits neither costs a little time, never correctness.
+    // Verified fast paths first (see the kernels): "already grouped by key" and, by destination with E == 4N, the
+    // reference layout.  `hint` only picks which of them is attempted (AUTO: both); whatever fails on the device is
+    // caught by the flags and the generic kernels queued behind rebuild the plan -- with small grids (they are
+    // grid-stride loops and return on their first instruction when a fast path succeeded).
+    const bool can_regular = by == 1 && E == 4 * n_key && E > 0;
+    const bool try_sorted = E > 0 && !(hint == DGNN_PLAN_HINT_REFERENCE && can_regular);
+    const bool try_regular = can_regular && hint != DGNN_PLAN_HINT_GROUPED;
+    hipLaunchKernelGGL(k_plan_init, dim3(dgnn_grid_cap(dgnn_cdiv(n_key, 256))), dim3(256), 0, stream, deg, n_key, big_count, need,
+                       try_sorted ? 0 : 1, try_regular ? 0 : 1);
     const int32_t* flag = nullptr;
     int cap = 1 << 30;
-    if (E > 0) {
-        const bool try_regular = by == 1 && E == 4 * n_key;
-        hipLaunchKernelGGL(k_fill2_i32, dim3(1), dim3(64), 0, stream, need, 0, try_regular ? 0 : 1);
-        hipLaunchKernelGGL(k_plan_sorted, dim3(dgnn_grid_cap(dgnn_cdiv(E, 256))), dim3(256), 0, stream, key, oth, sc, E, n_key, rowptr,
+    if (try_sorted) {
+        const dim3 g(dgnn_grid_cap(dgnn_cdiv(E, 256)));
+        hipLaunchKernelGGL(k_plan_sorted_check, g, dim3(256), 0, stream, key, sc, E, n_key, need);
+        hipLaunchKernelGGL(k_plan_sorted, g, dim3(256), 0, stream, key, oth, sc, E, n_key, rowptr, other, eid, need);
+    }
+    if (try_regular)
+        hipLaunchKernelGGL(k_plan_regular, dim3(dgnn_grid_cap(dgnn_cdiv(n_key, 256))), dim3(256), 0, stream, key, oth, sc, n_key, rowptr,
                            other, eid, need);
-        if (try_regular)
-            hipLaunchKernelGGL(k_plan_regular, dim3(dgnn_grid_cap(dgnn_cdiv(n_key, 256))), dim3(256), 0, stream, key, oth, sc, n_key,
-                               rowptr, other, eid, need);
+    if (try_sorted || try_regular) {
         flag = need;
         cap = 4 * DGNN_NUM_CU;
     }

@@ -19,12 +19,12 @@ class GraphPlan:
     ascending original edge position (the CPU scatter order of the reference); src[k] is the
     source of sorted edge k and eid[k] its row in the caller's edge_attr."""
 
-    def __init__(self, edge_index: torch.Tensor, n_src: int, n_dst: int):
+    def __init__(self, edge_index: torch.Tensor, n_src: int, n_dst: int, hint: int = ops.PLAN_HINT_AUTO):
         if edge_index.dtype != torch.int64:
             edge_index = edge_index.to(torch.int64)  # inference_layer does the same (:339)
         self.edge_index = edge_index  # any strides: the plan builder reads the (possibly transposed) view in place
         self.n_src, self.n_dst, self.E = int(n_src), int(n_dst), int(edge_index.size(1))
-        self.rowptr, self.src, self.eid = ops.plan_build(self.edge_index, self.n_dst, by=1)
+        self.rowptr, self.src, self.eid = ops.plan_build(self.edge_index, self.n_dst, by=1, hint=hint)
         self._t = None
         self._sorted_attr = None  # (weakref to edge_attr, version, sorted copy)
 
@@ -49,16 +49,16 @@ class GraphPlan:
 _cache: dict = {}
 
 
-def plan_for(edge_index: torch.Tensor, n_src: int, n_dst: int, cache: bool = True) -> GraphPlan:
+def plan_for(edge_index: torch.Tensor, n_src: int, n_dst: int, cache: bool = True, hint: int = ops.PLAN_HINT_AUTO) -> GraphPlan:
     """Plan lookup keyed on the identity of the edge_index storage (training reuses the same block
     adjacency for forward and backward; inference reuses it across the 4 layers)."""
     if not cache:
-        return GraphPlan(edge_index, n_src, n_dst)
+        return GraphPlan(edge_index, n_src, n_dst, hint)
     key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, int(n_src), int(n_dst), str(edge_index.device))
     hit = _cache.get(key)
     if hit is not None and hit[0]() is edge_index:
         return hit[1]
-    plan = GraphPlan(edge_index, n_src, n_dst)
+    plan = GraphPlan(edge_index, n_src, n_dst, hint)
     if len(_cache) > 64:
         _cache.clear()
     try:

@@ -185,7 +185,9 @@ class SurfaceNet(nn.Module):
         xe = xe[:, 1:] if self.clf.regularization.edge_type else xe
         edge_index = data_all.edge_index.to(dev)
         if plan is None:
-            plan = plan_for(edge_index, x.size(0), x.size(0))
+            # whole scene as processing/data.py delivers it: 4 adjacency rows per cell (verified on the device, any
+            # other layout falls through to the generic builder)
+            plan = plan_for(edge_index, x.size(0), x.size(0), hint=ops.PLAN_HINT_REFERENCE)
         x = self._eval_layers(x, x.size(0), xe, [plan] * self.num_layers, sorted_attr=True)
         return self._eval_decoder(x)
 
@@ -260,7 +262,7 @@ class SurfaceNet(nn.Module):
             x = ops.gather_rows(x_all, n_id.to(torch.int32))
             for i in range(self.num_layers):
                 edge_index, e_id, size = adjs[i]
-                plan = plan_for(edge_index.to(dev), size[0], size[1], cache=False)
+                plan = plan_for(edge_index.to(dev), size[0], size[1], cache=False, hint=ops.PLAN_HINT_GROUPED)
                 ea = ops.gather_rows(xe_all, e_id.to(dev).to(torch.int32))
                 x = self._eval_layers_one(i, x, ea, plan)
             x = self._eval_decoder(x)
@@ -292,7 +294,7 @@ class SurfaceNet(nn.Module):
             for batch_size, n_id, adj in batch_loader:
                 edge_index, e_id, size = adj
                 x = ops.gather_rows(x_all, n_id.to(dev).to(torch.int32))
-                plan = plan_for(edge_index.to(dev), size[0], size[1], cache=False)
+                plan = plan_for(edge_index.to(dev), size[0], size[1], cache=False, hint=ops.PLAN_HINT_GROUPED)
                 ea = ops.gather_rows(xe_all, e_id.to(dev).to(torch.int32))
                 xs.append(self._eval_layers_one(i, x, ea, plan))  # activations stay in HBM (no host round trip)
             x_all = torch.cat(xs, dim=0)

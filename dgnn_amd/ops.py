@@ -39,7 +39,10 @@ def _f32(n, device):
 
 
 # ---- plan ---------------------------------------------------------------------------------------
-def plan_build(edge_index: torch.Tensor, n_key: int, by: int):
+PLAN_HINT_AUTO, PLAN_HINT_GROUPED, PLAN_HINT_REFERENCE = 0, 1, 2
+
+
+def plan_build(edge_index: torch.Tensor, n_key: int, by: int, hint: int = PLAN_HINT_AUTO):
     """-> (rowptr int32 [n_key+1], other int32 [E], eid int32 [E]); see dgnn_plan_build."""
     _req(edge_index, "edge_index", torch.int64, 2, any_stride=True)
     if edge_index.size(0) != 2:
@@ -50,7 +53,7 @@ def plan_build(edge_index: torch.Tensor, n_key: int, by: int):
     other = torch.empty(max(E, 1), dtype=torch.int32, device=dev)[:E]
     eid = torch.empty(max(E, 1), dtype=torch.int32, device=dev)[:E]
     scratch = torch.empty(int(lib().dgnn_plan_scratch_elems(E, n_key)), dtype=torch.int32, device=dev)
-    check(lib().dgnn_plan_build(ptr(edge_index), edge_index.stride(0), edge_index.stride(1), E, n_key, by, ptr(rowptr), ptr(other), ptr(eid), ptr(scratch), stream_ptr()),
+    check(lib().dgnn_plan_build(ptr(edge_index), edge_index.stride(0), edge_index.stride(1), E, n_key, by, hint, ptr(rowptr), ptr(other), ptr(eid), ptr(scratch), stream_ptr()),
           "dgnn_plan_build")
     return rowptr, other, eid
 

@@ -238,7 +238,7 @@ class PartitionedScene:
         """Partitioned equivalent of SurfaceNet.inference_layer: logits [n_own, 2] of the owned tets."""
         n_src = self.n_own + self.n_halo
         if self.plan is None or rebuild_plan:
-            self.plan = self._GraphPlan(self.edge_index, n_src, self.n_own)
+            self.plan = self._GraphPlan(self.edge_index, n_src, self.n_own, hint=1)  # local list is grouped by destination
         plan = self.plan
         x = self.x_local[:, 1:] if net.clf.regularization.cell_type else self.x_local
         xe = self.edge_attr[:, 1:] if net.clf.regularization.edge_type else self.edge_attr

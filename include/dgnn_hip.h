@@ -58,13 +58,20 @@ const char* dgnn_last_error_string(void);
  *   other      : int32 [E]         out  (src for by=1, dst for by=0)
  *   eid        : int32 [E]         out  original edge position of the k-th sorted edge
  *   scratch    : int32 [dgnn_plan_scratch_elems(E,n_key)]
- * When E == 4*n_key the reference's own layout is tried first (row 4t+r = r-th neighbour of cell t, symmetric
- * relation): one verified pass without atomics/scan/sort; if the check fails on the device the generic
- * count/scan/fill/sort kernels queued behind it rebuild the plan.  Same result either way.
+ * Two verified single-pass builders run before the generic count/scan/fill/sort kernels:
+ *   GROUPED   - the edge list is already ascending in the key row (k-hop sampled blocks, a partition's local
+ *               list, the by-source plan of the reference layout): the sort is the identity;
+ *   REFERENCE - by destination, E == 4*n_key, row 4t+r = r-th neighbour of cell t, symmetric relation (what
+ *               processing/data.py hands the model): in-edges are the reversed out-edges, no atomics/scan/sort.
+ * `hint` only selects which of them is attempted (AUTO: both).  Each checks its precondition on the device;
+ * when it does not hold, the generic kernels queued behind it rebuild the plan.  Same result in every case.
  * ---------------------------------------------------------------------------------------------- */
+#define DGNN_PLAN_HINT_AUTO 0
+#define DGNN_PLAN_HINT_GROUPED 1
+#define DGNN_PLAN_HINT_REFERENCE 2
 int64_t dgnn_plan_scratch_elems(int64_t E, int64_t n_key);
 int dgnn_plan_build(const int64_t* edge_index, int64_t stride_row, int64_t stride_col, int64_t E, int64_t n_key, int by,
-                    int32_t* rowptr, int32_t* other,
+                    int hint, int32_t* rowptr, int32_t* other,
                     int32_t* eid, int32_t* scratch, void* stream);
 
 /* out[k, 0:cols] = in[idx[k], 0:cols]  -- stages edge_attr rows into plan order once per scene

@@ -71,13 +71,15 @@ def _check_plan(ops, ei, n_src, n_dst):
     assert not views[1].is_contiguous() or ei.shape[1] <= 1
     for t in views:
         for by, n_key in ((1, n_dst), (0, n_src)):
-            rowptr, other, eid = ops.plan_build(t, n_key, by)
             key, oth = ei[by], ei[1 - by]
             order = np.argsort(key, kind="stable")
             ref_rowptr = np.concatenate([[0], np.cumsum(np.bincount(key, minlength=n_key))])
-            assert np.array_equal(rowptr.cpu().numpy(), ref_rowptr)
-            assert np.array_equal(eid.cpu().numpy(), order)
-            assert np.array_equal(other.cpu().numpy(), oth[order])
+            # the hint only chooses which verified fast path is attempted; a wrong hint must still give the stable sort
+            for hint in (ops.PLAN_HINT_AUTO, ops.PLAN_HINT_GROUPED, ops.PLAN_HINT_REFERENCE):
+                rowptr, other, eid = ops.plan_build(t, n_key, by, hint)
+                assert np.array_equal(rowptr.cpu().numpy(), ref_rowptr), (by, hint)
+                assert np.array_equal(eid.cpu().numpy(), order), (by, hint)
+                assert np.array_equal(other.cpu().numpy(), oth[order]), (by, hint)
 
 
 @pytest.mark.parametrize("case", ["delaunay", "duplicates_selfloops", "one_way", "wrong_group", "out_of_pattern_src", "perm_rows"])
