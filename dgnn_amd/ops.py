@@ -254,6 +254,11 @@ GEMM_MODE = {"f32": GEMM_F32, "bf16x3": GEMM_BF16X3, "bf16x3f": GEMM_BF16X3_FILT
 EDGE_GATHER_IN_KERNEL = __import__("os").environ.get("DGNN_EDGE_STAGING", "0") != "1"
 
 
+# optional profiling hook (bench.py): called as tok = hook(None, c_in, c_out, n_dst) right before the launch and
+# hook(tok, c_in, c_out, n_dst) right after it, on the launching thread / current stream
+FUSED_LAUNCH_HOOK = None
+
+
 def sage_layer_fused_fwd(rowptr, src, n_dst, x_src, edge_attr, We, be, Wj, bj, Wi, scale, shift, relu, gemm_mode=None,
                          out=None, eid=None, x_dst=None):
     """`x_dst` (optional): own rows of the destinations when they are not x_src[:n_dst] (a destination sub-range).
@@ -269,10 +274,14 @@ def sage_layer_fused_fwd(rowptr, src, n_dst, x_src, edge_attr, We, be, Wj, bj, W
         _req(out, "out", dim=2)
         if out.size(0) < n_dst or out.size(1) != c_out or out.stride(0) != c_out:
             raise ValueError("out must be a contiguous [>= n_dst, c_out] buffer")
+    hook = FUSED_LAUNCH_HOOK
+    tok = hook(None, c_in, c_out, n_dst) if hook is not None else None
     check(lib().dgnn_sage_layer_fused_fwd(
         ptr(rowptr), ptr(src), ptr(eid), n_dst, ptr(x_src), ptr(x_dst), _ld(x_src), c_in, ptr(edge_attr), _ld(edge_attr), We.size(1),
         ptr(We), ptr(be), ptr(Wj), ptr(bj), ptr(Wi), ptr(scale), ptr(shift), int(bool(relu)), c_out, ptr(out), c_out,
         GEMM_MODE if gemm_mode is None else gemm_mode, stream_ptr()), "dgnn_sage_layer_fused_fwd")
+    if hook is not None:
+        hook(tok, c_in, c_out, n_dst)
     return out
 
 

@@ -123,10 +123,17 @@ class HaloExchange:
     start(h) posts the exchange, wait() makes the caller's stream see the received rows; on a GPU the sends/receives are
     issued on a side stream so kernels queued between start() and wait() overlap with the transfer.  __call__ = both."""
 
-    def __init__(self, lp: LocalPart, device, pack: Optional[Callable] = None, group=None):
+    def __init__(self, lp: LocalPart, device, pack: Optional[Callable] = None, group=None, via_host: Optional[bool] = None):
         self.lp = lp
         self.device = torch.device(device)
         self.group = group
+        if via_host is None:
+            # RCCL moves device buffers directly; any other backend (gloo: bring-up / single-GPU validation runs with
+            # several ranks on one device) gets the rows staged through host memory.  Transport only -- never compute.
+            import torch.distributed as dist
+            via_host = (self.device.type == "cuda" and lp.world > 1 and dist.is_available() and dist.is_initialized()
+                        and dist.get_backend(group) != "nccl")
+        self.via_host = bool(via_host)
         self.send_idx = torch.from_numpy(lp.send_idx).to(device)
         self.send_idx32 = self.send_idx.to(torch.int32)
         self.pack = pack
@@ -138,6 +145,10 @@ class HaloExchange:
     def _post(self, h_full, send):
         import torch.distributed as dist
         lp = self.lp
+        if self.via_host:
+            recv_dev, send_dev = h_full[self.n_own:], send
+            send = send_dev.cpu()                                   # synchronises the host with the current (side) stream
+            h_full = torch.empty((h_full.size(0), h_full.size(1)), dtype=h_full.dtype)   # only the halo tail is used
         ops, so, ro = [], 0, self.n_own
         for peer in range(lp.world):
             ns, nr = lp.send_counts[peer], lp.recv_counts[peer]
@@ -149,6 +160,8 @@ class HaloExchange:
             ro += nr
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+        if self.via_host:
+            recv_dev.copy_(h_full[self.n_own:].to(recv_dev.device, non_blocking=False))
 
     def start(self, h_full: torch.Tensor) -> None:
         """h_full [n_own + n_halo, C] with the rows to send valid: begins filling the halo rows in place."""

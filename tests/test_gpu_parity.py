@@ -439,25 +439,10 @@ def _two_rank_worker(rank, world, port, out_dir):
     ex, lp = scene.exchange, scene.lp
     assert ex.stream is not None and lp.n_interior > 0 and lp.n_halo > 0
 
-    def post(h_full, send):
-        # Test-only transport: both ranks share the box's single GPU (RCCL wants one GPU per rank), so the rows travel
-        # through host memory over gloo.  Stream choreography -- pack on the compute stream, transfer on the side
-        # stream, interior launch in between, boundary launch after wait() -- is the product's.
-        send_h = send.cpu()
-        recv_h = torch.empty(lp.n_halo, send.size(1))
-        ops_, so, ro = [], 0, 0
-        for peer in range(world):
-            ns, nr = lp.send_counts[peer], lp.recv_counts[peer]
-            if nr:
-                ops_.append(dist.P2POp(dist.irecv, recv_h[ro:ro + nr], peer))
-            if ns:
-                ops_.append(dist.P2POp(dist.isend, send_h[so:so + ns], peer))
-            so, ro = so + ns, ro + nr
-        for req in dist.batch_isend_irecv(ops_):
-            req.wait()
-        h_full[lp.n_own:].copy_(recv_h.to(h_full.device, non_blocking=True))
-
-    ex._post = post
+    # both ranks share the box's single GPU (RCCL wants one GPU per rank): under gloo the exchange stages the rows through
+    # host memory; the stream choreography -- pack on the compute stream, transfer on the side stream, interior launch in
+    # between, boundary launch after wait() -- is the same as with RCCL
+    assert ex.via_host
     for _ in range(3):  # several steps: buffers are recycled by the allocator across streams
         logits = scene.inference_layer(net)
     torch.cuda.synchronize()
