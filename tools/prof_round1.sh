@@ -11,4 +11,5 @@ rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpuru
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
 python3 bench.py --steps 20 --warmup 5 --gemm-mode f32 --no-cpu-baseline > gpurun_out/${T}_bench_f32.json 2>> gpurun_out/${T}_bench.err
 python3 bench.py --steps 20 --warmup 5 --cached-plan --no-cpu-baseline > gpurun_out/${T}_bench_cachedplan.json 2>> gpurun_out/${T}_bench.err
+python3 tools/bench_train.py > gpurun_out/${T}_train.json 2>> gpurun_out/${T}_bench.err
 tail -c 600 gpurun_out/${T}_bench.json
