@@ -237,16 +237,25 @@ __global__ void __launch_bounds__(256) k_agg_bwd(const int32_t* __restrict__ t_r
     }
 }
 
-// out[chunk][i] (+)= sum_b slabs[b][chunk][i]; one thread per output, fixed order.
-__global__ void k_reduce_slabs(const float* __restrict__ slabs, int nblocks, int nchunks, int per, int c_in, int fe,
-                               int cpl, float* __restrict__ dWe, float* __restrict__ dbe) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nchunks * per) return;
-    const int chunk = i / per, r = i - chunk * per;
+// out[chunk][i] (+)= sum_b slabs[b][chunk][i]; 16 outputs x 16 slices per block: slice s adds slabs s, s+16, ... in order,
+// the 16 slice sums are then added in slice order (deterministic, and not a 512-long dependent chain per output).
+__global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ slabs, int nblocks, int nchunks, int per, int c_in,
+                                                      int fe, int cpl, float* __restrict__ dWe, float* __restrict__ dbe) {
+    __shared__ float red[16][17];
+    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + o;
+    const bool live = i < nchunks * per;
+    const int chunk = live ? i / per : 0, r = live ? i - chunk * per : 0;
+    float p = 0.f;
+    if (live)
+        for (int b = sl; b < nblocks; b += 16) p += slabs[((int64_t)b * nchunks + chunk) * per + r];
+    red[sl][o] = p;
+    __syncthreads();
+    if (sl != 0 || !live) return;
     const int c = chunk * 64 * cpl + r / (fe + 1), f = r % (fe + 1);
     if (c >= c_in) return;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += slabs[((int64_t)b * nchunks + chunk) * per + r];
+    for (int k = 0; k < 16; ++k) s += red[k][o];
     if (f < fe)
         dWe[(int64_t)c * fe + f] += s;
     else
@@ -330,7 +339,7 @@ extern "C" int dgnn_sage_aggregate_bwd(const int32_t* t_rowptr, const int32_t* t
 #undef LAUNCH
     if (fused) {
         const int per = 64 * cpl * (f_e + 1);
-        hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)dgnn_cdiv((int64_t)chunks * per, 256)), dim3(256), 0, stream, partials,
+        hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)dgnn_cdiv((int64_t)chunks * per, 16)), dim3(256), 0, stream, partials,
                            nblocks, chunks, per, c_in, f_e, cpl, dWe, dbe);
     }
     return dgnn_check_launch("aggregate_bwd");

@@ -154,14 +154,23 @@ __global__ void __launch_bounds__(256) k_linear_wgrad(const float* __restrict__ 
     }
 }
 
-__global__ void k_wgrad_reduce(const float* __restrict__ partials, int splits, int na, int nb, float* __restrict__ dW,
-                               int64_t lddw, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= na * nb) return;
+// dW (+)= sum over the row splits, 16 outputs x 16 slices per block in a fixed order (see k_reduce_slabs)
+__global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ partials, int splits, int na, int nb,
+                                                      float* __restrict__ dW, int64_t lddw, int accumulate) {
+    __shared__ float red[16][17];
+    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + o;
+    const bool live = i < na * nb;
+    float p = 0.f;
+    if (live)
+        for (int z = sl; z < splits; z += 16) p += partials[(int64_t)z * na * nb + i];
+    red[sl][o] = p;
+    __syncthreads();
+    if (sl != 0 || !live) return;
     float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += partials[(int64_t)z * na * nb + i];
-    float* o = dW + (int64_t)(i / nb) * lddw + (i % nb);
-    *o = accumulate ? *o + s : s;
+    for (int k = 0; k < 16; ++k) s += red[k][o];
+    float* out = dW + (int64_t)(i / nb) * lddw + (i % nb);
+    *out = accumulate ? *out + s : s;
 }
 
 int wgrad_splits(int64_t M) {
@@ -204,7 +213,7 @@ extern "C" int dgnn_linear_wgrad(const float* A, int64_t lda, int n_a, const flo
     const int64_t rps = dgnn_cdiv(dgnn_cdiv(M, splits), RK) * RK;
     dim3 grid((unsigned)dgnn_cdiv(n_a, WT), (unsigned)dgnn_cdiv(n_b, WT), splits);
     hipLaunchKernelGGL(k_linear_wgrad, grid, dim3(256), 0, stream, A, lda, n_a, B, ldb, n_b, M, rps < RK ? RK : rps, partials);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)dgnn_cdiv((int64_t)n_a * n_b, 256)), dim3(256), 0, stream, partials, splits,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)dgnn_cdiv((int64_t)n_a * n_b, 16)), dim3(256), 0, stream, partials, splits,
                        n_a, n_b, dW, lddw, accumulate);
     return dgnn_check_launch("linear_wgrad");
 }

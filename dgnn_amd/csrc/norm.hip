@@ -58,15 +58,37 @@ __global__ void __launch_bounds__(256) k_colreduce(const float* __restrict__ x, 
     }
 }
 
-__global__ void k_stats_finalize(const double* __restrict__ partials, int nblk, int64_t M, int c, float* __restrict__ mean,
-                                 float* __restrict__ var, float* __restrict__ rmean, float* __restrict__ rvar, float momentum) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= c) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s += partials[((int64_t)b * 2 + 0) * c + col];
-        q += partials[((int64_t)b * 2 + 1) * c + col];
+// Deterministic two-level finalisers: 256 threads = 16 columns x 16 slices; slice s sums partial blocks s, s+16, ... in
+// ascending order, then the 16 slice sums are added in slice order.  (A single thread per column walking all ~500
+// partial blocks was a 80-90 us dependent-load chain -- 30 % of a training step.)
+__device__ __forceinline__ bool finalize_pair(const double* __restrict__ partials, int nblk, int c, double& s, double& q) {
+    __shared__ double red[2][16][17];
+    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4, col = blockIdx.x * 16 + o;
+    double ps = 0.0, pq = 0.0;
+    if (col < c)
+        for (int b = sl; b < nblk; b += 16) {
+            ps += partials[((int64_t)b * 2 + 0) * c + col];
+            pq += partials[((int64_t)b * 2 + 1) * c + col];
+        }
+    red[0][sl][o] = ps;
+    red[1][sl][o] = pq;
+    __syncthreads();
+    if (sl != 0 || col >= c) return false;
+    s = 0.0;
+    q = 0.0;
+    for (int k = 0; k < 16; ++k) {
+        s += red[0][k][o];
+        q += red[1][k][o];
     }
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_stats_finalize(const double* __restrict__ partials, int nblk, int64_t M, int c,
+                                                        float* __restrict__ mean, float* __restrict__ var,
+                                                        float* __restrict__ rmean, float* __restrict__ rvar, float momentum) {
+    double s, q;
+    if (!finalize_pair(partials, nblk, c, s, q)) return;
+    const int col = blockIdx.x * 16 + (threadIdx.x & 15);
     const double m = s / (double)M;
     double v = q / (double)M - m * m;
     if (v < 0.0) v = 0.0;
@@ -80,15 +102,11 @@ __global__ void k_stats_finalize(const double* __restrict__ partials, int nblk, 
 }
 
 // sums[0][c] = first quantity, sums[1][c] = second (float), optional accumulate into out0/out1
-__global__ void k_sum_finalize(const double* __restrict__ partials, int nblk, int c, float* __restrict__ out0,
-                               float* __restrict__ out1, int accumulate) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= c) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s += partials[((int64_t)b * 2 + 0) * c + col];
-        q += partials[((int64_t)b * 2 + 1) * c + col];
-    }
+__global__ void __launch_bounds__(256) k_sum_finalize(const double* __restrict__ partials, int nblk, int c, float* __restrict__ out0,
+                                                      float* __restrict__ out1, int accumulate) {
+    double s, q;
+    if (!finalize_pair(partials, nblk, c, s, q)) return;
+    const int col = blockIdx.x * 16 + (threadIdx.x & 15);
     if (out0) out0[col] = accumulate ? out0[col] + (float)s : (float)s;
     if (out1) out1[col] = accumulate ? out1[col] + (float)q : (float)q;
 }
@@ -175,7 +193,7 @@ extern "C" int dgnn_bn_batch_stats(const float* x, int64_t ldx, int64_t M, int c
     double* P = as_f64(scratch);
     hipLaunchKernelGGL((k_colreduce<0>), dim3(nblk), dim3(256), 0, stream, x, ldx, nullptr, (int64_t)0, nullptr, (int64_t)0, nullptr,
                        nullptr, 0.f, 0, M, c, rpb, P);
-    hipLaunchKernelGGL(k_stats_finalize, dim3((c + 255) / 256), dim3(256), 0, stream, P, nblk, M, c, mean, var, running_mean,
+    hipLaunchKernelGGL(k_stats_finalize, dim3((c + 15) / 16), dim3(256), 0, stream, P, nblk, M, c, mean, var, running_mean,
                        running_var, momentum);
     return dgnn_check_launch("bn_batch_stats");
 }
@@ -201,7 +219,7 @@ extern "C" int dgnn_bn_relu_bwd(const float* x, int64_t ldx, const float* y, int
     double* P = as_f64(scratch);
     float* sums = reinterpret_cast<float*>(P + (int64_t)nblk * 2 * c);
     hipLaunchKernelGGL((k_colreduce<1>), dim3(nblk), dim3(256), 0, stream, x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, rpb, P);
-    hipLaunchKernelGGL(k_sum_finalize, dim3((c + 255) / 256), dim3(256), 0, stream, P, nblk, c, sums, sums + c, 0);
+    hipLaunchKernelGGL(k_sum_finalize, dim3((c + 15) / 16), dim3(256), 0, stream, P, nblk, c, sums, sums + c, 0);
     hipLaunchKernelGGL(k_bn_relu_bwd_apply, dim3(dgnn_grid_cap(dgnn_cdiv(M * c, 256))), dim3(256), 0, stream, x, ldx, y, ldy, dy,
                        lddy, gamma, mean, var, eps, train, relu, M, c, sums, sums + c, dx, lddx);
     if (dbeta) (void)hipMemcpyAsync(dbeta, sums, sizeof(float) * c, hipMemcpyDeviceToDevice, stream);
@@ -218,6 +236,6 @@ extern "C" int dgnn_colsum(const float* x, int64_t ldx, int64_t M, int c, float*
     double* P = as_f64(scratch);
     hipLaunchKernelGGL((k_colreduce<2>), dim3(nblk), dim3(256), 0, stream, x, ldx, nullptr, (int64_t)0, nullptr, (int64_t)0, nullptr,
                        nullptr, 0.f, 0, M, c, rpb, P);
-    hipLaunchKernelGGL(k_sum_finalize, dim3((c + 255) / 256), dim3(256), 0, stream, P, nblk, c, out, nullptr, accumulate);
+    hipLaunchKernelGGL(k_sum_finalize, dim3((c + 15) / 16), dim3(256), 0, stream, P, nblk, c, out, nullptr, accumulate);
     return dgnn_check_launch("colsum");
 }
