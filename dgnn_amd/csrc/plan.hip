@@ -353,7 +353,7 @@ extern "C" int dgnn_plan_build(const int64_t* edge_index, int64_t stride_row, in
     hipStream_t stream = (hipStream_t)stream_;
     DGNN_REQUIRE(E >= 0 && n_key >= 0 && (by == 0 || by == 1), DGNN_E_INVALID, "plan_build: bad sizes E=%lld n=%lld by=%d",
                  (long long)E, (long long)n_key, by);
-    DGNN_REQUIRE(hint >= DGNN_PLAN_HINT_AUTO && hint <= DGNN_PLAN_HINT_REFERENCE, DGNN_E_INVALID, "plan_build: bad hint %d", hint);
+    DGNN_REQUIRE(hint >= DGNN_PLAN_HINT_AUTO && hint <= DGNN_PLAN_HINT_GENERIC, DGNN_E_INVALID, "plan_build: bad hint %d", hint);
     DGNN_REQUIRE(E < INT32_MAX && n_key < INT32_MAX, DGNN_E_UNSUPPORTED, "plan_build: E and n must fit int32");
     DGNN_REQUIRE(rowptr && scratch && (E == 0 || (edge_index && other && eid)), DGNN_E_INVALID, "plan_build: null pointer");
     DGNN_REQUIRE(E <= 1 || stride_col != 0, DGNN_E_INVALID, "plan_build: zero column stride");
@@ -377,8 +377,8 @@ extern "C" int dgnn_plan_build(const int64_t* edge_index, int64_t stride_row, in
     // caught by the flags and the generic kernels queued behind rebuild the plan -- with small grids (they are
     // grid-stride loops and return on their first instruction when a fast path succeeded).
     const bool can_regular = by == 1 && E == 4 * n_key && E > 0;
-    const bool try_sorted = E > 0 && !(hint == DGNN_PLAN_HINT_REFERENCE && can_regular);
-    const bool try_regular = can_regular && hint != DGNN_PLAN_HINT_GROUPED;
+    const bool try_sorted = E > 0 && hint != DGNN_PLAN_HINT_GENERIC && !(hint == DGNN_PLAN_HINT_REFERENCE && can_regular);
+    const bool try_regular = can_regular && hint != DGNN_PLAN_HINT_GROUPED && hint != DGNN_PLAN_HINT_GENERIC;
     hipLaunchKernelGGL(k_plan_init, dim3(dgnn_grid_cap(dgnn_cdiv(n_key, 256))), dim3(256), 0, stream, deg, n_key, big_count, need,
                        try_sorted ? 0 : 1, try_regular ? 0 : 1);
     const int32_t* flag = nullptr;

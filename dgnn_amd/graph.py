@@ -19,12 +19,15 @@ class GraphPlan:
     ascending original edge position (the CPU scatter order of the reference); src[k] is the
     source of sorted edge k and eid[k] its row in the caller's edge_attr."""
 
-    def __init__(self, edge_index: torch.Tensor, n_src: int, n_dst: int, hint: int = ops.PLAN_HINT_AUTO):
+    def __init__(self, edge_index: torch.Tensor, n_src: int, n_dst: int, hint: int = ops.PLAN_HINT_AUTO, parts=None):
+        """`parts` = (rowptr int32 [n_dst+1], src int32 [E], eid int32 [E]) when the producer of the edge list already has
+        them (the k-hop block builder emits its blocks grouped by destination: its own row offsets ARE the plan)."""
         if edge_index.dtype != torch.int64:
             edge_index = edge_index.to(torch.int64)  # inference_layer does the same (:339)
         self.edge_index = edge_index  # any strides: the plan builder reads the (possibly transposed) view in place
         self.n_src, self.n_dst, self.E = int(n_src), int(n_dst), int(edge_index.size(1))
-        self.rowptr, self.src, self.eid = ops.plan_build(self.edge_index, self.n_dst, by=1, hint=hint)
+        self.rowptr, self.src, self.eid = parts if parts is not None else ops.plan_build(self.edge_index, self.n_dst, by=1, hint=hint)
+        self._grouped = parts is not None or hint == ops.PLAN_HINT_GROUPED
         self._t = None
         self._sorted_attr = None  # (weakref to edge_attr, version, sorted copy)
 
@@ -33,7 +36,9 @@ class GraphPlan:
         """(t_rowptr [n_src+1], t_dst [E], t_eid [E]): out-edges of every source, ascending edge
         position -- the accumulation order of autograd's index_add_ for x.index_select(0, src)."""
         if self._t is None:
-            self._t = ops.plan_build(self.edge_index, self.n_src, by=0)
+            # an edge list grouped by destination is not grouped by source (unless it is the reference layout): skip the
+            # fast-path attempts there
+            self._t = ops.plan_build(self.edge_index, self.n_src, by=0, hint=ops.PLAN_HINT_GENERIC if self._grouped else ops.PLAN_HINT_AUTO)
         return self._t
 
     def sorted_edge_attr(self, edge_attr: torch.Tensor) -> torch.Tensor:
@@ -66,6 +71,14 @@ def plan_for(edge_index: torch.Tensor, n_src: int, n_dst: int, cache: bool = Tru
     except TypeError:
         pass
     return plan
+
+
+def register_plan(edge_index: torch.Tensor, plan: GraphPlan) -> None:
+    """Makes plan_for(edge_index, n_src, n_dst) return `plan` (used by producers that build the plan with the edge list)."""
+    key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, plan.n_src, plan.n_dst, str(edge_index.device))
+    if len(_cache) > 64:
+        _cache.clear()
+    _cache[key] = (weakref.ref(edge_index), plan)
 
 
 def clear_plan_cache():

@@ -39,7 +39,7 @@ def _f32(n, device):
 
 
 # ---- plan ---------------------------------------------------------------------------------------
-PLAN_HINT_AUTO, PLAN_HINT_GROUPED, PLAN_HINT_REFERENCE = 0, 1, 2
+PLAN_HINT_AUTO, PLAN_HINT_GROUPED, PLAN_HINT_REFERENCE, PLAN_HINT_GENERIC = 0, 1, 2, 3
 
 
 def plan_build(edge_index: torch.Tensor, n_key: int, by: int, hint: int = PLAN_HINT_AUTO):

@@ -15,7 +15,7 @@ from __future__ import annotations
 import torch
 
 from ._lib import check, lib, ptr, stream_ptr
-from .graph import GraphPlan
+from .graph import GraphPlan, register_plan
 
 _I32_MAX = 2 ** 31 - 1
 
@@ -56,6 +56,12 @@ class NeighborSampler:
         self.generator = generator
         self._pos = torch.full((n,), -1, dtype=torch.int32, device=self.device)
         self._first = torch.full((n,), _I32_MAX, dtype=torch.int32, device=self.device)
+        self._iota = torch.arange(0, dtype=torch.int32, device=self.device)
+
+    def _arange(self, n):
+        if self._iota.numel() < n:
+            self._iota = torch.arange(max(n, 2 * self._iota.numel()), dtype=torch.int32, device=self.device)
+        return self._iota[:n]
 
     def __len__(self):
         m = self.node_idx.numel()
@@ -83,8 +89,8 @@ class NeighborSampler:
             check(L.dgnn_khop_count(ptr(p.rowptr), ptr(n_id), n_t, int(hop == 0), ptr(self._pos), ptr(off), ptr(scratch), st),
                   "dgnn_khop_count")
             n_e = int(off[n_t].item())  # sizes the block tensors (the CPU sampler is synchronous as well)
-            e_src = torch.empty(n_e, dtype=torch.int64, device=self.device)
-            e_dst = torch.empty(n_e, dtype=torch.int64, device=self.device)
+            ei = torch.empty((2, n_e), dtype=torch.int64, device=self.device)
+            e_src, e_dst = ei[0], ei[1]
             e_id = torch.empty(n_e, dtype=torch.int64, device=self.device)
             n_id_out = torch.empty(n_t + n_e, dtype=torch.int64, device=self.device)
             n_new = torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -95,7 +101,9 @@ class NeighborSampler:
             n_all = n_t + int(n_new.item())
             check(L.dgnn_khop_commit(ptr(n_id_out), n_t, n_all, ptr(self._pos), ptr(self._first), st), "dgnn_khop_commit")
             n_id = n_id_out[:n_all]
-            adjs.append(EdgeIndex(torch.stack([e_src, e_dst]), e_id if self.return_e_id else None, (n_all, n_t)))
+            # the block is emitted grouped by destination with `off` as its row offsets: that IS its plan (identity order)
+            register_plan(ei, GraphPlan(ei, n_all, n_t, parts=(off, e_src.to(torch.int32), self._arange(n_e))))
+            adjs.append(EdgeIndex(ei, e_id if self.return_e_id else None, (n_all, n_t)))
         check(L.dgnn_khop_reset(ptr(n_id), n_id.numel(), ptr(self._pos), st), "dgnn_khop_reset")
         adjs = adjs[0] if len(adjs) == 1 else adjs[::-1]
         return batch_size, n_id, adjs

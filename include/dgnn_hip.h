@@ -69,6 +69,7 @@ const char* dgnn_last_error_string(void);
 #define DGNN_PLAN_HINT_AUTO 0
 #define DGNN_PLAN_HINT_GROUPED 1
 #define DGNN_PLAN_HINT_REFERENCE 2
+#define DGNN_PLAN_HINT_GENERIC 3 /* attempt neither: straight to the generic kernels */
 int64_t dgnn_plan_scratch_elems(int64_t E, int64_t n_key);
 int dgnn_plan_build(const int64_t* edge_index, int64_t stride_row, int64_t stride_col, int64_t E, int64_t n_key, int by,
                     int hint, int32_t* rowptr, int32_t* other,
