@@ -21,6 +21,9 @@
 // phase; the dense part is the K-split 32x32x16 split-bf16 product with the delayed epilogue.
 #include "fused_common.h"
 
+#ifndef DGNN_SMALL_NW
+#define DGNN_SMALL_NW 4  // wavefronts per workgroup for C_in <= 64 (4: two independent workgroups per CU; 8: one)
+#endif
 #ifndef DGNN_PHASE_PRIO
 #define DGNN_PHASE_PRIO 0  // measured: balances the barrier waits (0.6/0.4 us instead of 1.4/0.2) but the tile period does not move
 #endif
@@ -33,25 +36,31 @@ using namespace fused;
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-template <int CIN_PAD, int COUT>
+// NW wavefronts per workgroup, KS = how many ways the dense phase splits K between wavefronts.
+//   (8, 2): 8 waves = (32-column slice) x (K half) [x row group]; the only arrangement whose resident weights fit at C_in = 128.
+//   (4, 1): 4 waves = (32-column slice) [x row group], full K per wave, no partial-sum exchange; 70-76 KB of LDS, so TWO
+//           workgroups share a CU with independent barriers -- one fills the other's barrier / latency bubbles.  Used for
+//           C_in <= 64, where a tile is too little work to hide its own fixed latencies.
+template <int CIN_PAD, int COUT, int NW = 8, int KS = 2>
 struct Cfg2 {
     static constexpr int K = 2 * CIN_PAD;
     static constexpr int NSLICE = COUT / 32;
-    static constexpr int RG = NWAVE / (2 * NSLICE);
+    static constexpr int RG = NW / (KS * NSLICE);
     static constexpr int TILE = 32 * RG;
     static constexpr int ROWB = (K / 8) * 48 + 16;       // A-tile row: K/8 octets of [hi|mid|lo] 16 B each + pad
     static constexpr int A_BYTES = TILE * ROWB;
-    static constexpr int TPW = TILE / NWAVE;              // tets per wave (4 or 8)
+    static constexpr int TPW = TILE / NW;                 // tets per wave (4, 8 or 16)
     static constexpr int RB = TPW / 4;                    // 16-edge row blocks per wave
     static constexpr int NQ = TPW * 4;                    // edges per wave
     static constexpr int NB = CIN_PAD / 16;               // column blocks = contiguous channels per lane (8, 4, 2)
-    static constexpr int EA_BYTES = NQ * FE * 4;          // 1280 or 2560: whole KiB by 16-B DMA, the rest by 4-B DMA
+    static constexpr int EA_BYTES = NQ * FE * 4;          // 1280, 2560 or 5120: whole KiB by 16-B DMA, the rest by 4-B DMA
     static constexpr int EA_FULL = EA_BYTES / 1024, EA_TAIL = (EA_BYTES % 1024) / 256;
     static constexpr int BP_BYTES = NB * 3 * 768;         // [cb][part][g<3][j<16] x 16 B filter operand parts
-    static constexpr int RED_BYTES = NWAVE * 8 * 64 * 4;
-    static constexpr int SMEM_BYTES = 2 * A_BYTES + NWAVE * EA_BYTES + 2 * RED_BYTES + BP_BYTES;
-    static constexpr int NWB = CIN_PAD / 16;              // dense part: k-steps of 16 per K half
+    static constexpr int RED_BYTES = KS == 2 ? NW * 8 * 64 * 4 : 0;
+    static constexpr int SMEM_BYTES = 2 * A_BYTES + NW * EA_BYTES + 2 * RED_BYTES + BP_BYTES;
+    static constexpr int NWB = K / 16 / KS;               // dense part: k-steps of 16 per wave
     static_assert(EA_BYTES % 256 == 0, "attribute block must be DMA-able");
+    static_assert(RG >= 1 && NQ <= 64, "wave roles");
 };
 
 template <int NB>
@@ -70,20 +79,20 @@ __device__ __forceinline__ void ld_vec(float (&v)[NB], const float* p, bool vec)
     }
 }
 
-template <int CIN_PAD, int COUT>
-__global__ void __launch_bounds__(512, 2)
+template <int CIN_PAD, int COUT, int NW, int KS>
+__global__ void __launch_bounds__(64 * NW, 2)
 k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid, int64_t n_dst,
                   const float* __restrict__ x, const float* __restrict__ xdst, int64_t ldx, int c_in, const float* __restrict__ ea, int64_t lde,
                   const float* __restrict__ We, const float* __restrict__ be, const float* __restrict__ Wj,
                   const float* __restrict__ bj, const float* __restrict__ Wi, const float* __restrict__ scale,
                   const float* __restrict__ shift, int relu, float* __restrict__ out, int64_t ldo, int64_t ntiles,
                   int xvec, int64_t* __restrict__ trace, int64_t trace_cap) {
-    using C = Cfg2<CIN_PAD, COUT>;
+    using C = Cfg2<CIN_PAD, COUT, NW, KS>;
     constexpr int ROWB = C::ROWB, TILE = C::TILE, TPW = C::TPW, RB = C::RB, NB = C::NB, NWB = C::NWB;
     extern __shared__ __attribute__((aligned(16))) char smem2[];
     char* const abuf = smem2;                                        // [2][A_BYTES]
-    char* const eabuf = smem2 + 2 * C::A_BYTES;                      // [NWAVE][EA_BYTES] fp32 attribute strips
-    float* const redbuf = reinterpret_cast<float*>(eabuf + NWAVE * C::EA_BYTES);  // [2][NWAVE][8][64]
+    char* const eabuf = smem2 + 2 * C::A_BYTES;                      // [NW][EA_BYTES] fp32 attribute strips
+    float* const redbuf = reinterpret_cast<float*>(eabuf + NW * C::EA_BYTES);     // [2][NW][8][64] (KS == 2 only)
     char* const bpbuf = reinterpret_cast<char*>(redbuf) + 2 * C::RED_BYTES;       // filter operand parts
 
     const int lane = lane_id(), w = wave_id_uniform();
@@ -127,19 +136,22 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         dst[96] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
     }
 
-    // ---- dense-phase role: (column slice cs, K half kh, row group rg); half-K weights resident as 3 bf16 parts
-    const int cs = w % C::NSLICE, kh = (w / C::NSLICE) & 1, rg = w / (2 * C::NSLICE);
+    // ---- dense-phase role: (column slice cs, K part kh, row group rg); this wave's share of K resident as 3 bf16 parts
+    const int cs = w % C::NSLICE, kh = KS == 2 ? (w / C::NSLICE) & 1 : 0, rg = w / (KS * C::NSLICE);
     const int col = cs * 32 + l31;
     const int partner = w ^ C::NSLICE;
     bf16x8 wb[NWB][3];
     {
-        const float* Wsrc = kh ? Wi : Wj;
 #pragma unroll
         for (int S = 0; S < NWB; ++S) {
+            // k-steps 0 .. CIN_PAD/16-1 of the A row are the mean half (Wj), the rest the own-row half (Wi)
+            const bool second = KS == 2 ? kh != 0 : S >= CIN_PAD / 16;
+            const float* Wsrc = second ? Wi : Wj;
+            const int S_ = (KS == 1 && S >= CIN_PAD / 16) ? S - CIN_PAD / 16 : S;
             uint32_t ph[4], pm[4], pl[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                const int k = 16 * S + 8 * h + 2 * d;
+                const int k = 16 * S_ + 8 * h + 2 * d;
                 const float v0 = Wsrc[(int64_t)col * c_in + (k < c_in ? k : 0)];
                 const float v1 = Wsrc[(int64_t)col * c_in + (k + 1 < c_in ? k + 1 : 0)];
                 split3(k < c_in ? v0 : 0.f, k + 1 < c_in ? v1 : 0.f, ph[d], pm[d], pl[d]);
@@ -374,7 +386,7 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         if (w >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
 
-        if (it > 0) {
+        if (KS == 2 && it > 0) {
             // ============================================================ delayed epilogue of tile it-1
             const int64_t tile = tile_of(it - 1);
             const float* red = redbuf + ((it - 1) & 1) * (C::RED_BYTES / 4) + partner * 512 + lane;
@@ -416,11 +428,27 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wb[S][1], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wb[S][0], acc, 0, 0, 0);
             }
-            float* red = redbuf + (it & 1) * (C::RED_BYTES / 4) + w * 512 + lane;
+            if constexpr (KS == 2) {
+                float* red = redbuf + (it & 1) * (C::RED_BYTES / 4) + w * 512 + lane;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                mine[r] = kh ? acc[8 + r] : acc[r];
-                red[r * 64] = kh ? acc[r] : acc[8 + r];
+                for (int r = 0; r < 8; ++r) {
+                    mine[r] = kh ? acc[8 + r] : acc[r];
+                    red[r * 64] = kh ? acc[r] : acc[8 + r];
+                }
+            } else {
+                // full K in this wave: finish the 32 x 32 block right away (row (r&3) + 8(r>>2) + 4h, column `col`)
+                const int64_t tile = tile_of(it);
+                const int64_t row0 = tile * TILE + rg * 32 + 4 * h;
+                float* o = out + row0 * ldo + col;
+                const bool full = (tile + 1) * TILE <= n_dst;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[r] + bb;
+                    if (has_scale) v = __fmaf_rn(v, sc, sh);
+                    if (relu) v = fmaxf(v, 0.f);
+                    const int rr = (r & 3) + 8 * (r >> 2);
+                    if (full || row0 + rr < n_dst) o[(int64_t)rr * ldo] = v;
+                }
             }
             stamp(trace, trace_cap, it, w, 5);
         }
@@ -434,19 +462,24 @@ template <int CIN_PAD, int COUT>
 int launch2(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x, const float* xdst, int64_t ldx, int c_in, const float* ea,
             int64_t lde, const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
             const float* scale, const float* shift, int relu, float* out, int64_t ldo, int xvec, hipStream_t stream) {
-    using C = Cfg2<CIN_PAD, COUT>;
+    // C_in <= 64: four-wave workgroups, two per CU (see Cfg2); C_in = 128: eight waves with the K split
+    // (64 -> 64 would need 16 tets per wave with 4 channels per lane: 110 spilled registers -- it keeps the 8-wave form)
+    constexpr int NW = (CIN_PAD <= 64 && !(CIN_PAD == 64 && COUT == 64)) ? DGNN_SMALL_NW : 8, KS = NW == 8 ? 2 : 1;
+    using C = Cfg2<CIN_PAD, COUT, NW, KS>;
     const int64_t ntiles = dgnn_cdiv(n_dst, C::TILE);
     const size_t smem = C::SMEM_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sage_fused_mfma<CIN_PAD, COUT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sage_fused_mfma<CIN_PAD, COUT, NW, KS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
-    int grid = (int)(ntiles < DGNN_NUM_CU ? ntiles : DGNN_NUM_CU);
+    const int wg_max = DGNN_NUM_CU * (NW == 8 ? 1 : 2);
+    int grid = (int)(ntiles < wg_max ? ntiles : wg_max);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((k_sage_fused_mfma<CIN_PAD, COUT>), dim3(grid), dim3(512), smem, stream, rowptr, src, eid, n_dst, x, xdst, ldx, c_in, ea,
-                       lde, We, be, Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles, xvec, g_dgnn_trace_buf, g_dgnn_trace_cap);
+    hipLaunchKernelGGL((k_sage_fused_mfma<CIN_PAD, COUT, NW, KS>), dim3(grid), dim3(64 * NW), smem, stream, rowptr, src, eid, n_dst, x, xdst,
+                       ldx, c_in, ea, lde, We, be, Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles, xvec, g_dgnn_trace_buf,
+                       g_dgnn_trace_cap);
     return dgnn_check_launch("sage_layer_fused_fwd(mfma filter)");
 }
 
