@@ -6,7 +6,7 @@ import pandas as pd
 tag, name, title = sys.argv[1], sys.argv[2], sys.argv[3]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
-DOM = "k_sage_fused_mfma<128, 128>"
+DOM = "k_sage_fused_mfma<128, 128"
 
 
 def short(n):
