@@ -136,8 +136,28 @@ def main():
 
         def step():
             return scene.inference_layer(net)
+        transport = "RCCL" if backend == "nccl" else "host-staged %s (validation run, not a benchmark)" % backend
+        if backend == "nccl":
+            # Safety net: if the device-to-device exchange cannot run on this node (P2P/IPC disabled ...), every rank sees the
+            # error in its first step; all ranks then agree to stage the halo rows through host memory over gloo, and the
+            # JSON line says so.  Compute is unchanged.
+            import torch.distributed as dist
+            from dgnn_amd.partition import HaloExchange
+            gloo = dist.new_group(backend="gloo")
+            failed = 0
+            try:
+                step()
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                failed = 1
+                sys.stderr.write("rank %d: RCCL halo exchange failed (%s)\n" % (rank, e))
+            flag = torch.tensor([failed])
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=gloo)
+            if int(flag.item()):
+                scene.exchange = HaloExchange(scene.lp, dev, pack=ops.gather_rows, group=gloo, via_host=True)
+                transport = "host-staged gloo (RCCL point-to-point failed on this node)"
         workload = "synthetic Delaunay scene, %d points -> N=%d tets, %d-way spatial partition + %s halo exchange overlapped with interior cells" % (
-            args.points * world, n_total, world, "RCCL" if backend == "nccl" else "host-staged %s (validation run, not a benchmark)" % backend)
+            args.points * world, n_total, world, transport)
 
     def sync():
         if world > 1:
