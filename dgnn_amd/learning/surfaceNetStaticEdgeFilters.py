@@ -192,10 +192,20 @@ class SurfaceNet(nn.Module):
         return self._eval_decoder(x)
 
     def _fold(self, norm, c, device):
+        """BatchNorm(eval) as a per-channel (scale, shift) pair, cached until one of its tensors is written to
+        (load_state_dict / optimizer steps / train-mode running statistics all bump the tensors' version counters)."""
         if norm is None:
             return None, None
         bn = norm.module
-        return ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+        ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        key = tuple((t.data_ptr(), t._version) for t in ts) + (bn.eps,)
+        cache = self.__dict__.setdefault("_fold_cache", {})
+        hit = cache.get(id(bn))
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        out = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+        cache[id(bn)] = (key, out)
+        return out
 
     def _eval_layers(self, x, n_dst0, xe, plans, sorted_attr, only=None, out=None, rows=None):
         """Eval-mode conv stack: per layer one fused launch when the widths allow it, else the
