@@ -103,12 +103,15 @@ __global__ void __launch_bounds__(256) k_stats_finalize(const double* __restrict
 
 // sums[0][c] = first quantity, sums[1][c] = second (float), optional accumulate into out0/out1
 __global__ void __launch_bounds__(256) k_sum_finalize(const double* __restrict__ partials, int nblk, int c, float* __restrict__ out0,
-                                                      float* __restrict__ out1, int accumulate) {
+                                                      float* __restrict__ out1, int accumulate, float* __restrict__ copy0,
+                                                      float* __restrict__ copy1) {
     double s, q;
     if (!finalize_pair(partials, nblk, c, s, q)) return;
     const int col = blockIdx.x * 16 + (threadIdx.x & 15);
     if (out0) out0[col] = accumulate ? out0[col] + (float)s : (float)s;
     if (out1) out1[col] = accumulate ? out1[col] + (float)q : (float)q;
+    if (copy0) copy0[col] = (float)s;  // second destination (dbeta / dgamma of the caller) instead of two memcpy launches
+    if (copy1) copy1[col] = (float)q;
 }
 
 __global__ void k_bn_fold(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
@@ -219,11 +222,9 @@ extern "C" int dgnn_bn_relu_bwd(const float* x, int64_t ldx, const float* y, int
     double* P = as_f64(scratch);
     float* sums = reinterpret_cast<float*>(P + (int64_t)nblk * 2 * c);
     hipLaunchKernelGGL((k_colreduce<1>), dim3(nblk), dim3(256), 0, stream, x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, rpb, P);
-    hipLaunchKernelGGL(k_sum_finalize, dim3((c + 15) / 16), dim3(256), 0, stream, P, nblk, c, sums, sums + c, 0);
+    hipLaunchKernelGGL(k_sum_finalize, dim3((c + 15) / 16), dim3(256), 0, stream, P, nblk, c, sums, sums + c, 0, dbeta, dgamma);
     hipLaunchKernelGGL(k_bn_relu_bwd_apply, dim3(dgnn_grid_cap(dgnn_cdiv(M * c, 256))), dim3(256), 0, stream, x, ldx, y, ldy, dy,
                        lddy, gamma, mean, var, eps, train, relu, M, c, sums, sums + c, dx, lddx);
-    if (dbeta) (void)hipMemcpyAsync(dbeta, sums, sizeof(float) * c, hipMemcpyDeviceToDevice, stream);
-    if (dgamma) (void)hipMemcpyAsync(dgamma, sums + c, sizeof(float) * c, hipMemcpyDeviceToDevice, stream);
     return dgnn_check_launch("bn_relu_bwd");
 }
 
@@ -236,6 +237,7 @@ extern "C" int dgnn_colsum(const float* x, int64_t ldx, int64_t M, int c, float*
     double* P = as_f64(scratch);
     hipLaunchKernelGGL((k_colreduce<2>), dim3(nblk), dim3(256), 0, stream, x, ldx, nullptr, (int64_t)0, nullptr, (int64_t)0, nullptr,
                        nullptr, 0.f, 0, M, c, rpb, P);
-    hipLaunchKernelGGL(k_sum_finalize, dim3((c + 15) / 16), dim3(256), 0, stream, P, nblk, c, out, nullptr, accumulate);
+    hipLaunchKernelGGL(k_sum_finalize, dim3((c + 15) / 16), dim3(256), 0, stream, P, nblk, c, out, (float*)nullptr, accumulate,
+                       (float*)nullptr, (float*)nullptr);
     return dgnn_check_launch("colsum");
 }
