@@ -687,3 +687,34 @@ def test_npz_ingest_matches_reference_loader_and_feeds_inference():
         want = oracle_static().inference_layer(Config(x=torch.from_numpy(g["features"]), edge_attr=torch.from_numpy(g["edge_features"]),
                                                       edge_index=torch.from_numpy(g["edge_lists"])))
     assert (logits.cpu() - want).abs().max().item() <= TOL_LOGIT * max(1.0, want.abs().max().item())
+
+
+def test_integration_md_ctypes_stub_runs_and_matches_the_oracle():
+    """The ctypes stub printed in INTEGRATION.md (what a reference maintainer would paste into SAGEConv) is executed as
+    is -- only the library path is made absolute -- and must reproduce the oracle's SAGEConv.forward on a bipartite block."""
+    import re
+    from types import SimpleNamespace
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", md, flags=re.S)
+    code = next(b for b in blocks if "def forward(self, x, edge_attr, edge_index" in b)
+    code = code.replace('"dgnn_amd/libdgnn_hip.so"', repr(os.path.join(root, "dgnn_amd", "libdgnn_hip.so")))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    onet = oracle_static()
+    conv = onet.convs[1][0]  # 64 -> 128
+    g = torch.Generator().manual_seed(9)
+    n_src, n_dst, E = 900, 500, 2600
+    ei = torch.stack([torch.randint(0, n_src, (E,), generator=g), torch.randint(0, n_dst, (E,), generator=g)])
+    x = torch.randn(n_src, 64, generator=g)
+    ea = torch.randn(E, 20, generator=g)
+    with torch.no_grad():
+        ref = conv((x, x[:n_dst]), ea, ei)
+    dev_conv = SimpleNamespace(lin_e=SimpleNamespace(weight=conv.lin_e.weight.detach().to(DEV), bias=conv.lin_e.bias.detach().to(DEV)),
+                               lin_j=SimpleNamespace(weight=conv.lin_j.weight.detach().to(DEV), bias=conv.lin_j.bias.detach().to(DEV),
+                                                     out_features=conv.lin_j.out_features),
+                               lin_i=SimpleNamespace(weight=conv.lin_i.weight.detach().to(DEV)))
+    xd = x.to(DEV)
+    out = ns["forward"](dev_conv, (xd, xd[:n_dst]), ea.to(DEV), ei.to(DEV))
+    torch.cuda.synchronize()
+    assert rel_err(out, ref.double()) < 3e-6
