@@ -232,9 +232,25 @@ class SurfaceNet(nn.Module):
                     ea, eid = xe, plan.eid
                 else:
                     ea, eid = (plan.sorted_edge_attr(xe) if sorted_attr else xe), None
-                x = ops.sage_layer_fused_fwd(rowptr, plan.src, n, x, ea, le.weight, le.bias, conv.lin_j.weight,
-                                             conv.lin_j.bias, conv.lin_i.weight, scale, shift, True, out=out_v, eid=eid,
-                                             x_dst=x_dst if b else None)
+                # the kernels address rows with 32-bit element offsets relative to x_dst: beyond 2^31 elements per launch
+                # (16.7M cells at 128 channels) the destinations are processed as consecutive sub-ranges
+                if x.size(0) * x.stride(0) >= (1 << 32):
+                    raise ops.DgnnError("fused layer: source rows beyond 2^32 elements (%d x %d); partition the scene "
+                                        "(dgnn_amd.partition)" % (x.size(0), x.stride(0)))
+                chunk = max(1, (ops.FUSED_MAX_ELEMS - 1) // max(x.stride(0), 1))
+                if n <= chunk:
+                    x = ops.sage_layer_fused_fwd(rowptr, plan.src, n, x, ea, le.weight, le.bias, conv.lin_j.weight,
+                                                 conv.lin_j.bias, conv.lin_i.weight, scale, shift, True, out=out_v, eid=eid,
+                                                 x_dst=x_dst if b else None)
+                else:
+                    if out_v is None:
+                        out_v = torch.empty((n, conv.lin_j.out_features), dtype=torch.float32, device=x.device)
+                    for s0 in range(0, n, chunk):
+                        s1 = min(n, s0 + chunk)
+                        ops.sage_layer_fused_fwd(rowptr[s0:s1 + 1], plan.src, s1 - s0, x, ea, le.weight, le.bias, conv.lin_j.weight,
+                                                 conv.lin_j.bias, conv.lin_i.weight, scale, shift, True, out=out_v[s0:s1], eid=eid,
+                                                 x_dst=x_dst[s0:s1])
+                    x = out_v
                 continue
             if simple:
                 ea = plan.sorted_edge_attr(xe) if sorted_attr else xe

@@ -254,6 +254,8 @@ GEMM_MODE = {"f32": GEMM_F32, "bf16x3": GEMM_BF16X3, "bf16x3f": GEMM_BF16X3_FILT
 EDGE_GATHER_IN_KERNEL = __import__("os").environ.get("DGNN_EDGE_STAGING", "0") != "1"
 
 
+FUSED_MAX_ELEMS = 1 << 31  # row offsets inside one fused-layer launch are 32-bit element counts (tests lower it)
+
 # optional profiling hook (bench.py): called as tok = hook(None, c_in, c_out, n_dst) right before the launch and
 # hook(tok, c_in, c_out, n_dst) right after it, on the launching thread / current stream
 FUSED_LAUNCH_HOOK = None

@@ -718,3 +718,23 @@ def test_integration_md_ctypes_stub_runs_and_matches_the_oracle():
     out = ns["forward"](dev_conv, (xd, xd[:n_dst]), ea.to(DEV), ei.to(DEV))
     torch.cuda.synchronize()
     assert rel_err(out, ref.double()) < 3e-6
+
+
+def test_fused_layers_chunked_over_destination_ranges_are_bit_identical():
+    """Scenes beyond 2^31 activation elements are processed as consecutive destination sub-ranges; forcing the same
+    mechanism on a small graph must not change a single bit (also covers a chunk boundary inside a tile)."""
+    from dgnn_amd import ops
+    from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal
+    net = hip_static()
+    adj, _, _ = delaunay_tet_graph(3000, 8)
+    n = adj.shape[0] // 4
+    data = Config(x=hashed_normal(np.arange(n), 29, seed=1, device=DEV), edge_attr=hashed_normal(np.arange(4 * n), 20, seed=2, device=DEV),
+                  edge_index=torch.from_numpy(adj.T.astype(np.int64)).to(DEV))
+    ref = net.inference_layer(data)
+    old = ops.FUSED_MAX_ELEMS
+    try:
+        ops.FUSED_MAX_ELEMS = 128 * 3001  # ~3000 rows per launch at 128 channels, 6000+ at 64, ...
+        got = net.inference_layer(data)
+    finally:
+        ops.FUSED_MAX_ELEMS = old
+    assert torch.equal(got, ref)
