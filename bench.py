@@ -261,7 +261,8 @@ def main():
         # 64 -> 1.1e5, 128 -> 6.7e4 tets/s on a 256-core box): more threads only add contention
         cores = min(os.cpu_count() or 1, 16)
         v, n_s = cpu_baseline(args.cpu_points, cores)
-        cpu = {"value": round(v, 1), "unit": "tets/s", "cores": cores, "kind": "port",
+        v1, _ = cpu_baseline(args.cpu_points, 1)
+        cpu = {"value": round(v, 1), "unit": "tets/s", "cores": cores, "single_thread_value": round(v1, 1), "kind": "port",
                "sample": "oracle (PyTorch-CPU restatement of inference_layer), same generator at %d points -> %d tets, "
                          "1 warm-up + median of 3" % (args.cpu_points, n_s)}
 
