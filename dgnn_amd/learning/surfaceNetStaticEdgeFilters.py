@@ -288,14 +288,17 @@ class SurfaceNet(nn.Module):
             x = ops.gather_rows(x_all, n_id.to(torch.int32))
             for i in range(self.num_layers):
                 edge_index, e_id, size = adjs[i]
-                plan = plan_for(edge_index.to(dev), size[0], size[1], cache=False, hint=ops.PLAN_HINT_GROUPED)
+                # blocks from dgnn_amd.sampler come with their plan registered (a cache hit); any other producer's
+                # block is sorted here.  The fused layer then reads the block's edge rows through the plan's eid.
+                plan = plan_for(edge_index.to(dev), size[0], size[1], hint=ops.PLAN_HINT_GROUPED)
                 ea = ops.gather_rows(xe_all, e_id.to(dev).to(torch.int32))
-                x = self._eval_layers_one(i, x, ea, plan)
+                x = self._eval_layers(x, plan.n_dst, ea, [plan] * self.num_layers, True, only=i)
             x = self._eval_decoder(x)
             ops.scatter_rows_(x_out, n_id[:batch_size], x)
         return x_out
 
     def _eval_layers_one(self, i, x, ea, plan):
+        """Layer i as the unfused aggregate + GEMM pair (any width; the row-level tests use it as the reference path)."""
         layer = self.convs[i]
         conv = layer[0]
         norm = layer[1] if isinstance(layer[1], BatchNorm) else None
@@ -320,8 +323,8 @@ class SurfaceNet(nn.Module):
             for batch_size, n_id, adj in batch_loader:
                 edge_index, e_id, size = adj
                 x = ops.gather_rows(x_all, n_id.to(dev).to(torch.int32))
-                plan = plan_for(edge_index.to(dev), size[0], size[1], cache=False, hint=ops.PLAN_HINT_GROUPED)
+                plan = plan_for(edge_index.to(dev), size[0], size[1], hint=ops.PLAN_HINT_GROUPED)
                 ea = ops.gather_rows(xe_all, e_id.to(dev).to(torch.int32))
-                xs.append(self._eval_layers_one(i, x, ea, plan))  # activations stay in HBM (no host round trip)
+                xs.append(self._eval_layers(x, plan.n_dst, ea, [plan] * self.num_layers, True, only=i))  # stays in HBM
             x_all = torch.cat(xs, dim=0)
         return self._eval_decoder(x_all)
