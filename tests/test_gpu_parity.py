@@ -738,3 +738,21 @@ def test_fused_layers_chunked_over_destination_ranges_are_bit_identical():
     finally:
         ops.FUSED_MAX_ELEMS = old
     assert torch.equal(got, ref)
+
+
+def test_bn_fold_cache_follows_parameter_updates():
+    """The cached BatchNorm(eval) scale/shift must be rebuilt when the statistics or affine parameters change
+    (load_state_dict, an optimizer step, train-mode running statistics)."""
+    g = gold("static_f2_regular256.npz")
+    net = hip_static()
+    data = Config(x=torch.from_numpy(g["x"]).to(DEV), edge_attr=torch.from_numpy(g["edge_attr"]).to(DEV),
+                  edge_index=torch.from_numpy(g["adjacencies"].T.astype(np.int64)).to(DEV))
+    a = net.inference_layer(data)
+    assert np.abs(a.cpu().numpy() - g["logits"]).max() <= TOL_LOGIT
+    with torch.no_grad():
+        net.convs[1][1].module.running_mean.add_(0.5)      # in-place update bumps the tensor's version
+    b = net.inference_layer(data)
+    assert (a - b).abs().max().item() > 1e-3                 # the stale fold would have returned `a` again
+    net.load_state_dict(kf96_state_dict())
+    c = net.inference_layer(data)
+    assert torch.equal(a, c)
