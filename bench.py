@@ -245,7 +245,7 @@ def main():
         # gfx950 note + WRITE_SIZE); scaled by tets when the bench graph differs from the profiled one
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01e_final_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01f_final_traffic.json")))
             traffic = round(tj["traffic_bytes_per_launch"] * n_local / 1010078)
         except Exception:
             pass
