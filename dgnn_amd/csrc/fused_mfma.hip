@@ -1,8 +1,8 @@
 // Fused SAGE inference layer, "all matrix core" variant (gemm_mode DGNN_GEMM_BF16X3_FILTER):
 // the filter MLP phi = We.A + be runs on v_mfma_f32_16x16x32_bf16 as well, not on the VALU.
 //
-// Why: MFMA and VALU work serialise on a SIMD (fused.hip header), and in the split-bf16 variant the 20-tap
-// filter is ~70 % of the remaining VALU instructions.  As a matrix product it is tiny and cheap:
+// Why: MFMA and fp32 VALU work largely serialise on a SIMD (fused.hip header; profiles/r01_ubench_valu_kinds.txt has the
+// per-instruction-kind picture), and in the split-bf16 variant the 20-tap filter is ~70 % of the remaining VALU instructions.  As a matrix product it is tiny and cheap:
 //     PHI[16 edges x 16 channels] = A[16 edges x 32] . B[32 x 16 channels]
 // with A = the wave's 16 edge-attribute rows (k < 20 attributes, k = 20 the constant 1 that carries the bias,
 // rest 0) and B = We^T | be.  Both are split exactly into 3 bf16 parts and the 6 partial products of weight
@@ -18,7 +18,9 @@
 //
 // Everything else is fused.hip's uniform two-phase loop: loads of tile t+1 (neighbour rows, own rows,
 // LDS-DMA of the attribute block) are issued before the single per-tile barrier and land under the matrix
-// phase; the dense part is the K-split 32x32x16 split-bf16 product with the delayed epilogue.
+// phase; the dense part is the 32x32x16 split-bf16 product -- K split between wave pairs with a delayed epilogue at
+// C_in = 128 (8 waves), full K per wave and an immediate epilogue for C_in <= 64 (4 waves, two workgroups per CU; Cfg2).
+// Edge attributes are read in the caller's order through the plan's eid (per-lane DMA addresses) when eid is given.
 #include "fused_common.h"
 
 #ifndef DGNN_SMALL_NW
