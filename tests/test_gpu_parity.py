@@ -451,21 +451,22 @@ def _two_rank_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_partitioned_scene_two_processes_overlapped_exchange(tmp_path):
-    """PartitionedScene.inference_layer end to end in two processes (interior launch || exchange on a side stream,
+@pytest.mark.parametrize("world", [2, 4])
+def test_partitioned_scene_two_processes_overlapped_exchange(world, tmp_path):
+    """PartitionedScene.inference_layer end to end in several processes (interior launch || exchange on a side stream,
     boundary launch after the wait), union of the ranks' logits == whole-graph inference_layer, bit for bit."""
     import socket
     import torch.multiprocessing as mp
     from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal
     s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
-    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_two_rank_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     adj, _, _ = delaunay_tet_graph(6000, 5)
     n = adj.shape[0] // 4
     data = Config(x=hashed_normal(np.arange(n), 29, seed=1, device=DEV), edge_attr=hashed_normal(np.arange(4 * n), 20, seed=2, device=DEV),
                   edge_index=torch.from_numpy(adj.T.astype(np.int64)).to(DEV))
     ref = hip_static().inference_layer(data).cpu().numpy()
     got = np.full_like(ref, np.nan)
-    for r in range(2):
+    for r in range(world):
         d = np.load(os.path.join(str(tmp_path), "r%d.npz" % r))
         got[d["gid"]] = d["logits"]
     assert np.array_equal(got, ref)
