@@ -243,16 +243,18 @@ def main():
         achieved = algo / (dom_ms * 1e-3) / 1e9
         # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
         # gfx950 note + WRITE_SIZE); scaled by tets when the bench graph differs from the profiled one
-        traffic = None
+        traffic, pmc = None, {}
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01f_final_traffic.json")))
             traffic = round(tj["traffic_bytes_per_launch"] * n_local / 1010078)
+            pmc = {k: tj[k] for k in ("mfma_busy_frac", "valu_busy_frac", "tcc_hit_rate", "clock_ghz") if k in tj}
         except Exception:
             pass
         roof = {"bound": "hbm", "kernel": dom_name + " (layers 2 and 3)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(dom_ms, 4),
                 "timing": "HIP events around each launch inside the timed steps (%d launches)" % len(dom_events),
+                "pmc": dict(pmc, source="profiles/r01f_final.md (rocprofv3 --pmc passes of this command)"),
                 "whole_path_frac": round(value * BYTES_PER_TET / 1e9 / HBM_PEAK_GBS / world, 4)}
 
     cpu = None

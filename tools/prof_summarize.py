@@ -69,6 +69,8 @@ if fetch and write:
             % (fetch, write),
             "  = %.3f GB against %.3f GB algorithmic (1360 B/tet) -> %.2fx\n" % (traffic / 1e9, algo / 1e9, traffic / algo)]
     json.dump({"kernel": DOM, "traffic_bytes_per_launch": traffic, "fetch_kib": fetch, "write_kib": write,
+               "mfma_busy_frac": round(busy / 1024 / cyc, 4), "valu_busy_frac": round(valu * 4 / 1024 / cyc, 4),
+               "tcc_hit_rate": round(hit / (hit + miss), 4), "clock_ghz": round(clk, 3),
                "source": "profiles/%s.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH doubled per the guide)" % name},
               open(os.path.join(ROOT, "profiles", name + "_traffic.json"), "w"))
 open(os.path.join(ROOT, "profiles", name + ".md"), "w").write("\n".join(out))
