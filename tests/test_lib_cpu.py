@@ -57,3 +57,22 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 s = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", s, flags=re.M), f
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/dgnn_hip.h is a C header (no C++/torch types) and the library links from a plain C program."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "t.c"
+    src.write_text('#include "dgnn_hip.h"\n#include <stdio.h>\n'
+                   'int main(void) { printf("%d %s\\n", dgnn_version(), dgnn_last_error_string());\n'
+                   '  return dgnn_plan_scratch_elems(16, 4) >= 20 ? 0 : 1; }\n')
+    exe = tmp_path / "t"
+    libdir = os.path.join(root, "dgnn_amd")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-ldgnn_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert int(out[0]) >= 1 and out[1] == "ok"
