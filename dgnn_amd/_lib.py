@@ -19,7 +19,8 @@ SIGNATURES = {
     "dgnn_version": (i32, []),
     "dgnn_last_error_string": (C.c_char_p, []),
     "dgnn_plan_scratch_elems": (i64, [i64, i64]),
-    "dgnn_plan_build": (i32, [vp, i64, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp]),
+    "dgnn_poll_async_error": (i32, []),
+    "dgnn_plan_build": (i32, [vp, i64, i64, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp]),
     "dgnn_gather_rows_f32": (i32, [vp, i64, vp, i64, i32, vp, i64, vp]),
     "dgnn_scatter_rows_f32": (i32, [vp, i64, vp, i64, i32, vp, i64, vp]),
     "dgnn_relu": (i32, [vp, i64, vp, vp]),
@@ -78,6 +79,10 @@ def lib():
 
 
 def check(code: int, what: str = ""):
+    if code == 0:
+        code = lib().dgnn_poll_async_error()  # an earlier kernel met an out-of-range index (a host memory read, no sync)
+        if code != 0:
+            what = "an earlier dgnn kernel (reported at %s)" % (what or "this call")
     if code != 0:
         msg = lib().dgnn_last_error_string().decode()
         raise DgnnError("%s failed (%d): %s" % (what or "dgnn call", code, msg))
@@ -89,6 +94,41 @@ def ptr(t):
 
 
 def stream_ptr():
+    """torch's current stream of the CURRENT device; callers launch under `on_device_of` so that this is the device
+    the tensors live on (the reference addresses its GPU as "cuda:<n>" and never calls set_device: run.py:98,127)."""
     import torch
 
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def on_device_of(fn):
+    """Decorator for functions that launch kernels: runs `fn` with the device of its first GPU tensor argument current,
+    so kernels, torch's stream and every allocation inside agree on the device even when it is not device 0 / not the
+    thread's current device.  Tensors on different GPUs in one call raise."""
+    import functools
+
+    import torch
+
+    def _tensors(a, k):
+        for t in a:
+            if isinstance(t, torch.Tensor):
+                yield t
+        for t in k.values():
+            if isinstance(t, torch.Tensor):
+                yield t
+
+    @functools.wraps(fn)
+    def wrapper(*a, **k):
+        dev = None
+        for t in _tensors(a, k):
+            if t.is_cuda:
+                if dev is None:
+                    dev = t.device
+                elif t.device != dev:
+                    raise DgnnError("%s: tensors on different devices (%s, %s)" % (fn.__name__, dev, t.device))
+        if dev is not None and dev.index != torch.cuda.current_device():
+            with torch.cuda.device(dev):
+                return fn(*a, **k)
+        return fn(*a, **k)
+
+    return wrapper

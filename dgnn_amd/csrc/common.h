@@ -31,6 +31,32 @@ static inline int dgnn_check_launch(const char* what) {
     return DGNN_OK;
 }
 
+// Raises a kernel's dynamic-LDS limit once PER DEVICE (the attribute belongs to the device's code object: a process that
+// addresses its GPU as cuda:<n> with n != 0, as the reference does, would otherwise run device n with the default 64 KB cap).
+#define DGNN_MAX_DEVICES 64
+static inline void dgnn_allow_dynamic_lds(const void* kernel, size_t bytes, bool (&done)[DGNN_MAX_DEVICES]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DGNN_MAX_DEVICES) {
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        return;
+    }
+    if (!done[dev]) {
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        done[dev] = true;
+    }
+}
+
+// Asynchronous device-side error word (pinned host memory mapped into every GPU).  Kernels that meet data no launch-time
+// check can see -- an edge_index entry outside [0, n) -- stay memory-safe (the edge is skipped) and OR a DGNN_ASYNC_* bit
+// into it; dgnn_poll_async_error() (called by the Python binding after every entry point, and by anyone after a stream
+// sync) turns it into DGNN_E_INDEX.  Like HIP's own asynchronous errors it surfaces at a later call, not at the launch.
+#define DGNN_ASYNC_KEY_RANGE 1   /* plan_build: sort-key endpoint outside [0, n_key) */
+#define DGNN_ASYNC_OTHER_RANGE 2 /* plan_build: other endpoint outside [0, n_other) */
+int32_t* dgnn_async_flag_dev();  // device-visible pointer, NULL if pinned memory is unavailable (then errors are only skipped)
+__device__ __forceinline__ void dgnn_raise_async(int32_t* flag, int32_t bits) {
+    if (flag) atomicOr(flag, bits);
+}
+
 static inline int64_t dgnn_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // MI355X: 256 CUs in 8 XCDs.  Grid-stride kernels cap their grid at 8 blocks per CU.

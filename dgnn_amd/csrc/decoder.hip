@@ -260,12 +260,8 @@ extern "C" int dgnn_decoder_fused_fwd(const float* y, int64_t ldy, int64_t M, in
     if (vec) {
         constexpr int K = 128, LDH = HID + 4;
         const size_t smem = 3 * 2 * (K / 16) * 64 * 16 + 2 * HID * 4 + 8 * 32 * LDH * 4;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_rows<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)smem);
-            attr_set = true;
-        }
+        static bool attr_set[DGNN_MAX_DEVICES] = {};
+        dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_decoder_rows<128>), smem, attr_set);
         const int64_t nt = dgnn_cdiv(M, 32);
         const int grid = (int)(dgnn_cdiv(nt, 8) < DGNN_NUM_CU ? dgnn_cdiv(nt, 8) : DGNN_NUM_CU);
         hipLaunchKernelGGL((k_decoder_rows<128>), dim3(grid), dim3(512), smem, (hipStream_t)stream, y, ldy, M, W0, b0, scale, shift,

@@ -478,12 +478,8 @@ int launch_fused(const int32_t* rowptr, const int32_t* src, const int32_t* eid, 
     using C = FusedCfg<CIN_PAD, COUT, MODE>;
     const int64_t ntiles = dgnn_cdiv(n_dst, C::TILE);
     const size_t smem = sizeof(float) * C::SMEM_FLOATS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sage_fused<CIN_PAD, COUT, MODE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    static bool attr_set[DGNN_MAX_DEVICES] = {};
+    dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused<CIN_PAD, COUT, MODE>), smem, attr_set);
     int grid = (int)(ntiles < DGNN_NUM_CU ? ntiles : DGNN_NUM_CU);
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL((k_sage_fused<CIN_PAD, COUT, MODE>), dim3(grid), dim3(512), smem, stream, rowptr, src, eid, n_dst, x, xdst, ldx, c_in,

@@ -470,12 +470,8 @@ int launch2(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64
     using C = Cfg2<CIN_PAD, COUT, NW, KS>;
     const int64_t ntiles = dgnn_cdiv(n_dst, C::TILE);
     const size_t smem = C::SMEM_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sage_fused_mfma<CIN_PAD, COUT, NW, KS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    static bool attr_set[DGNN_MAX_DEVICES] = {};
+    dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_mfma<CIN_PAD, COUT, NW, KS>), smem, attr_set);
     const int wg_max = DGNN_NUM_CU * (NW == 8 ? 1 : 2);
     int grid = (int)(ntiles < wg_max ? ntiles : wg_max);
     if (grid < 1) grid = 1;

@@ -23,6 +23,37 @@ void dgnn_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* dgnn_last_error_string(void) { return g_err; }
+
+static int32_t* g_async_host = nullptr;
+static int32_t* g_async_dev = nullptr;
+int32_t* dgnn_async_flag_dev() {
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        void* h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess && h) {
+            *reinterpret_cast<volatile int32_t*>(h) = 0;
+            void* d = nullptr;
+            if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) {
+                g_async_host = reinterpret_cast<int32_t*>(h);
+                g_async_dev = reinterpret_cast<int32_t*>(d);
+            } else {
+                (void)hipHostFree(h);
+            }
+        }
+        (void)hipGetLastError();
+    }
+    return g_async_dev;
+}
+extern "C" int dgnn_poll_async_error(void) {
+    if (!g_async_host) return DGNN_OK;
+    const int32_t bits = __atomic_exchange_n(g_async_host, 0, __ATOMIC_ACQ_REL);
+    if (bits == 0) return DGNN_OK;
+    dgnn_set_error("asynchronous kernel error 0x%x:%s%s (edges with such endpoints were skipped; the reference's scatter raises an "
+                   "index error for them)", bits, (bits & DGNN_ASYNC_KEY_RANGE) ? " edge_index sort-key endpoint out of range;" : "",
+                   (bits & DGNN_ASYNC_OTHER_RANGE) ? " edge_index other endpoint out of range;" : "");
+    return DGNN_E_INDEX;
+}
 extern "C" int dgnn_version(void) { return DGNN_VERSION; }
 
 namespace {
@@ -46,11 +77,18 @@ __global__ void k_zero_i32(int32_t* p, int64_t n) {
 // need[0] = 1: the "already grouped by key" pass failed; need[1] = 1: the "reference layout" pass failed or was not tried.
 __device__ __forceinline__ bool plan_skip(const int32_t* need) { return need != nullptr && (need[0] == 0 || need[1] == 0); }
 
-__global__ void k_plan_count(const int64_t* __restrict__ key, int64_t sc, int64_t E, int32_t* __restrict__ deg,
-                             const int32_t* __restrict__ need) {
+// An edge whose key is outside [0, n_key) is left out of the plan (count and fill agree on that) and reported through the
+// asynchronous error word: torch's scatter raises an index error there, silently corrupting scratch memory is not an option.
+__global__ void k_plan_count(const int64_t* __restrict__ key, int64_t sc, int64_t E, int64_t n_key, int32_t* __restrict__ deg,
+                             const int32_t* __restrict__ need, int32_t* __restrict__ aflag) {
     if (plan_skip(need)) return;
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x)
-        atomicAdd(&deg[key[e * sc]], 1);
+    bool bad = false;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = key[e * sc];
+        if (k < 0 || k >= n_key) { bad = true; continue; }
+        atomicAdd(&deg[k], 1);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) dgnn_raise_async(aflag, DGNN_ASYNC_KEY_RANGE);
 }
 
 // block-local exclusive scan of SCAN_TILE items; block total -> sums[blockIdx.x]
@@ -130,14 +168,27 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_add(int32_t* __restrict__
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = sums[nb];
 }
 
-__global__ void k_plan_fill(const int64_t* __restrict__ key, int64_t sc, int64_t E, const int32_t* __restrict__ rowptr,
+__global__ void k_plan_fill(const int64_t* __restrict__ key, int64_t sc, int64_t E, int64_t n_key, const int32_t* __restrict__ rowptr,
                             int32_t* __restrict__ deg, int32_t* __restrict__ tmp, const int32_t* __restrict__ need) {
     if (plan_skip(need)) return;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t d = key[e * sc];
+        if (d < 0 || d >= n_key) continue;  // reported by k_plan_count
         const int32_t slot = rowptr[d] + atomicSub(&deg[d], 1) - 1;
         tmp[slot] = (int32_t)e;
     }
+}
+
+// other endpoint of sorted edge `pos`, range-checked against n_other (0 = unknown, unchecked): a bad id becomes 0 (memory-safe)
+// and is reported through the asynchronous error word
+__device__ __forceinline__ int32_t checked_other(const int64_t* __restrict__ other_row, int64_t pos, int64_t sc, int64_t n_other,
+                                                 int32_t* aflag) {
+    int64_t v = other_row[pos * sc];
+    if (n_other > 0 && (v < 0 || v >= n_other)) {
+        dgnn_raise_async(aflag, DGNN_ASYNC_OTHER_RANGE);
+        v = 0;
+    }
+    return (int32_t)v;
 }
 
 __device__ __forceinline__ void cswap(int32_t& a, int32_t& b) {
@@ -151,7 +202,7 @@ __device__ __forceinline__ void cswap(int32_t& a, int32_t& b) {
 __global__ void k_plan_emit(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ tmp,
                             const int64_t* __restrict__ other_row, int64_t sc, int64_t n_key, int32_t* __restrict__ eid,
                             int32_t* __restrict__ other, int32_t* __restrict__ big_count,
-                            int32_t* __restrict__ big_list, const int32_t* __restrict__ need) {
+                            int32_t* __restrict__ big_list, const int32_t* __restrict__ need, int64_t n_other, int32_t* aflag) {
     if (plan_skip(need)) return;
     for (int64_t d = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; d < n_key; d += (int64_t)gridDim.x * blockDim.x) {
         const int32_t beg = rowptr[d], n = rowptr[d + 1] - beg;
@@ -159,10 +210,10 @@ __global__ void k_plan_emit(const int32_t* __restrict__ rowptr, const int32_t* _
             int32_t v0 = n > 0 ? tmp[beg] : INT32_MAX, v1 = n > 1 ? tmp[beg + 1] : INT32_MAX;
             int32_t v2 = n > 2 ? tmp[beg + 2] : INT32_MAX, v3 = n > 3 ? tmp[beg + 3] : INT32_MAX;
             cswap(v0, v1); cswap(v2, v3); cswap(v0, v2); cswap(v1, v3); cswap(v1, v2);
-            if (n > 0) { eid[beg] = v0; other[beg] = (int32_t)other_row[(int64_t)v0 * sc]; }
-            if (n > 1) { eid[beg + 1] = v1; other[beg + 1] = (int32_t)other_row[(int64_t)v1 * sc]; }
-            if (n > 2) { eid[beg + 2] = v2; other[beg + 2] = (int32_t)other_row[(int64_t)v2 * sc]; }
-            if (n > 3) { eid[beg + 3] = v3; other[beg + 3] = (int32_t)other_row[(int64_t)v3 * sc]; }
+            if (n > 0) { eid[beg] = v0; other[beg] = checked_other(other_row, v0, sc, n_other, aflag); }
+            if (n > 1) { eid[beg + 1] = v1; other[beg + 1] = checked_other(other_row, v1, sc, n_other, aflag); }
+            if (n > 2) { eid[beg + 2] = v2; other[beg + 2] = checked_other(other_row, v2, sc, n_other, aflag); }
+            if (n > 3) { eid[beg + 3] = v3; other[beg + 3] = checked_other(other_row, v3, sc, n_other, aflag); }
         } else if (n <= 32) {
             int32_t v[32];
             for (int i = 0; i < n; ++i) {
@@ -171,7 +222,7 @@ __global__ void k_plan_emit(const int32_t* __restrict__ rowptr, const int32_t* _
                 while (j > 0 && v[j - 1] > x) { v[j] = v[j - 1]; --j; }
                 v[j] = x;
             }
-            for (int i = 0; i < n; ++i) { eid[beg + i] = v[i]; other[beg + i] = (int32_t)other_row[(int64_t)v[i] * sc]; }
+            for (int i = 0; i < n; ++i) { eid[beg + i] = v[i]; other[beg + i] = checked_other(other_row, v[i], sc, n_other, aflag); }
         } else {
             big_list[atomicAdd(big_count, 1)] = (int32_t)d;
         }
@@ -200,12 +251,12 @@ __global__ void __launch_bounds__(256) k_plan_sorted_check(const int64_t* __rest
 __global__ void __launch_bounds__(256) k_plan_sorted(const int64_t* __restrict__ key, const int64_t* __restrict__ oth, int64_t sc,
                                                      int64_t E, int64_t n_key, int32_t* __restrict__ rowptr,
                                                      int32_t* __restrict__ other, int32_t* __restrict__ eid,
-                                                     const int32_t* __restrict__ need) {
+                                                     const int32_t* __restrict__ need, int64_t n_other, int32_t* aflag) {
     if (need[0] != 0) return;
     for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < E; k += (int64_t)gridDim.x * blockDim.x) {
         const int64_t kk = key[k * sc], kp = k > 0 ? key[(k - 1) * sc] : -1;
         eid[k] = (int32_t)k;
-        other[k] = (int32_t)oth[k * sc];
+        other[k] = checked_other(oth, k, sc, n_other, aflag);
         for (int64_t d = kp + 1; d <= kk; ++d) rowptr[d] = (int32_t)k;
         if (k == E - 1)
             for (int64_t d = kk + 1; d <= n_key; ++d) rowptr[d] = (int32_t)E;
@@ -272,7 +323,8 @@ __global__ void __launch_bounds__(256) k_plan_emit_big(const int32_t* __restrict
                                                        const int64_t* __restrict__ other_row, int64_t sc,
                                                        int32_t* __restrict__ eid, int32_t* __restrict__ other,
                                                        const int32_t* __restrict__ big_count,
-                                                       const int32_t* __restrict__ big_list, const int32_t* __restrict__ need) {
+                                                       const int32_t* __restrict__ big_list, const int32_t* __restrict__ need,
+                                                       int64_t n_other, int32_t* aflag) {
     if (plan_skip(need)) return;
     const int nbig = *big_count;
     for (int b = blockIdx.x; b < nbig; b += gridDim.x) {
@@ -283,7 +335,7 @@ __global__ void __launch_bounds__(256) k_plan_emit_big(const int32_t* __restrict
             int32_t rank = 0;
             for (int j = 0; j < n; ++j) rank += tmp[beg + j] < x;
             eid[beg + rank] = x;
-            other[beg + rank] = (int32_t)other_row[(int64_t)x * sc];
+            other[beg + rank] = checked_other(other_row, x, sc, n_other, aflag);
         }
     }
 }
@@ -348,9 +400,11 @@ extern "C" int64_t dgnn_plan_scratch_elems(int64_t E, int64_t n_key) {
     return n_key + E + (dgnn_cdiv(n_key, SCAN_TILE) + 2) + 1 + (E / 33 + 2) + 2;
 }
 
-extern "C" int dgnn_plan_build(const int64_t* edge_index, int64_t stride_row, int64_t stride_col, int64_t E, int64_t n_key, int by,
-                               int hint, int32_t* rowptr, int32_t* other, int32_t* eid, int32_t* scratch, void* stream_) {
+extern "C" int dgnn_plan_build(const int64_t* edge_index, int64_t stride_row, int64_t stride_col, int64_t E, int64_t n_key,
+                               int64_t n_other, int by, int hint, int32_t* rowptr, int32_t* other, int32_t* eid, int32_t* scratch,
+                               void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    int32_t* const aflag = dgnn_async_flag_dev();
     DGNN_REQUIRE(E >= 0 && n_key >= 0 && (by == 0 || by == 1), DGNN_E_INVALID, "plan_build: bad sizes E=%lld n=%lld by=%d",
                  (long long)E, (long long)n_key, by);
     DGNN_REQUIRE(hint >= DGNN_PLAN_HINT_AUTO && hint <= DGNN_PLAN_HINT_GENERIC, DGNN_E_INVALID, "plan_build: bad hint %d", hint);
@@ -386,7 +440,7 @@ extern "C" int dgnn_plan_build(const int64_t* edge_index, int64_t stride_row, in
     if (try_sorted) {
         const dim3 g(dgnn_grid_cap(dgnn_cdiv(E, 256)));
         hipLaunchKernelGGL(k_plan_sorted_check, g, dim3(256), 0, stream, key, sc, E, n_key, need);
-        hipLaunchKernelGGL(k_plan_sorted, g, dim3(256), 0, stream, key, oth, sc, E, n_key, rowptr, other, eid, need);
+        hipLaunchKernelGGL(k_plan_sorted, g, dim3(256), 0, stream, key, oth, sc, E, n_key, rowptr, other, eid, need, n_other, aflag);
     }
     if (try_regular)
         hipLaunchKernelGGL(k_plan_regular, dim3(dgnn_grid_cap(dgnn_cdiv(n_key, 256))), dim3(256), 0, stream, key, oth, sc, n_key, rowptr,
@@ -396,16 +450,16 @@ extern "C" int dgnn_plan_build(const int64_t* edge_index, int64_t stride_row, in
         cap = 4 * DGNN_NUM_CU;
     }
     auto grid_for = [&](int64_t n) { const int64_t g = dgnn_grid_cap(dgnn_cdiv(n, 256)); return dim3((unsigned)(g < cap ? g : cap)); };
-    if (E > 0) hipLaunchKernelGGL(k_plan_count, grid_for(E), dim3(256), 0, stream, key, sc, E, deg, flag);
+    if (E > 0) hipLaunchKernelGGL(k_plan_count, grid_for(E), dim3(256), 0, stream, key, sc, E, n_key, deg, flag, aflag);
     hipLaunchKernelGGL(k_scan_tile, dim3(nb), dim3(SCAN_THREADS), 0, stream, deg, n_key, rowptr, sums, flag);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums, nb, flag);
     hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_THREADS), 0, stream, rowptr, n_key, sums, nb, flag);
     if (E > 0) {
-        hipLaunchKernelGGL(k_plan_fill, grid_for(E), dim3(256), 0, stream, key, sc, E, rowptr, deg, tmp, flag);
+        hipLaunchKernelGGL(k_plan_fill, grid_for(E), dim3(256), 0, stream, key, sc, E, n_key, rowptr, deg, tmp, flag);
         hipLaunchKernelGGL(k_plan_emit, grid_for(n_key), dim3(256), 0, stream, rowptr, tmp, oth, sc, n_key, eid, other, big_count,
-                           big_list, flag);
+                           big_list, flag, n_other, aflag);
         hipLaunchKernelGGL(k_plan_emit_big, dim3(256), dim3(256), 0, stream, rowptr, tmp, oth, sc, eid, other, big_count, big_list,
-                           flag);
+                           flag, n_other, aflag);
     }
     return dgnn_check_launch("plan_build");
 }

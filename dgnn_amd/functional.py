@@ -20,6 +20,7 @@ class _Aggregate(torch.autograd.Function):
     def forward(ctx, x_src, edge_attr, We, be, plan: GraphPlan):
         a = ops.aggregate_fwd(plan.rowptr, plan.src, plan.eid, plan.n_dst, x_src, edge_attr, We, be)
         ctx.plan = plan
+        ctx.edge_index = plan.edge_index  # the lazily built transposed plan (backward) reads it
         ctx.save_for_backward(x_src, edge_attr, We, be)
         return a
 
@@ -41,6 +42,7 @@ class _AggregatePhi(torch.autograd.Function):
     def forward(ctx, x_src, phi, plan: GraphPlan):
         a = ops.aggregate_fwd(plan.rowptr, plan.src, plan.eid, plan.n_dst, x_src, phi=phi)
         ctx.plan = plan
+        ctx.edge_index = plan.edge_index  # the lazily built transposed plan (backward) reads it
         ctx.save_for_backward(x_src, phi)
         return a
 
@@ -60,6 +62,7 @@ class _AggregatePlain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_src, plan: GraphPlan):
         ctx.plan = plan
+        ctx.edge_index = plan.edge_index  # the lazily built transposed plan (backward) reads it
         ctx.save_for_backward(x_src)
         return ops.aggregate_fwd(plan.rowptr, plan.src, plan.eid, plan.n_dst, x_src)
 

@@ -22,23 +22,37 @@ class GraphPlan:
     def __init__(self, edge_index: torch.Tensor, n_src: int, n_dst: int, hint: int = ops.PLAN_HINT_AUTO, parts=None):
         """`parts` = (rowptr int32 [n_dst+1], src int32 [E], eid int32 [E]) when the producer of the edge list already has
         them (the k-hop block builder emits its blocks grouped by destination: its own row offsets ARE the plan)."""
-        if edge_index.dtype != torch.int64:
+        converted = edge_index.dtype != torch.int64
+        if converted:
             edge_index = edge_index.to(torch.int64)  # inference_layer does the same (:339)
-        self.edge_index = edge_index  # any strides: the plan builder reads the (possibly transposed) view in place
+        # any strides: the plan builder reads the (possibly transposed) view in place.  Held WEAKLY: the transposed plan is
+        # built lazily from it (backward; the autograd nodes keep the tensor alive until then) and the plan itself hangs off
+        # the tensor (plan_for), so a strong reference would be a cycle (a converted int64 copy has no other owner and is kept).
+        self._ei_ref = weakref.ref(edge_index)
+        self._ei_own = edge_index if converted else None
         self.n_src, self.n_dst, self.E = int(n_src), int(n_dst), int(edge_index.size(1))
-        self.rowptr, self.src, self.eid = parts if parts is not None else ops.plan_build(self.edge_index, self.n_dst, by=1, hint=hint)
+        self.rowptr, self.src, self.eid = parts if parts is not None else ops.plan_build(edge_index, self.n_dst, by=1, hint=hint, n_other=self.n_src)
         self._grouped = parts is not None or hint == ops.PLAN_HINT_GROUPED
         self._t = None
         self._sorted_attr = None  # (weakref to edge_attr, version, sorted copy)
+
+    @property
+    def edge_index(self):
+        """The edge list this plan was built from (None once its owner has freed it)."""
+        return self._ei_own if self._ei_own is not None else self._ei_ref()
 
     @property
     def transposed(self):
         """(t_rowptr [n_src+1], t_dst [E], t_eid [E]): out-edges of every source, ascending edge
         position -- the accumulation order of autograd's index_add_ for x.index_select(0, src)."""
         if self._t is None:
+            edge_index = self.edge_index
+            if edge_index is None:
+                raise RuntimeError("GraphPlan.transposed: the edge_index tensor this plan was built from has been freed")
             # an edge list grouped by destination is not grouped by source (unless it is the reference layout): skip the
             # fast-path attempts there
-            self._t = ops.plan_build(self.edge_index, self.n_src, by=0, hint=ops.PLAN_HINT_GENERIC if self._grouped else ops.PLAN_HINT_AUTO)
+            self._t = ops.plan_build(edge_index, self.n_src, by=0, hint=ops.PLAN_HINT_GENERIC if self._grouped else ops.PLAN_HINT_AUTO,
+                                      n_other=self.n_dst)
         return self._t
 
     def sorted_edge_attr(self, edge_attr: torch.Tensor) -> torch.Tensor:
@@ -51,35 +65,40 @@ class GraphPlan:
         return out
 
 
-_cache: dict = {}
+def _key(edge_index: torch.Tensor, n_src: int, n_dst: int):
+    return (int(n_src), int(n_dst), edge_index._version, edge_index.data_ptr(), tuple(edge_index.shape), tuple(edge_index.stride()))
 
 
 def plan_for(edge_index: torch.Tensor, n_src: int, n_dst: int, cache: bool = True, hint: int = ops.PLAN_HINT_AUTO) -> GraphPlan:
-    """Plan lookup keyed on the identity of the edge_index storage (training reuses the same block
-    adjacency for forward and backward; inference reuses it across the 4 layers)."""
+    """Plan lookup.  The plan lives ON the caller's edge_index tensor object (training reuses the same block adjacency for
+    forward and backward; inference reuses it across the 4 layers; a resident scene across calls) and dies with it: there
+    is no global table that could pin rowptr/src/eid -- or a plan-ordered edge_attr copy -- in HBM after the graph is gone.
+    A tensor that arrives on the CPU is copied to the GPU by the model on every call; its plan then lasts one call."""
     if not cache:
         return GraphPlan(edge_index, n_src, n_dst, hint)
-    key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, int(n_src), int(n_dst), str(edge_index.device))
-    hit = _cache.get(key)
-    if hit is not None and hit[0]() is edge_index:
-        return hit[1]
+    key = _key(edge_index, n_src, n_dst)
+    held = getattr(edge_index, "_dgnn_plans", None)
+    if held is not None and key in held:
+        return held[key]
     plan = GraphPlan(edge_index, n_src, n_dst, hint)
-    if len(_cache) > 64:
-        _cache.clear()
-    try:
-        _cache[key] = (weakref.ref(edge_index), plan)
-    except TypeError:
-        pass
+    register_plan(edge_index, plan)
     return plan
 
 
 def register_plan(edge_index: torch.Tensor, plan: GraphPlan) -> None:
     """Makes plan_for(edge_index, n_src, n_dst) return `plan` (used by producers that build the plan with the edge list)."""
-    key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, plan.n_src, plan.n_dst, str(edge_index.device))
-    if len(_cache) > 64:
-        _cache.clear()
-    _cache[key] = (weakref.ref(edge_index), plan)
+    key = _key(edge_index, plan.n_src, plan.n_dst)
+    held = getattr(edge_index, "_dgnn_plans", None)
+    if held is None or any(k[2] != key[2] for k in held):   # first plan, or the tensor was written to since
+        held = {}
+    held[key] = plan
+    try:
+        edge_index._dgnn_plans = held
+    except AttributeError:
+        pass
 
 
-def clear_plan_cache():
-    _cache.clear()
+def clear_plan_cache(edge_index: torch.Tensor = None):
+    """Drops the plans attached to `edge_index` (nothing global exists any more; kept for callers of the old API)."""
+    if edge_index is not None and hasattr(edge_index, "_dgnn_plans"):
+        del edge_index._dgnn_plans

@@ -142,6 +142,10 @@ class SurfaceNet(nn.Module):
             raise RuntimeError("clf.temp.device=%r: dgnn_amd.SurfaceNet runs on a GPU only (no CPU fallback)" % (dev,))
         return dev
 
+    def _input_rows(self, x):
+        """drop column 0 (the loss-weight column) when regularization.cell_type is set, reference :329-332"""
+        return x[:, 1:] if self.clf.regularization.cell_type else x
+
     def _norm_act(self, layer, x):
         """convs[i][1] then convs[i][2] (reference :218-219): BatchNorm (if any) + ReLU, one kernel chain."""
         norm = layer[1] if len(layer) > 1 and isinstance(layer[1], BatchNorm) else None
@@ -215,52 +219,64 @@ class SurfaceNet(nn.Module):
         optionally names the [>= n_dst, C_out] buffer to write into and `rows=(b, e)` restricts the launch to
         the destinations [b, e) (written to out[b:e]; interior / boundary cells of a partition)."""
         for i in (range(self.num_layers) if only is None else [only]):
-            layer, plan = self.convs[i], plans[i]
-            conv = layer[0]
-            norm = layer[1] if isinstance(layer[1], BatchNorm) else None
-            scale, shift = self._fold(norm, conv.lin_j.out_features, x.device)
-            le = conv.lin_e
-            b, e = (0, plan.n_dst) if rows is None else rows
-            n, rowptr = e - b, (plan.rowptr if rows is None else plan.rowptr[b:e + 1])
-            x_dst = x[b:e]
-            out_v = out if (out is None or rows is None) else out[b:e]
-            simple = isinstance(le, Linear) and le.in_features in (2, 20)
-            if simple and le.in_features == 20 and ops.fused_layer_supported(x.size(1), conv.lin_j.out_features, 20):
-                # sorted_attr: xe is in the caller's edge order.  Either the kernel gathers each row by eid (no staging
-                # copy of the edge features), or the rows are staged into plan order once and reused by all layers.
-                if sorted_attr and ops.EDGE_GATHER_IN_KERNEL and xe.stride(0) == 20 and xe.data_ptr() % 16 == 0:
-                    ea, eid = xe, plan.eid
-                else:
-                    ea, eid = (plan.sorted_edge_attr(xe) if sorted_attr else xe), None
-                # the kernels address rows with 32-bit element offsets relative to x_dst: beyond 2^31 elements per launch
-                # (16.7M cells at 128 channels) the destinations are processed as consecutive sub-ranges
-                if x.size(0) * x.stride(0) >= (1 << 32):
-                    raise ops.DgnnError("fused layer: source rows beyond 2^32 elements (%d x %d); partition the scene "
-                                        "(dgnn_amd.partition)" % (x.size(0), x.stride(0)))
-                chunk = max(1, (ops.FUSED_MAX_ELEMS - 1) // max(x.stride(0), 1))
-                if n <= chunk:
-                    x = ops.sage_layer_fused_fwd(rowptr, plan.src, n, x, ea, le.weight, le.bias, conv.lin_j.weight,
-                                                 conv.lin_j.bias, conv.lin_i.weight, scale, shift, True, out=out_v, eid=eid,
-                                                 x_dst=x_dst if b else None)
-                else:
-                    if out_v is None:
-                        out_v = torch.empty((n, conv.lin_j.out_features), dtype=torch.float32, device=x.device)
-                    for s0 in range(0, n, chunk):
-                        s1 = min(n, s0 + chunk)
-                        ops.sage_layer_fused_fwd(rowptr[s0:s1 + 1], plan.src, s1 - s0, x, ea, le.weight, le.bias, conv.lin_j.weight,
-                                                 conv.lin_j.bias, conv.lin_i.weight, scale, shift, True, out=out_v[s0:s1], eid=eid,
-                                                 x_dst=x_dst[s0:s1])
-                    x = out_v
-                continue
-            if simple:
-                ea = plan.sorted_edge_attr(xe) if sorted_attr else xe
-                a = ops.aggregate_fwd(rowptr, plan.src, None, n, x, ea, le.weight, le.bias)
-            else:
-                if rows is not None:
-                    raise NotImplementedError("destination sub-ranges need a Linear edge filter")
-                a = Fn.aggregate(x, plan, **conv._filter_args(xe))
-            x = ops.linear_fwd(a, conv.lin_j.weight, x_dst, conv.lin_i.weight, conv.lin_j.bias, scale, shift, True, out=out_v)
+            hook = ops.LAYER_HOOK
+            conv_i = self.convs[i][0]
+            n_rows = plans[i].n_dst if rows is None else rows[1] - rows[0]
+            tok = hook(None, x.size(1), conv_i.lin_j.out_features, n_rows) if hook is not None else None
+            x = self._eval_layer(i, x, xe, plans[i], sorted_attr, out, rows)
+            if hook is not None:
+                hook(tok, conv_i.lin_i.in_features, conv_i.lin_j.out_features, n_rows)
         return x
+
+    def _eval_layer(self, i, x, xe, plan, sorted_attr, out, rows):
+        """One eval-mode conv layer + BN + ReLU (see _eval_layers)."""
+        layer = self.convs[i]
+        conv = layer[0]
+        norm = layer[1] if isinstance(layer[1], BatchNorm) else None
+        scale, shift = self._fold(norm, conv.lin_j.out_features, x.device)
+        le = conv.lin_e
+        b, e = (0, plan.n_dst) if rows is None else rows
+        n, rowptr = e - b, (plan.rowptr if rows is None else plan.rowptr[b:e + 1])
+        x_dst = x[b:e]
+        out_v = out if (out is None or rows is None) else out[b:e]
+        simple = isinstance(le, Linear) and le.in_features in (2, 20)
+        if simple and le.in_features == 20 and ops.fused_layer_supported(x.size(1), conv.lin_j.out_features, 20, x):
+            # sorted_attr: xe is in the caller's edge order.  Either the kernel gathers each row by eid (no staging
+            # copy of the edge features), or the rows are staged into plan order once and reused by all layers.
+            if sorted_attr and ops.EDGE_GATHER_IN_KERNEL and xe.stride(0) == 20 and xe.data_ptr() % 16 == 0:
+                ea, eid = xe, plan.eid
+            else:
+                ea, eid = (plan.sorted_edge_attr(xe) if sorted_attr else xe), None
+                if ea.stride(0) != 20 or ea.data_ptr() % 16:
+                    ea = ea.contiguous()  # e.g. a [:, 1:] view of 21-column rows (regularization.edge_type)
+            # the kernels address rows with 32-bit element offsets relative to x_dst: beyond 2^31 elements per launch
+            # (16.7M cells at 128 channels) the destinations are processed as consecutive sub-ranges
+            if x.size(0) * x.stride(0) >= (1 << 32):
+                raise ops.DgnnError("fused layer: source rows beyond 2^32 elements (%d x %d); partition the scene "
+                                    "(dgnn_amd.partition)" % (x.size(0), x.stride(0)))
+            chunk = max(1, (ops.FUSED_MAX_ELEMS - 1) // max(x.stride(0), 1))
+            if n <= chunk:
+                x = ops.sage_layer_fused_fwd(rowptr, plan.src, n, x, ea, le.weight, le.bias, conv.lin_j.weight,
+                                             conv.lin_j.bias, conv.lin_i.weight, scale, shift, True, out=out_v, eid=eid,
+                                             x_dst=x_dst if b else None)
+            else:
+                if out_v is None:
+                    out_v = torch.empty((n, conv.lin_j.out_features), dtype=torch.float32, device=x.device)
+                for s0 in range(0, n, chunk):
+                    s1 = min(n, s0 + chunk)
+                    ops.sage_layer_fused_fwd(rowptr[s0:s1 + 1], plan.src, s1 - s0, x, ea, le.weight, le.bias, conv.lin_j.weight,
+                                             conv.lin_j.bias, conv.lin_i.weight, scale, shift, True, out=out_v[s0:s1], eid=eid,
+                                             x_dst=x_dst[s0:s1])
+                x = out_v
+            return x
+        if simple:
+            ea = plan.sorted_edge_attr(xe) if sorted_attr else xe
+            a = ops.aggregate_fwd(rowptr, plan.src, None, n, x, ea, le.weight, le.bias)
+        else:
+            if rows is not None:
+                raise NotImplementedError("destination sub-ranges need a Linear edge filter")
+            a = Fn.aggregate(x, plan, **conv._filter_args(xe))
+        return ops.linear_fwd(a, conv.lin_j.weight, x_dst, conv.lin_i.weight, conv.lin_j.bias, scale, shift, True, out=out_v)
 
     def _eval_decoder(self, x):
         dec = self.decoder

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import torch
 
-from ._lib import DgnnError, check, lib, ptr, stream_ptr
+from ._lib import DgnnError, check, lib, on_device_of, ptr, stream_ptr
 
 
 def _req(t: torch.Tensor, name: str, dtype=torch.float32, dim=None, any_stride=False):
@@ -42,8 +42,10 @@ def _f32(n, device):
 PLAN_HINT_AUTO, PLAN_HINT_GROUPED, PLAN_HINT_REFERENCE, PLAN_HINT_GENERIC = 0, 1, 2, 3
 
 
-def plan_build(edge_index: torch.Tensor, n_key: int, by: int, hint: int = PLAN_HINT_AUTO):
-    """-> (rowptr int32 [n_key+1], other int32 [E], eid int32 [E]); see dgnn_plan_build."""
+@on_device_of
+def plan_build(edge_index: torch.Tensor, n_key: int, by: int, hint: int = PLAN_HINT_AUTO, n_other: int = 0):
+    """-> (rowptr int32 [n_key+1], other int32 [E], eid int32 [E]); see dgnn_plan_build.  `n_other`: node count of the other
+    side for range checking (0 = unchecked)."""
     _req(edge_index, "edge_index", torch.int64, 2, any_stride=True)
     if edge_index.size(0) != 2:
         raise ValueError("edge_index must be an int64 [2,E] tensor (any strides; the transposed [E,2] view is read in place)")
@@ -53,11 +55,12 @@ def plan_build(edge_index: torch.Tensor, n_key: int, by: int, hint: int = PLAN_H
     other = torch.empty(max(E, 1), dtype=torch.int32, device=dev)[:E]
     eid = torch.empty(max(E, 1), dtype=torch.int32, device=dev)[:E]
     scratch = torch.empty(int(lib().dgnn_plan_scratch_elems(E, n_key)), dtype=torch.int32, device=dev)
-    check(lib().dgnn_plan_build(ptr(edge_index), edge_index.stride(0), edge_index.stride(1), E, n_key, by, hint, ptr(rowptr), ptr(other), ptr(eid), ptr(scratch), stream_ptr()),
+    check(lib().dgnn_plan_build(ptr(edge_index), edge_index.stride(0), edge_index.stride(1), E, n_key, int(n_other), by, hint, ptr(rowptr), ptr(other), ptr(eid), ptr(scratch), stream_ptr()),
           "dgnn_plan_build")
     return rowptr, other, eid
 
 
+@on_device_of
 def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     _req(src, "src", dim=2)
     _req(idx, "idx", torch.int32, 1)
@@ -67,6 +70,7 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@on_device_of
 def scatter_rows_(out: torch.Tensor, idx: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
     _req(src, "src", dim=2)
     _req(out, "out", dim=2)
@@ -76,6 +80,7 @@ def scatter_rows_(out: torch.Tensor, idx: torch.Tensor, src: torch.Tensor) -> to
     return out
 
 
+@on_device_of
 def relu(x: torch.Tensor) -> torch.Tensor:
     _req(x, "x")
     x = x.contiguous()
@@ -84,6 +89,7 @@ def relu(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+@on_device_of
 def relu_bwd(y: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
     _req(y, "y")
     _req(g, "g")
@@ -94,6 +100,7 @@ def relu_bwd(y: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
 
 
 # ---- aggregation --------------------------------------------------------------------------------
+@on_device_of
 def aggregate_fwd(rowptr, src, eid, n_dst, x_src, edge_attr=None, We=None, be=None, phi=None, want_phi=False):
     _req(x_src, "x_src", dim=2)
     c_in = x_src.size(1)
@@ -120,6 +127,7 @@ def aggregate_fwd(rowptr, src, eid, n_dst, x_src, edge_attr=None, We=None, be=No
     return (a, phi_out) if want_phi else a
 
 
+@on_device_of
 def aggregate_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, da, edge_attr=None, We=None, be=None, phi=None,
                   need_dx=True):
     """-> (dx_src | None, dWe | None, dbe | None, dphi | None)"""
@@ -149,6 +157,7 @@ def aggregate_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, da, edge_att
 
 
 # ---- dense --------------------------------------------------------------------------------------
+@on_device_of
 def linear_fwd(A1, W1, A2=None, W2=None, bias=None, scale=None, shift=None, relu=False, out=None):
     _req(A1, "A1", dim=2)
     W1 = _req(W1, "W1", dim=2).contiguous()
@@ -171,6 +180,7 @@ def linear_fwd(A1, W1, A2=None, W2=None, bias=None, scale=None, shift=None, relu
     return out
 
 
+@on_device_of
 def linear_wgrad(A, B):
     """dW[n_a,n_b] = A^T . B  (A [M,n_a], B [M,n_b])"""
     _req(A, "A", dim=2)
@@ -185,6 +195,7 @@ def linear_wgrad(A, B):
     return dW
 
 
+@on_device_of
 def colsum(x):
     _req(x, "x", dim=2)
     out = torch.empty(x.size(1), dtype=torch.float32, device=x.device)
@@ -196,6 +207,7 @@ def colsum(x):
 
 
 # ---- batch norm ---------------------------------------------------------------------------------
+@on_device_of
 def bn_fold(gamma, beta, mean, var, eps):
     c = mean.numel()
     scale = torch.empty(c, dtype=torch.float32, device=mean.device)
@@ -205,6 +217,7 @@ def bn_fold(gamma, beta, mean, var, eps):
     return scale, shift
 
 
+@on_device_of
 def bn_batch_stats(x, running_mean=None, running_var=None, momentum=0.1):
     _req(x, "x", dim=2)
     M, c = x.shape
@@ -216,6 +229,7 @@ def bn_batch_stats(x, running_mean=None, running_var=None, momentum=0.1):
     return mean, var
 
 
+@on_device_of
 def scale_shift_act(x, scale, shift, relu):
     _req(x, "x", dim=2)
     y = torch.empty((x.size(0), x.size(1)), dtype=torch.float32, device=x.device)
@@ -224,6 +238,7 @@ def scale_shift_act(x, scale, shift, relu):
     return y
 
 
+@on_device_of
 def bn_relu_bwd(x, y, dy, gamma, mean, var, eps, train, relu):
     _req(x, "x", dim=2)
     _req(dy, "dy", dim=2)
@@ -239,8 +254,20 @@ def bn_relu_bwd(x, y, dy, gamma, mean, var, eps, train, relu):
 
 
 # ---- fused inference layer ----------------------------------------------------------------------
-def fused_layer_supported(c_in: int, c_out: int, f_e: int) -> bool:
-    return f_e == 20 and c_in <= 128 and c_out in (64, 128) and FUSED_ENABLED
+def fused_layer_supported(c_in: int, c_out: int, f_e: int, x: torch.Tensor = None) -> bool:
+    """Mirrors the shape dispatch of dgnn_sage_layer_fused_fwd (csrc/fused.hip): c_in <= 64 -> c_out in {64,128};
+    64 < c_in <= 128 -> c_out == 128 with even c_in / row stride and 8-byte aligned rows.  Everything else takes the
+    aggregate + linear pair."""
+    if not FUSED_ENABLED or f_e != 20:
+        return False
+    if c_in <= 64:
+        return c_out in (64, 128)
+    if c_in <= 128:
+        ok = c_out == 128 and c_in % 2 == 0
+        if x is not None:
+            ok = ok and x.stride(0) % 2 == 0 and x.data_ptr() % 8 == 0
+        return ok
+    return False
 
 
 FUSED_ENABLED = True
@@ -256,11 +283,13 @@ EDGE_GATHER_IN_KERNEL = __import__("os").environ.get("DGNN_EDGE_STAGING", "0") !
 
 FUSED_MAX_ELEMS = 1 << 31  # row offsets inside one fused-layer launch are 32-bit element counts (tests lower it)
 
-# optional profiling hook (bench.py): called as tok = hook(None, c_in, c_out, n_dst) right before the launch and
-# hook(tok, c_in, c_out, n_dst) right after it, on the launching thread / current stream
-FUSED_LAUNCH_HOOK = None
+# optional profiling hook (bench.py): SurfaceNet._eval_layers calls tok = hook(None, c_in, c_out, n_dst) right before the
+# launches of one eval-mode conv layer (fused: one launch; other widths: aggregate + GEMM) and hook(tok, c_in, c_out, n_dst)
+# right after them, on the launching thread / current stream
+LAYER_HOOK = None
 
 
+@on_device_of
 def sage_layer_fused_fwd(rowptr, src, n_dst, x_src, edge_attr, We, be, Wj, bj, Wi, scale, shift, relu, gemm_mode=None,
                          out=None, eid=None, x_dst=None):
     """`x_dst` (optional): own rows of the destinations when they are not x_src[:n_dst] (a destination sub-range).
@@ -276,14 +305,10 @@ def sage_layer_fused_fwd(rowptr, src, n_dst, x_src, edge_attr, We, be, Wj, bj, W
         _req(out, "out", dim=2)
         if out.size(0) < n_dst or out.size(1) != c_out or out.stride(0) != c_out:
             raise ValueError("out must be a contiguous [>= n_dst, c_out] buffer")
-    hook = FUSED_LAUNCH_HOOK
-    tok = hook(None, c_in, c_out, n_dst) if hook is not None else None
     check(lib().dgnn_sage_layer_fused_fwd(
         ptr(rowptr), ptr(src), ptr(eid), n_dst, ptr(x_src), ptr(x_dst), _ld(x_src), c_in, ptr(edge_attr), _ld(edge_attr), We.size(1),
         ptr(We), ptr(be), ptr(Wj), ptr(bj), ptr(Wi), ptr(scale), ptr(shift), int(bool(relu)), c_out, ptr(out), c_out,
         GEMM_MODE if gemm_mode is None else gemm_mode, stream_ptr()), "dgnn_sage_layer_fused_fwd")
-    if hook is not None:
-        hook(tok, c_in, c_out, n_dst)
     return out
 
 
@@ -291,6 +316,7 @@ def decoder_fused_supported(k: int, hidden: int, n_out: int) -> bool:
     return k == 128 and hidden == 64 and n_out in (1, 2)
 
 
+@on_device_of
 def decoder_fused_fwd(y, W0, b0, scale, shift, W3, b3):
     _req(y, "y", dim=2)
     M, n_out = y.size(0), W3.size(0)

@@ -231,16 +231,41 @@ class PartitionedScene:
         self.exchange = HaloExchange(lp, device, pack=ops.gather_rows)
         self._GraphPlan = GraphPlan
         self.plan = None
+        self._xe_stripped = None
 
     @staticmethod
     def build_synthetic(points: int, seed: int, rank: int, world: int, device) -> "PartitionedScene":
-        """Every rank builds the same seeded Delaunay scene, keeps its part and materialises only the
-        feature rows it needs (hashed N(0,1) values, identical across ranks for shared rows)."""
+        """The seeded Delaunay scene of bench.py cut into `world` parts.  Rank 0 runs the tetrahedralisation and the
+        coordinate bisection ONCE and broadcasts the adjacency column and the owner map (two int32 arrays) when a process
+        group exists -- every rank repeating scipy.spatial.Delaunay on the whole scene costs minutes at 10M tets; without
+        a process group (tests, world == 1) the rank builds them itself.  Each rank then derives its own index structures
+        and materialises only the feature rows it needs (hashed N(0,1) values, identical across ranks for shared rows)."""
+        import torch.distributed as dist
         from .synthetic import delaunay_tet_graph, hashed_normal
-        adj, cent, _ = delaunay_tet_graph(points, seed)
-        part = rcb_partition(cent, world)
-        ei = adj.T.astype(np.int64)
+        shared = world > 1 and dist.is_available() and dist.is_initialized()
+        if not shared or rank == 0:
+            adj, cent, _ = delaunay_tet_graph(points, seed)
+            part = rcb_partition(cent, world)
+            dst = np.ascontiguousarray(adj[:, 1], dtype=np.int32)
+            del adj, cent
+        if shared:
+            on_gpu = dist.get_backend() == "nccl"
+            tdev = torch.device(device) if on_gpu else torch.device("cpu")
+            meta = [int(part.shape[0])] if rank == 0 else [None]
+            dist.broadcast_object_list(meta, src=0)
+            n = meta[0]
+            t_dst = torch.from_numpy(dst).to(tdev) if rank == 0 else torch.empty(4 * n, dtype=torch.int32, device=tdev)
+            t_part = torch.from_numpy(part.astype(np.int32)).to(tdev) if rank == 0 else torch.empty(n, dtype=torch.int32, device=tdev)
+            dist.broadcast(t_dst, src=0)
+            dist.broadcast(t_part, src=0)
+            dst, part = t_dst.cpu().numpy(), t_part.cpu().numpy()
+            del t_dst, t_part
+        n = part.shape[0]
+        ei = np.empty((2, 4 * n), dtype=np.int64)
+        ei[0] = np.repeat(np.arange(n, dtype=np.int64), 4)   # the reference layout: row 4t+r = (t, r-th neighbour)
+        ei[1] = dst
         lp = build_local_part(ei, part, rank, world)
+        del ei
         rows = np.concatenate([lp.own_gid, lp.halo_gid])
         x_local = hashed_normal(rows, 29, seed=1, device=device)
         ea_local = hashed_normal(lp.edge_gid, 20, seed=2, device=device)
@@ -254,7 +279,13 @@ class PartitionedScene:
             self.plan = self._GraphPlan(self.edge_index, n_src, self.n_own, hint=1)  # local list is grouped by destination
         plan = self.plan
         x = self.x_local[:, 1:] if net.clf.regularization.cell_type else self.x_local
-        xe = self.edge_attr[:, 1:] if net.clf.regularization.edge_type else self.edge_attr
+        if net.clf.regularization.edge_type:
+            # column 0 is the regularisation column (reference :334-337): strip it once, the kernels want packed rows
+            if self._xe_stripped is None:
+                self._xe_stripped = self.edge_attr[:, 1:].contiguous()
+            xe = self._xe_stripped
+        else:
+            xe = self.edge_attr
 
         def layer_fn(i, h, out, b, e):
             net._eval_layers(h, self.n_own, xe, [plan] * net.num_layers, False, only=i, out=out, rows=(b, e))

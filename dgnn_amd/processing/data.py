@@ -21,11 +21,12 @@ from .._lib import check, lib, ptr, stream_ptr
 
 def standardize(cols64: np.ndarray, c_first: int, device) -> torch.Tensor:
     """[N,C] float64 (host) -> standardised fp32 [N,C] on `device`; columns < c_first are only cast."""
-    x = torch.from_numpy(np.ascontiguousarray(cols64)).to(device)
-    n, c = x.shape
-    out = torch.empty((n, c), dtype=torch.float32, device=device)
-    scratch = torch.empty(int(lib().dgnn_standardize_scratch_doubles(c)), dtype=torch.float64, device=device)
-    check(lib().dgnn_standardize_f64(ptr(x), c, n, c, c_first, ptr(out), c, ptr(scratch), stream_ptr()), "dgnn_standardize_f64")
+    with torch.cuda.device(device):
+        x = torch.from_numpy(np.ascontiguousarray(cols64)).to(device)
+        n, c = x.shape
+        out = torch.empty((n, c), dtype=torch.float32, device=device)
+        scratch = torch.empty(int(lib().dgnn_standardize_scratch_doubles(c)), dtype=torch.float64, device=device)
+        check(lib().dgnn_standardize_f64(ptr(x), c, n, c, c_first, ptr(out), c, ptr(scratch), stream_ptr()), "dgnn_standardize_f64")
     return out
 
 

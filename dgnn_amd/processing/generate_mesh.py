@@ -11,9 +11,10 @@ from __future__ import annotations
 
 import torch
 
-from .._lib import check, lib, ptr, stream_ptr
+from .._lib import check, lib, on_device_of, ptr, stream_ptr
 
 
+@on_device_of
 def _compact(values, keep, invert):
     n = keep.numel()
     out = torch.empty(max(n, 1), dtype=torch.int32, device=keep.device)
@@ -24,6 +25,7 @@ def _compact(values, keep, invert):
     return out[:int(cnt.item())]
 
 
+@on_device_of
 def labels_of_finite_cells(prediction: torch.Tensor, infinite: torch.Tensor) -> torch.Tensor:
     """int32 labels (0 inside / 1 outside) of the cells with infinite == 0, in cell order (reference :75)."""
     if not prediction.is_cuda:
@@ -35,6 +37,7 @@ def labels_of_finite_cells(prediction: torch.Tensor, infinite: torch.Tensor) -> 
     return _compact(labels, infinite.to(prediction.device, torch.int32).contiguous(), invert=True)
 
 
+@on_device_of
 def interface_from_labels(labels_finite: torch.Tensor, nfacets: torch.Tensor) -> torch.Tensor:
     """Indices (int32, ascending) of the facets whose two cells differ; cell -1 is the outside cell (:93-105)."""
     nfacets = nfacets.to(labels_finite.device, torch.int32).contiguous()

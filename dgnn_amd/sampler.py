@@ -82,6 +82,10 @@ class NeighborSampler:
             yield self.sample(b)
 
     def sample(self, batch: torch.Tensor):
+        with torch.cuda.device(self.device):  # the plan's GPU, whatever the thread's current device is
+            return self._sample(batch)
+
+    def _sample(self, batch: torch.Tensor):
         L, st, p = lib(), stream_ptr(), self.plan
         n_id = batch.to(self.device, torch.int64).contiguous()
         batch_size = n_id.numel()

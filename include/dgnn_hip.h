@@ -34,9 +34,15 @@ extern "C" {
 #define DGNN_E_INVALID -1     /* bad argument (null pointer, negative size, unsupported width) */
 #define DGNN_E_UNSUPPORTED -2 /* shape outside what the kernel family handles */
 #define DGNN_E_LAUNCH -3      /* hipGetLastError() after launch */
+#define DGNN_E_INDEX -4       /* a kernel met an index outside its range (reported asynchronously, see dgnn_poll_async_error) */
 
 int dgnn_version(void);
 const char* dgnn_last_error_string(void);
+/* Data-dependent errors a launch-time check cannot see (an edge_index entry outside [0, n): torch's scatter raises an index
+ * error there, surfaceNetStaticEdgeFilters.py:80) are reported asynchronously, like HIP's own: the kernel stays memory-safe
+ * (skips the edge), sets a bit in a pinned host word, and this call -- after any later stream synchronisation, or simply at
+ * the next entry point -- returns DGNN_E_INDEX once and clears it (0 = nothing pending). */
+int dgnn_poll_async_error(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Graph plan: destination-sorted CSR of an edge list, STABLE in edge position.
@@ -54,6 +60,9 @@ const char* dgnn_last_error_string(void);
  *   edge_index : int64 [2,E] view, row0=src row1=dst: element (r,k) at edge_index[r*stride_row + k*stride_col].
  *                The reference passes torch.transpose(adjacencies,1,0) (processing/data.py:434-438), i.e.
  *                strides (1,2) over the [E,2] array; a contiguous [2,E] tensor has (E,1).  Read in place.
+ *   n_other    : number of nodes on the OTHER side (sources for by=1), for range checking; 0 = unknown, unchecked.
+ *                Endpoints outside [0,n_key) / [0,n_other) never index memory: such edges are left out of the plan (key)
+ *                or point at node 0 (other) and DGNN_E_INDEX is reported through dgnn_poll_async_error().
  *   rowptr     : int32 [n_key+1]   out
  *   other      : int32 [E]         out  (src for by=1, dst for by=0)
  *   eid        : int32 [E]         out  original edge position of the k-th sorted edge
@@ -71,9 +80,9 @@ const char* dgnn_last_error_string(void);
 #define DGNN_PLAN_HINT_REFERENCE 2
 #define DGNN_PLAN_HINT_GENERIC 3 /* attempt neither: straight to the generic kernels */
 int64_t dgnn_plan_scratch_elems(int64_t E, int64_t n_key);
-int dgnn_plan_build(const int64_t* edge_index, int64_t stride_row, int64_t stride_col, int64_t E, int64_t n_key, int by,
-                    int hint, int32_t* rowptr, int32_t* other,
-                    int32_t* eid, int32_t* scratch, void* stream);
+int dgnn_plan_build(const int64_t* edge_index, int64_t stride_row, int64_t stride_col, int64_t E, int64_t n_key,
+                    int64_t n_other, int by, int hint, int32_t* rowptr, int32_t* other, int32_t* eid, int32_t* scratch,
+                    void* stream);
 
 /* out[k, 0:cols] = in[idx[k], 0:cols]  -- stages edge_attr rows into plan order once per scene
  * (the reference gathers them implicitly: `xe[e_id]` at surfaceNetStaticEdgeFilters.py:262,304). */

@@ -213,6 +213,68 @@ def ignatius_block(n_keep=768):
     return xs.float(), eas.float(), torch.from_numpy(np.stack([e_src, e_dst])).long()
 
 
+def ignatius_full(ref, sd):
+    """F4: the WHOLE real scene data/Ignatius (67 017 cells, CGAL cell order = no gather locality; real per-scene
+    standardised node features with outliers up to 174 sigma and the 16 real edge columns, both from the reference's own
+    loader; the 4 missing fgeom columns are seeded N(0,1) and are regenerated by the test from `fgeom_seed`).  Stores the
+    reference's inference_layer logits (fp32 + fp64 re-evaluation) and, for the layer trace, a strided sample of relu0..3."""
+    sys.path.insert(0, REF)
+    from processing.data import dataLoader
+    clf = static_clf()
+    clf.features.edge_features = [f for f in clf.features.edge_features if f != "shape"]
+    clf.inference.has_label = 0
+    dl = dataLoader(clf, verbosity=0)
+    dl.run(dict(path=os.path.join(REF, "data/Ignatius"), filename="99", category="", id="", scan_conf="",
+                gtfile="gt/99", ioufile=""))
+    x, ea16, ei = dl.features.float(), dl.edge_features.float(), dl.edge_lists.long()
+    n = x.shape[0]
+    assert x.shape == (n, 29) and ea16.shape == (4 * n, 16) and np.array_equal(ei[0].numpy(), np.repeat(np.arange(n), 4))
+    seed = 99
+    fg = torch.from_numpy(np.random.default_rng(seed).standard_normal((4 * n, 4)).astype(np.float32))
+    ea = torch.cat([fg, ea16], 1)
+    torch.set_num_threads(8)
+    logits, acts, _ = run_static(ref, sd, x, ea, ei, torch.float32)
+    logits64, _, _ = run_static(ref, sd, x, ea, ei, torch.float64)
+    torch.set_num_threads(1)
+    rows = np.arange(0, n, 97)
+    out = dict(x=x.numpy(), edge_attr16=ea16.numpy(), adj_dst=ei[1].numpy().astype(np.int32), fgeom_seed=np.asarray(seed),
+               logits=logits.numpy(), logits64=logits64.numpy(), trace_rows=rows)
+    for i in range(4):
+        out["relu%d_rows" % i] = acts["relu%d" % i].numpy()[rows]
+    np.savez_compressed(os.path.join(HERE, "static_f4_ignatius_full.npz"), **out)
+    print("F4", logits.shape, float((logits - logits64.float()).abs().max()), "max|x|", float(x.abs().max()))
+
+
+def layer_batch_fixture(ref, sd):
+    """Reference inference_layer_batch (:279-320) on a small Delaunay scene: 1-hop full-neighbour blocks of consecutive
+    target ranges (shuffle=False, as run.py:221-223 builds them), activations concatenated layer by layer."""
+    from dgnn_amd.synthetic import delaunay_tet_graph
+    from oracle.pyg_semantics import neighbor_sampler_full
+    adj, _, _ = delaunay_tet_graph(300, seed=21)
+    n = adj.shape[0] // 4
+    ei = adj.T.astype(np.int64)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(n, 29, generator=g)
+    ea = torch.randn(4 * n, 20, generator=g)
+    bs = 257
+    loader = []
+    for s in range(0, n, bs):
+        batch = np.arange(s, min(n, s + bs))
+        n_id, adjs = neighbor_sampler_full(ei, n, batch, 1)
+        a, e, size = adjs[0]
+        loader.append((len(batch), torch.from_numpy(n_id), (torch.from_numpy(a), torch.from_numpy(e), size)))
+    clf = static_clf()
+    net = ref["surfaceNetStaticEdgeFilters"].SurfaceNet(clf)
+    net.load_state_dict(sd)
+    net.eval()
+    with torch.no_grad():
+        out = net.inference_layer_batch(AD(x=x, edge_attr=ea), loader)
+        whole = net.inference_layer(AD(x=x, edge_attr=ea, edge_index=torch.from_numpy(ei)))
+    np.savez_compressed(os.path.join(HERE, "static_f5_layer_batch.npz"), x=x.numpy(), edge_attr=ea.numpy(), adjacencies=adj,
+                        batch_size=np.asarray(bs), logits=out.numpy(), logits_whole_graph=whole.numpy())
+    print("F5 layer_batch", out.shape, "vs whole-graph", float((out - whole).abs().max()))
+
+
 def run_static(ref, sd, x, ea, ei, dtype):
     clf = static_clf()
     net = ref["surfaceNetStaticEdgeFilters"].SurfaceNet(clf)
@@ -407,5 +469,15 @@ def main():
 if __name__ == "__main__":
     if sys.argv[1:] == ["ingest"]:      # only the 8f-3 fixture (independent seed)
         ingest_fixture(np.random.default_rng(5))
+    elif sys.argv[1:] == ["round2"]:    # only the fixtures added in round 2 (F4 full Ignatius scene, F5 layer_batch)
+        torch.set_num_threads(1)
+        _ref = load_ref()
+        _sd = torch.load(os.path.join(REF, "data/models/kf96/model_best.ptm"), map_location="cpu")
+        ignatius_full(_ref, _sd)
+        layer_batch_fixture(_ref, _sd)
     else:
         main()
+        _ref = load_ref()
+        _sd = torch.load(os.path.join(REF, "data/models/kf96/model_best.ptm"), map_location="cpu")
+        ignatius_full(_ref, _sd)
+        layer_batch_fixture(_ref, _sd)

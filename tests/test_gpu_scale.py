@@ -1,0 +1,223 @@
+"""GPU parity at the sizes that are benchmarked: the 1 010 078-tet metric graph against the fp32
+oracle evaluated on the host cores of the GPU box, the WHOLE real Ignatius scene against logits produced by the
+reference's own model file (tests/golden/static_f4_ignatius_full.npz), and the layer-major schedule against the
+reference's own inference_layer_batch output (static_f5_layer_batch.npz).
+
+Tolerance (stated): |dlogit| <= 1e-4 * max(1, |logit|).  On synthetic N(0,1) inputs logits stay within +-8 and this is the
+1e-4 absolute bound of SURVEY 8c; on the real scene standardised features reach 174 sigma, logits +-167, and the
+reference's fp32 result itself sits 5.3e-5 (1e-5 relative) away from its fp64 evaluation -- an absolute 1e-4 would be
+tighter than the reference is with itself.  Next to it the fp64 yardstick: the HIP logits may be at most 3x as far from
+the reference's fp64 evaluation as the reference's own fp32 logits are."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dgnn_amd.config import Config
+from helpers import gold, oracle_static
+from test_gpu_parity import DEV, TOL_LOGIT, hip_static
+
+pytestmark = pytest.mark.gpu
+
+
+def logit_check(got, ref, ref64=None):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    tol = TOL_LOGIT * np.maximum(1.0, np.abs(ref))
+    err = np.abs(got - ref)
+    assert (err <= tol).all(), "max|dlogit| %.3e (tol %.1e at that entry)" % (err.max(), tol.reshape(-1)[err.argmax()])
+    margin = np.abs(ref[:, 0] - ref[:, 1]) > 2 * tol.max(axis=1)
+    flips = int((got.argmax(1)[margin] != ref.argmax(1)[margin]).sum())
+    assert flips == 0, "%d arg-max flips among %d cells with a margin above the tolerance" % (flips, int(margin.sum()))
+    if ref64 is not None:
+        e_ref, e_got = np.abs(ref - ref64).max(), np.abs(got - ref64).max()
+        assert e_got <= max(3 * e_ref, 1e-5), "error vs fp64: ours %.3e, the reference's own %.3e" % (e_got, e_ref)
+    return float(err.max())
+
+
+_scene = {}
+
+
+def metric_graph():
+    """The BASELINE.md metric graph (bench.py's generator and seeds), built once per test session."""
+    if not _scene:
+        import bench
+        adj, _, x, ea = bench.make_scene(150000, 0)
+        _scene.update(adj=adj, x=x, ea=ea, ei=torch.from_numpy(adj.T.astype(np.int64)))
+    return _scene
+
+
+def test_metric_graph_1m_vs_oracle_all_gemm_modes():
+    """N = 1 010 078, E = 4 040 312: inference_layer in all three matrix-core modes against the fp32 oracle on the host CPU;
+    per-layer relu0..3 on a 50k-row sample against the oracle's trace."""
+    from dgnn_amd import ops
+    from dgnn_amd.graph import GraphPlan
+    s = metric_graph()
+    n = s["x"].shape[0]
+    assert n == 1010078
+    onet = oracle_static()
+    trace = []
+    torch.set_num_threads(min(os.cpu_count() or 8, 32))
+    with torch.no_grad():
+        ref = onet.inference_layer(Config(x=s["x"], edge_attr=s["ea"], edge_index=s["ei"]), trace)
+    ref = ref.numpy()
+    rows = torch.arange(0, n, 20)
+    tr = {k: v[rows].clone() for k, v in trace if k.startswith("relu")}
+    del trace
+    net = hip_static()
+    data = Config(x=s["x"].to(DEV), edge_attr=s["ea"].to(DEV), edge_index=s["ei"].to(DEV))
+    old = ops.GEMM_MODE
+    try:
+        for mode in (ops.GEMM_BF16X3_FILTER, ops.GEMM_BF16X3, ops.GEMM_F32):
+            ops.GEMM_MODE = mode
+            logits = net.inference_layer(data).cpu().numpy()
+            err = logit_check(logits, ref)
+            print("mode %d: max|dlogit| %.3e over %d tets" % (mode, err, n))
+            # layer trace: each fused layer on the device, 50k sampled rows against the oracle's activations
+            plan = GraphPlan(data.edge_index, n, n, hint=ops.PLAN_HINT_REFERENCE)
+            h = data.x[:, 1:]
+            for i in range(4):
+                h = net._eval_layers(h, n, data.edge_attr, [plan] * 4, True, only=i)
+                got, want = h[rows.to(DEV)].cpu().double(), tr["relu%d" % i].double()
+                rel = ((got - want).abs().max() / want.abs().max()).item()
+                assert rel < 2e-5, (mode, i, rel)
+    finally:
+        ops.GEMM_MODE = old
+
+
+def test_metric_graph_1m_properties():
+    """Size-independent properties at full size: bit-identical repeat runs, a plan built by the generic kernels gives the
+    same logits as the verified fast path, and relabelling the cells (a permutation of the graph) permutes the logits."""
+    from dgnn_amd import ops
+    from dgnn_amd.graph import GraphPlan
+    s = metric_graph()
+    n = s["x"].shape[0]
+    net = hip_static()
+    data = Config(x=s["x"].to(DEV), edge_attr=s["ea"].to(DEV), edge_index=s["ei"].to(DEV))
+    a = net.inference_layer(data)
+    b = net.inference_layer(data)
+    assert torch.equal(a, b)
+    g = net.inference_layer(data, plan=GraphPlan(data.edge_index, n, n, hint=ops.PLAN_HINT_GENERIC))
+    assert torch.equal(a, g)
+    # relabel: new id = perm[old id]; rows of x move with their cell, edge rows stay attached to their (src,dst) pair.
+    # Each destination still sums its 4 messages, in a different order -> equal up to fp32 summation order.
+    gen = torch.Generator().manual_seed(3)
+    perm = torch.randperm(n, generator=gen)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(n)
+    ei_p = perm[s["ei"]]                     # same edge positions, relabelled endpoints (no longer the reference layout)
+    data_p = Config(x=s["x"][inv].to(DEV), edge_attr=data.edge_attr, edge_index=ei_p.to(DEV))
+    c = net.inference_layer(data_p)          # generic plan builder (the fast paths reject this layout on the device)
+    d = (c[perm.to(DEV)] - a).abs().max().item()
+    assert d <= 2e-5, d
+
+
+def test_ignatius_full_scene_vs_reference_logits():
+    """67 017 cells in CGAL order (neighbour ids tens of thousands of rows apart), real standardised features; expected
+    logits come from the reference's own surfaceNetStaticEdgeFilters.inference_layer (make_golden.py ignatius_full)."""
+    from dgnn_amd import ops
+    g = gold("static_f4_ignatius_full.npz")
+    n = g["x"].shape[0]
+    fg = np.random.default_rng(int(g["fgeom_seed"])).standard_normal((4 * n, 4)).astype(np.float32)
+    ea = np.concatenate([fg, g["edge_attr16"]], axis=1)
+    adj = np.stack([np.repeat(np.arange(n, dtype=np.int64), 4), g["adj_dst"].astype(np.int64)])
+    data = Config(x=torch.from_numpy(g["x"]).to(DEV), edge_attr=torch.from_numpy(ea).to(DEV), edge_index=torch.from_numpy(adj).to(DEV))
+    net = hip_static()
+    old = ops.GEMM_MODE
+    try:
+        for mode in (ops.GEMM_BF16X3_FILTER, ops.GEMM_BF16X3, ops.GEMM_F32):
+            ops.GEMM_MODE = mode
+            logits = net.inference_layer(data).cpu().numpy()
+            err = logit_check(logits, g["logits"], g["logits64"])
+            print("Ignatius mode %d: max|dlogit| %.3e (logit range %.0f)" % (mode, err, np.abs(g["logits"]).max()))
+    finally:
+        ops.GEMM_MODE = old
+    # layer trace on the stored row sample
+    from dgnn_amd.graph import GraphPlan
+    plan = GraphPlan(data.edge_index, n, n, hint=ops.PLAN_HINT_REFERENCE)
+    rows = torch.from_numpy(g["trace_rows"]).to(DEV)
+    h = data.x[:, 1:]
+    for i in range(4):
+        h = net._eval_layers(h, n, data.edge_attr, [plan] * 4, True, only=i)
+        want = torch.from_numpy(g["relu%d_rows" % i]).double()
+        rel = ((h[rows].cpu().double() - want).abs().max() / want.abs().max()).item()
+        assert rel < 2e-5, (i, rel)
+    # the unfused aggregate + GEMM pair on the same scene (what other widths and training use)
+    ops.FUSED_ENABLED = False
+    try:
+        logit_check(net.inference_layer(data).cpu().numpy(), g["logits"], g["logits64"])
+    finally:
+        ops.FUSED_ENABLED = True
+
+
+def test_layer_batch_vs_reference_and_oracle():
+    """inference_layer_batch (layer-major, 1-hop blocks): against the reference's own output on the same blocks and
+    against the oracle's inference_layer_batch -- not against another HIP path."""
+    from oracle.pyg_semantics import neighbor_sampler_full
+    g = gold("static_f5_layer_batch.npz")
+    adj = g["adjacencies"]
+    n = adj.shape[0] // 4
+    ei = adj.T.astype(np.int64)
+    bs = int(g["batch_size"])
+    loader = []
+    for s in range(0, n, bs):
+        b = np.arange(s, min(n, s + bs))
+        n_id, adjs = neighbor_sampler_full(ei, n, b, 1)
+        a, e, size = adjs[0]
+        loader.append((len(b), torch.from_numpy(n_id), (torch.from_numpy(a), torch.from_numpy(e), size)))
+    x, ea = torch.from_numpy(g["x"]), torch.from_numpy(g["edge_attr"])
+    net = hip_static()
+    got = net.inference_layer_batch(Config(x=x.to(DEV), edge_attr=ea.to(DEV)), loader).cpu().numpy()
+    logit_check(got, g["logits"])
+    with torch.no_grad():
+        oref = oracle_static().inference_layer_batch(Config(x=x, edge_attr=ea), loader).numpy()
+    logit_check(got, oref)
+    # the GPU block builder as the loader (what a reference run.py would construct, run.py:221-223)
+    from dgnn_amd.sampler import NeighborSampler
+    gl = NeighborSampler(torch.from_numpy(ei).to(DEV), sizes=[-1], num_nodes=n, batch_size=bs, shuffle=False)
+    got2 = net.inference_layer_batch(Config(x=x.to(DEV), edge_attr=ea.to(DEV)), gl).cpu().numpy()
+    logit_check(got2, g["logits"])
+
+
+def test_out_of_range_edge_index_is_reported_not_corrupting():
+    """A malformed adjacency (-1 neighbours, ids >= N) must not write outside the plan arrays; the error surfaces at a later
+    call as DGNN_E_INDEX (torch's scatter raises an index error in the reference)."""
+    from dgnn_amd import ops
+    from dgnn_amd._lib import DgnnError
+    n = 1000
+    gen = torch.Generator().manual_seed(0)
+    ei = torch.randint(0, n, (2, 4000), generator=gen)
+    bad = ei.clone()
+    bad[1, 17] = -1
+    bad[1, 99] = n + 5
+    bad[0, 5] = n  # source out of range
+    guard = torch.full((8192,), 12345, dtype=torch.int32, device=DEV)  # canary allocations around the plan
+    with pytest.raises(DgnnError, match="out of range"):
+        rowptr, src, eid = ops.plan_build(bad.to(DEV), n, by=1, hint=ops.PLAN_HINT_GENERIC, n_other=n)
+        torch.cuda.synchronize()
+        assert int(rowptr[-1]) == 4000 - 2           # the two bad-key edges are left out
+        assert int(src.max()) < n and int(src[: int(rowptr[-1])].min()) >= 0
+        ops.relu(torch.zeros(4, device=DEV))         # any later entry point reports it
+    assert bool((guard == 12345).all())
+    # and the flag is cleared: a good plan afterwards works
+    rowptr, src, eid = ops.plan_build(ei.to(DEV), n, by=1, n_other=n)
+    torch.cuda.synchronize()
+    ops.relu(torch.zeros(4, device=DEV))
+    assert int(rowptr[-1]) == 4000
+
+
+def test_fused_predicate_matches_dispatch_128_to_64():
+    """convs [..,128,64] must fall back to the aggregate + GEMM pair instead of raising."""
+    from dgnn_amd.synthetic import delaunay_tet_graph
+    adj, _, _ = delaunay_tet_graph(800, seed=2)
+    n = adj.shape[0] // 4
+    gen = torch.Generator().manual_seed(1)
+    x, ea = torch.randn(n, 29, generator=gen), torch.randn(4 * n, 20, generator=gen)
+    ei = torch.from_numpy(adj.T.astype(np.int64))
+    convs = (64, 128, 64, 100)
+    onet = oracle_static(convs=convs, load=False, seed=4)
+    net = hip_static(convs=convs, sd=onet.state_dict())
+    with torch.no_grad():
+        ref = onet.inference_layer(Config(x=x, edge_attr=ea, edge_index=ei)).numpy()
+    got = net.inference_layer(Config(x=x.to(DEV), edge_attr=ea.to(DEV), edge_index=ei.to(DEV))).cpu().numpy()
+    logit_check(got, ref)

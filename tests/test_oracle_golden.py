@@ -157,3 +157,43 @@ def test_ingest_oracle_and_column_selection_match_reference_loader():
     clf.features.edge_features = ["vertex", "count", "min", "max"]
     with pytest.raises(AttributeError):
         dl._edge_columns(base)
+
+
+def test_static_inference_layer_f4_full_ignatius_scene():
+    """The whole real scene (67 017 cells, features up to 174 sigma, logits up to +-167): the oracle reproduces the
+    reference's logits and its sampled layer trace."""
+    g = gold("static_f4_ignatius_full.npz")
+    n = g["x"].shape[0]
+    fg = np.random.default_rng(int(g["fgeom_seed"])).standard_normal((4 * n, 4)).astype(np.float32)
+    ea = np.concatenate([fg, g["edge_attr16"]], axis=1)
+    ei = np.stack([np.repeat(np.arange(n, dtype=np.int64), 4), g["adj_dst"].astype(np.int64)])
+    net = oracle_static()
+    torch.set_num_threads(8)   # 67k cells: seconds instead of tens of seconds; tolerance covers the thread split
+    trace = []
+    with torch.no_grad():
+        logits = net.inference_layer(Config(x=torch.from_numpy(g["x"]), edge_attr=torch.from_numpy(ea), edge_index=torch.from_numpy(ei)), trace)
+    assert same(logits.numpy(), g["logits"], "F4 logits")
+    t = dict(trace)
+    for i in range(4):
+        assert same(t["relu%d" % i].numpy()[g["trace_rows"]], g["relu%d_rows" % i], "F4 relu%d" % i)
+
+
+def test_static_inference_layer_batch_f5():
+    """Layer-major schedule on 1-hop blocks: the oracle's inference_layer_batch against the reference's own output."""
+    from oracle.pyg_semantics import neighbor_sampler_full
+    g = gold("static_f5_layer_batch.npz")
+    adj = g["adjacencies"]
+    n = adj.shape[0] // 4
+    ei = adj.T.astype(np.int64)
+    bs = int(g["batch_size"])
+    loader = []
+    for s in range(0, n, bs):
+        b = np.arange(s, min(n, s + bs))
+        n_id, adjs = neighbor_sampler_full(ei, n, b, 1)
+        a, e, size = adjs[0]
+        loader.append((len(b), torch.from_numpy(n_id), (torch.from_numpy(a), torch.from_numpy(e), size)))
+    net = oracle_static()
+    with torch.no_grad():
+        out = net.inference_layer_batch(Config(x=torch.from_numpy(g["x"]), edge_attr=torch.from_numpy(g["edge_attr"])), loader)
+    assert same(out.numpy(), g["logits"], "F5 layer_batch")
+    assert same(g["logits"], g["logits_whole_graph"], "layer-major == whole graph in the reference itself")
