@@ -1,15 +1,23 @@
 """Counterpart of the reference's learning/runModel.py for the part that drives the hot path:
-``Trainer.train`` (:264-282), ``Trainer.inference`` (:412-451), ``calcLossAndOA`` (:163-259, cell loss) and
-``calcRegularization`` (:109-160), ``Metrics`` (:48-80), ``adjust_learning_rate`` (:95-99).
+``Trainer.train`` (:264-282), ``Trainer.train_test`` (:285-405: epochs, step LR decay, periodic validation,
+``model_best.ptm`` / ``model_<epoch>.ptm``), ``Trainer.inference`` (:412-451), ``calcLossAndOA`` (:163-259, cell loss),
+``calcRegularization`` (:109-160), ``Metrics`` (:48-80), ``adjust_learning_rate`` (:95-99) and the resume step of
+run.py:102-113 (``load_epoch``).
 
 Same names, arguments and error convention (``print`` + ``sys.exit(1)`` for config errors).  The model calls run
 on the HIP kernels; the loss itself is a few elementwise ops on [batch, 2] tensors and uses torch on the GPU.
-Validation-time mesh extraction / metrics (train_test :285-405) need the reference's CPU post-processing
-(gco, trimesh) and stay out of scope; the device string is no longer hard-wired to cuda:<gpu> (:287).
+New (no reference counterpart, single process there): ``group=`` on ``train`` / ``train_test`` = data-parallel
+replicas, one flat RCCL all-reduce of the gradients between ``backward()`` and ``step()`` (BASELINE config 5).
+Validation by mesh metrics (chamfer / iou, :355-362) needs the reference's CPU post-processing (gco, trimesh) and is used
+only when those import; the loss metric always works.  The device string is no longer hard-wired to cuda:<gpu> (:287).
 """
 from __future__ import annotations
 
+import csv
+import os
 import sys
+from datetime import datetime
+from shutil import copyfile
 
 import torch
 import torch.nn.functional as F
@@ -77,6 +85,11 @@ class Trainer:
     def calcLossAndOA(self, logits_cell, logits_edge, data, clf, metrics):
         """Volume-weighted cell loss, reference :163-259 (kl / bce / mse)."""
         dev = logits_cell.device
+        if not clf.regularization.cell_type:
+            # the reference computes the cell loss only under `if (clf.regularization.cell_type)` (:169) and then reads the
+            # unassigned `cell_loss` (:223): same exception type, with the reason spelled out
+            raise UnboundLocalError("local variable 'cell_loss' referenced before assignment: the reference's calcLossAndOA "
+                                    "needs regularization.cell_type (learning/runModel.py:169,223)")
         gt = data.batch_gt.to(dev)
         if clf.training.loss == "kl":
             cell_loss = F.kl_div(F.log_softmax(logits_cell, dim=-1), gt[:, :2], reduction='none').sum(dim=1)
@@ -95,10 +108,8 @@ class Trainer:
             w = torch.log(1 + vol)
         elif clf.regularization.cell_norm == "sqrt":
             w = torch.sqrt(vol)
-        elif clf.regularization.cell_type:
-            w = vol
         else:
-            w = torch.ones_like(cell_loss)
+            w = vol
         cell_loss = cell_loss * w
         metrics.addCellLossItem(cell_loss.sum().item(), w.sum().item())
         loss = cell_loss.sum() / w.sum()
@@ -110,8 +121,10 @@ class Trainer:
                 loss = loss + self.calcRegularization(logits_cell, data, clf, metrics)
         return loss
 
-    def train(self, data_train, optimizer, clf):
-        """One optimisation step on one sampled batch, reference :264-282."""
+    def train(self, data_train, optimizer, clf, group=None):
+        """One optimisation step on one sampled batch, reference :264-282.  `group`: data-parallel replicas (one scene shard
+        per rank): the flat gradient is all-reduced (mean) between backward() and step(); None + an initialised default
+        process group of size > 1 uses that group, a single process changes nothing."""
         self.model.train()
         logits_cell = self.model(data_train)
         n_sup = data_train.batch_adjs[self.model.num_layers - 1].size[1] if hasattr(data_train.batch_adjs[0], "size") \
@@ -122,8 +135,100 @@ class Trainer:
         loss = self.calcLossAndOA(logits_cell, None, data_train, clf, clf.training.metrics)
         optimizer.zero_grad()
         loss.backward()
+        from ..partition import allreduce_gradients
+        allreduce_gradients(self.model, group)   # no-op without a process group / with one rank
         optimizer.step()
         return loss.detach()
+
+    def train_test(self, data, clf, group=None):
+        """Epoch loop of the reference (:285-405): Adam, lr * 0.1^(epoch // adjust_lr_every), one `train` per sampled batch,
+        running metrics printed every `print_every` iterations, validation every `val_every` iterations (loss / OA over
+        data.validation.all through `inference`; chamfer / iou only when the reference's mesh post-processing imports),
+        `models/model_best.ptm` whenever the validation metric improves and `models/model_<epoch>.ptm` every `export_every`
+        iterations -- plain state_dicts, exactly what run.py:148-157 / :102-113 load.  Rows of the results table go to
+        clf.files.results (csv) when that is configured.  With `group` (data-parallel replicas) only rank 0 writes."""
+        if not getattr(clf.temp, "device", None):
+            clf.temp.device = "cuda:" + str(clf.temp.args.gpu)
+        from ..partition import broadcast_parameters
+        broadcast_parameters(self.model, group)   # data-parallel replicas start equal (no-op for a single process)
+        optimizer = torch.optim.Adam(self.model.parameters(), lr=clf.training.learning_rate)
+        import torch.distributed as dist
+        writer = (not (dist.is_available() and dist.is_initialized())) or dist.get_rank(group) == 0
+        models_dir = os.path.join(clf.paths.out, "models")
+        if writer:
+            os.makedirs(models_dir, exist_ok=True)
+        results = getattr(getattr(clf, "files", None), "results", None) if hasattr(clf, "files") else None
+        rows = []
+        metric_name = clf.temp.metrics[0] if getattr(clf.temp, "metrics", None) else "loss"
+        if not hasattr(clf, "best_metric") or clf.best_metric is None:
+            clf.best_metric = float("-inf") if metric_name == "iou" else float("inf")
+        clf.training.metrics = Metrics()
+        iterations = 0
+        row = {}
+        for current_epoch in range(1, clf.training.epochs + 1):
+            clf.temp.current_epoch = current_epoch
+            adjust_learning_rate(optimizer, clf)
+            for data.train.batch_size, data.train.batch_n_id, data.train.batch_adjs in data.train.batches:
+                iterations += 1
+                self.train(data.train, optimizer, clf, group)
+                m = clf.training.metrics
+                row.update(iteration=iterations, epoch=current_epoch, train_loss_cell=m.getCellLoss(), train_loss_reg=m.getRegLoss(),
+                           train_loss_total=m.getRegLoss() + m.getCellLoss(), train_OA=m.getOA())
+                if (iterations % clf.training.print_every) == 0 or iterations == 1:
+                    if writer:
+                        print('%s[%3d] Epoch %3d -> Train Loss (cell): %1.4f,  Train Loss (reg): %1.4f, Train Loss (total): %1.4f,  Train OA: %3.2f%%'
+                              % (datetime.now().strftime("[%H:%M:%S]"), iterations, current_epoch, row['train_loss_cell'],
+                                 row['train_loss_reg'], row['train_loss_total'], row['train_OA']))
+                    clf.training.metrics = Metrics()
+                if (iterations % clf.training.val_every) == 0 and getattr(data, "validation", None) is not None:
+                    OA = loss = reg = samples = weight = edges = 0
+                    current_metric = 0
+                    mesh_metric = metric_name in ("chamfer", "iou")
+                    for i, d in enumerate(data.validation.all):
+                        loader = data.validation.batches[i] if clf.validation.batch_size else []
+                        prediction = self.inference(d, loader, clf)
+                        im = clf.inference.metrics
+                        OA += im.OA_sum
+                        samples += im.samples_sum
+                        reg += im.reg_sum
+                        edges += im.edges_sum
+                        loss += im.cell_sum
+                        weight += im.weight_sum
+                        if mesh_metric:
+                            from ..processing import generate_mesh as gm
+                            _, eval_dict = gm.generate(d, prediction, clf)   # raises without trimesh (as the reference does)
+                            current_metric += eval_dict[metric_name]
+                    re = reg / edges if (reg > 0.0 and edges > 0.0) else 0.0
+                    loss /= weight
+                    loss_total = re + loss
+                    if metric_name == "loss":
+                        current_metric = loss_total
+                        improved = current_metric < clf.best_metric
+                    else:
+                        current_metric /= len(data.validation.all)
+                        improved = current_metric > clf.best_metric if metric_name == "iou" else current_metric < clf.best_metric
+                    if improved:
+                        clf.best_metric = current_metric
+                        if writer:
+                            torch.save(self.model.state_dict(), os.path.join(models_dir, "model_best.ptm"))
+                    row.update(test_loss_cell=loss, test_loss_reg=re, test_loss_total=loss_total, test_OA=OA * 100 / max(samples, 1))
+                    row['test_current_' + metric_name] = current_metric
+                    row['test_best_' + metric_name] = clf.best_metric
+                    rows.append(dict(row))
+                    if writer and results:
+                        keys = sorted({k for r in rows for k in r})
+                        with open(results, "w", newline="") as f:
+                            w = csv.DictWriter(f, fieldnames=keys)
+                            w.writeheader()
+                            w.writerows(rows)
+                if (iterations % clf.training.export_every) == 0 and writer:
+                    model_path = os.path.join(models_dir, "model_" + str(int(current_epoch)) + ".ptm")
+                    print('[{}] Epoch {} -> Export model to {}'.format(iterations, current_epoch, model_path))
+                    torch.save(self.model.state_dict(), model_path)
+                    if results and os.path.isfile(results):
+                        copyfile(results, os.path.splitext(results)[0] + "_" + str(current_epoch) + ".csv")
+        clf.results_rows = rows
+        return rows
 
     def inference(self, data_inference, subgraph_loader, clf):
         """Dispatch of the three inference schedules, reference :412-451.  Logits come back on the CPU."""
@@ -150,3 +255,17 @@ class Trainer:
         if clf.training.loss == "mse":
             logits_cell = torch.cat((1 - logits_cell, logits_cell), dim=1)
         return logits_cell.to('cpu')
+
+
+def load_epoch(model, clf):
+    """Resume step of run.py:102-113: training.load_epoch names `<out>/models/model_<load_epoch>.ptm`, a plain state_dict
+    (optimizer state, epoch counter and RNG are not part of the reference's checkpoints).  Returns True when loaded."""
+    if not clf.training.load_epoch:
+        return False
+    model_file = os.path.join(clf.paths.out, "models", "model_" + str(clf.training.load_epoch) + ".ptm")
+    print("\nLoad existing model at epoch ", clf.training.load_epoch)
+    if not os.path.isfile(model_file):
+        print("\nERROR: The model {} does not exist. Check that you have set the correct path in data:out in the config file!".format(model_file))
+        sys.exit(1)
+    model.load_state_dict(torch.load(model_file, map_location="cpu"))
+    return True

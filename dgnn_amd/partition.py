@@ -131,14 +131,16 @@ class HaloExchange:
             # RCCL moves device buffers directly; any other backend (gloo: bring-up / single-GPU validation runs with
             # several ranks on one device) gets the rows staged through host memory.  Transport only -- never compute.
             import torch.distributed as dist
-            via_host = (self.device.type == "cuda" and lp.world > 1 and dist.is_available() and dist.is_initialized()
+            via_host = (self.device.type == "cuda" and dist.is_available() and dist.is_initialized()
                         and dist.get_backend(group) != "nccl")
         self.via_host = bool(via_host)
         self.send_idx = torch.from_numpy(lp.send_idx).to(device)
         self.send_idx32 = self.send_idx.to(torch.int32)
         self.pack = pack
         self.n_own = lp.n_own
-        self.active = lp.world > 1 and (sum(lp.send_counts) + sum(lp.recv_counts)) > 0
+        # a rank with nothing to send or receive skips the collective (a single-rank part has no halo; a part may also list
+        # itself as its own peer -- RCCL allows self send/recv inside a group -- which the RCCL smoke test uses)
+        self.active = (sum(lp.send_counts) + sum(lp.recv_counts)) > 0
         self.stream = torch.cuda.Stream(device=self.device) if (self.device.type == "cuda" and self.active) else None
         self._pending = None
 
@@ -297,22 +299,63 @@ class PartitionedScene:
                                       widths=list(net.clf.model.convs))
 
 
+def _needs_host_staging(t: torch.Tensor, group) -> bool:
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend(group) != "nccl"
+
+
 def allreduce_gradients(model: torch.nn.Module, group=None, average: bool = True) -> None:
     """Data-parallel training step helper (BASELINE config 5: one scene shard per GPU, weight replicas):
     ONE collective over the flat fp32 gradient (0.4 MB for the shipped widths, 6.6 MB for [128..1024]) --
     latency-bound, so everything is bucketed into a single ncclAllReduce on RCCL.  BatchNorm statistics stay
-    per rank (the reference has a single rank; SyncBN would change its numerics).  Call between
-    loss.backward() and optimizer.step() (learning/runModel.py:279-282)."""
+    per rank (the reference has a single rank; SyncBN would change its numerics).  Called by Trainer.train between
+    loss.backward() and optimizer.step() (learning/runModel.py:279-282).  Parameters without a gradient on this rank (a
+    layer the rank's batch never reached) contribute zeros, so every rank reduces the same buffer layout.  Under a
+    non-RCCL backend (gloo bring-up runs) GPU gradients are staged through host memory."""
     import torch.distributed as dist
-    params = [p for p in model.parameters() if p.grad is not None]
-    if not params or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    params = [p for p in model.parameters() if p.requires_grad]
+    if not params:
+        return
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in params])
+    if _needs_host_staging(flat, group):
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat = host.to(flat.device)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     if average:
         flat /= dist.get_world_size(group)
     off = 0
     for p in params:
         n = p.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        g = flat[off:off + n].view_as(p).to(p.dtype)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
         off += n
+
+
+def broadcast_parameters(model: torch.nn.Module, group=None, src: int = 0) -> None:
+    """Replicas start from rank `src`'s weights and buffers (one flat broadcast per dtype class)."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    ts = [t for t in list(model.parameters()) + list(model.buffers()) if t.is_floating_point()]
+    if not ts:
+        return
+    flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in ts])
+    if _needs_host_staging(flat, group):
+        host = flat.cpu()
+        dist.broadcast(host, src=src, group=group)
+        flat = host.to(flat.device)
+    else:
+        dist.broadcast(flat, src=src, group=group)
+    off = 0
+    with torch.no_grad():
+        for t in ts:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t).to(t.dtype))
+            off += n

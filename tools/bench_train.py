@@ -2,72 +2,135 @@
 (configs/pretrained/reconbench.yaml: batch_size 2048 targets, 4-hop full-neighbour blocks, Adam, KL loss weighted by
 cell volume) on the synthetic 150k-point scene, everything on the GPU: k-hop block builder (dgnn_amd.sampler) ->
 SurfaceNet.forward (BN in train mode) -> loss -> backward through the HIP kernels -> Adam.
-Prints one JSON line: supervised targets/s and block tets/s (all cells touched by the 4-hop blocks)."""
-import json, os, sys, time
+
+    python tools/bench_train.py [--updated] [--dtype bf16] [--points P] [--batch B] [--steps K]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        tools/bench_train.py --gpus N ...
+
+--gpus N (BASELINE config 5): data-parallel replicas, ONE SCENE SHARD PER GPU (rank r trains on its own seeded scene),
+weights broadcast from rank 0, one flat RCCL all-reduce of the gradients per step (Trainer.train(..., group)); BatchNorm
+statistics stay per rank.  Prints one JSON line on rank 0: supervised targets/s and block tets/s (all cells touched by the
+4-hop blocks), summed over ranks, time = max over ranks."""
+import argparse
+import json
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import numpy as np
+import torch
+
 from dgnn_amd.config import Config, reconbench_pretrained
 from dgnn_amd.learning.runModel import Metrics, Trainer, adjust_learning_rate
 from dgnn_amd.learning.surfaceNetStaticEdgeFilters import SurfaceNet
 from dgnn_amd.sampler import NeighborSampler
 from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal
 
-dev = "cuda:0"
-UPDATED = "--updated" in sys.argv   # surfaceNetUpdatedEdgeFilters ("sage+", edge embeddings chained layer to layer) instead of Static
-sys.argv = [a for a in sys.argv if a != "--updated"]
-points = int(sys.argv[1]) if len(sys.argv) > 1 else 150000
-batch = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
-steps = int(sys.argv[3]) if len(sys.argv) > 3 else 40
-adj, _, _ = delaunay_tet_graph(points, 0)
+ap = argparse.ArgumentParser()
+ap.add_argument("--gpus", type=int, default=1)
+ap.add_argument("--updated", action="store_true", help="surfaceNetUpdatedEdgeFilters ('sage+', edge embeddings chained layer to layer)")
+ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="bf16: activations / phi stored in bf16, bf16 MFMA, fp32 accumulate and master weights")
+ap.add_argument("--points", type=int, default=150000)
+ap.add_argument("--batch", type=int, default=2048)
+ap.add_argument("--steps", type=int, default=40)
+ap.add_argument("--warmup", type=int, default=5)
+args = ap.parse_args()
+
+rank, local_rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+if world != args.gpus:
+    raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+backend = os.environ.get("DGNN_BENCH_BACKEND", "nccl")
+if backend != "nccl":
+    local_rank %= max(torch.cuda.device_count(), 1)
+torch.cuda.set_device(local_rank)
+dev = "cuda:%d" % local_rank
+if world > 1:
+    import torch.distributed as dist
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+    else:
+        dist.init_process_group(backend)
+
+points, batch, steps = args.points, args.batch, args.steps
+adj, _, _ = delaunay_tet_graph(points, rank)          # one scene shard per GPU: every rank its own scene
 n = adj.shape[0] // 4
 ei = torch.from_numpy(adj.T.astype(np.int64)).to(dev)
-x = hashed_normal(np.arange(n), 29, seed=1, device=dev)
+x = hashed_normal(np.arange(n), 29, seed=1 + 10 * rank, device=dev)
 x[:, 0] = x[:, 0].abs() + 0.05
-ea = hashed_normal(np.arange(4 * n), 20, seed=2, device=dev)
+ea = hashed_normal(np.arange(4 * n), 20, seed=2 + 10 * rank, device=dev)
 occ = torch.sigmoid(2 * x[:, 3:4] + x[:, 7:8])
 all_ = Config(x=x, y=torch.cat([occ, 1 - occ], 1), edge_attr=ea)
 clf = reconbench_pretrained(device=dev)
 clf.temp.current_epoch = 0
 clf.training.metrics = Metrics()
-if UPDATED:
+torch.manual_seed(0)
+if args.updated:
     import torch.nn.functional as F
     from dgnn_amd.learning.surfaceNetUpdatedEdgeFilters import SurfaceNet as UpdatedNet
+    from dgnn_amd.partition import allreduce_gradients
     uclf = Config.wrap(dict(training=dict(model_params=[64, 128, 128, 128], model_name="sage+", loss="kl"),
                             features=dict(normalization_feature=1, keep_normalization_feature=0), temp=dict(device=dev)))
     net = UpdatedNet(28, uclf).to(dev).train()
 
     class _Tr:   # the reference's loss (runModel.py:171-211) on the Updated model's (x, edge_attr, n_id, adjs) batch layout
-        def train(self, data, opt, clf):
+        def train(self, data, opt, clf, group=None):
             opt.zero_grad()
             ids = data.batch_n_id[:data.batch_adjs[-1][2][1]]
-            logits = net(Config(x=data.all.x, edge_attr=data.all.edge_attr, n_id=data.batch_n_id, adjs=data.batch_adjs))
+            logits = net(Config(x=data.all.x, edge_attr=data.all.edge_attr, n_id=data.batch_n_id, adjs=data.batch_adjs)).float()
             w = data.all.x[ids, 0]
             loss = (F.kl_div(F.log_softmax(logits, dim=-1), data.all.y[ids], reduction="none").sum(1) * w).sum() / w.sum()
             loss.backward()
+            allreduce_gradients(net, group)
             opt.step()
             return loss
     tr = _Tr()
 else:
     net = SurfaceNet(clf).to(dev).train()
     tr = Trainer(net)
+if args.dtype == "bf16":
+    net.set_storage_dtype(torch.bfloat16)
+if world > 1:
+    from dgnn_amd.partition import broadcast_parameters
+    broadcast_parameters(net)
 opt = torch.optim.Adam(net.parameters(), lr=clf.training.learning_rate, fused=True)  # one launch for all 49 tensors
 adjust_learning_rate(opt, clf)
-g = torch.Generator().manual_seed(0)
-idx = torch.randperm(n, generator=g)[:batch * (steps + 5)]
+g = torch.Generator().manual_seed(rank)
+idx = torch.randperm(n, generator=g)[:batch * (steps + args.warmup)]
 loader = NeighborSampler(ei, sizes=[-1] * 4, node_idx=idx.to(dev), num_nodes=n, batch_size=batch)
 it = iter(loader)
 block = 0
-for _ in range(5):
+for _ in range(args.warmup):
     bs, n_id, adjs = next(it)
     tr.train(Config(all=all_, batch_n_id=n_id, batch_adjs=adjs), opt, clf)
-torch.cuda.synchronize()
+
+
+def sync():
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+sync()
 t0 = time.perf_counter()
 for _ in range(steps):
     bs, n_id, adjs = next(it)
     block += int(n_id.numel())
     loss = tr.train(Config(all=all_, batch_n_id=n_id, batch_adjs=adjs), opt, clf)
-torch.cuda.synchronize()
+sync()
 dt = time.perf_counter() - t0
-print(json.dumps({"metric": "training step (block builder + fwd + bwd + Adam), one MI355X", "model": "UpdatedEdgeFilters sage+" if UPDATED else "StaticEdgeFilters", "targets_per_s": round(batch * steps / dt, 1),
-                  "block_tets_per_s": round(block / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3), "batch_targets": batch,
-                  "avg_block_tets": round(block / steps, 1), "steps": steps, "scene_tets": n, "final_loss": float(loss)}))
+if world > 1:
+    t = torch.tensor([dt, float(block)], device=dev, dtype=torch.float64)
+    tmax = t.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    dt, block = float(tmax[0]), float(t[1])
+if rank == 0:
+    print(json.dumps({"metric": "training step (block builder + fwd + bwd + %sAdam), %d x MI355X" % ("gradient all-reduce + " if world > 1 else "", world),
+                      "model": "UpdatedEdgeFilters sage+" if args.updated else "StaticEdgeFilters", "dtype": args.dtype, "n_gpus": world,
+                      "parallelism": "data-parallel replicas, one scene shard per GPU, flat RCCL all-reduce" if world > 1 else "single GPU",
+                      "targets_per_s": round(batch * steps * world / dt, 1), "block_tets_per_s": round(block / dt, 1),
+                      "ms_per_step": round(dt / steps * 1e3, 3), "batch_targets_per_gpu": batch,
+                      "avg_block_tets": round(block / steps / world, 1), "steps": steps, "scene_tets_per_gpu": n, "final_loss": float(loss)}))
+if world > 1:
+    dist.destroy_process_group()
