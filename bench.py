@@ -221,11 +221,48 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # HIP events around the launches of every conv layer INSIDE the timed region, recorded on the stream the kernels are
-    # launched on (torch's current stream); the roofline is reported for the layer shape that takes the most time
+    # ---- per-kernel breakdown (outside the timed region): replay each layer between events ----
+    breakdown = {}
+    if world == 1:
+        plan = GraphPlan(data.edge_index, n_local, n_local, hint=ops.PLAN_HINT_REFERENCE)
+
+        def timed(fn, reps=10):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+        breakdown["plan_ms"] = timed(lambda: GraphPlan(data.edge_index, n_local, n_local, hint=ops.PLAN_HINT_REFERENCE), 5)
+        h = net._input_rows(data.x)
+        if bf16:
+            breakdown["cast_ms"] = timed(lambda: ops.cast_to_bf16(h))
+            h = ops.cast_to_bf16(h)
+        for i in range(net.num_layers):
+            fn = lambda h=h, i=i: net._eval_layers(h, n_local, data.edge_attr, [plan] * net.num_layers, True, only=i)
+            breakdown["layer%d_ms" % i] = timed(fn)
+            h = fn()
+        breakdown["decoder_ms"] = timed(lambda: net._eval_decoder(h))
+
+    f_in = 28
+    shapes = list(zip([f_in] + list(convs)[:-1], convs))
+    if breakdown:
+        per_shape = {}
+        for i, sh_ in enumerate(shapes):
+            per_shape[sh_] = per_shape.get(sh_, 0.0) + breakdown["layer%d_ms" % i]
+        dom = max(per_shape, key=per_shape.get)
+    else:
+        dom = max(shapes, key=lambda s_: layer_bytes(*s_))
+    # HIP events around the launches of the dominant conv layer shape (the one the replays above found to take the most
+    # time) INSIDE the timed region, recorded on the stream the kernels are launched on (torch's current stream)
     layer_events = {}
 
     def hook(tok, c_in, c_out, n_dst):
+        if (c_in, c_out) != dom:
+            return None
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         if tok is None:
@@ -248,36 +285,10 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = n_total * args.steps / dt
 
-    # ---- per-kernel breakdown (outside the timed region): replay each layer between events ----
-    breakdown = {}
-    if world == 1:
-        plan = GraphPlan(data.edge_index, n_local, n_local, hint=ops.PLAN_HINT_REFERENCE)
-
-        def timed(fn, reps=10):
-            fn()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / reps
-        breakdown["plan_ms"] = timed(lambda: GraphPlan(data.edge_index, n_local, n_local, hint=ops.PLAN_HINT_REFERENCE), 5)
-        h = net._input_rows(data.x)
-        for i in range(net.num_layers):
-            fn = lambda h=h, i=i: net._eval_layers(h, n_local, data.edge_attr, [plan] * net.num_layers, True, only=i)
-            breakdown["layer%d_ms" % i] = timed(fn)
-            h = fn()
-        breakdown["decoder_ms"] = timed(lambda: net._eval_decoder(h))
-
     # ---- roofline of the dominant conv layer shape: HIP events on the launch stream, inside the timed steps ----
     roof = None
     if layer_events:
-        f_in = 28
-        shapes = list(zip([f_in] + list(convs)[:-1], convs))
         tot = {k: sum(a.elapsed_time(b) for a, b, _ in v) for k, v in layer_events.items()}
-        dom = max(tot, key=tot.get)
         n_layers_dom = max(1, sum(1 for s in shapes if s == dom))
         evs = layer_events[dom]
         rows = sum(r for _, _, r in evs)
@@ -297,7 +308,8 @@ def main():
         # valid only for the kernel sources they were measured on and for the shape that was profiled
         traffic, pmc, tsrc = None, {}, None
         try:
-            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+            cands = [c_ for c_ in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+                     if json.load(open(c_)).get("dtype", "f32") == args.dtype]
             tj = json.load(open(cands[-1]))
             tsrc = {"file": os.path.relpath(cands[-1], ROOT), "commit": tj.get("commit"), "csrc_sha": tj.get("csrc_sha")}
             same_kernel = tj.get("csrc_sha") == csrc_sha()

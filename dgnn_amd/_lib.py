@@ -52,6 +52,21 @@ SIGNATURES = {
     "dgnn_khop_commit": (i32, [vp, i64, i64, vp, vp, vp]),
     "dgnn_khop_reset": (i32, [vp, i64, vp, vp]),
     "dgnn_decoder_fused_fwd": (i32, [vp, i64, i64, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, i64, vp]),
+    "dgnn_cast_f32_to_bf16": (i32, [vp, i64, i64, i32, i32, vp, i64, vp]),
+    "dgnn_cast_bf16_to_f32": (i32, [vp, i64, i64, i32, vp, i64, vp]),
+    "dgnn_sage_layer_fused_fwd_bf16": (i32, [vp, vp, vp, i64, vp, vp, i64, i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i64, vp]),
+    "dgnn_decoder_fused_fwd_bf16": (i32, [vp, i64, i64, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, i64, vp]),
+    "dgnn_sage_aggregate_fwd_bf16": (i32, [vp, vp, vp, i64, vp, i64, i32, vp, i64, i32, vp, vp, vp, i64, vp, i64, vp, i64, vp]),
+    "dgnn_sage_aggregate_bwd_bf16": (i32, [vp, vp, vp, i64, vp, vp, i64, i32, vp, i64, i32, vp, vp, vp, i64, vp, i64, vp, i64,
+                                           vp, vp, vp, i64, vp, vp]),
+    "dgnn_linear_fwd_bf16": (i32, [vp, i64, i32, vp, i64, vp, i64, i32, vp, i64, vp, vp, vp, i32, i64, i32, vp, i64, i32, vp]),
+    "dgnn_linear_wgrad_bf16": (i32, [vp, i32, i64, i32, vp, i32, i64, i32, i64, vp, i64, i32, vp, vp]),
+    "dgnn_bn_batch_stats_bf16": (i32, [vp, i64, i64, i32, vp, vp, vp, vp, f32, vp, vp]),
+    "dgnn_scale_shift_act_bf16": (i32, [vp, i64, vp, vp, i32, i64, i32, vp, i64, vp]),
+    "dgnn_bn_relu_bwd_bf16": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, vp, f32, i32, i32, i64, i32, vp, i64, vp, vp, vp, vp]),
+    "dgnn_colsum_bf16": (i32, [vp, i64, i64, i32, vp, i32, vp, vp]),
+    "dgnn_relu_bf16": (i32, [vp, i64, vp, vp]),
+    "dgnn_relu_bwd_bf16": (i32, [vp, vp, i64, vp, vp]),
     "dgnn_sage_layer_fused_fwd": (i32, [vp, vp, vp, i64, vp, vp, i64, i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp,
                                         i64, i32, vp]),
 }

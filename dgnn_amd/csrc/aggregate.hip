@@ -18,16 +18,26 @@
 
 namespace {
 
-template <int CPL>
+// row fragments of CPL consecutive channels; T = float (fp32 storage) or uint16_t (bf16 storage: values are widened to fp32
+// on load and rounded to nearest-even bf16 on store -- all arithmetic in between is fp32)
+__device__ __forceinline__ uint16_t f2bf(float v) {
+    typedef __bf16 bf1 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const bf1 h = __builtin_convertvector(f2{v, 0.f}, bf1);
+    return (uint16_t)(__builtin_bit_cast(uint32_t, h) & 0xFFFFu);
+}
+__device__ __forceinline__ float bf2f(uint32_t bits16) { return __builtin_bit_cast(float, bits16 << 16); }
+
+template <int CPL, typename T>
 struct Vec;
 template <>
-struct Vec<1> {
+struct Vec<1, float> {
     float v[1];
     __device__ __forceinline__ void load(const float* p) { v[0] = *p; }
     __device__ __forceinline__ void store(float* p) const { *p = v[0]; }
 };
 template <>
-struct Vec<2> {
+struct Vec<2, float> {
     float v[2];
     __device__ __forceinline__ void load(const float* p) {
         float2 t = *reinterpret_cast<const float2*>(p);
@@ -36,16 +46,34 @@ struct Vec<2> {
     }
     __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]); }
 };
+template <>
+struct Vec<1, uint16_t> {
+    float v[1];
+    __device__ __forceinline__ void load(const uint16_t* p) { v[0] = bf2f(*p); }
+    __device__ __forceinline__ void store(uint16_t* p) const { *p = f2bf(v[0]); }
+};
+template <>
+struct Vec<2, uint16_t> {
+    float v[2];
+    __device__ __forceinline__ void load(const uint16_t* p) {
+        const uint32_t t = *reinterpret_cast<const uint32_t*>(p);
+        v[0] = bf2f(t & 0xFFFFu);
+        v[1] = __builtin_bit_cast(float, t & 0xFFFF0000u);
+    }
+    __device__ __forceinline__ void store(uint16_t* p) const {
+        *reinterpret_cast<uint32_t*>(p) = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    }
+};
 
-template <int CPL, int FE>
+template <int CPL, int FE, typename T>
 __global__ void __launch_bounds__(256) k_agg_fwd(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
                                                  const int32_t* __restrict__ eid, int64_t n_dst,
-                                                 const float* __restrict__ x, int64_t ldx, int c_in,
+                                                 const T* __restrict__ x, int64_t ldx, int c_in,
                                                  const float* __restrict__ ea, int64_t lde,
                                                  const float* __restrict__ We, const float* __restrict__ be,
-                                                 const float* __restrict__ phi, int64_t ldphi,
-                                                 float* __restrict__ phi_out, int64_t ldphi_out,
-                                                 float* __restrict__ a, int64_t lda) {
+                                                 const T* __restrict__ phi, int64_t ldphi,
+                                                 T* __restrict__ phi_out, int64_t ldphi_out,
+                                                 T* __restrict__ a, int64_t lda) {
     constexpr int NW = FE > 0 ? FE : 1;
     const int lane = lane_id();
     const int c0 = (blockIdx.y * 64 + lane) * CPL;
@@ -72,7 +100,7 @@ __global__ void __launch_bounds__(256) k_agg_fwd(const int32_t* __restrict__ row
         for (int k = beg; k < end; ++k) {
             const int s = src[k];
             const int64_t e = eid ? eid[k] : k;
-            Vec<CPL> xr;
+            Vec<CPL, T> xr;
             if (on) xr.load(x + (int64_t)s * ldx + c0);
             float p[CPL];
             if (FE > 0) {
@@ -88,13 +116,13 @@ __global__ void __launch_bounds__(256) k_agg_fwd(const int32_t* __restrict__ row
                     p[j] = t;
                 }
                 if (phi_out && on) {
-                    Vec<CPL> po;
+                    Vec<CPL, T> po;
 #pragma unroll
                     for (int j = 0; j < CPL; ++j) po.v[j] = p[j];
                     po.store(phi_out + e * ldphi_out + c0);
                 }
             } else if (FE == 0) {
-                Vec<CPL> pr;
+                Vec<CPL, T> pr;
                 if (on) pr.load(phi + e * ldphi + c0);
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) p[j] = pr.v[j];
@@ -110,7 +138,7 @@ __global__ void __launch_bounds__(256) k_agg_fwd(const int32_t* __restrict__ row
         }
         if (on) {
             const float cnt = (float)max(end - beg, 1);
-            Vec<CPL> o;
+            Vec<CPL, T> o;
 #pragma unroll
             for (int j = 0; j < CPL; ++j) o.v[j] = __fdiv_rn(acc[j], cnt);
             o.store(a + d * lda + c0);
@@ -123,15 +151,15 @@ __global__ void __launch_bounds__(256) k_agg_fwd(const int32_t* __restrict__ row
 // x_j = x.index_select(0, edge_index[0]).  Filter-weight gradients are kept per lane (CPL x (FE+1)
 // registers), reduced across the block's 4 waves through LDS in a fixed order and written as one
 // slab per block; k_reduce_slabs sums the slabs in block order (deterministic).
-template <int CPL, int FE>
+template <int CPL, int FE, typename T>
 __global__ void __launch_bounds__(256) k_agg_bwd(const int32_t* __restrict__ t_rowptr, const int32_t* __restrict__ t_dst,
                                                  const int32_t* __restrict__ t_eid, int64_t n_src,
-                                                 const int32_t* __restrict__ rowptr_dst, const float* __restrict__ x,
+                                                 const int32_t* __restrict__ rowptr_dst, const T* __restrict__ x,
                                                  int64_t ldx, int c_in, const float* __restrict__ ea, int64_t lde,
                                                  const float* __restrict__ We, const float* __restrict__ be,
-                                                 const float* __restrict__ phi, int64_t ldphi,
-                                                 const float* __restrict__ da, int64_t ldda, float* __restrict__ dx,
-                                                 int64_t lddx, float* __restrict__ dphi_out, int64_t lddphi,
+                                                 const T* __restrict__ phi, int64_t ldphi,
+                                                 const T* __restrict__ da, int64_t ldda, T* __restrict__ dx,
+                                                 int64_t lddx, T* __restrict__ dphi_out, int64_t lddphi,
                                                  float* __restrict__ slabs) {
     constexpr int NW = FE > 0 ? FE : 1;
     __shared__ float red[FE > 0 ? 4 * 64 * CPL * (FE + 1) : 1];
@@ -159,7 +187,7 @@ __global__ void __launch_bounds__(256) k_agg_bwd(const int32_t* __restrict__ t_r
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     for (int64_t s = wave; s < n_src; s += nwaves) {
         const int beg = t_rowptr[s], end = t_rowptr[s + 1];
-        Vec<CPL> xs;
+        Vec<CPL, T> xs;
 #pragma unroll
         for (int j = 0; j < CPL; ++j) xs.v[j] = 0.f;
         if (on && dx) {
@@ -173,7 +201,7 @@ __global__ void __launch_bounds__(256) k_agg_bwd(const int32_t* __restrict__ t_r
             const int d = t_dst[k];
             const int64_t e = t_eid[k];
             const float cnt = (float)max(rowptr_dst[d + 1] - rowptr_dst[d], 1);
-            Vec<CPL> g;
+            Vec<CPL, T> g;
             if (on) g.load(da + (int64_t)d * ldda + c0);
             float p[CPL];
             float A[NW];
@@ -189,7 +217,7 @@ __global__ void __launch_bounds__(256) k_agg_bwd(const int32_t* __restrict__ t_r
                     p[j] = t;
                 }
             } else if (FE == 0) {
-                Vec<CPL> pr;
+                Vec<CPL, T> pr;
                 if (on) pr.load(phi + e * ldphi + c0);
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) p[j] = pr.v[j];
@@ -198,7 +226,7 @@ __global__ void __launch_bounds__(256) k_agg_bwd(const int32_t* __restrict__ t_r
                 for (int j = 0; j < CPL; ++j) p[j] = 1.f;
             }
             if (on) {
-                Vec<CPL> dph;
+                Vec<CPL, T> dph;
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) {
                     const float dm = __fdiv_rn(g.v[j], cnt);
@@ -214,7 +242,7 @@ __global__ void __launch_bounds__(256) k_agg_bwd(const int32_t* __restrict__ t_r
             }
         }
         if (on && dx) {
-            Vec<CPL> o;
+            Vec<CPL, T> o;
 #pragma unroll
             for (int j = 0; j < CPL; ++j) o.v[j] = acc[j];
             o.store(dx + s * lddx + c0);
@@ -264,18 +292,15 @@ __global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ 
 
 constexpr int BWD_BLOCKS = 512;  // persistent-ish: 2 blocks per CU keeps the slab array small
 
-template <int CPL>
+template <int CPL, typename T = float>
 bool aligned_for(const void* p, int64_t ld) {
-    return CPL == 1 || (((uintptr_t)p % (sizeof(float) * CPL)) == 0 && ld % CPL == 0);
+    return CPL == 1 || (((uintptr_t)p % (sizeof(T) * CPL)) == 0 && ld % CPL == 0);
 }
 
-}  // namespace
-
-extern "C" int dgnn_sage_aggregate_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst,
-                                       const float* x_src, int64_t ldx, int c_in, const float* edge_attr, int64_t lde,
-                                       int f_e, const float* We, const float* be, const float* phi, int64_t ldphi,
-                                       float* phi_out, int64_t ldphi_out, float* a, int64_t lda, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+template <typename T>
+int agg_fwd_t(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const T* x_src, int64_t ldx, int c_in,
+              const float* edge_attr, int64_t lde, int f_e, const float* We, const float* be, const T* phi, int64_t ldphi, T* phi_out,
+              int64_t ldphi_out, T* a, int64_t lda, hipStream_t stream) {
     DGNN_REQUIRE(n_dst >= 0 && c_in > 0, DGNN_E_INVALID, "aggregate_fwd: bad sizes n_dst=%lld c_in=%d", (long long)n_dst, c_in);
     if (n_dst == 0) return DGNN_OK;
     DGNN_REQUIRE(rowptr && src && x_src && a, DGNN_E_INVALID, "aggregate_fwd: null pointer");
@@ -284,13 +309,13 @@ extern "C" int dgnn_sage_aggregate_fwd(const int32_t* rowptr, const int32_t* src
     DGNN_REQUIRE(!fused || f_e == 20 || f_e == 2, DGNN_E_UNSUPPORTED,
                  "aggregate_fwd: fused filter supports f_e in {2,20} (got %d); materialise phi with dgnn_linear_fwd", f_e);
     const bool given = !fused && phi != nullptr;
-    bool v2 = (c_in % 2 == 0) && c_in > 64 && aligned_for<2>(x_src, ldx) && aligned_for<2>(a, lda) &&
-              (!given || aligned_for<2>(phi, ldphi)) && (!phi_out || aligned_for<2>(phi_out, ldphi_out));
+    bool v2 = (c_in % 2 == 0) && (c_in > 64 || sizeof(T) == 2) && aligned_for<2, T>(x_src, ldx) && aligned_for<2, T>(a, lda) &&
+              (!given || aligned_for<2, T>(phi, ldphi)) && (!phi_out || aligned_for<2, T>(phi_out, ldphi_out));
     const int cpl = v2 ? 2 : 1;
     const int chunks = (int)dgnn_cdiv(c_in, 64 * cpl);
     dim3 grid(dgnn_grid_cap(dgnn_cdiv(n_dst, 4), 8), chunks), block(256);
 #define LAUNCH(CPL, FE)                                                                                               \
-    hipLaunchKernelGGL((k_agg_fwd<CPL, FE>), grid, block, 0, stream, rowptr, src, eid, n_dst, x_src, ldx, c_in, edge_attr, \
+    hipLaunchKernelGGL((k_agg_fwd<CPL, FE, T>), grid, block, 0, stream, rowptr, src, eid, n_dst, x_src, ldx, c_in, edge_attr, \
                        lde, We, be, phi, ldphi, phi_out, ldphi_out, a, lda)
     if (fused && f_e == 20) { if (v2) LAUNCH(2, 20); else LAUNCH(1, 20); }
     else if (fused && f_e == 2) { if (v2) LAUNCH(2, 2); else LAUNCH(1, 2); }
@@ -298,6 +323,59 @@ extern "C" int dgnn_sage_aggregate_fwd(const int32_t* rowptr, const int32_t* src
     else { if (v2) LAUNCH(2, -1); else LAUNCH(1, -1); }
 #undef LAUNCH
     return dgnn_check_launch("aggregate_fwd");
+}
+
+template <typename T>
+int agg_bwd_t(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, int64_t n_src, const int32_t* rowptr_dst,
+              const T* x_src, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e, const float* We, const float* be,
+              const T* phi, int64_t ldphi, const T* da, int64_t ldda, T* dx_src, int64_t lddx, float* dWe, float* dbe, T* dphi_out,
+              int64_t lddphi, float* partials, hipStream_t stream) {
+    DGNN_REQUIRE(n_src >= 0 && c_in > 0, DGNN_E_INVALID, "aggregate_bwd: bad sizes");
+    if (n_src == 0) return DGNN_OK;
+    DGNN_REQUIRE(t_rowptr && t_dst && t_eid && rowptr_dst && x_src && da, DGNN_E_INVALID, "aggregate_bwd: null pointer");
+    const bool fused = We != nullptr;
+    DGNN_REQUIRE(!fused || (be && edge_attr && dWe && dbe && partials), DGNN_E_INVALID, "aggregate_bwd: fused mode needs be, edge_attr, dWe, dbe, partials");
+    DGNN_REQUIRE(!fused || f_e == 20 || f_e == 2, DGNN_E_UNSUPPORTED, "aggregate_bwd: fused filter supports f_e in {2,20} (got %d)", f_e);
+    const bool given = !fused && phi != nullptr;
+    bool v2 = (c_in % 2 == 0) && (c_in > 64 || sizeof(T) == 2) && aligned_for<2, T>(x_src, ldx) && aligned_for<2, T>(da, ldda) &&
+              (!dx_src || aligned_for<2, T>(dx_src, lddx)) && (!given || aligned_for<2, T>(phi, ldphi)) &&
+              (!dphi_out || aligned_for<2, T>(dphi_out, lddphi));
+    const int cpl = v2 ? 2 : 1;
+    const int chunks = (int)dgnn_cdiv(c_in, 64 * cpl);
+    const int nblocks = (int)(dgnn_cdiv(n_src, 4) < BWD_BLOCKS ? dgnn_cdiv(n_src, 4) : BWD_BLOCKS);
+    dim3 grid(nblocks, chunks), block(256);
+#define LAUNCH(CPL, FE)                                                                                               \
+    hipLaunchKernelGGL((k_agg_bwd<CPL, FE, T>), grid, block, 0, stream, t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, ldx, \
+                       c_in, edge_attr, lde, We, be, phi, ldphi, da, ldda, dx_src, lddx, dphi_out, lddphi, partials)
+    if (fused && f_e == 20) { if (v2) LAUNCH(2, 20); else LAUNCH(1, 20); }
+    else if (fused && f_e == 2) { if (v2) LAUNCH(2, 2); else LAUNCH(1, 2); }
+    else if (given) { if (v2) LAUNCH(2, 0); else LAUNCH(1, 0); }
+    else { if (v2) LAUNCH(2, -1); else LAUNCH(1, -1); }
+#undef LAUNCH
+    if (fused) {
+        const int per = 64 * cpl * (f_e + 1);
+        hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)dgnn_cdiv((int64_t)chunks * per, 16)), dim3(256), 0, stream, partials,
+                           nblocks, chunks, per, c_in, f_e, cpl, dWe, dbe);
+    }
+    return dgnn_check_launch("aggregate_bwd");
+}
+
+}  // namespace
+
+extern "C" int dgnn_sage_aggregate_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst,
+                                       const float* x_src, int64_t ldx, int c_in, const float* edge_attr, int64_t lde,
+                                       int f_e, const float* We, const float* be, const float* phi, int64_t ldphi,
+                                       float* phi_out, int64_t ldphi_out, float* a, int64_t lda, void* stream) {
+    return agg_fwd_t<float>(rowptr, src, eid, n_dst, x_src, ldx, c_in, edge_attr, lde, f_e, We, be, phi, ldphi, phi_out, ldphi_out, a, lda,
+                            (hipStream_t)stream);
+}
+
+extern "C" int dgnn_sage_aggregate_fwd_bf16(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst,
+                                            const uint16_t* x_src, int64_t ldx, int c_in, const float* edge_attr, int64_t lde,
+                                            int f_e, const float* We, const float* be, const uint16_t* phi, int64_t ldphi,
+                                            uint16_t* phi_out, int64_t ldphi_out, uint16_t* a, int64_t lda, void* stream) {
+    return agg_fwd_t<uint16_t>(rowptr, src, eid, n_dst, x_src, ldx, c_in, edge_attr, lde, f_e, We, be, phi, ldphi, phi_out, ldphi_out, a, lda,
+                               (hipStream_t)stream);
 }
 
 extern "C" int64_t dgnn_sage_aggregate_bwd_scratch_elems(int64_t n_src, int c_in, int f_e) {
@@ -313,34 +391,17 @@ extern "C" int dgnn_sage_aggregate_bwd(const int32_t* t_rowptr, const int32_t* t
                                        const float* edge_attr, int64_t lde, int f_e, const float* We, const float* be,
                                        const float* phi, int64_t ldphi, const float* da, int64_t ldda, float* dx_src,
                                        int64_t lddx, float* dWe, float* dbe, float* dphi_out, int64_t lddphi,
-                                       float* partials, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    DGNN_REQUIRE(n_src >= 0 && c_in > 0, DGNN_E_INVALID, "aggregate_bwd: bad sizes");
-    if (n_src == 0) return DGNN_OK;
-    DGNN_REQUIRE(t_rowptr && t_dst && t_eid && rowptr_dst && x_src && da, DGNN_E_INVALID, "aggregate_bwd: null pointer");
-    const bool fused = We != nullptr;
-    DGNN_REQUIRE(!fused || (be && edge_attr && dWe && dbe && partials), DGNN_E_INVALID, "aggregate_bwd: fused mode needs be, edge_attr, dWe, dbe, partials");
-    DGNN_REQUIRE(!fused || f_e == 20 || f_e == 2, DGNN_E_UNSUPPORTED, "aggregate_bwd: fused filter supports f_e in {2,20} (got %d)", f_e);
-    const bool given = !fused && phi != nullptr;
-    bool v2 = (c_in % 2 == 0) && c_in > 64 && aligned_for<2>(x_src, ldx) && aligned_for<2>(da, ldda) &&
-              (!dx_src || aligned_for<2>(dx_src, lddx)) && (!given || aligned_for<2>(phi, ldphi)) &&
-              (!dphi_out || aligned_for<2>(dphi_out, lddphi));
-    const int cpl = v2 ? 2 : 1;
-    const int chunks = (int)dgnn_cdiv(c_in, 64 * cpl);
-    const int nblocks = (int)(dgnn_cdiv(n_src, 4) < BWD_BLOCKS ? dgnn_cdiv(n_src, 4) : BWD_BLOCKS);
-    dim3 grid(nblocks, chunks), block(256);
-#define LAUNCH(CPL, FE)                                                                                               \
-    hipLaunchKernelGGL((k_agg_bwd<CPL, FE>), grid, block, 0, stream, t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, ldx, \
-                       c_in, edge_attr, lde, We, be, phi, ldphi, da, ldda, dx_src, lddx, dphi_out, lddphi, partials)
-    if (fused && f_e == 20) { if (v2) LAUNCH(2, 20); else LAUNCH(1, 20); }
-    else if (fused && f_e == 2) { if (v2) LAUNCH(2, 2); else LAUNCH(1, 2); }
-    else if (given) { if (v2) LAUNCH(2, 0); else LAUNCH(1, 0); }
-    else { if (v2) LAUNCH(2, -1); else LAUNCH(1, -1); }
-#undef LAUNCH
-    if (fused) {
-        const int per = 64 * cpl * (f_e + 1);
-        hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)dgnn_cdiv((int64_t)chunks * per, 16)), dim3(256), 0, stream, partials,
-                           nblocks, chunks, per, c_in, f_e, cpl, dWe, dbe);
-    }
-    return dgnn_check_launch("aggregate_bwd");
+                                       float* partials, void* stream) {
+    return agg_bwd_t<float>(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, ldx, c_in, edge_attr, lde, f_e, We, be, phi, ldphi, da, ldda,
+                            dx_src, lddx, dWe, dbe, dphi_out, lddphi, partials, (hipStream_t)stream);
+}
+
+extern "C" int dgnn_sage_aggregate_bwd_bf16(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid,
+                                            int64_t n_src, const int32_t* rowptr_dst, const uint16_t* x_src, int64_t ldx, int c_in,
+                                            const float* edge_attr, int64_t lde, int f_e, const float* We, const float* be,
+                                            const uint16_t* phi, int64_t ldphi, const uint16_t* da, int64_t ldda, uint16_t* dx_src,
+                                            int64_t lddx, float* dWe, float* dbe, uint16_t* dphi_out, int64_t lddphi,
+                                            float* partials, void* stream) {
+    return agg_bwd_t<uint16_t>(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, ldx, c_in, edge_attr, lde, f_e, We, be, phi, ldphi, da, ldda,
+                               dx_src, lddx, dWe, dbe, dphi_out, lddphi, partials, (hipStream_t)stream);
 }

@@ -68,3 +68,15 @@ static inline int dgnn_grid_cap(int64_t blocks, int per_cu = 8) {
 
 __device__ __forceinline__ int wave_id_uniform() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// ---- element access for the two storage types: float (fp32) and uint16_t (bf16 bit patterns) --------------------------------
+// bf16 storage: widen on load, round to nearest even on store; everything in between is fp32 arithmetic.
+__device__ __forceinline__ float dgnn_ld(const float* p) { return *p; }
+__device__ __forceinline__ float dgnn_ld(const uint16_t* p) { return __builtin_bit_cast(float, (uint32_t)(*p) << 16); }
+__device__ __forceinline__ void dgnn_st(float* p, float v) { *p = v; }
+__device__ __forceinline__ void dgnn_st(uint16_t* p, float v) {
+    typedef __bf16 dgnn_bf2 __attribute__((ext_vector_type(2)));
+    typedef float dgnn_f2 __attribute__((ext_vector_type(2)));
+    const dgnn_bf2 h = __builtin_convertvector(dgnn_f2{v, 0.f}, dgnn_bf2);
+    *p = (uint16_t)(__builtin_bit_cast(uint32_t, h) & 0xFFFFu);
+}

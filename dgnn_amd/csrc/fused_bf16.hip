@@ -1,0 +1,564 @@
+// Fused SAGE inference layer with bf16 STORAGE (BASELINE config 3 / SURVEY 7 step 7): activations live in HBM as bf16,
+// every product runs ONCE on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16 for the filter MLP, v_mfma_f32_32x32x16_bf16
+// for the dense part) with fp32 accumulation; parameters stay fp32 in HBM (master weights) and are rounded to bf16 when a
+// workgroup stages them.  Stated tolerance of this path: |dlogit| <= 5e-2 * max(1, |logit| / 8), arg-max agreement >= 99.9 %
+// against the fp32 reference; it is NOT the fp32-class path of fused_mfma.hip.
+//
+// Same two-phase, one-barrier-per-tile loop as fused_mfma.hip, but with a third of the matrix work and no operand splits the
+// layer is HBM-bound, so the shape is chosen for bytes in flight instead of issue slots:
+//   * four-wave workgroups with the full K per wave (no partial-sum exchange).  Resident weights are K/16 x 4 VGPRs
+//     (64 at C_in = 128), LDS 50 KB at 128 -> 128: three workgroups share a CU, each with its own barrier;
+//   * a tile's rows (4 neighbour rows + own row per tet, 2*C_in bytes each) are issued one tile ahead as 16-byte loads and
+//     land under the dense phase; edge-attribute rows (fp32, the caller's tensor, read in place through the plan's eid)
+//     arrive by LDS-DMA exactly as in the fp32 kernel;
+//   * the filter product's C/D layout again leaves the 4 in-edges of a tet in the 4 accumulator registers of one lane:
+//     in-order fp32 sum over the gathered rows (unpacked bf16), x 0.25, rounded to bf16 into the LDS A-tile next to the tet's
+//     own row (copied as is);
+//   * epilogue: bias / BatchNorm(eval) / ReLU in fp32, neighbouring columns exchanged by DPP so that every lane stores one
+//     4-byte pair (2 bf16) -- 64-byte row segments per half-wave instead of 2-byte scatters.
+// Algorithmic bytes per tet: 2*C_in (own row) + 320 (4 attribute rows) + 16 (4 source ids) + 2*C_out.
+#include "fused_common.h"
+
+namespace {
+using namespace fused;
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int CIN_PAD, int COUT, int NW = 4>
+struct CfgB {
+    static constexpr int K = 2 * CIN_PAD;
+    static constexpr int NSLICE = COUT / 32;
+    static constexpr int RG = NW / NSLICE;
+    static constexpr int TILE = 32 * RG;
+    static constexpr int ROWB = K * 2 + 16;               // A-tile row: K bf16 + 16 B pad (odd number of 16-B slots)
+    static constexpr int A_BYTES = TILE * ROWB;
+    static constexpr int TPW = TILE / NW;                 // tets per wave (8 or 16)
+    static constexpr int RB = TPW / 4;                    // 16-edge row blocks per wave
+    static constexpr int NQ = TPW * 4;                    // edges per wave
+    static constexpr int NB = CIN_PAD / 16;               // contiguous channels per lane (8, 4, 2)
+    static constexpr int EA_BYTES = NQ * FE * 4;
+    static constexpr int EA_FULL = EA_BYTES / 1024, EA_TAIL = (EA_BYTES % 1024) / 256;
+    static constexpr int BP_BYTES = NB * 768;             // [cb][g<3][j<16] x 16 B filter operand
+    static constexpr int SMEM_BYTES = 2 * A_BYTES + NW * EA_BYTES + BP_BYTES;
+    static constexpr int NWB = K / 16;                    // dense part: k-steps of 16 (full K per wave)
+    static_assert(RG >= 1 && NQ <= 64 && EA_BYTES % 256 == 0, "wave roles");
+};
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    const bf16x2_t h = __builtin_convertvector(f32x2_t{a, b}, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
+__device__ __forceinline__ float bf16_round(float v) { return bf_lo(pack_bf16(v, 0.f)); }
+
+// NB bf16 = NB/2 dwords per lane
+template <int NB>
+__device__ __forceinline__ void ld_bf(uint32_t (&v)[NB / 2], const uint16_t* p) {
+    if (NB == 8) {
+        const uint4 a = *reinterpret_cast<const uint4*>(p);
+        v[0] = a.x; v[1 % (NB / 2)] = a.y; v[2 % (NB / 2)] = a.z; v[3 % (NB / 2)] = a.w;
+    } else if (NB == 4) {
+        const uint2 a = *reinterpret_cast<const uint2*>(p);
+        v[0] = a.x; v[1 % (NB / 2)] = a.y;
+    } else {
+        v[0] = *reinterpret_cast<const uint32_t*>(p);
+    }
+}
+
+template <int CIN_PAD, int COUT, int NW, int OCC>
+__global__ void __launch_bounds__(64 * NW, OCC)
+k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid, int64_t n_dst,
+                  const uint16_t* __restrict__ x, const uint16_t* __restrict__ xdst, int64_t ldx, int c_in, const float* __restrict__ ea,
+                  int64_t lde, const float* __restrict__ We, const float* __restrict__ be, const float* __restrict__ Wj,
+                  const float* __restrict__ bj, const float* __restrict__ Wi, const float* __restrict__ scale,
+                  const float* __restrict__ shift, int relu, uint16_t* __restrict__ out, int64_t ldo, int64_t ntiles) {
+    using C = CfgB<CIN_PAD, COUT, NW>;
+    constexpr int ROWB = C::ROWB, TILE = C::TILE, TPW = C::TPW, RB = C::RB, NB = C::NB, NWB = C::NWB, NH = NB / 2;
+    extern __shared__ __attribute__((aligned(16))) char smemb[];
+    char* const abuf = smemb;                                        // [2][A_BYTES]
+    char* const eabuf = smemb + 2 * C::A_BYTES;                      // [NW][EA_BYTES] fp32 attribute strips
+    char* const bpbuf = eabuf + NW * C::EA_BYTES;                    // filter operand (bf16)
+
+    const int lane = lane_id(), w = wave_id_uniform();
+    const int h = lane >> 5, l31 = lane & 31;
+    const int jcol = lane & 15, tq = lane >> 4;
+    const int ldx32 = (int)ldx;
+
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wg_per_xcd = (nwg + 7 - xcd) >> 3;
+    const int64_t per = (ntiles + 7) / 8;
+    const int64_t t_lo = xcd * per, t_hi = min(ntiles, t_lo + per);
+    int64_t my_n = 0;
+    if (t_lo + slot < t_hi) my_n = (t_hi - t_lo - slot + wg_per_xcd - 1) / wg_per_xcd;
+    auto tile_of = [&](int64_t it) { return t_lo + slot + it * wg_per_xcd; };
+
+    // ---- filter operand B = [We^T ; be ; 0] as bf16 -> LDS; entry (cb, g, j): channel c = NB*j + cb, k = 8g .. 8g+7
+    for (int e = threadIdx.x; e < NB * 48; e += blockDim.x) {
+        const int cb = e / 48, gj = e - cb * 48, g = gj >> 4, j = gj & 15;
+        const int c = NB * j + cb;
+        uint32_t p[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            float v[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = 8 * g + 2 * d + u;
+                v[u] = 0.f;
+                if (c < c_in) v[u] = k < FE ? We[(int64_t)c * FE + k] : (k == FE ? be[c] : 0.f);
+            }
+            p[d] = pack_bf16(v[0], v[1]);
+        }
+        *reinterpret_cast<uint4*>(bpbuf + (cb * 48 + gj) * 16) = make_uint4(p[0], p[1], p[2], p[3]);
+    }
+
+    // ---- dense-phase role: (column slice cs, row group rg); the whole K of this slice resident as bf16
+    const int cs = w % C::NSLICE, rg = w / C::NSLICE;
+    const int col = cs * 32 + l31;
+    bf16x8 wb[NWB];
+#pragma unroll
+    for (int S = 0; S < NWB; ++S) {
+        const bool second = S >= CIN_PAD / 16;                       // k-steps of the own-row half use Wi
+        const float* Wsrc = second ? Wi : Wj;
+        const int S_ = second ? S - CIN_PAD / 16 : S;
+        uint32_t p[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int k = 16 * S_ + 8 * h + 2 * d;
+            const float v0 = Wsrc[(int64_t)col * c_in + (k < c_in ? k : 0)];
+            const float v1 = Wsrc[(int64_t)col * c_in + (k + 1 < c_in ? k + 1 : 0)];
+            p[d] = pack_bf16(k < c_in ? v0 : 0.f, k + 1 < c_in ? v1 : 0.f);
+        }
+        wb[S] = pack8(p);
+    }
+    const float bb = bj ? bj[col] : 0.f;
+    const float sc = scale ? scale[col] : 1.f;
+    const float sh = scale ? shift[col] : 0.f;
+    const bool has_scale = scale != nullptr;
+    __syncthreads();
+
+    // ---- filter-phase role
+    const int c0 = NB * jcol;
+    const bool on = c0 < c_in;
+    const int c0l = on ? c0 : 0;
+    float* const myea = reinterpret_cast<float*>(eabuf + w * C::EA_BYTES);
+
+    uint32_t xd[RB][NH], xr[RB][4][NH];
+    bool regular = false;
+    int vbeg1 = 0, vbeg2 = 0, vsrc1 = 0, veid1 = 0;
+    bool ok1 = false, ok2 = false;
+    int nv1 = 0, nv2 = 0;
+
+    auto load_rowptr = [&](int64_t it, int& vb, int& nv) -> bool {
+        if (it >= my_n) return false;
+        const int64_t i0 = tile_of(it) * TILE + w * TPW;
+        if (i0 >= n_dst) return false;
+        nv = (int)(n_dst - i0 < TPW ? n_dst - i0 : TPW);
+        vb = rowptr[i0 + (lane < nv ? lane : nv)];
+        return true;
+    };
+    auto load_src = [&]() {
+        if (ok1) {
+            const int b0 = __builtin_amdgcn_readfirstlane(vbeg1);
+            ok1 = __all(vbeg1 == b0 + 4 * (lane < nv1 ? lane : nv1)) != 0;
+            if (ok1) {
+                vsrc1 = src[b0 + (lane < 4 * nv1 ? lane : 4 * nv1 - 1)];
+                if (eid) veid1 = eid[b0 + (lane < 4 * nv1 ? lane : 4 * nv1 - 1)];
+            }
+        }
+    };
+    auto issue_loads = [&](int64_t it) {
+        regular = ok1;
+        if (regular) {
+            const int i0 = (int)(tile_of(it) * TILE) + w * TPW;
+            const float* eab = ea + (int64_t)__builtin_amdgcn_readfirstlane(vbeg1) * lde;
+            const int ea_last = nv1 * 4 * FE - 4;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int tl = rb * 4 + tq;
+                ld_bf<NB>(xd[rb], xdst + (uint32_t)((i0 + (tl < nv1 ? tl : nv1 - 1)) * ldx32) + c0l);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int s_ = __shfl(vsrc1, tl * 4 + r);
+                    ld_bf<NB>(xr[rb][r], x + (uint32_t)(s_ * ldx32) + c0l);
+                }
+            }
+            if (eid) {
+                auto row_ptr = [&](int fi) -> const float* {
+                    const int e = (fi * 0xCCD) >> 16;             // fi / 20 for fi < 8192
+                    return ea + (int64_t)__shfl(veid1, e) * FE + (fi - e * FE);
+                };
+#pragma unroll
+                for (int q = 0; q < C::EA_FULL; ++q) glds16(row_ptr(q * 256 + lane * 4), myea + q * 256);
+#pragma unroll
+                for (int q = 0; q < C::EA_TAIL; ++q) glds4(row_ptr(C::EA_FULL * 256 + q * 64 + lane), myea + C::EA_FULL * 256 + q * 64);
+            } else {
+#pragma unroll
+                for (int q = 0; q < C::EA_FULL; ++q) glds16(eab + min(q * 256 + lane * 4, ea_last), myea + q * 256);
+#pragma unroll
+                for (int q = 0; q < C::EA_TAIL; ++q)
+                    glds4(eab + min(C::EA_FULL * 256 + q * 64 + lane, ea_last + 3), myea + C::EA_FULL * 256 + q * 64);
+            }
+        }
+    };
+    auto advance_idx = [&](int64_t it_next) {
+        ok1 = ok2;
+        vbeg1 = vbeg2;
+        nv1 = nv2;
+        load_src();
+        ok2 = load_rowptr(it_next + 1, vbeg2, nv2);
+    };
+    // one finished (tet row, NB channels) segment -> A-tile: bf16 columns [c0, c0+NB) of the mean half and of the own-row half
+    auto put_seg = [&](int buf, int row, const uint32_t (&av)[NH], const uint32_t (&xv)[NH]) {
+        char* dst = abuf + buf * C::A_BYTES + row * ROWB + c0 * 2;
+        char* dsx = dst + CIN_PAD * 2;
+        if (NB == 8) {
+            *reinterpret_cast<uint4*>(dst) = make_uint4(av[0], av[1 % NH], av[2 % NH], av[3 % NH]);
+            *reinterpret_cast<uint4*>(dsx) = make_uint4(xv[0], xv[1 % NH], xv[2 % NH], xv[3 % NH]);
+        } else if (NB == 4) {
+            *reinterpret_cast<uint2*>(dst) = make_uint2(av[0], av[1 % NH]);
+            *reinterpret_cast<uint2*>(dsx) = make_uint2(xv[0], xv[1 % NH]);
+        } else {
+            *reinterpret_cast<uint32_t*>(dst) = av[0];
+            *reinterpret_cast<uint32_t*>(dsx) = xv[0];
+        }
+    };
+
+    ok1 = load_rowptr(0, vbeg1, nv1);
+    load_src();
+    ok2 = load_rowptr(1, vbeg2, nv2);
+    issue_loads(0);
+
+    for (int64_t it = 0; it < my_n; ++it) {
+        // ================================================================ P: filter on the matrix cores + mean
+        const int64_t i0 = tile_of(it) * TILE + w * TPW;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // rows + LDS-DMA'd strip of this tile
+        const bool was_regular = regular;
+        advance_idx(it + 1);
+        if (was_regular) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                // A operand: lane (edge i = lane&15, k-group g = lane>>4) holds attributes 8g..8g+7 of its edge as bf16;
+                // k = 20 is the constant 1 multiplying the bias row, everything beyond is 0
+                const float* er = myea + (rb * 16 + jcol) * FE;
+                const f32x4_t q0 = *reinterpret_cast<const f32x4_t*>(er + 8 * (tq < 2 ? tq : 2));
+                const f32x4_t q1 = *reinterpret_cast<const f32x4_t*>(er + 8 * (tq < 1 ? tq : 1) + 4);
+                float av[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    av[i] = tq < 3 ? q0[i] : 0.f;
+                    av[4 + i] = tq < 2 ? q1[i] : 0.f;
+                }
+                if (tq == 2) av[4] = 1.0f;
+                uint32_t pa[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) pa[d] = pack_bf16(av[2 * d], av[2 * d + 1]);
+                const bf16x8 aop = pack8(pa);
+
+                uint32_t aout[NH];
+                float prev = 0.f;
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb) {
+                    const uint4 u0 = *reinterpret_cast<const uint4*>(bpbuf + (cb * 48 + (tq < 3 ? tq : 0) * 16 + jcol) * 16);
+                    f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aop, __builtin_bit_cast(bf16x8, u0), d, 0, 0, 0);
+                    // d[r] = phi of the r-th in-edge of this lane's tet, channel c0 + cb; in-order sum over the 4 in-edges
+                    const uint32_t w0 = xr[rb][0][cb >> 1], w1 = xr[rb][1][cb >> 1], w2 = xr[rb][2][cb >> 1], w3 = xr[rb][3][cb >> 1];
+                    float a = __fmul_rn((cb & 1) ? bf_hi(w0) : bf_lo(w0), d[0]);
+                    a = __fmaf_rn((cb & 1) ? bf_hi(w1) : bf_lo(w1), d[1], a);
+                    a = __fmaf_rn((cb & 1) ? bf_hi(w2) : bf_lo(w2), d[2], a);
+                    a = __fmaf_rn((cb & 1) ? bf_hi(w3) : bf_lo(w3), d[3], a);
+                    a *= 0.25f;
+                    if (cb & 1) aout[cb >> 1] = pack_bf16(prev, a);
+                    else prev = a;
+                }
+                put_seg((int)(it & 1), w * TPW + rb * 4 + tq, aout, xd[rb]);
+            }
+        } else {
+            // generic path (a group with any in-degree other than 4, or past the end): per lane, one edge at a time (rare).
+            // Operands are rounded to bf16 like the matrix-core path, products and sums are fp32.
+#pragma unroll 1
+            for (int rb = 0; rb < RB; ++rb) {
+                const int64_t i = i0 + rb * 4 + tq;
+                float af[NB];
+                uint32_t aout[NH], xv[NH];
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb) af[cb] = 0.f;
+#pragma unroll
+                for (int q = 0; q < NH; ++q) xv[q] = 0u;
+                if (i < n_dst && on) {
+                    const int b = rowptr[i], e_end = rowptr[i + 1];
+                    ld_bf<NB>(xv, xdst + i * ldx + c0);
+                    for (int k = b; k < e_end; ++k) {
+                        const int s_ = src[k];
+                        const float* ar = ea + (int64_t)(eid ? eid[k] : k) * lde;
+                        uint32_t xs[NH];
+                        ld_bf<NB>(xs, x + (int64_t)s_ * ldx + c0);
+#pragma unroll 1
+                        for (int cb = 0; cb < NB; ++cb) {
+                            float p = 0.f;
+                            if (c0 + cb < c_in) {
+                                p = bf16_round(be[c0 + cb]);
+                                for (int f = 0; f < FE; ++f) p = __fmaf_rn(bf16_round(We[(int64_t)(c0 + cb) * FE + f]), bf16_round(ar[f]), p);
+                            }
+                            const uint32_t wv = xs[cb >> 1];
+                            af[cb] = __fadd_rn(af[cb], __fmul_rn((cb & 1) ? bf_hi(wv) : bf_lo(wv), p));
+                        }
+                    }
+                    const float cnt = (float)max(e_end - b, 1);
+#pragma unroll
+                    for (int cb = 0; cb < NB; ++cb) af[cb] = __fdiv_rn(af[cb], cnt);
+                }
+#pragma unroll
+                for (int q = 0; q < NH; ++q) aout[q] = pack_bf16(af[2 * q], af[2 * q + 1]);
+                put_seg((int)(it & 1), w * TPW + rb * 4 + tq, aout, xv);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // strip reads returned before the next DMA may land
+        asm volatile("" : "+v"(vbeg2), "+v"(vsrc1), "+v"(vbeg1), "+v"(veid1));
+        issue_loads(it + 1);
+        tile_barrier();  // A-tile `it` complete
+
+        // ================================================================ C: dense part, one bf16 product per k-step, full K
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const char* A = abuf + (it & 1) * C::A_BYTES + (rg * 32 + l31) * ROWB + h * 16;
+#pragma unroll
+        for (int S = 0; S < NWB; ++S) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + S * 32);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wb[S], acc, 0, 0, 0);
+        }
+        // epilogue: row (r&3) + 8(r>>2) + 4h, column `col`; columns (col, col^1) of one row pair up into a 4-byte store:
+        // even lanes store row r of the pair, odd lanes row r+1
+        const int64_t tile = tile_of(it);
+        const int64_t row0 = tile * TILE + rg * 32 + 4 * h;
+        const bool full = (tile + 1) * TILE <= n_dst;
+        const int odd = lane & 1;
+        uint16_t* o = out + row0 * ldo + (col & ~1);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            float v0 = acc[r] + bb, v1 = acc[r + 1] + bb;
+            if (has_scale) { v0 = __fmaf_rn(v0, sc, sh); v1 = __fmaf_rn(v1, sc, sh); }
+            if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+            const float n0 = __shfl_xor(v0, 1), n1 = __shfl_xor(v1, 1);
+            const uint32_t pk = odd ? pack_bf16(n1, v1) : pack_bf16(v0, n0);
+            const int rr = (r & 3) + 8 * (r >> 2) + odd;
+            if (full || row0 + rr < n_dst) *reinterpret_cast<uint32_t*>(o + (int64_t)rr * ldo) = pk;
+        }
+    }
+}
+
+template <int CIN_PAD, int COUT, int OCC>
+int launch_b(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const uint16_t* x, const uint16_t* xdst, int64_t ldx,
+             int c_in, const float* ea, int64_t lde, const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
+             const float* scale, const float* shift, int relu, uint16_t* out, int64_t ldo, hipStream_t stream) {
+    constexpr int NW = 4;
+    using C = CfgB<CIN_PAD, COUT, NW>;
+    const int64_t ntiles = dgnn_cdiv(n_dst, C::TILE);
+    const size_t smem = C::SMEM_BYTES;
+    static bool attr_set[DGNN_MAX_DEVICES] = {};
+    dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_bf16<CIN_PAD, COUT, NW, OCC>), smem, attr_set);
+    const int per_cu = (int)(160 * 1024 / smem) < OCC ? (int)(160 * 1024 / smem) : OCC;
+    const int wg_max = DGNN_NUM_CU * (per_cu < 1 ? 1 : per_cu);
+    int grid = (int)(ntiles < wg_max ? ntiles : wg_max);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((k_sage_fused_bf16<CIN_PAD, COUT, NW, OCC>), dim3(grid), dim3(64 * NW), smem, stream, rowptr, src, eid, n_dst, x, xdst,
+                       ldx, c_in, ea, lde, We, be, Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles);
+    return dgnn_check_launch("sage_layer_fused_fwd_bf16");
+}
+
+// out[r, c] = bf16(in[r, c]) for c < cols, 0 for cols <= c < cols_pad (row stride ld_out >= cols_pad)
+__global__ void k_cast_f32_bf16(const float* __restrict__ in, int64_t ld_in, int64_t n, int cols, int cols_pad,
+                                uint16_t* __restrict__ out, int64_t ld_out) {
+    const int64_t total = n * (cols_pad / 2);
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / (cols_pad / 2);
+        const int c = (int)(t - r * (cols_pad / 2)) * 2;
+        const float a = c < cols ? in[r * ld_in + c] : 0.f, b = c + 1 < cols ? in[r * ld_in + c + 1] : 0.f;
+        *reinterpret_cast<uint32_t*>(out + r * ld_out + c) = pack_bf16(a, b);
+    }
+}
+
+__global__ void k_cast_bf16_f32(const uint16_t* __restrict__ in, int64_t ld_in, int64_t n, int cols, float* __restrict__ out,
+                                int64_t ld_out) {
+    const int64_t total = n * cols;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / cols;
+        const int c = (int)(t - r * cols);
+        out[r * ld_out + c] = __builtin_bit_cast(float, (uint32_t)in[r * ld_in + c] << 16);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused decoder on bf16 activations (reference :180-187 applied at :350-351): logits = W3 . relu((W0 . y + b0)*scale + shift) + b3.
+// 8 independent wavefronts per workgroup, each streams its own 32-row tiles: a y row segment of 8 bf16 IS the MFMA
+// A operand of its lane (row l31, k-group g), so rows go global -> registers -> matrix core with no staging; W0 (bf16) is
+// parked in LDS in B-operand order once per workgroup; the 32 x 64 hidden tile goes through a wave-private LDS strip and
+// lane (row, o) finishes logit o with 64 fp32 FMAs.  Reads 2*K bytes per row, writes 4*n_out (logits stay fp32).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int HIDB = 64;
+
+template <int K>
+__global__ void __launch_bounds__(512) k_decoder_rows_bf16(const uint16_t* __restrict__ y, int64_t ldy, int64_t M,
+                                                           const float* __restrict__ W0, const float* __restrict__ b0,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ W3, const float* __restrict__ b3, int n_out,
+                                                           float* __restrict__ out, int64_t ldo) {
+    constexpr int NS = K / 16, LDH = HIDB + 4;
+    extern __shared__ __attribute__((aligned(16))) char dsmb[];
+    uint4* const Bs = reinterpret_cast<uint4*>(dsmb);                         // [2 col blocks][NS][64 lanes] x 16 B
+    float* const W3s = reinterpret_cast<float*>(dsmb + 2 * NS * 64 * 16);     // [2][HIDB]
+    float* const Hall = W3s + 2 * HIDB;                                       // [8 waves][32][LDH]
+    const int lane = lane_id(), w = wave_id_uniform();
+    const int g = lane >> 5, l31 = lane & 31;
+    for (int e = threadIdx.x; e < 2 * NS * 64; e += blockDim.x) {
+        const int ln = e & 63, S = (e >> 6) % NS, cblk = e / (64 * NS);
+        const float* wr = W0 + (int64_t)(cblk * 32 + (ln & 31)) * K + 16 * S + 8 * (ln >> 5);
+        Bs[(cblk * NS + S) * 64 + ln] = make_uint4(pack_bf16(wr[0], wr[1]), pack_bf16(wr[2], wr[3]), pack_bf16(wr[4], wr[5]), pack_bf16(wr[6], wr[7]));
+    }
+    for (int e = threadIdx.x; e < 2 * HIDB; e += blockDim.x) W3s[e] = (e / HIDB) < n_out ? W3[e] : 0.f;
+    float bb[2], sc[2], sh[2];
+#pragma unroll
+    for (int cblk = 0; cblk < 2; ++cblk) {
+        const int col = cblk * 32 + l31;
+        bb[cblk] = b0 ? b0[col] : 0.f;
+        sc[cblk] = scale ? scale[col] : 1.f;
+        sh[cblk] = scale ? shift[col] : 0.f;
+    }
+    const bool has_scale = scale != nullptr;
+    const int po = g;
+    const float b3v = (b3 && po < n_out) ? b3[po] : 0.f;
+    float* const Hs = Hall + w * 32 * LDH;
+    __syncthreads();
+
+    const int64_t ntiles = (M + 31) / 32, stride = (int64_t)gridDim.x * 8;
+    uint4 a[NS], an[NS];
+    auto row_ptr = [&](int64_t tile) {
+        const int64_t r = tile * 32 + l31;
+        return y + (r < M ? r : M - 1) * ldy + 8 * g;
+    };
+    int64_t tile = (int64_t)blockIdx.x * 8 + w;
+    if (tile < ntiles) {
+        const uint16_t* p = row_ptr(tile);
+#pragma unroll
+        for (int S = 0; S < NS; ++S) a[S] = *reinterpret_cast<const uint4*>(p + 16 * S);
+    }
+    for (; tile < ntiles; tile += stride) {
+        const bool more = tile + stride < ntiles;
+        const uint16_t* pn = row_ptr(more ? tile + stride : tile);
+        if (more) {
+#pragma unroll
+            for (int S = 0; S < NS; ++S) an[S] = *reinterpret_cast<const uint4*>(pn + 16 * S);   // flies under this tile's work
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int cblk = 0; cblk < 2; ++cblk)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[cblk][i] = 0.f;
+#pragma unroll
+        for (int S = 0; S < NS; ++S)
+#pragma unroll
+            for (int cblk = 0; cblk < 2; ++cblk)
+                acc[cblk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[S]),
+                                                                    __builtin_bit_cast(bf16x8, Bs[(cblk * NS + S) * 64 + lane]), acc[cblk], 0, 0, 0);
+#pragma unroll
+        for (int cblk = 0; cblk < 2; ++cblk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[cblk][r] + bb[cblk];
+                if (has_scale) v = __fmaf_rn(v, sc[cblk], sh[cblk]);
+                Hs[((r & 3) + 8 * (r >> 2) + 4 * g) * LDH + cblk * 32 + l31] = fmaxf(v, 0.f);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float sacc = b3v;
+        const float* hr = Hs + l31 * LDH;
+        const float* w3 = W3s + po * HIDB;
+#pragma unroll
+        for (int c = 0; c < HIDB; c += 4) {
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(hr + c);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w3 + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sacc = __fmaf_rn(hv[j], wv[j], sacc);
+        }
+        const int64_t row = tile * 32 + l31;
+        if (row < M && po < n_out) out[row * ldo + po] = sacc;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (more) {
+#pragma unroll
+            for (int S = 0; S < NS; ++S) a[S] = an[S];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dgnn_cast_f32_to_bf16(const float* in, int64_t ld_in, int64_t n, int cols, int cols_pad, uint16_t* out, int64_t ld_out,
+                                     void* stream) {
+    DGNN_REQUIRE(n >= 0 && cols >= 0 && cols_pad >= cols && cols_pad % 2 == 0 && ld_out >= cols_pad && ld_out % 2 == 0, DGNN_E_INVALID,
+                 "cast_f32_to_bf16: bad sizes");
+    if (n == 0 || cols_pad == 0) return DGNN_OK;
+    DGNN_REQUIRE(in && out && ((uintptr_t)out % 4) == 0, DGNN_E_INVALID, "cast_f32_to_bf16: null / unaligned pointer");
+    hipLaunchKernelGGL(k_cast_f32_bf16, dim3(dgnn_grid_cap(dgnn_cdiv(n * (cols_pad / 2), 256))), dim3(256), 0, (hipStream_t)stream, in, ld_in, n,
+                       cols, cols_pad, out, ld_out);
+    return dgnn_check_launch("cast_f32_to_bf16");
+}
+
+extern "C" int dgnn_cast_bf16_to_f32(const uint16_t* in, int64_t ld_in, int64_t n, int cols, float* out, int64_t ld_out, void* stream) {
+    DGNN_REQUIRE(n >= 0 && cols >= 0, DGNN_E_INVALID, "cast_bf16_to_f32: bad sizes");
+    if (n == 0 || cols == 0) return DGNN_OK;
+    DGNN_REQUIRE(in && out, DGNN_E_INVALID, "cast_bf16_to_f32: null pointer");
+    hipLaunchKernelGGL(k_cast_bf16_f32, dim3(dgnn_grid_cap(dgnn_cdiv(n * cols, 256))), dim3(256), 0, (hipStream_t)stream, in, ld_in, n, cols, out,
+                       ld_out);
+    return dgnn_check_launch("cast_bf16_to_f32");
+}
+
+extern "C" int dgnn_sage_layer_fused_fwd_bf16(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst,
+                                              const uint16_t* x_src, const uint16_t* x_dst, int64_t ldx, int c_in, const float* edge_attr,
+                                              int64_t lde, int f_e, const float* We, const float* be, const float* Wj, const float* bj,
+                                              const float* Wi, const float* scale, const float* shift, int relu, int c_out, uint16_t* out,
+                                              int64_t ldo, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DGNN_REQUIRE(n_dst >= 0 && c_in > 0 && c_out > 0, DGNN_E_INVALID, "sage_layer_fused_fwd_bf16: bad sizes");
+    if (n_dst == 0) return DGNN_OK;
+    DGNN_REQUIRE(rowptr && src && x_src && edge_attr && We && be && Wj && Wi && out, DGNN_E_INVALID, "sage_layer_fused_fwd_bf16: null pointer");
+    DGNN_REQUIRE((scale == nullptr) == (shift == nullptr), DGNN_E_INVALID, "sage_layer_fused_fwd_bf16: scale/shift must come together");
+    if (x_dst == nullptr) x_dst = x_src;
+    DGNN_REQUIRE(f_e == FE && lde == FE && ((uintptr_t)edge_attr % 16) == 0, DGNN_E_UNSUPPORTED,
+                 "sage_layer_fused_fwd_bf16: needs f_e == 20, packed 16-byte aligned edge rows");
+    DGNN_REQUIRE(n_dst * ldx < ((int64_t)1 << 31), DGNN_E_UNSUPPORTED, "sage_layer_fused_fwd_bf16: activations beyond 2^31 elements");
+    const int cin_pad = c_in <= 32 ? 32 : (c_in <= 64 ? 64 : 128);
+    const int nb = cin_pad / 16;
+    DGNN_REQUIRE(c_in <= 128 && (c_out == 64 || c_out == 128), DGNN_E_UNSUPPORTED,
+                 "sage_layer_fused_fwd_bf16: supports c_in <= 128 and c_out in {64,128} (got %d -> %d)", c_in, c_out);
+    // a lane reads nb contiguous bf16 of a row: rows must be aligned to that, and every lane's piece must lie inside the row
+    DGNN_REQUIRE(c_in % nb == 0 && ldx % nb == 0 && (((uintptr_t)x_src | (uintptr_t)x_dst) % (2 * nb)) == 0, DGNN_E_UNSUPPORTED,
+                 "sage_layer_fused_fwd_bf16: c_in and the row stride must be multiples of %d, rows %d-byte aligned", nb, 2 * nb);
+    DGNN_REQUIRE(ldo % 2 == 0 && ((uintptr_t)out % 4) == 0, DGNN_E_UNSUPPORTED, "sage_layer_fused_fwd_bf16: out rows must be 4-byte aligned");
+#define GOB(CP, CO, OCC) return launch_b<CP, CO, OCC>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, \
+                                                      shift, relu, out, ldo, stream)
+    if (cin_pad == 32) { if (c_out == 64) GOB(32, 64, 2); else GOB(32, 128, 2); }
+    if (cin_pad == 64) { if (c_out == 64) GOB(64, 64, 2); else GOB(64, 128, 2); }
+    if (c_out == 64) GOB(128, 64, 2);
+    GOB(128, 128, 2);
+#undef GOB
+}
+
+extern "C" int dgnn_decoder_fused_fwd_bf16(const uint16_t* y, int64_t ldy, int64_t M, int k, const float* W0, const float* b0, const float* scale,
+                                           const float* shift, int hidden, const float* W3, const float* b3, int n_out, float* out, int64_t ldo,
+                                           void* stream) {
+    DGNN_REQUIRE(M >= 0 && k > 0 && hidden > 0 && n_out > 0, DGNN_E_INVALID, "decoder_fused_fwd_bf16: bad sizes");
+    if (M == 0) return DGNN_OK;
+    DGNN_REQUIRE(y && W0 && W3 && out, DGNN_E_INVALID, "decoder_fused_fwd_bf16: null pointer");
+    DGNN_REQUIRE((scale == nullptr) == (shift == nullptr), DGNN_E_INVALID, "decoder_fused_fwd_bf16: scale/shift must come together");
+    DGNN_REQUIRE(k == 128 && hidden == HIDB && n_out <= 2 && ((uintptr_t)y % 16) == 0 && ldy % 8 == 0, DGNN_E_UNSUPPORTED,
+                 "decoder_fused_fwd_bf16: supports 128 -> 64 -> {1,2} on 16-byte aligned rows (got %d -> %d -> %d)", k, hidden, n_out);
+    constexpr int K = 128, LDH = HIDB + 4;
+    const size_t smem = 2 * (K / 16) * 64 * 16 + 2 * HIDB * 4 + 8 * 32 * LDH * 4;
+    static bool attr_set[DGNN_MAX_DEVICES] = {};
+    dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_decoder_rows_bf16<128>), smem, attr_set);
+    const int64_t nt = dgnn_cdiv(M, 32);
+    const int grid = (int)(dgnn_cdiv(nt, 8) < DGNN_NUM_CU ? dgnn_cdiv(nt, 8) : DGNN_NUM_CU);
+    hipLaunchKernelGGL((k_decoder_rows_bf16<128>), dim3(grid), dim3(512), smem, (hipStream_t)stream, y, ldy, M, W0, b0, scale, shift, W3, b3,
+                       n_out, out, ldo);
+    return dgnn_check_launch("decoder_fused_fwd_bf16");
+}

@@ -173,6 +173,184 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
     *out = accumulate ? *out + s : s;
 }
 
+// =====================================================================================================================
+// bf16-storage GEMMs (BASELINE config 3): activations bf16 in HBM, weights fp32 in HBM (master copies, rounded to bf16 when a
+// block stages them), one v_mfma_f32_32x32x16_bf16 per product, fp32 accumulation, fp32 epilogue, output bf16 or fp32.
+//
+// k_linear_fwd_b: 128 x 64 output tile per 256-thread block as above; K is walked in chunks of 64 over [A1 | A2].  LDS rows are
+// 64 bf16 + 16 B pad = 144 B (an odd number of 16-B slots), so the b128 fragment reads of a 16-lane group never share a bank.
+// =====================================================================================================================
+constexpr int BKB = 64, LDB = BKB * 2 + 16;  // bytes per LDS row
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{a, b}, bf2));
+}
+
+// A tile: ROWS x 64 bf16 from a bf16 matrix; 8 threads per row, 16 B (8 elements) each
+template <int ROWS>
+__device__ __forceinline__ void stage_a_bf16(char* __restrict__ dst, const uint16_t* __restrict__ src, int64_t ld, int64_t row0, int64_t nrows,
+                                             int k0, int kmax, bool vec) {
+    const int t = threadIdx.x, r = t >> 3, c = (t & 7) * 8;
+#pragma unroll
+    for (int p = 0; p < ROWS / 32; ++p) {
+        const int rr = r + p * 32;
+        const int64_t gr = row0 + rr;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (gr < nrows && k0 + c < kmax) {
+            const uint16_t* g = src + gr * ld + k0 + c;
+            if (vec && k0 + c + 8 <= kmax) {
+                v = *reinterpret_cast<const uint4*>(g);
+            } else {
+                uint32_t e[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] = (k0 + c + j < kmax) ? (uint32_t)g[j] : 0u;
+                v = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+            }
+        }
+        *reinterpret_cast<uint4*>(dst + rr * LDB + c * 2) = v;
+    }
+}
+
+// W tile: ROWS x 64 from an fp32 matrix, rounded to bf16
+template <int ROWS>
+__device__ __forceinline__ void stage_w_bf16(char* __restrict__ dst, const float* __restrict__ src, int64_t ld, int64_t row0, int64_t nrows,
+                                             int k0, int kmax, bool vec) {
+    const int t = threadIdx.x, r = t >> 3, c = (t & 7) * 8;
+#pragma unroll
+    for (int p = 0; p < ROWS / 32; ++p) {
+        const int rr = r + p * 32;
+        const int64_t gr = row0 + rr;
+        float e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = 0.f;
+        if (gr < nrows && k0 + c < kmax) {
+            const float* g = src + gr * ld + k0 + c;
+            if (vec && k0 + c + 8 <= kmax) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(g), b = *reinterpret_cast<const f32x4*>(g + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { e[j] = a[j]; e[4 + j] = b[j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (k0 + c + j < kmax) e[j] = g[j];
+            }
+        }
+        *reinterpret_cast<uint4*>(dst + rr * LDB + c * 2) = make_uint4(pk_bf16(e[0], e[1]), pk_bf16(e[2], e[3]), pk_bf16(e[4], e[5]), pk_bf16(e[6], e[7]));
+    }
+}
+
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+
+template <typename TO>
+__global__ void __launch_bounds__(256) k_linear_fwd_b(const uint16_t* __restrict__ A1, int64_t lda1, int k1, const float* __restrict__ W1,
+                                                      int64_t ldw1, bool va1, bool vw1, const uint16_t* __restrict__ A2, int64_t lda2, int k2,
+                                                      const float* __restrict__ W2, int64_t ldw2, bool va2, bool vw2,
+                                                      const float* __restrict__ bias, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, int relu, int64_t M, int n_out, TO* __restrict__ out,
+                                                      int64_t ldo) {
+    __shared__ __attribute__((aligned(16))) char As[BM * LDB];
+    __shared__ __attribute__((aligned(16))) char Ws[BN * LDB];
+    const int lane = lane_id(), w = wave_id_uniform();
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    const int col0 = blockIdx.y * BN;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
+    const int nch1 = (k1 + BKB - 1) / BKB, nch2 = A2 ? (k2 + BKB - 1) / BKB : 0;
+    const int h = lane >> 5, l31 = lane & 31;
+    for (int ch = 0; ch < nch1 + nch2; ++ch) {
+        const bool first = ch < nch1;
+        const int kk = first ? k1 : k2, k0 = (first ? ch : ch - nch1) * BKB;
+        __syncthreads();
+        stage_a_bf16<BM>(As, first ? A1 : A2, first ? lda1 : lda2, row0, M, k0, kk, first ? va1 : va2);
+        stage_w_bf16<BN>(Ws, first ? W1 : W2, first ? ldw1 : ldw2, col0, n_out, k0, kk, first ? vw1 : vw2);
+        __syncthreads();
+        const char* ap = As + (w * 32 + l31) * LDB + h * 16;
+        const char* bp0 = Ws + l31 * LDB + h * 16;
+        const char* bp1 = bp0 + 32 * LDB;
+#pragma unroll
+        for (int S = 0; S < BKB / 16; ++S) {
+            const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(ap + 32 * S);
+            const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(bp0 + 32 * S);
+            const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(bp1 + 32 * S);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b1, acc1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int col = col0 + half * 32 + l31;
+        if (col >= n_out) continue;
+        const float bb = bias ? bias[col] : 0.f;
+        const float sc = scale ? scale[col] : 1.f;
+        const float sh = scale ? shift[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + w * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row >= M) continue;
+            float v = (half ? acc1[r] : acc0[r]) + bb;
+            if (scale) v = __fmaf_rn(v, sc, sh);
+            if (relu) v = fmaxf(v, 0.f);
+            dgnn_st(out + row * ldo + col, v);
+        }
+    }
+}
+
+// dW[na, nb] = sum_rows A[r, :]^T B[r, :] with bf16 A and B (TA/TB: uint16_t = bf16 storage, float = fp32 rounded to bf16 here).
+// Row slices of 64 rows are staged TRANSPOSED ([column][row], 144-byte rows) so that a lane's MFMA fragment -- 8 consecutive
+// rows of one column -- is one 16-byte LDS read.
+constexpr int RKB = 64, LDTB = RKB * 2 + 16;
+
+template <typename TA>
+__device__ __forceinline__ void stage_t(char* __restrict__ dst, const TA* __restrict__ src, int64_t ld, int64_t r0, int64_t r_end, int c0, int nc) {
+    // 256 threads: thread (tr = t>>2 in 0..63 rows, tc = (t&3)*16 columns): 16 elements of one row
+    const int t = threadIdx.x, tr = t >> 2, tc = (t & 3) * 16;
+    const int64_t gr = r0 + tr;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int cc = c0 + tc + j;
+        const float v = (gr < r_end && cc < nc) ? dgnn_ld(src + gr * ld + cc) : 0.f;
+        uint16_t b;
+        dgnn_st(&b, v);
+        *reinterpret_cast<uint16_t*>(dst + (tc + j) * LDTB + tr * 2) = b;
+    }
+}
+
+template <typename TA, typename TB>
+__global__ void __launch_bounds__(256) k_linear_wgrad_b(const TA* __restrict__ A, int64_t lda, int na, const TB* __restrict__ B, int64_t ldb,
+                                                        int nb, int64_t M, int64_t rows_per_split, float* __restrict__ partials) {
+    __shared__ __attribute__((aligned(16))) char At[WT * LDTB];
+    __shared__ __attribute__((aligned(16))) char Bt[WT * LDTB];
+    const int lane = lane_id(), w = wave_id_uniform();
+    const int wa = w >> 1, wb = w & 1, h = lane >> 5, l31 = lane & 31;
+    const int a0 = blockIdx.x * WT, b0 = blockIdx.y * WT;
+    const int64_t r_beg = (int64_t)blockIdx.z * rows_per_split;
+    const int64_t r_end = min(M, r_beg + rows_per_split);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int64_t r0 = r_beg; r0 < r_end; r0 += RKB) {
+        __syncthreads();
+        stage_t<TA>(At, A, lda, r0, r_end, a0, na);
+        stage_t<TB>(Bt, B, ldb, r0, r_end, b0, nb);
+        __syncthreads();
+        const char* ap = At + (wa * 32 + l31) * LDTB + h * 16;
+        const char* bp = Bt + (wb * 32 + l31) * LDTB + h * 16;
+#pragma unroll
+        for (int S = 0; S < RKB / 16; ++S)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(ap + 32 * S),
+                                                          *reinterpret_cast<const bf16x8_t*>(bp + 32 * S), acc, 0, 0, 0);
+    }
+    float* P = partials + (int64_t)blockIdx.z * na * nb;
+    const int col = b0 + wb * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = a0 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < na && col < nb) P[(int64_t)row * nb + col] = acc[r];
+    }
+}
+
 int wgrad_splits(int64_t M) {
     int64_t s = dgnn_cdiv(M, 4 * RK);  // at least 128 rows per split
     if (s > WGRAD_SPLITS) s = WGRAD_SPLITS;
@@ -216,4 +394,48 @@ extern "C" int dgnn_linear_wgrad(const float* A, int64_t lda, int n_a, const flo
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)dgnn_cdiv((int64_t)n_a * n_b, 16)), dim3(256), 0, stream, partials, splits,
                        n_a, n_b, dW, lddw, accumulate);
     return dgnn_check_launch("linear_wgrad");
+}
+
+
+// ---- bf16 storage entry points ----------------------------------------------------------------------------------------------
+static bool vec16(const void* p, int64_t ld_elems, size_t elem) { return ((uintptr_t)p % 16 == 0) && ((ld_elems * (int64_t)elem) % 16 == 0); }
+
+extern "C" int dgnn_linear_fwd_bf16(const uint16_t* A1, int64_t lda1, int k1, const float* W1, int64_t ldw1, const uint16_t* A2, int64_t lda2,
+                                    int k2, const float* W2, int64_t ldw2, const float* bias, const float* scale, const float* shift, int relu,
+                                    int64_t M, int n_out, void* out, int64_t ldo, int out_f32, void* stream) {
+    DGNN_REQUIRE(M >= 0 && n_out > 0 && k1 > 0, DGNN_E_INVALID, "linear_fwd_bf16: bad sizes M=%lld n_out=%d k1=%d", (long long)M, n_out, k1);
+    if (M == 0) return DGNN_OK;
+    DGNN_REQUIRE(A1 && W1 && out, DGNN_E_INVALID, "linear_fwd_bf16: null pointer");
+    DGNN_REQUIRE((A2 == nullptr) == (W2 == nullptr) && (!A2 || k2 > 0), DGNN_E_INVALID, "linear_fwd_bf16: A2/W2 must come together");
+    DGNN_REQUIRE((scale == nullptr) == (shift == nullptr), DGNN_E_INVALID, "linear_fwd_bf16: scale/shift must come together");
+    const bool va1 = vec16(A1, lda1, 2), vw1 = vec16(W1, ldw1, 4);
+    const bool va2 = A2 && vec16(A2, lda2, 2), vw2 = W2 && vec16(W2, ldw2, 4);
+    dim3 grid((unsigned)dgnn_cdiv(M, BM), (unsigned)dgnn_cdiv(n_out, BN));
+    if (out_f32)
+        hipLaunchKernelGGL((k_linear_fwd_b<float>), grid, dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, va1, vw1, A2, lda2, k2, W2, ldw2,
+                           va2, vw2, bias, scale, shift, relu, M, n_out, (float*)out, ldo);
+    else
+        hipLaunchKernelGGL((k_linear_fwd_b<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, va1, vw1, A2, lda2, k2, W2,
+                           ldw2, va2, vw2, bias, scale, shift, relu, M, n_out, (uint16_t*)out, ldo);
+    return dgnn_check_launch("linear_fwd_bf16");
+}
+
+extern "C" int dgnn_linear_wgrad_bf16(const void* A, int a_f32, int64_t lda, int n_a, const void* B, int b_f32, int64_t ldb, int n_b, int64_t M,
+                                      float* dW, int64_t lddw, int accumulate, float* partials, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DGNN_REQUIRE(M >= 0 && n_a > 0 && n_b > 0, DGNN_E_INVALID, "linear_wgrad_bf16: bad sizes");
+    DGNN_REQUIRE(dW && partials && (M == 0 || (A && B)), DGNN_E_INVALID, "linear_wgrad_bf16: null pointer");
+    const int splits = wgrad_splits(M);
+    int64_t rps = dgnn_cdiv(dgnn_cdiv(M, splits), RKB) * RKB;
+    if (rps < RKB) rps = RKB;
+    dim3 grid((unsigned)dgnn_cdiv(n_a, WT), (unsigned)dgnn_cdiv(n_b, WT), splits);
+#define WG(TA, TB) hipLaunchKernelGGL((k_linear_wgrad_b<TA, TB>), grid, dim3(256), 0, stream, (const TA*)A, lda, n_a, (const TB*)B, ldb, n_b, M, rps, partials)
+    if (a_f32 && b_f32) WG(float, float);
+    else if (a_f32) WG(float, uint16_t);
+    else if (b_f32) WG(uint16_t, float);
+    else WG(uint16_t, uint16_t);
+#undef WG
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)dgnn_cdiv((int64_t)n_a * n_b, 16)), dim3(256), 0, stream, partials, splits, n_a, n_b, dW, lddw,
+                       accumulate);
+    return dgnn_check_launch("linear_wgrad_bf16");
 }

@@ -12,9 +12,9 @@ namespace {
 constexpr int RED_BLOCKS = 1024;
 
 // MODE 0: (x, x*x)   MODE 1: (g, g*xhat) with g = dy*[y>0]   MODE 2: (x, 0)
-template <int MODE>
-__global__ void __launch_bounds__(256) k_colreduce(const float* __restrict__ x, int64_t ldx, const float* __restrict__ y,
-                                                   int64_t ldy, const float* __restrict__ dy, int64_t lddy,
+template <int MODE, typename T>
+__global__ void __launch_bounds__(256) k_colreduce(const T* __restrict__ x, int64_t ldx, const T* __restrict__ y,
+                                                   int64_t ldy, const T* __restrict__ dy, int64_t lddy,
                                                    const float* __restrict__ mean, const float* __restrict__ var, float eps,
                                                    int relu, int64_t M, int c, int64_t rows_per_block,
                                                    double* __restrict__ partials) {
@@ -33,17 +33,17 @@ __global__ void __launch_bounds__(256) k_colreduce(const float* __restrict__ x, 
             }
             for (int64_t r = r0 + ty; r < r1; r += 4) {
                 if (MODE == 0) {
-                    const float v = x[r * ldx + col];
+                    const float v = dgnn_ld(x + r * ldx + col);
                     s0 += v;
                     s1 += (double)v * v;
                 } else if (MODE == 1) {
-                    float g = dy[r * lddy + col];
-                    if (relu && !(y[r * ldy + col] > 0.f)) g = 0.f;
-                    const float xh = (x[r * ldx + col] - mu) * is;
+                    float g = dgnn_ld(dy + r * lddy + col);
+                    if (relu && !(dgnn_ld(y + r * ldy + col) > 0.f)) g = 0.f;
+                    const float xh = (dgnn_ld(x + r * ldx + col) - mu) * is;
                     s0 += g;
                     s1 += (double)g * xh;
                 } else {
-                    s0 += x[r * ldx + col];
+                    s0 += dgnn_ld(x + r * ldx + col);
                 }
             }
         }
@@ -125,42 +125,44 @@ __global__ void k_bn_fold(const float* __restrict__ gamma, const float* __restri
     shift[i] = (beta ? beta[i] : 0.f) - mean[i] * s;
 }
 
-__global__ void k_scale_shift_act(const float* __restrict__ x, int64_t ldx, const float* __restrict__ scale,
-                                  const float* __restrict__ shift, int relu, int64_t M, int c, float* __restrict__ y,
+template <typename T>
+__global__ void k_scale_shift_act(const T* __restrict__ x, int64_t ldx, const float* __restrict__ scale,
+                                  const float* __restrict__ shift, int relu, int64_t M, int c, T* __restrict__ y,
                                   int64_t ldy) {
     const int64_t total = M * c;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = t / c;
         const int col = (int)(t - r * c);
-        float v = __fmaf_rn(x[r * ldx + col], scale[col], shift[col]);
+        float v = __fmaf_rn(dgnn_ld(x + r * ldx + col), scale[col], shift[col]);
         if (relu) v = fmaxf(v, 0.f);
-        y[r * ldy + col] = v;
+        dgnn_st(y + r * ldy + col, v);
     }
 }
 
 // dx for y = relu(bn(x)).  sums: [0][c] = sum g, [1][c] = sum g*xhat (already final floats in dbeta/dgamma)
-__global__ void k_bn_relu_bwd_apply(const float* __restrict__ x, int64_t ldx, const float* __restrict__ y, int64_t ldy,
-                                    const float* __restrict__ dy, int64_t lddy, const float* __restrict__ gamma,
+template <typename T>
+__global__ void k_bn_relu_bwd_apply(const T* __restrict__ x, int64_t ldx, const T* __restrict__ y, int64_t ldy,
+                                    const T* __restrict__ dy, int64_t lddy, const float* __restrict__ gamma,
                                     const float* __restrict__ mean, const float* __restrict__ var, float eps, int train,
                                     int relu, int64_t M, int c, const float* __restrict__ sum_g,
-                                    const float* __restrict__ sum_gx, float* __restrict__ dx, int64_t lddx) {
+                                    const float* __restrict__ sum_gx, T* __restrict__ dx, int64_t lddx) {
     const int64_t total = M * c;
     const float invM = 1.0f / (float)M;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = t / c;
         const int col = (int)(t - r * c);
-        float g = dy[r * lddy + col];
-        if (relu && !(y[r * ldy + col] > 0.f)) g = 0.f;
+        float g = dgnn_ld(dy + r * lddy + col);
+        if (relu && !(dgnn_ld(y + r * ldy + col) > 0.f)) g = 0.f;
         const float is = 1.0f / sqrtf(var[col] + eps);
         const float gs = (gamma ? gamma[col] : 1.f) * is;
         float o;
         if (train) {
-            const float xh = (x[r * ldx + col] - mean[col]) * is;
+            const float xh = (dgnn_ld(x + r * ldx + col) - mean[col]) * is;
             o = gs * (g - invM * sum_g[col] - xh * invM * sum_gx[col]);
         } else {
             o = g * gs;
         }
-        dx[r * lddx + col] = o;
+        dgnn_st(dx + r * lddx + col, o);
     }
 }
 
@@ -187,57 +189,93 @@ extern "C" int dgnn_bn_fold(const float* gamma, const float* beta, const float* 
     return dgnn_check_launch("bn_fold");
 }
 
-extern "C" int dgnn_bn_batch_stats(const float* x, int64_t ldx, int64_t M, int c, float* mean, float* var,
-                                   float* running_mean, float* running_var, float momentum, float* scratch, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+template <typename T>
+static int bn_batch_stats_t(const T* x, int64_t ldx, int64_t M, int c, float* mean, float* var, float* running_mean, float* running_var,
+                            float momentum, float* scratch, hipStream_t stream) {
     DGNN_REQUIRE(M > 0 && c > 0 && x && mean && var && scratch, DGNN_E_INVALID, "bn_batch_stats: bad args (M=%lld c=%d)", (long long)M, c);
     const int nblk = red_blocks(M);
     const int64_t rpb = dgnn_cdiv(M, nblk);
     double* P = as_f64(scratch);
-    hipLaunchKernelGGL((k_colreduce<0>), dim3(nblk), dim3(256), 0, stream, x, ldx, nullptr, (int64_t)0, nullptr, (int64_t)0, nullptr,
-                       nullptr, 0.f, 0, M, c, rpb, P);
+    hipLaunchKernelGGL((k_colreduce<0, T>), dim3(nblk), dim3(256), 0, stream, x, ldx, (const T*)nullptr, (int64_t)0, (const T*)nullptr,
+                       (int64_t)0, nullptr, nullptr, 0.f, 0, M, c, rpb, P);
     hipLaunchKernelGGL(k_stats_finalize, dim3((c + 15) / 16), dim3(256), 0, stream, P, nblk, M, c, mean, var, running_mean,
                        running_var, momentum);
     return dgnn_check_launch("bn_batch_stats");
 }
 
-extern "C" int dgnn_scale_shift_act(const float* x, int64_t ldx, const float* scale, const float* shift, int relu, int64_t M,
-                                    int c, float* y, int64_t ldy, void* stream) {
+template <typename T>
+static int scale_shift_act_t(const T* x, int64_t ldx, const float* scale, const float* shift, int relu, int64_t M, int c, T* y, int64_t ldy,
+                             hipStream_t stream) {
     DGNN_REQUIRE(M >= 0 && c > 0, DGNN_E_INVALID, "scale_shift_act: bad sizes");
     if (M == 0) return DGNN_OK;
     DGNN_REQUIRE(x && scale && shift && y, DGNN_E_INVALID, "scale_shift_act: null pointer");
-    hipLaunchKernelGGL(k_scale_shift_act, dim3(dgnn_grid_cap(dgnn_cdiv(M * c, 256))), dim3(256), 0, (hipStream_t)stream, x, ldx,
-                       scale, shift, relu, M, c, y, ldy);
+    hipLaunchKernelGGL((k_scale_shift_act<T>), dim3(dgnn_grid_cap(dgnn_cdiv(M * c, 256))), dim3(256), 0, stream, x, ldx, scale, shift, relu, M,
+                       c, y, ldy);
     return dgnn_check_launch("scale_shift_act");
 }
 
-extern "C" int dgnn_bn_relu_bwd(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* dy, int64_t lddy,
-                                const float* gamma, const float* mean, const float* var, float eps, int train, int relu,
-                                int64_t M, int c, float* dx, int64_t lddx, float* dgamma, float* dbeta, float* scratch,
-                                void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+template <typename T>
+static int bn_relu_bwd_t(const T* x, int64_t ldx, const T* y, int64_t ldy, const T* dy, int64_t lddy, const float* gamma, const float* mean,
+                         const float* var, float eps, int train, int relu, int64_t M, int c, T* dx, int64_t lddx, float* dgamma, float* dbeta,
+                         float* scratch, hipStream_t stream) {
     DGNN_REQUIRE(M > 0 && c > 0 && x && dy && mean && var && dx && scratch && (!relu || y), DGNN_E_INVALID, "bn_relu_bwd: bad args");
     const int nblk = red_blocks(M);
     const int64_t rpb = dgnn_cdiv(M, nblk);
     double* P = as_f64(scratch);
     float* sums = reinterpret_cast<float*>(P + (int64_t)nblk * 2 * c);
-    hipLaunchKernelGGL((k_colreduce<1>), dim3(nblk), dim3(256), 0, stream, x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, rpb, P);
+    hipLaunchKernelGGL((k_colreduce<1, T>), dim3(nblk), dim3(256), 0, stream, x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, rpb, P);
     hipLaunchKernelGGL(k_sum_finalize, dim3((c + 15) / 16), dim3(256), 0, stream, P, nblk, c, sums, sums + c, 0, dbeta, dgamma);
-    hipLaunchKernelGGL(k_bn_relu_bwd_apply, dim3(dgnn_grid_cap(dgnn_cdiv(M * c, 256))), dim3(256), 0, stream, x, ldx, y, ldy, dy,
-                       lddy, gamma, mean, var, eps, train, relu, M, c, sums, sums + c, dx, lddx);
+    hipLaunchKernelGGL((k_bn_relu_bwd_apply<T>), dim3(dgnn_grid_cap(dgnn_cdiv(M * c, 256))), dim3(256), 0, stream, x, ldx, y, ldy, dy, lddy,
+                       gamma, mean, var, eps, train, relu, M, c, sums, sums + c, dx, lddx);
     return dgnn_check_launch("bn_relu_bwd");
 }
 
-extern "C" int dgnn_colsum(const float* x, int64_t ldx, int64_t M, int c, float* out, int accumulate, float* scratch,
-                           void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+template <typename T>
+static int colsum_t(const T* x, int64_t ldx, int64_t M, int c, float* out, int accumulate, float* scratch, hipStream_t stream) {
     DGNN_REQUIRE(M > 0 && c > 0 && x && out && scratch, DGNN_E_INVALID, "colsum: bad args");
     const int nblk = red_blocks(M);
     const int64_t rpb = dgnn_cdiv(M, nblk);
     double* P = as_f64(scratch);
-    hipLaunchKernelGGL((k_colreduce<2>), dim3(nblk), dim3(256), 0, stream, x, ldx, nullptr, (int64_t)0, nullptr, (int64_t)0, nullptr,
-                       nullptr, 0.f, 0, M, c, rpb, P);
+    hipLaunchKernelGGL((k_colreduce<2, T>), dim3(nblk), dim3(256), 0, stream, x, ldx, (const T*)nullptr, (int64_t)0, (const T*)nullptr,
+                       (int64_t)0, nullptr, nullptr, 0.f, 0, M, c, rpb, P);
     hipLaunchKernelGGL(k_sum_finalize, dim3((c + 15) / 16), dim3(256), 0, stream, P, nblk, c, out, (float*)nullptr, accumulate,
                        (float*)nullptr, (float*)nullptr);
     return dgnn_check_launch("colsum");
+}
+
+extern "C" int dgnn_bn_batch_stats(const float* x, int64_t ldx, int64_t M, int c, float* mean, float* var,
+                                   float* running_mean, float* running_var, float momentum, float* scratch, void* stream) {
+    return bn_batch_stats_t<float>(x, ldx, M, c, mean, var, running_mean, running_var, momentum, scratch, (hipStream_t)stream);
+}
+extern "C" int dgnn_bn_batch_stats_bf16(const uint16_t* x, int64_t ldx, int64_t M, int c, float* mean, float* var,
+                                        float* running_mean, float* running_var, float momentum, float* scratch, void* stream) {
+    return bn_batch_stats_t<uint16_t>(x, ldx, M, c, mean, var, running_mean, running_var, momentum, scratch, (hipStream_t)stream);
+}
+extern "C" int dgnn_scale_shift_act(const float* x, int64_t ldx, const float* scale, const float* shift, int relu, int64_t M,
+                                    int c, float* y, int64_t ldy, void* stream) {
+    return scale_shift_act_t<float>(x, ldx, scale, shift, relu, M, c, y, ldy, (hipStream_t)stream);
+}
+extern "C" int dgnn_scale_shift_act_bf16(const uint16_t* x, int64_t ldx, const float* scale, const float* shift, int relu, int64_t M,
+                                         int c, uint16_t* y, int64_t ldy, void* stream) {
+    return scale_shift_act_t<uint16_t>(x, ldx, scale, shift, relu, M, c, y, ldy, (hipStream_t)stream);
+}
+extern "C" int dgnn_bn_relu_bwd(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* dy, int64_t lddy,
+                                const float* gamma, const float* mean, const float* var, float eps, int train, int relu,
+                                int64_t M, int c, float* dx, int64_t lddx, float* dgamma, float* dbeta, float* scratch,
+                                void* stream) {
+    return bn_relu_bwd_t<float>(x, ldx, y, ldy, dy, lddy, gamma, mean, var, eps, train, relu, M, c, dx, lddx, dgamma, dbeta, scratch,
+                                (hipStream_t)stream);
+}
+extern "C" int dgnn_bn_relu_bwd_bf16(const uint16_t* x, int64_t ldx, const uint16_t* y, int64_t ldy, const uint16_t* dy, int64_t lddy,
+                                     const float* gamma, const float* mean, const float* var, float eps, int train, int relu,
+                                     int64_t M, int c, uint16_t* dx, int64_t lddx, float* dgamma, float* dbeta, float* scratch,
+                                     void* stream) {
+    return bn_relu_bwd_t<uint16_t>(x, ldx, y, ldy, dy, lddy, gamma, mean, var, eps, train, relu, M, c, dx, lddx, dgamma, dbeta, scratch,
+                                   (hipStream_t)stream);
+}
+extern "C" int dgnn_colsum(const float* x, int64_t ldx, int64_t M, int c, float* out, int accumulate, float* scratch, void* stream) {
+    return colsum_t<float>(x, ldx, M, c, out, accumulate, scratch, (hipStream_t)stream);
+}
+extern "C" int dgnn_colsum_bf16(const uint16_t* x, int64_t ldx, int64_t M, int c, float* out, int accumulate, float* scratch, void* stream) {
+    return colsum_t<uint16_t>(x, ldx, M, c, out, accumulate, scratch, (hipStream_t)stream);
 }

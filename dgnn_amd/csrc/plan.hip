@@ -361,14 +361,16 @@ __global__ void k_scatter_rows(const float* __restrict__ in, int64_t ld_in, cons
     }
 }
 
-__global__ void k_relu(const float* __restrict__ x, int64_t n, float* __restrict__ y) {
+template <typename T>
+__global__ void k_relu(const T* __restrict__ x, int64_t n, T* __restrict__ y) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        y[i] = fmaxf(x[i], 0.0f);
+        dgnn_st(y + i, fmaxf(dgnn_ld(x + i), 0.0f));
 }
 
-__global__ void k_relu_bwd(const float* __restrict__ y, const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+template <typename T>
+__global__ void k_relu_bwd(const T* __restrict__ y, const T* __restrict__ g, int64_t n, T* __restrict__ out) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = y[i] > 0.f ? g[i] : 0.f;
+        dgnn_st(out + i, dgnn_ld(y + i) > 0.f ? dgnn_ld(g + i) : 0.f);
 }
 
 }  // namespace
@@ -376,7 +378,7 @@ __global__ void k_relu_bwd(const float* __restrict__ y, const float* __restrict_
 extern "C" int dgnn_relu_bwd(const float* y, const float* g, int64_t n, float* out, void* stream) {
     DGNN_REQUIRE(n >= 0 && (n == 0 || (y && g && out)), DGNN_E_INVALID, "relu_bwd: bad args");
     if (n == 0) return DGNN_OK;
-    hipLaunchKernelGGL(k_relu_bwd, dim3(dgnn_grid_cap(dgnn_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream, y, g, n, out);
+    hipLaunchKernelGGL((k_relu_bwd<float>), dim3(dgnn_grid_cap(dgnn_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream, y, g, n, out);
     return dgnn_check_launch("relu_bwd");
 }
 
@@ -485,6 +487,20 @@ extern "C" int dgnn_scatter_rows_f32(const float* in, int64_t ld_in, const int64
 extern "C" int dgnn_relu(const float* x, int64_t n, float* y, void* stream) {
     DGNN_REQUIRE(n >= 0 && (n == 0 || (x && y)), DGNN_E_INVALID, "relu: bad args");
     if (n == 0) return DGNN_OK;
-    hipLaunchKernelGGL(k_relu, dim3(dgnn_grid_cap(dgnn_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream, x, n, y);
+    hipLaunchKernelGGL((k_relu<float>), dim3(dgnn_grid_cap(dgnn_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream, x, n, y);
     return dgnn_check_launch("relu");
+}
+
+extern "C" int dgnn_relu_bf16(const uint16_t* x, int64_t n, uint16_t* y, void* stream) {
+    DGNN_REQUIRE(n >= 0 && (n == 0 || (x && y)), DGNN_E_INVALID, "relu_bf16: bad args");
+    if (n == 0) return DGNN_OK;
+    hipLaunchKernelGGL((k_relu<uint16_t>), dim3(dgnn_grid_cap(dgnn_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream, x, n, y);
+    return dgnn_check_launch("relu_bf16");
+}
+
+extern "C" int dgnn_relu_bwd_bf16(const uint16_t* y, const uint16_t* g, int64_t n, uint16_t* out, void* stream) {
+    DGNN_REQUIRE(n >= 0 && (n == 0 || (y && g && out)), DGNN_E_INVALID, "relu_bwd_bf16: bad args");
+    if (n == 0) return DGNN_OK;
+    hipLaunchKernelGGL((k_relu_bwd<uint16_t>), dim3(dgnn_grid_cap(dgnn_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream, y, g, n, out);
+    return dgnn_check_launch("relu_bwd_bf16");
 }

@@ -76,25 +76,30 @@ class _AggregatePlain(torch.autograd.Function):
 
 
 class _Linear2(torch.autograd.Function):
-    """out = A1.W1^T + A2.W2^T + bias   (A2/W2/bias optional)"""
+    """out = A1.W1^T + A2.W2^T + bias   (A2/W2/bias optional).  bf16 storage: A1/A2 bf16, weights fp32 (master copies), out
+    bf16 or -- `out_f32`, the logits -- fp32; gradients of activations come back in the activations' type, gradients of the
+    parameters in fp32."""
 
     @staticmethod
-    def forward(ctx, A1, W1, A2, W2, bias):
+    def forward(ctx, A1, W1, A2, W2, bias, out_f32):
         ctx.save_for_backward(A1, W1, A2, W2)
         ctx.has_bias = bias is not None
-        return ops.linear_fwd(A1, W1, A2, W2, bias)
+        return ops.linear_fwd(A1, W1, A2, W2, bias, out_dtype=torch.float32 if out_f32 else None)
 
     @staticmethod
     def backward(ctx, g):
         A1, W1, A2, W2 = ctx.saved_tensors
         g = g.contiguous()
         need = ctx.needs_input_grad
-        dA1 = ops.linear_fwd(g, W1.t().contiguous()) if need[0] else None
+        gb = g
+        if A1.dtype == torch.bfloat16 and g.dtype == torch.float32:
+            gb = ops.cast_to_bf16(g)[:, :g.size(1)]     # gradient of fp32 logits entering the bf16 part of the graph
+        dA1 = ops.linear_fwd(gb, W1.t().contiguous()) if need[0] else None
         dW1 = ops.linear_wgrad(g, A1) if need[1] else None
-        dA2 = ops.linear_fwd(g, W2.t().contiguous()) if (A2 is not None and need[2]) else None
+        dA2 = ops.linear_fwd(gb, W2.t().contiguous()) if (A2 is not None and need[2]) else None
         dW2 = ops.linear_wgrad(g, A2) if (A2 is not None and need[3]) else None
         db = ops.colsum(g) if (ctx.has_bias and need[4]) else None
-        return dA1, dW1, dA2, dW2, db
+        return dA1, dW1, dA2, dW2, db, None
 
 
 class _BatchNormAct(torch.autograd.Function):
@@ -128,8 +133,24 @@ def aggregate(x_src, plan, edge_attr=None, We=None, be=None, phi=None):
     return _AggregatePlain.apply(x_src, plan)
 
 
-def linear2(A1, W1, A2=None, W2=None, bias=None):
-    return _Linear2.apply(A1, W1, A2, W2, bias)
+def linear2(A1, W1, A2=None, W2=None, bias=None, out_f32=False):
+    return _Linear2.apply(A1, W1, A2, W2, bias, out_f32)
+
+
+class _ToBF16(torch.autograd.Function):
+    """fp32 -> bf16 storage (inputs entering the bf16 part of the graph); the gradient is widened back"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.cast_to_bf16(x, x.size(1) if x.size(1) % 2 == 0 else None)[:, :x.size(1)]
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.cast_to_f32(g.contiguous())
+
+
+def to_bf16(x):
+    return x if x.dtype == torch.bfloat16 else _ToBF16.apply(x)
 
 
 def batch_norm_act(x, bn: torch.nn.BatchNorm1d, relu: bool):

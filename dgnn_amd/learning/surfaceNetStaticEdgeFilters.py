@@ -52,15 +52,18 @@ class SAGEConv(nn.Module):
         self.lin_j = lin_j
         self.lin_e = lin_e
 
-    def _filter_args(self, edge_attr):
-        """lin_e as (edge_attr, We, be) for the fused kernel, or a materialised phi for edge MLPs."""
+    def _filter_args(self, edge_attr, bf16=False):
+        """lin_e as (edge_attr, We, be) for the fused kernel, or a materialised phi for edge MLPs (`bf16`: phi is
+        materialised in the activations' bf16 storage type)."""
         le = self.lin_e
         if le is None:
             return dict()
         if isinstance(le, Linear):
             if le.in_features in (2, 20):
                 return dict(edge_attr=edge_attr, We=le.weight, be=le.bias)
-            return dict(phi=Fn.linear2(edge_attr, le.weight, bias=le.bias))
+            return dict(phi=Fn.linear2(Fn.to_bf16(edge_attr) if bf16 else edge_attr, le.weight, bias=le.bias))
+        if bf16:
+            edge_attr = Fn.to_bf16(edge_attr)
         # edge_convs == 2 (:131-136): Linear -> norm -> ReLU -> Linear, materialised per edge
         h = Fn.linear2(edge_attr, le[0].weight, bias=le[0].bias)
         h = le[1](h, relu=True) if le[1] is not None else Fn.relu(h)
@@ -72,7 +75,7 @@ class SAGEConv(nn.Module):
         x_src, x_dst = x
         if plan is None:
             plan = plan_for(edge_index, x_src.size(0), x_dst.size(0))
-        a = Fn.aggregate(x_src, plan, **self._filter_args(edge_attr))
+        a = Fn.aggregate(x_src, plan, **self._filter_args(edge_attr, x_src.dtype == torch.bfloat16))
         if x_dst is not None:
             return Fn.linear2(a, self.lin_j.weight, x_dst, self.lin_i.weight, self.lin_j.bias)
         return Fn.linear2(a, self.lin_j.weight, bias=self.lin_j.bias)
@@ -136,6 +139,20 @@ class SurfaceNet(nn.Module):
             self.decoder.add_module("3", nn.Linear(int(last / 2), self.output_dim))
 
     # ------------------------------------------------------------------------------------------
+    storage_dtype = torch.float32
+
+    def set_storage_dtype(self, dtype):
+        """torch.float32 (default: the reference's arithmetic) or torch.bfloat16 = the bf16 STORAGE path (BASELINE config 3):
+        activations are kept in HBM as bf16, every product runs once on the bf16 matrix cores with fp32 accumulation,
+        parameters stay fp32.  Tolerance of that path: |dlogit| <= 5e-2 * max(1, |logit|/8), arg-max agreement >= 99.9 %."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("storage dtype must be torch.float32 or torch.bfloat16")
+        self.storage_dtype = dtype
+        return self
+
+    def dominant_kernel_name(self, shape):
+        return "k_sage_fused_bf16<%d,%d>" % (32 if shape[0] <= 32 else (64 if shape[0] <= 64 else 128), shape[1])
+
     def _device(self):
         dev = self.clf.temp.device
         if not str(dev).startswith("cuda"):
@@ -158,10 +175,10 @@ class SurfaceNet(nn.Module):
         if len(dec) == 0:
             return x
         if len(dec) == 1:
-            return Fn.linear2(x, dec[0].weight, bias=dec[0].bias)
+            return Fn.linear2(x, dec[0].weight, bias=dec[0].bias, out_f32=True)
         h = Fn.linear2(x, dec[0].weight, bias=dec[0].bias)
         h = dec[1](h, relu=True) if dec[1] is not None else Fn.relu(h)
-        return Fn.linear2(h, dec[3].weight, bias=dec[3].bias)
+        return Fn.linear2(h, dec[3].weight, bias=dec[3].bias, out_f32=True)   # logits stay fp32 in the bf16 storage path too
 
     # ---- TRAIN FORWARD (reference :196-227) ---------------------------------------------------
     def forward(self, data):
@@ -169,6 +186,8 @@ class SurfaceNet(nn.Module):
         x_all = data.all.x
         n_id = data.batch_n_id.to(x_all.device)
         x = _dev_f32(x_all[n_id, 1:] if self.clf.regularization.cell_type else x_all[n_id, :], dev)
+        if self.storage_dtype == torch.bfloat16:
+            x = Fn.to_bf16(x)
         for i in range(self.num_layers):
             edge_index, e_id, size = data.batch_adjs[i]
             ea = _dev_f32(data.all.edge_attr[e_id.to(data.all.edge_attr.device)], dev)
@@ -177,7 +196,7 @@ class SurfaceNet(nn.Module):
             x = self._norm_act(self.convs[i], x)
         if self.clf.model.decoder:
             x = self._decode(x)
-        return x
+        return x.float() if x.dtype == torch.bfloat16 else x
 
     # ---- INFERENCE, whole graph (reference :323-355; the benchmarked path) ---------------------
     @torch.no_grad()
@@ -185,6 +204,8 @@ class SurfaceNet(nn.Module):
         dev = self._device()
         x = _dev_f32(data_all.x, dev)
         x = x[:, 1:] if self.clf.regularization.cell_type else x
+        if self.storage_dtype == torch.bfloat16:
+            x = ops.cast_to_bf16(x)      # [N, 32] bf16, zero padding columns; later layers write bf16 themselves
         xe = _dev_f32(data_all.edge_attr, dev)
         xe = xe[:, 1:] if self.clf.regularization.edge_type else xe
         edge_index = data_all.edge_index.to(dev)
@@ -240,6 +261,18 @@ class SurfaceNet(nn.Module):
         x_dst = x[b:e]
         out_v = out if (out is None or rows is None) else out[b:e]
         simple = isinstance(le, Linear) and le.in_features in (2, 20)
+        if x.dtype == torch.bfloat16:
+            c_in = conv.lin_j.in_features    # the logical width: bf16 rows may carry zero padding columns
+            if not (simple and le.in_features == 20 and ops.fused_layer_supported_bf16(c_in, conv.lin_j.out_features, 20, x)):
+                return self._eval_layer_bf16_unfused(conv, scale, shift, x, xe, plan, sorted_attr, out_v, rows)
+            if sorted_attr and ops.EDGE_GATHER_IN_KERNEL and xe.stride(0) == 20 and xe.data_ptr() % 16 == 0:
+                ea, eid = xe, plan.eid
+            else:
+                ea, eid = (plan.sorted_edge_attr(xe) if sorted_attr else xe), None
+                if ea.stride(0) != 20 or ea.data_ptr() % 16:
+                    ea = ea.contiguous()
+            return ops.sage_layer_fused_fwd_bf16(rowptr, plan.src, n, x, c_in, ea, le.weight, le.bias, conv.lin_j.weight, conv.lin_j.bias,
+                                                 conv.lin_i.weight, scale, shift, True, out=out_v, eid=eid, x_dst=x_dst if b else None)
         if simple and le.in_features == 20 and ops.fused_layer_supported(x.size(1), conv.lin_j.out_features, 20, x):
             # sorted_attr: xe is in the caller's edge order.  Either the kernel gathers each row by eid (no staging
             # copy of the edge features), or the rows are staged into plan order once and reused by all layers.
@@ -278,13 +311,33 @@ class SurfaceNet(nn.Module):
             a = Fn.aggregate(x, plan, **conv._filter_args(xe))
         return ops.linear_fwd(a, conv.lin_j.weight, x_dst, conv.lin_i.weight, conv.lin_j.bias, scale, shift, True, out=out_v)
 
+    def _eval_layer_bf16_unfused(self, conv, scale, shift, x, xe, plan, sorted_attr, out_v, rows):
+        """bf16 storage, widths the fused bf16 kernel does not cover: the generic bf16 aggregate + bf16-MFMA GEMM pair."""
+        if rows is not None:
+            raise NotImplementedError("destination sub-ranges in bf16 storage need a fused-kernel width")
+        le = conv.lin_e
+        c_in = conv.lin_j.in_features
+        xs = x[:, :c_in] if x.size(1) != c_in else x
+        if isinstance(le, Linear) and le.in_features in (2, 20):
+            ea = plan.sorted_edge_attr(xe) if sorted_attr else xe
+            a = ops.aggregate_fwd(plan.rowptr, plan.src, None, plan.n_dst, xs, ea, le.weight, le.bias)
+        else:
+            a = Fn.aggregate(xs, plan, **conv._filter_args(xe, True))
+        return ops.linear_fwd(a, conv.lin_j.weight, xs[:plan.n_dst], conv.lin_i.weight, conv.lin_j.bias, scale, shift, True, out=out_v,
+                              out_dtype=torch.bfloat16)
+
     def _eval_decoder(self, x):
         dec = self.decoder
         if not self.clf.model.decoder or len(dec) == 0:
-            return x
+            return x.float() if x.dtype == torch.bfloat16 else x
         if len(dec) == 1:
-            return ops.linear_fwd(x, dec[0].weight, bias=dec[0].bias)
+            return ops.linear_fwd(x, dec[0].weight, bias=dec[0].bias, out_dtype=torch.float32)
         scale, shift = self._fold(dec[1] if isinstance(dec[1], BatchNorm) else None, dec[0].out_features, x.device)
+        if x.dtype == torch.bfloat16:
+            if ops.decoder_fused_supported(dec[0].in_features, dec[0].out_features, dec[3].out_features) and x.stride(0) % 8 == 0:
+                return ops.decoder_fused_fwd_bf16(x, dec[0].weight, dec[0].bias, scale, shift, dec[3].weight, dec[3].bias)
+            h = ops.linear_fwd(x, dec[0].weight, bias=dec[0].bias, scale=scale, shift=shift, relu=True, out_dtype=torch.bfloat16)
+            return ops.linear_fwd(h, dec[3].weight, bias=dec[3].bias, out_dtype=torch.float32)
         if ops.decoder_fused_supported(dec[0].in_features, dec[0].out_features, dec[3].out_features):
             return ops.decoder_fused_fwd(x, dec[0].weight, dec[0].bias, scale, shift, dec[3].weight, dec[3].bias)
         h = ops.linear_fwd(x, dec[0].weight, bias=dec[0].bias, scale=scale, shift=shift, relu=True)

@@ -53,6 +53,8 @@ class SAGEConv(nn.Module):
         x_src, x_dst = x
         if plan is None:
             plan = plan_for(edge_index, x_src.size(0), x_dst.size(0))
+        if x_src.dtype == torch.bfloat16:
+            edge_attr = Fn.to_bf16(edge_attr)                                        # bf16 storage: phi is written once in bf16
         phi = Fn.linear2(edge_attr, self.lin_e.weight, bias=self.lin_e.bias)        # :156
         a = Fn.aggregate(x_src, plan, phi=phi)                                       # :158 (mean of x_j * phi)
         out = Fn.linear2(a, self.lin_l.weight, x_dst, self.lin_r.weight, self.lin_l.bias)  # :159-165
@@ -82,6 +84,17 @@ class SurfaceNet(nn.Module):
         if clf.training.model_name[-1] == "+":
             self.out_net = nn.Sequential(nn.ReLU(True), nn.Linear(p[-1], 128), nn.ReLU(True), nn.Linear(128, 2))
 
+    storage_dtype = torch.float32
+
+    def set_storage_dtype(self, dtype):
+        """torch.float32 (default) or torch.bfloat16: node activations and the chained edge embeddings phi are stored in bf16
+        (phi is the [E, C] tensor that is written once and read twice per layer -- where bf16 halves the traffic), products on
+        the bf16 matrix cores with fp32 accumulation, parameters and their gradients fp32 (BASELINE config 3)."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("storage dtype must be torch.float32 or torch.bfloat16")
+        self.storage_dtype = dtype
+        return self
+
     def forward(self, data_all):
         dev = self.clf.temp.device
         if not str(dev).startswith("cuda"):
@@ -93,6 +106,8 @@ class SurfaceNet(nn.Module):
             x = _dev_f32(x_all[n_id, 1:], dev)
         else:
             x = _dev_f32(x_all[n_id, :], dev)
+        if self.storage_dtype == torch.bfloat16:
+            x = Fn.to_bf16(x)
         edge_attr = _dev_f32(data_all.edge_attr, dev)
         n_edges = edge_attr.size(0)
         for i in range(self.num_layers):
@@ -110,8 +125,8 @@ class SurfaceNet(nn.Module):
             x = Fn.relu(x)  # out_net[0] is another ReLU (idempotent)
             x = Fn.linear2(x, self.out_net[1].weight, bias=self.out_net[1].bias)
             x = Fn.relu(x)
-            x = Fn.linear2(x, self.out_net[3].weight, bias=self.out_net[3].bias)
-        return x
+            x = Fn.linear2(x, self.out_net[3].weight, bias=self.out_net[3].bias, out_f32=True)
+        return x.float() if x.dtype == torch.bfloat16 else x
 
     def _unsupported(self, *a, **k):
         raise NotImplementedError("the reference's surfaceNetUpdatedEdgeFilters.inference_* methods call the conv without "

@@ -15,7 +15,7 @@ def _req(t: torch.Tensor, name: str, dtype=torch.float32, dim=None, any_stride=F
         raise TypeError("%s must be a tensor" % name)
     if not t.is_cuda:
         raise DgnnError("%s is on %s: dgnn_amd runs on the GPU only (no CPU fallback)" % (name, t.device))
-    if t.dtype != dtype:
+    if (t.dtype not in dtype) if isinstance(dtype, tuple) else (t.dtype != dtype):
         raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
     if dim is not None and t.dim() != dim:
         raise ValueError("%s must be %d-D, got shape %s" % (name, dim, tuple(t.shape)))
@@ -31,6 +31,20 @@ def _ld(t: torch.Tensor) -> int:
 def rows2d(t: torch.Tensor, name: str) -> torch.Tensor:
     """Returns `t` as a 2-D fp32 tensor with unit column stride (copies only when it must)."""
     _req(t, name, dim=2)
+    return t
+
+
+ACT = (torch.float32, torch.bfloat16)   # storage types of activations: fp32 (reference arithmetic) or bf16 (BASELINE config 3)
+
+
+def _sfx(t: torch.Tensor) -> str:
+    """entry-point suffix for the storage type of `t`"""
+    return "_bf16" if t.dtype == torch.bfloat16 else ""
+
+
+def _same(t, ref, name):
+    if t is not None and t.dtype != ref.dtype:
+        raise TypeError("%s must have the storage type of its companion (%s), got %s" % (name, ref.dtype, t.dtype))
     return t
 
 
@@ -62,6 +76,10 @@ def plan_build(edge_index: torch.Tensor, n_key: int, by: int, hint: int = PLAN_H
 
 @on_device_of
 def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    if src.dtype == torch.bfloat16:   # rows of bf16 pairs move as fp32 words (bit copies)
+        if not src.is_contiguous() or src.size(1) % 2:
+            raise ValueError("bf16 gather_rows needs contiguous rows of even width")
+        return gather_rows(src.view(torch.float32), idx).view(torch.bfloat16)
     _req(src, "src", dim=2)
     _req(idx, "idx", torch.int32, 1)
     out = torch.empty((idx.numel(), src.size(1)), dtype=torch.float32, device=src.device)
@@ -72,6 +90,11 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 
 @on_device_of
 def scatter_rows_(out: torch.Tensor, idx: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    if src.dtype == torch.bfloat16:   # bit copies of bf16 pairs as fp32 words
+        if not (src.is_contiguous() and out.is_contiguous()) or src.size(1) % 2 or out.dtype != torch.bfloat16:
+            raise ValueError("bf16 scatter_rows_ needs contiguous bf16 rows of even width")
+        scatter_rows_(out.view(torch.float32), idx, src.view(torch.float32))
+        return out
     _req(src, "src", dim=2)
     _req(out, "out", dim=2)
     _req(idx, "idx", torch.int64, 1)
@@ -82,29 +105,29 @@ def scatter_rows_(out: torch.Tensor, idx: torch.Tensor, src: torch.Tensor) -> to
 
 @on_device_of
 def relu(x: torch.Tensor) -> torch.Tensor:
-    _req(x, "x")
+    _req(x, "x", ACT)
     x = x.contiguous()
     y = torch.empty_like(x)
-    check(lib().dgnn_relu(ptr(x), x.numel(), ptr(y), stream_ptr()), "dgnn_relu")
+    check(getattr(lib(), "dgnn_relu" + _sfx(x))(ptr(x), x.numel(), ptr(y), stream_ptr()), "dgnn_relu")
     return y
 
 
 @on_device_of
 def relu_bwd(y: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
-    _req(y, "y")
-    _req(g, "g")
+    _req(y, "y", ACT)
+    _same(_req(g, "g", ACT), y, "g")
     y, g = y.contiguous(), g.contiguous()
     out = torch.empty_like(g)
-    check(lib().dgnn_relu_bwd(ptr(y), ptr(g), g.numel(), ptr(out), stream_ptr()), "dgnn_relu_bwd")
+    check(getattr(lib(), "dgnn_relu_bwd" + _sfx(y))(ptr(y), ptr(g), g.numel(), ptr(out), stream_ptr()), "dgnn_relu_bwd")
     return out
 
 
 # ---- aggregation --------------------------------------------------------------------------------
 @on_device_of
 def aggregate_fwd(rowptr, src, eid, n_dst, x_src, edge_attr=None, We=None, be=None, phi=None, want_phi=False):
-    _req(x_src, "x_src", dim=2)
+    _req(x_src, "x_src", ACT, dim=2)
     c_in = x_src.size(1)
-    a = torch.empty((n_dst, c_in), dtype=torch.float32, device=x_src.device)
+    a = torch.empty((n_dst, c_in), dtype=x_src.dtype, device=x_src.device)
     phi_out = None
     f_e = 0
     if We is not None:
@@ -116,10 +139,10 @@ def aggregate_fwd(rowptr, src, eid, n_dst, x_src, edge_attr=None, We=None, be=No
         if We.size(0) != c_in or edge_attr.size(1) < f_e:
             raise ValueError("lin_e weight %s does not match c_in=%d / edge_attr %s" % (tuple(We.shape), c_in, tuple(edge_attr.shape)))
         if want_phi:
-            phi_out = torch.empty((edge_attr.size(0), c_in), dtype=torch.float32, device=x_src.device)
+            phi_out = torch.empty((edge_attr.size(0), c_in), dtype=x_src.dtype, device=x_src.device)
     elif phi is not None:
-        _req(phi, "phi", dim=2)
-    check(lib().dgnn_sage_aggregate_fwd(
+        _same(_req(phi, "phi", ACT, dim=2), x_src, "phi")
+    check(getattr(lib(), "dgnn_sage_aggregate_fwd" + _sfx(x_src))(
         ptr(rowptr), ptr(src), ptr(eid), n_dst, ptr(x_src), _ld(x_src), c_in,
         ptr(edge_attr) if We is not None else None, _ld(edge_attr) if We is not None else 0, f_e,
         ptr(We), ptr(be), ptr(phi), _ld(phi) if phi is not None else 0,
@@ -131,11 +154,12 @@ def aggregate_fwd(rowptr, src, eid, n_dst, x_src, edge_attr=None, We=None, be=No
 def aggregate_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, da, edge_attr=None, We=None, be=None, phi=None,
                   need_dx=True):
     """-> (dx_src | None, dWe | None, dbe | None, dphi | None)"""
-    _req(x_src, "x_src", dim=2)
-    _req(da, "da", dim=2)
+    _req(x_src, "x_src", ACT, dim=2)
+    _same(_req(da, "da", ACT, dim=2), x_src, "da")
+    _same(phi, x_src, "phi")
     c_in = x_src.size(1)
     dev = x_src.device
-    dx = torch.empty((n_src, c_in), dtype=torch.float32, device=dev) if need_dx else None
+    dx = torch.empty((n_src, c_in), dtype=x_src.dtype, device=dev) if need_dx else None
     dWe = dbe = dphi = None
     f_e = 0
     partials = None
@@ -147,8 +171,8 @@ def aggregate_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, da, edge_att
         dbe = torch.zeros_like(be)
         partials = _f32(lib().dgnn_sage_aggregate_bwd_scratch_elems(n_src, c_in, f_e), dev)
     elif phi is not None:
-        dphi = torch.zeros((phi.size(0), c_in), dtype=torch.float32, device=dev)
-    check(lib().dgnn_sage_aggregate_bwd(
+        dphi = torch.zeros((phi.size(0), c_in), dtype=x_src.dtype, device=dev)
+    check(getattr(lib(), "dgnn_sage_aggregate_bwd" + _sfx(x_src))(
         ptr(t_rowptr), ptr(t_dst), ptr(t_eid), n_src, ptr(rowptr_dst), ptr(x_src), _ld(x_src), c_in,
         ptr(edge_attr) if We is not None else None, _ld(edge_attr) if We is not None else 0, f_e, ptr(We), ptr(be),
         ptr(phi), _ld(phi) if phi is not None else 0, ptr(da), _ld(da), ptr(dx), c_in, ptr(dWe), ptr(dbe), ptr(dphi), c_in,
@@ -158,21 +182,36 @@ def aggregate_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, da, edge_att
 
 # ---- dense --------------------------------------------------------------------------------------
 @on_device_of
-def linear_fwd(A1, W1, A2=None, W2=None, bias=None, scale=None, shift=None, relu=False, out=None):
-    _req(A1, "A1", dim=2)
+def linear_fwd(A1, W1, A2=None, W2=None, bias=None, scale=None, shift=None, relu=False, out=None, out_dtype=None):
+    """out = act((A1.W1^T + A2.W2^T + bias) * scale + shift).  fp32 operands: fp32 MFMA, fp32 out.  bf16 operands (bf16 storage
+    path): bf16 MFMA with fp32 accumulation, `out_dtype` bf16 (default) or fp32 (logits); an fp32 A next to bf16 storage (a
+    gradient of fp32 logits) is rounded to bf16 first."""
+    _req(A1, "A1", ACT, dim=2)
     W1 = _req(W1, "W1", dim=2).contiguous()
     M, n_out = A1.size(0), W1.size(0)
     if W1.size(1) != A1.size(1):
         raise ValueError("W1 %s does not match A1 %s" % (tuple(W1.shape), tuple(A1.shape)))
     if A2 is not None:
-        _req(A2, "A2", dim=2)
+        _same(_req(A2, "A2", ACT, dim=2), A1, "A2")
         W2 = _req(W2, "W2", dim=2).contiguous()
         if A2.size(0) != M or W2.size(0) != n_out or W2.size(1) != A2.size(1):
             raise ValueError("second operand shapes do not match")
+    bf = A1.dtype == torch.bfloat16
+    if out_dtype is None:
+        out_dtype = out.dtype if out is not None else A1.dtype
+    if not bf and out_dtype != torch.float32:
+        raise TypeError("fp32 operands produce fp32 output")
     if out is None:
-        out = torch.empty((M, n_out), dtype=torch.float32, device=A1.device)
-    elif out.size(0) < M or out.size(1) != n_out or out.stride(0) != n_out:
-        raise ValueError("out must be a contiguous [>= M, n_out] buffer")
+        out = torch.empty((M, n_out), dtype=out_dtype, device=A1.device)
+    elif out.size(0) < M or out.size(1) != n_out or out.stride(0) != n_out or out.dtype != out_dtype:
+        raise ValueError("out must be a contiguous [>= M, n_out] buffer of the output type")
+    if bf:
+        check(lib().dgnn_linear_fwd_bf16(
+            ptr(A1), _ld(A1), A1.size(1), ptr(W1), W1.size(1),
+            ptr(A2), _ld(A2) if A2 is not None else 0, A2.size(1) if A2 is not None else 0, ptr(W2), W2.size(1) if W2 is not None else 0,
+            ptr(bias), ptr(scale), ptr(shift), int(bool(relu)), M, n_out, ptr(out), n_out, int(out_dtype == torch.float32), stream_ptr()),
+            "dgnn_linear_fwd_bf16")
+        return out
     check(lib().dgnn_linear_fwd(
         ptr(A1), _ld(A1), A1.size(1), ptr(W1), W1.size(1),
         ptr(A2), _ld(A2) if A2 is not None else 0, A2.size(1) if A2 is not None else 0, ptr(W2), W2.size(1) if W2 is not None else 0,
@@ -183,13 +222,17 @@ def linear_fwd(A1, W1, A2=None, W2=None, bias=None, scale=None, shift=None, relu
 @on_device_of
 def linear_wgrad(A, B):
     """dW[n_a,n_b] = A^T . B  (A [M,n_a], B [M,n_b])"""
-    _req(A, "A", dim=2)
-    _req(B, "B", dim=2)
+    _req(A, "A", ACT, dim=2)
+    _req(B, "B", ACT, dim=2)
     M, na, nb = A.size(0), A.size(1), B.size(1)
     dW = torch.empty((na, nb), dtype=torch.float32, device=A.device)
     if M == 0:
         return dW.zero_()
     partials = _f32(lib().dgnn_linear_wgrad_scratch_elems(M, na, nb), A.device)
+    if A.dtype == torch.bfloat16 or B.dtype == torch.bfloat16:   # bf16 storage path: bf16 MFMA, fp32 gradient
+        check(lib().dgnn_linear_wgrad_bf16(ptr(A), int(A.dtype == torch.float32), _ld(A), na, ptr(B), int(B.dtype == torch.float32), _ld(B), nb,
+                                           M, ptr(dW), nb, 0, ptr(partials), stream_ptr()), "dgnn_linear_wgrad_bf16")
+        return dW
     check(lib().dgnn_linear_wgrad(ptr(A), _ld(A), na, ptr(B), _ld(B), nb, M, ptr(dW), nb, 0, ptr(partials), stream_ptr()),
           "dgnn_linear_wgrad")
     return dW
@@ -197,12 +240,12 @@ def linear_wgrad(A, B):
 
 @on_device_of
 def colsum(x):
-    _req(x, "x", dim=2)
+    _req(x, "x", ACT, dim=2)
     out = torch.empty(x.size(1), dtype=torch.float32, device=x.device)
     if x.size(0) == 0:
         return out.zero_()
     scratch = _f32(lib().dgnn_colstats_scratch_elems(x.size(0), x.size(1)), x.device)
-    check(lib().dgnn_colsum(ptr(x), _ld(x), x.size(0), x.size(1), ptr(out), 0, ptr(scratch), stream_ptr()), "dgnn_colsum")
+    check(getattr(lib(), "dgnn_colsum" + _sfx(x))(ptr(x), _ld(x), x.size(0), x.size(1), ptr(out), 0, ptr(scratch), stream_ptr()), "dgnn_colsum")
     return out
 
 
@@ -219,35 +262,36 @@ def bn_fold(gamma, beta, mean, var, eps):
 
 @on_device_of
 def bn_batch_stats(x, running_mean=None, running_var=None, momentum=0.1):
-    _req(x, "x", dim=2)
+    _req(x, "x", ACT, dim=2)
     M, c = x.shape
     mean = torch.empty(c, dtype=torch.float32, device=x.device)
     var = torch.empty(c, dtype=torch.float32, device=x.device)
     scratch = _f32(lib().dgnn_colstats_scratch_elems(M, c), x.device)
-    check(lib().dgnn_bn_batch_stats(ptr(x), _ld(x), M, c, ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
+    check(getattr(lib(), "dgnn_bn_batch_stats" + _sfx(x))(ptr(x), _ld(x), M, c, ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
                                     float(momentum), ptr(scratch), stream_ptr()), "dgnn_bn_batch_stats")
     return mean, var
 
 
 @on_device_of
 def scale_shift_act(x, scale, shift, relu):
-    _req(x, "x", dim=2)
-    y = torch.empty((x.size(0), x.size(1)), dtype=torch.float32, device=x.device)
-    check(lib().dgnn_scale_shift_act(ptr(x), _ld(x), ptr(scale), ptr(shift), int(bool(relu)), x.size(0), x.size(1), ptr(y),
+    _req(x, "x", ACT, dim=2)
+    y = torch.empty((x.size(0), x.size(1)), dtype=x.dtype, device=x.device)
+    check(getattr(lib(), "dgnn_scale_shift_act" + _sfx(x))(ptr(x), _ld(x), ptr(scale), ptr(shift), int(bool(relu)), x.size(0), x.size(1), ptr(y),
                                      x.size(1), stream_ptr()), "dgnn_scale_shift_act")
     return y
 
 
 @on_device_of
 def bn_relu_bwd(x, y, dy, gamma, mean, var, eps, train, relu):
-    _req(x, "x", dim=2)
-    _req(dy, "dy", dim=2)
+    _req(x, "x", ACT, dim=2)
+    _same(_req(dy, "dy", ACT, dim=2), x, "dy")
+    _same(y, x, "y")
     M, c = x.shape
-    dx = torch.empty((M, c), dtype=torch.float32, device=x.device)
+    dx = torch.empty((M, c), dtype=x.dtype, device=x.device)
     dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
     dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
     scratch = _f32(lib().dgnn_colstats_scratch_elems(M, c), x.device)
-    check(lib().dgnn_bn_relu_bwd(ptr(x), _ld(x), ptr(y), _ld(y) if y is not None else 0, ptr(dy), _ld(dy), ptr(gamma), ptr(mean),
+    check(getattr(lib(), "dgnn_bn_relu_bwd" + _sfx(x))(ptr(x), _ld(x), ptr(y), _ld(y) if y is not None else 0, ptr(dy), _ld(dy), ptr(gamma), ptr(mean),
                                  ptr(var), float(eps), int(bool(train)), int(bool(relu)), M, c, ptr(dx), c, ptr(dgamma), ptr(dbeta),
                                  ptr(scratch), stream_ptr()), "dgnn_bn_relu_bwd")
     return dx, dgamma, dbeta
@@ -324,4 +368,70 @@ def decoder_fused_fwd(y, W0, b0, scale, shift, W3, b3):
     check(lib().dgnn_decoder_fused_fwd(ptr(y), _ld(y), M, y.size(1), ptr(W0.contiguous()), ptr(b0), ptr(scale), ptr(shift),
                                        W0.size(0), ptr(W3.contiguous()), ptr(b3), n_out, ptr(out), n_out, stream_ptr()),
           "dgnn_decoder_fused_fwd")
+    return out
+
+
+# ---- bf16 storage path (BASELINE config 3) ----------------------------------------------------------------------------------
+BF16 = torch.bfloat16
+
+
+@on_device_of
+def cast_to_bf16(x: torch.Tensor, cols_pad: int = None) -> torch.Tensor:
+    """fp32 [n, cols] (any row stride) -> bf16 [n, cols_pad] with zero padding columns (cols_pad even, default: cols rounded up to even)."""
+    _req(x, "x", dim=2)
+    n, cols = x.shape
+    if cols_pad is None:
+        cols_pad = (cols + 1) // 2 * 2
+    out = torch.empty((n, cols_pad), dtype=BF16, device=x.device)
+    check(lib().dgnn_cast_f32_to_bf16(ptr(x), _ld(x), n, cols, cols_pad, ptr(out), cols_pad, stream_ptr()), "dgnn_cast_f32_to_bf16")
+    return out
+
+
+@on_device_of
+def cast_to_f32(x: torch.Tensor) -> torch.Tensor:
+    _req(x, "x", BF16, dim=2)
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(lib().dgnn_cast_bf16_to_f32(ptr(x), _ld(x), x.size(0), x.size(1), ptr(out), x.size(1), stream_ptr()), "dgnn_cast_bf16_to_f32")
+    return out
+
+
+def fused_layer_supported_bf16(c_in: int, c_out: int, f_e: int, x: torch.Tensor = None) -> bool:
+    """Mirrors the shape dispatch of dgnn_sage_layer_fused_fwd_bf16 (csrc/fused_bf16.hip)."""
+    if not FUSED_ENABLED or f_e != 20 or c_in > 128 or c_out not in (64, 128):
+        return False
+    nb = 2 if c_in <= 32 else (4 if c_in <= 64 else 8)
+    ok = c_in % nb == 0
+    if x is not None:
+        ok = ok and x.stride(0) % nb == 0 and x.data_ptr() % (2 * nb) == 0
+    return ok
+
+
+@on_device_of
+def sage_layer_fused_fwd_bf16(rowptr, src, n_dst, x_src, c_in, edge_attr, We, be, Wj, bj, Wi, scale, shift, relu, out=None, eid=None,
+                              x_dst=None):
+    """bf16-storage twin of sage_layer_fused_fwd.  `x_src` bf16 [n_src, ld >= c_in] (padding columns allowed: `c_in` is the
+    logical width = Wj.shape[1]); returns bf16 [n_dst, c_out]."""
+    _req(x_src, "x_src", BF16, dim=2)
+    c_out = Wj.size(0)
+    if out is None:
+        out = torch.empty((n_dst, c_out), dtype=BF16, device=x_src.device)
+    else:
+        _req(out, "out", BF16, dim=2)
+        if out.size(0) < n_dst or out.size(1) != c_out or out.stride(0) != c_out:
+            raise ValueError("out must be a contiguous [>= n_dst, c_out] buffer")
+    check(lib().dgnn_sage_layer_fused_fwd_bf16(
+        ptr(rowptr), ptr(src), ptr(eid), n_dst, ptr(x_src), ptr(x_dst), _ld(x_src), c_in, ptr(edge_attr), _ld(edge_attr), We.size(1),
+        ptr(We), ptr(be), ptr(Wj), ptr(bj), ptr(Wi), ptr(scale), ptr(shift), int(bool(relu)), c_out, ptr(out), c_out, stream_ptr()),
+        "dgnn_sage_layer_fused_fwd_bf16")
+    return out
+
+
+@on_device_of
+def decoder_fused_fwd_bf16(y, W0, b0, scale, shift, W3, b3):
+    _req(y, "y", BF16, dim=2)
+    M, n_out = y.size(0), W3.size(0)
+    out = torch.empty((M, n_out), dtype=torch.float32, device=y.device)
+    check(lib().dgnn_decoder_fused_fwd_bf16(ptr(y), _ld(y), M, y.size(1), ptr(W0.contiguous()), ptr(b0), ptr(scale), ptr(shift),
+                                            W0.size(0), ptr(W3.contiguous()), ptr(b3), n_out, ptr(out), n_out, stream_ptr()),
+          "dgnn_decoder_fused_fwd_bf16")
     return out

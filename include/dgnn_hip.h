@@ -201,6 +201,56 @@ int dgnn_decoder_fused_fwd(const float* y, int64_t ldy, int64_t M, int k, const 
                            const float* scale, const float* shift, int hidden, const float* W3, const float* b3, int n_out,
                            float* out, int64_t ldo, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * bf16 STORAGE path (BASELINE config 3): activations (and, for the Updated variant, the edge
+ * embeddings phi) live in HBM as bf16 (uint16_t bit patterns here, torch.bfloat16 on the Python side), every matrix
+ * product runs once on the bf16 matrix cores with fp32 accumulation, parameters stay fp32 (master weights, rounded to
+ * bf16 when staged).  Stated tolerance: |dlogit| <= 5e-2 * max(1, |logit|/8), arg-max agreement >= 99.9 % vs fp32.
+ * Same argument meaning as the fp32 entry points of the same name; rows must be aligned as each comment says.
+ * ---------------------------------------------------------------------------------------------- */
+/* out[r, 0:cols] = bf16(in[r, 0:cols]), out[r, cols:cols_pad] = 0   (cols_pad even, ld_out >= cols_pad, ld_out even) */
+int dgnn_cast_f32_to_bf16(const float* in, int64_t ld_in, int64_t n, int cols, int cols_pad, uint16_t* out, int64_t ld_out, void* stream);
+int dgnn_cast_bf16_to_f32(const uint16_t* in, int64_t ld_in, int64_t n, int cols, float* out, int64_t ld_out, void* stream);
+/* dgnn_sage_layer_fused_fwd with bf16 x_src / x_dst / out (edge_attr and all parameters fp32).  c_in <= 128, c_out in {64,128};
+ * with nb = 2/4/8 for c_in <= 32/64/128: c_in % nb == 0, ldx % nb == 0, rows 2*nb-byte aligned; ldo even, out 4-byte aligned. */
+int dgnn_sage_layer_fused_fwd_bf16(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const uint16_t* x_src,
+                                   const uint16_t* x_dst, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e,
+                                   const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
+                                   const float* scale, const float* shift, int relu, int c_out, uint16_t* out, int64_t ldo, void* stream);
+/* dgnn_decoder_fused_fwd on bf16 rows (16-byte aligned, ldy % 8 == 0); logits stay fp32 */
+int dgnn_decoder_fused_fwd_bf16(const uint16_t* y, int64_t ldy, int64_t M, int k, const float* W0, const float* b0, const float* scale,
+                                const float* shift, int hidden, const float* W3, const float* b3, int n_out, float* out, int64_t ldo,
+                                void* stream);
+
+/* bf16-storage twins of the generic (training / any-width) entry points above: x / phi / a / gradients of activations are
+ * bf16, parameters and their gradients fp32, all arithmetic fp32 between a widening load and a rounding store; the GEMMs run
+ * on v_mfma_f32_32x32x16_bf16.  dgnn_linear_fwd_bf16: out is bf16 (out_f32 == 0) or fp32 (logits).  dgnn_linear_wgrad_bf16:
+ * A / B are bf16 (x_f32 == 0) or fp32 (rounded to bf16 when staged); scratch sizes as for the fp32 functions. */
+int dgnn_sage_aggregate_fwd_bf16(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const uint16_t* x_src,
+                                 int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e, const float* We, const float* be,
+                                 const uint16_t* phi, int64_t ldphi, uint16_t* phi_out, int64_t ldphi_out, uint16_t* a, int64_t lda,
+                                 void* stream);
+int dgnn_sage_aggregate_bwd_bf16(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, int64_t n_src,
+                                 const int32_t* rowptr_dst, const uint16_t* x_src, int64_t ldx, int c_in, const float* edge_attr,
+                                 int64_t lde, int f_e, const float* We, const float* be, const uint16_t* phi, int64_t ldphi,
+                                 const uint16_t* da, int64_t ldda, uint16_t* dx_src, int64_t lddx, float* dWe, float* dbe,
+                                 uint16_t* dphi_out, int64_t lddphi, float* partials, void* stream);
+int dgnn_linear_fwd_bf16(const uint16_t* A1, int64_t lda1, int k1, const float* W1, int64_t ldw1, const uint16_t* A2, int64_t lda2, int k2,
+                         const float* W2, int64_t ldw2, const float* bias, const float* scale, const float* shift, int relu, int64_t M,
+                         int n_out, void* out, int64_t ldo, int out_f32, void* stream);
+int dgnn_linear_wgrad_bf16(const void* A, int a_f32, int64_t lda, int n_a, const void* B, int b_f32, int64_t ldb, int n_b, int64_t M,
+                           float* dW, int64_t lddw, int accumulate, float* partials, void* stream);
+int dgnn_bn_batch_stats_bf16(const uint16_t* x, int64_t ldx, int64_t M, int c, float* mean, float* var, float* running_mean,
+                             float* running_var, float momentum, float* scratch, void* stream);
+int dgnn_scale_shift_act_bf16(const uint16_t* x, int64_t ldx, const float* scale, const float* shift, int relu, int64_t M, int c,
+                              uint16_t* y, int64_t ldy, void* stream);
+int dgnn_bn_relu_bwd_bf16(const uint16_t* x, int64_t ldx, const uint16_t* y, int64_t ldy, const uint16_t* dy, int64_t lddy,
+                          const float* gamma, const float* mean, const float* var, float eps, int train, int relu, int64_t M, int c,
+                          uint16_t* dx, int64_t lddx, float* dgamma, float* dbeta, float* scratch, void* stream);
+int dgnn_colsum_bf16(const uint16_t* x, int64_t ldx, int64_t M, int c, float* out, int accumulate, float* scratch, void* stream);
+int dgnn_relu_bf16(const uint16_t* x, int64_t n, uint16_t* y, void* stream);
+int dgnn_relu_bwd_bf16(const uint16_t* y, const uint16_t* g, int64_t n, uint16_t* out, void* stream);
+
 /* Debug only: register a device buffer of n int64 slots; workgroup 0 of the fused kernel then stamps
  * wall_clock64() at phase boundaries (slot = (tile_iter*12 + wave)*8 + phase).  NULL disables. */
 int dgnn_debug_trace_buffer(int64_t* dev_buf, int64_t n);

@@ -1,0 +1,302 @@
+"""bf16 STORAGE path (BASELINE config 3): activations / edge embeddings bf16 in HBM, one bf16 MFMA per
+product, fp32 accumulation, fp32 parameters.
+
+Stated tolerance: |dlogit| <= 5e-2 * max(1, |logit| / 8) against the fp32 reference and arg-max agreement
+>= 99.9 %.  Kernel-level checks compare each bf16 op with the SAME op evaluated in fp64 on the bf16-rounded inputs: what is
+left is the rounding of the result (2^-9 relative) and the fp32 accumulation order, so those bounds are tight."""
+import numpy as np
+import pytest
+import torch
+
+from dgnn_amd.config import Config
+from helpers import f3_data, gold, oracle_static
+from test_gpu_parity import DEV, hip_static, rel_err
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+EPS = 2.0 ** -8   # bf16 spacing relative to the value (8 significant bits): rounding error <= EPS/2
+
+
+def bf_check(got, ref, what=""):
+    """stated bf16 tolerance on logits"""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    tol = 5e-2 * np.maximum(1.0, np.abs(ref) / 8)
+    err = np.abs(got - ref)
+    assert (err <= tol).all(), "%s max|dlogit| %.3e vs tol %.3e" % (what, err.max(), tol.reshape(-1)[err.argmax()])
+    agree = float((got.argmax(1) == ref.argmax(1)).mean())
+    assert agree >= 0.999, "%s arg-max agreement %.5f" % (what, agree)
+    return float(err.max()), agree
+
+
+def test_cast_round_trip_and_padding():
+    from dgnn_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1001, 29, generator=g) * 50
+    xb = ops.cast_to_bf16(x.to(DEV)[:, 1:])                 # strided fp32 view in, packed bf16 out
+    assert xb.dtype == BF and xb.shape == (1001, 28)
+    assert torch.equal(xb.cpu(), x[:, 1:].to(BF))           # round to nearest even, as torch
+    xp = ops.cast_to_bf16(x.to(DEV), 32)
+    assert xp.shape == (1001, 32) and torch.equal(xp[:, :29].cpu(), x.to(BF)) and bool((xp[:, 29:] == 0).all())
+    assert torch.equal(ops.cast_to_f32(xb).cpu(), x[:, 1:].to(BF).float())
+
+
+@pytest.mark.parametrize("c_in,c_out", [(28, 64), (64, 128), (128, 128), (64, 64), (32, 128)])
+def test_fused_layer_bf16_vs_fp64_on_rounded_inputs(c_in, c_out):
+    """one fused bf16 layer against fp64 evaluated on the bf16-rounded x, attributes and weights"""
+    from dgnn_amd import ops
+    from dgnn_amd.synthetic import delaunay_tet_graph
+    from oracle.pyg_semantics import propagate_mean
+    adj, _, _ = delaunay_tet_graph(900, seed=c_in)
+    n = adj.shape[0] // 4
+    ei = torch.from_numpy(adj.T.astype(np.int64))
+    g = torch.Generator().manual_seed(c_in + c_out)
+    x = torch.randn(n, c_in, generator=g)
+    x[::53] *= 30
+    ea = torch.randn(4 * n, 20, generator=g)
+    We, be = torch.randn(c_in, 20, generator=g) * 0.3, torch.randn(c_in, generator=g)
+    Wj, Wi, bj = torch.randn(c_out, c_in, generator=g) * 0.1, torch.randn(c_out, c_in, generator=g) * 0.1, torch.randn(c_out, generator=g)
+    scale, shift = torch.rand(c_out, generator=g) + 0.5, torch.randn(c_out, generator=g)
+    r = lambda t: t.to(BF).double()
+    phi = r(ea) @ r(We).t() + r(be)
+    a = propagate_mean(r(x), n, ei, phi)
+    ab = a.float().to(BF).double()                               # the kernel rounds the mean to bf16 before the dense part
+    ref = torch.relu((ab @ r(Wj).t() + r(x) @ r(Wi).t() + bj.double()) * scale.double() + shift.double())
+    rowptr, src, eid = ops.plan_build(ei.to(DEV), n, 1, n_other=n)
+    xb = ops.cast_to_bf16(x.to(DEV))
+    out = ops.sage_layer_fused_fwd_bf16(rowptr, src, n, xb, c_in, ea.to(DEV), We.to(DEV), be.to(DEV), Wj.to(DEV), bj.to(DEV), Wi.to(DEV),
+                                        scale.to(DEV), shift.to(DEV), True, eid=eid)
+    assert out.dtype == BF and out.shape == (n, c_out)
+    # a differs from the fp64 mean by fp32 rounding, which can flip its bf16 rounding: one bf16 ulp of a (2^-8 relative) through
+    # Wj, plus the rounding of the output itself
+    err = (out.cpu().double() - ref).abs()
+    bound = EPS * (ab.abs() @ r(Wj).abs().t()) * scale.double().abs() * 0.6 + EPS * ref.abs() * 0.6 + 1e-3
+    assert bool((err <= bound).all()), float((err / bound).max())
+    # rows in plan order (eid=None) give the same bits
+    out2 = ops.sage_layer_fused_fwd_bf16(rowptr, src, n, xb, c_in, ops.gather_rows(ea.to(DEV), eid), We.to(DEV), be.to(DEV), Wj.to(DEV),
+                                         bj.to(DEV), Wi.to(DEV), scale.to(DEV), shift.to(DEV), True)
+    assert torch.equal(out, out2)
+
+
+def test_fused_layer_bf16_irregular_degrees_and_tail():
+    """in-degree 0..many (generic per-lane path) and a destination count that is not a multiple of the tile"""
+    from dgnn_amd import ops
+    from oracle.pyg_semantics import propagate_mean
+    g = torch.Generator().manual_seed(5)
+    n_src, n_dst, E, c_in, c_out = 1500, 1003, 5200, 64, 128
+    ei = torch.stack([torch.randint(0, n_src, (E,), generator=g), torch.randint(0, n_dst + 30, (E,), generator=g).clamp_max(n_dst - 1)])
+    x = torch.randn(n_src, c_in, generator=g)
+    ea = torch.randn(E, 20, generator=g)
+    We, be = torch.randn(c_in, 20, generator=g) * 0.3, torch.randn(c_in, generator=g)
+    Wj, Wi, bj = torch.randn(c_out, c_in, generator=g) * 0.1, torch.randn(c_out, c_in, generator=g) * 0.1, torch.randn(c_out, generator=g)
+    r = lambda t: t.to(BF).double()
+    a = propagate_mean(r(x), n_dst, ei, r(ea) @ r(We).t() + r(be))
+    ref = a.float().to(BF).double() @ r(Wj).t() + r(x)[:n_dst] @ r(Wi).t() + bj.double()
+    rowptr, src, eid = ops.plan_build(ei.to(DEV), n_dst, 1, n_other=n_src)
+    out = ops.sage_layer_fused_fwd_bf16(rowptr, src, n_dst, ops.cast_to_bf16(x.to(DEV)), c_in, ea.to(DEV), We.to(DEV), be.to(DEV), Wj.to(DEV),
+                                        bj.to(DEV), Wi.to(DEV), None, None, False, eid=eid)
+    assert rel_err(out.float(), ref) < 1.5e-2
+
+
+def test_generic_bf16_ops_vs_fp64_on_rounded_inputs():
+    """aggregate (fused filter / given phi) fwd + bwd, GEMM fwd, weight gradient, BatchNorm train fwd/bwd, relu, column sums"""
+    from dgnn_amd import ops
+    from oracle.pyg_semantics import propagate_mean
+    g = torch.Generator().manual_seed(11)
+    n_src, n_dst, E, c = 800, 600, 2900, 96
+    ei = torch.stack([torch.randint(0, n_src, (E,), generator=g), torch.randint(0, n_dst, (E,), generator=g)])
+    x, phi, ea = torch.randn(n_src, c, generator=g), torch.randn(E, c, generator=g), torch.randn(E, 20, generator=g)
+    We, be = torch.randn(c, 20, generator=g) * 0.3, torch.randn(c, generator=g)
+    r = lambda t: t.to(BF).double()
+    rowptr, src, eid = ops.plan_build(ei.to(DEV), n_dst, 1, n_other=n_src)
+    xb, pb = ops.cast_to_bf16(x.to(DEV)), ops.cast_to_bf16(phi.to(DEV))
+    a = ops.aggregate_fwd(rowptr, src, eid, n_dst, xb, phi=pb)
+    assert a.dtype == BF and rel_err(a.float(), propagate_mean(r(x), n_dst, ei, r(phi))) < EPS
+    a2, phi_o = ops.aggregate_fwd(rowptr, src, eid, n_dst, xb, ea.to(DEV), We.to(DEV), be.to(DEV), want_phi=True)
+    phi64 = ea.double() @ We.double().t() + be.double()
+    assert rel_err(a2.float(), propagate_mean(r(x), n_dst, ei, phi64)) < EPS and rel_err(phi_o.float(), phi64) < EPS
+    # backward (given phi): dx, dphi against autograd in fp64
+    xd, pd = r(x).requires_grad_(), r(phi).requires_grad_()
+    da = torch.randn(n_dst, c, generator=g)
+    (propagate_mean(xd, n_dst, ei, pd) * r(da)).sum().backward()
+    t_rowptr, t_dst, t_eid = ops.plan_build(ei.to(DEV), n_src, 0, n_other=n_dst)
+    dx, _, _, dphi = ops.aggregate_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr, xb, ops.cast_to_bf16(da.to(DEV)), phi=pb)
+    assert dx.dtype == BF and rel_err(dx.float(), xd.grad) < EPS and rel_err(dphi.float(), pd.grad) < EPS
+    dx2, dWe, dbe, _ = ops.aggregate_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr, xb, ops.cast_to_bf16(da.to(DEV)), ea.to(DEV), We.to(DEV), be.to(DEV))
+    Wd, bd, xd2 = We.double().requires_grad_(), be.double().requires_grad_(), r(x).requires_grad_()
+    (propagate_mean(xd2, n_dst, ei, ea.double() @ Wd.t() + bd) * r(da)).sum().backward()
+    assert rel_err(dx2.float(), xd2.grad) < EPS and rel_err(dWe, Wd.grad) < 2e-5 and rel_err(dbe, bd.grad) < 2e-5
+    # GEMM: two bf16 operands, fp32 weights (rounded to bf16 when staged), bias, scale/shift, ReLU; bf16 and fp32 outputs
+    for M, k1, k2, n_out in [(1000, 28, 28, 64), (777, 64, 64, 128), (2048, 128, 128, 128), (300, 128, 0, 2), (130, 38, 6, 70), (1, 128, 0, 64),
+                             (515, 256, 256, 512), (4000, 2, 0, 28)]:
+        A1, W1 = torch.randn(M, k1, generator=g), torch.randn(n_out, k1, generator=g) * 0.2
+        A2, W2 = (torch.randn(M, k2, generator=g), torch.randn(n_out, k2, generator=g) * 0.2) if k2 else (None, None)
+        bias, sc, sh = torch.randn(n_out, generator=g), torch.rand(n_out, generator=g) + 0.5, torch.randn(n_out, generator=g)
+        ref = r(A1) @ r(W1).t() + bias.double()
+        if k2:
+            ref = ref + r(A2) @ r(W2).t()
+        ref = torch.relu(ref * sc.double() + sh.double())
+        dv = lambda t: None if t is None else t.to(DEV)
+        bfv = lambda t: None if t is None else ops.cast_to_bf16(t.to(DEV))[:, :t.size(1)]
+        for od in (BF, torch.float32):
+            out = ops.linear_fwd(bfv(A1), dv(W1), bfv(A2), dv(W2), dv(bias), dv(sc), dv(sh), True, out_dtype=od)
+            assert out.dtype == od
+            assert rel_err(out.float(), ref) < (EPS if od == BF else 2e-6), (M, k1, k2, n_out, od)
+    # weight gradient: dW = G^T . A with bf16 / fp32 operand mixes
+    for M, na, nb in [(5000, 128, 128), (333, 64, 28), (70000, 2, 64), (64, 130, 38)]:
+        G, A = torch.randn(M, na, generator=g), torch.randn(M, nb, generator=g)
+        ref = r(G).t() @ r(A)
+        Gb, Ab = ops.cast_to_bf16(G.to(DEV))[:, :na], ops.cast_to_bf16(A.to(DEV))[:, :nb]
+        assert rel_err(ops.linear_wgrad(Gb, Ab), ref) < 2e-5
+        assert rel_err(ops.linear_wgrad(G.to(DEV), Ab), ref) < 2e-5     # fp32 gradient of fp32 logits against bf16 activations
+        assert rel_err(ops.colsum(Gb), r(G).sum(0)) < 2e-5
+    # BatchNorm train-mode forward / backward on bf16 rows (statistics in fp64 on the device)
+    M, c2 = 3000, 70
+    xx, gg = torch.randn(M, c2, generator=g) * 3 + 1, torch.randn(M, c2, generator=g)
+    gamma, beta = torch.rand(c2, generator=g) + 0.5, torch.randn(c2, generator=g)
+    xr, gr = r(xx), r(gg)
+    bn = torch.nn.BatchNorm1d(c2).double().train()
+    with torch.no_grad():
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    xin = xr.clone().requires_grad_()
+    y = torch.relu(bn(xin))
+    xbn = ops.cast_to_bf16(xx.to(DEV))
+    mean, var = ops.bn_batch_stats(xbn)
+    assert rel_err(mean, xr.mean(0)) < 1e-6 and rel_err(var, xr.var(0, unbiased=False)) < 1e-5
+    s_, t_ = ops.bn_fold(gamma.to(DEV), beta.to(DEV), mean, var, 1e-5)
+    yb = ops.scale_shift_act(xbn, s_, t_, True)
+    assert yb.dtype == BF and rel_err(yb.float(), y) < EPS
+    # backward with the bf16-rounded y as the ReLU mask source (what the kernel sees)
+    (y * gr).sum().backward()
+    dxb, dgam, dbet = ops.bn_relu_bwd(xbn, yb, ops.cast_to_bf16(gg.to(DEV)), gamma.to(DEV), mean, var, 1e-5, True, True)
+    assert dxb.dtype == BF and rel_err(dxb.float(), xin.grad) < 2 * EPS
+    assert rel_err(dgam, bn.weight.grad) < 1e-3 and rel_err(dbet, bn.bias.grad) < 1e-3
+    # relu / relu_bwd
+    assert torch.equal(ops.relu(xbn).cpu(), torch.relu(xx.to(BF)))
+    assert torch.equal(ops.relu_bwd(yb, ops.cast_to_bf16(gg.to(DEV))).cpu(), torch.where(yb.cpu() > 0, gg.to(BF), torch.zeros((), dtype=BF)))
+
+
+def _bf16_inference(net, data):
+    net.set_storage_dtype(BF)
+    try:
+        return net.inference_layer(data).cpu().numpy()
+    finally:
+        net.set_storage_dtype(torch.float32)
+
+
+def test_inference_layer_bf16_golden_f2_and_lognormal_inputs():
+    g = gold("static_f2_regular256.npz")
+    net = hip_static()
+    data = Config(x=torch.from_numpy(g["x"]).to(DEV), edge_attr=torch.from_numpy(g["edge_attr"]).to(DEV),
+                  edge_index=torch.from_numpy(g["adjacencies"].T.astype(np.int64)).to(DEV))
+    logits = _bf16_inference(net, data)
+    assert logits.dtype == np.float32
+    err, agree = bf_check(logits, g["logits"], "F2")
+    print("bf16 F2: max|dlogit| %.3e, arg-max agreement %.4f" % (err, agree))
+    # heavy-tailed (log-normal) inputs: bf16 keeps the fp32 exponent range, nothing may overflow
+    from dgnn_amd.synthetic import delaunay_tet_graph
+    adj, _, _ = delaunay_tet_graph(3000, seed=8)
+    n = adj.shape[0] // 4
+    gen = torch.Generator().manual_seed(2)
+    x = torch.exp(2.5 * torch.randn(n, 29, generator=gen)) * torch.sign(torch.randn(n, 29, generator=gen))
+    ea = torch.exp(1.5 * torch.randn(4 * n, 20, generator=gen)) * torch.sign(torch.randn(4 * n, 20, generator=gen))
+    ei = torch.from_numpy(adj.T.astype(np.int64))
+    with torch.no_grad():
+        ref = oracle_static().inference_layer(Config(x=x, edge_attr=ea, edge_index=ei)).numpy()
+    got = _bf16_inference(net, Config(x=x.to(DEV), edge_attr=ea.to(DEV), edge_index=ei.to(DEV)))
+    assert np.isfinite(got).all()
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 2e-2 * scale, (np.abs(got - ref).max(), scale)
+    assert (got.argmax(1) == ref.argmax(1)).mean() >= 0.995
+
+
+def test_inference_layer_bf16_metric_graph_and_ignatius():
+    """the 1M-tet metric graph and the whole real scene in bf16 storage against the fp32 references"""
+    from test_gpu_scale import metric_graph
+    s = metric_graph()
+    net = hip_static()
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        ref = oracle_static().inference_layer(Config(x=s["x"], edge_attr=s["ea"], edge_index=s["ei"])).numpy()
+    got = _bf16_inference(net, Config(x=s["x"].to(DEV), edge_attr=s["ea"].to(DEV), edge_index=s["ei"].to(DEV)))
+    err, agree = bf_check(got, ref, "1M")
+    print("bf16 1M graph: max|dlogit| %.3e, arg-max agreement %.5f" % (err, agree))
+    g = gold("static_f4_ignatius_full.npz")
+    n = g["x"].shape[0]
+    fg = np.random.default_rng(int(g["fgeom_seed"])).standard_normal((4 * n, 4)).astype(np.float32)
+    ea = np.concatenate([fg, g["edge_attr16"]], axis=1)
+    adj = np.stack([np.repeat(np.arange(n, dtype=np.int64), 4), g["adj_dst"].astype(np.int64)])
+    got = _bf16_inference(net, Config(x=torch.from_numpy(g["x"]).to(DEV), edge_attr=torch.from_numpy(ea).to(DEV),
+                                      edge_index=torch.from_numpy(adj).to(DEV)))
+    err, agree = bf_check(got, g["logits"], "Ignatius")
+    print("bf16 Ignatius: max|dlogit| %.3e (logit range %.0f), arg-max agreement %.5f" % (err, np.abs(g["logits"]).max(), agree))
+
+
+def test_bf16_other_widths_take_the_generic_pair():
+    """widths the fused bf16 kernel does not cover run the bf16 aggregate + bf16-MFMA GEMM pair"""
+    from dgnn_amd.synthetic import delaunay_tet_graph
+    adj, _, _ = delaunay_tet_graph(1200, seed=4)
+    n = adj.shape[0] // 4
+    gen = torch.Generator().manual_seed(6)
+    x, ea = torch.randn(n, 29, generator=gen), torch.randn(4 * n, 20, generator=gen)
+    ei = torch.from_numpy(adj.T.astype(np.int64))
+    convs = (64, 128, 256, 512)
+    onet = oracle_static(convs=convs, load=False, seed=4)
+    net = hip_static(convs=convs, sd=onet.state_dict())
+    with torch.no_grad():
+        ref = onet.inference_layer(Config(x=x, edge_attr=ea, edge_index=ei)).numpy()
+    got = _bf16_inference(net, Config(x=x.to(DEV), edge_attr=ea.to(DEV), edge_index=ei.to(DEV)))
+    assert np.abs(got - ref).max() <= 3e-2 * max(1.0, np.abs(ref).max())
+
+
+def test_train_forward_backward_bf16_static_f3():
+    """Static SurfaceNet.forward in train mode (BN batch statistics) + backward in bf16 storage against the fp32 golden"""
+    g = gold("static_f3_train_blocks.npz")
+    net = hip_static(train=True).set_storage_dtype(BF)
+    d = f3_data(g)
+    data = Config(all=Config(x=d.all.x.to(DEV), edge_attr=d.all.edge_attr.to(DEV)), batch_n_id=d.batch_n_id.to(DEV),
+                  batch_adjs=[(a.to(DEV), e.to(DEV), s) for a, e, s in d.batch_adjs])
+    logits = net(data)
+    assert logits.dtype == torch.float32
+    ref = g["logits"]
+    assert np.abs(logits.detach().cpu().numpy() - ref).max() <= 5e-2 * max(1.0, np.abs(ref).max() / 8)
+    (logits * torch.from_numpy(g["G"]).to(DEV)).sum().backward()
+    # gradients: direction and size against the fp32 reference, per tensor
+    for k, p in net.named_parameters():
+        r_ = torch.from_numpy(g["grad." + k]).double().flatten()
+        q = p.grad.double().cpu().flatten()
+        assert p.grad.dtype == torch.float32
+        if r_.norm() < 1e-4 * max(np.abs(g[kk]).max() for kk in g.files if kk.startswith("grad.")):
+            continue   # biases ahead of a train-mode BatchNorm: analytically zero gradient
+        cos = float((q @ r_) / (q.norm() * r_.norm()))
+        assert cos > 0.995 and 0.9 < float(q.norm() / r_.norm()) < 1.1, (k, cos, float(q.norm() / r_.norm()))
+
+
+def test_updated_variant_bf16_forward_backward():
+    """surfaceNetUpdatedEdgeFilters in bf16 storage (the BASELINE config-3 model): phi written and chained in bf16"""
+    from dgnn_amd.learning.surfaceNetUpdatedEdgeFilters import SurfaceNet
+    g = gold("static_f3_train_blocks.npz")
+    u = gold("updated_f3_blocks.npz")
+    d = f3_data(g)
+    for tag, name in (("plus", "sage+"), ("plain", "sage")):
+        clf = Config.wrap(dict(training=dict(model_params=[int(v) for v in u[tag + ".model_params"]], model_name=name, loss="kl"),
+                               features=dict(normalization_feature=1, keep_normalization_feature=0), temp=dict(device=DEV)))
+        net = SurfaceNet(28, clf)
+        net.load_state_dict({k[len(tag) + 7:]: torch.from_numpy(u[k]) for k in u.files if k.startswith(tag + ".param.")})
+        net = net.to(DEV).set_storage_dtype(BF)
+        data = Config(x=d.all.x.to(DEV), edge_attr=d.all.edge_attr.to(DEV), n_id=d.batch_n_id.to(DEV),
+                      adjs=[(a.to(DEV), e.to(DEV), s) for a, e, s in d.batch_adjs])
+        logits = net(data)
+        ref = u[tag + ".logits"]
+        assert logits.dtype == torch.float32
+        assert np.abs(logits.detach().cpu().numpy() - ref).max() <= 5e-2 * max(1.0, np.abs(ref).max() / 8), tag
+        (logits * torch.from_numpy(g["G"]).to(DEV)).sum().backward()
+        if tag == "plain":
+            gmax = max(np.abs(u[k]).max() for k in u.files if k.startswith("plain.grad."))
+            for k, p in net.named_parameters():
+                r_ = torch.from_numpy(u["plain.grad." + k]).double().flatten()
+                q = p.grad.double().cpu().flatten()
+                if r_.abs().max() < 1e-3 * gmax:
+                    continue
+                cos = float((q @ r_) / (q.norm() * r_.norm()))
+                assert cos > 0.99 and 0.9 < float(q.norm() / r_.norm()) < 1.1, (k, cos, float(q.norm() / r_.norm()))

@@ -136,7 +136,7 @@ def test_ignatius_full_scene_vs_reference_logits():
     from dgnn_amd.graph import GraphPlan
     plan = GraphPlan(data.edge_index, n, n, hint=ops.PLAN_HINT_REFERENCE)
     rows = torch.from_numpy(g["trace_rows"]).to(DEV)
-    h = data.x[:, 1:]
+    h = data.x.contiguous()[:, 1:]          # the fixture keeps the loader's column-major layout (pandas -> torch)
     for i in range(4):
         h = net._eval_layers(h, n, data.edge_attr, [plan] * 4, True, only=i)
         want = torch.from_numpy(g["relu%d_rows" % i]).double()
@@ -199,6 +199,10 @@ def test_out_of_range_edge_index_is_reported_not_corrupting():
         assert int(src.max()) < n and int(src[: int(rowptr[-1])].min()) >= 0
         ops.relu(torch.zeros(4, device=DEV))         # any later entry point reports it
     assert bool((guard == 12345).all())
+    # the report is asynchronous: kernels that were still running when it was raised may add to it; drain it after a sync
+    from dgnn_amd._lib import lib
+    torch.cuda.synchronize()
+    lib().dgnn_poll_async_error()
     # and the flag is cleared: a good plan afterwards works
     rowptr, src, eid = ops.plan_build(ei.to(DEV), n, by=1, n_other=n)
     torch.cuda.synchronize()
