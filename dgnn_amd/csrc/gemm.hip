@@ -351,6 +351,206 @@ __global__ void __launch_bounds__(256) k_linear_wgrad_b(const TA* __restrict__ A
     }
 }
 
+// =====================================================================================================================
+// fp32-CLASS GEMMs on the bf16 matrix cores ("x3": the arithmetic of the fused layers, fused_common.h split3): both fp32
+// operands are split exactly into 3 bf16 parts while they are staged into LDS, the 6 partial products of weight >= 2^-18 run on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation (dropped terms <= 2^-25 relative, below fp32 rounding) -- 6/16 of the time of
+// the bit-faithful fp32 MFMA above.  Used for the wide conv layers the fused kernel does not cover and for the training GEMMs
+// when ops.GEMM_MODE is not "f32".
+//
+// k_linear_fwd_x3: 128 x 128 output tile per 256-thread block, wave (wr, wc) owns a 64 x 64 quadrant = 2 x 2 MFMA blocks
+// (4 accumulators); K is walked in chunks of 32 over [A1 | A2].  LDS row = [hi | mid | lo] x 32 bf16 + 16 B pad = 208 B (an odd
+// number of 16-B slots): conflict-free b128 fragment reads.  Per chunk and wave: 24 b128 reads feed 48 MFMAs.
+// =====================================================================================================================
+constexpr int XM = 128, XN = 128, XK = 32, XLD = 3 * XK * 2 + 16;
+
+__device__ __forceinline__ void x3_split(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{x0, x1}, bf2));
+    const float r0 = x0 - __builtin_bit_cast(float, hi << 16), r1 = x1 - __builtin_bit_cast(float, hi & 0xFFFF0000u);
+    mid = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{r0, r1}, bf2));
+    const float s0 = r0 - __builtin_bit_cast(float, mid << 16), s1 = r1 - __builtin_bit_cast(float, mid & 0xFFFF0000u);
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{s0, s1}, bf2));
+}
+
+// [128 x 32] fp32 tile -> 3 bf16 parts in LDS; 8 threads per row (4 floats each), 32 rows per pass
+__device__ __forceinline__ void stage_x3(char* __restrict__ dst, const float* __restrict__ src, int64_t ld, int64_t row0, int64_t nrows, int k0,
+                                         int kmax, bool vec) {
+    const int t = threadIdx.x, r = t >> 3, c = (t & 7) * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int rr = r + p * 32;
+        const int64_t gr = row0 + rr;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gr < nrows) {
+            const float* g = src + gr * ld + k0 + c;
+            if (vec && k0 + c + 3 < kmax) {
+                v = *reinterpret_cast<const f32x4*>(g);
+            } else {
+                if (k0 + c + 0 < kmax) v[0] = g[0];
+                if (k0 + c + 1 < kmax) v[1] = g[1];
+                if (k0 + c + 2 < kmax) v[2] = g[2];
+                if (k0 + c + 3 < kmax) v[3] = g[3];
+            }
+        }
+        uint32_t h0, m0, l0, h1, m1, l1;
+        x3_split(v[0], v[1], h0, m0, l0);
+        x3_split(v[2], v[3], h1, m1, l1);
+        char* d = dst + rr * XLD + c * 2;
+        *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(d + 64) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(d + 128) = make_uint2(l0, l1);
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) k_linear_fwd_x3(const float* __restrict__ A1, int64_t lda1, int k1, const float* __restrict__ W1,
+                                                          int64_t ldw1, bool vec1, const float* __restrict__ A2, int64_t lda2, int k2,
+                                                          const float* __restrict__ W2, int64_t ldw2, bool vec2,
+                                                          const float* __restrict__ bias, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int relu, int64_t M, int n_out,
+                                                          float* __restrict__ out, int64_t ldo) {
+    __shared__ __attribute__((aligned(16))) char As[XM * XLD];
+    __shared__ __attribute__((aligned(16))) char Ws[XN * XLD];
+    const int lane = lane_id(), w = wave_id_uniform();
+    const int wr = w >> 1, wc = w & 1, h = lane >> 5, l31 = lane & 31;
+    const int64_t row0 = (int64_t)blockIdx.x * XM;
+    const int col0 = blockIdx.y * XN;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    const int nch1 = (k1 + XK - 1) / XK, nch2 = A2 ? (k2 + XK - 1) / XK : 0;
+    for (int ch = 0; ch < nch1 + nch2; ++ch) {
+        const bool first = ch < nch1;
+        const int kk = first ? k1 : k2, k0 = (first ? ch : ch - nch1) * XK;
+        __syncthreads();
+        stage_x3(As, first ? A1 : A2, first ? lda1 : lda2, row0, M, k0, kk, first ? vec1 : vec2);
+        stage_x3(Ws, first ? W1 : W2, first ? ldw1 : ldw2, col0, n_out, k0, kk, first ? vec1 : vec2);
+        __syncthreads();
+        const char* ap = As + (wr * 64 + l31) * XLD + h * 16;
+        const char* bp = Ws + (wc * 64 + l31) * XLD + h * 16;
+#pragma unroll
+        for (int S = 0; S < XK / 16; ++S) {
+            bf16x8_t af[2][3], bf[2][3];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    af[m][p] = *reinterpret_cast<const bf16x8_t*>(ap + m * 32 * XLD + p * 64 + S * 32);
+                    bf[m][p] = *reinterpret_cast<const bf16x8_t*>(bp + m * 32 * XLD + p * 64 + S * 32);
+                }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    f32x16 c = acc[a][b];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][2], bf[b][0], c, 0, 0, 0);   // small terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][0], c, 0, 0, 0);
+                    acc[a][b] = c;
+                }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int col = col0 + wc * 64 + b * 32 + l31;
+        if (col >= n_out) continue;
+        const float bb = bias ? bias[col] : 0.f;
+        const float sc = scale ? scale[col] : 1.f;
+        const float sh = scale ? shift[col] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= M) continue;
+                float v = acc[a][b][r] + bb;
+                if (scale) v = __fmaf_rn(v, sc, sh);
+                if (relu) v = fmaxf(v, 0.f);
+                out[row * ldo + col] = v;
+            }
+    }
+}
+
+// dW[na, nb] = sum_rows A[r, :]^T B[r, :], fp32 operands split in 3 bf16 parts while they are staged TRANSPOSED ([column][row]):
+// a thread takes 2 consecutive rows x 4 columns, so that a packed bf16 pair is two consecutive k (= rows) of one column.
+// 64 x 64 tile per block, wave (wa, wb) owns a 32 x 32 block; row slices of 32.
+constexpr int XRK = 32, XLDT = 3 * XRK * 2 + 16;
+
+__device__ __forceinline__ void stage_t_x3(char* __restrict__ dst, const float* __restrict__ src, int64_t ld, int64_t r0, int64_t r_end, int c0,
+                                           int nc) {
+    // 256 threads: (row pair tp = t >> 4 in 0..15, column quad tc = (t & 15) * 4)
+    const int t = threadIdx.x, tp = t >> 4, tc = (t & 15) * 4;
+    const int64_t ra = r0 + 2 * tp, rb = ra + 1;
+    float va[4], vb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int cc = c0 + tc + j;
+        va[j] = (ra < r_end && cc < nc) ? src[ra * ld + cc] : 0.f;
+        vb[j] = (rb < r_end && cc < nc) ? src[rb * ld + cc] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t hh, mm, ll;
+        x3_split(va[j], vb[j], hh, mm, ll);
+        char* d = dst + (tc + j) * XLDT + tp * 4;
+        *reinterpret_cast<uint32_t*>(d) = hh;
+        *reinterpret_cast<uint32_t*>(d + 64) = mm;
+        *reinterpret_cast<uint32_t*>(d + 128) = ll;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_linear_wgrad_x3(const float* __restrict__ A, int64_t lda, int na, const float* __restrict__ B, int64_t ldb,
+                                                         int nb, int64_t M, int64_t rows_per_split, float* __restrict__ partials) {
+    __shared__ __attribute__((aligned(16))) char At[WT * XLDT];
+    __shared__ __attribute__((aligned(16))) char Bt[WT * XLDT];
+    const int lane = lane_id(), w = wave_id_uniform();
+    const int wa = w >> 1, wb = w & 1, h = lane >> 5, l31 = lane & 31;
+    const int a0 = blockIdx.x * WT, b0 = blockIdx.y * WT;
+    const int64_t r_beg = (int64_t)blockIdx.z * rows_per_split;
+    const int64_t r_end = min(M, r_beg + rows_per_split);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int64_t r0 = r_beg; r0 < r_end; r0 += XRK) {
+        __syncthreads();
+        stage_t_x3(At, A, lda, r0, r_end, a0, na);
+        stage_t_x3(Bt, B, ldb, r0, r_end, b0, nb);
+        __syncthreads();
+        const char* ap = At + (wa * 32 + l31) * XLDT + h * 16;
+        const char* bp = Bt + (wb * 32 + l31) * XLDT + h * 16;
+#pragma unroll
+        for (int S = 0; S < XRK / 16; ++S) {
+            bf16x8_t af[3], bf[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                af[p] = *reinterpret_cast<const bf16x8_t*>(ap + p * 64 + S * 32);
+                bf[p] = *reinterpret_cast<const bf16x8_t*>(bp + p * 64 + S * 32);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc, 0, 0, 0);
+        }
+    }
+    float* P = partials + (int64_t)blockIdx.z * na * nb;
+    const int col = b0 + wb * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = a0 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < na && col < nb) P[(int64_t)row * nb + col] = acc[r];
+    }
+}
+
 int wgrad_splits(int64_t M) {
     int64_t s = dgnn_cdiv(M, 4 * RK);  // at least 128 rows per split
     if (s > WGRAD_SPLITS) s = WGRAD_SPLITS;
@@ -438,4 +638,36 @@ extern "C" int dgnn_linear_wgrad_bf16(const void* A, int a_f32, int64_t lda, int
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)dgnn_cdiv((int64_t)n_a * n_b, 16)), dim3(256), 0, stream, partials, splits, n_a, n_b, dW, lddw,
                        accumulate);
     return dgnn_check_launch("linear_wgrad_bf16");
+}
+
+
+// ---- fp32-class GEMMs on the bf16 matrix cores (3-way exact split, 6 products) ---------------------------------------------
+extern "C" int dgnn_linear_fwd_x3(const float* A1, int64_t lda1, int k1, const float* W1, int64_t ldw1, const float* A2, int64_t lda2, int k2,
+                                  const float* W2, int64_t ldw2, const float* bias, const float* scale, const float* shift, int relu,
+                                  int64_t M, int n_out, float* out, int64_t ldo, void* stream) {
+    DGNN_REQUIRE(M >= 0 && n_out > 0 && k1 > 0, DGNN_E_INVALID, "linear_fwd_x3: bad sizes M=%lld n_out=%d k1=%d", (long long)M, n_out, k1);
+    if (M == 0) return DGNN_OK;
+    DGNN_REQUIRE(A1 && W1 && out, DGNN_E_INVALID, "linear_fwd_x3: null pointer");
+    DGNN_REQUIRE((A2 == nullptr) == (W2 == nullptr) && (!A2 || k2 > 0), DGNN_E_INVALID, "linear_fwd_x3: A2/W2 must come together");
+    DGNN_REQUIRE((scale == nullptr) == (shift == nullptr), DGNN_E_INVALID, "linear_fwd_x3: scale/shift must come together");
+    const bool v1 = vec_ok(A1, lda1) && vec_ok(W1, ldw1);
+    const bool v2 = A2 && vec_ok(A2, lda2) && vec_ok(W2, ldw2);
+    dim3 grid((unsigned)dgnn_cdiv(M, XM), (unsigned)dgnn_cdiv(n_out, XN));
+    hipLaunchKernelGGL(k_linear_fwd_x3, grid, dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2, lda2, k2, W2, ldw2, v2, bias,
+                       scale, shift, relu, M, n_out, out, ldo);
+    return dgnn_check_launch("linear_fwd_x3");
+}
+
+extern "C" int dgnn_linear_wgrad_x3(const float* A, int64_t lda, int n_a, const float* B, int64_t ldb, int n_b, int64_t M, float* dW,
+                                    int64_t lddw, int accumulate, float* partials, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DGNN_REQUIRE(M >= 0 && n_a > 0 && n_b > 0, DGNN_E_INVALID, "linear_wgrad_x3: bad sizes");
+    DGNN_REQUIRE(dW && partials && (M == 0 || (A && B)), DGNN_E_INVALID, "linear_wgrad_x3: null pointer");
+    const int splits = wgrad_splits(M);
+    const int64_t rps = dgnn_cdiv(dgnn_cdiv(M, splits), XRK) * XRK;
+    dim3 grid((unsigned)dgnn_cdiv(n_a, WT), (unsigned)dgnn_cdiv(n_b, WT), splits);
+    hipLaunchKernelGGL(k_linear_wgrad_x3, grid, dim3(256), 0, stream, A, lda, n_a, B, ldb, n_b, M, rps < XRK ? XRK : rps, partials);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)dgnn_cdiv((int64_t)n_a * n_b, 16)), dim3(256), 0, stream, partials, splits, n_a, n_b, dW, lddw,
+                       accumulate);
+    return dgnn_check_launch("linear_wgrad_x3");
 }

@@ -212,7 +212,9 @@ def linear_fwd(A1, W1, A2=None, W2=None, bias=None, scale=None, shift=None, relu
             ptr(bias), ptr(scale), ptr(shift), int(bool(relu)), M, n_out, ptr(out), n_out, int(out_dtype == torch.float32), stream_ptr()),
             "dgnn_linear_fwd_bf16")
         return out
-    check(lib().dgnn_linear_fwd(
+    # fp32 operands: bit-faithful fp32 MFMA ("f32" mode) or the fused layers' exact-split bf16 arithmetic (fp32-class, 6/16 of the time)
+    fn = lib().dgnn_linear_fwd if GEMM_MODE == GEMM_F32 else lib().dgnn_linear_fwd_x3
+    check(fn(
         ptr(A1), _ld(A1), A1.size(1), ptr(W1), W1.size(1),
         ptr(A2), _ld(A2) if A2 is not None else 0, A2.size(1) if A2 is not None else 0, ptr(W2), W2.size(1) if W2 is not None else 0,
         ptr(bias), ptr(scale), ptr(shift), int(bool(relu)), M, n_out, ptr(out), n_out, stream_ptr()), "dgnn_linear_fwd")
@@ -233,8 +235,8 @@ def linear_wgrad(A, B):
         check(lib().dgnn_linear_wgrad_bf16(ptr(A), int(A.dtype == torch.float32), _ld(A), na, ptr(B), int(B.dtype == torch.float32), _ld(B), nb,
                                            M, ptr(dW), nb, 0, ptr(partials), stream_ptr()), "dgnn_linear_wgrad_bf16")
         return dW
-    check(lib().dgnn_linear_wgrad(ptr(A), _ld(A), na, ptr(B), _ld(B), nb, M, ptr(dW), nb, 0, ptr(partials), stream_ptr()),
-          "dgnn_linear_wgrad")
+    fn = lib().dgnn_linear_wgrad if GEMM_MODE == GEMM_F32 else lib().dgnn_linear_wgrad_x3
+    check(fn(ptr(A), _ld(A), na, ptr(B), _ld(B), nb, M, ptr(dW), nb, 0, ptr(partials), stream_ptr()), "dgnn_linear_wgrad")
     return dW
 
 

@@ -121,6 +121,15 @@ int dgnn_linear_fwd(const float* A1, int64_t lda1, int k1, const float* W1, int6
                     int64_t lda2, int k2, const float* W2, int64_t ldw2, const float* bias, const float* scale,
                     const float* shift, int relu, int64_t M, int n_out, float* out, int64_t ldo, void* stream);
 
+/* dgnn_linear_fwd / dgnn_linear_wgrad with the fused layers' arithmetic (DGNN_GEMM_BF16X3): both fp32 operands are split exactly
+ * into 3 bf16 parts while staged, 6 partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulate -- fp32-class accuracy
+ * (dropped terms <= 2^-25 relative) at 6/16 of the fp32-MFMA time.  Same arguments and scratch sizes. */
+int dgnn_linear_fwd_x3(const float* A1, int64_t lda1, int k1, const float* W1, int64_t ldw1, const float* A2, int64_t lda2, int k2,
+                       const float* W2, int64_t ldw2, const float* bias, const float* scale, const float* shift, int relu, int64_t M,
+                       int n_out, float* out, int64_t ldo, void* stream);
+int dgnn_linear_wgrad_x3(const float* A, int64_t lda, int n_a, const float* B, int64_t ldb, int n_b, int64_t M, float* dW, int64_t lddw,
+                         int accumulate, float* partials, void* stream);
+
 /* dW[n_a, n_b] (+)= A^T . B over M rows (weight gradients of the Linears above: autograd of :81-86).
  * Deterministic two-stage reduction; `partials` holds dgnn_linear_wgrad_scratch_elems floats. */
 int64_t dgnn_linear_wgrad_scratch_elems(int64_t M, int n_a, int n_b);
