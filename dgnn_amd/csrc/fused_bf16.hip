@@ -19,15 +19,32 @@
 // Algorithmic bytes per tet: 2*C_in (own row) + 320 (4 attribute rows) + 16 (4 source ids) + 2*C_out.
 #include "fused_common.h"
 
+#ifndef DGNN_BF16_DENSE_GROUP
+#define DGNN_BF16_DENSE_GROUP 0
+#endif
+#ifndef DGNN_BF16_CB_GROUP
+#define DGNN_BF16_CB_GROUP 2
+#endif
+
 namespace {
 using namespace fused;
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-template <int CIN_PAD, int COUT, int NW = 4>
+// PR (compensated mode, the default): what is STORED is bf16, but nothing else is rounded to bf16 on the way -- the fp32 mean
+// `a`, the fp32 attributes and every fp32 parameter enter the matrix cores as a (hi, lo) pair of bf16 values (16 significant
+// bits; the hi x lo cross terms are kept, lo x lo is dropped):  filter = 3 products, a . Wj = 3 products, x_i . Wi = 2 products
+// (x_i is exactly its stored bf16 value).  The only roundings left per layer are the ones storage implies: the gathered /
+// own rows as they were stored and the layer's output.  PR = 0 is the plain single-product form (every operand rounded to
+// bf16 once); it is ~2x further from the fp32 reference (measured: rms 1.0e-2 vs the compensated mode's on the 1M-tet graph).
+template <int CIN_PAD, int COUT, int NW = 4, int PR = 0>
 struct CfgB {
-    static constexpr int K = 2 * CIN_PAD;
-    static constexpr int NSLICE = COUT / 32;
+    static constexpr int K = (PR ? 3 : 2) * CIN_PAD;      // A-tile row: [a_hi | a_lo | x_i] or [a | x_i]
+    // NW == 4: four waves, each a 32-column slice of v_mfma_f32_32x32x16_bf16 blocks.  NW == 8: eight waves, each a 16-column slice
+    // of v_mfma_f32_16x16x32_bf16 blocks -- half the resident weights per wave (the compensated 128 -> 128 layer keeps 4 weight
+    // parts resident: 128 VGPRs in the 4-wave form = spills, 64 here) and 4 tets per wave in the filter phase.
+    static constexpr bool D16 = NW == 8;
+    static constexpr int NSLICE = COUT / (D16 ? 16 : 32);
     static constexpr int RG = NW / NSLICE;
     static constexpr int TILE = 32 * RG;
     static constexpr int ROWB = K * 2 + 16;               // A-tile row: K bf16 + 16 B pad (odd number of 16-B slots)
@@ -38,9 +55,9 @@ struct CfgB {
     static constexpr int NB = CIN_PAD / 16;               // contiguous channels per lane (8, 4, 2)
     static constexpr int EA_BYTES = NQ * FE * 4;
     static constexpr int EA_FULL = EA_BYTES / 1024, EA_TAIL = (EA_BYTES % 1024) / 256;
-    static constexpr int BP_BYTES = NB * 768;             // [cb][g<3][j<16] x 16 B filter operand
+    static constexpr int BP_BYTES = (PR ? 2 : 1) * NB * 768;   // [part][cb][g<3][j<16] x 16 B filter operand
     static constexpr int SMEM_BYTES = 2 * A_BYTES + NW * EA_BYTES + BP_BYTES;
-    static constexpr int NWB = K / 16;                    // dense part: k-steps of 16 (full K per wave)
+    static constexpr int NS = CIN_PAD / (D16 ? 32 : 16);  // k-steps (of 16, D16: of 32) per operand part (full K per wave)
     static_assert(RG >= 1 && NQ <= 64 && EA_BYTES % 256 == 0, "wave roles");
 };
 
@@ -51,6 +68,11 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
 __device__ __forceinline__ float bf16_round(float v) { return bf_lo(pack_bf16(v, 0.f)); }
+// (x0, x1) -> packed hi pair and packed lo pair: x = hi + lo + O(2^-17 |x|), both parts bf16
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    hi = pack_bf16(x0, x1);
+    lo = pack_bf16(x0 - bf_lo(hi), x1 - bf_hi(hi));
+}
 
 // NB bf16 = NB/2 dwords per lane
 template <int NB>
@@ -66,15 +88,15 @@ __device__ __forceinline__ void ld_bf(uint32_t (&v)[NB / 2], const uint16_t* p) 
     }
 }
 
-template <int CIN_PAD, int COUT, int NW, int OCC>
+template <int CIN_PAD, int COUT, int NW, int OCC, int PR>
 __global__ void __launch_bounds__(64 * NW, OCC)
 k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid, int64_t n_dst,
                   const uint16_t* __restrict__ x, const uint16_t* __restrict__ xdst, int64_t ldx, int c_in, const float* __restrict__ ea,
                   int64_t lde, const float* __restrict__ We, const float* __restrict__ be, const float* __restrict__ Wj,
                   const float* __restrict__ bj, const float* __restrict__ Wi, const float* __restrict__ scale,
                   const float* __restrict__ shift, int relu, uint16_t* __restrict__ out, int64_t ldo, int64_t ntiles) {
-    using C = CfgB<CIN_PAD, COUT, NW>;
-    constexpr int ROWB = C::ROWB, TILE = C::TILE, TPW = C::TPW, RB = C::RB, NB = C::NB, NWB = C::NWB, NH = NB / 2;
+    using C = CfgB<CIN_PAD, COUT, NW, PR>;
+    constexpr int ROWB = C::ROWB, TILE = C::TILE, TPW = C::TPW, RB = C::RB, NB = C::NB, NS = C::NS, NH = NB / 2;
     extern __shared__ __attribute__((aligned(16))) char smemb[];
     char* const abuf = smemb;                                        // [2][A_BYTES]
     char* const eabuf = smemb + 2 * C::A_BYTES;                      // [NW][EA_BYTES] fp32 attribute strips
@@ -96,7 +118,7 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     for (int e = threadIdx.x; e < NB * 48; e += blockDim.x) {
         const int cb = e / 48, gj = e - cb * 48, g = gj >> 4, j = gj & 15;
         const int c = NB * j + cb;
-        uint32_t p[4];
+        uint32_t p[4], q[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             float v[2];
@@ -106,29 +128,34 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                 v[u] = 0.f;
                 if (c < c_in) v[u] = k < FE ? We[(int64_t)c * FE + k] : (k == FE ? be[c] : 0.f);
             }
-            p[d] = pack_bf16(v[0], v[1]);
+            split2(v[0], v[1], p[d], q[d]);
         }
         *reinterpret_cast<uint4*>(bpbuf + (cb * 48 + gj) * 16) = make_uint4(p[0], p[1], p[2], p[3]);
+        if (PR) *reinterpret_cast<uint4*>(bpbuf + NB * 768 + (cb * 48 + gj) * 16) = make_uint4(q[0], q[1], q[2], q[3]);
     }
 
     // ---- dense-phase role: (column slice cs, row group rg); the whole K of this slice resident as bf16
+    constexpr bool D16 = C::D16;
     const int cs = w % C::NSLICE, rg = w / C::NSLICE;
-    const int col = cs * 32 + l31;
-    bf16x8 wb[NWB];
+    const int col = D16 ? cs * 16 + jcol : cs * 32 + l31;
+    const int kg = D16 ? tq : h;                                     // this lane's k-group inside a k-step (8 consecutive k)
+    bf16x8 wjh[NS], wih[NS], wjl[PR ? NS : 1], wil[PR ? NS : 1];   // Wj / Wi rows of this slice: hi parts (+ lo parts when PR)
 #pragma unroll
-    for (int S = 0; S < NWB; ++S) {
-        const bool second = S >= CIN_PAD / 16;                       // k-steps of the own-row half use Wi
-        const float* Wsrc = second ? Wi : Wj;
-        const int S_ = second ? S - CIN_PAD / 16 : S;
-        uint32_t p[4];
+    for (int S = 0; S < NS; ++S) {
+        uint32_t ph[4], pl[4], qh[4], ql[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const int k = 16 * S_ + 8 * h + 2 * d;
-            const float v0 = Wsrc[(int64_t)col * c_in + (k < c_in ? k : 0)];
-            const float v1 = Wsrc[(int64_t)col * c_in + (k + 1 < c_in ? k + 1 : 0)];
-            p[d] = pack_bf16(k < c_in ? v0 : 0.f, k + 1 < c_in ? v1 : 0.f);
+            const int k = (D16 ? 32 : 16) * S + 8 * kg + 2 * d;
+            const int64_t o0 = (int64_t)col * c_in + (k < c_in ? k : 0), o1 = (int64_t)col * c_in + (k + 1 < c_in ? k + 1 : 0);
+            split2(k < c_in ? Wj[o0] : 0.f, k + 1 < c_in ? Wj[o1] : 0.f, ph[d], pl[d]);
+            split2(k < c_in ? Wi[o0] : 0.f, k + 1 < c_in ? Wi[o1] : 0.f, qh[d], ql[d]);
         }
-        wb[S] = pack8(p);
+        wjh[S] = pack8(ph);
+        wih[S] = pack8(qh);
+        if (PR) {
+            wjl[S] = pack8(pl);
+            wil[S] = pack8(ql);
+        }
     }
     const float bb = bj ? bj[col] : 0.f;
     const float sc = scale ? scale[col] : 1.f;
@@ -207,20 +234,17 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         load_src();
         ok2 = load_rowptr(it_next + 1, vbeg2, nv2);
     };
-    // one finished (tet row, NB channels) segment -> A-tile: bf16 columns [c0, c0+NB) of the mean half and of the own-row half
-    auto put_seg = [&](int buf, int row, const uint32_t (&av)[NH], const uint32_t (&xv)[NH]) {
+    // one finished (tet row, NB channels) segment -> A-tile: bf16 columns [c0, c0+NB) of the mean part(s) and of the own-row part
+    auto put16 = [&](char* d, const uint32_t (&v)[NH]) {
+        if (NB == 8) *reinterpret_cast<uint4*>(d) = make_uint4(v[0], v[1 % NH], v[2 % NH], v[3 % NH]);
+        else if (NB == 4) *reinterpret_cast<uint2*>(d) = make_uint2(v[0], v[1 % NH]);
+        else *reinterpret_cast<uint32_t*>(d) = v[0];
+    };
+    auto put_seg = [&](int buf, int row, const uint32_t (&av)[NH], const uint32_t (&al)[NH], const uint32_t (&xv)[NH]) {
         char* dst = abuf + buf * C::A_BYTES + row * ROWB + c0 * 2;
-        char* dsx = dst + CIN_PAD * 2;
-        if (NB == 8) {
-            *reinterpret_cast<uint4*>(dst) = make_uint4(av[0], av[1 % NH], av[2 % NH], av[3 % NH]);
-            *reinterpret_cast<uint4*>(dsx) = make_uint4(xv[0], xv[1 % NH], xv[2 % NH], xv[3 % NH]);
-        } else if (NB == 4) {
-            *reinterpret_cast<uint2*>(dst) = make_uint2(av[0], av[1 % NH]);
-            *reinterpret_cast<uint2*>(dsx) = make_uint2(xv[0], xv[1 % NH]);
-        } else {
-            *reinterpret_cast<uint32_t*>(dst) = av[0];
-            *reinterpret_cast<uint32_t*>(dsx) = xv[0];
-        }
+        put16(dst, av);
+        if (PR) put16(dst + CIN_PAD * 2, al);
+        put16(dst + (PR ? 2 : 1) * CIN_PAD * 2, xv);
     };
 
     ok1 = load_rowptr(0, vbeg1, nv1);
@@ -249,17 +273,23 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                     av[4 + i] = tq < 2 ? q1[i] : 0.f;
                 }
                 if (tq == 2) av[4] = 1.0f;
-                uint32_t pa[4];
+                uint32_t pa[4], pl[4];
 #pragma unroll
-                for (int d = 0; d < 4; ++d) pa[d] = pack_bf16(av[2 * d], av[2 * d + 1]);
-                const bf16x8 aop = pack8(pa);
+                for (int d = 0; d < 4; ++d) split2(av[2 * d], av[2 * d + 1], pa[d], pl[d]);
+                const bf16x8 aop = pack8(pa), aol = pack8(pl);
 
-                uint32_t aout[NH];
+                uint32_t aout[NH], alo[NH];
                 float prev = 0.f;
 #pragma unroll
                 for (int cb = 0; cb < NB; ++cb) {
-                    const uint4 u0 = *reinterpret_cast<const uint4*>(bpbuf + (cb * 48 + (tq < 3 ? tq : 0) * 16 + jcol) * 16);
+                    const char* bp = bpbuf + (cb * 48 + (tq < 3 ? tq : 0) * 16 + jcol) * 16;
+                    const uint4 u0 = *reinterpret_cast<const uint4*>(bp);
                     f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+                    if (PR) {
+                        const uint4 u1 = *reinterpret_cast<const uint4*>(bp + NB * 768);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aol, __builtin_bit_cast(bf16x8, u0), d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aop, __builtin_bit_cast(bf16x8, u1), d, 0, 0, 0);
+                    }
                     d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aop, __builtin_bit_cast(bf16x8, u0), d, 0, 0, 0);
                     // d[r] = phi of the r-th in-edge of this lane's tet, channel c0 + cb; in-order sum over the 4 in-edges
                     const uint32_t w0 = xr[rb][0][cb >> 1], w1 = xr[rb][1][cb >> 1], w2 = xr[rb][2][cb >> 1], w3 = xr[rb][3][cb >> 1];
@@ -268,19 +298,23 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                     a = __fmaf_rn((cb & 1) ? bf_hi(w2) : bf_lo(w2), d[2], a);
                     a = __fmaf_rn((cb & 1) ? bf_hi(w3) : bf_lo(w3), d[3], a);
                     a *= 0.25f;
-                    if (cb & 1) aout[cb >> 1] = pack_bf16(prev, a);
+                    if (cb & 1) split2(prev, a, aout[cb >> 1], alo[cb >> 1]);
                     else prev = a;
+                    // keep at most DGNN_BF16_CB_GROUP channel blocks in flight: fully interleaved, their operands and results
+                    // push the 128 -> 128 compensated kernel over the register file (73 spilled VGPRs)
+                    if (PR && NB == 8 && (cb % DGNN_BF16_CB_GROUP) == DGNN_BF16_CB_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
                 }
-                put_seg((int)(it & 1), w * TPW + rb * 4 + tq, aout, xd[rb]);
+                put_seg((int)(it & 1), w * TPW + rb * 4 + tq, aout, alo, xd[rb]);
             }
         } else {
             // generic path (a group with any in-degree other than 4, or past the end): per lane, one edge at a time (rare).
-            // Operands are rounded to bf16 like the matrix-core path, products and sums are fp32.
+            // Operands are rounded to bf16 like the matrix-core path (PR: left in fp32, as the compensated products are fp32-class),
+            // products and sums are fp32.
 #pragma unroll 1
             for (int rb = 0; rb < RB; ++rb) {
                 const int64_t i = i0 + rb * 4 + tq;
                 float af[NB];
-                uint32_t aout[NH], xv[NH];
+                uint32_t aout[NH], alo[NH], xv[NH];
 #pragma unroll
                 for (int cb = 0; cb < NB; ++cb) af[cb] = 0.f;
 #pragma unroll
@@ -297,8 +331,10 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                         for (int cb = 0; cb < NB; ++cb) {
                             float p = 0.f;
                             if (c0 + cb < c_in) {
-                                p = bf16_round(be[c0 + cb]);
-                                for (int f = 0; f < FE; ++f) p = __fmaf_rn(bf16_round(We[(int64_t)(c0 + cb) * FE + f]), bf16_round(ar[f]), p);
+                                p = PR ? be[c0 + cb] : bf16_round(be[c0 + cb]);
+                                for (int f = 0; f < FE; ++f)
+                                    p = PR ? __fmaf_rn(We[(int64_t)(c0 + cb) * FE + f], ar[f], p)
+                                           : __fmaf_rn(bf16_round(We[(int64_t)(c0 + cb) * FE + f]), bf16_round(ar[f]), p);
                             }
                             const uint32_t wv = xs[cb >> 1];
                             af[cb] = __fadd_rn(af[cb], __fmul_rn((cb & 1) ? bf_hi(wv) : bf_lo(wv), p));
@@ -309,8 +345,8 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                     for (int cb = 0; cb < NB; ++cb) af[cb] = __fdiv_rn(af[cb], cnt);
                 }
 #pragma unroll
-                for (int q = 0; q < NH; ++q) aout[q] = pack_bf16(af[2 * q], af[2 * q + 1]);
-                put_seg((int)(it & 1), w * TPW + rb * 4 + tq, aout, xv);
+                for (int q = 0; q < NH; ++q) split2(af[2 * q], af[2 * q + 1], aout[q], alo[q]);
+                put_seg((int)(it & 1), w * TPW + rb * 4 + tq, aout, alo, xv);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // strip reads returned before the next DMA may land
@@ -318,51 +354,99 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         issue_loads(it + 1);
         tile_barrier();  // A-tile `it` complete
 
-        // ================================================================ C: dense part, one bf16 product per k-step, full K
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        const char* A = abuf + (it & 1) * C::A_BYTES + (rg * 32 + l31) * ROWB + h * 16;
-#pragma unroll
-        for (int S = 0; S < NWB; ++S) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + S * 32);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wb[S], acc, 0, 0, 0);
-        }
-        // epilogue: row (r&3) + 8(r>>2) + 4h, column `col`; columns (col, col^1) of one row pair up into a 4-byte store:
-        // even lanes store row r of the pair, odd lanes row r+1
+        // ================================================================ C: dense part on bf16 operands, full K per wave
         const int64_t tile = tile_of(it);
-        const int64_t row0 = tile * TILE + rg * 32 + 4 * h;
         const bool full = (tile + 1) * TILE <= n_dst;
         const int odd = lane & 1;
-        uint16_t* o = out + row0 * ldo + (col & ~1);
+        if constexpr (!D16) {
+            f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            float v0 = acc[r] + bb, v1 = acc[r + 1] + bb;
-            if (has_scale) { v0 = __fmaf_rn(v0, sc, sh); v1 = __fmaf_rn(v1, sc, sh); }
-            if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-            const float n0 = __shfl_xor(v0, 1), n1 = __shfl_xor(v1, 1);
-            const uint32_t pk = odd ? pack_bf16(n1, v1) : pack_bf16(v0, n0);
-            const int rr = (r & 3) + 8 * (r >> 2) + odd;
-            if (full || row0 + rr < n_dst) *reinterpret_cast<uint32_t*>(o + (int64_t)rr * ldo) = pk;
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            const char* A = abuf + (it & 1) * C::A_BYTES + (rg * 32 + l31) * ROWB + h * 16;
+#pragma unroll
+            for (int S = 0; S < NS; ++S) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(A + S * 32);
+                const bf16x8 xi = *reinterpret_cast<const bf16x8*>(A + (PR ? 2 : 1) * CIN_PAD * 2 + S * 32);
+                if (PR) {   // small terms first
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(A + CIN_PAD * 2 + S * 32);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wjh[S], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wjl[S], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xi, wil[S], acc, 0, 0, 0);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wjh[S], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xi, wih[S], acc, 0, 0, 0);
+            }
+            // epilogue: row (r&3) + 8(r>>2) + 4h, column `col`; columns (col, col^1) of one row pair up into a 4-byte store:
+            // even lanes store row r of the pair, odd lanes row r+1
+            const int64_t row0 = tile * TILE + rg * 32 + 4 * h;
+            uint16_t* o = out + row0 * ldo + (col & ~1);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                float v0 = acc[r] + bb, v1 = acc[r + 1] + bb;
+                if (has_scale) { v0 = __fmaf_rn(v0, sc, sh); v1 = __fmaf_rn(v1, sc, sh); }
+                if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                const float n0 = __shfl_xor(v0, 1), n1 = __shfl_xor(v1, 1);
+                const uint32_t pk = odd ? pack_bf16(n1, v1) : pack_bf16(v0, n0);
+                const int rr = (r & 3) + 8 * (r >> 2) + odd;
+                if (full || row0 + rr < n_dst) *reinterpret_cast<uint32_t*>(o + (int64_t)rr * ldo) = pk;
+            }
+        } else {
+            // sixteen columns per wave: two 16-row blocks of v_mfma_f32_16x16x32_bf16, lane (row jcol, k-group tq)
+            f32x4_t acc2[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc2[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            const char* A = abuf + (it & 1) * C::A_BYTES + (rg * 32 + jcol) * ROWB + tq * 16;
+#pragma unroll
+            for (int S = 0; S < NS; ++S) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const char* Am = A + m * 16 * ROWB + S * 64;
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Am);
+                    const bf16x8 xi = *reinterpret_cast<const bf16x8*>(Am + (PR ? 2 : 1) * CIN_PAD * 2);
+                    f32x4_t c = acc2[m];
+                    if (PR) {
+                        const bf16x8 al = *reinterpret_cast<const bf16x8*>(Am + CIN_PAD * 2);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wjh[S], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wjl[S], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xi, wil[S], c, 0, 0, 0);
+                    }
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wjh[S], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xi, wih[S], c, 0, 0, 0);
+                    acc2[m] = c;
+                }
+            }
+            // C/D layout: column jcol, rows 4*tq + r of the block; (col, col^1) pair up as above
+            uint16_t* o = out + (tile * TILE + rg * 32) * ldo + (col & ~1);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    float v0 = acc2[m][r] + bb, v1 = acc2[m][r + 1] + bb;
+                    if (has_scale) { v0 = __fmaf_rn(v0, sc, sh); v1 = __fmaf_rn(v1, sc, sh); }
+                    if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                    const float n0 = __shfl_xor(v0, 1), n1 = __shfl_xor(v1, 1);
+                    const uint32_t pk = odd ? pack_bf16(n1, v1) : pack_bf16(v0, n0);
+                    const int rr = m * 16 + 4 * tq + r + odd;
+                    if (full || tile * TILE + rg * 32 + rr < n_dst) *reinterpret_cast<uint32_t*>(o + (int64_t)rr * ldo) = pk;
+                }
         }
     }
 }
 
-template <int CIN_PAD, int COUT, int OCC>
+template <int CIN_PAD, int COUT, int OCC, int PR, int NW = 4>
 int launch_b(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const uint16_t* x, const uint16_t* xdst, int64_t ldx,
              int c_in, const float* ea, int64_t lde, const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
              const float* scale, const float* shift, int relu, uint16_t* out, int64_t ldo, hipStream_t stream) {
-    constexpr int NW = 4;
-    using C = CfgB<CIN_PAD, COUT, NW>;
+    using C = CfgB<CIN_PAD, COUT, NW, PR>;
     const int64_t ntiles = dgnn_cdiv(n_dst, C::TILE);
     const size_t smem = C::SMEM_BYTES;
     static bool attr_set[DGNN_MAX_DEVICES] = {};
-    dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_bf16<CIN_PAD, COUT, NW, OCC>), smem, attr_set);
+    dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_bf16<CIN_PAD, COUT, NW, OCC, PR>), smem, attr_set);
     const int per_cu = (int)(160 * 1024 / smem) < OCC ? (int)(160 * 1024 / smem) : OCC;
     const int wg_max = DGNN_NUM_CU * (per_cu < 1 ? 1 : per_cu);
     int grid = (int)(ntiles < wg_max ? ntiles : wg_max);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((k_sage_fused_bf16<CIN_PAD, COUT, NW, OCC>), dim3(grid), dim3(64 * NW), smem, stream, rowptr, src, eid, n_dst, x, xdst,
+    hipLaunchKernelGGL((k_sage_fused_bf16<CIN_PAD, COUT, NW, OCC, PR>), dim3(grid), dim3(64 * NW), smem, stream, rowptr, src, eid, n_dst, x, xdst,
                        ldx, c_in, ea, lde, We, be, Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles);
     return dgnn_check_launch("sage_layer_fused_fwd_bf16");
 }
@@ -398,7 +482,7 @@ __global__ void k_cast_bf16_f32(const uint16_t* __restrict__ in, int64_t ld_in, 
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int HIDB = 64;
 
-template <int K>
+template <int K, int PR>
 __global__ void __launch_bounds__(512) k_decoder_rows_bf16(const uint16_t* __restrict__ y, int64_t ldy, int64_t M,
                                                            const float* __restrict__ W0, const float* __restrict__ b0,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
@@ -406,15 +490,19 @@ __global__ void __launch_bounds__(512) k_decoder_rows_bf16(const uint16_t* __res
                                                            float* __restrict__ out, int64_t ldo) {
     constexpr int NS = K / 16, LDH = HIDB + 4;
     extern __shared__ __attribute__((aligned(16))) char dsmb[];
-    uint4* const Bs = reinterpret_cast<uint4*>(dsmb);                         // [2 col blocks][NS][64 lanes] x 16 B
-    float* const W3s = reinterpret_cast<float*>(dsmb + 2 * NS * 64 * 16);     // [2][HIDB]
+    uint4* const Bs = reinterpret_cast<uint4*>(dsmb);                         // [parts][2 col blocks][NS][64 lanes] x 16 B
+    float* const W3s = reinterpret_cast<float*>(dsmb + (PR ? 2 : 1) * 2 * NS * 64 * 16);     // [2][HIDB]
     float* const Hall = W3s + 2 * HIDB;                                       // [8 waves][32][LDH]
     const int lane = lane_id(), w = wave_id_uniform();
     const int g = lane >> 5, l31 = lane & 31;
     for (int e = threadIdx.x; e < 2 * NS * 64; e += blockDim.x) {
         const int ln = e & 63, S = (e >> 6) % NS, cblk = e / (64 * NS);
         const float* wr = W0 + (int64_t)(cblk * 32 + (ln & 31)) * K + 16 * S + 8 * (ln >> 5);
-        Bs[(cblk * NS + S) * 64 + ln] = make_uint4(pack_bf16(wr[0], wr[1]), pack_bf16(wr[2], wr[3]), pack_bf16(wr[4], wr[5]), pack_bf16(wr[6], wr[7]));
+        uint32_t ph[4], pl[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) split2(wr[2 * d], wr[2 * d + 1], ph[d], pl[d]);
+        Bs[(cblk * NS + S) * 64 + ln] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+        if (PR) Bs[2 * NS * 64 + (cblk * NS + S) * 64 + ln] = make_uint4(pl[0], pl[1], pl[2], pl[3]);   // W0 = hi + lo: y . W0 to 16 bits
     }
     for (int e = threadIdx.x; e < 2 * HIDB; e += blockDim.x) W3s[e] = (e / HIDB) < n_out ? W3[e] : 0.f;
     float bb[2], sc[2], sh[2];
@@ -458,9 +546,14 @@ __global__ void __launch_bounds__(512) k_decoder_rows_bf16(const uint16_t* __res
 #pragma unroll
         for (int S = 0; S < NS; ++S)
 #pragma unroll
-            for (int cblk = 0; cblk < 2; ++cblk)
+            for (int cblk = 0; cblk < 2; ++cblk) {
+                if (PR)
+                    acc[cblk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[S]),
+                                                                        __builtin_bit_cast(bf16x8, Bs[2 * NS * 64 + (cblk * NS + S) * 64 + lane]),
+                                                                        acc[cblk], 0, 0, 0);
                 acc[cblk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[S]),
                                                                     __builtin_bit_cast(bf16x8, Bs[(cblk * NS + S) * 64 + lane]), acc[cblk], 0, 0, 0);
+            }
 #pragma unroll
         for (int cblk = 0; cblk < 2; ++cblk)
 #pragma unroll
@@ -516,7 +609,7 @@ extern "C" int dgnn_sage_layer_fused_fwd_bf16(const int32_t* rowptr, const int32
                                               const uint16_t* x_src, const uint16_t* x_dst, int64_t ldx, int c_in, const float* edge_attr,
                                               int64_t lde, int f_e, const float* We, const float* be, const float* Wj, const float* bj,
                                               const float* Wi, const float* scale, const float* shift, int relu, int c_out, uint16_t* out,
-                                              int64_t ldo, void* stream_) {
+                                              int64_t ldo, int mode, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DGNN_REQUIRE(n_dst >= 0 && c_in > 0 && c_out > 0, DGNN_E_INVALID, "sage_layer_fused_fwd_bf16: bad sizes");
     if (n_dst == 0) return DGNN_OK;
@@ -534,18 +627,29 @@ extern "C" int dgnn_sage_layer_fused_fwd_bf16(const int32_t* rowptr, const int32
     DGNN_REQUIRE(c_in % nb == 0 && ldx % nb == 0 && (((uintptr_t)x_src | (uintptr_t)x_dst) % (2 * nb)) == 0, DGNN_E_UNSUPPORTED,
                  "sage_layer_fused_fwd_bf16: c_in and the row stride must be multiples of %d, rows %d-byte aligned", nb, 2 * nb);
     DGNN_REQUIRE(ldo % 2 == 0 && ((uintptr_t)out % 4) == 0, DGNN_E_UNSUPPORTED, "sage_layer_fused_fwd_bf16: out rows must be 4-byte aligned");
-#define GOB(CP, CO, OCC) return launch_b<CP, CO, OCC>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, \
-                                                      shift, relu, out, ldo, stream)
+    DGNN_REQUIRE(mode == DGNN_BF16_SINGLE || mode == DGNN_BF16_COMPENSATED, DGNN_E_INVALID, "sage_layer_fused_fwd_bf16: bad mode %d", mode);
+#define GOB(CP, CO, OCC)                                                                                                                  \
+    do {                                                                                                                                  \
+        if (mode == DGNN_BF16_COMPENSATED)                                                                                                \
+            return launch_b<CP, CO, OCC, 1>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale,  \
+                                            shift, relu, out, ldo, stream);                                                               \
+        return launch_b<CP, CO, OCC, 0>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale,      \
+                                        shift, relu, out, ldo, stream);                                                                   \
+    } while (0)
     if (cin_pad == 32) { if (c_out == 64) GOB(32, 64, 2); else GOB(32, 128, 2); }
     if (cin_pad == 64) { if (c_out == 64) GOB(64, 64, 2); else GOB(64, 128, 2); }
     if (c_out == 64) GOB(128, 64, 2);
+    // 128 -> 128: the compensated form keeps four weight parts resident -> eight-wave workgroups with 16-column slices
+    if (mode == DGNN_BF16_COMPENSATED)
+        return launch_b<128, 128, 1, 1, 8>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, shift, relu,
+                                           out, ldo, stream);
     GOB(128, 128, 2);
 #undef GOB
 }
 
 extern "C" int dgnn_decoder_fused_fwd_bf16(const uint16_t* y, int64_t ldy, int64_t M, int k, const float* W0, const float* b0, const float* scale,
                                            const float* shift, int hidden, const float* W3, const float* b3, int n_out, float* out, int64_t ldo,
-                                           void* stream) {
+                                           int mode, void* stream) {
     DGNN_REQUIRE(M >= 0 && k > 0 && hidden > 0 && n_out > 0, DGNN_E_INVALID, "decoder_fused_fwd_bf16: bad sizes");
     if (M == 0) return DGNN_OK;
     DGNN_REQUIRE(y && W0 && W3 && out, DGNN_E_INVALID, "decoder_fused_fwd_bf16: null pointer");
@@ -553,12 +657,21 @@ extern "C" int dgnn_decoder_fused_fwd_bf16(const uint16_t* y, int64_t ldy, int64
     DGNN_REQUIRE(k == 128 && hidden == HIDB && n_out <= 2 && ((uintptr_t)y % 16) == 0 && ldy % 8 == 0, DGNN_E_UNSUPPORTED,
                  "decoder_fused_fwd_bf16: supports 128 -> 64 -> {1,2} on 16-byte aligned rows (got %d -> %d -> %d)", k, hidden, n_out);
     constexpr int K = 128, LDH = HIDB + 4;
-    const size_t smem = 2 * (K / 16) * 64 * 16 + 2 * HIDB * 4 + 8 * 32 * LDH * 4;
-    static bool attr_set[DGNN_MAX_DEVICES] = {};
-    dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_decoder_rows_bf16<128>), smem, attr_set);
+    DGNN_REQUIRE(mode == DGNN_BF16_SINGLE || mode == DGNN_BF16_COMPENSATED, DGNN_E_INVALID, "decoder_fused_fwd_bf16: bad mode %d", mode);
+    const int parts = mode == DGNN_BF16_COMPENSATED ? 2 : 1;
+    const size_t smem = parts * 2 * (K / 16) * 64 * 16 + 2 * HIDB * 4 + 8 * 32 * LDH * 4;
     const int64_t nt = dgnn_cdiv(M, 32);
     const int grid = (int)(dgnn_cdiv(nt, 8) < DGNN_NUM_CU ? dgnn_cdiv(nt, 8) : DGNN_NUM_CU);
-    hipLaunchKernelGGL((k_decoder_rows_bf16<128>), dim3(grid), dim3(512), smem, (hipStream_t)stream, y, ldy, M, W0, b0, scale, shift, W3, b3,
-                       n_out, out, ldo);
+    if (parts == 2) {
+        static bool attr_set[DGNN_MAX_DEVICES] = {};
+        dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_decoder_rows_bf16<128, 1>), smem, attr_set);
+        hipLaunchKernelGGL((k_decoder_rows_bf16<128, 1>), dim3(grid), dim3(512), smem, (hipStream_t)stream, y, ldy, M, W0, b0, scale, shift, W3,
+                           b3, n_out, out, ldo);
+    } else {
+        static bool attr_set[DGNN_MAX_DEVICES] = {};
+        dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_decoder_rows_bf16<128, 0>), smem, attr_set);
+        hipLaunchKernelGGL((k_decoder_rows_bf16<128, 0>), dim3(grid), dim3(512), smem, (hipStream_t)stream, y, ldy, M, W0, b0, scale, shift, W3,
+                           b3, n_out, out, ldo);
+    }
     return dgnn_check_launch("decoder_fused_fwd_bf16");
 }

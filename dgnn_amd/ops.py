@@ -375,6 +375,10 @@ def decoder_fused_fwd(y, W0, b0, scale, shift, W3, b3):
 
 # ---- bf16 storage path (BASELINE config 3) ----------------------------------------------------------------------------------
 BF16 = torch.bfloat16
+BF16_SINGLE, BF16_COMPENSATED = 0, 1
+# how the fused bf16-storage kernels feed the matrix cores: "single" = every operand rounded to bf16 once; "compensated"
+# (default) = only the stored activations are bf16, the fp32 mean / attributes / parameters go in as (hi, lo) bf16 pairs
+BF16_MODE = {"single": BF16_SINGLE, "compensated": BF16_COMPENSATED}[__import__("os").environ.get("DGNN_BF16_MODE", "compensated")]
 
 
 @on_device_of
@@ -423,7 +427,7 @@ def sage_layer_fused_fwd_bf16(rowptr, src, n_dst, x_src, c_in, edge_attr, We, be
             raise ValueError("out must be a contiguous [>= n_dst, c_out] buffer")
     check(lib().dgnn_sage_layer_fused_fwd_bf16(
         ptr(rowptr), ptr(src), ptr(eid), n_dst, ptr(x_src), ptr(x_dst), _ld(x_src), c_in, ptr(edge_attr), _ld(edge_attr), We.size(1),
-        ptr(We), ptr(be), ptr(Wj), ptr(bj), ptr(Wi), ptr(scale), ptr(shift), int(bool(relu)), c_out, ptr(out), c_out, stream_ptr()),
+        ptr(We), ptr(be), ptr(Wj), ptr(bj), ptr(Wi), ptr(scale), ptr(shift), int(bool(relu)), c_out, ptr(out), c_out, BF16_MODE, stream_ptr()),
         "dgnn_sage_layer_fused_fwd_bf16")
     return out
 
@@ -434,6 +438,6 @@ def decoder_fused_fwd_bf16(y, W0, b0, scale, shift, W3, b3):
     M, n_out = y.size(0), W3.size(0)
     out = torch.empty((M, n_out), dtype=torch.float32, device=y.device)
     check(lib().dgnn_decoder_fused_fwd_bf16(ptr(y), _ld(y), M, y.size(1), ptr(W0.contiguous()), ptr(b0), ptr(scale), ptr(shift),
-                                            W0.size(0), ptr(W3.contiguous()), ptr(b3), n_out, ptr(out), n_out, stream_ptr()),
+                                            W0.size(0), ptr(W3.contiguous()), ptr(b3), n_out, ptr(out), n_out, BF16_MODE, stream_ptr()),
           "dgnn_decoder_fused_fwd_bf16")
     return out

@@ -217,6 +217,9 @@ int dgnn_decoder_fused_fwd(const float* y, int64_t ldy, int64_t M, int k, const 
  * bf16 when staged).  Stated tolerance: |dlogit| <= 5e-2 * max(1, |logit|/8), arg-max agreement >= 99.9 % vs fp32.
  * Same argument meaning as the fp32 entry points of the same name; rows must be aligned as each comment says.
  * ---------------------------------------------------------------------------------------------- */
+#define DGNN_BF16_SINGLE 0      /* every operand rounded to bf16 once, one MFMA per product */
+#define DGNN_BF16_COMPENSATED 1 /* only what is STORED is bf16: the fp32 mean, attributes and parameters enter the matrix cores as
+                                   (hi, lo) bf16 pairs (16 bits; filter 3 products, a.Wj 3, x_i.Wi 2) -- the default */
 /* out[r, 0:cols] = bf16(in[r, 0:cols]), out[r, cols:cols_pad] = 0   (cols_pad even, ld_out >= cols_pad, ld_out even) */
 int dgnn_cast_f32_to_bf16(const float* in, int64_t ld_in, int64_t n, int cols, int cols_pad, uint16_t* out, int64_t ld_out, void* stream);
 int dgnn_cast_bf16_to_f32(const uint16_t* in, int64_t ld_in, int64_t n, int cols, float* out, int64_t ld_out, void* stream);
@@ -225,11 +228,12 @@ int dgnn_cast_bf16_to_f32(const uint16_t* in, int64_t ld_in, int64_t n, int cols
 int dgnn_sage_layer_fused_fwd_bf16(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const uint16_t* x_src,
                                    const uint16_t* x_dst, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e,
                                    const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
-                                   const float* scale, const float* shift, int relu, int c_out, uint16_t* out, int64_t ldo, void* stream);
+                                   const float* scale, const float* shift, int relu, int c_out, uint16_t* out, int64_t ldo, int mode,
+                                   void* stream);
 /* dgnn_decoder_fused_fwd on bf16 rows (16-byte aligned, ldy % 8 == 0); logits stay fp32 */
 int dgnn_decoder_fused_fwd_bf16(const uint16_t* y, int64_t ldy, int64_t M, int k, const float* W0, const float* b0, const float* scale,
                                 const float* shift, int hidden, const float* W3, const float* b3, int n_out, float* out, int64_t ldo,
-                                void* stream);
+                                int mode, void* stream);
 
 /* bf16-storage twins of the generic (training / any-width) entry points above: x / phi / a / gradients of activations are
  * bf16, parameters and their gradients fp32, all arithmetic fp32 between a widening load and a rounding store; the GEMMs run

@@ -90,9 +90,14 @@ def main():
         return worker(args.libs[0], args.dtype, args.points)
     import numpy as np
     procs = []
-    for lib in args.libs:
+    for spec in args.libs:
+        lib, _, envs = spec.partition("@")          # lib.so@KEY=VAL,KEY2=VAL2 sets environment variables for that worker
+        env = dict(os.environ)
+        for kv in filter(None, envs.split(",")):
+            k_, _, v_ = kv.partition("=")
+            env[k_] = v_
         p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", "--dtype", args.dtype, "--points", str(args.points), lib],
-                             stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+                             stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env)
         procs.append(p)
 
     def read_json(p):
@@ -123,7 +128,7 @@ def main():
         tmin = np.min(np.asarray(times[k]), axis=0)
         d3 = float(np.abs(np.asarray(samples[k][0]) - np.asarray(base[0])).max())
         dl = float(np.abs(np.asarray(samples[k][1]) - np.asarray(base[1])).max())
-        print("%-34s " % os.path.basename(lib)[:34] + " ".join("%8.4f" % v for v in t) + "   %.2e %.2e" % (d3, dl))
+        print("%-34s " % os.path.basename(lib)[-34:] + " ".join("%8.4f" % v for v in t) + "   %.2e %.2e" % (d3, dl))
         print("%-34s " % "   (min)" + " ".join("%8.4f" % v for v in tmin))
 
 
