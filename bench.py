@@ -238,7 +238,7 @@ def main():
             return e0.elapsed_time(e1) / reps
         breakdown["plan_ms"] = timed(lambda: GraphPlan(data.edge_index, n_local, n_local, hint=ops.PLAN_HINT_REFERENCE), 5)
         h = net._input_rows(data.x)
-        if bf16:
+        if bf16 and net._storage_input(h).dtype != h.dtype:
             breakdown["cast_ms"] = timed(lambda: ops.cast_to_bf16(h))
             h = ops.cast_to_bf16(h)
         for i in range(net.num_layers):
@@ -357,13 +357,26 @@ def main():
             got = step().float().cpu()
         refn = ref.double()
         err = (got.double() - refn).abs()
-        tol = (TOL_BF16 if bf16 else TOL_F32) * refn.abs().clamp_min(1.0)
-        margin = (refn[:, 0] - refn[:, 1]).abs() > 2 * tol.max(dim=1).values
-        flips_margin = int((got.argmax(1)[margin] != ref.argmax(1)[margin]).sum())
         agree = float((got.argmax(1) == ref.argmax(1)).double().mean())
-        ok = bool((err <= tol).all()) and (agree >= 0.999 if bf16 else flips_margin == 0)
+        if bf16:
+            # stated tolerance of the bf16 storage path (tests/test_gpu_bf16.py): 5e-2 * max(1, |logit|/8) for >= 99.99 % of the
+            # logits and twice that for every one (single-product mode: both doubled), arg-max agreement >= 99.9 % (99.8 %)
+            k = 1.0 if ops.BF16_MODE == ops.BF16_COMPENSATED else 2.0
+            tol = k * TOL_BF16 * (refn.abs() / 8).clamp_min(1.0)
+            inside = float((err <= tol).double().mean())
+            margin = (refn[:, 0] - refn[:, 1]).abs() > 2 * tol.max(dim=1).values
+            flips_margin = int((got.argmax(1)[margin] != ref.argmax(1)[margin]).sum())
+            ok = inside >= 0.9999 and bool((err <= 2 * tol).all()) and flips_margin == 0 and agree >= (0.999 if k == 1.0 else 0.998)
+            tol_text = "%g * max(1,|logit|/8) for >= 99.99 %% of the logits (within: %.6f), 2x that for all; arg-max agreement >= %s" % (
+                k * TOL_BF16, inside, "99.9 %" if k == 1.0 else "99.8 %")
+        else:
+            tol = TOL_F32 * refn.abs().clamp_min(1.0)
+            margin = (refn[:, 0] - refn[:, 1]).abs() > 2 * tol.max(dim=1).values
+            flips_margin = int((got.argmax(1)[margin] != ref.argmax(1)[margin]).sum())
+            ok = bool((err <= tol).all()) and flips_margin == 0
+            tol_text = "%g * max(1,|logit|)" % TOL_F32
         check = {"reference": "CPU oracle, same graph and weights (%d tets)" % n_full, "max_abs_err": float(err.max()),
-                 "tolerance": "%g * max(1,|logit|)" % (TOL_BF16 if bf16 else TOL_F32), "argmax_flips": int((got.argmax(1) != ref.argmax(1)).sum()),
+                 "rms_err": float((err ** 2).mean().sqrt()), "tolerance": tol_text, "argmax_flips": int((got.argmax(1) != ref.argmax(1)).sum()),
                  "argmax_flips_above_margin": flips_margin, "argmax_agreement": round(agree, 6), "ok": ok}
         failed = not ok
 
@@ -371,7 +384,9 @@ def main():
         gemm = {0: "fp32 MFMA", 1: "split-bf16 MFMA for the dense part (3 exact bf16 parts per fp32 operand, 6 products, fp32 accumulate)",
                 2: "split-bf16 MFMA for the dense part and the filter MLP (3 exact bf16 parts per fp32 operand, 6 products, fp32 accumulate)"}[ops.GEMM_MODE]
         if bf16:
-            gemm = "bf16 storage of activations, single-product bf16 MFMA (v_mfma_f32_32x32x16_bf16 / 16x16x32), fp32 accumulate"
+            gemm = ("bf16 storage of activations; compensated mode: the fp32 mean / attributes / parameters enter the bf16 MFMAs as (hi, lo) pairs, "
+                    "fp32 accumulate; first layer reads the fp32 features in place" if ops.BF16_MODE == ops.BF16_COMPENSATED else
+                    "bf16 storage of activations, single-product bf16 MFMA (every operand rounded to bf16 once), fp32 accumulate")
         out = {
             "metric": "tetrahedra/sec (in/out classified), 1M-tet graph at 1/2/4/8 MI355X",
             "value": round(value, 1), "unit": "tets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -37,9 +37,14 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // (x_i is exactly its stored bf16 value).  The only roundings left per layer are the ones storage implies: the gathered /
 // own rows as they were stored and the layer's output.  PR = 0 is the plain single-product form (every operand rounded to
 // bf16 once); it is ~2x further from the fp32 reference (measured: rms 1.0e-2 vs the compensated mode's on the 1M-tet graph).
-template <int CIN_PAD, int COUT, int NW = 4, int PR = 0>
+// XF: the layer's INPUT rows are fp32 (the first layer reads the caller's fp32 feature matrix in place -- no cast pass, and
+// real standardised features reach 174 sigma, where a bf16 rounding of the input alone costs 0.3 absolute): gathered rows enter
+// the fp32 products as they are, the own row goes to the matrix cores as a (hi, lo) pair (PR) or rounded once (PR = 0).
+template <int CIN_PAD, int COUT, int NW = 4, int PR = 0, int XF = 0>
 struct CfgB {
-    static constexpr int K = (PR ? 3 : 2) * CIN_PAD;      // A-tile row: [a_hi | a_lo | x_i] or [a | x_i]
+    static constexpr int XPARTS = (PR && XF) ? 2 : 1;     // own-row parts in the A-tile
+    static constexpr int APARTS = PR ? 2 : 1;             // mean parts
+    static constexpr int K = (APARTS + XPARTS) * CIN_PAD; // A-tile row: [a_hi | a_lo | x_hi | x_lo] ... [a | x_i]
     // NW == 4: four waves, each a 32-column slice of v_mfma_f32_32x32x16_bf16 blocks.  NW == 8: eight waves, each a 16-column slice
     // of v_mfma_f32_16x16x32_bf16 blocks -- half the resident weights per wave (the compensated 128 -> 128 layer keeps 4 weight
     // parts resident: 128 VGPRs in the 4-wave form = spills, 64 here) and 4 tets per wave in the filter phase.
@@ -58,7 +63,7 @@ struct CfgB {
     static constexpr int BP_BYTES = (PR ? 2 : 1) * NB * 768;   // [part][cb][g<3][j<16] x 16 B filter operand
     static constexpr int SMEM_BYTES = 2 * A_BYTES + NW * EA_BYTES + BP_BYTES;
     static constexpr int NS = CIN_PAD / (D16 ? 32 : 16);  // k-steps (of 16, D16: of 32) per operand part (full K per wave)
-    static_assert(RG >= 1 && NQ <= 64 && EA_BYTES % 256 == 0, "wave roles");
+    static_assert(RG >= 1 && NQ <= 64 && EA_BYTES % 256 == 0 && !(XF && NW == 8), "wave roles");
 };
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
@@ -88,15 +93,39 @@ __device__ __forceinline__ void ld_bf(uint32_t (&v)[NB / 2], const uint16_t* p) 
     }
 }
 
-template <int CIN_PAD, int COUT, int NW, int OCC, int PR>
+template <int CIN_PAD, int COUT, int NW, int OCC, int PR, int XF>
 __global__ void __launch_bounds__(64 * NW, OCC)
 k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid, int64_t n_dst,
-                  const uint16_t* __restrict__ x, const uint16_t* __restrict__ xdst, int64_t ldx, int c_in, const float* __restrict__ ea,
+                  const void* __restrict__ x_, const void* __restrict__ xdst_, int64_t ldx, int c_in, const float* __restrict__ ea,
                   int64_t lde, const float* __restrict__ We, const float* __restrict__ be, const float* __restrict__ Wj,
                   const float* __restrict__ bj, const float* __restrict__ Wi, const float* __restrict__ scale,
                   const float* __restrict__ shift, int relu, uint16_t* __restrict__ out, int64_t ldo, int64_t ntiles) {
-    using C = CfgB<CIN_PAD, COUT, NW, PR>;
+    using C = CfgB<CIN_PAD, COUT, NW, PR, XF>;
     constexpr int ROWB = C::ROWB, TILE = C::TILE, TPW = C::TPW, RB = C::RB, NB = C::NB, NS = C::NS, NH = NB / 2;
+    constexpr int NX = XF ? NB : NH;                                 // dwords per lane and row: NB floats or NB/2 bf16 pairs
+    constexpr int XOFF = C::APARTS * CIN_PAD * 2;                    // byte offset of the own-row part(s) in an A-tile row
+    const uint16_t* const x = reinterpret_cast<const uint16_t*>(x_);
+    const uint16_t* const xdst = reinterpret_cast<const uint16_t*>(xdst_);
+    const float* const xf = reinterpret_cast<const float*>(x_);
+    const float* const xdstf = reinterpret_cast<const float*>(xdst_);
+    // row fragment of this lane: NB channels from c0l
+    auto ld_row = [&](uint32_t (&v)[NX], const void* base, int64_t elem_off) {
+        if constexpr (XF) {
+            const float* p = reinterpret_cast<const float*>(base) + elem_off;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) v[i] = __builtin_bit_cast(uint32_t, p[i]);
+        } else {
+            uint32_t t[NH];
+            ld_bf<NB>(t, reinterpret_cast<const uint16_t*>(base) + elem_off);
+#pragma unroll
+            for (int i = 0; i < NH; ++i) v[i] = t[i];
+        }
+    };
+    auto chan = [&](const uint32_t (&v)[NX], int cb) -> float {    // channel cb of a fragment as fp32
+        if constexpr (XF) return __builtin_bit_cast(float, v[cb]);
+        else return (cb & 1) ? bf_hi(v[cb >> 1]) : bf_lo(v[cb >> 1]);
+    };
+    (void)x; (void)xdst; (void)xf; (void)xdstf;
     extern __shared__ __attribute__((aligned(16))) char smemb[];
     char* const abuf = smemb;                                        // [2][A_BYTES]
     char* const eabuf = smemb + 2 * C::A_BYTES;                      // [NW][EA_BYTES] fp32 attribute strips
@@ -169,7 +198,7 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     const int c0l = on ? c0 : 0;
     float* const myea = reinterpret_cast<float*>(eabuf + w * C::EA_BYTES);
 
-    uint32_t xd[RB][NH], xr[RB][4][NH];
+    uint32_t xd[RB][NX], xr[RB][4][NX];
     bool regular = false;
     int vbeg1 = 0, vbeg2 = 0, vsrc1 = 0, veid1 = 0;
     bool ok1 = false, ok2 = false;
@@ -202,11 +231,11 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const int tl = rb * 4 + tq;
-                ld_bf<NB>(xd[rb], xdst + (uint32_t)((i0 + (tl < nv1 ? tl : nv1 - 1)) * ldx32) + c0l);
+                ld_row(xd[rb], xdst_, (int64_t)(uint32_t)((i0 + (tl < nv1 ? tl : nv1 - 1)) * ldx32) + c0l);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int s_ = __shfl(vsrc1, tl * 4 + r);
-                    ld_bf<NB>(xr[rb][r], x + (uint32_t)(s_ * ldx32) + c0l);
+                    ld_row(xr[rb][r], x_, (int64_t)(uint32_t)(s_ * ldx32) + c0l);
                 }
             }
             if (eid) {
@@ -240,11 +269,22 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         else if (NB == 4) *reinterpret_cast<uint2*>(d) = make_uint2(v[0], v[1 % NH]);
         else *reinterpret_cast<uint32_t*>(d) = v[0];
     };
-    auto put_seg = [&](int buf, int row, const uint32_t (&av)[NH], const uint32_t (&al)[NH], const uint32_t (&xv)[NH]) {
+    auto put_seg = [&](int buf, int row, const uint32_t (&av)[NH], const uint32_t (&al)[NH], const uint32_t (&xv)[NX]) {
         char* dst = abuf + buf * C::A_BYTES + row * ROWB + c0 * 2;
         put16(dst, av);
         if (PR) put16(dst + CIN_PAD * 2, al);
-        put16(dst + (PR ? 2 : 1) * CIN_PAD * 2, xv);
+        if constexpr (XF) {
+            uint32_t xh[NH], xl[NH];
+#pragma unroll
+            for (int q = 0; q < NH; ++q) split2(__builtin_bit_cast(float, xv[2 * q]), __builtin_bit_cast(float, xv[2 * q + 1]), xh[q], xl[q]);
+            put16(dst + XOFF, xh);
+            if (PR) put16(dst + XOFF + CIN_PAD * 2, xl);
+        } else {
+            uint32_t t[NH];
+#pragma unroll
+            for (int q = 0; q < NH; ++q) t[q] = xv[q];
+            put16(dst + XOFF, t);
+        }
     };
 
     ok1 = load_rowptr(0, vbeg1, nv1);
@@ -292,11 +332,10 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                     }
                     d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aop, __builtin_bit_cast(bf16x8, u0), d, 0, 0, 0);
                     // d[r] = phi of the r-th in-edge of this lane's tet, channel c0 + cb; in-order sum over the 4 in-edges
-                    const uint32_t w0 = xr[rb][0][cb >> 1], w1 = xr[rb][1][cb >> 1], w2 = xr[rb][2][cb >> 1], w3 = xr[rb][3][cb >> 1];
-                    float a = __fmul_rn((cb & 1) ? bf_hi(w0) : bf_lo(w0), d[0]);
-                    a = __fmaf_rn((cb & 1) ? bf_hi(w1) : bf_lo(w1), d[1], a);
-                    a = __fmaf_rn((cb & 1) ? bf_hi(w2) : bf_lo(w2), d[2], a);
-                    a = __fmaf_rn((cb & 1) ? bf_hi(w3) : bf_lo(w3), d[3], a);
+                    float a = __fmul_rn(chan(xr[rb][0], cb), d[0]);
+                    a = __fmaf_rn(chan(xr[rb][1], cb), d[1], a);
+                    a = __fmaf_rn(chan(xr[rb][2], cb), d[2], a);
+                    a = __fmaf_rn(chan(xr[rb][3], cb), d[3], a);
                     a *= 0.25f;
                     if (cb & 1) split2(prev, a, aout[cb >> 1], alo[cb >> 1]);
                     else prev = a;
@@ -314,19 +353,19 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
             for (int rb = 0; rb < RB; ++rb) {
                 const int64_t i = i0 + rb * 4 + tq;
                 float af[NB];
-                uint32_t aout[NH], alo[NH], xv[NH];
+                uint32_t aout[NH], alo[NH], xv[NX];
 #pragma unroll
                 for (int cb = 0; cb < NB; ++cb) af[cb] = 0.f;
 #pragma unroll
-                for (int q = 0; q < NH; ++q) xv[q] = 0u;
+                for (int q = 0; q < NX; ++q) xv[q] = 0u;
                 if (i < n_dst && on) {
                     const int b = rowptr[i], e_end = rowptr[i + 1];
-                    ld_bf<NB>(xv, xdst + i * ldx + c0);
+                    ld_row(xv, xdst_, i * ldx + c0);
                     for (int k = b; k < e_end; ++k) {
                         const int s_ = src[k];
                         const float* ar = ea + (int64_t)(eid ? eid[k] : k) * lde;
-                        uint32_t xs[NH];
-                        ld_bf<NB>(xs, x + (int64_t)s_ * ldx + c0);
+                        uint32_t xs[NX];
+                        ld_row(xs, x_, (int64_t)s_ * ldx + c0);
 #pragma unroll 1
                         for (int cb = 0; cb < NB; ++cb) {
                             float p = 0.f;
@@ -336,8 +375,10 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                                     p = PR ? __fmaf_rn(We[(int64_t)(c0 + cb) * FE + f], ar[f], p)
                                            : __fmaf_rn(bf16_round(We[(int64_t)(c0 + cb) * FE + f]), bf16_round(ar[f]), p);
                             }
-                            const uint32_t wv = xs[cb >> 1];
-                            af[cb] = __fadd_rn(af[cb], __fmul_rn((cb & 1) ? bf_hi(wv) : bf_lo(wv), p));
+                            float xc = 0.f;   // (runtime cb: select, no dynamic register indexing)
+#pragma unroll
+                            for (int q = 0; q < NB; ++q) xc = q == cb ? chan(xs, q) : xc;
+                            af[cb] = __fadd_rn(af[cb], __fmul_rn(xc, p));
                         }
                     }
                     const float cnt = (float)max(e_end - b, 1);
@@ -366,11 +407,12 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
 #pragma unroll
             for (int S = 0; S < NS; ++S) {
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(A + S * 32);
-                const bf16x8 xi = *reinterpret_cast<const bf16x8*>(A + (PR ? 2 : 1) * CIN_PAD * 2 + S * 32);
+                const bf16x8 xi = *reinterpret_cast<const bf16x8*>(A + XOFF + S * 32);
                 if (PR) {   // small terms first
                     const bf16x8 al = *reinterpret_cast<const bf16x8*>(A + CIN_PAD * 2 + S * 32);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wjh[S], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wjl[S], acc, 0, 0, 0);
+                    if (XF) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(A + XOFF + CIN_PAD * 2 + S * 32), wih[S], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xi, wil[S], acc, 0, 0, 0);
                 }
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wjh[S], acc, 0, 0, 0);
@@ -402,7 +444,7 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                 for (int m = 0; m < 2; ++m) {
                     const char* Am = A + m * 16 * ROWB + S * 64;
                     const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Am);
-                    const bf16x8 xi = *reinterpret_cast<const bf16x8*>(Am + (PR ? 2 : 1) * CIN_PAD * 2);
+                    const bf16x8 xi = *reinterpret_cast<const bf16x8*>(Am + XOFF);
                     f32x4_t c = acc2[m];
                     if (PR) {
                         const bf16x8 al = *reinterpret_cast<const bf16x8*>(Am + CIN_PAD * 2);
@@ -433,20 +475,20 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     }
 }
 
-template <int CIN_PAD, int COUT, int OCC, int PR, int NW = 4>
-int launch_b(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const uint16_t* x, const uint16_t* xdst, int64_t ldx,
+template <int CIN_PAD, int COUT, int OCC, int PR, int NW = 4, int XF = 0>
+int launch_b(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const void* x, const void* xdst, int64_t ldx,
              int c_in, const float* ea, int64_t lde, const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
              const float* scale, const float* shift, int relu, uint16_t* out, int64_t ldo, hipStream_t stream) {
-    using C = CfgB<CIN_PAD, COUT, NW, PR>;
+    using C = CfgB<CIN_PAD, COUT, NW, PR, XF>;
     const int64_t ntiles = dgnn_cdiv(n_dst, C::TILE);
     const size_t smem = C::SMEM_BYTES;
     static bool attr_set[DGNN_MAX_DEVICES] = {};
-    dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_bf16<CIN_PAD, COUT, NW, OCC, PR>), smem, attr_set);
+    dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_bf16<CIN_PAD, COUT, NW, OCC, PR, XF>), smem, attr_set);
     const int per_cu = (int)(160 * 1024 / smem) < OCC ? (int)(160 * 1024 / smem) : OCC;
     const int wg_max = DGNN_NUM_CU * (per_cu < 1 ? 1 : per_cu);
     int grid = (int)(ntiles < wg_max ? ntiles : wg_max);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((k_sage_fused_bf16<CIN_PAD, COUT, NW, OCC, PR>), dim3(grid), dim3(64 * NW), smem, stream, rowptr, src, eid, n_dst, x, xdst,
+    hipLaunchKernelGGL((k_sage_fused_bf16<CIN_PAD, COUT, NW, OCC, PR, XF>), dim3(grid), dim3(64 * NW), smem, stream, rowptr, src, eid, n_dst, x, xdst,
                        ldx, c_in, ea, lde, We, be, Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles);
     return dgnn_check_launch("sage_layer_fused_fwd_bf16");
 }
@@ -606,7 +648,7 @@ extern "C" int dgnn_cast_bf16_to_f32(const uint16_t* in, int64_t ld_in, int64_t 
 }
 
 extern "C" int dgnn_sage_layer_fused_fwd_bf16(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst,
-                                              const uint16_t* x_src, const uint16_t* x_dst, int64_t ldx, int c_in, const float* edge_attr,
+                                              const void* x_src, int x_f32, const void* x_dst, int64_t ldx, int c_in, const float* edge_attr,
                                               int64_t lde, int f_e, const float* We, const float* be, const float* Wj, const float* bj,
                                               const float* Wi, const float* scale, const float* shift, int relu, int c_out, uint16_t* out,
                                               int64_t ldo, int mode, void* stream_) {
@@ -624,8 +666,11 @@ extern "C" int dgnn_sage_layer_fused_fwd_bf16(const int32_t* rowptr, const int32
     DGNN_REQUIRE(c_in <= 128 && (c_out == 64 || c_out == 128), DGNN_E_UNSUPPORTED,
                  "sage_layer_fused_fwd_bf16: supports c_in <= 128 and c_out in {64,128} (got %d -> %d)", c_in, c_out);
     // a lane reads nb contiguous bf16 of a row: rows must be aligned to that, and every lane's piece must lie inside the row
-    DGNN_REQUIRE(c_in % nb == 0 && ldx % nb == 0 && (((uintptr_t)x_src | (uintptr_t)x_dst) % (2 * nb)) == 0, DGNN_E_UNSUPPORTED,
-                 "sage_layer_fused_fwd_bf16: c_in and the row stride must be multiples of %d, rows %d-byte aligned", nb, 2 * nb);
+    DGNN_REQUIRE(c_in % nb == 0, DGNN_E_UNSUPPORTED, "sage_layer_fused_fwd_bf16: c_in must be a multiple of %d", nb);
+    DGNN_REQUIRE(x_f32 || (ldx % nb == 0 && (((uintptr_t)x_src | (uintptr_t)x_dst) % (2 * nb)) == 0), DGNN_E_UNSUPPORTED,
+                 "sage_layer_fused_fwd_bf16: the row stride must be a multiple of %d, rows %d-byte aligned", nb, 2 * nb);
+    DGNN_REQUIRE(!x_f32 || (cin_pad == 32 && (((uintptr_t)x_src | (uintptr_t)x_dst) % 4) == 0), DGNN_E_UNSUPPORTED,
+                 "sage_layer_fused_fwd_bf16: fp32 input rows are supported for c_in <= 32 (the first layer)");
     DGNN_REQUIRE(ldo % 2 == 0 && ((uintptr_t)out % 4) == 0, DGNN_E_UNSUPPORTED, "sage_layer_fused_fwd_bf16: out rows must be 4-byte aligned");
     DGNN_REQUIRE(mode == DGNN_BF16_SINGLE || mode == DGNN_BF16_COMPENSATED, DGNN_E_INVALID, "sage_layer_fused_fwd_bf16: bad mode %d", mode);
 #define GOB(CP, CO, OCC)                                                                                                                  \
@@ -636,6 +681,14 @@ extern "C" int dgnn_sage_layer_fused_fwd_bf16(const int32_t* rowptr, const int32
         return launch_b<CP, CO, OCC, 0>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale,      \
                                         shift, relu, out, ldo, stream);                                                                   \
     } while (0)
+    if (x_f32) {
+        const bool pr = mode == DGNN_BF16_COMPENSATED;
+#define GOX(CO, PRV) return launch_b<32, CO, 2, PRV, 4, 1>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, \
+                                                          scale, shift, relu, out, ldo, stream)
+        if (c_out == 64) { if (pr) GOX(64, 1); else GOX(64, 0); }
+        if (pr) GOX(128, 1); else GOX(128, 0);
+#undef GOX
+    }
     if (cin_pad == 32) { if (c_out == 64) GOB(32, 64, 2); else GOB(32, 128, 2); }
     if (cin_pad == 64) { if (c_out == 64) GOB(64, 64, 2); else GOB(64, 128, 2); }
     if (c_out == 64) GOB(128, 64, 2);

@@ -163,6 +163,17 @@ class SurfaceNet(nn.Module):
         """drop column 0 (the loss-weight column) when regularization.cell_type is set, reference :329-332"""
         return x[:, 1:] if self.clf.regularization.cell_type else x
 
+    def _storage_input(self, x):
+        """fp32 input rows as the first conv layer takes them: unchanged in fp32 storage; in bf16 storage the fused first layer
+        reads the fp32 features in place (they are never rounded), any other first layer gets a bf16 copy."""
+        if self.storage_dtype != torch.bfloat16 or x.dtype == torch.bfloat16:
+            return x
+        c0 = self.convs[0][0]
+        if isinstance(c0.lin_e, Linear) and c0.lin_e.in_features == 20 and \
+                ops.fused_layer_supported_bf16(c0.lin_j.in_features, c0.lin_j.out_features, 20, x):
+            return x
+        return ops.cast_to_bf16(x)
+
     def _norm_act(self, layer, x):
         """convs[i][1] then convs[i][2] (reference :218-219): BatchNorm (if any) + ReLU, one kernel chain."""
         norm = layer[1] if len(layer) > 1 and isinstance(layer[1], BatchNorm) else None
@@ -204,8 +215,7 @@ class SurfaceNet(nn.Module):
         dev = self._device()
         x = _dev_f32(data_all.x, dev)
         x = x[:, 1:] if self.clf.regularization.cell_type else x
-        if self.storage_dtype == torch.bfloat16:
-            x = ops.cast_to_bf16(x)      # [N, 32] bf16, zero padding columns; later layers write bf16 themselves
+        x = self._storage_input(x)
         xe = _dev_f32(data_all.edge_attr, dev)
         xe = xe[:, 1:] if self.clf.regularization.edge_type else xe
         edge_index = data_all.edge_index.to(dev)
@@ -261,7 +271,8 @@ class SurfaceNet(nn.Module):
         x_dst = x[b:e]
         out_v = out if (out is None or rows is None) else out[b:e]
         simple = isinstance(le, Linear) and le.in_features in (2, 20)
-        if x.dtype == torch.bfloat16:
+        if x.dtype == torch.bfloat16 or (self.storage_dtype == torch.bfloat16 and simple and le.in_features == 20
+                                         and ops.fused_layer_supported_bf16(conv.lin_j.in_features, conv.lin_j.out_features, 20, x)):
             c_in = conv.lin_j.in_features    # the logical width: bf16 rows may carry zero padding columns
             if not (simple and le.in_features == 20 and ops.fused_layer_supported_bf16(c_in, conv.lin_j.out_features, 20, x)):
                 return self._eval_layer_bf16_unfused(conv, scale, shift, x, xe, plan, sorted_attr, out_v, rows)

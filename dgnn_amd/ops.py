@@ -402,11 +402,14 @@ def cast_to_f32(x: torch.Tensor) -> torch.Tensor:
 
 
 def fused_layer_supported_bf16(c_in: int, c_out: int, f_e: int, x: torch.Tensor = None) -> bool:
-    """Mirrors the shape dispatch of dgnn_sage_layer_fused_fwd_bf16 (csrc/fused_bf16.hip)."""
+    """Mirrors the shape dispatch of dgnn_sage_layer_fused_fwd_bf16 (csrc/fused_bf16.hip).  `x` fp32: the first layer reading the
+    caller's fp32 features in place (c_in <= 32)."""
     if not FUSED_ENABLED or f_e != 20 or c_in > 128 or c_out not in (64, 128):
         return False
     nb = 2 if c_in <= 32 else (4 if c_in <= 64 else 8)
     ok = c_in % nb == 0
+    if x is not None and x.dtype == torch.float32:
+        return ok and c_in <= 32 and x.data_ptr() % 4 == 0
     if x is not None:
         ok = ok and x.stride(0) % nb == 0 and x.data_ptr() % (2 * nb) == 0
     return ok
@@ -416,8 +419,10 @@ def fused_layer_supported_bf16(c_in: int, c_out: int, f_e: int, x: torch.Tensor 
 def sage_layer_fused_fwd_bf16(rowptr, src, n_dst, x_src, c_in, edge_attr, We, be, Wj, bj, Wi, scale, shift, relu, out=None, eid=None,
                               x_dst=None):
     """bf16-storage twin of sage_layer_fused_fwd.  `x_src` bf16 [n_src, ld >= c_in] (padding columns allowed: `c_in` is the
-    logical width = Wj.shape[1]); returns bf16 [n_dst, c_out]."""
-    _req(x_src, "x_src", BF16, dim=2)
+    logical width = Wj.shape[1]) -- or, for the first layer (c_in <= 32), the caller's fp32 rows read in place; returns bf16
+    [n_dst, c_out]."""
+    _req(x_src, "x_src", ACT, dim=2)
+    _same(x_dst, x_src, "x_dst")
     c_out = Wj.size(0)
     if out is None:
         out = torch.empty((n_dst, c_out), dtype=BF16, device=x_src.device)
@@ -426,7 +431,8 @@ def sage_layer_fused_fwd_bf16(rowptr, src, n_dst, x_src, c_in, edge_attr, We, be
         if out.size(0) < n_dst or out.size(1) != c_out or out.stride(0) != c_out:
             raise ValueError("out must be a contiguous [>= n_dst, c_out] buffer")
     check(lib().dgnn_sage_layer_fused_fwd_bf16(
-        ptr(rowptr), ptr(src), ptr(eid), n_dst, ptr(x_src), ptr(x_dst), _ld(x_src), c_in, ptr(edge_attr), _ld(edge_attr), We.size(1),
+        ptr(rowptr), ptr(src), ptr(eid), n_dst, ptr(x_src), int(x_src.dtype == torch.float32), ptr(x_dst), _ld(x_src), c_in, ptr(edge_attr),
+        _ld(edge_attr), We.size(1),
         ptr(We), ptr(be), ptr(Wj), ptr(bj), ptr(Wi), ptr(scale), ptr(shift), int(bool(relu)), c_out, ptr(out), c_out, BF16_MODE, stream_ptr()),
         "dgnn_sage_layer_fused_fwd_bf16")
     return out

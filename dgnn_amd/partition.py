@@ -281,6 +281,7 @@ class PartitionedScene:
             self.plan = self._GraphPlan(self.edge_index, n_src, self.n_own, hint=1)  # local list is grouped by destination
         plan = self.plan
         x = self.x_local[:, 1:] if net.clf.regularization.cell_type else self.x_local
+        x = net._storage_input(x) if hasattr(net, "_storage_input") else x
         if net.clf.regularization.edge_type:
             # column 0 is the regularisation column (reference :334-337): strip it once, the kernels want packed rows
             if self._xe_stripped is None:
@@ -293,7 +294,7 @@ class PartitionedScene:
             net._eval_layers(h, self.n_own, xe, [plan] * net.num_layers, False, only=i, out=out, rows=(b, e))
 
         def alloc(r, c):
-            return torch.empty((r, c), dtype=torch.float32, device=self.device)
+            return torch.empty((r, c), dtype=getattr(net, "storage_dtype", torch.float32), device=self.device)
 
         return run_partitioned_layers(self.lp, x, net.num_layers, layer_fn, net._eval_decoder, self.exchange, alloc,
                                       widths=list(net.clf.model.convs))

@@ -224,9 +224,11 @@ int dgnn_decoder_fused_fwd(const float* y, int64_t ldy, int64_t M, int k, const 
 int dgnn_cast_f32_to_bf16(const float* in, int64_t ld_in, int64_t n, int cols, int cols_pad, uint16_t* out, int64_t ld_out, void* stream);
 int dgnn_cast_bf16_to_f32(const uint16_t* in, int64_t ld_in, int64_t n, int cols, float* out, int64_t ld_out, void* stream);
 /* dgnn_sage_layer_fused_fwd with bf16 x_src / x_dst / out (edge_attr and all parameters fp32).  c_in <= 128, c_out in {64,128};
- * with nb = 2/4/8 for c_in <= 32/64/128: c_in % nb == 0, ldx % nb == 0, rows 2*nb-byte aligned; ldo even, out 4-byte aligned. */
-int dgnn_sage_layer_fused_fwd_bf16(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const uint16_t* x_src,
-                                   const uint16_t* x_dst, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e,
+ * with nb = 2/4/8 for c_in <= 32/64/128: c_in % nb == 0, ldx % nb == 0, rows 2*nb-byte aligned; ldo even, out 4-byte aligned.
+ * x_f32 != 0 (c_in <= 32, the first layer): x_src / x_dst are the caller's fp32 rows (any 4-byte aligned stride), read in
+ * place -- the input features are never rounded to bf16; the output is bf16 as always. */
+int dgnn_sage_layer_fused_fwd_bf16(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const void* x_src, int x_f32,
+                                   const void* x_dst, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e,
                                    const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
                                    const float* scale, const float* shift, int relu, int c_out, uint16_t* out, int64_t ldo, int mode,
                                    void* stream);

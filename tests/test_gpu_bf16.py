@@ -105,6 +105,47 @@ def test_fused_layer_bf16_vs_fp64_on_rounded_inputs(c_in, c_out, mode):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("mode", ["compensated", "single"])
+@pytest.mark.parametrize("c_out", [64, 128])
+def test_first_layer_reads_fp32_rows_in_place(c_out, mode):
+    """c_in <= 32: the fused bf16 layer takes the caller's fp32 feature rows (the reference's x[:, 1:] view: row stride 29, 4-byte
+    aligned) -- no bf16 copy of the input, outliers of 170 sigma are not rounded.  Output bf16."""
+    from dgnn_amd import ops
+    from dgnn_amd.synthetic import delaunay_tet_graph
+    from oracle.pyg_semantics import propagate_mean
+    adj, _, _ = delaunay_tet_graph(700, seed=c_out)
+    n = adj.shape[0] // 4
+    ei = torch.from_numpy(adj.T.astype(np.int64))
+    g = torch.Generator().manual_seed(c_out)
+    x29 = torch.randn(n, 29, generator=g)
+    x29[::41] *= 170
+    x = x29[:, 1:]
+    ea = torch.randn(4 * n, 20, generator=g)
+    We, be = torch.randn(28, 20, generator=g) * 0.3, torch.randn(28, generator=g)
+    Wj, Wi, bj = torch.randn(c_out, 28, generator=g) * 0.1, torch.randn(c_out, 28, generator=g) * 0.1, torch.randn(c_out, generator=g)
+    r = lambda t: t.to(BF).double()
+    comp = mode == "compensated"
+    p = (lambda t: t.double()) if comp else r
+    a = propagate_mean(x.double(), n, ei, p(ea) @ p(We).t() + p(be))        # gathered rows are exact fp32 in both modes
+    ab = a if comp else a.float().to(BF).double()
+    xi = x.double() if comp else r(x)                                       # own row: (hi, lo) pair / rounded once
+    ref = ab @ p(Wj).t() + xi @ p(Wi).t() + bj.double()
+    mag = ab.abs() @ p(Wj).abs().t() + xi.abs() @ p(Wi).abs().t()
+    rowptr, src, eid = ops.plan_build(ei.to(DEV), n, 1, n_other=n)
+    xd = x29.to(DEV)[:, 1:]
+    assert ops.fused_layer_supported_bf16(28, c_out, 20, xd)
+    old, ops.BF16_MODE = ops.BF16_MODE, ops.BF16_COMPENSATED if comp else ops.BF16_SINGLE
+    try:
+        out = ops.sage_layer_fused_fwd_bf16(rowptr, src, n, xd, 28, ea.to(DEV), We.to(DEV), be.to(DEV), Wj.to(DEV), bj.to(DEV), Wi.to(DEV),
+                                            None, None, False, eid=eid)
+    finally:
+        ops.BF16_MODE = old
+    assert out.dtype == BF
+    err = (out.cpu().double() - ref).abs()
+    bound = EPS * ref.abs() + (2.0 ** -14 * mag if comp else 2 * EPS * (ab.abs() @ p(Wj).abs().t())) + 1e-3
+    assert bool((err <= bound).all()), float((err / bound).max())
+
+
 def test_fused_layer_bf16_irregular_degrees_and_tail():
     """in-degree 0..many (generic per-lane path) and a destination count that is not a multiple of the tile"""
     from dgnn_amd import ops
