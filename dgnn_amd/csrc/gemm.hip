@@ -54,8 +54,11 @@ __global__ void __launch_bounds__(256) k_linear_fwd(const float* __restrict__ A1
     __shared__ __attribute__((aligned(16))) float As[BM * LDT];
     __shared__ __attribute__((aligned(16))) float Ws[BN * LDT];
     const int lane = lane_id(), w = wave_id_uniform();
-    const int64_t row0 = (int64_t)blockIdx.x * BM;
-    const int col0 = blockIdx.y * BN;
+    // 1-D grid, column blocks fastest: the blocks that share a row panel of A run together and read it once from HBM (with the
+    // row blocks fastest every column block streamed all of A again: 4x the traffic at n_out = 512)
+    const int ncb = (n_out + BN - 1) / BN;
+    const int64_t row0 = (int64_t)(blockIdx.x / ncb) * BM;
+    const int col0 = (int)(blockIdx.x % ncb) * BN;
     f32x16 acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
@@ -252,8 +255,11 @@ __global__ void __launch_bounds__(256) k_linear_fwd_b(const uint16_t* __restrict
     __shared__ __attribute__((aligned(16))) char As[BM * LDB];
     __shared__ __attribute__((aligned(16))) char Ws[BN * LDB];
     const int lane = lane_id(), w = wave_id_uniform();
-    const int64_t row0 = (int64_t)blockIdx.x * BM;
-    const int col0 = blockIdx.y * BN;
+    // 1-D grid, column blocks fastest: the blocks that share a row panel of A run together and read it once from HBM (with the
+    // row blocks fastest every column block streamed all of A again: 4x the traffic at n_out = 512)
+    const int ncb = (n_out + BN - 1) / BN;
+    const int64_t row0 = (int64_t)(blockIdx.x / ncb) * BM;
+    const int col0 = (int)(blockIdx.x % ncb) * BN;
     f32x16 acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
@@ -374,30 +380,42 @@ __device__ __forceinline__ void x3_split(float x0, float x1, uint32_t& hi, uint3
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{s0, s1}, bf2));
 }
 
-// [128 x 32] fp32 tile -> 3 bf16 parts in LDS; 8 threads per row (4 floats each), 32 rows per pass
-__device__ __forceinline__ void stage_x3(char* __restrict__ dst, const float* __restrict__ src, int64_t ld, int64_t row0, int64_t nrows, int k0,
-                                         int kmax, bool vec) {
+// [128 x 32] fp32 tile -> 3 bf16 parts in LDS; 8 threads per row (4 floats each), 32 rows per pass.  Two steps, so that the next
+// chunk's global loads are in flight while the current chunk is multiplied (register staging, guide T14): x3_load issues the
+// loads into 4 x float4, x3_store splits them and writes the LDS image after the barrier.
+__device__ __forceinline__ void x3_load(f32x4 (&v)[4], const float* __restrict__ src, int64_t ld, int64_t row0, int64_t nrows, int k0, int kmax,
+                                        bool vec) {
+    const int t = threadIdx.x, r = t >> 3, c = (t & 7) * 4;
+    if (vec && k0 + XK <= kmax) {
+        // whole chunk inside K and 16-byte aligned rows (uniform per chunk): four unconditional loads.  Rows past the end are
+        // clamped to the last row -- they only feed output rows / columns that are never stored.
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int64_t gr = row0 + r + p * 32;
+            v[p] = *reinterpret_cast<const f32x4*>(src + (gr < nrows ? gr : nrows - 1) * ld + k0 + c);
+        }
+        return;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int64_t gr = row0 + r + p * 32;
+        const float* g = src + (gr < nrows ? gr : nrows - 1) * ld;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + c + j;
+            const float val = g[k < kmax ? k : kmax - 1];
+            v[p][j] = k < kmax ? val : 0.f;
+        }
+    }
+}
+__device__ __forceinline__ void x3_store(char* __restrict__ dst, const f32x4 (&v)[4]) {
     const int t = threadIdx.x, r = t >> 3, c = (t & 7) * 4;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const int rr = r + p * 32;
-        const int64_t gr = row0 + rr;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (gr < nrows) {
-            const float* g = src + gr * ld + k0 + c;
-            if (vec && k0 + c + 3 < kmax) {
-                v = *reinterpret_cast<const f32x4*>(g);
-            } else {
-                if (k0 + c + 0 < kmax) v[0] = g[0];
-                if (k0 + c + 1 < kmax) v[1] = g[1];
-                if (k0 + c + 2 < kmax) v[2] = g[2];
-                if (k0 + c + 3 < kmax) v[3] = g[3];
-            }
-        }
         uint32_t h0, m0, l0, h1, m1, l1;
-        x3_split(v[0], v[1], h0, m0, l0);
-        x3_split(v[2], v[3], h1, m1, l1);
-        char* d = dst + rr * XLD + c * 2;
+        x3_split(v[p][0], v[p][1], h0, m0, l0);
+        x3_split(v[p][2], v[p][3], h1, m1, l1);
+        char* d = dst + (r + p * 32) * XLD + c * 2;
         *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(d + 64) = make_uint2(m0, m1);
         *reinterpret_cast<uint2*>(d + 128) = make_uint2(l0, l1);
@@ -414,8 +432,11 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_x3(const float* __restric
     __shared__ __attribute__((aligned(16))) char Ws[XN * XLD];
     const int lane = lane_id(), w = wave_id_uniform();
     const int wr = w >> 1, wc = w & 1, h = lane >> 5, l31 = lane & 31;
-    const int64_t row0 = (int64_t)blockIdx.x * XM;
-    const int col0 = blockIdx.y * XN;
+    // 1-D grid, column blocks fastest: the blocks that share a row panel of A run together and read it once from HBM (with the
+    // row blocks fastest every column block streamed all of A again: 4x the traffic at n_out = 512)
+    const int ncb = (n_out + XN - 1) / XN;
+    const int64_t row0 = (int64_t)(blockIdx.x / ncb) * XM;
+    const int col0 = (int)(blockIdx.x % ncb) * XN;
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -423,14 +444,21 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_x3(const float* __restric
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-    const int nch1 = (k1 + XK - 1) / XK, nch2 = A2 ? (k2 + XK - 1) / XK : 0;
-    for (int ch = 0; ch < nch1 + nch2; ++ch) {
+    const int nch1 = (k1 + XK - 1) / XK, nch2 = A2 ? (k2 + XK - 1) / XK : 0, nch = nch1 + nch2;
+    f32x4 ra[4], rw[4];
+    auto load_chunk = [&](int ch) {
         const bool first = ch < nch1;
         const int kk = first ? k1 : k2, k0 = (first ? ch : ch - nch1) * XK;
+        x3_load(ra, first ? A1 : A2, first ? lda1 : lda2, row0, M, k0, kk, first ? vec1 : vec2);
+        x3_load(rw, first ? W1 : W2, first ? ldw1 : ldw2, col0, n_out, k0, kk, first ? vec1 : vec2);
+    };
+    load_chunk(0);
+    for (int ch = 0; ch < nch; ++ch) {
+        __syncthreads();                 // the previous chunk's fragments have been read
+        x3_store(As, ra);
+        x3_store(Ws, rw);
         __syncthreads();
-        stage_x3(As, first ? A1 : A2, first ? lda1 : lda2, row0, M, k0, kk, first ? vec1 : vec2);
-        stage_x3(Ws, first ? W1 : W2, first ? ldw1 : ldw2, col0, n_out, k0, kk, first ? vec1 : vec2);
-        __syncthreads();
+        if (ch + 1 < nch) load_chunk(ch + 1);   // in flight under the 48 MFMAs below
         const char* ap = As + (wr * 64 + l31) * XLD + h * 16;
         const char* bp = Ws + (wc * 64 + l31) * XLD + h * 16;
 #pragma unroll
@@ -571,7 +599,7 @@ extern "C" int dgnn_linear_fwd(const float* A1, int64_t lda1, int k1, const floa
     DGNN_REQUIRE((scale == nullptr) == (shift == nullptr), DGNN_E_INVALID, "linear_fwd: scale/shift must come together");
     const bool v1 = vec_ok(A1, lda1) && vec_ok(W1, ldw1);
     const bool v2 = A2 && vec_ok(A2, lda2) && vec_ok(W2, ldw2);
-    dim3 grid((unsigned)dgnn_cdiv(M, BM), (unsigned)dgnn_cdiv(n_out, BN));
+    dim3 grid((unsigned)(dgnn_cdiv(M, BM) * dgnn_cdiv(n_out, BN)));
     hipLaunchKernelGGL(k_linear_fwd, grid, dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2, lda2, k2, W2,
                        ldw2, v2, bias, scale, shift, relu, M, n_out, out, ldo);
     return dgnn_check_launch("linear_fwd");
@@ -610,7 +638,7 @@ extern "C" int dgnn_linear_fwd_bf16(const uint16_t* A1, int64_t lda1, int k1, co
     DGNN_REQUIRE((scale == nullptr) == (shift == nullptr), DGNN_E_INVALID, "linear_fwd_bf16: scale/shift must come together");
     const bool va1 = vec16(A1, lda1, 2), vw1 = vec16(W1, ldw1, 4);
     const bool va2 = A2 && vec16(A2, lda2, 2), vw2 = W2 && vec16(W2, ldw2, 4);
-    dim3 grid((unsigned)dgnn_cdiv(M, BM), (unsigned)dgnn_cdiv(n_out, BN));
+    dim3 grid((unsigned)(dgnn_cdiv(M, BM) * dgnn_cdiv(n_out, BN)));
     if (out_f32)
         hipLaunchKernelGGL((k_linear_fwd_b<float>), grid, dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, va1, vw1, A2, lda2, k2, W2, ldw2,
                            va2, vw2, bias, scale, shift, relu, M, n_out, (float*)out, ldo);
@@ -652,7 +680,7 @@ extern "C" int dgnn_linear_fwd_x3(const float* A1, int64_t lda1, int k1, const f
     DGNN_REQUIRE((scale == nullptr) == (shift == nullptr), DGNN_E_INVALID, "linear_fwd_x3: scale/shift must come together");
     const bool v1 = vec_ok(A1, lda1) && vec_ok(W1, ldw1);
     const bool v2 = A2 && vec_ok(A2, lda2) && vec_ok(W2, ldw2);
-    dim3 grid((unsigned)dgnn_cdiv(M, XM), (unsigned)dgnn_cdiv(n_out, XN));
+    dim3 grid((unsigned)(dgnn_cdiv(M, XM) * dgnn_cdiv(n_out, XN)));
     hipLaunchKernelGGL(k_linear_fwd_x3, grid, dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2, lda2, k2, W2, ldw2, v2, bias,
                        scale, shift, relu, M, n_out, out, ldo);
     return dgnn_check_launch("linear_fwd_x3");
