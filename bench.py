@@ -47,6 +47,15 @@ def layer_bytes(c_in, c_out, elem=4):
     return elem * c_in + 320 + 16 + elem * c_out
 
 
+def layer_flops(c_in, c_out):
+    """algorithmic FLOPs per tet of one conv layer: lin_e on 4 edges, the 4-term product-sum, lin_j + lin_i."""
+    return 4 * 2 * 20 * c_in + 8 * c_in + 4 * c_in * c_out
+
+
+FP32_MATRIX_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA peak (= the fp32 vector peak)
+BF16_MATRIX_PEAK_TF = 2500.0  # dense bf16 MFMA peak
+
+
 def path_bytes(f_in, widths, elem=4):
     """whole path: conv layers + decoder (reads the last activations, writes 2 fp32 logits): 5048 B/tet for the shipped widths."""
     cs = [f_in] + list(widths)
@@ -112,6 +121,7 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="bf16: bf16 activation storage, single-product bf16 MFMA, fp32 accumulate")
     ap.add_argument("--cpu-points", type=int, default=30000, help="sample size of the single-thread CPU leg")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle legs (and with them the logit check)")
+    ap.add_argument("--no-breakdown", action="store_true", help="skip the per-layer replays (the roofline is then reported for the largest layer shape)")
     ap.add_argument("--cached-plan", action="store_true", help="reuse the graph plan across steps (reported, not the metric)")
     ap.add_argument("--gemm-mode", choices=["f32", "bf16x3", "bf16x3f"], default=None,
                     help="dense part of the fused fp32 layer: exact fp32 MFMA, or 3-way split-bf16 MFMA (fp32-class accuracy)")
@@ -223,7 +233,7 @@ def main():
         step()
     # ---- per-kernel breakdown (outside the timed region): replay each layer between events ----
     breakdown = {}
-    if world == 1:
+    if world == 1 and not args.no_breakdown:
         plan = GraphPlan(data.edge_index, n_local, n_local, hint=ops.PLAN_HINT_REFERENCE)
 
         def timed(fn, reps=10):
@@ -329,6 +339,17 @@ def main():
                 "timing": "HIP events around each layer's launches inside the timed steps (%d launches)" % len(evs),
                 "pmc": pmc or None,
                 "whole_path_frac": round(value * path_bytes(f_in, convs, elem) / 1e9 / HBM_PEAK_GBS / world, 4)}
+        if not fused and not bf16:
+            # a wide layer (aggregate + GEMM pair): 4*C_in*C_out FLOPs per tet against ~4*(C_in+C_out) bytes -- the matrix cores
+            # bound it, not HBM.  fp32 arithmetic: priced against the fp32 matrix peak; it executes as 6 bf16 products per
+            # fp32 product (exact 3-way split), i.e. 6x that rate on the bf16 pipe.
+            fl = layer_flops(dom[0], dom[1]) * rows / (n_layers_dom * args.steps)
+            tf = fl / (dom_ms * 1e-3) / 1e12
+            x3 = ops.GEMM_MODE != ops.GEMM_F32
+            roof.update({"bound": "mfma", "achieved": round(tf, 1), "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / FP32_MATRIX_PEAK_TF, 4),
+                         "algorithmic_flops_per_launch": int(fl), "hbm_frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "note": ("fp32-class arithmetic executed as 6 bf16 MFMA products per fp32 product: %.0f TFLOP/s on the bf16 pipe = %.3f of its %.0f TFLOP/s dense peak"
+                                  % (6 * tf, 6 * tf / BF16_MATRIX_PEAK_TF, BF16_MATRIX_PEAK_TF)) if x3 else "bit-faithful fp32 MFMA (v_mfma_f32_32x32x2_f32)"})
 
     # ---- CPU baseline (the oracle on the host cores) + self-check of the GPU logits against it ----
     cpu, check, failed = None, None, False

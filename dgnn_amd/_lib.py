@@ -95,9 +95,18 @@ def lib():
     return _lib
 
 
-def check(code: int, what: str = ""):
-    if code == 0:
-        code = lib().dgnn_poll_async_error()  # an earlier kernel met an out-of-range index (a host memory read, no sync)
+_calls = 0
+
+
+def check(code: int, what: str = "", poll: bool = False):
+    """Raises DgnnError for a non-zero status.  Asynchronous kernel errors (an edge_index entry out of range, see
+    dgnn_poll_async_error in the header) are polled -- a host memory read, no sync -- at the entry points that consume index
+    data (`poll=True`: plan and block builders) and at every 16th call of any entry point, so they surface within a few
+    launches without a second library call per launch."""
+    global _calls
+    _calls += 1
+    if code == 0 and (poll or (_calls & 15) == 0):
+        code = lib().dgnn_poll_async_error()
         if code != 0:
             what = "an earlier dgnn kernel (reported at %s)" % (what or "this call")
     if code != 0:

@@ -70,7 +70,7 @@ def plan_build(edge_index: torch.Tensor, n_key: int, by: int, hint: int = PLAN_H
     eid = torch.empty(max(E, 1), dtype=torch.int32, device=dev)[:E]
     scratch = torch.empty(int(lib().dgnn_plan_scratch_elems(E, n_key)), dtype=torch.int32, device=dev)
     check(lib().dgnn_plan_build(ptr(edge_index), edge_index.stride(0), edge_index.stride(1), E, n_key, int(n_other), by, hint, ptr(rowptr), ptr(other), ptr(eid), ptr(scratch), stream_ptr()),
-          "dgnn_plan_build")
+          "dgnn_plan_build", poll=True)
     return rowptr, other, eid
 
 
