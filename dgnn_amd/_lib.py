@@ -71,6 +71,11 @@ SIGNATURES = {
     "dgnn_relu_bwd_bf16": (i32, [vp, vp, i64, vp, vp]),
     "dgnn_sage_layer_fused_fwd": (i32, [vp, vp, vp, i64, vp, vp, i64, i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp,
                                         i64, i32, vp]),
+    "dgnn_sage_layer_train_scratch_elems": (i64, [i64, i64, i32, i32, i32]),
+    "dgnn_sage_layer_train_fwd": (i32, [vp, vp, vp, i64, vp, i64, i32, vp, i64, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, f32, f32, i32,
+                                        vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "dgnn_sage_layer_train_bwd": (i32, [vp, vp, vp, vp, i64, i64, vp, i64, i32, vp, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, f32, i32,
+                                        vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
 }
 
 _lib = None

@@ -104,7 +104,8 @@ __global__ void __launch_bounds__(256) k_linear_fwd(const float* __restrict__ A1
             if (row >= M) continue;
             float v = (half ? acc1[r] : acc0[r]) + bb;
             if (scale) v = __fmaf_rn(v, sc, sh);
-            if (relu) v = fmaxf(v, 0.f);
+            if (relu & 1) v = fmaxf(v, 0.f);
+            if (relu & DGNN_LINEAR_ACCUMULATE) v += out[row * ldo + col];
             out[row * ldo + col] = v;
         }
     }
@@ -297,7 +298,8 @@ __global__ void __launch_bounds__(256) k_linear_fwd_b(const uint16_t* __restrict
             if (row >= M) continue;
             float v = (half ? acc1[r] : acc0[r]) + bb;
             if (scale) v = __fmaf_rn(v, sc, sh);
-            if (relu) v = fmaxf(v, 0.f);
+            if (relu & 1) v = fmaxf(v, 0.f);
+            if (relu & DGNN_LINEAR_ACCUMULATE) v += dgnn_ld(out + row * ldo + col);
             dgnn_st(out + row * ldo + col, v);
         }
     }
@@ -501,7 +503,8 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_x3(const float* __restric
                 if (row >= M) continue;
                 float v = acc[a][b][r] + bb;
                 if (scale) v = __fmaf_rn(v, sc, sh);
-                if (relu) v = fmaxf(v, 0.f);
+                if (relu & 1) v = fmaxf(v, 0.f);
+                if (relu & DGNN_LINEAR_ACCUMULATE) v += out[row * ldo + col];
                 out[row * ldo + col] = v;
             }
     }

@@ -125,6 +125,56 @@ class _BatchNormAct(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
+class _SageTrainLayer(torch.autograd.Function):
+    """y = relu(BatchNorm_train(lin_j(mean_j x_j * lin_e(e_ji)) + lin_i(x[:n_dst])))  -- conv + norm + ReLU of one training-mode
+    layer (reference :214-219) as one library call forward and one backward (csrc/train.hip issues the same kernels as the
+    Functions above, in the same order: bit-identical results, a fraction of the host time).  plan None: the decoder's
+    Linear + BatchNorm + ReLU block (:180-186)."""
+
+    @staticmethod
+    def forward(ctx, x, edge_attr, We, be, Wj, bj, Wi, gamma, beta, bn, plan, relu):
+        n_dst = plan.n_dst if plan is not None else x.size(0)
+        parts = (plan.rowptr, plan.src, plan.eid) if plan is not None else None
+        y, a, z, stats = ops.sage_layer_train_fwd(parts, n_dst, x, edge_attr, We, be, Wj, bj, Wi, gamma, beta, bn.running_mean, bn.running_var,
+                                                  bn.momentum if bn.momentum is not None else 0.1, bn.eps, relu)
+        ctx.plan = plan
+        ctx.edge_index = plan.edge_index if plan is not None else None   # the lazily built transposed plan (backward) reads it
+        ctx.cfg = (float(bn.eps), bool(relu), bj is not None)
+        ctx.save_for_backward(x, edge_attr, We, be, Wj, Wi, gamma, a, z, y, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, edge_attr, We, be, Wj, Wi, gamma, a, z, y, stats = ctx.saved_tensors
+        eps, relu, has_bias = ctx.cfg
+        plan = ctx.plan
+        t_parts = rowptr = None
+        n_src = n_dst = x.size(0)
+        if plan is not None:
+            t_parts, rowptr, n_src, n_dst = plan.transposed, plan.rowptr, plan.n_src, plan.n_dst
+        dx, dWe, dbe, dWj, dbj, dWi, dgamma, dbeta = ops.sage_layer_train_bwd(
+            t_parts, rowptr, n_src, n_dst, x, edge_attr, We, be, Wj, Wi, has_bias, gamma, stats, eps, relu, a, z, y, dy.contiguous(),
+            ctx.needs_input_grad[0])
+        return dx, None, dWe, dbe, dWj, dbj, dWi, dgamma, dbeta, None, None, None
+
+
+def sage_train_layer(x, plan, edge_attr, lin_e, lin_j, lin_i, bn: torch.nn.BatchNorm1d, relu: bool = True):
+    """One training-mode layer through the composite entry points; callers check `sage_train_layer_supported` first."""
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    We, be = (lin_e.weight, lin_e.bias) if lin_e is not None else (None, None)
+    return _SageTrainLayer.apply(x, edge_attr if lin_e is not None else None, We, be, lin_j.weight, lin_j.bias,
+                                 lin_i.weight if lin_i is not None else None, bn.weight, bn.bias, bn, plan, relu)
+
+
+def sage_train_layer_supported(x, lin_e, bn) -> bool:
+    """fp32 activations with unit column stride, lin_e a single Linear over <= 32 attributes (or None), BatchNorm in training mode
+    with affine parameters and running buffers; everything else runs through the separate Functions."""
+    return (ops.TRAIN_COMPOSITE and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.size(0) > 0
+            and (lin_e is None or (isinstance(lin_e, torch.nn.Linear) and lin_e.in_features <= 32 and lin_e.bias is not None))
+            and isinstance(bn, torch.nn.BatchNorm1d) and bn.training and bn.affine and bn.running_mean is not None)
+
+
 def aggregate(x_src, plan, edge_attr=None, We=None, be=None, phi=None):
     if We is not None:
         return _Aggregate.apply(x_src, edge_attr, We, be, plan)

@@ -24,36 +24,58 @@ import torch.nn.functional as F
 
 
 class Metrics:
-    """Running sums, reference :48-80."""
+    """Running sums, reference :48-80.  The reference reads every item back to the host as it is added (`.item()`, three
+    device round trips per training step); here tensor items are added ON THEIR DEVICE into fp64 / int64 accumulators -- the
+    same double-precision sums -- and come back to the host only when a sum is read (the print / validation cadence), so the
+    training step enqueues without draining the GPU."""
+
+    _FIELDS = ("samples_sum", "OA_sum", "cell_sum", "weight_sum", "reg_sum", "edges_sum")
 
     def __init__(self):
-        self.samples_sum = 0
-        self.OA_sum = 0
-        self.cell_sum = 0
-        self.weight_sum = 0
-        self.reg_sum = 0
-        self.edges_sum = 0
+        self._host = dict.fromkeys(self._FIELDS, 0)
+        self._dev = {}
+
+    def _add(self, name, v):
+        if isinstance(v, torch.Tensor) and v.is_cuda:
+            v = v.detach().reshape(())
+            acc = self._dev.get(name)
+            if acc is None or acc.device != v.device:
+                if acc is not None:
+                    self._host[name] += acc.item()
+                self._dev[name] = v.to(torch.float64 if v.is_floating_point() else torch.int64, copy=True)
+            else:
+                acc.add_(v)
+        else:
+            self._host[name] += v.item() if isinstance(v, torch.Tensor) else v
+
+    def __getattr__(self, name):
+        if name in Metrics._FIELDS:
+            acc = self.__dict__.get("_dev", {}).get(name)
+            return self._host[name] + (acc.item() if acc is not None else 0)
+        raise AttributeError(name)
 
     def addOAItem(self, oa, samples):
-        self.OA_sum += oa
-        self.samples_sum += samples
+        self._add("OA_sum", oa)
+        self._add("samples_sum", samples)
 
     def addCellLossItem(self, cell_loss, weight):
-        self.cell_sum += float(cell_loss)
-        self.weight_sum += float(weight)
+        self._add("cell_sum", cell_loss)
+        self._add("weight_sum", weight)
 
     def addRegLossItem(self, reg_loss, edges):
-        self.reg_sum += float(reg_loss)
-        self.edges_sum += edges
+        self._add("reg_sum", reg_loss)
+        self._add("edges_sum", edges)
 
     def getOA(self):
         return self.OA_sum * 100 / max(self.samples_sum, 1)
 
     def getCellLoss(self):
-        return self.cell_sum / self.weight_sum if self.weight_sum else 0.0
+        w = self.weight_sum
+        return self.cell_sum / w if w else 0.0
 
     def getRegLoss(self):
-        return self.reg_sum / self.edges_sum if self.edges_sum else 0.0
+        e = self.edges_sum
+        return self.reg_sum / e if e else 0.0
 
 
 def adjust_learning_rate(optimizer, clf):
@@ -94,10 +116,10 @@ class Trainer:
         if clf.training.loss == "kl":
             cell_loss = F.kl_div(F.log_softmax(logits_cell, dim=-1), gt[:, :2], reduction='none').sum(dim=1)
             pred = logits_cell.argmax(1)
-            metrics.addOAItem(int(((gt[:, 0] > gt[:, 1]).long() == pred).sum()), data.batch_x.shape[0])
+            metrics.addOAItem(((gt[:, 0] > gt[:, 1]).long() == pred).sum(), data.batch_x.shape[0])
         elif clf.training.loss == "bce":
             cell_loss = F.binary_cross_entropy_with_logits(logits_cell.squeeze(-1), gt[:, 3], reduction='none')
-            metrics.addOAItem(int((gt[:, 3] == torch.round(torch.sigmoid(logits_cell.squeeze(-1)))).sum()), data.batch_x.shape[0])
+            metrics.addOAItem((gt[:, 3] == torch.round(torch.sigmoid(logits_cell.squeeze(-1)))).sum(), data.batch_x.shape[0])
         elif clf.training.loss == "mse":
             cell_loss = F.mse_loss(torch.sigmoid(logits_cell).squeeze(), gt[:, 0])
         else:
@@ -111,8 +133,9 @@ class Trainer:
         else:
             w = vol
         cell_loss = cell_loss * w
-        metrics.addCellLossItem(cell_loss.sum().item(), w.sum().item())
-        loss = cell_loss.sum() / w.sum()
+        cell_sum, w_sum = cell_loss.sum(), w.sum()
+        metrics.addCellLossItem(cell_sum, w_sum)
+        loss = cell_sum / w_sum
         if clf.regularization.edge_epoch is not None:
             if clf.graph.additional_num_hops != 1:
                 print("ERROR: clf.graph.additional_num_hops has to be >= 1 to use regularization")

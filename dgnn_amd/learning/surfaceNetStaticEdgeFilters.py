@@ -187,8 +187,11 @@ class SurfaceNet(nn.Module):
             return x
         if len(dec) == 1:
             return Fn.linear2(x, dec[0].weight, bias=dec[0].bias, out_f32=True)
-        h = Fn.linear2(x, dec[0].weight, bias=dec[0].bias)
-        h = dec[1](h, relu=True) if dec[1] is not None else Fn.relu(h)
+        if isinstance(dec[1], BatchNorm) and Fn.sage_train_layer_supported(x, None, dec[1].module):
+            h = Fn.sage_train_layer(x, None, None, None, dec[0], None, dec[1].module)
+        else:
+            h = Fn.linear2(x, dec[0].weight, bias=dec[0].bias)
+            h = dec[1](h, relu=True) if dec[1] is not None else Fn.relu(h)
         return Fn.linear2(h, dec[3].weight, bias=dec[3].bias, out_f32=True)   # logits stay fp32 in the bf16 storage path too
 
     # ---- TRAIN FORWARD (reference :196-227) ---------------------------------------------------
@@ -203,7 +206,12 @@ class SurfaceNet(nn.Module):
             edge_index, e_id, size = data.batch_adjs[i]
             ea = _dev_f32(data.all.edge_attr[e_id.to(data.all.edge_attr.device)], dev)
             edge_index = edge_index.to(dev)
-            x = self.convs[i][0]((x, x[:size[1]]), ea, edge_index)
+            conv, norm = self.convs[i][0], self.convs[i][1] if len(self.convs[i]) > 1 else None
+            if isinstance(norm, BatchNorm) and Fn.sage_train_layer_supported(x, conv.lin_e, norm.module):
+                # conv + norm + ReLU as one library call forward, one backward
+                x = Fn.sage_train_layer(x, plan_for(edge_index, x.size(0), size[1]), ea, conv.lin_e, conv.lin_j, conv.lin_i, norm.module)
+                continue
+            x = conv((x, x[:size[1]]), ea, edge_index)
             x = self._norm_act(self.convs[i], x)
         if self.clf.model.decoder:
             x = self._decode(x)

@@ -37,7 +37,7 @@ class EdgeIndex(tuple):
 
 class NeighborSampler:
     def __init__(self, edge_index, sizes, node_idx=None, num_nodes=None, batch_size=1, shuffle=False, drop_last=False,
-                 return_e_id=True, plan: GraphPlan = None, generator=None, **kwargs):
+                 return_e_id=True, plan: GraphPlan = None, generator=None, prefetch=True, **kwargs):
         if any(int(s) != -1 for s in sizes):
             raise NotImplementedError("only full neighbourhoods (size -1) are used by the reference (clique_sizes: [-1])")
         if not edge_index.is_cuda:
@@ -54,6 +54,12 @@ class NeighborSampler:
         self.node_idx = node_idx.to(self.device, torch.int64)
         self.batch_size, self.shuffle, self.drop_last, self.return_e_id = int(batch_size), shuffle, drop_last, return_e_id
         self.generator = generator
+        # iteration builds block k+1 on a side stream while the caller's stream still runs step k-1 / k (the reference's
+        # NeighborSampler is a DataLoader: its workers prefetch batches the same way); the builder's host round trips then
+        # wait for the side stream only, not for the training step's kernels
+        self.prefetch = bool(prefetch)
+        self._side = None
+        self._escaped = None
         self._pos = torch.full((n,), -1, dtype=torch.int32, device=self.device)
         self._first = torch.full((n,), _I32_MAX, dtype=torch.int32, device=self.device)
         self._iota = torch.arange(0, dtype=torch.int32, device=self.device)
@@ -75,11 +81,39 @@ class NeighborSampler:
         idx = self.node_idx
         if self.shuffle:
             idx = idx[torch.randperm(idx.numel(), device=self.device, generator=self.generator)]
-        for s in range(0, idx.numel(), self.batch_size):
-            b = idx[s:s + self.batch_size]
-            if self.drop_last and b.numel() < self.batch_size:
-                break
-            yield self.sample(b)
+        starts = [s for s in range(0, idx.numel(), self.batch_size)
+                  if not (self.drop_last and idx.numel() - s < self.batch_size)]
+        if not self.prefetch:
+            for s in starts:
+                yield self.sample(idx[s:s + self.batch_size])
+            return
+        with torch.cuda.device(self.device):
+            if self._side is None:
+                self._side = torch.cuda.Stream(self.device)
+            side = self._side
+            side.wait_stream(torch.cuda.current_stream())   # idx (and the builder state) were produced on the caller's stream
+        pending = None
+        for s in starts:
+            with torch.cuda.device(self.device), torch.cuda.stream(side):
+                self._escaped = []
+                out = self._sample(idx[s:s + self.batch_size])
+                nxt = (out, self._escaped, side.record_event())
+                self._escaped = None
+            if pending is not None:
+                yield self._hand_over(pending)
+            pending = nxt
+        if pending is not None:
+            yield self._hand_over(pending)
+
+    def _hand_over(self, pending):
+        """makes a block built on the side stream usable on the caller's current stream"""
+        out, tensors, ev = pending
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            for t in tensors:
+                t.record_stream(cur)   # the allocator must not recycle them for the next block while this stream reads them
+        return out
 
     def sample(self, batch: torch.Tensor):
         with torch.cuda.device(self.device):  # the plan's GPU, whatever the thread's current device is
@@ -110,7 +144,10 @@ class NeighborSampler:
             check(L.dgnn_khop_commit(ptr(n_id_out), n_t, n_all, ptr(self._pos), ptr(self._first), st), "dgnn_khop_commit")
             n_id = n_id_out[:n_all]
             # the block is emitted grouped by destination with `off` as its row offsets: that IS its plan (identity order)
-            register_plan(ei, GraphPlan(ei, n_all, n_t, parts=(off, e_src.to(torch.int32), self._arange(n_e))))
+            src32 = e_src.to(torch.int32)
+            register_plan(ei, GraphPlan(ei, n_all, n_t, parts=(off, src32, self._arange(n_e))))
+            if self._escaped is not None:
+                self._escaped += [ei, e_id, off, src32, self._iota, n_id_out]
             adjs.append(EdgeIndex(ei, e_id if self.return_e_id else None, (n_all, n_t)))
         check(L.dgnn_khop_reset(ptr(n_id), n_id.numel(), ptr(self._pos), st), "dgnn_khop_reset")
         adjs = adjs[0] if len(adjs) == 1 else adjs[::-1]

@@ -115,8 +115,10 @@ int dgnn_sage_aggregate_fwd(const int32_t* rowptr, const int32_t* src, const int
  * surfaceNetUpdatedEdgeFilters.py:159-165), eval-mode BatchNorm folded to scale/shift (:218) and
  * ReLU (:219); also the decoder Linears (:180-187) and lin_e of the Updated variant when its input
  * is wide.  W1 [n_out,K1], W2 [n_out,K2] are torch.nn.Linear weights (row-major).  A2/W2, bias,
- * scale/shift may be NULL.  relu != 0 applies max(0,.).  fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * scale/shift may be NULL.  `relu`: bit 0 applies max(0,.); bit 1 (DGNN_LINEAR_ACCUMULATE) adds the result to what `out`
+ * holds (dx_dst += G . Wi in the backward pass).  fp32 MFMA (v_mfma_f32_32x32x2_f32).
  * ---------------------------------------------------------------------------------------------- */
+#define DGNN_LINEAR_ACCUMULATE 2
 int dgnn_linear_fwd(const float* A1, int64_t lda1, int k1, const float* W1, int64_t ldw1, const float* A2,
                     int64_t lda2, int k2, const float* W2, int64_t ldw2, const float* bias, const float* scale,
                     const float* shift, int relu, int64_t M, int n_out, float* out, int64_t ldo, void* stream);
@@ -202,6 +204,29 @@ int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* src, const i
                               const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
                               const float* scale, const float* shift, int relu, int c_out, float* out, int64_t ldo,
                               int gemm_mode, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Training-mode conv layer, one call each way (SurfaceNet.forward :214-219 and its autograd, learning/runModel.py:279):
+ *   forward : a = aggregate(x)  ->  z = a.Wj^T + x[:n_dst].Wi^T + bj  ->  BatchNorm1d with batch statistics (running buffers
+ *             updated when given)  ->  y = relu(.)       rowptr == NULL: a plain Linear + BatchNorm (+ReLU) block, z = x.Wj^T + bj
+ *   backward: dy -> dx (NULL: x is data), dWe, dbe, dWj, dbj (NULL: no bias), dWi, dgamma, dbeta
+ * Both issue the launch chain of the separate entry points above, in the same order, on `stream` (results are bit-identical
+ * to calling them one by one); nothing allocates or synchronises.  Buffers: a [n_dst,c_in], z / y [n_dst,c_out], mean / var /
+ * scale / shift [c_out]; forward scratch = dgnn_colstats_scratch_elems(n_dst, c_out) floats, backward scratch =
+ * dgnn_sage_layer_train_scratch_elems floats.  Transposed plan (t_*) and rowptr_dst as dgnn_sage_aggregate_bwd.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t dgnn_sage_layer_train_scratch_elems(int64_t n_src, int64_t n_dst, int c_in, int c_out, int f_e);
+int dgnn_sage_layer_train_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x, int64_t ldx,
+                              int c_in, const float* edge_attr, int64_t lde, int f_e, const float* We, const float* be, const float* Wj,
+                              const float* bj, const float* Wi, int c_out, const float* gamma, const float* beta, float* running_mean,
+                              float* running_var, float momentum, float eps, int relu, float* a, float* z, float* mean, float* var,
+                              float* scale, float* shift, float* y, float* scratch, int gemm_mode, void* stream);
+int dgnn_sage_layer_train_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, const int32_t* rowptr_dst,
+                              int64_t n_src, int64_t n_dst, const float* x, int64_t ldx, int c_in, const float* edge_attr, int64_t lde,
+                              int f_e, const float* We, const float* be, const float* Wj, const float* Wi, int c_out, const float* gamma,
+                              const float* mean, const float* var, float eps, int relu, const float* a, const float* z, const float* y,
+                              const float* dy, float* dx, float* dWe, float* dbe, float* dWj, float* dbj, float* dWi, float* dgamma,
+                              float* dbeta, float* scratch, int gemm_mode, void* stream);
 
 /* Fused decoder, eval mode (reference :180-187 applied at :350-351):
  *   logits = W3 . relu((W0 . y + b0) * scale + shift) + b3,   y [M,k] -> out [M,n_out]

@@ -186,3 +186,42 @@ def test_generate_signature_labels_and_interface(tmp_path):
     # same result with the prediction already on the device
     mesh2, _ = generate(data, prediction.to(DEV), clf)
     assert np.array_equal(np.asarray(mesh2.faces), np.asarray(mesh.faces))
+
+
+def test_composite_train_layer_is_bit_identical_to_the_separate_calls(monkeypatch):
+    """dgnn_sage_layer_train_fwd / _bwd (one library call per layer each way) issue the kernels of the separate entry points in
+    the same order: logits, every gradient and every BatchNorm buffer must match bit for bit."""
+    from dgnn_amd import ops
+    from dgnn_amd.sampler import NeighborSampler
+    from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal
+    from test_gpu_parity import gold, f3_data
+    g = gold("static_f3_train_blocks.npz")
+    d = f3_data(g)
+    data = Config(all=Config(x=d.all.x.to(DEV), edge_attr=d.all.edge_attr.to(DEV)), batch_n_id=d.batch_n_id.to(DEV),
+                  batch_adjs=[(a.to(DEV), e.to(DEV), s) for a, e, s in d.batch_adjs])
+    G = torch.from_numpy(g["G"]).to(DEV)
+
+    def run(composite, data, G):
+        monkeypatch.setattr(ops, "TRAIN_COMPOSITE", composite)
+        net = hip_static(train=True)
+        logits = net(data)
+        (logits * G).sum().backward()
+        return logits.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()}, {k: b.clone() for k, b in net.named_buffers()}
+
+    for case in range(2):
+        if case == 1:   # a 4-hop block of the GPU block builder on a larger scene (sampler-made plans, ragged last tiles)
+            adj, _, _ = delaunay_tet_graph(3000, seed=4)
+            n = adj.shape[0] // 4
+            ei = torch.from_numpy(adj.T.astype(np.int64)).to(DEV)
+            x = hashed_normal(np.arange(n), 29, seed=5, device=DEV)
+            ea = hashed_normal(np.arange(4 * n), 20, seed=6, device=DEV)
+            _, n_id, adjs = NeighborSampler(ei, sizes=[-1] * 4, num_nodes=n, batch_size=257).sample(torch.arange(100, 357, device=DEV))
+            data = Config(all=Config(x=x, edge_attr=ea), batch_n_id=n_id, batch_adjs=adjs)
+            G = hashed_normal(np.arange(257), 2, seed=7, device=DEV)
+        la, ga, ba = run(True, data, G)
+        lb, gb, bb = run(False, data, G)
+        assert torch.equal(la, lb)
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), (case, k, (ga[k] - gb[k]).abs().max().item())
+        for k in ba:
+            assert torch.equal(ba[k], bb[k]), (case, k)
