@@ -53,6 +53,9 @@ SIGNATURES = {
     "dgnn_khop_expand": (i32, [vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dgnn_khop_commit": (i32, [vp, i64, i64, vp, vp, vp]),
     "dgnn_khop_reset": (i32, [vp, i64, vp, vp]),
+    "dgnn_khop_blocks_regular": (i32, [vp, vp, vp, i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dgnn_khop_blocks_regular_start": (vp, [vp, vp, vp, i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dgnn_khop_blocks_regular_wait": (i32, [vp, i32, vp]),
     "dgnn_decoder_fused_fwd": (i32, [vp, i64, i64, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, i64, vp]),
     "dgnn_cast_f32_to_bf16": (i32, [vp, i64, i64, i32, i32, vp, i64, vp]),
     "dgnn_cast_bf16_to_f32": (i32, [vp, i64, i64, i32, vp, i64, vp]),
@@ -71,6 +74,13 @@ SIGNATURES = {
     "dgnn_relu_bwd_bf16": (i32, [vp, vp, i64, vp, vp]),
     "dgnn_sage_layer_fused_fwd": (i32, [vp, vp, vp, i64, vp, vp, i64, i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp,
                                         i64, i32, vp]),
+    "dgnn_edge_chain_fwd": (i32, [vp, i64, i32, vp, i64, vp, i64, i64, vp, i32, vp, i64, vp, vp]),
+    "dgnn_edge_chain_fwd_bf16": (i32, [vp, i64, i32, vp, i64, vp, i64, i64, vp, i32, vp, i64, vp, vp]),
+    "dgnn_edge_chain_bwd": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i64, vp]),
+    "dgnn_edge_chain_bwd_bf16": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i64, vp]),
+    "dgnn_kl_cell_loss_scratch_doubles": (i64, [i64]),
+    "dgnn_kl_cell_loss_fwd": (i32, [vp, i64, vp, i64, vp, i64, i32, i64, vp, vp, vp, vp]),
+    "dgnn_kl_cell_loss_bwd": (i32, [vp, i64, vp, i64, vp, i64, i32, i64, vp, vp, vp, i64, vp]),
     "dgnn_sage_layer_train_scratch_elems": (i64, [i64, i64, i32, i32, i32]),
     "dgnn_sage_layer_train_fwd": (i32, [vp, vp, vp, i64, vp, i64, i32, vp, i64, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, f32, f32, i32,
                                         vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),

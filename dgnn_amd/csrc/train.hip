@@ -118,8 +118,12 @@ extern "C" int dgnn_sage_layer_train_bwd(const int32_t* t_rowptr, const int32_t*
     if (agg) {
         if (We) {
             DGNN_REQUIRE(dWe && dbe, DGNN_E_INVALID, "sage_layer_train_bwd: dWe / dbe missing");
-            (void)hipMemsetAsync(dWe, 0, sizeof(float) * (size_t)c_in * f_e, stream);
-            (void)hipMemsetAsync(dbe, 0, sizeof(float) * (size_t)c_in, stream);
+            if (dbe == dWe + (size_t)c_in * f_e) {   // one buffer (the Python binding's layout): one fill
+                (void)hipMemsetAsync(dWe, 0, sizeof(float) * (size_t)c_in * (f_e + 1), stream);
+            } else {
+                (void)hipMemsetAsync(dWe, 0, sizeof(float) * (size_t)c_in * f_e, stream);
+                (void)hipMemsetAsync(dbe, 0, sizeof(float) * (size_t)c_in, stream);
+            }
         }
         if (need_da)
             TRY(dgnn_sage_aggregate_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x, ldx, c_in, edge_attr, lde, f_e, We, be, nullptr, 0, da, c_in, dx,

@@ -132,39 +132,44 @@ class _SageTrainLayer(torch.autograd.Function):
     Linear + BatchNorm + ReLU block (:180-186)."""
 
     @staticmethod
-    def forward(ctx, x, edge_attr, We, be, Wj, bj, Wi, gamma, beta, bn, plan, relu):
+    def forward(ctx, x, edge_attr, We, be, Wj, bj, Wi, gamma, beta, bn, plan, relu, scene_rows):
         n_dst = plan.n_dst if plan is not None else x.size(0)
-        parts = (plan.rowptr, plan.src, plan.eid) if plan is not None else None
+        # scene_rows: `edge_attr` is the SCENE's tensor and plan.edge_rows (the block's e_id) selects its rows inside the kernels
+        # -- the values of edge_attr[e_id] without the per-layer copy
+        parts = (plan.rowptr, plan.src, plan.edge_rows if scene_rows else plan.eid) if plan is not None else None
         y, a, z, stats = ops.sage_layer_train_fwd(parts, n_dst, x, edge_attr, We, be, Wj, bj, Wi, gamma, beta, bn.running_mean, bn.running_var,
                                                   bn.momentum if bn.momentum is not None else 0.1, bn.eps, relu)
         ctx.plan = plan
         ctx.edge_index = plan.edge_index if plan is not None else None   # the lazily built transposed plan (backward) reads it
-        ctx.cfg = (float(bn.eps), bool(relu), bj is not None)
+        ctx.cfg = (float(bn.eps), bool(relu), bj is not None, bool(scene_rows))
         ctx.save_for_backward(x, edge_attr, We, be, Wj, Wi, gamma, a, z, y, stats)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, edge_attr, We, be, Wj, Wi, gamma, a, z, y, stats = ctx.saved_tensors
-        eps, relu, has_bias = ctx.cfg
+        eps, relu, has_bias, scene_rows = ctx.cfg
         plan = ctx.plan
         t_parts = rowptr = None
         n_src = n_dst = x.size(0)
         if plan is not None:
             t_parts, rowptr, n_src, n_dst = plan.transposed, plan.rowptr, plan.n_src, plan.n_dst
+            if scene_rows:
+                t_parts = (t_parts[0], t_parts[1], plan.transposed_edge_rows)
         dx, dWe, dbe, dWj, dbj, dWi, dgamma, dbeta = ops.sage_layer_train_bwd(
             t_parts, rowptr, n_src, n_dst, x, edge_attr, We, be, Wj, Wi, has_bias, gamma, stats, eps, relu, a, z, y, dy.contiguous(),
             ctx.needs_input_grad[0])
-        return dx, None, dWe, dbe, dWj, dbj, dWi, dgamma, dbeta, None, None, None
+        return dx, None, dWe, dbe, dWj, dbj, dWi, dgamma, dbeta, None, None, None, None
 
 
-def sage_train_layer(x, plan, edge_attr, lin_e, lin_j, lin_i, bn: torch.nn.BatchNorm1d, relu: bool = True):
-    """One training-mode layer through the composite entry points; callers check `sage_train_layer_supported` first."""
+def sage_train_layer(x, plan, edge_attr, lin_e, lin_j, lin_i, bn: torch.nn.BatchNorm1d, relu: bool = True, scene_rows: bool = False):
+    """One training-mode layer through the composite entry points; callers check `sage_train_layer_supported` first.
+    `scene_rows`: edge_attr is the scene's [E_all, F] tensor, read through plan.edge_rows (see GraphPlan.edge_rows)."""
     if bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     We, be = (lin_e.weight, lin_e.bias) if lin_e is not None else (None, None)
     return _SageTrainLayer.apply(x, edge_attr if lin_e is not None else None, We, be, lin_j.weight, lin_j.bias,
-                                 lin_i.weight if lin_i is not None else None, bn.weight, bn.bias, bn, plan, relu)
+                                 lin_i.weight if lin_i is not None else None, bn.weight, bn.bias, bn, plan, relu, scene_rows)
 
 
 def sage_train_layer_supported(x, lin_e, bn) -> bool:
@@ -173,6 +178,27 @@ def sage_train_layer_supported(x, lin_e, bn) -> bool:
     return (ops.TRAIN_COMPOSITE and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.size(0) > 0
             and (lin_e is None or (isinstance(lin_e, torch.nn.Linear) and lin_e.in_features <= 32 and lin_e.bias is not None))
             and isinstance(bn, torch.nn.BatchNorm1d) and bn.training and bn.affine and bn.running_mean is not None)
+
+
+class _KLCellLoss(torch.autograd.Function):
+    """volume-weighted KL cell loss (reference learning/runModel.py:171-209) -> (loss, sums[3] = sum cell*w, sum w, OA count)"""
+
+    @staticmethod
+    def forward(ctx, logits, gt, vol, norm):
+        loss, sums = ops.kl_cell_loss_fwd(logits, gt, vol, norm)
+        ctx.save_for_backward(logits, gt, vol, sums)
+        ctx.norm = norm
+        ctx.mark_non_differentiable(sums)
+        return loss, sums
+
+    @staticmethod
+    def backward(ctx, g, _):
+        logits, gt, vol, sums = ctx.saved_tensors
+        return ops.kl_cell_loss_bwd(logits, gt, vol, ctx.norm, sums, g), None, None, None
+
+
+def kl_cell_loss(logits, gt, vol, cell_norm=None):
+    return _KLCellLoss.apply(logits, gt, vol, ops.CELL_NORMS.get(cell_norm, 0))
 
 
 def aggregate(x_src, plan, edge_attr=None, We=None, be=None, phi=None):
@@ -228,19 +254,42 @@ def relu(x):
 
 
 class _GatherRows(torch.autograd.Function):
-    """out = src[idx]  (rows; idx unique)"""
+    """out = src[idx, :cols]  (rows; idx unique)"""
 
     @staticmethod
-    def forward(ctx, src, idx):
+    def forward(ctx, src, idx, cols):
         ctx.save_for_backward(idx)
-        ctx.n = src.size(0)
-        return ops.gather_rows(src, idx.to(torch.int32))
+        ctx.shape = (src.size(0), src.size(1))
+        return ops.gather_rows(src, idx.to(torch.int32), cols)
 
     @staticmethod
     def backward(ctx, g):
         (idx,) = ctx.saved_tensors
-        out = torch.zeros((ctx.n, g.size(1)), dtype=g.dtype, device=g.device)
-        return ops.scatter_rows_(out, idx, g.contiguous()), None
+        out = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
+        ops.scatter_rows_(out[:, :g.size(1)], idx, g.contiguous())
+        return out, None, None
+
+
+class _ChainEdges(torch.autograd.Function):
+    """next layer's edge rows out of this layer's phi: relu(zeros[E_all, C]; [e_id_cur] = phi)[e_id_next, :c] (reference
+    surfaceNetUpdatedEdgeFilters.py:233-241) without the [E_all, C] tensor; see csrc/chain.hip"""
+
+    @staticmethod
+    def forward(ctx, phi, e_id_cur, e_id_next, c, pos, relu):
+        out, inv = ops.edge_chain_fwd(phi, e_id_cur, e_id_next, c, pos, relu)
+        ctx.save_for_backward(phi, inv)
+        ctx.cfg = (int(c), bool(relu))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        phi, inv = ctx.saved_tensors
+        c, relu = ctx.cfg
+        return ops.edge_chain_bwd(g.contiguous(), phi, inv, c, relu), None, None, None, None, None
+
+
+def chain_edges(phi, e_id_cur, e_id_next, c, pos, relu=True):
+    return _ChainEdges.apply(phi, e_id_cur, e_id_next, c, pos, relu)
 
 
 class _ScatterRows(torch.autograd.Function):
@@ -258,8 +307,8 @@ class _ScatterRows(torch.autograd.Function):
         return ops.gather_rows(g.contiguous(), idx.to(torch.int32)), None, None
 
 
-def gather_rows(src, idx):
-    return _GatherRows.apply(src, idx)
+def gather_rows(src, idx, cols=None):
+    return _GatherRows.apply(src, idx, cols)
 
 
 def scatter_rows(src, idx, n_rows):

@@ -35,6 +35,10 @@ class GraphPlan:
         self._grouped = parts is not None or hint == ops.PLAN_HINT_GROUPED
         self._t = None
         self._sorted_attr = None  # (weakref to edge_attr, version, sorted copy)
+        # optional, set by producers whose eid is the identity (the k-hop block builder): int32 [E], row of the SCENE's edge_attr
+        # behind block edge k, so that kernels gather attribute rows from the scene tensor instead of a per-block copy
+        self.edge_rows = None
+        self._t_rows = None
 
     @property
     def edge_index(self):
@@ -54,6 +58,13 @@ class GraphPlan:
             self._t = ops.plan_build(edge_index, self.n_src, by=0, hint=ops.PLAN_HINT_GENERIC if self._grouped else ops.PLAN_HINT_AUTO,
                                       n_other=self.n_dst)
         return self._t
+
+    @property
+    def transposed_edge_rows(self):
+        """edge_rows in the transposed plan's order (None without edge_rows)"""
+        if self._t_rows is None and self.edge_rows is not None:
+            self._t_rows = torch.index_select(self.edge_rows, 0, self.transposed[2])
+        return self._t_rows
 
     def sorted_edge_attr(self, edge_attr: torch.Tensor) -> torch.Tensor:
         """edge_attr rows permuted into plan order (one gather per scene, reused by every layer)."""

@@ -22,6 +22,11 @@ from shutil import copyfile
 import torch
 import torch.nn.functional as F
 
+from .. import functional as Fn
+
+# the "kl" cell loss (+ OA counter) as one library call each way on GPU logits; DGNN_FUSED_LOSS=0 runs the reference's op chain
+FUSED_KL_LOSS = os.environ.get("DGNN_FUSED_LOSS", "1") != "0"
+
 
 class Metrics:
     """Running sums, reference :48-80.  The reference reads every item back to the host as it is added (`.item()`, three
@@ -50,9 +55,30 @@ class Metrics:
 
     def __getattr__(self, name):
         if name in Metrics._FIELDS:
+            if name in Metrics._PACKED:
+                self._flush_packed()
             acc = self.__dict__.get("_dev", {}).get(name)
             return self._host[name] + (acc.item() if acc is not None else 0)
         raise AttributeError(name)
+
+    def addPacked(self, sums, samples):
+        """`sums` = device fp64 [cell_sum, weight_sum, OA_sum] of one batch (the fused loss kernel's by-product): one add"""
+        acc = self._dev.get("_packed")
+        if acc is None or acc.device != sums.device:
+            if acc is not None:
+                self._flush_packed()
+            self._dev["_packed"] = sums.detach().clone()
+        else:
+            acc.add_(sums)
+        self._host["samples_sum"] += samples
+
+    _PACKED = ("cell_sum", "weight_sum", "OA_sum")
+
+    def _flush_packed(self):
+        acc = self._dev.pop("_packed", None)
+        if acc is not None:
+            for name, v in zip(self._PACKED, acc.tolist()):
+                self._host[name] += int(v) if name == "OA_sum" else v
 
     def addOAItem(self, oa, samples):
         self._add("OA_sum", oa)
@@ -113,6 +139,13 @@ class Trainer:
             raise UnboundLocalError("local variable 'cell_loss' referenced before assignment: the reference's calcLossAndOA "
                                     "needs regularization.cell_type (learning/runModel.py:169,223)")
         gt = data.batch_gt.to(dev)
+        if clf.training.loss == "kl" and FUSED_KL_LOSS and logits_cell.is_cuda and logits_cell.dtype == torch.float32 and logits_cell.size(0) > 0 \
+                and clf.regularization.cell_norm in Fn.ops.CELL_NORMS and gt.dtype == torch.float32:
+            # log_softmax, kl_div, the volume weights, both sums, the quotient and the OA counter in one launch (and one backward)
+            vol = data.batch_x[:, 0].to(dev)
+            loss, sums = Fn.kl_cell_loss(logits_cell, gt, vol if vol.dtype == torch.float32 else vol.float(), clf.regularization.cell_norm)
+            metrics.addPacked(sums, data.batch_x.shape[0])
+            return self._with_regularization(loss, logits_cell, data, clf, metrics)
         if clf.training.loss == "kl":
             cell_loss = F.kl_div(F.log_softmax(logits_cell, dim=-1), gt[:, :2], reduction='none').sum(dim=1)
             pred = logits_cell.argmax(1)
@@ -135,7 +168,9 @@ class Trainer:
         cell_loss = cell_loss * w
         cell_sum, w_sum = cell_loss.sum(), w.sum()
         metrics.addCellLossItem(cell_sum, w_sum)
-        loss = cell_sum / w_sum
+        return self._with_regularization(cell_sum / w_sum, logits_cell, data, clf, metrics)
+
+    def _with_regularization(self, loss, logits_cell, data, clf, metrics):
         if clf.regularization.edge_epoch is not None:
             if clf.graph.additional_num_hops != 1:
                 print("ERROR: clf.graph.additional_num_hops has to be >= 1 to use regularization")

@@ -204,13 +204,19 @@ class SurfaceNet(nn.Module):
             x = Fn.to_bf16(x)
         for i in range(self.num_layers):
             edge_index, e_id, size = data.batch_adjs[i]
-            ea = _dev_f32(data.all.edge_attr[e_id.to(data.all.edge_attr.device)], dev)
             edge_index = edge_index.to(dev)
             conv, norm = self.convs[i][0], self.convs[i][1] if len(self.convs[i]) > 1 else None
+            ea_all = data.all.edge_attr
             if isinstance(norm, BatchNorm) and Fn.sage_train_layer_supported(x, conv.lin_e, norm.module):
                 # conv + norm + ReLU as one library call forward, one backward
-                x = Fn.sage_train_layer(x, plan_for(edge_index, x.size(0), size[1]), ea, conv.lin_e, conv.lin_j, conv.lin_i, norm.module)
+                plan = plan_for(edge_index, x.size(0), size[1])
+                in_place = plan.edge_rows is not None and ea_all.is_cuda and ea_all.device == x.device and ea_all.dtype == torch.float32 \
+                    and ea_all.dim() == 2 and ea_all.stride(1) == 1
+                # a block whose plan carries edge_rows (the GPU block builder): edge_attr[e_id] (:215) is read in place
+                ea = ea_all if in_place else _dev_f32(ea_all[e_id.to(ea_all.device)], dev)
+                x = Fn.sage_train_layer(x, plan, ea, conv.lin_e, conv.lin_j, conv.lin_i, norm.module, scene_rows=in_place)
                 continue
+            ea = _dev_f32(ea_all[e_id.to(ea_all.device)], dev)
             x = conv((x, x[:size[1]]), ea, edge_index)
             x = self._norm_act(self.convs[i], x)
         if self.clf.model.decoder:

@@ -22,6 +22,11 @@ from .. import functional as Fn
 from ..graph import GraphPlan, plan_for
 
 
+# materialise the whole-scene [E_all, C] edge tensor per layer as the reference does (DGNN_CHAIN_DENSE=1) instead of chaining
+# only the rows the next layer reads; same values, kept for A/B tests
+CHAIN_SPARSE = __import__("os").environ.get("DGNN_CHAIN_DENSE", "0") != "1"
+
+
 def _dev_f32(t, device):
     if t.device != torch.device(device) or t.dtype != torch.float32:
         t = t.to(device=device, dtype=torch.float32)
@@ -85,6 +90,14 @@ class SurfaceNet(nn.Module):
             self.out_net = nn.Sequential(nn.ReLU(True), nn.Linear(p[-1], 128), nn.ReLU(True), nn.Linear(128, 2))
 
     storage_dtype = torch.float32
+    _chain_pos = None
+
+    def _chain_table(self, n_edges, dev):
+        """[E_all] int32 position table of the edge chaining, all -1 between uses (one per model and device, 4 bytes per scene edge)"""
+        t = self._chain_pos
+        if t is None or t.numel() != n_edges or t.device != torch.device(dev):
+            t = self._chain_pos = torch.full((n_edges,), -1, dtype=torch.int32, device=dev)
+        return t
 
     def set_storage_dtype(self, dtype):
         """torch.float32 (default) or torch.bfloat16: node activations and the chained edge embeddings phi are stored in bf16
@@ -110,19 +123,25 @@ class SurfaceNet(nn.Module):
             x = Fn.to_bf16(x)
         edge_attr = _dev_f32(data_all.edge_attr, dev)
         n_edges = edge_attr.size(0)
+        phi = e_prev = None
         for i in range(self.num_layers):
             edge_index, e_id, size = data_all.adjs[i]
             e_id = e_id.to(dev)
             conv = self.convs[i]
-            ea = Fn.gather_rows(edge_attr, e_id)[:, :conv.edge_in_channels]          # :237 edge_attr[e_id, :edge_in]
+            if i == 0:
+                ea = Fn.gather_rows(edge_attr, e_id, conv.edge_in_channels)           # :237 edge_attr[e_id, :edge_in]
+            elif CHAIN_SPARSE:
+                # :236-241 zeros[E_all, C]; [e_prev] = phi; relu; [e_id, :edge_in] -- computed for the rows that are read
+                ea = Fn.chain_edges(phi, e_prev, e_id, conv.edge_in_channels, self._chain_table(n_edges, dev), relu=True)
+            else:
+                ea = Fn.gather_rows(Fn.relu(Fn.scatter_rows(phi, e_prev, n_edges)), e_id, conv.edge_in_channels)
             x, phi = conv((x, x[:size[1]]), ea, edge_index.to(dev))
-            edge_attr = Fn.scatter_rows(phi, e_id, n_edges)                           # :236-237 zeros[E_all,C]; [e_id] = phi
+            e_prev = e_id
             if i != self.num_layers - 1:                                              # :239-241
                 x = Fn.relu(x)
-                edge_attr = Fn.relu(edge_attr)
+        # (the last layer's new_edge_attr, :236-237, is never read)
         if self.clf.training.model_name[-1] == "+":                                   # :245-247
-            x = Fn.relu(x)
-            x = Fn.relu(x)  # out_net[0] is another ReLU (idempotent)
+            x = Fn.relu(x)  # F.relu(x) and out_net[0], another ReLU: relu(relu(x)) == relu(x), values and gradient mask alike
             x = Fn.linear2(x, self.out_net[1].weight, bias=self.out_net[1].bias)
             x = Fn.relu(x)
             x = Fn.linear2(x, self.out_net[3].weight, bias=self.out_net[3].bias, out_f32=True)

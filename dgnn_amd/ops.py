@@ -75,15 +75,19 @@ def plan_build(edge_index: torch.Tensor, n_key: int, by: int, hint: int = PLAN_H
 
 
 @on_device_of
-def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+def gather_rows(src: torch.Tensor, idx: torch.Tensor, cols: int = None) -> torch.Tensor:
+    """out = src[idx, :cols] (cols None: all columns); only the requested columns are read"""
     if src.dtype == torch.bfloat16:   # rows of bf16 pairs move as fp32 words (bit copies)
-        if not src.is_contiguous() or src.size(1) % 2:
+        if not src.is_contiguous() or src.size(1) % 2 or (cols is not None and cols % 2):
             raise ValueError("bf16 gather_rows needs contiguous rows of even width")
-        return gather_rows(src.view(torch.float32), idx).view(torch.bfloat16)
+        return gather_rows(src.view(torch.float32), idx, None if cols is None else cols // 2).view(torch.bfloat16)
     _req(src, "src", dim=2)
     _req(idx, "idx", torch.int32, 1)
-    out = torch.empty((idx.numel(), src.size(1)), dtype=torch.float32, device=src.device)
-    check(lib().dgnn_gather_rows_f32(ptr(src), _ld(src), ptr(idx), idx.numel(), src.size(1), ptr(out), out.size(1), stream_ptr()),
+    cols = src.size(1) if cols is None else int(cols)
+    if not 0 < cols <= src.size(1):
+        raise ValueError("cols=%d outside (0, %d]" % (cols, src.size(1)))
+    out = torch.empty((idx.numel(), cols), dtype=torch.float32, device=src.device)
+    check(lib().dgnn_gather_rows_f32(ptr(src), _ld(src), ptr(idx), idx.numel(), cols, ptr(out), cols, stream_ptr()),
           "dgnn_gather_rows_f32")
     return out
 
@@ -510,3 +514,64 @@ def sage_layer_train_bwd(t_parts, rowptr_dst, n_src, n_dst, x, edge_attr, We, be
         ptr(scratch), GEMM_MODE, stream_ptr()), "dgnn_sage_layer_train_bwd")
     return (dx, dWe.view(c_in, f_e) if f_e else None, dbe, dWj.view(c_out, c_in), dbj, dWi.view(c_out, c_in) if dWi is not None else None,
             dgamma, dbeta)
+
+
+# ---- edge-embedding chaining of the Updated variant (csrc/chain.hip) ---------------------------------------------------------
+@on_device_of
+def edge_chain_fwd(phi, e_id_cur, e_id_next, c, pos, relu):
+    """-> (out [n_next, c] = relu?(zeros[E_all, C]; [e_id_cur] = phi)[e_id_next, :c], inv int32 [n_cur]); `pos`: int32 [E_all]
+    table holding -1 everywhere (left that way)."""
+    _req(phi, "phi", ACT, dim=2)
+    _req(e_id_cur, "e_id_cur", torch.int64, 1)
+    _req(e_id_next, "e_id_next", torch.int64, 1)
+    _req(pos, "pos", torch.int32, 1)
+    n_cur, n_next = e_id_cur.numel(), e_id_next.numel()
+    if phi.size(0) != n_cur or not 0 < c <= phi.size(1):
+        raise ValueError("phi %s does not match e_id_cur (%d) / c=%d" % (tuple(phi.shape), n_cur, c))
+    e_id_cur, e_id_next = e_id_cur.contiguous(), e_id_next.contiguous()
+    out = torch.empty((n_next, c), dtype=phi.dtype, device=phi.device)
+    inv = torch.empty(max(n_cur, 1), dtype=torch.int32, device=phi.device)[:n_cur]
+    check(getattr(lib(), "dgnn_edge_chain_fwd" + _sfx(phi))(ptr(phi), _ld(phi), int(c), ptr(e_id_cur), n_cur, ptr(e_id_next), n_next, pos.numel(),
+                                                            ptr(pos), int(bool(relu)), ptr(out), c, ptr(inv), stream_ptr()),
+          "dgnn_edge_chain_fwd", poll=True)
+    return out, inv
+
+
+@on_device_of
+def edge_chain_bwd(g, phi, inv, c, relu):
+    _req(phi, "phi", ACT, dim=2)
+    _same(_req(g, "g", ACT, dim=2), phi, "g")
+    dphi = torch.empty((phi.size(0), phi.size(1)), dtype=phi.dtype, device=phi.device)
+    check(getattr(lib(), "dgnn_edge_chain_bwd" + _sfx(phi))(ptr(g), _ld(g), ptr(phi), _ld(phi), ptr(inv), phi.size(0), int(c), phi.size(1),
+                                                            int(bool(relu)), ptr(dphi), phi.size(1), stream_ptr()), "dgnn_edge_chain_bwd")
+    return dphi
+
+
+# ---- volume-weighted KL cell loss (csrc/loss.hip) ------------------------------------------------------------------------------
+CELL_NORMS = {None: 0, "": 0, "none": 0, "log": 1, "sqrt": 2}
+
+
+@on_device_of
+def kl_cell_loss_fwd(logits, gt, vol, norm: int):
+    """-> (loss fp32 0-dim, sums fp64 [3] = sum cell*w, sum w, OA count)"""
+    _req(logits, "logits", dim=2)
+    _req(gt, "gt", dim=2)
+    _req(vol, "vol", dim=1)
+    n = logits.size(0)
+    if logits.size(1) != 2 or gt.size(1) < 2 or gt.size(0) != n or vol.numel() != n:
+        raise ValueError("kl_cell_loss: logits [n,2], gt [n,>=2], vol [n] expected, got %s %s %s" % (tuple(logits.shape), tuple(gt.shape), tuple(vol.shape)))
+    out = torch.empty(4, dtype=torch.float64, device=logits.device)   # sums[3] | the fp32 loss in the first half of the 4th
+    loss = out[3:].view(torch.float32)[:1].view(())
+    scratch = torch.empty(int(lib().dgnn_kl_cell_loss_scratch_doubles(n)), dtype=torch.float64, device=logits.device)
+    check(lib().dgnn_kl_cell_loss_fwd(ptr(logits), _ld(logits), ptr(gt), _ld(gt), ptr(vol), vol.stride(0), int(norm), n, ptr(out), ptr(loss), ptr(scratch),
+                                      stream_ptr()), "dgnn_kl_cell_loss_fwd")
+    return loss, out[:3]
+
+
+@on_device_of
+def kl_cell_loss_bwd(logits, gt, vol, norm: int, sums, grad_loss):
+    dl = torch.empty((logits.size(0), 2), dtype=torch.float32, device=logits.device)
+    grad_loss = grad_loss.to(torch.float32).contiguous()
+    check(lib().dgnn_kl_cell_loss_bwd(ptr(logits), _ld(logits), ptr(gt), _ld(gt), ptr(vol), vol.stride(0), int(norm), logits.size(0), ptr(sums),
+                                      ptr(grad_loss), ptr(dl), 2, stream_ptr()), "dgnn_kl_cell_loss_bwd")
+    return dl

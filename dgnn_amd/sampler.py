@@ -18,6 +18,7 @@ from ._lib import check, lib, ptr, stream_ptr
 from .graph import GraphPlan, register_plan
 
 _I32_MAX = 2 ** 31 - 1
+ONE_CALL = __import__("os").environ.get("DGNN_KHOP_ONE_CALL", "1") != "0"   # regular graphs: all hops in one library call
 
 
 class EdgeIndex(tuple):
@@ -37,7 +38,7 @@ class EdgeIndex(tuple):
 
 class NeighborSampler:
     def __init__(self, edge_index, sizes, node_idx=None, num_nodes=None, batch_size=1, shuffle=False, drop_last=False,
-                 return_e_id=True, plan: GraphPlan = None, generator=None, prefetch=True, **kwargs):
+                 return_e_id=True, plan: GraphPlan = None, generator=None, prefetch=True, transposed_plans=True, **kwargs):
         if any(int(s) != -1 for s in sizes):
             raise NotImplementedError("only full neighbourhoods (size -1) are used by the reference (clique_sizes: [-1])")
         if not edge_index.is_cuda:
@@ -57,8 +58,11 @@ class NeighborSampler:
         # iteration builds block k+1 on a side stream while the caller's stream still runs step k-1 / k (the reference's
         # NeighborSampler is a DataLoader: its workers prefetch batches the same way); the builder's host round trips then
         # wait for the side stream only, not for the training step's kernels
-        self.prefetch = bool(prefetch)
+        self.prefetch = "thread" if prefetch == "thread" else bool(prefetch)   # False | True (side stream, this thread) | "thread"
         self._side = None
+        # prefetching iteration also builds every block's source-sorted (transposed) plan, which the backward pass needs, on the
+        # builder's stream; False leaves it to the first backward (inference loaders never need it)
+        self.transposed_plans = bool(transposed_plans)
         self._escaped = None
         self._pos = torch.full((n,), -1, dtype=torch.int32, device=self.device)
         self._first = torch.full((n,), _I32_MAX, dtype=torch.int32, device=self.device)
@@ -92,18 +96,91 @@ class NeighborSampler:
                 self._side = torch.cuda.Stream(self.device)
             side = self._side
             side.wait_stream(torch.cuda.current_stream())   # idx (and the builder state) were produced on the caller's stream
-        pending = None
-        for s in starts:
-            with torch.cuda.device(self.device), torch.cuda.stream(side):
-                self._escaped = []
-                out = self._sample(idx[s:s + self.batch_size])
-                nxt = (out, self._escaped, side.record_event())
-                self._escaped = None
+        if self.prefetch != "thread" and self._regular and ONE_CALL and self.batch_size > 0:
+            # the library's own host thread builds block k+1 while this thread enqueues step k
+            pending = None
+            try:
+                for s in starts:
+                    blk = self._finish_on_side(pending) if pending is not None else None
+                    pending = None
+                    with torch.cuda.device(self.device), torch.cuda.stream(side):
+                        self._escaped = []
+                        pending = (self._start_regular(idx[s:s + self.batch_size].contiguous(), background=True), self._escaped)
+                        self._escaped = None
+                    if blk is not None:
+                        yield self._hand_over(blk)
+                if pending is not None:
+                    blk, pending = self._finish_on_side(pending), None
+                    yield self._hand_over(blk)
+            finally:
+                if pending is not None:   # abandoned mid-way: the builder thread must not outlive its buffers
+                    self._finish_on_side(pending)
+            return
+        if self.prefetch != "thread":
+            pending = None
+            for s in starts:
+                nxt = self._build_on_side(idx[s:s + self.batch_size])
+                if pending is not None:
+                    yield self._hand_over(pending)
+                pending = nxt
             if pending is not None:
                 yield self._hand_over(pending)
-            pending = nxt
-        if pending is not None:
-            yield self._hand_over(pending)
+            return
+        # a worker thread builds blocks ahead (queue of 2): its host round trips (one per hop) wait while this thread keeps
+        # enqueueing the training step -- ctypes calls and .item() release the GIL
+        import queue
+        import threading
+        q, stop = queue.Queue(maxsize=2), threading.Event()
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
+        def worker():
+            try:
+                for s in starts:
+                    if stop.is_set() or not put(self._build_on_side(idx[s:s + self.batch_size])):
+                        return
+                put(None)
+            except BaseException as e:   # surfaces in the consuming thread
+                put(e)
+
+        t = threading.Thread(target=worker, name="dgnn-block-builder", daemon=True)
+        t.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                yield self._hand_over(item)
+        finally:
+            stop.set()
+            t.join()
+
+    def _finish_on_side(self, pending):
+        b, escaped = pending
+        with torch.cuda.device(self.device), torch.cuda.stream(self._side):
+            self._escaped = escaped
+            try:
+                out = self._finish_regular(b)
+            finally:
+                self._escaped = None
+            return (out, escaped, self._side.record_event())
+
+    def _build_on_side(self, batch):
+        with torch.cuda.device(self.device), torch.cuda.stream(self._side):
+            self._escaped = []
+            out = self._sample(batch)
+            item = (out, self._escaped, self._side.record_event())
+            self._escaped = None
+        return item
 
     def _hand_over(self, pending):
         """makes a block built on the side stream usable on the caller's current stream"""
@@ -119,10 +196,79 @@ class NeighborSampler:
         with torch.cuda.device(self.device):  # the plan's GPU, whatever the thread's current device is
             return self._sample(batch)
 
+    def _start_regular(self, n_id: torch.Tensor, background: bool):
+        """every node has exactly 4 in-edges: all hops (and, when iterating with prefetch, the transposed plans) in one library
+        call into buffers sized by the 5^h growth bound.  `background`: the call runs on a library-owned host thread
+        (dgnn_khop_blocks_regular_start) and this returns at once; _finish_regular joins it and cuts the views."""
+        import ctypes as C
+        hops, p, dev = len(self.sizes), self.plan, self.device
+        nb = n_id.numel()
+        cap_t = [min(nb * 5 ** h, self.num_nodes) for h in range(hops)]
+        cap_e = [4 * t for t in cap_t]
+        i64 = lambda n: torch.empty(n, dtype=torch.int64, device=dev)      # nb > 0: every capacity is positive
+        i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
+        b = dict(nb=nb, n_id=n_id, hops=hops,
+                 ei=[torch.empty((2, e), dtype=torch.int64, device=dev) for e in cap_e], e_id=[i64(e) for e in cap_e],
+                 src32=[i32(e) for e in cap_e], e_id32=[i32(e) for e in cap_e], off=[i32(t + 1) for t in cap_t],
+                 n_out=[i64(t + e) for t, e in zip(cap_t, cap_e)])
+        L = lib()
+        b["scratch"] = scratch = i32(max(int(L.dgnn_khop_scratch_elems(t, e)) for t, e in zip(cap_t, cap_e)) + 1)
+        arr = lambda ts: (C.c_void_p * hops)(*[t.data_ptr() for t in ts])
+        caps = lambda v: (C.c_int64 * hops)(*v)
+        b["counts"] = counts = (C.c_int64 * (hops + 1))()
+        # prefetching iteration (training): the source-sorted plans the backward pass walks come out of the same call
+        b["want_t"] = want_t = self.transposed_plans and self._escaped is not None
+        t_arrs, cap_all, plan_scratch = [None] * 4, None, None
+        if want_t:
+            cap_all = [min(t + e, self.num_nodes) for t, e in zip(cap_t, cap_e)]
+            b["t_rowptr"] = [i32(a + 1) for a in cap_all]
+            b["t_dst"], b["t_eid"], b["t_rows"] = ([i32(e) for e in cap_e] for _ in range(3))
+            b["plan_scratch"] = plan_scratch = i32(max(int(L.dgnn_plan_scratch_elems(e, a)) for e, a in zip(cap_e, cap_all)))
+            t_arrs = [arr(b[k]) for k in ("t_rowptr", "t_dst", "t_eid", "t_rows")]
+        args = (ptr(p.rowptr), ptr(p.src), ptr(p.eid), 4, ptr(n_id), nb, hops, ptr(self._pos), ptr(self._first), arr(b["ei"]), arr(b["e_id"]),
+                arr(b["src32"]), arr(b["e_id32"]), arr(b["off"]), arr(b["n_out"]), caps(cap_t), caps(cap_e), ptr(scratch[:-1]), ptr(scratch[-1:]),
+                *t_arrs, caps(cap_all) if want_t else None, ptr(plan_scratch))
+        if background:
+            b["job"] = L.dgnn_khop_blocks_regular_start(*args, stream_ptr())
+            if not b["job"]:
+                check(-1, "dgnn_khop_blocks_regular_start")
+        else:
+            check(L.dgnn_khop_blocks_regular(*args, counts, stream_ptr()), "dgnn_khop_blocks_regular", poll=True)
+        return b
+
+    def _finish_regular(self, b):
+        hops, counts = b["hops"], b["counts"]
+        if b.get("job"):
+            job, b["job"] = b["job"], None
+            check(lib().dgnn_khop_blocks_regular_wait(job, hops, counts), "dgnn_khop_blocks_regular", poll=True)
+        adjs = []
+        for h in range(hops):
+            n_t, n_all = int(counts[h]), int(counts[h + 1])
+            n_e = 4 * n_t
+            e = b["ei"][h][:, :n_e]     # a strided view: plans and kernels read edge lists in place
+            plan = GraphPlan(e, n_all, n_t, parts=(b["off"][h][:n_t + 1], b["src32"][h][:n_e], self._arange(n_e)))
+            # plan position k <-> block edge k <-> row e_id[k] of the scene's edge_attr: consumers may read those rows in place
+            plan.edge_rows = b["e_id32"][h][:n_e]
+            if b["want_t"]:
+                plan._t = (b["t_rowptr"][h][:n_all + 1], b["t_dst"][h][:n_e], b["t_eid"][h][:n_e])
+                plan._t_rows = b["t_rows"][h][:n_e]
+                self._escaped += [b[k][h] for k in ("t_rowptr", "t_dst", "t_eid", "t_rows")]
+            register_plan(e, plan)
+            adjs.append(EdgeIndex(e, b["e_id"][h][:n_e] if self.return_e_id else None, (n_all, n_t)))
+            if self._escaped is not None:
+                self._escaped += [b[k][h] for k in ("ei", "e_id", "off", "src32", "e_id32", "n_out")] + [self._iota]
+        adjs = adjs[0] if len(adjs) == 1 else adjs[::-1]
+        return b["nb"], b["n_out"][-1][:int(counts[hops])], adjs
+
+    def _sample_regular(self, n_id: torch.Tensor):
+        return self._finish_regular(self._start_regular(n_id, background=False))
+
     def _sample(self, batch: torch.Tensor):
         L, st, p = lib(), stream_ptr(), self.plan
         n_id = batch.to(self.device, torch.int64).contiguous()
         batch_size = n_id.numel()
+        if self._regular and batch_size > 0 and ONE_CALL:
+            return self._sample_regular(n_id)
         adjs = []
         for hop in range(len(self.sizes)):
             n_t = n_id.numel()
@@ -145,9 +291,12 @@ class NeighborSampler:
             n_id = n_id_out[:n_all]
             # the block is emitted grouped by destination with `off` as its row offsets: that IS its plan (identity order)
             src32 = e_src.to(torch.int32)
-            register_plan(ei, GraphPlan(ei, n_all, n_t, parts=(off, src32, self._arange(n_e))))
+            plan = GraphPlan(ei, n_all, n_t, parts=(off, src32, self._arange(n_e)))
+            register_plan(ei, plan)
             if self._escaped is not None:
                 self._escaped += [ei, e_id, off, src32, self._iota, n_id_out]
+                if self.transposed_plans:
+                    self._escaped += list(plan.transposed)
             adjs.append(EdgeIndex(ei, e_id if self.return_e_id else None, (n_all, n_t)))
         check(L.dgnn_khop_reset(ptr(n_id), n_id.numel(), ptr(self._pos), st), "dgnn_khop_reset")
         adjs = adjs[0] if len(adjs) == 1 else adjs[::-1]

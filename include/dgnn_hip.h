@@ -228,6 +228,39 @@ int dgnn_sage_layer_train_bwd(const int32_t* t_rowptr, const int32_t* t_dst, con
                               const float* dy, float* dx, float* dWe, float* dbe, float* dWj, float* dbj, float* dWi, float* dgamma,
                               float* dbeta, float* scratch, int gemm_mode, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Edge-embedding chaining of the Updated variant (surfaceNetUpdatedEdgeFilters.py:233-241): the next layer's edge rows
+ *   out[k, :c] = relu?( phi[r, :c] )  where e_id_cur[r] == e_id_next[k],   0 when this layer did not produce that edge
+ * i.e. relu(zeros[E_all, C]; [e_id_cur] = phi)[e_id_next, :c] without materialising the [E_all, C] tensor.  `pos` is an
+ * [n_edges] int32 table that must hold -1 everywhere on entry and does again on exit (only e_id_cur entries are touched);
+ * `inv` [n_cur] receives the inverse map (row of `out` that read phi row r, or -1) for the backward pass:
+ *   dphi[r, j] = (inv[r] >= 0 && j < c) ? g[inv[r], j] * [phi[r, j] > 0] : 0        (dphi [n_cur, c_tot], fully written)
+ * Edge ids are unique within a block (k-hop blocks: every graph edge appears once).  Ids outside [0, n_edges) are skipped
+ * and reported through dgnn_poll_async_error.
+ * ---------------------------------------------------------------------------------------------- */
+int dgnn_edge_chain_fwd(const float* phi, int64_t ldphi, int c, const int64_t* e_id_cur, int64_t n_cur, const int64_t* e_id_next,
+                        int64_t n_next, int64_t n_edges, int32_t* pos, int relu, float* out, int64_t ldo, int32_t* inv, void* stream);
+int dgnn_edge_chain_fwd_bf16(const uint16_t* phi, int64_t ldphi, int c, const int64_t* e_id_cur, int64_t n_cur, const int64_t* e_id_next,
+                             int64_t n_next, int64_t n_edges, int32_t* pos, int relu, uint16_t* out, int64_t ldo, int32_t* inv, void* stream);
+int dgnn_edge_chain_bwd(const float* g, int64_t ldg, const float* phi, int64_t ldphi, const int32_t* inv, int64_t n_cur, int c, int c_tot,
+                        int relu, float* dphi, int64_t lddphi, void* stream);
+int dgnn_edge_chain_bwd_bf16(const uint16_t* g, int64_t ldg, const uint16_t* phi, int64_t ldphi, const int32_t* inv, int64_t n_cur, int c,
+                             int c_tot, int relu, uint16_t* dphi, int64_t lddphi, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Volume-weighted KL cell loss of the training step (learning/runModel.py:171-209), one launch each way:
+ *   cell_k = sum_c kl_div(log_softmax(logits_k)_c, gt_kc);  w_k = vol_k | log(1+vol_k) | sqrt(vol_k)  (norm 0 | 1 | 2)
+ *   loss = sum cell_k w_k / sum w_k;   sums[3] (fp64) = sum cell_k w_k, sum w_k, #{k: [gt_k0 > gt_k1] == argmax logits_k}
+ *   backward: dlogits_kc = grad_loss * w_k / sums[1] * (softmax_kc (gt_k0 + gt_k1) - gt_kc)
+ * logits / gt: two leading columns of rows with strides ldl / ldg; vol: element stride ldv.  scratch:
+ * dgnn_kl_cell_loss_scratch_doubles(n) doubles.  grad_loss: device pointer to the upstream scalar.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t dgnn_kl_cell_loss_scratch_doubles(int64_t n);
+int dgnn_kl_cell_loss_fwd(const float* logits, int64_t ldl, const float* gt, int64_t ldg, const float* vol, int64_t ldv, int norm, int64_t n,
+                          double* sums, float* loss, double* scratch, void* stream);
+int dgnn_kl_cell_loss_bwd(const float* logits, int64_t ldl, const float* gt, int64_t ldg, const float* vol, int64_t ldv, int norm, int64_t n,
+                          const double* sums, const float* grad_loss, float* dlogits, int64_t ldd, void* stream);
+
 /* Fused decoder, eval mode (reference :180-187 applied at :350-351):
  *   logits = W3 . relu((W0 . y + b0) * scale + shift) + b3,   y [M,k] -> out [M,n_out]
  * Supports k == 128, hidden == 64, n_out in {1,2}; DGNN_E_UNSUPPORTED otherwise (use dgnn_linear_fwd twice). */
@@ -313,6 +346,31 @@ int dgnn_khop_expand(const int32_t* rowptr, const int32_t* src, const int32_t* e
                      int64_t* e_id, int64_t* n_id_out, int32_t* n_new_out, int32_t* scratch, void* stream);
 int dgnn_khop_commit(const int64_t* n_id_out, int64_t n_t, int64_t n_all, int32_t* pos, int32_t* first, void* stream);
 int dgnn_khop_reset(const int64_t* n_id, int64_t n, int32_t* pos, void* stream);
+/* All hops of one batch in one call for graphs with exactly `deg` in-edges per node (Delaunay scenes: 4): edge counts are known
+ * without a read-back, the one 4-byte read per hop (new-node count) is waited for inside the call.  Hop h writes into
+ * caller-allocated buffers of capacity cap_t[h] targets / cap_e[h] edges: ei[h] int64 [2, cap_e[h]], e_id[h] int64 [cap_e[h]],
+ * src32[h] / e_id32[h] int32 [cap_e[h]] (int32 copies of ei[h] row 0 and of e_id[h]), off[h] int32 [cap_t[h]+1], n_id_out[h] int64 [cap_t[h]+cap_e[h]]; scratch =
+ * max_h dgnn_khop_scratch_elems(cap_t[h], cap_e[h]) int32; n_new_dev one device int32; counts_out HOST int64 [hops+1] = targets
+ * of every hop, then the node count of the outermost block.  t_rowptr != NULL also builds every hop's transposed plan (by source:
+ * t_rowptr[h] int32 [cap_all[h]+1], t_dst[h] / t_eid[h] int32 [cap_e[h]]) and t_rows[h] = e_id32[h][t_eid[h]], with plan_scratch =
+ * max_h dgnn_plan_scratch_elems(cap_e[h], cap_all[h]) int32.  DGNN_E_INVALID if a capacity is too small (pos is left all -1).
+ * The per-hop count travels through pinned host memory the GPU writes to, not through a stream synchronize, so a host thread
+ * running this call does not contend with another one that is launching kernels. */
+int dgnn_khop_blocks_regular(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int deg, const int64_t* batch, int64_t n_batch,
+                             int hops, int32_t* pos, int32_t* first, int64_t* const* ei, int64_t* const* e_id, int32_t* const* src32,
+                             int32_t* const* e_id32, int32_t* const* off, int64_t* const* n_id_out, const int64_t* cap_t, const int64_t* cap_e, int32_t* scratch,
+                             int32_t* n_new_dev, int32_t* const* t_rowptr, int32_t* const* t_dst, int32_t* const* t_eid, int32_t* const* t_rows,
+                             const int64_t* cap_all, int32_t* plan_scratch, int64_t* counts_out, void* stream);
+/* The same call on a library-owned host thread: start() returns a job handle at once (NULL + error text on bad arguments), a
+ * std::thread issues the launches on `stream` and waits for the per-hop counts, wait() joins it, fills counts_out [hops+1] and
+ * frees the job.  Between the two the caller may enqueue on OTHER streams only and must leave pos / first / the buffers alone. */
+void* dgnn_khop_blocks_regular_start(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int deg, const int64_t* batch,
+                                     int64_t n_batch, int hops, int32_t* pos, int32_t* first, int64_t* const* ei, int64_t* const* e_id,
+                                     int32_t* const* src32, int32_t* const* e_id32, int32_t* const* off, int64_t* const* n_id_out,
+                                     const int64_t* cap_t, const int64_t* cap_e, int32_t* scratch, int32_t* n_new_dev, int32_t* const* t_rowptr,
+                                     int32_t* const* t_dst, int32_t* const* t_eid, int32_t* const* t_rows, const int64_t* cap_all,
+                                     int32_t* plan_scratch, void* stream);
+int dgnn_khop_blocks_regular_wait(void* job, int hops, int64_t* counts_out);
 
 /* ------------------------------------------------------------------------------------------------
  * Logits -> labels -> interface facets (reference processing/generate_mesh.py:75 and :93-105).

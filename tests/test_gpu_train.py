@@ -225,3 +225,128 @@ def test_composite_train_layer_is_bit_identical_to_the_separate_calls(monkeypatc
             assert torch.equal(ga[k], gb[k]), (case, k, (ga[k] - gb[k]).abs().max().item())
         for k in ba:
             assert torch.equal(ba[k], bb[k]), (case, k)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("c,C", [(28, 28), (64, 64), (6, 10), (128, 128)])
+def test_edge_chain_matches_the_dense_statement(dtype, c, C):
+    """out / dphi of the chaining kernels == relu(zeros[E_all, C]; [e_cur] = phi)[e_next, :c] and its autograd, written with
+    plain torch ops (reference surfaceNetUpdatedEdgeFilters.py:233-241); e_next is NOT a subset of e_cur here."""
+    from dgnn_amd import functional as Fn
+    g = torch.Generator().manual_seed(3)
+    n_edges, n_cur, n_next = 5000, 1700, 900
+    perm = torch.randperm(n_edges, generator=g)
+    e_cur = perm[:n_cur].to(DEV)
+    e_next = torch.cat([perm[200:900], perm[4000:4200]]).to(DEV)      # 700 produced by this layer, 200 not
+    phi = torch.randn(n_cur, C, generator=g).to(DEV).to(dtype).requires_grad_(True)
+    G = torch.randn(n_next, c, generator=g).to(DEV).to(dtype)
+    pos = torch.full((n_edges,), -1, dtype=torch.int32, device=DEV)
+    out = Fn.chain_edges(phi, e_cur, e_next, c, pos, relu=True)
+    out.backward(G)
+    got_g = phi.grad.clone()
+    assert bool((pos == -1).all())
+    phi2 = phi.detach().clone().requires_grad_(True)
+    dense = torch.zeros(n_edges, C, device=DEV, dtype=dtype)
+    dense = dense.index_put((e_cur,), phi2)
+    ref = torch.relu(dense)[e_next, :c]
+    ref.backward(G)
+    assert torch.equal(out, ref)
+    assert torch.equal(got_g, phi2.grad)
+    # ids outside the scene's edge range are skipped and reported
+    from dgnn_amd._lib import DgnnError, lib
+    torch.cuda.synchronize()
+    lib().dgnn_poll_async_error()
+    bad = e_next.clone()
+    bad[5] = n_edges + 3
+    with pytest.raises(DgnnError):
+        Fn.chain_edges(phi.detach(), e_cur, bad, c, pos, relu=True)
+        torch.cuda.synchronize()
+        from dgnn_amd._lib import check
+        check(0, "poll", poll=True)
+    assert bool((pos == -1).all())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_updated_sparse_chaining_is_bit_identical_to_the_dense_edge_tensor(monkeypatch, dtype):
+    from dgnn_amd.learning import surfaceNetUpdatedEdgeFilters as U
+    from dgnn_amd.sampler import NeighborSampler
+    from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal
+    adj, _, _ = delaunay_tet_graph(3000, seed=4)
+    n = adj.shape[0] // 4
+    ei = torch.from_numpy(adj.T.astype(np.int64)).to(DEV)
+    x = hashed_normal(np.arange(n), 29, seed=5, device=DEV)
+    ea = hashed_normal(np.arange(4 * n), 20, seed=6, device=DEV)
+    _, n_id, adjs = NeighborSampler(ei, sizes=[-1] * 4, num_nodes=n, batch_size=257).sample(torch.arange(100, 357, device=DEV))
+    G = hashed_normal(np.arange(257), 2, seed=7, device=DEV)
+    clf = Config.wrap(dict(training=dict(model_params=[64, 128, 128, 128], model_name="sage+", loss="kl"),
+                           features=dict(normalization_feature=1, keep_normalization_feature=0), temp=dict(device=DEV)))
+    torch.manual_seed(1)
+    sd = U.SurfaceNet(28, clf).state_dict()
+    res = []
+    for sparse in (True, False):
+        monkeypatch.setattr(U, "CHAIN_SPARSE", sparse)
+        net = U.SurfaceNet(28, clf)
+        net.load_state_dict(sd)
+        net = net.to(DEV).set_storage_dtype(dtype)
+        logits = net(Config(x=x, edge_attr=ea, n_id=n_id, adjs=adjs))
+        (logits * G).sum().backward()
+        res.append((logits.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
+@pytest.mark.parametrize("norm", [None, "log", "sqrt"])
+@pytest.mark.parametrize("n", [1, 777, 2048, 300000])
+def test_fused_kl_cell_loss_matches_the_reference_op_chain(monkeypatch, norm, n):
+    """Trainer.calcLossAndOA through dgnn_kl_cell_loss_{fwd,bwd} vs the reference's own op chain (learning/runModel.py:171-209,
+    run here with torch ops on the same GPU tensors): loss, d loss / d logits, and the three running sums."""
+    from dgnn_amd.learning import runModel as R
+    from test_trainer_cpu import make_clf
+    g = torch.Generator().manual_seed(n)
+    logits = (3 * torch.randn(n, 2, generator=g)).to(DEV)
+    p = torch.rand(n, 1, generator=g)
+    p[::7] = 0.0                                   # exact zeros and ones in the target: the xlogy branch
+    gt = torch.cat([p, 1 - p, torch.zeros(n, 2)], 1).to(DEV)
+    bx = torch.cat([torch.rand(n, 1, generator=g) * 5 + 1e-3, torch.randn(n, 3, generator=g)], 1).to(DEV)
+    clf = make_clf()
+    clf.regularization.cell_norm = norm
+    out = []
+    for fused in (True, False):
+        monkeypatch.setattr(R, "FUSED_KL_LOSS", fused)
+        lg = logits.clone().requires_grad_(True)
+        m = R.Metrics()
+        loss = R.Trainer(None).calcLossAndOA(lg, None, Config(batch_gt=gt, batch_x=bx), clf, m)
+        (loss * 1.7).backward()
+        out.append((loss.item(), lg.grad.clone(), m.getCellLoss(), m.getOA(), m.OA_sum, m.samples_sum))
+    (la, ga, ca, oa, osa, sa), (lb, gb, cb, ob, osb, sb) = out
+    assert abs(la - lb) <= 2e-6 * max(abs(lb), 1e-3), (la, lb)
+    assert (ga - gb).abs().max().item() <= 2e-6 * gb.abs().max().item() + 1e-12
+    assert abs(ca - cb) <= 2e-6 * abs(cb) and osa == osb and sa == sb == n and oa == ob
+
+
+@pytest.mark.parametrize("mode", [True, "thread"])
+def test_prefetching_block_builder_yields_the_same_blocks_and_plans(mode):
+    """iteration with the builder one block ahead (side stream / worker thread, all hops + transposed plans in one library
+    call) == the in-line builder, block for block; the transposed plans equal dgnn_plan_build's on the same edge list"""
+    from dgnn_amd import ops
+    from dgnn_amd.graph import plan_for
+    from dgnn_amd.sampler import NeighborSampler
+    from dgnn_amd.synthetic import delaunay_tet_graph
+    adj, _, _ = delaunay_tet_graph(4000, seed=9)
+    n = adj.shape[0] // 4
+    ei = torch.from_numpy(adj.T.astype(np.int64)).to(DEV)
+    idx = torch.randperm(n, generator=torch.Generator().manual_seed(0))[:1000].to(DEV)
+    ref = list(NeighborSampler(ei, sizes=[-1] * 3, node_idx=idx, num_nodes=n, batch_size=128, prefetch=False))
+    got = list(NeighborSampler(ei, sizes=[-1] * 3, node_idx=idx, num_nodes=n, batch_size=128, prefetch=mode))
+    assert len(ref) == len(got) == 8
+    for (ba, na, aa), (bb, nb, ab) in zip(ref, got):
+        assert ba == bb and torch.equal(na, nb)
+        for (e1, i1, s1), (e2, i2, s2) in zip(aa, ab):
+            assert s1 == s2 and torch.equal(e1, e2) and torch.equal(i1, i2)
+            plan = plan_for(e2, s2[0], s2[1])
+            assert plan._t is not None and plan.edge_rows is not None      # came with the block
+            t_ref = ops.plan_build(e2, s2[0], by=0, hint=ops.PLAN_HINT_GENERIC, n_other=s2[1])
+            for a, b in zip(plan.transposed, t_ref):
+                assert torch.equal(a, b)
+            assert torch.equal(plan.edge_rows.long(), i2) and torch.equal(plan.transposed_edge_rows.long(), i2[t_ref[2].long()])

@@ -35,6 +35,8 @@ ap.add_argument("--points", type=int, default=150000)
 ap.add_argument("--batch", type=int, default=2048)
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--warmup", type=int, default=5)
+ap.add_argument("--prefetch", choices=["none", "stream", "thread"], default="thread",
+                help="block builder: in line | one block ahead on a side stream | ahead in a worker thread (default)")
 args = ap.parse_args()
 
 rank, local_rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,7 +99,8 @@ opt = torch.optim.Adam(net.parameters(), lr=clf.training.learning_rate, fused=Tr
 adjust_learning_rate(opt, clf)
 g = torch.Generator().manual_seed(rank)
 idx = torch.randperm(n, generator=g)[:batch * (steps + args.warmup)]
-loader = NeighborSampler(ei, sizes=[-1] * 4, node_idx=idx.to(dev), num_nodes=n, batch_size=batch)
+loader = NeighborSampler(ei, sizes=[-1] * 4, node_idx=idx.to(dev), num_nodes=n, batch_size=batch,
+                         prefetch={"none": False, "stream": True, "thread": "thread"}[args.prefetch])
 it = iter(loader)
 block = 0
 for _ in range(args.warmup):
@@ -131,6 +134,6 @@ if rank == 0:
                       "parallelism": "data-parallel replicas, one scene shard per GPU, flat RCCL all-reduce" if world > 1 else "single GPU",
                       "targets_per_s": round(batch * steps * world / dt, 1), "block_tets_per_s": round(block / dt, 1),
                       "ms_per_step": round(dt / steps * 1e3, 3), "batch_targets_per_gpu": batch,
-                      "avg_block_tets": round(block / steps / world, 1), "steps": steps, "scene_tets_per_gpu": n, "final_loss": float(loss)}))
+                      "avg_block_tets": round(block / steps / world, 1), "steps": steps, "block_builder": args.prefetch, "scene_tets_per_gpu": n, "final_loss": float(loss)}))
 if world > 1:
     dist.destroy_process_group()

@@ -26,7 +26,7 @@ tr = Trainer(net)
 opt = torch.optim.Adam(net.parameters(), lr=clf.training.learning_rate, fused=True)
 adjust_learning_rate(opt, clf)
 idx = torch.randperm(n)[:2048 * (2 * steps + 10)].to(dev)
-PREFETCH = os.environ.get("PREFETCH", "1") == "1"
+PREFETCH = {"0": False, "1": True, "thread": "thread"}[os.environ.get("PREFETCH", "1")]
 loader = NeighborSampler(ei, sizes=[-1] * 4, node_idx=idx, num_nodes=n, batch_size=2048, prefetch=PREFETCH)
 it = iter(loader)
 names = ["sample", "forward+loss", "backward", "adam"]

@@ -1,0 +1,12 @@
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_gpu_train.py tests/test_gpu_parity.py -m gpu -q -x 2>&1 | tail -4
+for rep in 1 2; do
+for pf in none stream thread; do
+  python tools/bench_train.py --steps 80 --prefetch $pf 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['model'],d['dtype'],d['block_builder'],d['ms_per_step'],d['final_loss'])"
+done
+done
+for a in "--updated" "--updated --dtype bf16"; do
+for pf in stream thread; do
+  python tools/bench_train.py --steps 80 --prefetch $pf $a 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['model'],d['dtype'],d['block_builder'],d['ms_per_step'],d['final_loss'])"
+done
+done

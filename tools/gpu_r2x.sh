@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_gpu_train.py tests/test_gpu_parity.py -m gpu -q -x 2>&1 | tail -4
+python tools/diag_sampler.py 2>/dev/null
+for rep in 1 2 3; do
+for pf in stream thread; do
+  python tools/bench_train.py --steps 80 --prefetch $pf 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['model'],d['dtype'],d['block_builder'],d['ms_per_step'],d['final_loss'])"
+done
+done
