@@ -12,6 +12,8 @@
 // fragment reads (ds_read_b128) bank-conflict free for the 16-lane groups of that instruction.
 // k-permutation: within a chunk, half-wave h of MFMA step (S,j) multiplies k = 8S + 4h + j, so one
 // b128 read per operand feeds 4 MFMAs; A and B use the same map, hence every k is used exactly once.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -510,6 +512,141 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_x3(const float* __restric
     }
 }
 
+// Large problems (M >= 8192 rows, n_out > 128): 256 x 256 output tile per 512-thread block, wave (wr, wc) of the 2 x 4 wave grid owns
+// a 128 x 64 block = 4 x 2 MFMA blocks (8 accumulators).  Splitting the operands costs VALU issue slots (about 12 per element
+// pair) that share the SIMD's issue port with the MFMAs: at 128 x 128 a chunk is 32 elements per thread for 48 MFMAs per wave,
+// about as many VALU as can hide behind them; the 256 x 256 tile stages the same 32 elements per thread for 96 MFMAs, and
+// fetches A and W half as often.  LDS: 512 rows x 208 B = 104 KB, one block per CU, 2 waves per SIMD.
+constexpr int YM = 256, YN = 256, YT = 512;
+
+template <int NP>
+__device__ __forceinline__ void y3_load(f32x4 (&v)[NP], const float* __restrict__ src, int64_t ld, int64_t row0, int64_t nrows, int k0, int kmax,
+                                        bool vec) {
+    constexpr int RPP = YT / 8;   // rows per pass
+    const int t = threadIdx.x, r = t >> 3, c = (t & 7) * 4;
+    if (vec && k0 + XK <= kmax) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int64_t gr = row0 + r + p * RPP;
+            v[p] = *reinterpret_cast<const f32x4*>(src + (gr < nrows ? gr : nrows - 1) * ld + k0 + c);
+        }
+        return;
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int64_t gr = row0 + r + p * RPP;
+        const float* g = src + (gr < nrows ? gr : nrows - 1) * ld;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + c + j;
+            const float val = g[k < kmax ? k : kmax - 1];
+            v[p][j] = k < kmax ? val : 0.f;
+        }
+    }
+}
+template <int NP>
+__device__ __forceinline__ void y3_store(char* __restrict__ dst, const f32x4 (&v)[NP]) {
+    constexpr int RPP = YT / 8;
+    const int t = threadIdx.x, r = t >> 3, c = (t & 7) * 4;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        uint32_t h0, m0, l0, h1, m1, l1;
+        x3_split(v[p][0], v[p][1], h0, m0, l0);
+        x3_split(v[p][2], v[p][3], h1, m1, l1);
+        char* d = dst + (r + p * RPP) * XLD + c * 2;
+        *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(d + 64) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(d + 128) = make_uint2(l0, l1);
+    }
+}
+
+__global__ void __launch_bounds__(YT, 1) k_linear_fwd_x3_big(const float* __restrict__ A1, int64_t lda1, int k1, const float* __restrict__ W1,
+                                                             int64_t ldw1, bool vec1, const float* __restrict__ A2, int64_t lda2, int k2,
+                                                             const float* __restrict__ W2, int64_t ldw2, bool vec2,
+                                                             const float* __restrict__ bias, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int relu, int64_t M, int n_out,
+                                                             float* __restrict__ out, int64_t ldo) {
+    extern __shared__ __attribute__((aligned(16))) char y3_smem[];
+    char* const As = y3_smem;
+    char* const Ws = y3_smem + YM * XLD;
+    const int lane = lane_id(), w = wave_id_uniform();
+    const int wr = w >> 2, wc = w & 3, h = lane >> 5, l31 = lane & 31;
+    const int ncb = (n_out + YN - 1) / YN;   // column blocks fastest (see k_linear_fwd_x3)
+    const int64_t row0 = (int64_t)(blockIdx.x / ncb) * YM;
+    const int col0 = (int)(blockIdx.x % ncb) * YN;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    const int nch1 = (k1 + XK - 1) / XK, nch2 = A2 ? (k2 + XK - 1) / XK : 0, nch = nch1 + nch2;
+    constexpr int NP = YM / (YT / 8);
+    f32x4 ra[NP], rw[NP];
+    auto load_chunk = [&](int ch) {
+        const bool first = ch < nch1;
+        const int kk = first ? k1 : k2, k0 = (first ? ch : ch - nch1) * XK;
+        y3_load<NP>(ra, first ? A1 : A2, first ? lda1 : lda2, row0, M, k0, kk, first ? vec1 : vec2);
+        y3_load<NP>(rw, first ? W1 : W2, first ? ldw1 : ldw2, col0, n_out, k0, kk, first ? vec1 : vec2);
+    };
+    load_chunk(0);
+    for (int ch = 0; ch < nch; ++ch) {
+        __syncthreads();
+        y3_store<NP>(As, ra);
+        y3_store<NP>(Ws, rw);
+        __syncthreads();
+        if (ch + 1 < nch) load_chunk(ch + 1);   // in flight under the 96 MFMAs below
+        const char* ap = As + (wr * 128 + l31) * XLD + h * 16;
+        const char* bp = Ws + (wc * 64 + l31) * XLD + h * 16;
+#pragma unroll
+        for (int S = 0; S < XK / 16; ++S) {
+            bf16x8_t bf[2][3];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bf[m][p] = *reinterpret_cast<const bf16x8_t*>(bp + m * 32 * XLD + p * 64 + S * 32);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                bf16x8_t af[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const bf16x8_t*>(ap + a * 32 * XLD + p * 64 + S * 32);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    f32x16 c = acc[a][b];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[b][0], c, 0, 0, 0);   // small terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[b][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[b][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[b][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[b][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[b][0], c, 0, 0, 0);
+                    acc[a][b] = c;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int col = col0 + wc * 64 + b * 32 + l31;
+        if (col >= n_out) continue;
+        const float bb = bias ? bias[col] : 0.f;
+        const float sc = scale ? scale[col] : 1.f;
+        const float sh = scale ? shift[col] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + wr * 128 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= M) continue;
+                float v = acc[a][b][r] + bb;
+                if (scale) v = __fmaf_rn(v, sc, sh);
+                if (relu & 1) v = fmaxf(v, 0.f);
+                if (relu & DGNN_LINEAR_ACCUMULATE) v += out[row * ldo + col];
+                out[row * ldo + col] = v;
+            }
+    }
+}
+
 // dW[na, nb] = sum_rows A[r, :]^T B[r, :], fp32 operands split in 3 bf16 parts while they are staged TRANSPOSED ([column][row]):
 // a thread takes 2 consecutive rows x 4 columns, so that a packed bf16 pair is two consecutive k (= rows) of one column.
 // 64 x 64 tile per block, wave (wa, wb) owns a 32 x 32 block; row slices of 32.
@@ -683,6 +820,16 @@ extern "C" int dgnn_linear_fwd_x3(const float* A1, int64_t lda1, int k1, const f
     DGNN_REQUIRE((scale == nullptr) == (shift == nullptr), DGNN_E_INVALID, "linear_fwd_x3: scale/shift must come together");
     const bool v1 = vec_ok(A1, lda1) && vec_ok(W1, ldw1);
     const bool v2 = A2 && vec_ok(A2, lda2) && vec_ok(W2, ldw2);
+    static const bool big_ok = !(getenv("DGNN_X3_BIG") && getenv("DGNN_X3_BIG")[0] == '0');
+    if (big_ok && M >= 8192 && n_out > XN) {   // same arithmetic per output element (chunk order, product order): identical results
+        static bool attr_set[DGNN_MAX_DEVICES];
+        constexpr size_t lds = (size_t)(YM + YN) * XLD;
+        dgnn_allow_dynamic_lds((const void*)k_linear_fwd_x3_big, lds, attr_set);
+        dim3 grid((unsigned)(dgnn_cdiv(M, YM) * dgnn_cdiv(n_out, YN)));
+        hipLaunchKernelGGL(k_linear_fwd_x3_big, grid, dim3(YT), lds, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2, lda2, k2, W2, ldw2, v2,
+                           bias, scale, shift, relu, M, n_out, out, ldo);
+        return dgnn_check_launch("linear_fwd_x3");
+    }
     dim3 grid((unsigned)(dgnn_cdiv(M, XM) * dgnn_cdiv(n_out, XN)));
     hipLaunchKernelGGL(k_linear_fwd_x3, grid, dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2, lda2, k2, W2, ldw2, v2, bias,
                        scale, shift, relu, M, n_out, out, ldo);

@@ -225,3 +225,27 @@ def test_fused_predicate_matches_dispatch_128_to_64():
         ref = onet.inference_layer(Config(x=x, edge_attr=ea, edge_index=ei)).numpy()
     got = net.inference_layer(Config(x=x.to(DEV), edge_attr=ea.to(DEV), edge_index=ei.to(DEV))).cpu().numpy()
     logit_check(got, ref)
+
+
+@pytest.mark.parametrize("k1,k2,n_out", [(256, 256, 512), (128, 128, 256), (70, 0, 300), (512, 512, 1024)])
+def test_x3_gemm_large_tile_equals_the_small_tile_and_fp64(monkeypatch, k1, k2, n_out):
+    """dgnn_linear_fwd_x3 takes a 256 x 256 tile for M >= 8192, n_out > 128: per output element the same chunk and product
+    order as the 128 x 128 tile (reached here by calling it on row slices below the threshold), so results are bit-identical;
+    and both are fp32-class against an fp64 product."""
+    from dgnn_amd import ops
+    monkeypatch.setattr(ops, "GEMM_MODE", ops.GEMM_BF16X3)
+    g = torch.Generator().manual_seed(k1 + n_out)
+    M = 8192 + 2 * 256 + 77                                # ragged last row block
+    A1 = torch.randn(M, k1, generator=g).to(DEV)
+    W1 = (torch.randn(n_out, k1, generator=g) / k1 ** 0.5).to(DEV)
+    A2 = torch.randn(M, k2, generator=g).to(DEV) if k2 else None
+    W2 = (torch.randn(n_out, k2, generator=g) / k2 ** 0.5).to(DEV) if k2 else None
+    bias = torch.randn(n_out, generator=g).to(DEV)
+    big = ops.linear_fwd(A1, W1, A2, W2, bias, relu=True)
+    small = torch.cat([ops.linear_fwd(A1[s:s + 4096], W1, A2[s:s + 4096] if k2 else None, W2, bias, relu=True) for s in range(0, M, 4096)])
+    assert torch.equal(big, small)
+    ref = A1.double() @ W1.double().t() + bias.double()
+    if k2:
+        ref = ref + A2.double() @ W2.double().t()
+    ref = ref.clamp_min(0)
+    assert (big.double() - ref).abs().max().item() <= 4e-6 * ref.abs().max().item()
