@@ -109,6 +109,24 @@ def cpu_oracle(net_sd, convs, x, ea, ei, threads, runs):
     return float(np.median(times)), out
 
 
+def training_leg():
+    """SURVEY 8d "fwd+bwd+Adam, reported separately": tools/bench_train.py (block builder + SurfaceNet.forward in train mode + KL loss +
+    backward + Adam on 2048-target 4-hop blocks of the same scene) run as a child process once the timed inference region is over;
+    returns its JSON line (ms_per_step, targets/s, its own roofline object) or the reason it could not run."""
+    import subprocess
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "bench_train.py"), "--steps", "60", "--warmup", "8"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": "bench_train exited %d: %s" % (r.returncode, r.stderr.strip().splitlines()[-1:] or "")}
+        return json.loads(line[-1])
+    except Exception as e:  # a missing leg must not cost the inference line
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,6 +141,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle legs (and with them the logit check)")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the per-layer replays (the roofline is then reported for the largest layer shape)")
     ap.add_argument("--cached-plan", action="store_true", help="reuse the graph plan across steps (reported, not the metric)")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (tools/bench_train.py as a child process after the "
+                                                            "timed region; its line is nested under `training_step`)")
     ap.add_argument("--gemm-mode", choices=["f32", "bf16x3", "bf16x3f"], default=None,
                     help="dense part of the fused fp32 layer: exact fp32 MFMA, or 3-way split-bf16 MFMA (fp32-class accuracy)")
     args = ap.parse_args()
@@ -418,6 +438,8 @@ def main():
                        "breakdown_ms": {k: round(v, 4) for k, v in breakdown.items()}},
             "roofline": roof, "cpu_baseline": cpu, "check": check,
         }
+        if world == 1 and not args.no_train and args.widths is None and not bf16 and args.points == 150000:
+            out["training_step"] = training_leg()
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

@@ -97,6 +97,8 @@ __global__ void __launch_bounds__(256) k_agg_fwd(const int32_t* __restrict__ row
         float acc[CPL];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) acc[j] = 0.f;
+        // (one edge per iteration: batching the 4 in-edges' loads, which pays in k_agg_bwd, measured 25-35 % SLOWER here -- the
+        // kernel already runs 8 blocks per CU and the wave-uniform attribute rows travel through the scalar cache)
         for (int k = beg; k < end; ++k) {
             const int s = src[k];
             const int64_t e = eid ? eid[k] : k;
@@ -197,48 +199,66 @@ __global__ void __launch_bounds__(256) k_agg_bwd(const int32_t* __restrict__ t_r
         float acc[CPL];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) acc[j] = 0.f;
-        for (int k = beg; k < end; ++k) {
-            const int d = t_dst[k];
-            const int64_t e = t_eid[k];
-            const float cnt = (float)max(rowptr_dst[d + 1] - rowptr_dst[d], 1);
-            Vec<CPL, T> g;
-            if (on) g.load(da + (int64_t)d * ldda + c0);
-            float p[CPL];
-            float A[NW];
-            if (FE > 0) {
-                const float* ar = ea + e * lde;
+        // 4 out-edges per batch: indices first, then every row they point at, then the arithmetic in edge order (see k_agg_fwd)
+        for (int k0 = beg; k0 < end; k0 += 4) {
+            const int nk = min(4, end - k0);
+            int dq[4];
+            int64_t eq[4];
 #pragma unroll
-                for (int f = 0; f < NW; ++f) A[f] = ar[f];
-#pragma unroll
-                for (int j = 0; j < CPL; ++j) {
-                    float t = b[j];
-#pragma unroll
-                    for (int f = 0; f < NW; ++f) t = __fmaf_rn(w[j][f], A[f], t);
-                    p[j] = t;
-                }
-            } else if (FE == 0) {
-                Vec<CPL, T> pr;
-                if (on) pr.load(phi + e * ldphi + c0);
-#pragma unroll
-                for (int j = 0; j < CPL; ++j) p[j] = pr.v[j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < CPL; ++j) p[j] = 1.f;
+            for (int q = 0; q < 4; ++q) {
+                const int kk = k0 + (q < nk ? q : 0);
+                dq[q] = t_dst[kk];
+                eq[q] = t_eid[kk];
             }
-            if (on) {
-                Vec<CPL, T> dph;
+            float cntq[4];
+            Vec<CPL, T> gq[4], prq[4];
+            float A[4][NW];
 #pragma unroll
-                for (int j = 0; j < CPL; ++j) {
-                    const float dm = __fdiv_rn(g.v[j], cnt);
-                    acc[j] = __fadd_rn(acc[j], __fmul_rn(dm, p[j]));
-                    dph.v[j] = __fmul_rn(dm, xs.v[j]);
-                    if (FE > 0) {
-                        gb[j] += dph.v[j];
+            for (int q = 0; q < 4; ++q) {
+                cntq[q] = (float)max(rowptr_dst[dq[q] + 1] - rowptr_dst[dq[q]], 1);
+                if (on) gq[q].load(da + (int64_t)dq[q] * ldda + c0);
+                if (FE > 0) {
+                    const float* ar = ea + eq[q] * lde;
 #pragma unroll
-                        for (int f = 0; f < NW; ++f) gw[j][f] = __fmaf_rn(dph.v[j], A[f], gw[j][f]);
-                    }
+                    for (int f = 0; f < NW; ++f) A[q][f] = ar[f];
+                } else if (FE == 0) {
+                    if (on) prq[q].load(phi + eq[q] * ldphi + c0);
                 }
-                if (FE == 0 && dphi_out) dph.store(dphi_out + e * lddphi + c0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q >= nk) break;
+                float p[CPL];
+                if (FE > 0) {
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        float t = b[j];
+#pragma unroll
+                        for (int f = 0; f < NW; ++f) t = __fmaf_rn(w[j][f], A[q][f], t);
+                        p[j] = t;
+                    }
+                } else if (FE == 0) {
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) p[j] = prq[q].v[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) p[j] = 1.f;
+                }
+                if (on) {
+                    Vec<CPL, T> dph;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        const float dm = __fdiv_rn(gq[q].v[j], cntq[q]);
+                        acc[j] = __fadd_rn(acc[j], __fmul_rn(dm, p[j]));
+                        dph.v[j] = __fmul_rn(dm, xs.v[j]);
+                        if (FE > 0) {
+                            gb[j] += dph.v[j];
+#pragma unroll
+                            for (int f = 0; f < NW; ++f) gw[j][f] = __fmaf_rn(dph.v[j], A[q][f], gw[j][f]);
+                        }
+                    }
+                    if (FE == 0 && dphi_out) dph.store(dphi_out + eq[q] * lddphi + c0);
+                }
             }
         }
         if (on && dx) {
@@ -265,32 +285,33 @@ __global__ void __launch_bounds__(256) k_agg_bwd(const int32_t* __restrict__ t_r
     }
 }
 
-// out[chunk][i] (+)= sum_b slabs[b][chunk][i]; 16 outputs x 16 slices per block: slice s adds slabs s, s+16, ... in order,
-// the 16 slice sums are then added in slice order (deterministic, and not a 512-long dependent chain per output).
-__global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ slabs, int nblocks, int nchunks, int per, int c_in,
-                                                      int fe, int cpl, float* __restrict__ dWe, float* __restrict__ dbe) {
-    __shared__ float red[16][17];
+// out[chunk][i] (+)= sum_b slabs[b][chunk][i]; 16 outputs x 64 slices per block: slice s adds slabs s, s+64, ... in order,
+// the 64 slice sums are then added in slice order (deterministic, and not a 1024-long dependent chain per output).
+constexpr int RS_SLICES = 64;
+__global__ void __launch_bounds__(16 * RS_SLICES) k_reduce_slabs(const float* __restrict__ slabs, int nblocks, int nchunks, int per, int c_in,
+                                                                 int fe, int cpl, float* __restrict__ dWe, float* __restrict__ dbe) {
+    __shared__ float red[RS_SLICES][17];
     const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int i = blockIdx.x * 16 + o;
     const bool live = i < nchunks * per;
     const int chunk = live ? i / per : 0, r = live ? i - chunk * per : 0;
     float p = 0.f;
     if (live)
-        for (int b = sl; b < nblocks; b += 16) p += slabs[((int64_t)b * nchunks + chunk) * per + r];
+        for (int b = sl; b < nblocks; b += RS_SLICES) p += slabs[((int64_t)b * nchunks + chunk) * per + r];
     red[sl][o] = p;
     __syncthreads();
     if (sl != 0 || !live) return;
     const int c = chunk * 64 * cpl + r / (fe + 1), f = r % (fe + 1);
     if (c >= c_in) return;
     float s = 0.f;
-    for (int k = 0; k < 16; ++k) s += red[k][o];
+    for (int k = 0; k < RS_SLICES; ++k) s += red[k][o];
     if (f < fe)
         dWe[(int64_t)c * fe + f] += s;
     else
         dbe[c] += s;
 }
 
-constexpr int BWD_BLOCKS = 512;  // persistent-ish: 2 blocks per CU keeps the slab array small
+constexpr int BWD_BLOCKS = 1024;  // 4 blocks (16 waves) per CU: the kernel lives on memory latency; one slab per block
 
 template <int CPL, typename T = float>
 bool aligned_for(const void* p, int64_t ld) {
@@ -354,7 +375,7 @@ int agg_bwd_t(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
 #undef LAUNCH
     if (fused) {
         const int per = 64 * cpl * (f_e + 1);
-        hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)dgnn_cdiv((int64_t)chunks * per, 16)), dim3(256), 0, stream, partials,
+        hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)dgnn_cdiv((int64_t)chunks * per, 16)), dim3(16 * RS_SLICES), 0, stream, partials,
                            nblocks, chunks, per, c_in, f_e, cpl, dWe, dbe);
     }
     return dgnn_check_launch("aggregate_bwd");

@@ -58,15 +58,16 @@ __global__ void __launch_bounds__(256) k_colreduce(const T* __restrict__ x, int6
     }
 }
 
-// Deterministic two-level finalisers: 256 threads = 16 columns x 16 slices; slice s sums partial blocks s, s+16, ... in
-// ascending order, then the 16 slice sums are added in slice order.  (A single thread per column walking all ~500
-// partial blocks was a 80-90 us dependent-load chain -- 30 % of a training step.)
+// Deterministic two-level finalisers: 1024 threads = 16 columns x 64 slices; slice s sums partial blocks s, s+64, ... in
+// ascending order, then the 64 slice sums are added in slice order.  (A single thread per column walking all ~1000 partial
+// blocks was a 80-90 us dependent-load chain -- 30 % of a training step; 16 slices still left a 64-long chain, 10-20 us.)
+constexpr int FIN_SLICES = 64, FIN_THREADS = 16 * FIN_SLICES;
 __device__ __forceinline__ bool finalize_pair(const double* __restrict__ partials, int nblk, int c, double& s, double& q) {
-    __shared__ double red[2][16][17];
+    __shared__ double red[2][FIN_SLICES][17];
     const int o = threadIdx.x & 15, sl = threadIdx.x >> 4, col = blockIdx.x * 16 + o;
     double ps = 0.0, pq = 0.0;
     if (col < c)
-        for (int b = sl; b < nblk; b += 16) {
+        for (int b = sl; b < nblk; b += FIN_SLICES) {
             ps += partials[((int64_t)b * 2 + 0) * c + col];
             pq += partials[((int64_t)b * 2 + 1) * c + col];
         }
@@ -76,14 +77,14 @@ __device__ __forceinline__ bool finalize_pair(const double* __restrict__ partial
     if (sl != 0 || col >= c) return false;
     s = 0.0;
     q = 0.0;
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < FIN_SLICES; ++k) {
         s += red[0][k][o];
         q += red[1][k][o];
     }
     return true;
 }
 
-__global__ void __launch_bounds__(256) k_stats_finalize(const double* __restrict__ partials, int nblk, int64_t M, int c,
+__global__ void __launch_bounds__(FIN_THREADS) k_stats_finalize(const double* __restrict__ partials, int nblk, int64_t M, int c,
                                                         float* __restrict__ mean, float* __restrict__ var,
                                                         float* __restrict__ rmean, float* __restrict__ rvar, float momentum) {
     double s, q;
@@ -102,7 +103,7 @@ __global__ void __launch_bounds__(256) k_stats_finalize(const double* __restrict
 }
 
 // sums[0][c] = first quantity, sums[1][c] = second (float), optional accumulate into out0/out1
-__global__ void __launch_bounds__(256) k_sum_finalize(const double* __restrict__ partials, int nblk, int c, float* __restrict__ out0,
+__global__ void __launch_bounds__(FIN_THREADS) k_sum_finalize(const double* __restrict__ partials, int nblk, int c, float* __restrict__ out0,
                                                       float* __restrict__ out1, int accumulate, float* __restrict__ copy0,
                                                       float* __restrict__ copy1) {
     double s, q;
@@ -198,7 +199,7 @@ static int bn_batch_stats_t(const T* x, int64_t ldx, int64_t M, int c, float* me
     double* P = as_f64(scratch);
     hipLaunchKernelGGL((k_colreduce<0, T>), dim3(nblk), dim3(256), 0, stream, x, ldx, (const T*)nullptr, (int64_t)0, (const T*)nullptr,
                        (int64_t)0, nullptr, nullptr, 0.f, 0, M, c, rpb, P);
-    hipLaunchKernelGGL(k_stats_finalize, dim3((c + 15) / 16), dim3(256), 0, stream, P, nblk, M, c, mean, var, running_mean,
+    hipLaunchKernelGGL(k_stats_finalize, dim3((c + 15) / 16), dim3(FIN_THREADS), 0, stream, P, nblk, M, c, mean, var, running_mean,
                        running_var, momentum);
     return dgnn_check_launch("bn_batch_stats");
 }
@@ -224,7 +225,7 @@ static int bn_relu_bwd_t(const T* x, int64_t ldx, const T* y, int64_t ldy, const
     double* P = as_f64(scratch);
     float* sums = reinterpret_cast<float*>(P + (int64_t)nblk * 2 * c);
     hipLaunchKernelGGL((k_colreduce<1, T>), dim3(nblk), dim3(256), 0, stream, x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, rpb, P);
-    hipLaunchKernelGGL(k_sum_finalize, dim3((c + 15) / 16), dim3(256), 0, stream, P, nblk, c, sums, sums + c, 0, dbeta, dgamma);
+    hipLaunchKernelGGL(k_sum_finalize, dim3((c + 15) / 16), dim3(FIN_THREADS), 0, stream, P, nblk, c, sums, sums + c, 0, dbeta, dgamma);
     hipLaunchKernelGGL((k_bn_relu_bwd_apply<T>), dim3(dgnn_grid_cap(dgnn_cdiv(M * c, 256))), dim3(256), 0, stream, x, ldx, y, ldy, dy, lddy,
                        gamma, mean, var, eps, train, relu, M, c, sums, sums + c, dx, lddx);
     return dgnn_check_launch("bn_relu_bwd");
@@ -238,7 +239,7 @@ static int colsum_t(const T* x, int64_t ldx, int64_t M, int c, float* out, int a
     double* P = as_f64(scratch);
     hipLaunchKernelGGL((k_colreduce<2, T>), dim3(nblk), dim3(256), 0, stream, x, ldx, (const T*)nullptr, (int64_t)0, (const T*)nullptr,
                        (int64_t)0, nullptr, nullptr, 0.f, 0, M, c, rpb, P);
-    hipLaunchKernelGGL(k_sum_finalize, dim3((c + 15) / 16), dim3(256), 0, stream, P, nblk, c, out, (float*)nullptr, accumulate,
+    hipLaunchKernelGGL(k_sum_finalize, dim3((c + 15) / 16), dim3(FIN_THREADS), 0, stream, P, nblk, c, out, (float*)nullptr, accumulate,
                        (float*)nullptr, (float*)nullptr);
     return dgnn_check_launch("colsum");
 }

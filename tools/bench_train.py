@@ -35,8 +35,10 @@ ap.add_argument("--points", type=int, default=150000)
 ap.add_argument("--batch", type=int, default=2048)
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--warmup", type=int, default=5)
-ap.add_argument("--prefetch", choices=["none", "stream", "thread"], default="thread",
-                help="block builder: in line | one block ahead on a side stream | ahead in a worker thread (default)")
+ap.add_argument("--prefetch", choices=["none", "stream", "thread"], default="stream",
+                help="block builder: in line | one block ahead on a side stream, issued by the library's builder thread (default) | "
+                     "ahead in a Python worker thread")
+ap.add_argument("--no-roofline", action="store_true", help="skip the GEMM / aggregate replays behind the `roofline` object")
 args = ap.parse_args()
 
 rank, local_rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,12 +130,69 @@ if world > 1:
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     dt, block = float(tmax[0]), float(t[1])
+
+
+def replay_roofline():
+    """The step's dominant kernel by GPU time is the fp32-class GEMM (k_linear_fwd_x3, 15 launches per step: conv / decoder GEMMs
+    forward, input gradients backward).  Its launches are replayed at the LAST block's shapes (HIP events on the current stream,
+    10 launches each): achieved = their algorithmic flops / their time.  Peak: the dense bf16 MFMA rate / 6 (every fp32 product
+    is 6 bf16 partial products).  The HBM-bound aggregate backward (k_agg_bwd, the largest single launch) is reported next to it."""
+    from dgnn_amd import ops
+    from dgnn_amd.graph import plan_for
+
+    def timed(f, it=10):
+        f()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(it):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / it
+
+    w = [28, 64, 128, 128, 128]
+    gemms, flops, ms = [], 0.0, 0.0
+    for i, (e, e_id, size) in enumerate(adjs):
+        n_src, n_dst = size
+        gemms.append((n_dst, w[i], w[i], w[i + 1]))                      # z = a.Wj^T + x_dst.Wi^T
+        gemms += [(n_dst, w[i + 1], 0, w[i])] * (2 if i > 0 else 1)      # da = dz.Wj (+ dx_dst += dz.Wi)
+    gemms += [(batch, 128, 0, 64), (batch, 64, 0, 2), (batch, 2, 0, 64), (batch, 64, 0, 128)]   # decoder forward / backward
+    for M, k1, k2, no in gemms:
+        A1, W1 = torch.randn(M, k1, device=dev), torch.randn(no, k1, device=dev)
+        A2, W2 = (torch.randn(M, k2, device=dev), torch.randn(no, k2, device=dev)) if k2 else (None, None)
+        out = torch.empty(M, no, device=dev)
+        ms += timed(lambda: ops.linear_fwd(A1, W1, A2, W2, out=out))
+        flops += 2.0 * M * (k1 + k2) * no
+    e, e_id, size = adjs[1]                     # 64-channel layer: the largest launch that also writes dx
+    plan = plan_for(e, size[0], size[1])
+    tp, rows = plan.transposed, plan.transposed_edge_rows
+    x, da = torch.randn(size[0], 64, device=dev), torch.randn(size[1], 64, device=dev)
+    We, be = torch.randn(64, 20, device=dev), torch.randn(64, device=dev)
+    t_b = timed(lambda: ops.aggregate_bwd(tp[0], tp[1], rows if rows is not None else tp[2], size[0], plan.rowptr, x, da, all_.edge_attr if rows is not None
+                                          else all_.edge_attr[e_id], We, be))
+    bytes_b = size[0] * 64 * 4 * 2 + e.size(1) * 88 + size[1] * 64 * 4 + size[0] * 4
+    peak = 2500.0 / 6
+    # primary object: the HBM-bound gather / scatter kernel with the longest single launch; the GEMMs (largest share of the
+    # step's GPU time, but 15 small launches: M <= 70k rows, K <= 256) are reported next to it
+    return {"bound": "hbm", "kernel": "k_agg_bwd<1,20> (64 channels: the longest single launch of the step; gathers da rows, recomputes the filter, "
+                                       "writes dx, dWe, dbe)", "achieved": round(bytes_b / t_b / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(bytes_b / t_b / 1e6 / 8000.0, 4), "traffic": None, "algorithmic_bytes_per_launch": bytes_b, "avg_launch_ms": round(t_b, 4),
+            "timing": "each launch replayed 10x at the last block's shapes, HIP events on the launching stream",
+            "gemm": {"bound": "mfma", "kernel": "k_linear_fwd_x3 (%d launches per step: conv / decoder GEMMs forward, input gradients backward)" % len(gemms),
+                     "achieved": round(flops / ms / 1e9, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(flops / ms / 1e9 / peak, 4),
+                     "algorithmic_flops_per_step": flops, "gemm_ms_per_step": round(ms, 4),
+                     "peak_note": "dense bf16 MFMA 2.5 PFLOP/s / 6 partial products per fp32-class product; launches of 2k..70k rows are latency-bound"}}
+
+
+roof = None
+if rank == 0 and not args.no_roofline and not args.updated and args.dtype == "f32":
+    roof = replay_roofline()
 if rank == 0:
     print(json.dumps({"metric": "training step (block builder + fwd + bwd + %sAdam), %d x MI355X" % ("gradient all-reduce + " if world > 1 else "", world),
                       "model": "UpdatedEdgeFilters sage+" if args.updated else "StaticEdgeFilters", "dtype": args.dtype, "n_gpus": world,
                       "parallelism": "data-parallel replicas, one scene shard per GPU, flat RCCL all-reduce" if world > 1 else "single GPU",
                       "targets_per_s": round(batch * steps * world / dt, 1), "block_tets_per_s": round(block / dt, 1),
                       "ms_per_step": round(dt / steps * 1e3, 3), "batch_targets_per_gpu": batch,
-                      "avg_block_tets": round(block / steps / world, 1), "steps": steps, "block_builder": args.prefetch, "scene_tets_per_gpu": n, "final_loss": float(loss)}))
+                      "avg_block_tets": round(block / steps / world, 1), "steps": steps, "block_builder": args.prefetch, "scene_tets_per_gpu": n, "final_loss": float(loss), "roofline": roof}))
 if world > 1:
     dist.destroy_process_group()

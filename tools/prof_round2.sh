@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 T=$1; shift
-B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $@"
+B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${T}_trace -- $B > gpurun_out/${T}_trace.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d gpurun_out/${T}_pmc1 -- $B > gpurun_out/${T}_pmc1.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS --output-format csv -d gpurun_out/${T}_pmc2 -- $B > gpurun_out/${T}_pmc2.log 2>&1
