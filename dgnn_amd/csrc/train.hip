@@ -135,3 +135,161 @@ extern "C" int dgnn_sage_layer_train_bwd(const int32_t* t_rowptr, const int32_t*
     }
     return dgnn_check_launch("sage_layer_train_bwd");
 }
+
+// =====================================================================================================================
+// Updated variant (surfaceNetUpdatedEdgeFilters.py:147-170 and its autograd): one conv layer per call each way, fp32 or bf16
+// storage (activations / phi bf16, parameters and their gradients fp32).
+//   forward : phi = ea.We^T + be  [E, c_in]   ->   a = mean_j x_j * phi   ->   y = relu?(a.Wl^T + x[:n_dst].Wr^T + bl)
+//   backward: dz = dy * [y > 0]; dWl, dbl, dWr; da = dz.Wl; (dx, dphi) = aggregate backward; dx[:n_dst] += dz.Wr;
+//             dphi += dphi_ext (the next layer's use of phi as its edge input); dWe = dphi^T ea, dbe, d_ea = dphi.We
+// The same kernels in the same order as the separate entry points (bit-identical results).
+// =====================================================================================================================
+namespace {
+
+template <typename T>
+__global__ void k_add_inplace(T* __restrict__ a, const T* __restrict__ b, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dgnn_st(a + i, dgnn_ld(a + i) + dgnn_ld(b + i));
+}
+
+// the two storage types behind one set of names
+struct F32 {
+    typedef float T;
+    static int linear(const T* A1, int64_t lda1, int k1, const float* W1, int64_t ldw1, const T* A2, int64_t lda2, int k2, const float* W2, int64_t ldw2,
+                      const float* bias, int flags, int64_t M, int n, T* out, int64_t ldo, int mode, void* st) {
+        return mode == DGNN_GEMM_F32 ? dgnn_linear_fwd(A1, lda1, k1, W1, ldw1, A2, lda2, k2, W2, ldw2, bias, nullptr, nullptr, flags, M, n, out, ldo, st)
+                                     : dgnn_linear_fwd_x3(A1, lda1, k1, W1, ldw1, A2, lda2, k2, W2, ldw2, bias, nullptr, nullptr, flags, M, n, out, ldo, st);
+    }
+    static int wgrad(const T* A, int64_t lda, int na, const T* B, int64_t ldb, int nb, int64_t M, float* dW, float* tmp, int mode, void* st) {
+        return mode == DGNN_GEMM_F32 ? dgnn_linear_wgrad(A, lda, na, B, ldb, nb, M, dW, nb, 0, tmp, st)
+                                     : dgnn_linear_wgrad_x3(A, lda, na, B, ldb, nb, M, dW, nb, 0, tmp, st);
+    }
+    static int colsum(const T* x, int64_t ld, int64_t M, int c, float* out, float* tmp, void* st) { return dgnn_colsum(x, ld, M, c, out, 0, tmp, st); }
+    static int relu_bwd(const T* y, const T* g, int64_t n, T* out, void* st) { return dgnn_relu_bwd(y, g, n, out, st); }
+    static int agg_fwd(const int32_t* rp, const int32_t* src, const int32_t* eid, int64_t n_dst, const T* x, int64_t ldx, int c, const T* phi, T* a, void* st) {
+        return dgnn_sage_aggregate_fwd(rp, src, eid, n_dst, x, ldx, c, nullptr, 0, 0, nullptr, nullptr, phi, c, nullptr, 0, a, c, st);
+    }
+    static int agg_bwd(const int32_t* trp, const int32_t* td, const int32_t* te, int64_t n_src, const int32_t* rpd, const T* x, int64_t ldx, int c, const T* phi,
+                       const T* da, T* dx, T* dphi, void* st) {
+        return dgnn_sage_aggregate_bwd(trp, td, te, n_src, rpd, x, ldx, c, nullptr, 0, 0, nullptr, nullptr, phi, c, da, c, dx, c, nullptr, nullptr, dphi, c, nullptr, st);
+    }
+};
+struct BF16 {
+    typedef uint16_t T;
+    static int linear(const T* A1, int64_t lda1, int k1, const float* W1, int64_t ldw1, const T* A2, int64_t lda2, int k2, const float* W2, int64_t ldw2,
+                      const float* bias, int flags, int64_t M, int n, T* out, int64_t ldo, int, void* st) {
+        return dgnn_linear_fwd_bf16(A1, lda1, k1, W1, ldw1, A2, lda2, k2, W2, ldw2, bias, nullptr, nullptr, flags, M, n, out, ldo, 0, st);
+    }
+    static int wgrad(const T* A, int64_t lda, int na, const T* B, int64_t ldb, int nb, int64_t M, float* dW, float* tmp, int, void* st) {
+        return dgnn_linear_wgrad_bf16(A, 0, lda, na, B, 0, ldb, nb, M, dW, nb, 0, tmp, st);
+    }
+    static int colsum(const T* x, int64_t ld, int64_t M, int c, float* out, float* tmp, void* st) { return dgnn_colsum_bf16(x, ld, M, c, out, 0, tmp, st); }
+    static int relu_bwd(const T* y, const T* g, int64_t n, T* out, void* st) { return dgnn_relu_bwd_bf16(y, g, n, out, st); }
+    static int agg_fwd(const int32_t* rp, const int32_t* src, const int32_t* eid, int64_t n_dst, const T* x, int64_t ldx, int c, const T* phi, T* a, void* st) {
+        return dgnn_sage_aggregate_fwd_bf16(rp, src, eid, n_dst, x, ldx, c, nullptr, 0, 0, nullptr, nullptr, phi, c, nullptr, 0, a, c, st);
+    }
+    static int agg_bwd(const int32_t* trp, const int32_t* td, const int32_t* te, int64_t n_src, const int32_t* rpd, const T* x, int64_t ldx, int c, const T* phi,
+                       const T* da, T* dx, T* dphi, void* st) {
+        return dgnn_sage_aggregate_bwd_bf16(trp, td, te, n_src, rpd, x, ldx, c, nullptr, 0, 0, nullptr, nullptr, phi, c, da, c, dx, c, nullptr, nullptr, dphi, c, nullptr,
+                                            st);
+    }
+};
+
+inline void transpose_to(const float* W, int rows, int cols, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_transpose, dim3(dgnn_grid_cap(dgnn_cdiv((int64_t)rows * cols, 256))), dim3(256), 0, stream, W, rows, cols, out);
+}
+
+template <typename K>
+int updated_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const void* x_, int64_t ldx, int c_in, const void* ea_,
+                int64_t lde, int k_e, int64_t E, const float* We, const float* be, const float* Wl, const float* bl, const float* Wr, int c_out, int relu,
+                void* phi_, void* a_, void* y_, int mode, void* st) {
+    typedef typename K::T T;
+    const T *x = (const T*)x_, *ea = (const T*)ea_;
+    T *phi = (T*)phi_, *a = (T*)a_, *y = (T*)y_;
+    if (E > 0) TRY(K::linear(ea, lde, k_e, We, k_e, nullptr, 0, 0, nullptr, 0, be, 0, E, c_in, phi, c_in, mode, st));                     // :156
+    TRY(K::agg_fwd(rowptr, src, eid, n_dst, x, ldx, c_in, phi, a, st));                                                                   // :158
+    TRY(K::linear(a, c_in, c_in, Wl, c_in, Wr ? x : nullptr, ldx, Wr ? c_in : 0, Wr, c_in, bl, relu ? 1 : 0, n_dst, c_out, y, c_out, mode, st));   // :159-165
+    return DGNN_OK;
+}
+
+template <typename K>
+int updated_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, const int32_t* rowptr_dst, int64_t n_src, int64_t n_dst, int64_t E,
+                const void* x_, int64_t ldx, int c_in, const void* ea_, int64_t lde, int k_e, const float* We, const float* Wl, const float* Wr, int c_out,
+                int relu, const void* phi_, const void* a_, const void* y_, const void* dy_, const void* dphi_ext_, void* dx_, void* d_ea_, float* dWe,
+                float* dbe, float* dWl, float* dbl, float* dWr, void* dz_, void* da_, void* dphi_, float* scratch, int mode, void* st) {
+    typedef typename K::T T;
+    hipStream_t stream = (hipStream_t)st;
+    const T *x = (const T*)x_, *ea = (const T*)ea_, *phi = (const T*)phi_, *a = (const T*)a_, *y = (const T*)y_, *dy = (const T*)dy_,
+            *dphi_ext = (const T*)dphi_ext_;
+    T *dx = (T*)dx_, *d_ea = (T*)d_ea_, *dz = (T*)dz_, *da = (T*)da_, *dphi = (T*)dphi_;
+    float* WlT = scratch;
+    float* WrT = WlT + align4((int64_t)c_in * c_out);
+    float* WeT = WrT + align4((int64_t)c_in * c_out);
+    float* tmp = WeT + align4((int64_t)c_in * k_e);
+    const T* g = dy;
+    if (relu) {
+        TRY(K::relu_bwd(y, dy, n_dst * c_out, dz, st));
+        g = dz;
+    }
+    TRY(K::wgrad(g, c_out, c_out, a, c_in, c_in, n_dst, dWl, tmp, mode, st));
+    if (dbl) TRY(K::colsum(g, c_out, n_dst, c_out, dbl, tmp, st));
+    if (Wr && dWr) TRY(K::wgrad(g, c_out, c_out, x, ldx, c_in, n_dst, dWr, tmp, mode, st));
+    transpose_to(Wl, c_out, c_in, WlT, stream);
+    TRY(K::linear(g, c_out, c_out, WlT, c_out, nullptr, 0, 0, nullptr, 0, nullptr, 0, n_dst, c_in, da, c_in, mode, st));
+    TRY(K::agg_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x, ldx, c_in, phi, da, dx, dphi, st));
+    if (dx && Wr) {
+        transpose_to(Wr, c_out, c_in, WrT, stream);
+        TRY(K::linear(g, c_out, c_out, WrT, c_out, nullptr, 0, 0, nullptr, 0, nullptr, DGNN_LINEAR_ACCUMULATE, n_dst, c_in, dx, c_in, mode, st));
+    }
+    if (E > 0) {
+        if (dphi_ext)
+            hipLaunchKernelGGL((k_add_inplace<T>), dim3(dgnn_grid_cap(dgnn_cdiv(E * c_in, 256))), dim3(256), 0, stream, dphi, dphi_ext, E * c_in);
+        TRY(K::wgrad(dphi, c_in, c_in, ea, lde, k_e, E, dWe, tmp, mode, st));
+        TRY(K::colsum(dphi, c_in, E, c_in, dbe, tmp, st));
+        if (d_ea) {
+            transpose_to(We, c_in, k_e, WeT, stream);
+            TRY(K::linear(dphi, c_in, c_in, WeT, c_in, nullptr, 0, 0, nullptr, 0, nullptr, 0, E, k_e, d_ea, k_e, mode, st));
+        }
+    } else {
+        (void)hipMemsetAsync(dWe, 0, sizeof(float) * (size_t)c_in * k_e, stream);
+        (void)hipMemsetAsync(dbe, 0, sizeof(float) * (size_t)c_in, stream);
+    }
+    return dgnn_check_launch("sage_updated_train_bwd");
+}
+
+}  // namespace
+
+extern "C" int64_t dgnn_sage_updated_train_scratch_elems(int64_t n_dst, int64_t E, int c_in, int c_out, int k_e) {
+    if (n_dst < 0 || E < 0 || c_in <= 0 || c_out <= 0 || k_e <= 0) return 16;
+    int64_t big = dgnn_colstats_scratch_elems(n_dst > E ? n_dst : E, c_in > c_out ? c_in : c_out);
+    const int64_t w1 = dgnn_linear_wgrad_scratch_elems(n_dst, c_out, c_in), w2 = dgnn_linear_wgrad_scratch_elems(E, c_in, k_e);
+    if (w1 > big) big = w1;
+    if (w2 > big) big = w2;
+    return 2 * align4((int64_t)c_in * c_out) + align4((int64_t)c_in * k_e) + align4(big) + 64;
+}
+
+extern "C" int dgnn_sage_updated_train_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const void* x, int64_t ldx,
+                                           int c_in, const void* ea, int64_t lde, int k_e, int64_t E, const float* We, const float* be,
+                                           const float* Wl, const float* bl, const float* Wr, int c_out, int relu, void* phi, void* a, void* y,
+                                           int bf16, int gemm_mode, void* stream) {
+    DGNN_REQUIRE(n_dst > 0 && E >= 0 && c_in > 0 && c_out > 0 && k_e > 0, DGNN_E_INVALID, "sage_updated_train_fwd: bad sizes");
+    DGNN_REQUIRE(rowptr && src && x && We && be && Wl && phi && a && y && (E == 0 || ea), DGNN_E_INVALID, "sage_updated_train_fwd: null pointer");
+    return bf16 ? updated_fwd<BF16>(rowptr, src, eid, n_dst, x, ldx, c_in, ea, lde, k_e, E, We, be, Wl, bl, Wr, c_out, relu, phi, a, y, gemm_mode, stream)
+                : updated_fwd<F32>(rowptr, src, eid, n_dst, x, ldx, c_in, ea, lde, k_e, E, We, be, Wl, bl, Wr, c_out, relu, phi, a, y, gemm_mode, stream);
+}
+
+extern "C" int dgnn_sage_updated_train_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, const int32_t* rowptr_dst,
+                                           int64_t n_src, int64_t n_dst, int64_t E, const void* x, int64_t ldx, int c_in, const void* ea, int64_t lde,
+                                           int k_e, const float* We, const float* Wl, const float* Wr, int c_out, int relu, const void* phi,
+                                           const void* a, const void* y, const void* dy, const void* dphi_ext, void* dx, void* d_ea, float* dWe,
+                                           float* dbe, float* dWl, float* dbl, float* dWr, void* dz, void* da, void* dphi, float* scratch, int bf16,
+                                           int gemm_mode, void* stream) {
+    DGNN_REQUIRE(n_dst > 0 && n_src >= n_dst && E >= 0 && c_in > 0 && c_out > 0 && k_e > 0, DGNN_E_INVALID, "sage_updated_train_bwd: bad sizes");
+    DGNN_REQUIRE(t_rowptr && t_dst && t_eid && rowptr_dst && x && We && Wl && phi && a && dy && dWe && dbe && dWl && da && dphi && scratch &&
+                     (!relu || (y && dz)) && (E == 0 || ea),
+                 DGNN_E_INVALID, "sage_updated_train_bwd: null pointer");
+    return bf16 ? updated_bwd<BF16>(t_rowptr, t_dst, t_eid, rowptr_dst, n_src, n_dst, E, x, ldx, c_in, ea, lde, k_e, We, Wl, Wr, c_out, relu, phi, a, y, dy,
+                                    dphi_ext, dx, d_ea, dWe, dbe, dWl, dbl, dWr, dz, da, dphi, scratch, gemm_mode, stream)
+                : updated_bwd<F32>(t_rowptr, t_dst, t_eid, rowptr_dst, n_src, n_dst, E, x, ldx, c_in, ea, lde, k_e, We, Wl, Wr, c_out, relu, phi, a, y, dy,
+                                   dphi_ext, dx, d_ea, dWe, dbe, dWl, dbl, dWr, dz, da, dphi, scratch, gemm_mode, stream);
+}

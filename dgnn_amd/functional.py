@@ -180,6 +180,42 @@ def sage_train_layer_supported(x, lin_e, bn) -> bool:
             and isinstance(bn, torch.nn.BatchNorm1d) and bn.training and bn.affine and bn.running_mean is not None)
 
 
+class _SageUpdatedLayer(torch.autograd.Function):
+    """(y, phi) of one Updated-variant conv (reference surfaceNetUpdatedEdgeFilters.py:147-170) with the ReLU that follows it
+    (:239-247), one library call forward and one backward (csrc/train.hip); fp32 or bf16 storage."""
+
+    @staticmethod
+    def forward(ctx, x, ea, We, be, Wl, bl, Wr, plan, relu):
+        y, phi, a = ops.sage_updated_train_fwd((plan.rowptr, plan.src, plan.eid), plan.n_dst, x, ea, We, be, Wl, bl, Wr, relu)
+        ctx.plan = plan
+        ctx.edge_index = plan.edge_index   # the lazily built transposed plan (backward) reads it
+        ctx.cfg = (bool(relu), bl is not None)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x, ea, We, Wl, Wr, phi, a, y)
+        return y, phi
+
+    @staticmethod
+    def backward(ctx, dy, dphi_ext):
+        x, ea, We, Wl, Wr, phi, a, y = ctx.saved_tensors
+        relu, has_bias = ctx.cfg
+        plan = ctx.plan
+        if dy is None:
+            dy = torch.zeros_like(y)
+        dx, d_ea, dWe, dbe, dWl, dbl, dWr = ops.sage_updated_train_bwd(
+            plan.transposed, plan.rowptr, plan.n_src, plan.n_dst, x, ea, We, Wl, Wr, has_bias, relu, phi, a, y, dy.contiguous(),
+            dphi_ext.contiguous() if dphi_ext is not None else None, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dx, d_ea, dWe, dbe, dWl, dbl, dWr, None, None
+
+
+def sage_updated_layer(x, plan, ea, lin_e, lin_l, lin_r, relu):
+    return _SageUpdatedLayer.apply(x, ea, lin_e.weight, lin_e.bias, lin_l.weight, lin_l.bias, lin_r.weight if lin_r is not None else None, plan, relu)
+
+
+def sage_updated_layer_supported(x, ea, lin_e) -> bool:
+    return (ops.TRAIN_COMPOSITE and x.dim() == 2 and x.dtype in ops.ACT and x.stride(1) == 1 and x.size(0) > 0 and ea.dim() == 2 and ea.dtype == x.dtype
+            and ea.stride(1) == 1 and lin_e.bias is not None and (x.dtype == torch.float32 or (x.size(1) % 2 == 0 and x.stride(0) % 2 == 0)))
+
+
 class _KLCellLoss(torch.autograd.Function):
     """volume-weighted KL cell loss (reference learning/runModel.py:171-209) -> (loss, sums[3] = sum cell*w, sum w, OA count)"""
 

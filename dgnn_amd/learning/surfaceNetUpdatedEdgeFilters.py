@@ -124,6 +124,7 @@ class SurfaceNet(nn.Module):
         edge_attr = _dev_f32(data_all.edge_attr, dev)
         n_edges = edge_attr.size(0)
         phi = e_prev = None
+        plus = self.clf.training.model_name[-1] == "+"
         for i in range(self.num_layers):
             edge_index, e_id, size = data_all.adjs[i]
             e_id = e_id.to(dev)
@@ -135,13 +136,20 @@ class SurfaceNet(nn.Module):
                 ea = Fn.chain_edges(phi, e_prev, e_id, conv.edge_in_channels, self._chain_table(n_edges, dev), relu=True)
             else:
                 ea = Fn.gather_rows(Fn.relu(Fn.scatter_rows(phi, e_prev, n_edges)), e_id, conv.edge_in_channels)
-            x, phi = conv((x, x[:size[1]]), ea, edge_index.to(dev))
+            last = i == self.num_layers - 1
+            relu_after = (not last) or plus        # :239-241 between layers; :245-246 F.relu + out_net[0] after the last one of "sage+"
+            ea_in = Fn.to_bf16(ea) if x.dtype == torch.bfloat16 else ea               # bf16 storage: phi is written once in bf16
+            if not conv.normalize and Fn.sage_updated_layer_supported(x, ea_in, conv.lin_e):
+                # conv (+ the ReLU that follows it) as one library call forward, one backward
+                edge_index = edge_index.to(dev)
+                x, phi = Fn.sage_updated_layer(x, plan_for(edge_index, x.size(0), size[1]), ea_in, conv.lin_e, conv.lin_l, conv.lin_r, relu_after)
+            else:
+                x, phi = conv((x, x[:size[1]]), ea, edge_index.to(dev))
+                if relu_after:
+                    x = Fn.relu(x)  # after the last layer: F.relu(x) and out_net[0], another ReLU -- relu(relu(x)) == relu(x)
             e_prev = e_id
-            if i != self.num_layers - 1:                                              # :239-241
-                x = Fn.relu(x)
         # (the last layer's new_edge_attr, :236-237, is never read)
-        if self.clf.training.model_name[-1] == "+":                                   # :245-247
-            x = Fn.relu(x)  # F.relu(x) and out_net[0], another ReLU: relu(relu(x)) == relu(x), values and gradient mask alike
+        if plus:                                                                      # :245-247
             x = Fn.linear2(x, self.out_net[1].weight, bias=self.out_net[1].bias)
             x = Fn.relu(x)
             x = Fn.linear2(x, self.out_net[3].weight, bias=self.out_net[3].bias, out_f32=True)

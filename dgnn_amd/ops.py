@@ -575,3 +575,48 @@ def kl_cell_loss_bwd(logits, gt, vol, norm: int, sums, grad_loss):
     check(lib().dgnn_kl_cell_loss_bwd(ptr(logits), _ld(logits), ptr(gt), _ld(gt), ptr(vol), vol.stride(0), int(norm), logits.size(0), ptr(sums),
                                       ptr(grad_loss), ptr(dl), 2, stream_ptr()), "dgnn_kl_cell_loss_bwd")
     return dl
+
+
+# ---- Updated variant: one conv layer per call each way (csrc/train.hip) --------------------------------------------------------
+@on_device_of
+def sage_updated_train_fwd(plan_parts, n_dst, x, ea, We, be, Wl, bl, Wr, relu):
+    """-> (y [n_dst,c_out], phi [E,c_in], a [n_dst,c_in]) in the storage type of x (fp32 or bf16)"""
+    _req(x, "x", ACT, dim=2)
+    _same(_req(ea, "edge_attr", ACT, dim=2), x, "edge_attr")
+    rowptr, src, eid = plan_parts
+    c_in, c_out, k_e, E = x.size(1), Wl.size(0), We.size(1), ea.size(0)
+    if We.size(0) != c_in or ea.size(1) != k_e or Wl.size(1) != c_in:
+        raise ValueError("Updated conv: lin_e %s / lin_l %s do not match x %s, edge_attr %s" % (tuple(We.shape), tuple(Wl.shape), tuple(x.shape), tuple(ea.shape)))
+    phi = torch.empty((E, c_in), dtype=x.dtype, device=x.device)
+    a = torch.empty((n_dst, c_in), dtype=x.dtype, device=x.device)
+    y = torch.empty((n_dst, c_out), dtype=x.dtype, device=x.device)
+    check(lib().dgnn_sage_updated_train_fwd(ptr(rowptr), ptr(src), ptr(eid), n_dst, ptr(x), _ld(x), c_in, ptr(ea), _ld(ea), k_e, E, ptr(We), ptr(be), ptr(Wl),
+                                            ptr(bl), ptr(Wr), c_out, int(bool(relu)), ptr(phi), ptr(a), ptr(y), int(x.dtype == torch.bfloat16), GEMM_MODE,
+                                            stream_ptr()), "dgnn_sage_updated_train_fwd")
+    return y, phi, a
+
+
+@on_device_of
+def sage_updated_train_bwd(t_parts, rowptr_dst, n_src, n_dst, x, ea, We, Wl, Wr, has_bias, relu, phi, a, y, dy, dphi_ext, need_dx, need_dea):
+    """-> (dx | None, d_ea | None, dWe, dbe, dWl, dbl | None, dWr | None); parameter gradients are views of one fp32 buffer"""
+    c_in, c_out, k_e, E = x.size(1), Wl.size(0), We.size(1), ea.size(0)
+    dev, dt = x.device, x.dtype
+    sizes = [c_in * k_e, c_in, c_out * c_in, c_out if has_bias else 0, c_out * c_in if Wr is not None else 0]
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+    parts, o = [], 0
+    for sz in sizes:
+        parts.append(flat[o:o + sz] if sz else None)
+        o += sz
+    dWe, dbe, dWl, dbl, dWr = parts
+    dx = torch.empty((n_src, c_in), dtype=dt, device=dev) if need_dx else None
+    d_ea = torch.empty((E, k_e), dtype=dt, device=dev) if need_dea else None
+    dz = torch.empty((n_dst, c_out), dtype=dt, device=dev) if relu else None
+    da = torch.empty((n_dst, c_in), dtype=dt, device=dev)
+    dphi = torch.empty((max(E, 1), c_in), dtype=dt, device=dev)
+    scratch = _f32(lib().dgnn_sage_updated_train_scratch_elems(n_dst, E, c_in, c_out, k_e), dev)
+    t_rowptr, t_dst, t_eid = t_parts
+    check(lib().dgnn_sage_updated_train_bwd(ptr(t_rowptr), ptr(t_dst), ptr(t_eid), ptr(rowptr_dst), n_src, n_dst, E, ptr(x), _ld(x), c_in, ptr(ea), _ld(ea), k_e,
+                                            ptr(We), ptr(Wl), ptr(Wr), c_out, int(bool(relu)), ptr(phi), ptr(a), ptr(y), ptr(dy), ptr(dphi_ext), ptr(dx), ptr(d_ea),
+                                            ptr(dWe), ptr(dbe), ptr(dWl), ptr(dbl), ptr(dWr), ptr(dz), ptr(da), ptr(dphi), ptr(scratch),
+                                            int(dt == torch.bfloat16), GEMM_MODE, stream_ptr()), "dgnn_sage_updated_train_bwd")
+    return (dx, d_ea, dWe.view(c_in, k_e), dbe, dWl.view(c_out, c_in), dbl, dWr.view(c_out, c_in) if dWr is not None else None)

@@ -248,6 +248,27 @@ int dgnn_edge_chain_bwd_bf16(const uint16_t* g, int64_t ldg, const uint16_t* phi
                              int c_tot, int relu, uint16_t* dphi, int64_t lddphi, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Updated variant, one conv layer per call each way (surfaceNetUpdatedEdgeFilters.py:147-170 and its autograd); `bf16` != 0:
+ * x / ea / phi / a / y / dy and the gradients of activations are bf16 (uint16_t), parameters and their gradients fp32.
+ *   forward : phi [E,c_in] = ea.We^T + be;  a [n_dst,c_in] = mean_j x_j * phi;  y [n_dst,c_out] = relu?(a.Wl^T + x[:n_dst].Wr^T + bl)
+ *   backward: dy (+ dphi_ext [E,c_in], the gradient reaching phi through the next layer's edge input, or NULL) ->
+ *             dx [n_src,c_in] (NULL: not needed), d_ea [E,k_e] (NULL: not needed), dWe, dbe, dWl, dbl (NULL: no bias), dWr;
+ *             dz [n_dst,c_out] (relu only), da [n_dst,c_in], dphi [E,c_in] are work buffers of the activations' type,
+ *             scratch = dgnn_sage_updated_train_scratch_elems floats.  Plans as dgnn_sage_aggregate_fwd / _bwd.
+ * The launch chain of the separate entry points in the same order; nothing allocates or synchronises.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t dgnn_sage_updated_train_scratch_elems(int64_t n_dst, int64_t E, int c_in, int c_out, int k_e);
+int dgnn_sage_updated_train_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const void* x, int64_t ldx, int c_in,
+                                const void* ea, int64_t lde, int k_e, int64_t E, const float* We, const float* be, const float* Wl,
+                                const float* bl, const float* Wr, int c_out, int relu, void* phi, void* a, void* y, int bf16, int gemm_mode,
+                                void* stream);
+int dgnn_sage_updated_train_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, const int32_t* rowptr_dst, int64_t n_src,
+                                int64_t n_dst, int64_t E, const void* x, int64_t ldx, int c_in, const void* ea, int64_t lde, int k_e,
+                                const float* We, const float* Wl, const float* Wr, int c_out, int relu, const void* phi, const void* a,
+                                const void* y, const void* dy, const void* dphi_ext, void* dx, void* d_ea, float* dWe, float* dbe, float* dWl,
+                                float* dbl, float* dWr, void* dz, void* da, void* dphi, float* scratch, int bf16, int gemm_mode, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Volume-weighted KL cell loss of the training step (learning/runModel.py:171-209), one launch each way:
  *   cell_k = sum_c kl_div(log_softmax(logits_k)_c, gt_kc);  w_k = vol_k | log(1+vol_k) | sqrt(vol_k)  (norm 0 | 1 | 2)
  *   loss = sum cell_k w_k / sum w_k;   sums[3] (fp64) = sum cell_k w_k, sum w_k, #{k: [gt_k0 > gt_k1] == argmax logits_k}

@@ -350,3 +350,42 @@ def test_prefetching_block_builder_yields_the_same_blocks_and_plans(mode):
             for a, b in zip(plan.transposed, t_ref):
                 assert torch.equal(a, b)
             assert torch.equal(plan.edge_rows.long(), i2) and torch.equal(plan.transposed_edge_rows.long(), i2[t_ref[2].long()])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", ["sage+", "sage"])
+def test_updated_composite_layer_matches_the_separate_calls(monkeypatch, dtype, name):
+    """dgnn_sage_updated_train_fwd / _bwd (one library call per conv each way) vs the chain of separate Functions: fp32 is
+    bit-identical (same kernels, same order); bf16 storage differs only where the composite adds dz.Wr into dx before rounding
+    to bf16 instead of after (one rounding instead of two), so it is compared at bf16 resolution."""
+    from dgnn_amd import ops
+    from dgnn_amd.learning import surfaceNetUpdatedEdgeFilters as U
+    from dgnn_amd.sampler import NeighborSampler
+    from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal
+    adj, _, _ = delaunay_tet_graph(3000, seed=4)
+    n = adj.shape[0] // 4
+    ei = torch.from_numpy(adj.T.astype(np.int64)).to(DEV)
+    x = hashed_normal(np.arange(n), 29, seed=5, device=DEV)
+    ea = hashed_normal(np.arange(4 * n), 20, seed=6, device=DEV)
+    _, n_id, adjs = NeighborSampler(ei, sizes=[-1] * 4, num_nodes=n, batch_size=257).sample(torch.arange(100, 357, device=DEV))
+    G = hashed_normal(np.arange(257), 2 if name == "sage+" else 128, seed=7, device=DEV)
+    clf = Config.wrap(dict(training=dict(model_params=[64, 128, 128, 128], model_name=name, loss="kl"),
+                           features=dict(normalization_feature=1, keep_normalization_feature=0), temp=dict(device=DEV)))
+    torch.manual_seed(1)
+    sd = U.SurfaceNet(28, clf).state_dict()
+    res = []
+    for composite in (True, False):
+        monkeypatch.setattr(ops, "TRAIN_COMPOSITE", composite)
+        net = U.SurfaceNet(28, clf)
+        net.load_state_dict(sd)
+        net = net.to(DEV).set_storage_dtype(dtype)
+        logits = net(Config(x=x, edge_attr=ea, n_id=n_id, adjs=adjs))
+        (logits * G).sum().backward()
+        res.append((logits.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()}))
+    (la, ga), (lb, gb) = res
+    assert torch.equal(la, lb)                      # forward: identical in both storage types
+    for k in ga:
+        if dtype == torch.float32:
+            assert torch.equal(ga[k], gb[k]), k
+        else:
+            assert (ga[k] - gb[k]).abs().max().item() <= 2e-2 * gb[k].abs().max().item() + 1e-6, (k, (ga[k] - gb[k]).abs().max().item(), gb[k].abs().max().item())
