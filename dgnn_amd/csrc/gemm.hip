@@ -369,7 +369,10 @@ __global__ void __launch_bounds__(256) k_linear_wgrad_b(const TA* __restrict__ A
 // when ops.GEMM_MODE is not "f32".
 //
 // k_linear_fwd_x3: 128 x 128 output tile per 256-thread block, wave (wr, wc) owns a 64 x 64 quadrant = 2 x 2 MFMA blocks
-// (4 accumulators); K is walked in chunks of 32 over [A1 | A2].  LDS row = [hi | mid | lo] x 32 bf16 + 16 B pad = 208 B (an odd
+// (4 accumulators); K is walked in chunks of 32 over [A1 | A2].  What-if builds (-DDGNN_WHATIF_NO_SPLIT / _NO_GLOBAL / _NO_MFMA,
+// tools/dbg_gemm2.py; M = 1M, K = 256+256, N = 512, 3.95 ms): without the split and LDS stores 3.92 ms, without global loads 2.86,
+// without fragment reads + MFMAs 2.75 -- the split VALU is free, loads and MFMAs each cost ~1.1 ms and do NOT overlap, ~1.6 ms is
+// neither (epilogue stores, barriers, per-block ramp); a W pre-split variant was 40 % slower (more L2 traffic, same stalls).  LDS row = [hi | mid | lo] x 32 bf16 + 16 B pad = 208 B (an odd
 // number of 16-B slots): conflict-free b128 fragment reads.  Per chunk and wave: 24 b128 reads feed 48 MFMAs.
 // =====================================================================================================================
 constexpr int XM = 128, XN = 128, XK = 32, XLD = 3 * XK * 2 + 16;
@@ -459,10 +462,20 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_x3(const float* __restric
     load_chunk(0);
     for (int ch = 0; ch < nch; ++ch) {
         __syncthreads();                 // the previous chunk's fragments have been read
+#ifndef DGNN_WHATIF_NO_SPLIT
         x3_store(As, ra);
         x3_store(Ws, rw);
+#else
+        if (ch == 0) { x3_store(As, ra); x3_store(Ws, rw); }
+        else asm volatile("" :: "v"(ra[0][0]), "v"(ra[1][0]), "v"(ra[2][0]), "v"(ra[3][0]), "v"(rw[0][0]), "v"(rw[1][0]), "v"(rw[2][0]), "v"(rw[3][0]));
+#endif
         __syncthreads();
+#ifndef DGNN_WHATIF_NO_GLOBAL
         if (ch + 1 < nch) load_chunk(ch + 1);   // in flight under the 48 MFMAs below
+#endif
+#ifdef DGNN_WHATIF_NO_MFMA
+        if (ch + 1 < nch) continue;
+#endif
         const char* ap = As + (wr * 64 + l31) * XLD + h * 16;
         const char* bp = Ws + (wc * 64 + l31) * XLD + h * 16;
 #pragma unroll

@@ -1,5 +1,8 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dgnn_amd._lib as L
+if os.environ.get("DGNN_LIB"):
+    L.LIB_PATH = os.path.abspath(os.environ["DGNN_LIB"])
 import torch
 from dgnn_amd import ops
 dev = "cuda:0"
@@ -12,12 +15,9 @@ def t(f, it=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / it
 M = 1010078
-for k, n in ((128, 256), (256, 512), (512, 1024), (512, 64)):
+for k, n in ((256, 512),):
     A1 = torch.randn(M, k, device=dev); A2 = torch.randn(M, k, device=dev)
     W1 = torch.randn(n, k, device=dev) * 0.1; W2 = torch.randn(n, k, device=dev) * 0.1
     out = torch.empty(M, n, device=dev)
     ms = t(lambda: ops.linear_fwd(A1, W1, A2, W2, out=out))
-    ref = (A1[:2000].double() @ W1.double().t() + A2[:2000].double() @ W2.double().t())
-    err = ((out[:2000].double() - ref).abs().max() / ref.abs().max()).item()
-    print("M=%d K=%d+%d N=%d: %.3f ms  %.0f TFLOP/s  rel err %.1e" % (M, k, k, n, ms, 2.0 * M * 2 * k * n / ms / 1e9, err))
-    del A1, A2, out
+    print("%s M=%d K=%d+%d N=%d: %.3f ms" % (os.environ.get("DGNN_LIB", "default"), M, k, k, n, ms))
