@@ -116,7 +116,7 @@ def training_leg():
     import subprocess
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
-    cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "bench_train.py"), "--steps", "60", "--warmup", "8"]
+    cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "bench_train.py"), "--steps", "200", "--warmup", "300"]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -15,6 +15,9 @@
 //             da = dz.Wj                              dgnn_linear_fwd on Wj^T (transposed here)
 //             dx_src, dWe, dbe                        dgnn_sage_aggregate_bwd   (dx_src == NULL: first layer, x is data)
 //             dx_src[:n_dst] += dz.Wi                 dgnn_linear_fwd with DGNN_LINEAR_ACCUMULATE
+#include <cstdlib>
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -42,10 +45,11 @@ extern "C" int64_t dgnn_sage_layer_train_scratch_elems(int64_t n_src, int64_t n_
     const int64_t stats = dgnn_colstats_scratch_elems(n_dst, c_out > c_in ? c_out : c_in);
     const int64_t wg = dgnn_linear_wgrad_scratch_elems(n_dst, c_out, c_in);
     const int64_t ab = dgnn_sage_aggregate_bwd_scratch_elems(n_src, c_in, f_e > 0 ? f_e : 1);
-    // backward: dz [n_dst,c_out] | da [n_dst,c_in] | WjT, WiT [c_in,c_out] each | max(stats, wgrad, agg-bwd partials)
+    // backward: dz [n_dst,c_out] | da [n_dst,c_in] | WjT, WiT [c_in,c_out] each | max(stats, wgrad, agg-bwd partials), twice (the weight
+    // gradients run on a second stream with their own partials)
     int64_t big = stats > wg ? stats : wg;
     if (ab > big) big = ab;
-    return align4(n_dst * c_out) + align4(n_dst * c_in) + 2 * align4((int64_t)c_in * c_out) + align4(big) + 64;
+    return align4(n_dst * c_out) + align4(n_dst * c_in) + 2 * align4((int64_t)c_in * c_out) + 2 * align4(big) + 64;
 }
 
 extern "C" int dgnn_sage_layer_train_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x,
@@ -77,37 +81,92 @@ extern "C" int dgnn_sage_layer_train_fwd(const int32_t* rowptr, const int32_t* s
     return DGNN_OK;
 }
 
-extern "C" int dgnn_sage_layer_train_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, const int32_t* rowptr_dst,
-                                         int64_t n_src, int64_t n_dst, const float* x, int64_t ldx, int c_in, const float* edge_attr,
-                                         int64_t lde, int f_e, const float* We, const float* be, const float* Wj, const float* Wi, int c_out,
-                                         const float* gamma, const float* mean, const float* var, float eps, int relu, const float* a,
-                                         const float* z, const float* y, const float* dy, float* dx, float* dWe, float* dbe, float* dWj,
-                                         float* dbj, float* dWi, float* dgamma, float* dbeta, float* scratch, int gemm_mode, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    DGNN_REQUIRE(n_dst > 0 && n_src >= n_dst && c_in > 0 && c_out > 0, DGNN_E_INVALID, "sage_layer_train_bwd: bad sizes");
-    DGNN_REQUIRE(x && Wj && z && y && dy && mean && var && dWj && dgamma && dbeta && scratch, DGNN_E_INVALID, "sage_layer_train_bwd: null pointer");
+namespace {
+
+// A second stream for the weight gradients (per device, created on first use): dWj, dbj and dWi depend only on dz, nothing on the
+// dx chain (da -> aggregate backward -> dx) depends on them, and at ~10 us per kernel plus the queue's per-kernel turnaround the
+// chain is what the backward pass takes; on their own queue they run beside it.  (Measured: no gain, see aux_enabled.)
+struct Aux {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[32] = {};
+    int next = 0;
+    bool ok = false;
+};
+Aux* aux_of_current_device() {
+    static Aux table[DGNN_MAX_DEVICES];
+    static std::mutex m;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DGNN_MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lock(m);
+    Aux& a = table[dev];
+    if (!a.stream) {
+        a.ok = hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; a.ok && i < 32; ++i) a.ok = hipEventCreateWithFlags(&a.ev[i], hipEventDisableTiming) == hipSuccess;
+        (void)hipGetLastError();
+    }
+    return a.ok ? &a : nullptr;
+}
+hipEvent_t next_event(Aux* a) {
+    hipEvent_t e = a->ev[a->next];
+    a->next = (a->next + 1) & 31;
+    return e;
+}
+// OFF by default: interleaved A/B runs (tools/ab_train.py aux=1 aux=0) put the two-stream backward 2-8 % BEHIND the one-stream one --
+// the event hand-offs cost what the overlap of ~10 us kernels buys.  Kept as an option (DGNN_TRAIN_AUX_STREAM=1,
+// dgnn_train_set_aux_stream) because the balance shifts with block size.
+int g_aux_on = -1;
+bool aux_enabled() {
+    if (g_aux_on < 0) g_aux_on = (getenv("DGNN_TRAIN_AUX_STREAM") && getenv("DGNN_TRAIN_AUX_STREAM")[0] == '1') ? 1 : 0;
+    return g_aux_on != 0;
+}
+// partial-sum scratch of one layer's backward on the main stream (column reductions, aggregate backward slabs; also the weight
+// gradients when there is no second stream)
+int64_t layer_tmp_elems(int64_t n_src, int64_t n_dst, int c_in, int c_out, int f_e) {
+    const int64_t stats = dgnn_colstats_scratch_elems(n_dst, c_out > c_in ? c_out : c_in);
+    const int64_t wg = dgnn_linear_wgrad_scratch_elems(n_dst, c_out, c_in);
+    const int64_t ab = dgnn_sage_aggregate_bwd_scratch_elems(n_src, c_in, f_e > 0 ? f_e : 1);
+    int64_t big = stats > wg ? stats : wg;
+    if (ab > big) big = ab;
+    return align4(big);
+}
+
+// One layer's backward.  `aux` == nullptr: everything on `stream`, in the order of the separate entry points.  Otherwise the
+// weight gradients go to aux->stream (scratch tmp_w, ordered after dz by an event) and *done receives the event that marks them
+// finished -- the caller must make `stream` wait for it before dz / tmp_w are reused and before the gradients are consumed.
+int layer_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, const int32_t* rowptr_dst, int64_t n_src, int64_t n_dst, const float* x,
+              int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e, const float* We, const float* be, const float* Wj, const float* Wi, int c_out,
+              const float* gamma, const float* mean, const float* var, float eps, int relu, const float* a, const float* z, const float* y, const float* dy,
+              float* dx, float* dWe, float* dbe, float* dWj, float* dbj, float* dWi, float* dgamma, float* dbeta, float* dz, float* da, float* WjT, float* WiT,
+              float* tmp, float* tmp_w, int gemm_mode, hipStream_t stream, Aux* aux, hipEvent_t* done) {
+    void* stream_ = (void*)stream;
     const bool agg = t_rowptr != nullptr;
-    float* dz = scratch;
-    float* da = dz + align4(n_dst * c_out);
-    float* WjT = da + align4(n_dst * c_in);
-    float* WiT = WjT + align4((int64_t)c_in * c_out);
-    float* tmp = WiT + align4((int64_t)c_in * c_out);
     const bool x3 = gemm_mode != DGNN_GEMM_F32;
     auto gemm = [&](const float* A, int64_t lda, int k, const float* W, int64_t ldw, int flags, int64_t M, int n, float* out, int64_t ldo) {
         return x3 ? dgnn_linear_fwd_x3(A, lda, k, W, ldw, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, flags, M, n, out, ldo, stream_)
                   : dgnn_linear_fwd(A, lda, k, W, ldw, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, flags, M, n, out, ldo, stream_);
     };
+    void* wstream = aux ? (void*)aux->stream : stream_;
+    float* wtmp = aux ? tmp_w : tmp;
     auto wgrad = [&](const float* A, int64_t lda, int na, const float* B, int64_t ldb, int nb, float* dW) {
-        return x3 ? dgnn_linear_wgrad_x3(A, lda, na, B, ldb, nb, n_dst, dW, nb, 0, tmp, stream_)
-                  : dgnn_linear_wgrad(A, lda, na, B, ldb, nb, n_dst, dW, nb, 0, tmp, stream_);
+        return x3 ? dgnn_linear_wgrad_x3(A, lda, na, B, ldb, nb, n_dst, dW, nb, 0, wtmp, wstream)
+                  : dgnn_linear_wgrad(A, lda, na, B, ldb, nb, n_dst, dW, nb, 0, wtmp, wstream);
     };
     // BatchNorm (batch statistics) + ReLU backward: dz, dgamma, dbeta
     TRY(dgnn_bn_relu_bwd(z, c_out, y, c_out, dy, c_out, gamma, mean, var, eps, 1, relu, n_dst, c_out, dz, c_out, dgamma, dbeta, tmp, stream_));
+    if (aux) {
+        hipEvent_t e = next_event(aux);
+        (void)hipEventRecord(e, stream);
+        (void)hipStreamWaitEvent(aux->stream, e, 0);
+    }
     const float* A1 = agg ? a : x;
     const int64_t lda1 = agg ? c_in : ldx;
     TRY(wgrad(dz, c_out, c_out, A1, lda1, c_in, dWj));
-    if (dbj) TRY(dgnn_colsum(dz, c_out, n_dst, c_out, dbj, 0, tmp, stream_));
+    if (dbj) TRY(dgnn_colsum(dz, c_out, n_dst, c_out, dbj, 0, wtmp, wstream));
     if (agg && Wi && dWi) TRY(wgrad(dz, c_out, c_out, x, ldx, c_in, dWi));
+    if (aux) {
+        *done = next_event(aux);
+        (void)hipEventRecord(*done, aux->stream);
+    }
     const bool need_dx = dx != nullptr;
     const bool need_da = agg ? (need_dx || We != nullptr) : need_dx;
     if (need_da) {
@@ -134,6 +193,36 @@ extern "C" int dgnn_sage_layer_train_bwd(const int32_t* t_rowptr, const int32_t*
         }
     }
     return dgnn_check_launch("sage_layer_train_bwd");
+}
+
+}  // namespace
+
+extern "C" int dgnn_sage_layer_train_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, const int32_t* rowptr_dst,
+                                         int64_t n_src, int64_t n_dst, const float* x, int64_t ldx, int c_in, const float* edge_attr,
+                                         int64_t lde, int f_e, const float* We, const float* be, const float* Wj, const float* Wi, int c_out,
+                                         const float* gamma, const float* mean, const float* var, float eps, int relu, const float* a,
+                                         const float* z, const float* y, const float* dy, float* dx, float* dWe, float* dbe, float* dWj,
+                                         float* dbj, float* dWi, float* dgamma, float* dbeta, float* scratch, int gemm_mode, void* stream_) {
+    DGNN_REQUIRE(n_dst > 0 && n_src >= n_dst && c_in > 0 && c_out > 0, DGNN_E_INVALID, "sage_layer_train_bwd: bad sizes");
+    DGNN_REQUIRE(x && Wj && z && y && dy && mean && var && dWj && dgamma && dbeta && scratch, DGNN_E_INVALID, "sage_layer_train_bwd: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    float* dz = scratch;
+    float* da = dz + align4(n_dst * c_out);
+    float* WjT = da + align4(n_dst * c_in);
+    float* WiT = WjT + align4((int64_t)c_in * c_out);
+    float* tmp = WiT + align4((int64_t)c_in * c_out);
+    float* tmp_w = tmp + layer_tmp_elems(n_src, n_dst, c_in, c_out, f_e);
+    Aux* aux = aux_enabled() ? aux_of_current_device() : nullptr;
+    hipEvent_t done = nullptr;
+    if (aux) {   // the scratch may still be in use by the previous call's kernels on `stream`: the second stream starts behind them
+        hipEvent_t e = next_event(aux);
+        (void)hipEventRecord(e, stream);
+        (void)hipStreamWaitEvent(aux->stream, e, 0);
+    }
+    const int rc = layer_bwd(t_rowptr, t_dst, t_eid, rowptr_dst, n_src, n_dst, x, ldx, c_in, edge_attr, lde, f_e, We, be, Wj, Wi, c_out, gamma, mean, var, eps,
+                             relu, a, z, y, dy, dx, dWe, dbe, dWj, dbj, dWi, dgamma, dbeta, dz, da, WjT, WiT, tmp, tmp_w, gemm_mode, stream, aux, &done);
+    if (aux && done) (void)hipStreamWaitEvent(stream, done, 0);   // join: the caller consumes the gradients on `stream`
+    return rc;
 }
 
 // =====================================================================================================================
@@ -226,14 +315,25 @@ int updated_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_
     float* WrT = WlT + align4((int64_t)c_in * c_out);
     float* WeT = WrT + align4((int64_t)c_in * c_out);
     float* tmp = WeT + align4((int64_t)c_in * k_e);
+    // weight gradients and bias sums (the only kernels here that use partial-sum scratch) go to the second stream: dWl / dbl / dWr once
+    // dz exists, dWe / dbe once dphi is complete; the dx / d_ea chain stays on `stream`, which joins them at the end
+    Aux* aux = aux_enabled() ? aux_of_current_device() : nullptr;
+    void* ws = aux ? (void*)aux->stream : st;
+    auto fork = [&]() {
+        if (!aux) return;
+        hipEvent_t e = next_event(aux);
+        (void)hipEventRecord(e, stream);
+        (void)hipStreamWaitEvent(aux->stream, e, 0);
+    };
     const T* g = dy;
     if (relu) {
         TRY(K::relu_bwd(y, dy, n_dst * c_out, dz, st));
         g = dz;
     }
-    TRY(K::wgrad(g, c_out, c_out, a, c_in, c_in, n_dst, dWl, tmp, mode, st));
-    if (dbl) TRY(K::colsum(g, c_out, n_dst, c_out, dbl, tmp, st));
-    if (Wr && dWr) TRY(K::wgrad(g, c_out, c_out, x, ldx, c_in, n_dst, dWr, tmp, mode, st));
+    fork();   // also orders the second stream behind whatever used `scratch` before on `stream`
+    TRY(K::wgrad(g, c_out, c_out, a, c_in, c_in, n_dst, dWl, tmp, mode, ws));
+    if (dbl) TRY(K::colsum(g, c_out, n_dst, c_out, dbl, tmp, ws));
+    if (Wr && dWr) TRY(K::wgrad(g, c_out, c_out, x, ldx, c_in, n_dst, dWr, tmp, mode, ws));
     transpose_to(Wl, c_out, c_in, WlT, stream);
     TRY(K::linear(g, c_out, c_out, WlT, c_out, nullptr, 0, 0, nullptr, 0, nullptr, 0, n_dst, c_in, da, c_in, mode, st));
     TRY(K::agg_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x, ldx, c_in, phi, da, dx, dphi, st));
@@ -244,8 +344,9 @@ int updated_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_
     if (E > 0) {
         if (dphi_ext)
             hipLaunchKernelGGL((k_add_inplace<T>), dim3(dgnn_grid_cap(dgnn_cdiv(E * c_in, 256))), dim3(256), 0, stream, dphi, dphi_ext, E * c_in);
-        TRY(K::wgrad(dphi, c_in, c_in, ea, lde, k_e, E, dWe, tmp, mode, st));
-        TRY(K::colsum(dphi, c_in, E, c_in, dbe, tmp, st));
+        fork();
+        TRY(K::wgrad(dphi, c_in, c_in, ea, lde, k_e, E, dWe, tmp, mode, ws));
+        TRY(K::colsum(dphi, c_in, E, c_in, dbe, tmp, ws));
         if (d_ea) {
             transpose_to(We, c_in, k_e, WeT, stream);
             TRY(K::linear(dphi, c_in, c_in, WeT, c_in, nullptr, 0, 0, nullptr, 0, nullptr, 0, E, k_e, d_ea, k_e, mode, st));
@@ -253,6 +354,11 @@ int updated_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_
     } else {
         (void)hipMemsetAsync(dWe, 0, sizeof(float) * (size_t)c_in * k_e, stream);
         (void)hipMemsetAsync(dbe, 0, sizeof(float) * (size_t)c_in, stream);
+    }
+    if (aux) {   // join
+        hipEvent_t e = next_event(aux);
+        (void)hipEventRecord(e, aux->stream);
+        (void)hipStreamWaitEvent(stream, e, 0);
     }
     return dgnn_check_launch("sage_updated_train_bwd");
 }
@@ -293,3 +399,135 @@ extern "C" int dgnn_sage_updated_train_bwd(const int32_t* t_rowptr, const int32_
                 : updated_bwd<F32>(t_rowptr, t_dst, t_eid, rowptr_dst, n_src, n_dst, E, x, ldx, c_in, ea, lde, k_e, We, Wl, Wr, c_out, relu, phi, a, y, dy,
                                    dphi_ext, dx, d_ea, dWe, dbe, dWl, dbl, dWr, dz, da, dphi, scratch, gemm_mode, stream);
 }
+
+// =====================================================================================================================
+// Static model, training mode, ALL layers per call: the chain of dgnn_sage_layer_train_fwd / _bwd calls (conv layers, then the
+// decoder's Linear + BatchNorm + ReLU block as a layer with rowptr[l] == NULL) issued from one entry point each way.  Layer l
+// reads the previous layer's y (layer 0: x0); the blocks nest (the destinations of layer l are the sources of layer l+1), so
+// layer l's output gradient IS layer l+1's dx.  Per-layer arrays are HOST arrays of device pointers / sizes.
+// =====================================================================================================================
+namespace {
+struct Ptr8 {
+    int64_t* p[8];
+};
+__global__ void k_inc_i64(Ptr8 ps, int n) {
+    if (threadIdx.x < n && ps.p[threadIdx.x]) *ps.p[threadIdx.x] += 1;
+}
+}  // namespace
+
+extern "C" int dgnn_static_train_fwd(int n_layers, const int32_t* const* rowptr, const int32_t* const* src, const int32_t* const* eid,
+                                     const int64_t* n_dst, const float* x0, int64_t ldx0, const int32_t* widths, const float* const* edge_attr,
+                                     const int64_t* lde, int f_e, const float* const* We, const float* const* be, const float* const* Wj,
+                                     const float* const* bj, const float* const* Wi, const float* const* gamma, const float* const* beta,
+                                     float* const* running_mean, float* const* running_var, int64_t* const* num_batches_tracked,
+                                     const float* momentum, const float* eps, float* const* a, float* const* z, float* const* stats,
+                                     float* const* y, float* scratch, int gemm_mode, void* stream) {
+    DGNN_REQUIRE(n_layers >= 1 && n_layers <= 8 && rowptr && src && eid && n_dst && x0 && widths && edge_attr && lde && We && be && Wj && bj && Wi && gamma &&
+                     beta && running_mean && running_var && momentum && eps && a && z && stats && y && scratch,
+                 DGNN_E_INVALID, "static_train_fwd: bad args (at most 8 layers)");
+    const float* x = x0;
+    int64_t ldx = ldx0;
+    for (int l = 0; l < n_layers; ++l) {
+        const int c_in = widths[l], c_out = widths[l + 1];
+        float* st = stats[l];
+        TRY(dgnn_sage_layer_train_fwd(rowptr[l], src[l], eid[l], n_dst[l], x, ldx, c_in, edge_attr[l], lde[l], We[l] ? f_e : 0, We[l], be[l], Wj[l], bj[l],
+                                      Wi[l], c_out, gamma[l], beta[l], running_mean[l], running_var[l], momentum[l], eps[l], 1, a[l], z[l], st, st + c_out,
+                                      st + 2 * c_out, st + 3 * c_out, y[l], scratch, gemm_mode, stream));
+        x = y[l];
+        ldx = c_out;
+    }
+    if (num_batches_tracked) {
+        Ptr8 ps;
+        for (int l = 0; l < 8; ++l) ps.p[l] = l < n_layers ? num_batches_tracked[l] : nullptr;
+        hipLaunchKernelGGL(k_inc_i64, dim3(1), dim3(64), 0, (hipStream_t)stream, ps, n_layers);
+    }
+    return dgnn_check_launch("static_train_fwd");
+}
+
+// dy: gradient of the last layer's y.  dx_buf[0], dx_buf[1]: two work buffers of max_l n_src[l] * widths[l] floats (layer l writes
+// its dx into dx_buf[l & 1], layer l-1 reads it as dy); layer 0's input is data (no dx).  Parameter gradients per layer.
+extern "C" int64_t dgnn_static_train_scratch_elems(int n_layers, const int64_t* n_src, const int64_t* n_dst, const int32_t* widths, int f_e) {
+    if (n_layers < 1 || !n_src || !n_dst || !widths) return 16;
+    int64_t dz = 0, da = 0, wt = 0, tmp = 0, tw = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        const int ci = widths[l], co = widths[l + 1];
+        const int64_t a1 = align4(n_dst[l] * co), a2 = align4(n_dst[l] * ci), a3 = align4((int64_t)ci * co);
+        const int64_t stats = dgnn_colstats_scratch_elems(n_dst[l], co > ci ? co : ci), wg = dgnn_linear_wgrad_scratch_elems(n_dst[l], co, ci),
+                      ab = dgnn_sage_aggregate_bwd_scratch_elems(n_src[l], ci, f_e > 0 ? f_e : 1);
+        if (a1 > dz) dz = a1;
+        if (a2 > da) da = a2;
+        if (a3 > wt) wt = a3;
+        const int64_t t1 = align4(stats > ab ? stats : ab), t2 = align4(stats > wg ? stats : wg);
+        if (t1 > tmp) tmp = t1;
+        if (t2 > tw) tw = t2;
+    }
+    return 2 * dz + da + 2 * wt + tmp + tw + 64;   // dz ping-pong | da | WjT, WiT | main-stream partials | weight-gradient partials
+}
+
+// dy: gradient of the last layer's y.  dx_buf[0], dx_buf[1]: two work buffers of max_l n_src[l] * widths[l] floats (layer l writes
+// its dx into dx_buf[l & 1], layer l-1 reads it as dy); layer 0's input is data (no dx).  Parameter gradients per layer.  scratch:
+// dgnn_static_train_scratch_elems floats.  The weight gradients (dWj, dbj, dWi) run on a library-owned second stream beside the dx
+// chain (DGNN_TRAIN_AUX_STREAM=0: everything on `stream`); `stream` has waited for all of them when the call returns.
+extern "C" int dgnn_static_train_bwd(int n_layers, const int32_t* const* t_rowptr, const int32_t* const* t_dst, const int32_t* const* t_eid,
+                                     const int32_t* const* rowptr_dst, const int64_t* n_src, const int64_t* n_dst, const float* x0, int64_t ldx0,
+                                     const int32_t* widths, const float* const* edge_attr, const int64_t* lde, int f_e, const float* const* We,
+                                     const float* const* be, const float* const* Wj, const float* const* Wi, const float* const* gamma,
+                                     const float* const* stats, const float* eps, const float* const* a, const float* const* z,
+                                     const float* const* y, const float* dy, float* const* dWe, float* const* dbe, float* const* dWj,
+                                     float* const* dbj, float* const* dWi, float* const* dgamma, float* const* dbeta, float* const* dx_buf,
+                                     float* scratch, int gemm_mode, void* stream_) {
+    DGNN_REQUIRE(n_layers >= 1 && n_layers <= 8 && t_rowptr && t_dst && t_eid && rowptr_dst && n_src && n_dst && x0 && widths && edge_attr && lde && We && be &&
+                     Wj && Wi && gamma && stats && eps && a && z && y && dy && dWe && dbe && dWj && dbj && dWi && dgamma && dbeta && dx_buf && scratch,
+                 DGNN_E_INVALID, "static_train_bwd: bad args");
+    hipStream_t stream = (hipStream_t)stream_;
+    Aux* aux = aux_enabled() ? aux_of_current_device() : nullptr;
+    int64_t dzn = 0, dan = 0, wtn = 0, tmpn = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        const int ci = widths[l], co = widths[l + 1];
+        const int64_t a1 = align4(n_dst[l] * co), a2 = align4(n_dst[l] * ci), a3 = align4((int64_t)ci * co);
+        const int64_t st = dgnn_colstats_scratch_elems(n_dst[l], co > ci ? co : ci), ab = dgnn_sage_aggregate_bwd_scratch_elems(n_src[l], ci, f_e > 0 ? f_e : 1);
+        const int64_t t1 = align4(st > ab ? st : ab);
+        if (a1 > dzn) dzn = a1;
+        if (a2 > dan) dan = a2;
+        if (a3 > wtn) wtn = a3;
+        if (t1 > tmpn) tmpn = t1;
+    }
+    float* dzb[2] = {scratch, scratch + dzn};
+    float* da = scratch + 2 * dzn;
+    float* WjT = da + dan;
+    float* WiT = WjT + wtn;
+    float* tmp = WiT + wtn;
+    float* tmp_w = tmp + tmpn;
+    hipEvent_t done[8] = {};
+    if (aux) {   // the second stream starts after everything already queued on `stream` (its inputs, and last step's use of the scratch)
+        hipEvent_t e = next_event(aux);
+        (void)hipEventRecord(e, stream);
+        (void)hipStreamWaitEvent(aux->stream, e, 0);
+    }
+    const float* g = dy;
+    int rc = DGNN_OK;
+    for (int l = n_layers - 1; l >= 0 && rc == DGNN_OK; --l) {
+        const int c_in = widths[l], c_out = widths[l + 1];
+        const float* x = l == 0 ? x0 : y[l - 1];
+        const int64_t ldx = l == 0 ? ldx0 : c_in;
+        float* dx = l == 0 ? nullptr : dx_buf[l & 1];
+        const float* st = stats[l];
+        if (aux && l + 2 < n_layers && done[l + 2]) (void)hipStreamWaitEvent(stream, done[l + 2], 0);   // dz[l & 1] is still read by layer l+2's weight gradients
+        rc = layer_bwd(t_rowptr[l], t_dst[l], t_eid[l], rowptr_dst[l], n_src[l], n_dst[l], x, ldx, c_in, edge_attr[l], lde[l], We[l] ? f_e : 0, We[l], be[l], Wj[l],
+                       Wi[l], c_out, gamma[l], st, st + c_out, eps[l], 1, a[l], z[l], y[l], g, dx, dWe[l], dbe[l], dWj[l], dbj[l], dWi[l], dgamma[l], dbeta[l],
+                       dzb[l & 1], da, WjT, WiT, tmp, tmp_w, gemm_mode, stream, aux, aux ? &done[l] : nullptr);
+        g = dx;
+    }
+    if (aux)   // the gradients are consumed on `stream` (optimizer step): join.  In-order on the second stream: the last event covers all.
+        for (int l = 0; l < n_layers; ++l)
+            if (done[l]) (void)hipStreamWaitEvent(stream, done[l], 0);
+    return rc;
+}
+
+// Whether the composite backward entry points run the weight gradients on the library's second stream (default: no).
+extern "C" int dgnn_train_set_aux_stream(int on) {
+    const int was = aux_enabled() ? 1 : 0;
+    g_aux_on = on ? 1 : 0;
+    return was;
+}
+

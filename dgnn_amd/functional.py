@@ -180,6 +180,52 @@ def sage_train_layer_supported(x, lin_e, bn) -> bool:
             and isinstance(bn, torch.nn.BatchNorm1d) and bn.training and bn.affine and bn.running_mean is not None)
 
 
+class _StaticTrainModel(torch.autograd.Function):
+    """All conv layers of the Static model (+ the decoder's Linear + BatchNorm + ReLU block) in training mode: one library call
+    forward, one backward (dgnn_static_train_fwd / _bwd = the per-layer composite calls issued back to back from C++).  Tensor
+    inputs: x0, then 7 parameters per layer (We, be, Wj, bj, Wi, gamma, beta; None where a layer has none)."""
+
+    @staticmethod
+    def forward(ctx, x0, spec, *params):
+        layers = []
+        for i, sp in enumerate(spec):
+            We, be, Wj, bj, Wi, gamma, beta = params[7 * i:7 * i + 7]
+            plan = sp["plan"]
+            rows = plan.edge_rows if (plan is not None and sp["scene_rows"]) else None
+            layers.append(dict(plan_parts=(plan.rowptr, plan.src, rows if rows is not None else plan.eid) if plan is not None else None,
+                               n_dst=plan.n_dst if plan is not None else sp["n_rows"], n_src=plan.n_src if plan is not None else sp["n_rows"],
+                               edge_attr=sp["edge_attr"] if We is not None else None, We=We, be=be, Wj=Wj, bj=bj, Wi=Wi, gamma=gamma, beta=beta, bn=sp["bn"]))
+        y, buf, meta = ops.static_train_fwd(x0, layers)
+        ctx.layers, ctx.meta, ctx.spec = layers, meta, spec
+        ctx.edge_indices = [sp["plan"].edge_index for sp in spec if sp["plan"] is not None]   # lazily built transposed plans read them
+        ctx.save_for_backward(x0, buf)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x0, buf = ctx.saved_tensors
+        for l, sp in zip(ctx.layers, ctx.spec):
+            plan = sp["plan"]
+            if plan is not None:
+                t = plan.transposed
+                l["t_parts"] = (t[0], t[1], plan.transposed_edge_rows if sp["scene_rows"] else t[2])
+        grads = ops.static_train_bwd(x0, ctx.layers, buf, ctx.meta, dy.contiguous())
+        out = [None, None]
+        for g in grads:
+            out += list(g)
+        return tuple(out)
+
+
+def static_train_model(x0, spec):
+    """spec: per layer dict(plan | None, n_rows (plain block), edge_attr, scene_rows, lin_e | None, lin_j, lin_i | None, bn)"""
+    params = []
+    for sp in spec:
+        le, lj, li, bn = sp["lin_e"], sp["lin_j"], sp["lin_i"], sp["bn"]
+        params += [le.weight if le is not None else None, le.bias if le is not None else None, lj.weight, lj.bias, li.weight if li is not None else None,
+                   bn.weight, bn.bias]
+    return _StaticTrainModel.apply(x0, spec, *params)
+
+
 class _SageUpdatedLayer(torch.autograd.Function):
     """(y, phi) of one Updated-variant conv (reference surfaceNetUpdatedEdgeFilters.py:147-170) with the ReLU that follows it
     (:239-247), one library call forward and one backward (csrc/train.hip); fp32 or bf16 storage."""

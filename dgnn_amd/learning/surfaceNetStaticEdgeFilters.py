@@ -202,6 +202,9 @@ class SurfaceNet(nn.Module):
         x = _dev_f32(x_all[n_id, 1:] if self.clf.regularization.cell_type else x_all[n_id, :], dev)
         if self.storage_dtype == torch.bfloat16:
             x = Fn.to_bf16(x)
+        whole = self._train_whole_model(x, data, dev)
+        if whole is not None:
+            return whole
         for i in range(self.num_layers):
             edge_index, e_id, size = data.batch_adjs[i]
             edge_index = edge_index.to(dev)
@@ -222,6 +225,41 @@ class SurfaceNet(nn.Module):
         if self.clf.model.decoder:
             x = self._decode(x)
         return x.float() if x.dtype == torch.bfloat16 else x
+
+    def _train_whole_model(self, x, data, dev):
+        """Training-mode forward through ONE library call (and one in the backward) when every layer qualifies for the composite
+        entry points: fp32 rows, lin_e a Linear over <= 32 attributes, BatchNorm in training mode after every conv and inside the
+        decoder.  Returns the logits, or None (the per-layer path then runs)."""
+        from .. import ops
+        if not (ops.TRAIN_COMPOSITE and ops.TRAIN_WHOLE_MODEL) or x.dtype != torch.float32 or self.num_layers + 1 > 8:
+            return None
+        dec = self.decoder if self.clf.model.decoder else ()
+        if len(dec) not in (0, 4) or (len(dec) == 4 and not isinstance(dec[1], BatchNorm)):
+            return None
+        ea_all = data.all.edge_attr
+        spec, n_src = [], x.size(0)
+        for i in range(self.num_layers):
+            edge_index, e_id, size = data.batch_adjs[i]
+            conv, norm = self.convs[i][0], self.convs[i][1] if len(self.convs[i]) > 1 else None
+            if not isinstance(norm, BatchNorm) or not Fn.sage_train_layer_supported(x, conv.lin_e, norm.module) or size[0] != n_src:
+                return None
+            plan = plan_for(edge_index.to(dev), size[0], size[1])
+            in_place = plan.edge_rows is not None and ea_all.is_cuda and ea_all.device == x.device and ea_all.dtype == torch.float32 \
+                and ea_all.dim() == 2 and ea_all.stride(1) == 1
+            ea = None
+            if conv.lin_e is not None:
+                ea = ea_all if in_place else _dev_f32(ea_all[e_id.to(ea_all.device)], dev)
+            spec.append(dict(plan=plan, edge_attr=ea, scene_rows=in_place and conv.lin_e is not None, lin_e=conv.lin_e, lin_j=conv.lin_j, lin_i=conv.lin_i,
+                             bn=norm.module))
+            n_src = size[1]
+        if len(dec) == 4:
+            if not dec[1].module.training:
+                return None
+            spec.append(dict(plan=None, n_rows=n_src, edge_attr=None, scene_rows=False, lin_e=None, lin_j=dec[0], lin_i=None, bn=dec[1].module))
+        h = Fn.static_train_model(x, spec)
+        if len(dec) == 4:
+            h = Fn.linear2(h, dec[3].weight, bias=dec[3].bias, out_f32=True)
+        return h
 
     # ---- INFERENCE, whole graph (reference :323-355; the benchmarked path) ---------------------
     @torch.no_grad()

@@ -455,6 +455,7 @@ def decoder_fused_fwd_bf16(y, W0, b0, scale, shift, W3, b3):
 
 # ---- training-mode conv layer, one call each way (csrc/train.hip) -----------------------------------------------------------
 TRAIN_COMPOSITE = __import__("os").environ.get("DGNN_TRAIN_COMPOSITE", "1") != "0"
+TRAIN_WHOLE_MODEL = __import__("os").environ.get("DGNN_TRAIN_WHOLE_MODEL", "1") != "0"   # Static fp32: all layers in one call each way
 
 
 @on_device_of
@@ -620,3 +621,99 @@ def sage_updated_train_bwd(t_parts, rowptr_dst, n_src, n_dst, x, ea, We, Wl, Wr,
                                             ptr(dWe), ptr(dbe), ptr(dWl), ptr(dbl), ptr(dWr), ptr(dz), ptr(da), ptr(dphi), ptr(scratch),
                                             int(dt == torch.bfloat16), GEMM_MODE, stream_ptr()), "dgnn_sage_updated_train_bwd")
     return (dx, d_ea, dWe.view(c_in, k_e), dbe, dWl.view(c_out, c_in), dbl, dWr.view(c_out, c_in) if dWr is not None else None)
+
+
+# ---- Static model in training mode, all layers per call (csrc/train.hip) -------------------------------------------------------
+def _parr(vals):
+    import ctypes as C
+    return (C.c_void_p * len(vals))(*[(v.data_ptr() if isinstance(v, torch.Tensor) else v) for v in vals])
+
+
+def _iarr(vals, ty):
+    return (ty * len(vals))(*vals)
+
+
+@on_device_of
+def static_train_fwd(x0, layers):
+    """`layers`: list of dicts (one per conv layer, then optionally the decoder's Linear + BN block with plan None) with keys
+    plan_parts (rowptr, src, eid) | None, n_dst, edge_attr | None, We, be, Wj, bj, Wi, gamma, beta, bn.
+    -> (y_last, buf, meta): one fp32 buffer holding every layer's a / z / y / stats, `meta` the element offsets."""
+    import ctypes as C
+    _req(x0, "x", dim=2)
+    dev, L = x0.device, len(layers)
+    widths = [x0.size(1)] + [l["Wj"].size(0) for l in layers]
+    meta, off = [], 0
+    for i, l in enumerate(layers):
+        n, ci, co = l["n_dst"], widths[i], widths[i + 1]
+        if l["Wj"].size(1) != ci:
+            raise ValueError("layer %d: lin_j %s does not take %d channels" % (i, tuple(l["Wj"].shape), ci))
+        m = dict(a=off if l["plan_parts"] is not None else None)
+        off += n * ci if l["plan_parts"] is not None else 0
+        m["z"], off = off, off + n * co
+        m["y"], off = off, off + n * co
+        m["stats"], off = off, off + 4 * co
+        meta.append(m)
+    buf = torch.empty(off, dtype=torch.float32, device=dev)
+    base = buf.data_ptr()
+    at = lambda o: None if o is None else base + 4 * o
+    scratch = _f32(max(lib().dgnn_colstats_scratch_elems(l["n_dst"], widths[i + 1]) for i, l in enumerate(layers)), dev)
+    pp = lambda k: _parr([(l["plan_parts"][k] if l["plan_parts"] is not None else None) for l in layers])
+    key = lambda k: _parr([l[k] for l in layers])
+    f_e = max([l["We"].size(1) for l in layers if l["We"] is not None] or [0])
+    check(lib().dgnn_static_train_fwd(
+        L, pp(0), pp(1), pp(2), _iarr([l["n_dst"] for l in layers], C.c_int64), ptr(x0), _ld(x0), _iarr(widths, C.c_int32),
+        key("edge_attr"), _iarr([(_ld(l["edge_attr"]) if l["edge_attr"] is not None else 0) for l in layers], C.c_int64), f_e,
+        key("We"), key("be"), key("Wj"), key("bj"), key("Wi"), key("gamma"), key("beta"),
+        _parr([l["bn"].running_mean for l in layers]), _parr([l["bn"].running_var for l in layers]),
+        _parr([(l["bn"].num_batches_tracked if l["bn"].track_running_stats else None) for l in layers]),
+        _iarr([(l["bn"].momentum if l["bn"].momentum is not None else 0.1) for l in layers], C.c_float), _iarr([l["bn"].eps for l in layers], C.c_float),
+        _parr([at(m["a"]) for m in meta]), _parr([at(m["z"]) for m in meta]), _parr([at(m["stats"]) for m in meta]), _parr([at(m["y"]) for m in meta]),
+        ptr(scratch), GEMM_MODE, stream_ptr()), "dgnn_static_train_fwd")
+    n, co = layers[-1]["n_dst"], widths[-1]
+    return buf[meta[-1]["y"]:meta[-1]["y"] + n * co].view(n, co), buf, (meta, widths)
+
+
+@on_device_of
+def static_train_bwd(x0, layers, buf, meta_widths, dy):
+    """-> per-layer parameter gradients [(dWe, dbe, dWj, dbj, dWi, dgamma, dbeta), ...] (views of one buffer; None where the layer has
+    no such parameter)"""
+    import ctypes as C
+    meta, widths = meta_widths
+    dev, L = x0.device, len(layers)
+    base = buf.data_ptr()
+    at = lambda o: None if o is None else base + 4 * o
+    sizes, off = [], 0
+    for i, l in enumerate(layers):
+        ci, co = widths[i], widths[i + 1]
+        fe = l["We"].size(1) if l["We"] is not None else 0
+        row = []
+        for sz in (ci * fe, ci if fe else 0, co * ci, co if l["bj"] is not None else 0, co * ci if l["Wi"] is not None else 0, co, co):
+            row.append((off, sz) if sz else None)
+            off += sz
+        sizes.append(row)
+    flat = torch.empty(off, dtype=torch.float32, device=dev)
+    gbase = flat.data_ptr()
+    gat = lambda e: None if e is None else gbase + 4 * e[0]
+    n_src = [(l["n_src"] if l["plan_parts"] is not None else l["n_dst"]) for l in layers]
+    dxn = max([n_src[i] * widths[i] for i in range(1, L)] or [1])
+    dxb = torch.empty((2, dxn), dtype=torch.float32, device=dev)
+    f_e = max([l["We"].size(1) for l in layers if l["We"] is not None] or [0])
+    scratch = _f32(lib().dgnn_static_train_scratch_elems(L, _iarr(n_src, C.c_int64), _iarr([l["n_dst"] for l in layers], C.c_int64), _iarr(widths, C.c_int32), f_e),
+                   dev)
+    tp = lambda k: _parr([(l["t_parts"][k] if l["plan_parts"] is not None else None) for l in layers])
+    key = lambda k: _parr([l[k] for l in layers])
+    col = lambda j: _parr([gat(r[j]) for r in sizes])
+    check(lib().dgnn_static_train_bwd(
+        L, tp(0), tp(1), tp(2), _parr([(l["plan_parts"][0] if l["plan_parts"] is not None else None) for l in layers]), _iarr(n_src, C.c_int64),
+        _iarr([l["n_dst"] for l in layers], C.c_int64), ptr(x0), _ld(x0), _iarr(widths, C.c_int32), key("edge_attr"),
+        _iarr([(_ld(l["edge_attr"]) if l["edge_attr"] is not None else 0) for l in layers], C.c_int64), f_e, key("We"), key("be"), key("Wj"), key("Wi"),
+        key("gamma"), _parr([at(m["stats"]) for m in meta]), _iarr([l["bn"].eps for l in layers], C.c_float), _parr([at(m["a"]) for m in meta]),
+        _parr([at(m["z"]) for m in meta]), _parr([at(m["y"]) for m in meta]), ptr(dy), col(0), col(1), col(2), col(3), col(4), col(5), col(6),
+        _parr([dxb[0], dxb[1]]), ptr(scratch), GEMM_MODE, stream_ptr()), "dgnn_static_train_bwd")
+    grads = []
+    for i, (l, row) in enumerate(zip(layers, sizes)):
+        ci, co = widths[i], widths[i + 1]
+        fe = l["We"].size(1) if l["We"] is not None else 0
+        v = lambda e, *shape: None if e is None else flat[e[0]:e[0] + e[1]].view(*shape)
+        grads.append((v(row[0], ci, fe) if fe else None, v(row[1], ci) if fe else None, v(row[2], co, ci), v(row[3], co), v(row[4], co, ci), v(row[5], co), v(row[6], co)))
+    return grads

@@ -113,8 +113,14 @@ class NeighborSampler:
                     blk, pending = self._finish_on_side(pending), None
                     yield self._hand_over(blk)
             finally:
-                if pending is not None:   # abandoned mid-way: the builder thread must not outlive its buffers
-                    self._finish_on_side(pending)
+                if pending is not None:   # abandoned mid-way (also at interpreter exit): the builder thread must not outlive its buffers
+                    b = pending[0]
+                    job, b["job"] = b.get("job"), None
+                    if job:
+                        try:
+                            lib().dgnn_khop_blocks_regular_wait(job, b["hops"], b["counts"])   # joins; no torch calls on this path
+                        except Exception:  # noqa: BLE001 -- module globals may be gone during teardown
+                            pass
             return
         if self.prefetch != "thread":
             pending = None

@@ -248,6 +248,36 @@ int dgnn_edge_chain_bwd_bf16(const uint16_t* g, int64_t ldg, const uint16_t* phi
                              int c_tot, int relu, uint16_t* dphi, int64_t lddphi, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Static model in training mode, ALL layers per call (SurfaceNet.forward :196-227 up to the decoder's last Linear, and its
+ * autograd): the chain of dgnn_sage_layer_train_fwd / _bwd calls issued from one entry point each way.  Per-layer arguments are
+ * HOST arrays [n_layers] of device pointers / sizes (widths [n_layers+1]); rowptr[l] == NULL marks a plain Linear + BatchNorm +
+ * ReLU block (the decoder's).  Layer l reads y[l-1] (layer 0: x0); stats[l] = [4, widths[l+1]] (mean, var, scale, shift).
+ * Forward scratch: max_l dgnn_colstats_scratch_elems(n_dst[l], widths[l+1]); backward scratch: dgnn_static_train_scratch_elems
+ * (host arrays); dx_buf[0..1]: max_l n_src[l] * widths[l] floats each.  The backward runs the weight gradients (dWj, dbj, dWi: they
+ * depend on dz only) on a second, library-owned stream beside the dx chain when dgnn_train_set_aux_stream(1) / DGNN_TRAIN_AUX_STREAM=1
+ * is in effect, and makes `stream` wait for them before it returns; default: one stream.  Results are the same either way.
+ * num_batches_tracked (may be NULL): device int64 counters of the BatchNorm modules, incremented once.
+ * ---------------------------------------------------------------------------------------------- */
+int dgnn_static_train_fwd(int n_layers, const int32_t* const* rowptr, const int32_t* const* src, const int32_t* const* eid, const int64_t* n_dst,
+                          const float* x0, int64_t ldx0, const int32_t* widths, const float* const* edge_attr, const int64_t* lde, int f_e,
+                          const float* const* We, const float* const* be, const float* const* Wj, const float* const* bj, const float* const* Wi,
+                          const float* const* gamma, const float* const* beta, float* const* running_mean, float* const* running_var,
+                          int64_t* const* num_batches_tracked, const float* momentum, const float* eps, float* const* a, float* const* z,
+                          float* const* stats, float* const* y, float* scratch, int gemm_mode, void* stream);
+/* Whether the composite backward entry points (dgnn_sage_layer_train_bwd, dgnn_sage_updated_train_bwd, dgnn_static_train_bwd) run the
+ * weight gradients on the library's second stream (default 0 -- measured 2-8 % slower than one stream at the reference's block sizes;
+ * environment DGNN_TRAIN_AUX_STREAM=1 starts with 1).  Returns the previous setting.  Results do not depend on it. */
+int dgnn_train_set_aux_stream(int on);
+int64_t dgnn_static_train_scratch_elems(int n_layers, const int64_t* n_src, const int64_t* n_dst, const int32_t* widths, int f_e);
+int dgnn_static_train_bwd(int n_layers, const int32_t* const* t_rowptr, const int32_t* const* t_dst, const int32_t* const* t_eid,
+                          const int32_t* const* rowptr_dst, const int64_t* n_src, const int64_t* n_dst, const float* x0, int64_t ldx0,
+                          const int32_t* widths, const float* const* edge_attr, const int64_t* lde, int f_e, const float* const* We,
+                          const float* const* be, const float* const* Wj, const float* const* Wi, const float* const* gamma,
+                          const float* const* stats, const float* eps, const float* const* a, const float* const* z, const float* const* y,
+                          const float* dy, float* const* dWe, float* const* dbe, float* const* dWj, float* const* dbj, float* const* dWi,
+                          float* const* dgamma, float* const* dbeta, float* const* dx_buf, float* scratch, int gemm_mode, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Updated variant, one conv layer per call each way (surfaceNetUpdatedEdgeFilters.py:147-170 and its autograd); `bf16` != 0:
  * x / ea / phi / a / y / dy and the gradients of activations are bf16 (uint16_t), parameters and their gradients fp32.
  *   forward : phi [E,c_in] = ea.We^T + be;  a [n_dst,c_in] = mean_j x_j * phi;  y [n_dst,c_out] = relu?(a.Wl^T + x[:n_dst].Wr^T + bl)

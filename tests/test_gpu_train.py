@@ -201,8 +201,9 @@ def test_composite_train_layer_is_bit_identical_to_the_separate_calls(monkeypatc
                   batch_adjs=[(a.to(DEV), e.to(DEV), s) for a, e, s in d.batch_adjs])
     G = torch.from_numpy(g["G"]).to(DEV)
 
-    def run(composite, data, G):
+    def run(composite, data, G, whole=True):
         monkeypatch.setattr(ops, "TRAIN_COMPOSITE", composite)
+        monkeypatch.setattr(ops, "TRAIN_WHOLE_MODEL", whole)
         net = hip_static(train=True)
         logits = net(data)
         (logits * G).sum().backward()
@@ -218,13 +219,14 @@ def test_composite_train_layer_is_bit_identical_to_the_separate_calls(monkeypatc
             _, n_id, adjs = NeighborSampler(ei, sizes=[-1] * 4, num_nodes=n, batch_size=257).sample(torch.arange(100, 357, device=DEV))
             data = Config(all=Config(x=x, edge_attr=ea), batch_n_id=n_id, batch_adjs=adjs)
             G = hashed_normal(np.arange(257), 2, seed=7, device=DEV)
-        la, ga, ba = run(True, data, G)
-        lb, gb, bb = run(False, data, G)
-        assert torch.equal(la, lb)
-        for k in ga:
-            assert torch.equal(ga[k], gb[k]), (case, k, (ga[k] - gb[k]).abs().max().item())
-        for k in ba:
-            assert torch.equal(ba[k], bb[k]), (case, k)
+        lb, gb, bb = run(False, data, G)                       # separate Functions
+        for whole in (True, False):                            # all layers in one call each way | one call per layer each way
+            la, ga, ba = run(True, data, G, whole)
+            assert torch.equal(la, lb)
+            for k in ga:
+                assert torch.equal(ga[k], gb[k]), (case, whole, k, (ga[k] - gb[k]).abs().max().item())
+            for k in ba:
+                assert torch.equal(ba[k], bb[k]), (case, whole, k)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -389,3 +391,27 @@ def test_updated_composite_layer_matches_the_separate_calls(monkeypatch, dtype, 
             assert torch.equal(ga[k], gb[k]), k
         else:
             assert (ga[k] - gb[k]).abs().max().item() <= 2e-2 * gb[k].abs().max().item() + 1e-6, (k, (ga[k] - gb[k]).abs().max().item(), gb[k].abs().max().item())
+
+
+def test_aux_stream_backward_gives_identical_gradients():
+    """dgnn_train_set_aux_stream(1): weight gradients on the library's second stream beside the dx chain -- same numbers"""
+    from dgnn_amd._lib import lib
+    from test_gpu_parity import gold, f3_data
+    g = gold("static_f3_train_blocks.npz")
+    d = f3_data(g)
+    data = Config(all=Config(x=d.all.x.to(DEV), edge_attr=d.all.edge_attr.to(DEV)), batch_n_id=d.batch_n_id.to(DEV),
+                  batch_adjs=[(a.to(DEV), e.to(DEV), s) for a, e, s in d.batch_adjs])
+    G = torch.from_numpy(g["G"]).to(DEV)
+    res = []
+    was = lib().dgnn_train_set_aux_stream(0)
+    try:
+        for on in (0, 1, 1):
+            lib().dgnn_train_set_aux_stream(on)
+            net = hip_static(train=True)
+            (net(data) * G).sum().backward()
+            torch.cuda.synchronize()
+            res.append({k: p.grad.clone() for k, p in net.named_parameters()})
+    finally:
+        lib().dgnn_train_set_aux_stream(was)
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]) and torch.equal(res[0][k], res[2][k]), k

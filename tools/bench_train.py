@@ -33,8 +33,8 @@ ap.add_argument("--updated", action="store_true", help="surfaceNetUpdatedEdgeFil
 ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="bf16: activations / phi stored in bf16, bf16 MFMA, fp32 accumulate and master weights")
 ap.add_argument("--points", type=int, default=150000)
 ap.add_argument("--batch", type=int, default=2048)
-ap.add_argument("--steps", type=int, default=40)
-ap.add_argument("--warmup", type=int, default=5)
+ap.add_argument("--steps", type=int, default=200)
+ap.add_argument("--warmup", type=int, default=300, help="untimed steps; the GPU needs ~0.5 s of this load before its step time settles (measured: 2.4 -> 1.5 ms over the first ~300 steps of a process)")
 ap.add_argument("--prefetch", choices=["none", "stream", "thread"], default="stream",
                 help="block builder: in line | one block ahead on a side stream, issued by the library's builder thread (default) | "
                      "ahead in a Python worker thread")
@@ -100,7 +100,9 @@ if world > 1:
 opt = torch.optim.Adam(net.parameters(), lr=clf.training.learning_rate, fused=True)  # one launch for all 49 tensors
 adjust_learning_rate(opt, clf)
 g = torch.Generator().manual_seed(rank)
-idx = torch.randperm(n, generator=g)[:batch * (steps + args.warmup)]
+per = (n // batch) * batch     # whole batches per permutation: no duplicate targets inside a batch
+need = batch * (steps + args.warmup)
+idx = torch.cat([torch.randperm(n, generator=g)[:per] for _ in range(need // per + 1)])[:need]
 loader = NeighborSampler(ei, sizes=[-1] * 4, node_idx=idx.to(dev), num_nodes=n, batch_size=batch,
                          prefetch={"none": False, "stream": True, "thread": "thread"}[args.prefetch])
 it = iter(loader)
