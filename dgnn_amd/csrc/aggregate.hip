@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(256) k_agg_bwd(const int32_t* __restrict__ t_r
     }
 }
 
-// out[chunk][i] (+)= sum_b slabs[b][chunk][i]; 16 outputs x 64 slices per block: slice s adds slabs s, s+64, ... in order,
+// out[chunk][i] = sum_b slabs[b][chunk][i] (written, not accumulated: callers need no zero fill); 16 outputs x 64 slices per block: slice s adds slabs s, s+64, ... in order,
 // the 64 slice sums are then added in slice order (deterministic, and not a 1024-long dependent chain per output).
 constexpr int RS_SLICES = 64;
 __global__ void __launch_bounds__(16 * RS_SLICES) k_reduce_slabs(const float* __restrict__ slabs, int nblocks, int nchunks, int per, int c_in,
@@ -306,9 +306,9 @@ __global__ void __launch_bounds__(16 * RS_SLICES) k_reduce_slabs(const float* __
     float s = 0.f;
     for (int k = 0; k < RS_SLICES; ++k) s += red[k][o];
     if (f < fe)
-        dWe[(int64_t)c * fe + f] += s;
+        dWe[(int64_t)c * fe + f] = s;
     else
-        dbe[c] += s;
+        dbe[c] = s;
 }
 
 constexpr int BWD_BLOCKS = 1024;  // 4 blocks (16 waves) per CU: the kernel lives on memory latency; one slab per block
@@ -352,7 +352,13 @@ int agg_bwd_t(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
               const T* phi, int64_t ldphi, const T* da, int64_t ldda, T* dx_src, int64_t lddx, float* dWe, float* dbe, T* dphi_out,
               int64_t lddphi, float* partials, hipStream_t stream) {
     DGNN_REQUIRE(n_src >= 0 && c_in > 0, DGNN_E_INVALID, "aggregate_bwd: bad sizes");
-    if (n_src == 0) return DGNN_OK;
+    if (n_src == 0) {   // nothing to sum: the parameter gradients are zero (they are written, not accumulated, otherwise)
+        if (We && dWe && dbe) {
+            (void)hipMemsetAsync(dWe, 0, sizeof(float) * (size_t)c_in * f_e, stream);
+            (void)hipMemsetAsync(dbe, 0, sizeof(float) * (size_t)c_in, stream);
+        }
+        return DGNN_OK;
+    }
     DGNN_REQUIRE(t_rowptr && t_dst && t_eid && rowptr_dst && x_src && da, DGNN_E_INVALID, "aggregate_bwd: null pointer");
     const bool fused = We != nullptr;
     DGNN_REQUIRE(!fused || (be && edge_attr && dWe && dbe && partials), DGNN_E_INVALID, "aggregate_bwd: fused mode needs be, edge_attr, dWe, dbe, partials");

@@ -86,7 +86,9 @@ __device__ __forceinline__ bool finalize_pair(const double* __restrict__ partial
 
 __global__ void __launch_bounds__(FIN_THREADS) k_stats_finalize(const double* __restrict__ partials, int nblk, int64_t M, int c,
                                                         float* __restrict__ mean, float* __restrict__ var,
-                                                        float* __restrict__ rmean, float* __restrict__ rvar, float momentum) {
+                                                        float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                        float* __restrict__ scale, float* __restrict__ shift) {
     double s, q;
     if (!finalize_pair(partials, nblk, c, s, q)) return;
     const int col = blockIdx.x * 16 + (threadIdx.x & 15);
@@ -95,6 +97,12 @@ __global__ void __launch_bounds__(FIN_THREADS) k_stats_finalize(const double* __
     if (v < 0.0) v = 0.0;
     mean[col] = (float)m;
     var[col] = (float)v;
+    if (scale) {   // the fold of k_bn_fold on the values just stored (same fp32 arithmetic): one launch less per training layer
+        const float invstd = 1.0f / sqrtf((float)v + eps);
+        const float sc = (gamma ? gamma[col] : 1.f) * invstd;
+        scale[col] = sc;
+        shift[col] = (beta ? beta[col] : 0.f) - (float)m * sc;
+    }
     if (rmean) rmean[col] = (1.f - momentum) * rmean[col] + momentum * (float)m;
     if (rvar) {
         const double unb = M > 1 ? v * (double)M / (double)(M - 1) : v;
@@ -192,7 +200,8 @@ extern "C" int dgnn_bn_fold(const float* gamma, const float* beta, const float* 
 
 template <typename T>
 static int bn_batch_stats_t(const T* x, int64_t ldx, int64_t M, int c, float* mean, float* var, float* running_mean, float* running_var,
-                            float momentum, float* scratch, hipStream_t stream) {
+                            float momentum, float* scratch, hipStream_t stream, const float* gamma = nullptr, const float* beta = nullptr,
+                            float eps = 0.f, float* scale = nullptr, float* shift = nullptr) {
     DGNN_REQUIRE(M > 0 && c > 0 && x && mean && var && scratch, DGNN_E_INVALID, "bn_batch_stats: bad args (M=%lld c=%d)", (long long)M, c);
     const int nblk = red_blocks(M);
     const int64_t rpb = dgnn_cdiv(M, nblk);
@@ -200,7 +209,7 @@ static int bn_batch_stats_t(const T* x, int64_t ldx, int64_t M, int c, float* me
     hipLaunchKernelGGL((k_colreduce<0, T>), dim3(nblk), dim3(256), 0, stream, x, ldx, (const T*)nullptr, (int64_t)0, (const T*)nullptr,
                        (int64_t)0, nullptr, nullptr, 0.f, 0, M, c, rpb, P);
     hipLaunchKernelGGL(k_stats_finalize, dim3((c + 15) / 16), dim3(FIN_THREADS), 0, stream, P, nblk, M, c, mean, var, running_mean,
-                       running_var, momentum);
+                       running_var, momentum, gamma, beta, eps, scale, shift);
     return dgnn_check_launch("bn_batch_stats");
 }
 
@@ -247,6 +256,13 @@ static int colsum_t(const T* x, int64_t ldx, int64_t M, int c, float* out, int a
 extern "C" int dgnn_bn_batch_stats(const float* x, int64_t ldx, int64_t M, int c, float* mean, float* var,
                                    float* running_mean, float* running_var, float momentum, float* scratch, void* stream) {
     return bn_batch_stats_t<float>(x, ldx, M, c, mean, var, running_mean, running_var, momentum, scratch, (hipStream_t)stream);
+}
+// batch statistics AND the scale / shift fold from them in one pass (training-mode forward): = dgnn_bn_batch_stats + dgnn_bn_fold
+extern "C" int dgnn_bn_batch_stats_fold(const float* x, int64_t ldx, int64_t M, int c, float* mean, float* var, float* running_mean,
+                                        float* running_var, float momentum, const float* gamma, const float* beta, float eps, float* scale,
+                                        float* shift, float* scratch, void* stream) {
+    DGNN_REQUIRE(scale && shift, DGNN_E_INVALID, "bn_batch_stats_fold: scale / shift missing");
+    return bn_batch_stats_t<float>(x, ldx, M, c, mean, var, running_mean, running_var, momentum, scratch, (hipStream_t)stream, gamma, beta, eps, scale, shift);
 }
 extern "C" int dgnn_bn_batch_stats_bf16(const uint16_t* x, int64_t ldx, int64_t M, int c, float* mean, float* var,
                                         float* running_mean, float* running_var, float momentum, float* scratch, void* stream) {

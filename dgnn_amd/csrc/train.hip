@@ -7,8 +7,8 @@
 //
 //   forward : a = mean_j x_j * (We.A + be)          dgnn_sage_aggregate_fwd   (rowptr == NULL: a = x, a plain Linear + BN block)
 //             z = a.Wj^T + x_dst.Wi^T + bj           dgnn_linear_fwd / _x3
-//             mean, var (+ running statistics)       dgnn_bn_batch_stats
-//             scale, shift                           dgnn_bn_fold
+//             mean, var (+ running statistics),      dgnn_bn_batch_stats_fold (= dgnn_bn_batch_stats + dgnn_bn_fold, the fold computed
+//             scale, shift                             by the finalising kernel on the values it has just stored)
 //             y = relu(z * scale + shift)            dgnn_scale_shift_act
 //   backward: dz, dgamma, dbeta                      dgnn_bn_relu_bwd
 //             dWj = dz^T a, dWi = dz^T x_dst, dbj    dgnn_linear_wgrad / _x3, dgnn_colsum
@@ -27,6 +27,16 @@ __global__ void k_transpose(const float* __restrict__ in, int rows, int cols, fl
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int r = i / cols, c = i - r * cols;
         out[c * rows + r] = in[i];
+    }
+}
+// two matrices of one shape in one launch (lin_j and lin_i of a layer)
+__global__ void k_transpose2(const float* __restrict__ in0, const float* __restrict__ in1, int rows, int cols, float* __restrict__ out0,
+                             float* __restrict__ out1) {
+    const int n = rows * cols;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n; i += gridDim.x * blockDim.x) {
+        const int j = i < n ? i : i - n;
+        const int r = j / cols, c = j - r * cols;
+        (i < n ? out0 : out1)[c * rows + r] = (i < n ? in0 : in1)[j];
     }
 }
 
@@ -75,8 +85,7 @@ extern "C" int dgnn_sage_layer_train_fwd(const int32_t* rowptr, const int32_t* s
     else
         TRY(dgnn_linear_fwd_x3(A1, lda1, c_in, Wj, c_in, A2, ldx, A2 ? c_in : 0, A2 ? Wi : nullptr, c_in, bj, nullptr, nullptr, 0, n_dst, c_out, z,
                                c_out, stream));
-    TRY(dgnn_bn_batch_stats(z, c_out, n_dst, c_out, mean, var, running_mean, running_var, momentum, scratch, stream));
-    TRY(dgnn_bn_fold(gamma, beta, mean, var, eps, c_out, scale, shift, stream));
+    TRY(dgnn_bn_batch_stats_fold(z, c_out, n_dst, c_out, mean, var, running_mean, running_var, momentum, gamma, beta, eps, scale, shift, scratch, stream));
     TRY(dgnn_scale_shift_act(z, c_out, scale, shift, relu, n_dst, c_out, y, c_out, stream));
     return DGNN_OK;
 }
@@ -169,26 +178,21 @@ int layer_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
     }
     const bool need_dx = dx != nullptr;
     const bool need_da = agg ? (need_dx || We != nullptr) : need_dx;
+    const bool both = need_da && agg && need_dx && Wi;
+    if (both)
+        hipLaunchKernelGGL(k_transpose2, dim3(dgnn_grid_cap(dgnn_cdiv((int64_t)2 * c_in * c_out, 256))), dim3(256), 0, stream, Wj, Wi, c_out, c_in, WjT, WiT);
     if (need_da) {
-        hipLaunchKernelGGL(k_transpose, dim3(dgnn_grid_cap(dgnn_cdiv((int64_t)c_in * c_out, 256))), dim3(256), 0, stream, Wj, c_out, c_in, WjT);
+        if (!both) hipLaunchKernelGGL(k_transpose, dim3(dgnn_grid_cap(dgnn_cdiv((int64_t)c_in * c_out, 256))), dim3(256), 0, stream, Wj, c_out, c_in, WjT);
         // plain Linear block: the gradient of the input is da itself
         TRY(gemm(dz, c_out, c_out, WjT, c_out, 0, n_dst, c_in, agg ? da : dx, c_in));
     }
     if (agg) {
-        if (We) {
-            DGNN_REQUIRE(dWe && dbe, DGNN_E_INVALID, "sage_layer_train_bwd: dWe / dbe missing");
-            if (dbe == dWe + (size_t)c_in * f_e) {   // one buffer (the Python binding's layout): one fill
-                (void)hipMemsetAsync(dWe, 0, sizeof(float) * (size_t)c_in * (f_e + 1), stream);
-            } else {
-                (void)hipMemsetAsync(dWe, 0, sizeof(float) * (size_t)c_in * f_e, stream);
-                (void)hipMemsetAsync(dbe, 0, sizeof(float) * (size_t)c_in, stream);
-            }
-        }
-        if (need_da)
+        if (We) DGNN_REQUIRE(dWe && dbe, DGNN_E_INVALID, "sage_layer_train_bwd: dWe / dbe missing");
+        if (need_da)   // dWe / dbe are written (not accumulated) by the slab reduction: no fill
             TRY(dgnn_sage_aggregate_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x, ldx, c_in, edge_attr, lde, f_e, We, be, nullptr, 0, da, c_in, dx,
                                         c_in, dWe, dbe, nullptr, 0, tmp, stream_));
         if (need_dx && Wi) {
-            hipLaunchKernelGGL(k_transpose, dim3(dgnn_grid_cap(dgnn_cdiv((int64_t)c_in * c_out, 256))), dim3(256), 0, stream, Wi, c_out, c_in, WiT);
+            if (!both) hipLaunchKernelGGL(k_transpose, dim3(dgnn_grid_cap(dgnn_cdiv((int64_t)c_in * c_out, 256))), dim3(256), 0, stream, Wi, c_out, c_in, WiT);
             TRY(gemm(dz, c_out, c_out, WiT, c_out, DGNN_LINEAR_ACCUMULATE, n_dst, c_in, dx, c_in));
         }
     }

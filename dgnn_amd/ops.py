@@ -179,8 +179,8 @@ def aggregate_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, da, edge_att
         We = We.contiguous()
         be = be.contiguous()
         f_e = We.size(1)
-        dWe = torch.zeros_like(We)
-        dbe = torch.zeros_like(be)
+        dWe = torch.empty_like(We)     # written, not accumulated, by the slab reduction
+        dbe = torch.empty_like(be)
         partials = _f32(lib().dgnn_sage_aggregate_bwd_scratch_elems(n_src, c_in, f_e), dev)
     elif phi is not None:
         dphi = torch.zeros((phi.size(0), c_in), dtype=x_src.dtype, device=dev)

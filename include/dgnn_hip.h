@@ -150,6 +150,10 @@ int dgnn_bn_fold(const float* gamma, const float* beta, const float* mean, const
 int64_t dgnn_colstats_scratch_elems(int64_t M, int c);
 int dgnn_bn_batch_stats(const float* x, int64_t ldx, int64_t M, int c, float* mean, float* var, float* running_mean,
                         float* running_var, float momentum, float* scratch, void* stream);
+/* dgnn_bn_batch_stats followed by dgnn_bn_fold on its result, in the same two launches as dgnn_bn_batch_stats alone */
+int dgnn_bn_batch_stats_fold(const float* x, int64_t ldx, int64_t M, int c, float* mean, float* var, float* running_mean,
+                             float* running_var, float momentum, const float* gamma, const float* beta, float eps, float* scale,
+                             float* shift, float* scratch, void* stream);
 /* y = act(x*scale + shift) elementwise over [M,c] (train-mode BN apply + ReLU; in place allowed) */
 int dgnn_scale_shift_act(const float* x, int64_t ldx, const float* scale, const float* shift, int relu, int64_t M,
                          int c, float* y, int64_t ldy, void* stream);
@@ -167,10 +171,10 @@ int dgnn_colsum(const float* x, int64_t ldx, int64_t M, int c, float* out, int a
  * Runs over the TRANSPOSED plan (edges grouped by source) so dx_src needs no atomics:
  *   dm_e   = da[dst_e,:] / max(deg_dst,1)
  *   dphi_e = dm_e * x_src[s,:]          dx_src[s,:] = sum_e dm_e * phi_e
- *   fused mode (We != NULL): phi recomputed; dWe += dphi_e (x) edge_attr[e]; dbe += dphi_e
+ *   fused mode (We != NULL): phi recomputed; dWe = sum_e dphi_e (x) edge_attr[e]; dbe = sum_e dphi_e
  *   given mode (phi != NULL): dphi written to dphi_out[e,:]
  *   t_rowptr/t_dst/t_eid : transposed plan (dgnn_plan_build with by=0); deg_dst from rowptr_dst.
- * dWe [c_in,f_e], dbe [c_in] are accumulated deterministically via `partials`.
+ * dWe [c_in,f_e], dbe [c_in] are WRITTEN (no zero fill needed), summed deterministically via `partials`.
  * ---------------------------------------------------------------------------------------------- */
 int64_t dgnn_sage_aggregate_bwd_scratch_elems(int64_t n_src, int c_in, int f_e);
 int dgnn_sage_aggregate_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, int64_t n_src,
