@@ -525,6 +525,117 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_x3(const float* __restric
     }
 }
 
+// n_out <= 64 (first conv layer, input gradients of the narrow layers, the decoder's hidden layer): 128 x 64 tile, the 2 x 2 wave grid
+// owns 64 x 32 blocks (2 accumulators each) -- the 128-wide tile computes 64..100 % padding columns there.  Same chunk and product
+// order per output element as k_linear_fwd_x3.
+constexpr int ZN = 64;
+__global__ void __launch_bounds__(256, 2) k_linear_fwd_x3_n64(const float* __restrict__ A1, int64_t lda1, int k1, const float* __restrict__ W1,
+                                                              int64_t ldw1, bool vec1, const float* __restrict__ A2, int64_t lda2, int k2,
+                                                              const float* __restrict__ W2, int64_t ldw2, bool vec2,
+                                                              const float* __restrict__ bias, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int relu, int64_t M, int n_out,
+                                                              float* __restrict__ out, int64_t ldo) {
+    __shared__ __attribute__((aligned(16))) char As[XM * XLD];
+    __shared__ __attribute__((aligned(16))) char Ws[ZN * XLD];
+    const int lane = lane_id(), w = wave_id_uniform();
+    const int wr = w >> 1, wc = w & 1, h = lane >> 5, l31 = lane & 31;
+    const int64_t row0 = (int64_t)blockIdx.x * XM;
+    f32x16 acc[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+    const int nch1 = (k1 + XK - 1) / XK, nch2 = A2 ? (k2 + XK - 1) / XK : 0, nch = nch1 + nch2;
+    f32x4 ra[4], rw[2];
+    // W tile: 64 rows x 32 floats: 8 threads per row, 32 rows per pass, 2 passes
+    auto load_w = [&](const float* __restrict__ src, int64_t ld, int k0, int kmax, bool vec) {
+        const int t = threadIdx.x, r = t >> 3, c = (t & 7) * 4;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int gr = r + p * 32;
+            const float* g = src + (int64_t)(gr < n_out ? gr : n_out - 1) * ld;
+            if (vec && k0 + XK <= kmax) {
+                rw[p] = *reinterpret_cast<const f32x4*>(g + k0 + c);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = k0 + c + j;
+                    const float val = g[k < kmax ? k : kmax - 1];
+                    rw[p][j] = k < kmax ? val : 0.f;
+                }
+            }
+        }
+    };
+    auto store_w = [&]() {
+        const int t = threadIdx.x, r = t >> 3, c = (t & 7) * 4;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            uint32_t h0, m0, l0, h1, m1, l1;
+            x3_split(rw[p][0], rw[p][1], h0, m0, l0);
+            x3_split(rw[p][2], rw[p][3], h1, m1, l1);
+            char* d = Ws + (r + p * 32) * XLD + c * 2;
+            *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(d + 64) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2*>(d + 128) = make_uint2(l0, l1);
+        }
+    };
+    auto load_chunk = [&](int ch) {
+        const bool first = ch < nch1;
+        const int kk = first ? k1 : k2, k0 = (first ? ch : ch - nch1) * XK;
+        x3_load(ra, first ? A1 : A2, first ? lda1 : lda2, row0, M, k0, kk, first ? vec1 : vec2);
+        load_w(first ? W1 : W2, first ? ldw1 : ldw2, k0, kk, first ? vec1 : vec2);
+    };
+    load_chunk(0);
+    for (int ch = 0; ch < nch; ++ch) {
+        __syncthreads();
+        x3_store(As, ra);
+        store_w();
+        __syncthreads();
+        if (ch + 1 < nch) load_chunk(ch + 1);
+        const char* ap = As + (wr * 64 + l31) * XLD + h * 16;
+        const char* bp = Ws + (wc * 32 + l31) * XLD + h * 16;
+#pragma unroll
+        for (int S = 0; S < XK / 16; ++S) {
+            bf16x8_t af[2][3], bf[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                bf[p] = *reinterpret_cast<const bf16x8_t*>(bp + p * 64 + S * 32);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) af[m][p] = *reinterpret_cast<const bf16x8_t*>(ap + m * 32 * XLD + p * 64 + S * 32);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                f32x16 c = acc[a];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][2], bf[0], c, 0, 0, 0);   // small terms first
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[0], c, 0, 0, 0);
+                acc[a] = c;
+            }
+        }
+    }
+    const int col = wc * 32 + l31;
+    if (col < n_out) {
+        const float bb = bias ? bias[col] : 0.f;
+        const float sc = scale ? scale[col] : 1.f;
+        const float sh = scale ? shift[col] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= M) continue;
+                float v = acc[a][r] + bb;
+                if (scale) v = __fmaf_rn(v, sc, sh);
+                if (relu & 1) v = fmaxf(v, 0.f);
+                if (relu & DGNN_LINEAR_ACCUMULATE) v += out[row * ldo + col];
+                out[row * ldo + col] = v;
+            }
+    }
+}
+
 // Large problems (M >= 8192 rows, n_out > 128): 256 x 256 output tile per 512-thread block, wave (wr, wc) of the 2 x 4 wave grid owns
 // a 128 x 64 block = 4 x 2 MFMA blocks (8 accumulators).  Splitting the operands costs VALU issue slots (about 12 per element
 // pair) that share the SIMD's issue port with the MFMAs: at 128 x 128 a chunk is 32 elements per thread for 48 MFMAs per wave,
@@ -841,6 +952,12 @@ extern "C" int dgnn_linear_fwd_x3(const float* A1, int64_t lda1, int k1, const f
         dim3 grid((unsigned)(dgnn_cdiv(M, YM) * dgnn_cdiv(n_out, YN)));
         hipLaunchKernelGGL(k_linear_fwd_x3_big, grid, dim3(YT), lds, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2, lda2, k2, W2, ldw2, v2,
                            bias, scale, shift, relu, M, n_out, out, ldo);
+        return dgnn_check_launch("linear_fwd_x3");
+    }
+    static const bool n64_ok = !(getenv("DGNN_X3_N64") && getenv("DGNN_X3_N64")[0] == '0');
+    if (n64_ok && n_out <= ZN) {
+        hipLaunchKernelGGL(k_linear_fwd_x3_n64, dim3((unsigned)dgnn_cdiv(M, XM)), dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2, lda2, k2,
+                           W2, ldw2, v2, bias, scale, shift, relu, M, n_out, out, ldo);
         return dgnn_check_launch("linear_fwd_x3");
     }
     dim3 grid((unsigned)(dgnn_cdiv(M, XM) * dgnn_cdiv(n_out, XN)));

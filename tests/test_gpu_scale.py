@@ -249,3 +249,28 @@ def test_x3_gemm_large_tile_equals_the_small_tile_and_fp64(monkeypatch, k1, k2, 
         ref = ref + A2.double() @ W2.double().t()
     ref = ref.clamp_min(0)
     assert (big.double() - ref).abs().max().item() <= 4e-6 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("k1,k2,n_out", [(28, 28, 64), (128, 0, 64), (64, 64, 28), (64, 0, 2), (512, 0, 64), (70, 33, 37)])
+def test_x3_gemm_narrow_tile_equals_the_128_wide_tile(monkeypatch, k1, k2, n_out):
+    """n_out <= 64 takes a 128 x 64 tile; per output element it is the 128 x 128 kernel's arithmetic (reached here by padding W with zero
+    rows to 128 outputs), so the shared columns are bit-identical."""
+    from dgnn_amd import ops
+    monkeypatch.setattr(ops, "GEMM_MODE", ops.GEMM_BF16X3)
+    g = torch.Generator().manual_seed(k1 * 7 + n_out)
+    M = 5000 + 77
+    A1 = torch.randn(M, k1, generator=g).to(DEV)
+    W1 = (torch.randn(n_out, k1, generator=g) / k1 ** 0.5).to(DEV)
+    A2 = torch.randn(M, k2, generator=g).to(DEV) if k2 else None
+    W2 = (torch.randn(n_out, k2, generator=g) / k2 ** 0.5).to(DEV) if k2 else None
+    bias = torch.randn(n_out, generator=g).to(DEV)
+    pad = lambda W: torch.cat([W, torch.zeros(128 - n_out, W.size(1), device=DEV)])
+    narrow = ops.linear_fwd(A1, W1, A2, W2, bias, relu=True)
+    wide = ops.linear_fwd(A1, pad(W1), A2, pad(W2) if k2 else None, torch.cat([bias, torch.zeros(128 - n_out, device=DEV)]), relu=True)
+    assert torch.equal(narrow, wide[:, :n_out])
+    acc = torch.randn(M, n_out, generator=g).to(DEV)      # the accumulate flag of the backward pass
+    out = acc.clone()
+    from dgnn_amd._lib import lib, ptr, stream_ptr, check
+    check(lib().dgnn_linear_fwd_x3(ptr(A1), A1.stride(0), k1, ptr(W1), k1, None, 0, 0, None, 0, None, None, None, 2, M, n_out, ptr(out), n_out, stream_ptr()), "x3")
+    ref = acc + ops.linear_fwd(A1, W1)
+    assert torch.equal(out, ref)
