@@ -439,11 +439,15 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_x3(const float* __restric
     __shared__ __attribute__((aligned(16))) char Ws[XN * XLD];
     const int lane = lane_id(), w = wave_id_uniform();
     const int wr = w >> 1, wc = w & 1, h = lane >> 5, l31 = lane & 31;
-    // 1-D grid, column blocks fastest: the blocks that share a row panel of A run together and read it once from HBM (with the
-    // row blocks fastest every column block streamed all of A again: 4x the traffic at n_out = 512)
+    // 1-D grid with an XCD-aware tile map: workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8) and every XCD has its own L2,
+    // so the column blocks of one row panel sit on ONE XCD, next to each other in its queue, and the panel of A comes through the fabric
+    // once (FETCH_SIZE at M = 1M, K = 512, N = 512: 2.5 GB; with plain "column blocks fastest" the four column blocks landed on four
+    // XCDs: 8.4 GB; with row blocks fastest every column block streamed all of A again).  The grid is padded to 8 x ceil(row blocks / 8).
     const int ncb = (n_out + XN - 1) / XN;
-    const int64_t row0 = (int64_t)(blockIdx.x / ncb) * XM;
-    const int col0 = (int)(blockIdx.x % ncb) * XN;
+    const int64_t rb = (int64_t)((blockIdx.x >> 3) / ncb) * 8 + (blockIdx.x & 7);
+    if (rb * XM >= M) return;
+    const int64_t row0 = rb * XM;
+    const int col0 = (int)((blockIdx.x >> 3) % ncb) * XN;
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -695,9 +699,11 @@ __global__ void __launch_bounds__(YT, 1) k_linear_fwd_x3_big(const float* __rest
     char* const Ws = y3_smem + YM * XLD;
     const int lane = lane_id(), w = wave_id_uniform();
     const int wr = w >> 2, wc = w & 3, h = lane >> 5, l31 = lane & 31;
-    const int ncb = (n_out + YN - 1) / YN;   // column blocks fastest (see k_linear_fwd_x3)
-    const int64_t row0 = (int64_t)(blockIdx.x / ncb) * YM;
-    const int col0 = (int)(blockIdx.x % ncb) * YN;
+    const int ncb = (n_out + YN - 1) / YN;   // XCD-aware tile map (see k_linear_fwd_x3)
+    const int64_t rb = (int64_t)((blockIdx.x >> 3) / ncb) * 8 + (blockIdx.x & 7);
+    if (rb * YM >= M) return;
+    const int64_t row0 = rb * YM;
+    const int col0 = (int)((blockIdx.x >> 3) % ncb) * YN;
     f32x16 acc[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -949,7 +955,7 @@ extern "C" int dgnn_linear_fwd_x3(const float* A1, int64_t lda1, int k1, const f
         static bool attr_set[DGNN_MAX_DEVICES];
         constexpr size_t lds = (size_t)(YM + YN) * XLD;
         dgnn_allow_dynamic_lds((const void*)k_linear_fwd_x3_big, lds, attr_set);
-        dim3 grid((unsigned)(dgnn_cdiv(M, YM) * dgnn_cdiv(n_out, YN)));
+        dim3 grid((unsigned)(dgnn_cdiv(dgnn_cdiv(M, YM), 8) * 8 * dgnn_cdiv(n_out, YN)));
         hipLaunchKernelGGL(k_linear_fwd_x3_big, grid, dim3(YT), lds, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2, lda2, k2, W2, ldw2, v2,
                            bias, scale, shift, relu, M, n_out, out, ldo);
         return dgnn_check_launch("linear_fwd_x3");
@@ -960,7 +966,7 @@ extern "C" int dgnn_linear_fwd_x3(const float* A1, int64_t lda1, int k1, const f
                            W2, ldw2, v2, bias, scale, shift, relu, M, n_out, out, ldo);
         return dgnn_check_launch("linear_fwd_x3");
     }
-    dim3 grid((unsigned)(dgnn_cdiv(M, XM) * dgnn_cdiv(n_out, XN)));
+    dim3 grid((unsigned)(dgnn_cdiv(dgnn_cdiv(M, XM), 8) * 8 * dgnn_cdiv(n_out, XN)));
     hipLaunchKernelGGL(k_linear_fwd_x3, grid, dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2, lda2, k2, W2, ldw2, v2, bias,
                        scale, shift, relu, M, n_out, out, ldo);
     return dgnn_check_launch("linear_fwd_x3");
