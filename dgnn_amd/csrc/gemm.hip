@@ -741,17 +741,13 @@ __global__ void __launch_bounds__(YT, 1) k_linear_fwd_x3_big(const float* __rest
                 bf16x8_t af[3];
 #pragma unroll
                 for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const bf16x8_t*>(ap + a * 32 * XLD + p * 64 + S * 32);
+                // the two column blocks alternate product by product: consecutive MFMAs never wait for each other's result, and every
+                // accumulator still sees its six products in the same order (small terms first)
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    f32x16 c = acc[a][b];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[b][0], c, 0, 0, 0);   // small terms first
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[b][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[b][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[b][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[b][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[b][0], c, 0, 0, 0);
-                    acc[a][b] = c;
-                }
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[q]], bf[b][PB[q]], acc[a][b], 0, 0, 0);
             }
         }
     }
