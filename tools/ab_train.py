@@ -1,7 +1,8 @@
 """Interleaved A/B of training-step variants inside ONE process (box-to-box and run-to-run drift is +-15 %): segments of 40 steps
 alternate between the settings, the median segment time per setting is reported.
-    python tools/ab_train.py whole=1 whole=0            (ops.TRAIN_WHOLE_MODEL)
-    python tools/ab_train.py composite=1 composite=0    (ops.TRAIN_COMPOSITE)"""
+    python tools/ab_train.py whole=1 whole=0 composite=0     all layers in one call | one call per layer | separate Functions
+    python tools/ab_train.py aux=0 aux=1                      weight gradients on the second stream
+Every setting starts from the defaults (composite=1, whole=1, aux=0); several flags: "whole=0,aux=1"."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -38,13 +39,17 @@ def _timed_finish(self, b):
     return out
 NeighborSampler._finish_regular = _timed_finish
 def apply(s):
-    k, v = s.split("=")
-    if k == "whole": ops.TRAIN_WHOLE_MODEL = v == "1"
-    elif k == "composite": ops.TRAIN_COMPOSITE = v == "1"
-    elif k == "aux":
-        from dgnn_amd._lib import lib
-        lib().dgnn_train_set_aux_stream(int(v))
-    else: raise SystemExit("unknown setting " + s)
+    """every setting names the COMPLETE configuration (an earlier version of this tool changed one flag per setting and left the others
+    where the previous setting had put them: 'whole=1 whole=0 composite=0' then measured composite=0 three times)"""
+    from dgnn_amd._lib import lib
+    ops.TRAIN_COMPOSITE, ops.TRAIN_WHOLE_MODEL = True, True
+    lib().dgnn_train_set_aux_stream(0)
+    for part in s.split(","):
+        k, v = part.split("=")
+        if k == "whole": ops.TRAIN_WHOLE_MODEL = v == "1"
+        elif k == "composite": ops.TRAIN_COMPOSITE = v == "1"
+        elif k == "aux": lib().dgnn_train_set_aux_stream(int(v))
+        else: raise SystemExit("unknown setting " + s)
 def seg(nsteps):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(nsteps):

@@ -18,8 +18,8 @@ for t, title in [("", "StaticEdgeFilters fp32 (all layers in one library call ea
                  ("updateddtypebf16", "UpdatedEdgeFilters sage+ bf16 storage (BASELINE config 3's shape of work)")]:
     out += ["## " + title, "", "```"] + open("%s/%s_train%s.gaps.txt" % (G, T, t)).read().rstrip().split("\n") + ["```", ""]
 out += ["## reading", "",
-        "* ~110 kernels of 5-100 us on the step's stream, 1.3-1.6 ms of GPU time; the un-profiled step takes 1.5-2.3 ms depending on the box (some are",
-        "  host-bound, some sit on the GPU's chain of dependent kernels: on those the three host-side variants of the A/B above take the same time).",
+        "* ~110 kernels of 5-100 us on the step's stream, 1.3-1.6 ms of GPU time; the un-profiled step takes 1.4-2.3 ms depending on the box: it is",
+        "  host-bound, and the A/B above shows what each layer of host-side work costs (all layers per call < one call per layer < separate Functions).",
         "* Round 2 removed the launches that were pure overhead (the ~40-launch loss, the per-layer `edge_attr[e_id]` copies, the whole-scene `[E_all, C]` edge",
         "  tensors of the Updated variant, the transposed-plan builds on the main stream, three host round trips in the metrics, four in the block builder,",
         "  the BatchNorm fold, one weight transpose and the zero fills per layer) and moved the block builder to the library's own thread and stream.",
