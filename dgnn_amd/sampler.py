@@ -38,7 +38,8 @@ class EdgeIndex(tuple):
 
 class NeighborSampler:
     def __init__(self, edge_index, sizes, node_idx=None, num_nodes=None, batch_size=1, shuffle=False, drop_last=False,
-                 return_e_id=True, plan: GraphPlan = None, generator=None, prefetch=True, transposed_plans=True, **kwargs):
+                 return_e_id=True, plan: GraphPlan = None, generator=None, prefetch=True, transposed_plans=True, reuse_buffers=False,
+                 **kwargs):
         if any(int(s) != -1 for s in sizes):
             raise NotImplementedError("only full neighbourhoods (size -1) are used by the reference (clique_sizes: [-1])")
         if not edge_index.is_cuda:
@@ -63,6 +64,11 @@ class NeighborSampler:
         # prefetching iteration also builds every block's source-sorted (transposed) plan, which the backward pass needs, on the
         # builder's stream; False leaves it to the first backward (inference loaders never need it)
         self.transposed_plans = bool(transposed_plans)
+        # reuse_buffers (prefetching iteration over a 4-regular graph only): blocks are built into a ring of three preallocated buffer
+        # sets instead of ~50 fresh tensors each -- a block (its n_id, edge lists, plans) is then valid only until TWO more blocks have
+        # been drawn.  A training loop consumes a block before it asks for the next; anything that keeps blocks (list(loader)) must not
+        # set it.
+        self._ring = [None] * 3 if reuse_buffers else None
         self._escaped = None
         self._pos = torch.full((n,), -1, dtype=torch.int32, device=self.device)
         self._first = torch.full((n,), _I32_MAX, dtype=torch.int32, device=self.device)
@@ -99,15 +105,37 @@ class NeighborSampler:
         if self.prefetch != "thread" and self._regular and ONE_CALL and self.batch_size > 0:
             # the library's own host thread builds block k+1 while this thread enqueues step k
             pending = None
+            ring, ring_free, k = self._ring, [None] * 3, 0   # reuse_buffers: three buffer sets, block j builds into set j % 3
+            with torch.cuda.device(self.device):
+                self._caller_stream = torch.cuda.current_stream()
             try:
                 for s in starts:
                     blk = self._finish_on_side(pending) if pending is not None else None
                     pending = None
                     with torch.cuda.device(self.device), torch.cuda.stream(side):
-                        self._escaped = []
-                        pending = (self._start_regular(idx[s:s + self.batch_size].contiguous(), background=True), self._escaped)
+                        batch = idx[s:s + self.batch_size].contiguous()
+                        slot = None
+                        if ring is not None:
+                            # everything the caller enqueued up to now (the step on block k-2 and before) precedes this point on its
+                            # stream; set k % 3 was last handed out as block k-3: the builder may overwrite it once that point is passed
+                            slot = k % 3
+                            if ring[slot] is None or ring[slot]["cap_nb"] < batch.numel():
+                                ring[slot] = self._alloc_regular(max(self.batch_size, batch.numel()), self.transposed_plans)
+                                for v in ring[slot].values():   # allocated on the builder's stream, read on the caller's for their whole life
+                                    for t in (v if isinstance(v, list) else [v]):
+                                        if isinstance(t, torch.Tensor):
+                                            t.record_stream(self._caller_stream)
+                            if ring_free[slot] is not None:
+                                side.wait_event(ring_free[slot])
+                        self._escaped = [] if ring is None else None
+                        pending = (self._start_regular(batch, background=True, b=ring[slot] if ring is not None else None), self._escaped)
                         self._escaped = None
+                        k += 1
                     if blk is not None:
+                        if ring is not None:
+                            # the caller is done enqueueing the step on the block before this one: mark that point on ITS stream
+                            with torch.cuda.device(self.device):
+                                ring_free[(k - 3) % 3] = torch.cuda.current_stream().record_event()
                         yield self._hand_over(blk)
                 if pending is not None:
                     blk, pending = self._finish_on_side(pending), None
@@ -194,7 +222,7 @@ class NeighborSampler:
         with torch.cuda.device(self.device):
             cur = torch.cuda.current_stream()
             cur.wait_event(ev)
-            for t in tensors:
+            for t in tensors or ():     # (None: the block lives in the reuse ring, nothing is freed)
                 t.record_stream(cur)   # the allocator must not recycle them for the next block while this stream reads them
         return out
 
@@ -202,18 +230,16 @@ class NeighborSampler:
         with torch.cuda.device(self.device):  # the plan's GPU, whatever the thread's current device is
             return self._sample(batch)
 
-    def _start_regular(self, n_id: torch.Tensor, background: bool):
-        """every node has exactly 4 in-edges: all hops (and, when iterating with prefetch, the transposed plans) in one library
-        call into buffers sized by the 5^h growth bound.  `background`: the call runs on a library-owned host thread
-        (dgnn_khop_blocks_regular_start) and this returns at once; _finish_regular joins it and cuts the views."""
+    def _alloc_regular(self, nb: int, want_t: bool):
+        """buffers of one batch of `nb` targets, sized by the 5^h growth bound (4-regular graph: 4 new sources per target at most),
+        and the argument arrays that only depend on them"""
         import ctypes as C
-        hops, p, dev = len(self.sizes), self.plan, self.device
-        nb = n_id.numel()
+        hops, dev = len(self.sizes), self.device
         cap_t = [min(nb * 5 ** h, self.num_nodes) for h in range(hops)]
         cap_e = [4 * t for t in cap_t]
         i64 = lambda n: torch.empty(n, dtype=torch.int64, device=dev)      # nb > 0: every capacity is positive
         i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
-        b = dict(nb=nb, n_id=n_id, hops=hops,
+        b = dict(cap_nb=nb, hops=hops, want_t=want_t,
                  ei=[torch.empty((2, e), dtype=torch.int64, device=dev) for e in cap_e], e_id=[i64(e) for e in cap_e],
                  src32=[i32(e) for e in cap_e], e_id32=[i32(e) for e in cap_e], off=[i32(t + 1) for t in cap_t],
                  n_out=[i64(t + e) for t, e in zip(cap_t, cap_e)])
@@ -221,19 +247,29 @@ class NeighborSampler:
         b["scratch"] = scratch = i32(max(int(L.dgnn_khop_scratch_elems(t, e)) for t, e in zip(cap_t, cap_e)) + 1)
         arr = lambda ts: (C.c_void_p * hops)(*[t.data_ptr() for t in ts])
         caps = lambda v: (C.c_int64 * hops)(*v)
-        b["counts"] = counts = (C.c_int64 * (hops + 1))()
-        # prefetching iteration (training): the source-sorted plans the backward pass walks come out of the same call
-        b["want_t"] = want_t = self.transposed_plans and self._escaped is not None
         t_arrs, cap_all, plan_scratch = [None] * 4, None, None
-        if want_t:
+        if want_t:   # prefetching iteration (training): the source-sorted plans the backward pass walks come out of the same call
             cap_all = [min(t + e, self.num_nodes) for t, e in zip(cap_t, cap_e)]
             b["t_rowptr"] = [i32(a + 1) for a in cap_all]
             b["t_dst"], b["t_eid"], b["t_rows"] = ([i32(e) for e in cap_e] for _ in range(3))
             b["plan_scratch"] = plan_scratch = i32(max(int(L.dgnn_plan_scratch_elems(e, a)) for e, a in zip(cap_e, cap_all)))
             t_arrs = [arr(b[k]) for k in ("t_rowptr", "t_dst", "t_eid", "t_rows")]
-        args = (ptr(p.rowptr), ptr(p.src), ptr(p.eid), 4, ptr(n_id), nb, hops, ptr(self._pos), ptr(self._first), arr(b["ei"]), arr(b["e_id"]),
-                arr(b["src32"]), arr(b["e_id32"]), arr(b["off"]), arr(b["n_out"]), caps(cap_t), caps(cap_e), ptr(scratch[:-1]), ptr(scratch[-1:]),
-                *t_arrs, caps(cap_all) if want_t else None, ptr(plan_scratch))
+        b["args_tail"] = (arr(b["ei"]), arr(b["e_id"]), arr(b["src32"]), arr(b["e_id32"]), arr(b["off"]), arr(b["n_out"]), caps(cap_t), caps(cap_e),
+                          ptr(scratch[:-1]), ptr(scratch[-1:]), *t_arrs, caps(cap_all) if want_t else None, ptr(plan_scratch))
+        return b
+
+    def _start_regular(self, n_id: torch.Tensor, background: bool, b=None):
+        """every node has exactly 4 in-edges: all hops (and, when iterating with prefetch, the transposed plans) in one library
+        call.  `background`: the call runs on a library-owned host thread (dgnn_khop_blocks_regular_start) and this returns at
+        once; _finish_regular joins it and cuts the views.  `b`: buffers to build into (a slot of the reuse ring), default fresh ones."""
+        import ctypes as C
+        p, nb = self.plan, n_id.numel()
+        if b is None:
+            b = self._alloc_regular(nb, self.transposed_plans and self._escaped is not None)
+        b["nb"], b["n_id"] = nb, n_id
+        b["counts"] = counts = (C.c_int64 * (b["hops"] + 1))()
+        L = lib()
+        args = (ptr(p.rowptr), ptr(p.src), ptr(p.eid), 4, ptr(n_id), nb, b["hops"], ptr(self._pos), ptr(self._first)) + b["args_tail"]
         if background:
             b["job"] = L.dgnn_khop_blocks_regular_start(*args, stream_ptr())
             if not b["job"]:
@@ -258,7 +294,8 @@ class NeighborSampler:
             if b["want_t"]:
                 plan._t = (b["t_rowptr"][h][:n_all + 1], b["t_dst"][h][:n_e], b["t_eid"][h][:n_e])
                 plan._t_rows = b["t_rows"][h][:n_e]
-                self._escaped += [b[k][h] for k in ("t_rowptr", "t_dst", "t_eid", "t_rows")]
+                if self._escaped is not None:
+                    self._escaped += [b[k][h] for k in ("t_rowptr", "t_dst", "t_eid", "t_rows")]
             register_plan(e, plan)
             adjs.append(EdgeIndex(e, b["e_id"][h][:n_e] if self.return_e_id else None, (n_all, n_t)))
             if self._escaped is not None:

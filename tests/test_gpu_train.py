@@ -415,3 +415,37 @@ def test_aux_stream_backward_gives_identical_gradients():
         lib().dgnn_train_set_aux_stream(was)
     for k in res[0]:
         assert torch.equal(res[0][k], res[1][k]) and torch.equal(res[0][k], res[2][k]), k
+
+
+def test_block_builder_buffer_ring_gives_the_same_training_run():
+    """reuse_buffers=True (blocks built into a ring of three preallocated buffer sets, valid until two more have been drawn) under a
+    training loop that consumes each block before asking for the next: same losses and parameters as with fresh tensors per block"""
+    from dgnn_amd.learning.runModel import Metrics, Trainer
+    from dgnn_amd.sampler import NeighborSampler
+    from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal
+    from test_trainer_cpu import make_clf
+    adj, _, _ = delaunay_tet_graph(4000, seed=3)
+    n = adj.shape[0] // 4
+    ei = torch.from_numpy(adj.T.astype(np.int64)).to(DEV)
+    x = hashed_normal(np.arange(n), 29, seed=1, device=DEV)
+    x[:, 0] = x[:, 0].abs() + 0.05
+    ea = hashed_normal(np.arange(4 * n), 20, seed=2, device=DEV)
+    occ = torch.sigmoid(2 * x[:, 3:4] + x[:, 7:8])
+    all_ = Config(x=x, y=torch.cat([occ, 1 - occ], 1), edge_attr=ea)
+    idx = torch.randperm(n, generator=torch.Generator().manual_seed(1))[:12 * 300 + 77].to(DEV)     # 13 batches, the last one short
+    out = []
+    for ring in (False, True):
+        clf = make_clf()
+        clf.temp.device = DEV
+        clf.training.metrics = Metrics()
+        net = hip_static(train=True)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        tr = Trainer(net)
+        losses = []
+        for bs, n_id, adjs in NeighborSampler(ei, sizes=[-1] * 4, node_idx=idx, num_nodes=n, batch_size=300, reuse_buffers=ring):
+            losses.append(tr.train(Config(all=all_, batch_n_id=n_id, batch_adjs=adjs), opt, clf))
+        torch.cuda.synchronize()
+        out.append((torch.stack(losses).cpu(), {k: v.detach().clone() for k, v in net.state_dict().items()}))
+    assert torch.equal(out[0][0], out[1][0])
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k

@@ -31,7 +31,7 @@ adjust_learning_rate(opt, clf)
 per = (n // 2048) * 2048      # whole batches per permutation: no duplicate targets inside a batch
 need = 2048 * (ROUNDS * len(settings) * SEG + 5 * len(settings) + 8)
 idx = torch.cat([torch.randperm(n)[:per] for _ in range(need // per + 1)])[:need].to(dev)
-it = iter(NeighborSampler(ei, sizes=[-1] * 4, node_idx=idx, num_nodes=n, batch_size=2048))
+it = iter(NeighborSampler(ei, sizes=[-1] * 4, node_idx=idx, num_nodes=n, batch_size=2048, reuse_buffers=os.environ.get("RING", "1") == "1"))
 _wait = [0.0, 0]
 _orig_finish = NeighborSampler._finish_regular
 def _timed_finish(self, b):

@@ -38,6 +38,7 @@ ap.add_argument("--warmup", type=int, default=300, help="untimed steps; the GPU 
 ap.add_argument("--prefetch", choices=["none", "stream", "thread"], default="stream",
                 help="block builder: in line | one block ahead on a side stream, issued by the library's builder thread (default) | "
                      "ahead in a Python worker thread")
+ap.add_argument("--fresh-blocks", action="store_true", help="fresh tensors for every block instead of the builder's ring of three buffer sets")
 ap.add_argument("--no-roofline", action="store_true", help="skip the GEMM / aggregate replays behind the `roofline` object")
 args = ap.parse_args()
 
@@ -104,7 +105,7 @@ per = (n // batch) * batch     # whole batches per permutation: no duplicate tar
 need = batch * (steps + args.warmup)
 idx = torch.cat([torch.randperm(n, generator=g)[:per] for _ in range(need // per + 1)])[:need]
 loader = NeighborSampler(ei, sizes=[-1] * 4, node_idx=idx.to(dev), num_nodes=n, batch_size=batch,
-                         prefetch={"none": False, "stream": True, "thread": "thread"}[args.prefetch])
+                         prefetch={"none": False, "stream": True, "thread": "thread"}[args.prefetch], reuse_buffers=not args.fresh_blocks)
 it = iter(loader)
 block = 0
 for _ in range(args.warmup):
