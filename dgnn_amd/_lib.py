@@ -146,9 +146,13 @@ def ptr(t):
 
 def stream_ptr():
     """torch's current stream of the CURRENT device; callers launch under `on_device_of` so that this is the device
-    the tensors live on (the reference addresses its GPU as "cuda:<n>" and never calls set_device: run.py:98,127)."""
+    the tensors live on (the reference addresses its GPU as "cuda:<n>" and never calls set_device: run.py:98,127).
+    (torch.cuda.current_stream() builds a Stream object through three Python layers, ~10 us; the training step asks ~30 times.)"""
     import torch
 
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is not None:
+        return C.c_void_p(raw(torch._C._cuda_getDevice()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -159,6 +163,8 @@ def on_device_of(fn):
     import functools
 
     import torch
+
+    _current_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
 
     def _tensors(a, k):
         for t in a:
@@ -177,7 +183,7 @@ def on_device_of(fn):
                     dev = t.device
                 elif t.device != dev:
                     raise DgnnError("%s: tensors on different devices (%s, %s)" % (fn.__name__, dev, t.device))
-        if dev is not None and dev.index != torch.cuda.current_device():
+        if dev is not None and dev.index != _current_device():
             with torch.cuda.device(dev):
                 return fn(*a, **k)
         return fn(*a, **k)

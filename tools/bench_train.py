@@ -83,8 +83,8 @@ if args.updated:
             opt.zero_grad()
             ids = data.batch_n_id[:data.batch_adjs[-1][2][1]]
             logits = net(Config(x=data.all.x, edge_attr=data.all.edge_attr, n_id=data.batch_n_id, adjs=data.batch_adjs)).float()
-            w = data.all.x[ids, 0]
-            loss = (F.kl_div(F.log_softmax(logits, dim=-1), data.all.y[ids], reduction="none").sum(1) * w).sum() / w.sum()
+            from dgnn_amd import functional as Fn
+            loss, _ = Fn.kl_cell_loss(logits, data.all.y[ids], data.all.x[ids, 0])   # the Trainer's fused loss (runModel.py:171-209)
             loss.backward()
             allreduce_gradients(net, group)
             opt.step()
