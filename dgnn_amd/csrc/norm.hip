@@ -58,6 +58,71 @@ __global__ void __launch_bounds__(256) k_colreduce(const T* __restrict__ x, int6
     }
 }
 
+// fp32 rows of 4 | 8 | ... | 256 channels with 16-byte aligned rows: every thread walks FOUR columns with 16-byte loads (256 threads =
+// c/4 column groups x 1024/c row lanes).  The scalar kernel above keeps one 4-byte load per row in flight per lane and ran the training
+// step's 15 column reductions at 1.4-2.7 TB/s.  Same partials layout; sums are fp64, so the different association order is invisible
+// after the rounding to fp32 except at exact ties.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_colreduce4(const float* __restrict__ x, int64_t ldx, const float* __restrict__ y, int64_t ldy,
+                                                    const float* __restrict__ dy, int64_t lddy, const float* __restrict__ mean,
+                                                    const float* __restrict__ var, float eps, int relu, int64_t M, int c,
+                                                    int64_t rows_per_block, double* __restrict__ partials) {
+    __shared__ double red[2][1024];   // [quantity][row lane][column], nrl * c = 1024
+    const int ng = c >> 2, nrl = 256 / ng;
+    const int tg = threadIdx.x % ng, ty = threadIdx.x / ng, col = 4 * tg;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(M, r0 + rows_per_block);
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f};
+    if (MODE == 1) {
+        mu = *reinterpret_cast<const f32x4*>(mean + col);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(var + col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) is[j] = 1.0f / sqrtf(v[j] + eps);
+    }
+    for (int64_t r = r0 + ty; r < r1; r += nrl) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * ldx + col);
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s0[j] += xv[j];
+                s1[j] += (double)xv[j] * xv[j];
+            }
+        } else if (MODE == 1) {
+            f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * lddy + col);
+            if (relu) {
+                const f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * ldy + col);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (!(yv[j] > 0.f)) g[j] = 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (xv[j] - mu[j]) * is[j];
+                s0[j] += g[j];
+                s1[j] += (double)g[j] * xh;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s0[j] += xv[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[0][ty * c + col + j] = s0[j];
+        red[1][ty * c + col + j] = s1[j];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 2 * c; o += 256) {
+        const int q = o / c, cc = o - q * c;
+        double t = 0.0;
+        for (int k = 0; k < nrl; ++k) t += red[q][k * c + cc];
+        partials[((int64_t)blockIdx.x * 2 + q) * c + cc] = t;
+    }
+}
+
+__device__ __host__ inline bool colreduce4_ok(int c) { return c >= 4 && c <= 256 && (c & (c - 1)) == 0; }
+
 // Deterministic two-level finalisers: 1024 threads = 16 columns x 64 slices; slice s sums partial blocks s, s+64, ... in
 // ascending order, then the 64 slice sums are added in slice order.  (A single thread per column walking all ~1000 partial
 // blocks was a 80-90 us dependent-load chain -- 30 % of a training step; 16 slices still left a 64-long chain, 10-20 us.)
@@ -198,6 +263,21 @@ extern "C" int dgnn_bn_fold(const float* gamma, const float* beta, const float* 
     return dgnn_check_launch("bn_fold");
 }
 
+// MODE-templated launch: the vectorised kernel for fp32 rows it covers, the general one otherwise
+template <int MODE, typename T>
+static void launch_colreduce(int nblk, hipStream_t stream, const T* x, int64_t ldx, const T* y, int64_t ldy, const T* dy, int64_t lddy, const float* mean,
+                             const float* var, float eps, int relu, int64_t M, int c, int64_t rpb, double* P) {
+    if constexpr (sizeof(T) == 4) {
+        auto al = [](const void* p, int64_t ld) { return p == nullptr || ((((uintptr_t)p) & 15) == 0 && ld % 4 == 0); };
+        if (colreduce4_ok(c) && al(x, ldx) && al(y, ldy) && al(dy, lddy) && al(mean, 4) && al(var, 4)) {
+            hipLaunchKernelGGL((k_colreduce4<MODE>), dim3(nblk), dim3(256), 0, stream, (const float*)x, ldx, (const float*)y, ldy, (const float*)dy, lddy, mean,
+                               var, eps, relu, M, c, rpb, P);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((k_colreduce<MODE, T>), dim3(nblk), dim3(256), 0, stream, x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, rpb, P);
+}
+
 template <typename T>
 static int bn_batch_stats_t(const T* x, int64_t ldx, int64_t M, int c, float* mean, float* var, float* running_mean, float* running_var,
                             float momentum, float* scratch, hipStream_t stream, const float* gamma = nullptr, const float* beta = nullptr,
@@ -206,8 +286,7 @@ static int bn_batch_stats_t(const T* x, int64_t ldx, int64_t M, int c, float* me
     const int nblk = red_blocks(M);
     const int64_t rpb = dgnn_cdiv(M, nblk);
     double* P = as_f64(scratch);
-    hipLaunchKernelGGL((k_colreduce<0, T>), dim3(nblk), dim3(256), 0, stream, x, ldx, (const T*)nullptr, (int64_t)0, (const T*)nullptr,
-                       (int64_t)0, nullptr, nullptr, 0.f, 0, M, c, rpb, P);
+    launch_colreduce<0, T>(nblk, stream, x, ldx, (const T*)nullptr, (int64_t)0, (const T*)nullptr, (int64_t)0, nullptr, nullptr, 0.f, 0, M, c, rpb, P);
     hipLaunchKernelGGL(k_stats_finalize, dim3((c + 15) / 16), dim3(FIN_THREADS), 0, stream, P, nblk, M, c, mean, var, running_mean,
                        running_var, momentum, gamma, beta, eps, scale, shift);
     return dgnn_check_launch("bn_batch_stats");
@@ -233,7 +312,7 @@ static int bn_relu_bwd_t(const T* x, int64_t ldx, const T* y, int64_t ldy, const
     const int64_t rpb = dgnn_cdiv(M, nblk);
     double* P = as_f64(scratch);
     float* sums = reinterpret_cast<float*>(P + (int64_t)nblk * 2 * c);
-    hipLaunchKernelGGL((k_colreduce<1, T>), dim3(nblk), dim3(256), 0, stream, x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, rpb, P);
+    launch_colreduce<1, T>(nblk, stream, x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, rpb, P);
     hipLaunchKernelGGL(k_sum_finalize, dim3((c + 15) / 16), dim3(FIN_THREADS), 0, stream, P, nblk, c, sums, sums + c, 0, dbeta, dgamma);
     hipLaunchKernelGGL((k_bn_relu_bwd_apply<T>), dim3(dgnn_grid_cap(dgnn_cdiv(M * c, 256))), dim3(256), 0, stream, x, ldx, y, ldy, dy, lddy,
                        gamma, mean, var, eps, train, relu, M, c, sums, sums + c, dx, lddx);
@@ -246,8 +325,7 @@ static int colsum_t(const T* x, int64_t ldx, int64_t M, int c, float* out, int a
     const int nblk = red_blocks(M);
     const int64_t rpb = dgnn_cdiv(M, nblk);
     double* P = as_f64(scratch);
-    hipLaunchKernelGGL((k_colreduce<2, T>), dim3(nblk), dim3(256), 0, stream, x, ldx, (const T*)nullptr, (int64_t)0, (const T*)nullptr,
-                       (int64_t)0, nullptr, nullptr, 0.f, 0, M, c, rpb, P);
+    launch_colreduce<2, T>(nblk, stream, x, ldx, (const T*)nullptr, (int64_t)0, (const T*)nullptr, (int64_t)0, nullptr, nullptr, 0.f, 0, M, c, rpb, P);
     hipLaunchKernelGGL(k_sum_finalize, dim3((c + 15) / 16), dim3(FIN_THREADS), 0, stream, P, nblk, c, out, (float*)nullptr, accumulate,
                        (float*)nullptr, (float*)nullptr);
     return dgnn_check_launch("colsum");
