@@ -335,11 +335,12 @@ class NeighborSampler:
             # the block is emitted grouped by destination with `off` as its row offsets: that IS its plan (identity order)
             src32 = e_src.to(torch.int32)
             plan = GraphPlan(ei, n_all, n_t, parts=(off, src32, self._arange(n_e)))
+            plan.edge_rows = e_id.to(torch.int32)   # rows of the scene's edge_attr behind the block's edges (see _finish_regular)
             register_plan(ei, plan)
             if self._escaped is not None:
-                self._escaped += [ei, e_id, off, src32, self._iota, n_id_out]
+                self._escaped += [ei, e_id, off, src32, self._iota, n_id_out, plan.edge_rows]
                 if self.transposed_plans:
-                    self._escaped += list(plan.transposed)
+                    self._escaped += list(plan.transposed) + [plan.transposed_edge_rows]
             adjs.append(EdgeIndex(ei, e_id if self.return_e_id else None, (n_all, n_t)))
         check(L.dgnn_khop_reset(ptr(n_id), n_id.numel(), ptr(self._pos), st), "dgnn_khop_reset")
         adjs = adjs[0] if len(adjs) == 1 else adjs[::-1]
