@@ -109,14 +109,14 @@ def cpu_oracle(net_sd, convs, x, ea, ei, threads, runs):
     return float(np.median(times)), out
 
 
-def training_leg():
+def training_leg(extra=()):
     """SURVEY 8d "fwd+bwd+Adam, reported separately": tools/bench_train.py (block builder + SurfaceNet.forward in train mode + KL loss +
     backward + Adam on 2048-target 4-hop blocks of the same scene) run as a child process once the timed inference region is over;
     returns its JSON line (ms_per_step, targets/s, its own roofline object) or the reason it could not run."""
     import subprocess
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
-    cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "bench_train.py"), "--steps", "200", "--warmup", "300"]
+    cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "bench_train.py"), "--steps", "200", "--warmup", "300"] + list(extra)
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -438,8 +438,9 @@ def main():
                        "breakdown_ms": {k: round(v, 4) for k, v in breakdown.items()}},
             "roofline": roof, "cpu_baseline": cpu, "check": check,
         }
-        if world == 1 and not args.no_train and args.widths is None and not bf16 and args.points == 150000:
-            out["training_step"] = training_leg()
+        if world == 1 and not args.no_train and args.widths is None and args.points == 150000:
+            # fp32 line: the Static model's step; bf16 line: BASELINE config 3's shape of work (Updated variant, bf16 storage)
+            out["training_step"] = training_leg(["--updated", "--dtype", "bf16"] if bf16 else [])
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

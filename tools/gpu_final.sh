@@ -4,7 +4,7 @@ T=${1:-r3z}
 bash tools/prof_round2.sh ${T}_f32
 bash tools/prof_round2.sh ${T}_bf16 --dtype bf16
 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
-python bench.py --dtype bf16 --no-train > gpurun_out/${T}_bench_bf16.json 2> gpurun_out/${T}_bench_bf16.err
+python bench.py --dtype bf16 > gpurun_out/${T}_bench_bf16.json 2> gpurun_out/${T}_bench_bf16.err
 DGNN_BF16_MODE=single python bench.py --dtype bf16 --no-train > gpurun_out/${T}_bench_bf16_single.json 2> /dev/null
 python bench.py --widths 64,128,256,512 --no-train > gpurun_out/${T}_bench_w512.json 2> gpurun_out/${T}_bench_w512.err
 python bench.py --widths 128,256,512,1024 --no-train > gpurun_out/${T}_bench_w1024.json 2> gpurun_out/${T}_bench_w1024.err
