@@ -79,6 +79,10 @@ SIGNATURES = {
     "dgnn_edge_chain_fwd_bf16": (i32, [vp, i64, i32, vp, i64, vp, i64, i64, vp, i32, vp, i64, vp, vp]),
     "dgnn_edge_chain_bwd": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i64, vp]),
     "dgnn_edge_chain_bwd_bf16": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i64, vp]),
+    "dgnn_sage_layer_train_fwd_bf16": (i32, [vp, vp, vp, i64, vp, i64, i32, vp, i64, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, f32, f32, i32,
+                                             vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dgnn_sage_layer_train_bwd_bf16": (i32, [vp, vp, vp, vp, i64, i64, vp, i64, i32, vp, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, f32, i32,
+                                             vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dgnn_static_train_fwd": (i32, [i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "dgnn_train_set_aux_stream": (i32, [i32]),
     "dgnn_static_train_scratch_elems": (i64, [i32, vp, vp, vp, i32]),

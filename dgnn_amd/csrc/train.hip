@@ -535,3 +535,77 @@ extern "C" int dgnn_train_set_aux_stream(int on) {
     return was;
 }
 
+
+// =====================================================================================================================
+// Static conv layer in training mode with bf16 STORAGE (activations bf16, parameters / statistics / gradients of parameters fp32):
+// the launch chain of dgnn_sage_layer_train_fwd / _bwd over the *_bf16 entry points.  Scratch sizes as for the fp32 functions.
+// =====================================================================================================================
+extern "C" int dgnn_sage_layer_train_fwd_bf16(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const uint16_t* x,
+                                              int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e, const float* We,
+                                              const float* be, const float* Wj, const float* bj, const float* Wi, int c_out,
+                                              const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                                              float eps, int relu, uint16_t* a, uint16_t* z, float* mean, float* var, float* scale, float* shift,
+                                              uint16_t* y, float* scratch, void* stream) {
+    DGNN_REQUIRE(n_dst > 0 && c_in > 0 && c_out > 0, DGNN_E_INVALID, "sage_layer_train_fwd_bf16: bad sizes (BatchNorm needs at least one row)");
+    DGNN_REQUIRE(x && Wj && z && mean && var && scale && shift && y && scratch, DGNN_E_INVALID, "sage_layer_train_fwd_bf16: null pointer");
+    const uint16_t* A1 = x;
+    int64_t lda1 = ldx;
+    if (rowptr) {
+        DGNN_REQUIRE(a && src, DGNN_E_INVALID, "sage_layer_train_fwd_bf16: the aggregate needs src and a");
+        TRY(dgnn_sage_aggregate_fwd_bf16(rowptr, src, eid, n_dst, x, ldx, c_in, edge_attr, lde, f_e, We, be, nullptr, 0, nullptr, 0, a, c_in, stream));
+        A1 = a;
+        lda1 = c_in;
+    }
+    const uint16_t* A2 = (rowptr && Wi) ? x : nullptr;
+    TRY(dgnn_linear_fwd_bf16(A1, lda1, c_in, Wj, c_in, A2, ldx, A2 ? c_in : 0, A2 ? Wi : nullptr, c_in, bj, nullptr, nullptr, 0, n_dst, c_out, z, c_out, 0,
+                             stream));
+    TRY(dgnn_bn_batch_stats_bf16(z, c_out, n_dst, c_out, mean, var, running_mean, running_var, momentum, scratch, stream));
+    TRY(dgnn_bn_fold(gamma, beta, mean, var, eps, c_out, scale, shift, stream));
+    TRY(dgnn_scale_shift_act_bf16(z, c_out, scale, shift, relu, n_dst, c_out, y, c_out, stream));
+    return DGNN_OK;
+}
+
+// dz / da: work buffers [n_dst, c_out] / [n_dst, c_in] of bf16; scratch (floats): dgnn_sage_layer_train_scratch_elems
+extern "C" int dgnn_sage_layer_train_bwd_bf16(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, const int32_t* rowptr_dst,
+                                              int64_t n_src, int64_t n_dst, const uint16_t* x, int64_t ldx, int c_in, const float* edge_attr,
+                                              int64_t lde, int f_e, const float* We, const float* be, const float* Wj, const float* Wi, int c_out,
+                                              const float* gamma, const float* mean, const float* var, float eps, int relu, const uint16_t* a,
+                                              const uint16_t* z, const uint16_t* y, const uint16_t* dy, uint16_t* dx, float* dWe, float* dbe,
+                                              float* dWj, float* dbj, float* dWi, float* dgamma, float* dbeta, uint16_t* dz, uint16_t* da,
+                                              float* scratch, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DGNN_REQUIRE(n_dst > 0 && n_src >= n_dst && c_in > 0 && c_out > 0, DGNN_E_INVALID, "sage_layer_train_bwd_bf16: bad sizes");
+    DGNN_REQUIRE(x && Wj && z && y && dy && mean && var && dWj && dgamma && dbeta && dz && scratch, DGNN_E_INVALID, "sage_layer_train_bwd_bf16: null pointer");
+    const bool agg = t_rowptr != nullptr;
+    float* WjT = scratch;
+    float* WiT = WjT + align4((int64_t)c_in * c_out);
+    float* tmp = WiT + align4((int64_t)c_in * c_out);
+    TRY(dgnn_bn_relu_bwd_bf16(z, c_out, y, c_out, dy, c_out, gamma, mean, var, eps, 1, relu, n_dst, c_out, dz, c_out, dgamma, dbeta, tmp, stream_));
+    const uint16_t* A1 = agg ? a : x;
+    const int64_t lda1 = agg ? c_in : ldx;
+    TRY(dgnn_linear_wgrad_bf16(dz, 0, c_out, c_out, A1, 0, lda1, c_in, n_dst, dWj, c_in, 0, tmp, stream_));
+    if (dbj) TRY(dgnn_colsum_bf16(dz, c_out, n_dst, c_out, dbj, 0, tmp, stream_));
+    if (agg && Wi && dWi) TRY(dgnn_linear_wgrad_bf16(dz, 0, c_out, c_out, x, 0, ldx, c_in, n_dst, dWi, c_in, 0, tmp, stream_));
+    const bool need_dx = dx != nullptr;
+    const bool need_da = agg ? (need_dx || We != nullptr) : need_dx;
+    const bool both = need_da && agg && need_dx && Wi;
+    if (both)
+        hipLaunchKernelGGL(k_transpose2, dim3(dgnn_grid_cap(dgnn_cdiv((int64_t)2 * c_in * c_out, 256))), dim3(256), 0, stream, Wj, Wi, c_out, c_in, WjT, WiT);
+    if (need_da) {
+        DGNN_REQUIRE(!agg || da, DGNN_E_INVALID, "sage_layer_train_bwd_bf16: da buffer missing");
+        if (!both) hipLaunchKernelGGL(k_transpose, dim3(dgnn_grid_cap(dgnn_cdiv((int64_t)c_in * c_out, 256))), dim3(256), 0, stream, Wj, c_out, c_in, WjT);
+        TRY(dgnn_linear_fwd_bf16(dz, c_out, c_out, WjT, c_out, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, n_dst, c_in, agg ? da : dx, c_in, 0, stream_));
+    }
+    if (agg) {
+        if (We) DGNN_REQUIRE(dWe && dbe, DGNN_E_INVALID, "sage_layer_train_bwd_bf16: dWe / dbe missing");
+        if (need_da)
+            TRY(dgnn_sage_aggregate_bwd_bf16(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x, ldx, c_in, edge_attr, lde, f_e, We, be, nullptr, 0, da, c_in, dx, c_in,
+                                             dWe, dbe, nullptr, 0, tmp, stream_));
+        if (need_dx && Wi) {
+            if (!both) hipLaunchKernelGGL(k_transpose, dim3(dgnn_grid_cap(dgnn_cdiv((int64_t)c_in * c_out, 256))), dim3(256), 0, stream, Wi, c_out, c_in, WiT);
+            TRY(dgnn_linear_fwd_bf16(dz, c_out, c_out, WiT, c_out, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, DGNN_LINEAR_ACCUMULATE, n_dst, c_in, dx, c_in, 0,
+                                     stream_));
+        }
+    }
+    return dgnn_check_launch("sage_layer_train_bwd_bf16");
+}

@@ -173,9 +173,9 @@ def sage_train_layer(x, plan, edge_attr, lin_e, lin_j, lin_i, bn: torch.nn.Batch
 
 
 def sage_train_layer_supported(x, lin_e, bn) -> bool:
-    """fp32 activations with unit column stride, lin_e a single Linear over <= 32 attributes (or None), BatchNorm in training mode
+    """fp32 or bf16 activations with unit column stride, lin_e a single Linear over <= 32 attributes (or None), BatchNorm in training mode
     with affine parameters and running buffers; everything else runs through the separate Functions."""
-    return (ops.TRAIN_COMPOSITE and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.size(0) > 0
+    return (ops.TRAIN_COMPOSITE and x.dtype in ops.ACT and x.dim() == 2 and x.stride(1) == 1 and x.size(0) > 0
             and (lin_e is None or (isinstance(lin_e, torch.nn.Linear) and lin_e.in_features <= 32 and lin_e.bias is not None))
             and isinstance(bn, torch.nn.BatchNorm1d) and bn.training and bn.affine and bn.running_mean is not None)
 

@@ -468,17 +468,17 @@ TRAIN_WHOLE_MODEL = __import__("os").environ.get("DGNN_TRAIN_WHOLE_MODEL", "1") 
 
 @on_device_of
 def sage_layer_train_fwd(plan_parts, n_dst, x, edge_attr, We, be, Wj, bj, Wi, gamma, beta, running_mean, running_var, momentum, eps, relu):
-    """conv (aggregate + lin_j + lin_i) -> BatchNorm(batch statistics, running buffers updated) -> ReLU as ONE library call.
-    `plan_parts` = (rowptr, src, eid) of the destination-sorted plan, or None for a plain Linear + BatchNorm block (decoder).
-    -> (y, a | None, z, stats[4, c_out] = mean, var, scale, shift)"""
-    _req(x, "x", dim=2)
+    """conv (aggregate + lin_j + lin_i) -> BatchNorm(batch statistics, running buffers updated) -> ReLU as ONE library call; fp32 or
+    bf16 storage (the type of x).  `plan_parts` = (rowptr, src, eid) of the destination-sorted plan, or None for a plain
+    Linear + BatchNorm block (decoder).  -> (y, a | None, z, stats[4, c_out] = mean, var, scale, shift)"""
+    _req(x, "x", ACT, dim=2)
     c_in, c_out = x.size(1), Wj.size(0)
-    dev = x.device
+    dev, dt = x.device, x.dtype
     rowptr = src = eid = a = None
     f_e = 0
     if plan_parts is not None:
         rowptr, src, eid = plan_parts
-        a = torch.empty((n_dst, c_in), dtype=torch.float32, device=dev)
+        a = torch.empty((n_dst, c_in), dtype=dt, device=dev)
         if We is not None:
             _req(edge_attr, "edge_attr", dim=2)
             f_e = We.size(1)
@@ -486,24 +486,26 @@ def sage_layer_train_fwd(plan_parts, n_dst, x, edge_attr, We, be, Wj, bj, Wi, ga
                 raise ValueError("lin_e weight %s does not match c_in=%d / edge_attr %s" % (tuple(We.shape), c_in, tuple(edge_attr.shape)))
     if Wj.size(1) != c_in or (Wi is not None and tuple(Wi.shape) != tuple(Wj.shape)):
         raise ValueError("lin_j / lin_i weights do not match c_in=%d" % c_in)
-    z = torch.empty((n_dst, c_out), dtype=torch.float32, device=dev)
-    y = torch.empty((n_dst, c_out), dtype=torch.float32, device=dev)
+    z = torch.empty((n_dst, c_out), dtype=dt, device=dev)
+    y = torch.empty((n_dst, c_out), dtype=dt, device=dev)
     stats = torch.empty((4, c_out), dtype=torch.float32, device=dev)
     scratch = _f32(lib().dgnn_colstats_scratch_elems(n_dst, c_out), dev)
-    check(lib().dgnn_sage_layer_train_fwd(
-        ptr(rowptr), ptr(src), ptr(eid), n_dst, ptr(x), _ld(x), c_in, ptr(edge_attr) if f_e else None, _ld(edge_attr) if f_e else 0, f_e,
-        ptr(We), ptr(be), ptr(Wj), ptr(bj), ptr(Wi), c_out, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps),
-        int(bool(relu)), ptr(a), ptr(z), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), ptr(y), ptr(scratch), GEMM_MODE, stream_ptr()),
-        "dgnn_sage_layer_train_fwd")
+    head = (ptr(rowptr), ptr(src), ptr(eid), n_dst, ptr(x), _ld(x), c_in, ptr(edge_attr) if f_e else None, _ld(edge_attr) if f_e else 0, f_e,
+            ptr(We), ptr(be), ptr(Wj), ptr(bj), ptr(Wi), c_out, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps),
+            int(bool(relu)), ptr(a), ptr(z), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), ptr(y), ptr(scratch))
+    if dt == torch.bfloat16:
+        check(lib().dgnn_sage_layer_train_fwd_bf16(*head, stream_ptr()), "dgnn_sage_layer_train_fwd_bf16")
+    else:
+        check(lib().dgnn_sage_layer_train_fwd(*head, GEMM_MODE, stream_ptr()), "dgnn_sage_layer_train_fwd")
     return y, a, z, stats
 
 
 @on_device_of
 def sage_layer_train_bwd(t_parts, rowptr_dst, n_src, n_dst, x, edge_attr, We, be, Wj, Wi, has_bias, gamma, stats, eps, relu, a, z, y, dy, need_dx):
     """backward of sage_layer_train_fwd as ONE library call -> (dx | None, dWe, dbe, dWj, dbj, dWi, dgamma, dbeta); parameter
-    gradients are views of one buffer."""
+    gradients are fp32 views of one buffer, dx has the storage type of x."""
     c_in, c_out = x.size(1), Wj.size(0)
-    dev = x.device
+    dev, dt = x.device, x.dtype
     agg = t_parts is not None
     f_e = We.size(1) if (agg and We is not None) else 0
     sizes = [c_in * f_e, c_in if f_e else 0, c_out * c_in, c_out if has_bias else 0, c_out * c_in if (agg and Wi is not None) else 0, c_out, c_out]
@@ -513,14 +515,18 @@ def sage_layer_train_bwd(t_parts, rowptr_dst, n_src, n_dst, x, edge_attr, We, be
         parts.append(flat[o:o + s] if s else None)
         o += s
     dWe, dbe, dWj, dbj, dWi, dgamma, dbeta = parts
-    dx = torch.empty((n_src if agg else n_dst, c_in), dtype=torch.float32, device=dev) if need_dx else None
+    dx = torch.empty((n_src if agg else n_dst, c_in), dtype=dt, device=dev) if need_dx else None
     scratch = _f32(lib().dgnn_sage_layer_train_scratch_elems(n_src, n_dst, c_in, c_out, f_e), dev)
     t_rowptr, t_dst, t_eid = t_parts if agg else (None, None, None)
-    check(lib().dgnn_sage_layer_train_bwd(
-        ptr(t_rowptr), ptr(t_dst), ptr(t_eid), ptr(rowptr_dst), n_src, n_dst, ptr(x), _ld(x), c_in, ptr(edge_attr) if f_e else None,
-        _ld(edge_attr) if f_e else 0, f_e, ptr(We), ptr(be), ptr(Wj), ptr(Wi), c_out, ptr(gamma), ptr(stats[0]), ptr(stats[1]), float(eps),
-        int(bool(relu)), ptr(a), ptr(z), ptr(y), ptr(dy), ptr(dx), ptr(dWe), ptr(dbe), ptr(dWj), ptr(dbj), ptr(dWi), ptr(dgamma), ptr(dbeta),
-        ptr(scratch), GEMM_MODE, stream_ptr()), "dgnn_sage_layer_train_bwd")
+    head = (ptr(t_rowptr), ptr(t_dst), ptr(t_eid), ptr(rowptr_dst), n_src, n_dst, ptr(x), _ld(x), c_in, ptr(edge_attr) if f_e else None,
+            _ld(edge_attr) if f_e else 0, f_e, ptr(We), ptr(be), ptr(Wj), ptr(Wi), c_out, ptr(gamma), ptr(stats[0]), ptr(stats[1]), float(eps),
+            int(bool(relu)), ptr(a), ptr(z), ptr(y), ptr(dy), ptr(dx), ptr(dWe), ptr(dbe), ptr(dWj), ptr(dbj), ptr(dWi), ptr(dgamma), ptr(dbeta))
+    if dt == torch.bfloat16:
+        dz = torch.empty((n_dst, c_out), dtype=dt, device=dev)
+        da = torch.empty((n_dst, c_in), dtype=dt, device=dev) if agg else None
+        check(lib().dgnn_sage_layer_train_bwd_bf16(*head, ptr(dz), ptr(da), ptr(scratch), stream_ptr()), "dgnn_sage_layer_train_bwd_bf16")
+    else:
+        check(lib().dgnn_sage_layer_train_bwd(*head, ptr(scratch), GEMM_MODE, stream_ptr()), "dgnn_sage_layer_train_bwd")
     return (dx, dWe.view(c_in, f_e) if f_e else None, dbe, dWj.view(c_out, c_in), dbj, dWi.view(c_out, c_in) if dWi is not None else None,
             dgamma, dbeta)
 

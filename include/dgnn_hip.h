@@ -251,6 +251,21 @@ int dgnn_edge_chain_bwd(const float* g, int64_t ldg, const float* phi, int64_t l
 int dgnn_edge_chain_bwd_bf16(const uint16_t* g, int64_t ldg, const uint16_t* phi, int64_t ldphi, const int32_t* inv, int64_t n_cur, int c,
                              int c_tot, int relu, uint16_t* dphi, int64_t lddphi, void* stream);
 
+/* dgnn_sage_layer_train_fwd / _bwd with bf16 STORAGE: x / a / z / y / dy / dx (and the work buffers dz [n_dst,c_out], da [n_dst,c_in]) are bf16
+ * bit patterns, parameters, statistics and parameter gradients fp32; the chain of the *_bf16 entry points.  Scratch (floats) as for the
+ * fp32 functions. */
+int dgnn_sage_layer_train_fwd_bf16(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const uint16_t* x, int64_t ldx,
+                                   int c_in, const float* edge_attr, int64_t lde, int f_e, const float* We, const float* be, const float* Wj,
+                                   const float* bj, const float* Wi, int c_out, const float* gamma, const float* beta, float* running_mean,
+                                   float* running_var, float momentum, float eps, int relu, uint16_t* a, uint16_t* z, float* mean, float* var,
+                                   float* scale, float* shift, uint16_t* y, float* scratch, void* stream);
+int dgnn_sage_layer_train_bwd_bf16(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, const int32_t* rowptr_dst, int64_t n_src,
+                                   int64_t n_dst, const uint16_t* x, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e,
+                                   const float* We, const float* be, const float* Wj, const float* Wi, int c_out, const float* gamma,
+                                   const float* mean, const float* var, float eps, int relu, const uint16_t* a, const uint16_t* z,
+                                   const uint16_t* y, const uint16_t* dy, uint16_t* dx, float* dWe, float* dbe, float* dWj, float* dbj,
+                                   float* dWi, float* dgamma, float* dbeta, uint16_t* dz, uint16_t* da, float* scratch, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Static model in training mode, ALL layers per call (SurfaceNet.forward :196-227 up to the decoder's last Linear, and its
  * autograd): the chain of dgnn_sage_layer_train_fwd / _bwd calls issued from one entry point each way.  Per-layer arguments are
