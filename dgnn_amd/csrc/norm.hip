@@ -58,57 +58,70 @@ __global__ void __launch_bounds__(256) k_colreduce(const T* __restrict__ x, int6
     }
 }
 
-// fp32 rows of 4 | 8 | ... | 256 channels with 16-byte aligned rows: every thread walks FOUR columns with 16-byte loads (256 threads =
-// c/4 column groups x 1024/c row lanes).  The scalar kernel above keeps one 4-byte load per row in flight per lane and ran the training
-// step's 15 column reductions at 1.4-2.7 TB/s.  Same partials layout; sums are fp64, so the different association order is invisible
-// after the rounding to fp32 except at exact ties.
-template <int MODE>
-__global__ void __launch_bounds__(256) k_colreduce4(const float* __restrict__ x, int64_t ldx, const float* __restrict__ y, int64_t ldy,
-                                                    const float* __restrict__ dy, int64_t lddy, const float* __restrict__ mean,
+// Rows of a power-of-two number of channels (fp32: 4..256, bf16: 8..256) with 16-byte aligned rows: every thread walks V = 16 / sizeof(T)
+// columns with 16-byte loads (256 threads = c/V column groups x 256 V / c row lanes).  The scalar kernel above keeps one element load per
+// row in flight per lane and ran the training step's 15 column reductions at 1.4-2.7 TB/s.  Same partials layout; sums are fp64, so the
+// different association order is invisible after the rounding to fp32 except at exact ties.
+template <typename T>
+struct RowPiece {
+    static constexpr int V = 16 / sizeof(T);
+    alignas(16) T v[V];
+    __device__ __forceinline__ void load(const T* p) { *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ float get(int j) const { return dgnn_ld(&v[j]); }
+};
+
+template <int MODE, typename T>
+__global__ void __launch_bounds__(256) k_colreduce4(const T* __restrict__ x, int64_t ldx, const T* __restrict__ y, int64_t ldy,
+                                                    const T* __restrict__ dy, int64_t lddy, const float* __restrict__ mean,
                                                     const float* __restrict__ var, float eps, int relu, int64_t M, int c,
                                                     int64_t rows_per_block, double* __restrict__ partials) {
-    __shared__ double red[2][1024];   // [quantity][row lane][column], nrl * c = 1024
-    const int ng = c >> 2, nrl = 256 / ng;
-    const int tg = threadIdx.x % ng, ty = threadIdx.x / ng, col = 4 * tg;
+    constexpr int V = RowPiece<T>::V;
+    __shared__ double red[2][256 * V];   // [quantity][row lane][column], nrl * c = 256 V
+    const int ng = c / V, nrl = 256 / ng;
+    const int tg = threadIdx.x % ng, ty = threadIdx.x / ng, col = V * tg;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = min(M, r0 + rows_per_block);
-    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
-    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f};
-    if (MODE == 1) {
-        mu = *reinterpret_cast<const f32x4*>(mean + col);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(var + col);
+    double s0[V], s1[V];
+    float mu[V], is[V];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) is[j] = 1.0f / sqrtf(v[j] + eps);
+    for (int j = 0; j < V; ++j) {
+        s0[j] = s1[j] = 0.0;
+        mu[j] = 0.f;
+        is[j] = 1.f;
+        if (MODE == 1) {
+            mu[j] = mean[col + j];
+            is[j] = 1.0f / sqrtf(var[col + j] + eps);
+        }
     }
     for (int64_t r = r0 + ty; r < r1; r += nrl) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * ldx + col);
+        RowPiece<T> xv;
+        xv.load(x + r * ldx + col);
         if (MODE == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                s0[j] += xv[j];
-                s1[j] += (double)xv[j] * xv[j];
+            for (int j = 0; j < V; ++j) {
+                const float v = xv.get(j);
+                s0[j] += v;
+                s1[j] += (double)v * v;
             }
         } else if (MODE == 1) {
-            f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * lddy + col);
-            if (relu) {
-                const f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * ldy + col);
+            RowPiece<T> gv, yv;
+            gv.load(dy + r * lddy + col);
+            if (relu) yv.load(y + r * ldy + col);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (!(yv[j] > 0.f)) g[j] = 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float xh = (xv[j] - mu[j]) * is[j];
-                s0[j] += g[j];
-                s1[j] += (double)g[j] * xh;
+            for (int j = 0; j < V; ++j) {
+                float g = gv.get(j);
+                if (relu && !(yv.get(j) > 0.f)) g = 0.f;
+                const float xh = (xv.get(j) - mu[j]) * is[j];
+                s0[j] += g;
+                s1[j] += (double)g * xh;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s0[j] += xv[j];
+            for (int j = 0; j < V; ++j) s0[j] += xv.get(j);
         }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < V; ++j) {
         red[0][ty * c + col + j] = s0[j];
         red[1][ty * c + col + j] = s1[j];
     }
@@ -121,7 +134,8 @@ __global__ void __launch_bounds__(256) k_colreduce4(const float* __restrict__ x,
     }
 }
 
-__device__ __host__ inline bool colreduce4_ok(int c) { return c >= 4 && c <= 256 && (c & (c - 1)) == 0; }
+template <typename T>
+inline bool colreduce4_ok(int c) { return c >= (int)(16 / sizeof(T)) && c <= 256 && (c & (c - 1)) == 0; }
 
 // Deterministic two-level finalisers: 1024 threads = 16 columns x 64 slices; slice s sums partial blocks s, s+64, ... in
 // ascending order, then the 64 slice sums are added in slice order.  (A single thread per column walking all ~1000 partial
@@ -263,17 +277,15 @@ extern "C" int dgnn_bn_fold(const float* gamma, const float* beta, const float* 
     return dgnn_check_launch("bn_fold");
 }
 
-// MODE-templated launch: the vectorised kernel for fp32 rows it covers, the general one otherwise
+// MODE-templated launch: the vectorised kernel for the rows it covers, the general one otherwise
 template <int MODE, typename T>
 static void launch_colreduce(int nblk, hipStream_t stream, const T* x, int64_t ldx, const T* y, int64_t ldy, const T* dy, int64_t lddy, const float* mean,
                              const float* var, float eps, int relu, int64_t M, int c, int64_t rpb, double* P) {
-    if constexpr (sizeof(T) == 4) {
-        auto al = [](const void* p, int64_t ld) { return p == nullptr || ((((uintptr_t)p) & 15) == 0 && ld % 4 == 0); };
-        if (colreduce4_ok(c) && al(x, ldx) && al(y, ldy) && al(dy, lddy) && al(mean, 4) && al(var, 4)) {
-            hipLaunchKernelGGL((k_colreduce4<MODE>), dim3(nblk), dim3(256), 0, stream, (const float*)x, ldx, (const float*)y, ldy, (const float*)dy, lddy, mean,
-                               var, eps, relu, M, c, rpb, P);
-            return;
-        }
+    constexpr int V = 16 / sizeof(T);
+    auto al = [](const void* p, int64_t ld) { return p == nullptr || ((((uintptr_t)p) & 15) == 0 && ld % V == 0); };
+    if (colreduce4_ok<T>(c) && al(x, ldx) && al(y, ldy) && al(dy, lddy)) {
+        hipLaunchKernelGGL((k_colreduce4<MODE, T>), dim3(nblk), dim3(256), 0, stream, x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, rpb, P);
+        return;
     }
     hipLaunchKernelGGL((k_colreduce<MODE, T>), dim3(nblk), dim3(256), 0, stream, x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, rpb, P);
 }
