@@ -168,3 +168,22 @@ def test_dp_training_two_ranks_equals_mean_gradient_step(tmp_path):
             o.step()
     for k, p in nets[0].named_parameters():
         assert torch.equal(p.detach(), sd[0][k]), k
+
+
+def test_metrics_running_sums_equal_the_reference_formulas():
+    """Metrics (reference learning/runModel.py:48-80): OA = 100 * sum(correct) / sum(samples), cell loss = sum(cell) / sum(weight),
+    reg loss = sum(reg) / sum(edges); items may be Python numbers or tensors (tensors on a GPU are summed there, see the class
+    docstring -- here they are CPU tensors, the read-back path), and the packed form the fused loss kernel produces adds the same sums."""
+    import torch
+    from dgnn_amd.learning.runModel import Metrics
+    m, p = Metrics(), Metrics()
+    oa, n, cell, w = [120, 99, 250], [128, 128, 256], [0.5, 0.25, 1.125], [2.0, 1.5, 4.0]
+    for a, b, c, d in zip(oa, n, cell, w):
+        m.addOAItem(torch.tensor(a), b)
+        m.addCellLossItem(torch.tensor(c), torch.tensor(d))
+        p.addPacked(torch.tensor([c, d, float(a)], dtype=torch.float64), b)
+    m.addRegLossItem(torch.tensor(3.0), 10)
+    assert m.getOA() == p.getOA() == 100 * sum(oa) / sum(n)
+    assert m.getCellLoss() == p.getCellLoss() == sum(cell) / sum(w)
+    assert m.getRegLoss() == 0.3 and p.getRegLoss() == 0.0
+    assert m.samples_sum == sum(n) and p.OA_sum == sum(oa) and Metrics().getOA() == 0 and Metrics().getCellLoss() == 0.0
