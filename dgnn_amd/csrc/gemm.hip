@@ -640,6 +640,112 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_x3_n64(const float* __res
     }
 }
 
+// Small problems (M <= 16384 rows: the innermost training blocks, the decoder): a 128-row tile leaves most of the chip idle (M = 2048,
+// n_out = 128: 16 workgroups) and walks K chunk by chunk behind two barriers each -- 20-33 us for 0.1 GFLOP.  Here ONE WAVEFRONT owns a
+// 32 x 32 output block and takes both operands straight from global memory in the MFMA's own layout (a lane's fragment is 8 consecutive
+// k of one row: two 16-byte loads), splitting them in registers: no LDS, no barrier, four k-steps of loads in flight, 4 x as many
+// independent workgroup slots.  k-steps and products in the order of k_linear_fwd_x3: bit-identical results.
+__global__ void __launch_bounds__(256) k_linear_fwd_x3_small(const float* __restrict__ A1, int64_t lda1, int k1, const float* __restrict__ W1,
+                                                             int64_t ldw1, bool vec1, const float* __restrict__ A2, int64_t lda2, int k2,
+                                                             const float* __restrict__ W2, int64_t ldw2, bool vec2,
+                                                             const float* __restrict__ bias, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int relu, int64_t M, int n_out,
+                                                             float* __restrict__ out, int64_t ldo) {
+    const int lane = lane_id(), w = wave_id_uniform();
+    const int h = lane >> 5, l31 = lane & 31;
+    const int nct = (n_out + 31) / 32;                      // column tiles; a workgroup = 4 consecutive (row tile, column tile) pairs
+    const int64_t tile = (int64_t)blockIdx.x * 4 + w;
+    const int64_t rt = tile / nct;
+    const int ct = (int)(tile - rt * nct);
+    if (rt * 32 >= M) return;
+    const int64_t row = rt * 32 + l31, rowc = row < M ? row : M - 1;
+    const int col = ct * 32 + l31, colc = col < n_out ? col : n_out - 1;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // one operand pair after the other ([A1 | A2] against [W1 | W2]), k-steps of 16
+    for (int part = 0; part < 2; ++part) {
+        const float* A = part == 0 ? A1 : A2;
+        if (!A) break;
+        const float* W = part == 0 ? W1 : W2;
+        const int kk = part == 0 ? k1 : k2;
+        const bool vec = part == 0 ? vec1 : vec2;
+        const float* ap = A + rowc * (part == 0 ? lda1 : lda2) + 8 * h;
+        const float* wp = W + (int64_t)colc * (part == 0 ? ldw1 : ldw2) + 8 * h;
+        const int nst = (kk + 15) / 16;
+        auto load_step = [&](f32x4 (&v)[4], int st) {      // v[0..1]: A k .. k+7, v[2..3]: W k .. k+7 (k = 16 st + 8 h)
+            const int k0 = 16 * st;
+            if (vec && k0 + 16 <= kk) {
+                v[0] = *reinterpret_cast<const f32x4*>(ap + k0);
+                v[1] = *reinterpret_cast<const f32x4*>(ap + k0 + 4);
+                v[2] = *reinterpret_cast<const f32x4*>(wp + k0);
+                v[3] = *reinterpret_cast<const f32x4*>(wp + k0 + 4);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = k0 + 8 * h + 4 * q + j;
+                        const int kc = k < kk ? k : kk - 1;
+                        const float av = A[rowc * (part == 0 ? lda1 : lda2) + kc], wv = W[(int64_t)colc * (part == 0 ? ldw1 : ldw2) + kc];
+                        v[q][j] = k < kk ? av : 0.f;
+                        v[2 + q][j] = k < kk ? wv : 0.f;
+                    }
+            }
+        };
+        auto mul_step = [&](const f32x4 (&v)[4]) {
+            uint32_t ph[4], pm[4], pl[4], qh[4], qm[4], ql[4];
+            x3_split(v[0][0], v[0][1], ph[0], pm[0], pl[0]);
+            x3_split(v[0][2], v[0][3], ph[1], pm[1], pl[1]);
+            x3_split(v[1][0], v[1][1], ph[2], pm[2], pl[2]);
+            x3_split(v[1][2], v[1][3], ph[3], pm[3], pl[3]);
+            x3_split(v[2][0], v[2][1], qh[0], qm[0], ql[0]);
+            x3_split(v[2][2], v[2][3], qh[1], qm[1], ql[1]);
+            x3_split(v[3][0], v[3][1], qh[2], qm[2], ql[2]);
+            x3_split(v[3][2], v[3][3], qh[3], qm[3], ql[3]);
+            const bf16x8_t a0 = __builtin_bit_cast(bf16x8_t, make_uint4(ph[0], ph[1], ph[2], ph[3])),
+                           a1 = __builtin_bit_cast(bf16x8_t, make_uint4(pm[0], pm[1], pm[2], pm[3])),
+                           a2 = __builtin_bit_cast(bf16x8_t, make_uint4(pl[0], pl[1], pl[2], pl[3])),
+                           b0 = __builtin_bit_cast(bf16x8_t, make_uint4(qh[0], qh[1], qh[2], qh[3])),
+                           b1 = __builtin_bit_cast(bf16x8_t, make_uint4(qm[0], qm[1], qm[2], qm[3])),
+                           b2 = __builtin_bit_cast(bf16x8_t, make_uint4(ql[0], ql[1], ql[2], ql[3]));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc, 0, 0, 0);   // small terms first
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc, 0, 0, 0);
+        };
+        // four k-steps of loads in flight
+        f32x4 r0[4], r1[4], r2[4], r3[4];
+        for (int st = 0; st < nst; st += 4) {
+            load_step(r0, st);
+            if (st + 1 < nst) load_step(r1, st + 1);
+            if (st + 2 < nst) load_step(r2, st + 2);
+            if (st + 3 < nst) load_step(r3, st + 3);
+            mul_step(r0);
+            if (st + 1 < nst) mul_step(r1);
+            if (st + 2 < nst) mul_step(r2);
+            if (st + 3 < nst) mul_step(r3);
+        }
+    }
+    if (col < n_out) {
+        const float bb = bias ? bias[col] : 0.f;
+        const float sc = scale ? scale[col] : 1.f;
+        const float sh = scale ? shift[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t orow = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (orow >= M) continue;
+            float v = acc[r] + bb;
+            if (scale) v = __fmaf_rn(v, sc, sh);
+            if (relu & 1) v = fmaxf(v, 0.f);
+            if (relu & DGNN_LINEAR_ACCUMULATE) v += out[orow * ldo + col];
+            out[orow * ldo + col] = v;
+        }
+    }
+}
+
 // Large problems (M >= 8192 rows, n_out > 128): 256 x 256 output tile per 512-thread block, wave (wr, wc) of the 2 x 4 wave grid owns
 // a 128 x 64 block = 4 x 2 MFMA blocks (8 accumulators).  Splitting the operands costs VALU issue slots (about 12 per element
 // pair) that share the SIMD's issue port with the MFMAs: at 128 x 128 a chunk is 32 elements per thread for 48 MFMAs per wave,
@@ -954,6 +1060,14 @@ extern "C" int dgnn_linear_fwd_x3(const float* A1, int64_t lda1, int k1, const f
         dim3 grid((unsigned)(dgnn_cdiv(dgnn_cdiv(M, YM), 8) * 8 * dgnn_cdiv(n_out, YN)));
         hipLaunchKernelGGL(k_linear_fwd_x3_big, grid, dim3(YT), lds, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2, lda2, k2, W2, ldw2, v2,
                            bias, scale, shift, relu, M, n_out, out, ldo);
+        return dgnn_check_launch("linear_fwd_x3");
+    }
+    static const bool small_ok = !(getenv("DGNN_X3_SMALL") && getenv("DGNN_X3_SMALL")[0] == '0');
+    static const int64_t small_m = getenv("DGNN_X3_SMALL_M") ? atoll(getenv("DGNN_X3_SMALL_M")) : 16384;
+    if (small_ok && M <= small_m) {
+        const int64_t tiles = dgnn_cdiv(M, 32) * dgnn_cdiv(n_out, 32);
+        hipLaunchKernelGGL(k_linear_fwd_x3_small, dim3((unsigned)dgnn_cdiv(tiles, 4)), dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2, lda2,
+                           k2, W2, ldw2, v2, bias, scale, shift, relu, M, n_out, out, ldo);
         return dgnn_check_launch("linear_fwd_x3");
     }
     static const bool n64_ok = !(getenv("DGNN_X3_N64") && getenv("DGNN_X3_N64")[0] == '0');

@@ -384,3 +384,31 @@ def test_updated_training_step_at_scale_matches_the_oracle(dtype):
     for k, p in net.named_parameters():
         e = (p.grad.double().cpu() - ograds[k]).abs().max().item()
         assert e <= rel * ograds[k].abs().max().item() + floor * gmax, (k, e, ograds[k].abs().max().item(), gmax)
+
+
+@pytest.mark.parametrize("k1,k2,n_out", [(128, 128, 128), (64, 0, 2), (128, 0, 64), (70, 33, 37), (256, 256, 512), (28, 28, 64)])
+def test_x3_gemm_small_problem_kernel_equals_the_tiled_kernels(monkeypatch, k1, k2, n_out):
+    """M <= 16384 takes the no-LDS kernel (one wavefront per 32 x 32 output block, operands split in registers); same k-step and product
+    order per output element as the tiled kernels, which the same rows reach when they are part of a larger problem: bit-identical."""
+    from dgnn_amd import ops
+    monkeypatch.setattr(ops, "GEMM_MODE", ops.GEMM_BF16X3)
+    g = torch.Generator().manual_seed(k1 + 3 * n_out)
+    M = 2048 + 19
+    A1 = torch.randn(M, k1, generator=g).to(DEV)
+    W1 = (torch.randn(n_out, k1, generator=g) / k1 ** 0.5).to(DEV)
+    A2 = torch.randn(M, k2, generator=g).to(DEV) if k2 else None
+    W2 = (torch.randn(n_out, k2, generator=g) / k2 ** 0.5).to(DEV) if k2 else None
+    bias = torch.randn(n_out, generator=g).to(DEV)
+    small = ops.linear_fwd(A1, W1, A2, W2, bias, relu=True)
+    rep = 9                                                                  # 18603 rows: past the small-problem threshold
+    big = ops.linear_fwd(A1.repeat(rep, 1), W1, A2.repeat(rep, 1) if k2 else None, W2, bias, relu=True)
+    assert torch.equal(small, big[:M]) and torch.equal(small, big[-M:])
+    ref = A1.double() @ W1.double().t() + bias.double()
+    if k2:
+        ref = ref + A2.double() @ W2.double().t()
+    assert (small.double() - ref.clamp_min(0)).abs().max().item() <= 4e-6 * max(ref.abs().max().item(), 1.0)
+    acc = torch.randn(M, n_out, generator=g).to(DEV)
+    out = acc.clone()
+    from dgnn_amd._lib import lib, ptr, stream_ptr, check
+    check(lib().dgnn_linear_fwd_x3(ptr(A1), A1.stride(0), k1, ptr(W1), k1, None, 0, 0, None, 0, None, None, None, 2, M, n_out, ptr(out), n_out, stream_ptr()), "x3")
+    assert torch.equal(out, acc + ops.linear_fwd(A1, W1))
