@@ -482,3 +482,42 @@ def test_static_composite_layer_in_bf16_storage_matches_the_separate_calls(monke
     for k in ga:
         err = (ga[k] - gb[k]).abs().max().item()
         assert err <= 3e-2 * gb[k].abs().max().item() + 2e-3 * gmax, (k, err, gb[k].abs().max().item(), gmax)
+
+
+def test_buffer_ring_blocks_are_correct_when_consumed_in_order_across_epochs_and_early_exit():
+    """reuse_buffers=True: every block, checked at the moment it is handed over, equals the in-line builder's; a loop abandoned mid-epoch
+    (the builder thread's job is joined), a second epoch over the same sampler (ring slots reused from the start) and shuffling work too"""
+    from dgnn_amd.graph import plan_for
+    from dgnn_amd.sampler import NeighborSampler
+    from dgnn_amd.synthetic import delaunay_tet_graph
+    adj, _, _ = delaunay_tet_graph(5000, seed=21)
+    n = adj.shape[0] // 4
+    ei = torch.from_numpy(adj.T.astype(np.int64)).to(DEV)
+    idx = torch.randperm(n, generator=torch.Generator().manual_seed(2))[:1500].to(DEV)
+    ref = [(b, nid.clone(), [(e.clone(), i.clone(), s) for e, i, s in adjs])
+           for b, nid, adjs in NeighborSampler(ei, sizes=[-1] * 3, node_idx=idx, num_nodes=n, batch_size=100, prefetch=False)]
+    ring = NeighborSampler(ei, sizes=[-1] * 3, node_idx=idx, num_nodes=n, batch_size=100, reuse_buffers=True)
+
+    def check(k, blk):
+        b, nid, adjs = blk
+        rb, rn, ra = ref[k]
+        assert b == rb and torch.equal(nid, rn)
+        for (e1, i1, s1), (e2, i2, s2) in zip(ra, adjs):
+            assert s1 == s2 and torch.equal(e1, e2) and torch.equal(i1, i2)
+            plan = plan_for(e2, s2[0], s2[1])
+            assert torch.equal(plan.edge_rows.long(), i2) and torch.equal(plan.src.long(), e2[0])
+            t = plan.transposed
+            assert int(t[0][-1]) == e2.size(1)
+        # some work on the caller's stream that reads the block while the builder is already filling the next slot
+        return float(nid.double().sum().item())
+
+    for k, blk in enumerate(ring):          # epoch 1, abandoned after 7 of 15 blocks
+        check(k, blk)
+        if k == 6:
+            break
+    for epoch in range(2):                  # two full epochs over the same sampler
+        seen = 0
+        for k, blk in enumerate(ring):
+            check(k, blk)
+            seen += 1
+        assert seen == len(ref) == 15
