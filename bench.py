@@ -143,7 +143,7 @@ def main():
     ap.add_argument("--cached-plan", action="store_true", help="reuse the graph plan across steps (reported, not the metric)")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (tools/bench_train.py as a child process after the "
                                                             "timed region; its line is nested under `training_step`)")
-    ap.add_argument("--gemm-mode", choices=["f32", "bf16x3", "bf16x3f"], default=None,
+    ap.add_argument("--gemm-mode", choices=["f32", "bf16x3", "bf16x3f", "f16x2d", "f16x2"], default=None,
                     help="dense part of the fused fp32 layer: exact fp32 MFMA, or 3-way split-bf16 MFMA (fp32-class accuracy)")
     args = ap.parse_args()
 
@@ -172,7 +172,7 @@ def main():
     from dgnn_amd.learning.surfaceNetStaticEdgeFilters import SurfaceNet
 
     if args.gemm_mode is not None:
-        ops.GEMM_MODE = {"f32": ops.GEMM_F32, "bf16x3": ops.GEMM_BF16X3, "bf16x3f": ops.GEMM_BF16X3_FILTER}[args.gemm_mode]
+        ops.GEMM_MODE = ops.GEMM_MODE_NAMES[args.gemm_mode]
     if args.widths:
         convs = tuple(int(v) for v in args.widths.split(","))
         torch.manual_seed(0)
@@ -336,7 +336,8 @@ def main():
         if bf16:
             kname = net.dominant_kernel_name(dom)
         elif fused:
-            kname = {0: "k_sage_fused<%d,%d,0>", 1: "k_sage_fused<%d,%d,1>", 2: "k_sage_fused_mfma<%d,%d>"}[ops.GEMM_MODE] % (
+            kname = {0: "k_sage_fused<%d,%d,0>", 1: "k_sage_fused<%d,%d,1>", 2: "k_sage_fused_mfma<%d,%d>", 3: "k_sage_fused_mfma<%d,%d,dense f16x2>",
+                     4: "k_sage_fused_mfma<%d,%d,f16x2>"}[ops.GEMM_MODE] % (
                 32 if dom[0] <= 32 else (64 if dom[0] <= 64 else 128), dom[1])
         else:
             kname = "k_agg_fwd + k_linear_fwd (unfused aggregate + GEMM pair, %d->%d)" % dom
@@ -429,7 +430,10 @@ def main():
 
     if rank == 0:
         gemm = {0: "fp32 MFMA", 1: "split-bf16 MFMA for the dense part (3 exact bf16 parts per fp32 operand, 6 products, fp32 accumulate)",
-                2: "split-bf16 MFMA for the dense part and the filter MLP (3 exact bf16 parts per fp32 operand, 6 products, fp32 accumulate)"}[ops.GEMM_MODE]
+                2: "split-bf16 MFMA for the dense part and the filter MLP (3 exact bf16 parts per fp32 operand, 6 products, fp32 accumulate)",
+                3: "dense part: fp32 operands scaled by powers of two and split into 2 fp16 parts (22 bits), 3 products on fp16 MFMA, fp32 accumulate; filter MLP split-bf16 x 3",
+                4: "dense part and filter MLP: fp32 operands scaled by powers of two and split into 2 fp16 parts (22 significand bits), 3 products on fp16 MFMA, "
+                   "fp32 accumulate (the 3xTF32 scheme)"}[ops.GEMM_MODE]
         if bf16:
             gemm = ("bf16 storage of activations; compensated mode: the fp32 mean / attributes / parameters enter the bf16 MFMAs as (hi, lo) pairs, "
                     "fp32 accumulate; first layer reads the fp32 features in place" if ops.BF16_MODE == ops.BF16_COMPENSATED else

@@ -493,7 +493,7 @@ int dgnn_sage_layer_fused_mfma_try(const int32_t* rowptr, const int32_t* src, co
                                    const float* x_dst, int64_t ldx,
                                    int c_in, const float* edge_attr, int64_t lde, const float* We, const float* be,
                                    const float* Wj, const float* bj, const float* Wi, const float* scale, const float* shift,
-                                   int relu, int c_out, float* out, int64_t ldo, hipStream_t stream);  // fused_mfma.hip
+                                   int relu, int c_out, float* out, int64_t ldo, int f16_parts, hipStream_t stream);  // fused_mfma.hip
 
 extern "C" int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src,
                                          const float* x_dst, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e,
@@ -502,7 +502,7 @@ extern "C" int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* s
                                          int gemm_mode, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DGNN_REQUIRE(n_dst >= 0 && c_in > 0 && c_out > 0, DGNN_E_INVALID, "sage_layer_fused_fwd: bad sizes");
-    DGNN_REQUIRE(gemm_mode >= DGNN_GEMM_F32 && gemm_mode <= DGNN_GEMM_BF16X3_FILTER, DGNN_E_INVALID,
+    DGNN_REQUIRE(gemm_mode >= DGNN_GEMM_F32 && gemm_mode <= DGNN_GEMM_F16X2, DGNN_E_INVALID,
                  "sage_layer_fused_fwd: bad gemm_mode %d", gemm_mode);
     if (n_dst == 0) return DGNN_OK;
     DGNN_REQUIRE(rowptr && src && x_src && edge_attr && We && be && Wj && Wi && out, DGNN_E_INVALID,
@@ -514,9 +514,10 @@ extern "C" int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* s
     DGNN_REQUIRE(n_dst * ldx < ((int64_t)1 << 31), DGNN_E_UNSUPPORTED, "sage_layer_fused_fwd: activations beyond 2^31 elements");
     DGNN_REQUIRE(c_in <= 128 && (c_out == 64 || c_out == 128), DGNN_E_UNSUPPORTED,
                  "sage_layer_fused_fwd: supports c_in <= 128 and c_out in {64,128} (got %d -> %d)", c_in, c_out);
-    if (gemm_mode == DGNN_GEMM_BF16X3_FILTER) {
+    if (gemm_mode >= DGNN_GEMM_BF16X3_FILTER) {
         const int rc = dgnn_sage_layer_fused_mfma_try(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi,
-                                                      scale, shift, relu, c_out, out, ldo, stream);
+                                                      scale, shift, relu, c_out, out, ldo,
+                                                      gemm_mode == DGNN_GEMM_F16X2 ? 2 : (gemm_mode == DGNN_GEMM_F16X2_DENSE ? 1 : 0), stream);
         if (rc != DGNN_E_UNSUPPORTED) return rc;
         gemm_mode = DGNN_GEMM_BF16X3;  // shape not covered by the all-MFMA variant
     }

@@ -78,4 +78,56 @@ __device__ __forceinline__ bf16x8 pack8(const uint32_t (&d)[4]) {
                                             __builtin_bit_cast(float, d[2]), __builtin_bit_cast(float, d[3])});
 }
 
+// ---- fp16 two-way split (gemm_mode DGNN_GEMM_F16X2) ------------------------------------------------------------------
+// x*s = hi + lo with hi = RN16(x*s), lo = RN16(x*s - hi): 22 significand bits in two fp16 values (the residual is exact in fp32).
+// Three products hi.hi + hi.lo + lo.hi on v_mfma_f32_*_f16 with fp32 accumulation drop only lo.lo (<= 2^-22 relative) -- the
+// "3xTF32" scheme (TF32 and fp16 both carry 11 significant bits) at half the matrix work and a third of the split instructions of
+// the bf16 x 3 form.  fp16 has 5 exponent bits, so every operand is first multiplied by a power of two s (exact) that puts the
+// largest magnitude of its scaling group into [2^14, 2^15): elements down to 2^-15 of that maximum keep all 22 bits AND split
+// identically under any other s with the same property; smaller ones are quantised to 2^-24 (fp16 subnormals, honoured by the
+// MFMA: tools/ubench_f16_denorm.hip), i.e. to <= 2^-39 of the group maximum.  The inverse powers of two are applied to the fp32
+// accumulator (exact).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split2h(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    const f16x2_t h = __builtin_convertvector(f32x2_t{x0, x1}, f16x2_t);  // v_cvt_pk_f16_f32 (round to nearest even)
+    hi = __builtin_bit_cast(uint32_t, h);
+    float r0, r1;  // x - hi in ONE instruction each (fp16 source operand widened by the mixed-precision FMA)
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(x1));
+    const f16x2_t l = __builtin_convertvector(f32x2_t{r0, r1}, f16x2_t);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// maxbits = bit pattern of the largest |value| of a scaling group (sign cleared).  s = 2^(141-E) moves it into [2^14, 2^15);
+// inv = 1/s.  E is clamped to [14, 254]: groups below 2^-113 (all-zero rows included) come out as 0, inf/nan stay inf/nan.
+__device__ __forceinline__ void pow2_scales(uint32_t maxbits, float& s, float& inv) {
+    uint32_t E = maxbits >> 23;
+    E = E < 14u ? 14u : (E > 254u ? 254u : E);
+    s = __builtin_bit_cast(float, (268u - E) << 23);
+    inv = __builtin_bit_cast(float, (E - 14u) << 23);
+}
+__device__ __forceinline__ uint32_t absbits(float v) { return __builtin_bit_cast(uint32_t, v) & 0x7FFFFFFFu; }
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+// maximum over each aligned group of 16 lanes, left in every lane of the group (four v_max_u32_dpp row_ror)
+__device__ __forceinline__ uint32_t row16_umax(uint32_t m) {
+    m = umax(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xf, 0xf, false));
+    m = umax(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x124, 0xf, 0xf, false));
+    m = umax(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x122, 0xf, 0xf, false));
+    m = umax(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x121, 0xf, 0xf, false));
+    return m;
+}
+// maximum over the wavefront as a wave-uniform (SGPR) value
+__device__ __forceinline__ uint32_t wave_umax(uint32_t m) {
+    m = row16_umax(m);
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)m, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)m, 16),
+                   c = (uint32_t)__builtin_amdgcn_readlane((int)m, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)m, 48);
+    return umax(umax(a, b), umax(c, d));
+}
+__device__ __forceinline__ f16x8 pack8h(const uint32_t (&d)[4]) {
+    return __builtin_bit_cast(f16x8, f32x4{__builtin_bit_cast(float, d[0]), __builtin_bit_cast(float, d[1]),
+                                           __builtin_bit_cast(float, d[2]), __builtin_bit_cast(float, d[3])});
+}
+
 }  // namespace fused

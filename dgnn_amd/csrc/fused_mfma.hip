@@ -37,19 +37,25 @@ namespace {
 using namespace fused;
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#define H8(v) __builtin_bit_cast(f16x8, v)
 
 // NW wavefronts per workgroup, KS = how many ways the dense phase splits K between wavefronts.
 //   (8, 2): 8 waves = (32-column slice) x (K half) [x row group]; the only arrangement whose resident weights fit at C_in = 128.
 //   (4, 1): 4 waves = (32-column slice) [x row group], full K per wave, no partial-sum exchange; 70-76 KB of LDS, so TWO
 //           workgroups share a CU with independent barriers -- one fills the other's barrier / latency bubbles.  Used for
 //           C_in <= 64, where a tile is too little work to hide its own fixed latencies.
-template <int CIN_PAD, int COUT, int NW = 8, int KS = 2>
+//   DSP / FSP = parts per operand of the dense product / the filter product: 3 = bf16 x 3 (6 products), 2 = fp16 x 2 with
+//   power-of-two group scales (3 products; fused_common.h).  Scaling groups: one per A-tile row (a tet's [mean | own] row, so a tet's
+//   result does not depend on its neighbours in the tile), one per weight matrix pair [Wj | Wi], one per [We | be], one per 16-edge
+//   attribute block of the filter product (FSP == 2).
+template <int CIN_PAD, int COUT, int NW = 8, int KS = 2, int DSP = 3, int FSP = 3>
 struct Cfg2 {
     static constexpr int K = 2 * CIN_PAD;
     static constexpr int NSLICE = COUT / 32;
     static constexpr int RG = NW / (KS * NSLICE);
     static constexpr int TILE = 32 * RG;
-    static constexpr int ROWB = (K / 8) * 48 + 16;       // A-tile row: K/8 octets of [hi|mid|lo] 16 B each + pad
+    static constexpr int OCT = 16 * DSP;                  // one k-octet of an A-tile row: [hi|mid|lo] or [hi|lo], 16 B each
+    static constexpr int ROWB = (K / 8) * OCT + 16;       // A-tile row: K/8 octets + pad
     static constexpr int A_BYTES = TILE * ROWB;
     static constexpr int TPW = TILE / NW;                 // tets per wave (4, 8 or 16)
     static constexpr int RB = TPW / 4;                    // 16-edge row blocks per wave
@@ -57,9 +63,12 @@ struct Cfg2 {
     static constexpr int NB = CIN_PAD / 16;               // column blocks = contiguous channels per lane (8, 4, 2)
     static constexpr int EA_BYTES = NQ * FE * 4;          // 1280, 2560 or 5120: whole KiB by 16-B DMA, the rest by 4-B DMA
     static constexpr int EA_FULL = EA_BYTES / 1024, EA_TAIL = (EA_BYTES % 1024) / 256;
-    static constexpr int BP_BYTES = NB * 3 * 768;         // [cb][part][g<3][j<16] x 16 B filter operand parts
+    static constexpr int BP_BYTES = NB * FSP * 768;       // [cb][part][g<3][j<16] x 16 B filter operand parts
     static constexpr int RED_BYTES = KS == 2 ? NW * 8 * 64 * 4 : 0;
-    static constexpr int SMEM_BYTES = 2 * A_BYTES + NW * EA_BYTES + 2 * RED_BYTES + BP_BYTES;
+    static constexpr int ROWF_BYTES = DSP == 2 ? 4 * TILE * 4 : 0;  // per-row inverse scales, 4 tiles deep (written in P(it), read up to the
+                                                                    // delayed epilogue after barrier it+1 while P(it+2) may already write)
+    static constexpr int SC_BYTES = 16;                   // launch-wide weight maxima (prologue)
+    static constexpr int SMEM_BYTES = 2 * A_BYTES + NW * EA_BYTES + 2 * RED_BYTES + BP_BYTES + ROWF_BYTES + SC_BYTES;
     static constexpr int NWB = K / 16 / KS;               // dense part: k-steps of 16 per wave
     static_assert(EA_BYTES % 256 == 0, "attribute block must be DMA-able");
     static_assert(RG >= 1 && NQ <= 64, "wave roles");
@@ -81,7 +90,7 @@ __device__ __forceinline__ void ld_vec(float (&v)[NB], const float* p, bool vec)
     }
 }
 
-template <int CIN_PAD, int COUT, int NW, int KS>
+template <int CIN_PAD, int COUT, int NW, int KS, int DSP, int FSP>
 __global__ void __launch_bounds__(64 * NW, 2)
 k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid, int64_t n_dst,
                   const float* __restrict__ x, const float* __restrict__ xdst, int64_t ldx, int c_in, const float* __restrict__ ea, int64_t lde,
@@ -89,13 +98,15 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                   const float* __restrict__ bj, const float* __restrict__ Wi, const float* __restrict__ scale,
                   const float* __restrict__ shift, int relu, float* __restrict__ out, int64_t ldo, int64_t ntiles,
                   int xvec, int64_t* __restrict__ trace, int64_t trace_cap) {
-    using C = Cfg2<CIN_PAD, COUT, NW, KS>;
-    constexpr int ROWB = C::ROWB, TILE = C::TILE, TPW = C::TPW, RB = C::RB, NB = C::NB, NWB = C::NWB;
+    using C = Cfg2<CIN_PAD, COUT, NW, KS, DSP, FSP>;
+    constexpr int ROWB = C::ROWB, TILE = C::TILE, TPW = C::TPW, RB = C::RB, NB = C::NB, NWB = C::NWB, OCT = C::OCT;
     extern __shared__ __attribute__((aligned(16))) char smem2[];
     char* const abuf = smem2;                                        // [2][A_BYTES]
     char* const eabuf = smem2 + 2 * C::A_BYTES;                      // [NW][EA_BYTES] fp32 attribute strips
     float* const redbuf = reinterpret_cast<float*>(eabuf + NW * C::EA_BYTES);     // [2][NW][8][64] (KS == 2 only)
     char* const bpbuf = reinterpret_cast<char*>(redbuf) + 2 * C::RED_BYTES;       // filter operand parts
+    float* const rowf = reinterpret_cast<float*>(bpbuf + C::BP_BYTES);            // [4][TILE] (DSP == 2 only)
+    uint32_t* const scbuf = reinterpret_cast<uint32_t*>(bpbuf + C::BP_BYTES + C::ROWF_BYTES);
 
     const int lane = lane_id(), w = wave_id_uniform();
 #if DGNN_YOUNG_PRIO
@@ -115,7 +126,31 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     if (t_lo + slot < t_hi) my_n = (t_hi - t_lo - slot + wg_per_xcd - 1) / wg_per_xcd;
     auto tile_of = [&](int64_t it) { return t_lo + slot + it * wg_per_xcd; };
 
-    // ---- filter operand B = [We^T ; be ; 0] split in 3 bf16 parts -> LDS, once per launch.
+    // ---- fp16 forms: power-of-two scales of the two weight groups from their largest magnitudes (every workgroup reads both
+    // matrices once, coalesced; they are L2-resident)
+    float sW = 1.f, inv_sW = 1.f, sWe = 1.f, inv_sWe = 1.f;
+    if constexpr (DSP == 2 || FSP == 2) {
+        if (threadIdx.x < 2) scbuf[threadIdx.x] = 0u;
+        __syncthreads();
+        uint32_t mw = 0u, me = 0u;
+        if constexpr (DSP == 2)
+            for (int e = threadIdx.x; e < COUT * c_in; e += blockDim.x) mw = umax(mw, umax(absbits(Wj[e]), absbits(Wi[e])));
+        if constexpr (FSP == 2) {
+            for (int e = threadIdx.x; e < c_in * FE; e += blockDim.x) me = umax(me, absbits(We[e]));
+            for (int e = threadIdx.x; e < c_in; e += blockDim.x) me = umax(me, absbits(be[e]));
+        }
+        mw = wave_umax(mw);
+        me = wave_umax(me);
+        if (lane == 0) {
+            atomicMax(&scbuf[0], mw);
+            atomicMax(&scbuf[1], me);
+        }
+        __syncthreads();
+        if constexpr (DSP == 2) pow2_scales(scbuf[0], sW, inv_sW);
+        if constexpr (FSP == 2) pow2_scales(scbuf[1], sWe, inv_sWe);
+    }
+
+    // ---- filter operand B = [We^T ; be ; 0] split in FSP parts -> LDS, once per launch.
     // entry (cb, g, j): channel c = NB*j + cb, k = 8g .. 8g+7 (g < 3; the k-group 3 of the MFMA is all zero)
     for (int e = threadIdx.x; e < NB * 48; e += blockDim.x) {
         const int cb = e / 48, gj = e - cb * 48, g = gj >> 4, j = gj & 15;
@@ -130,19 +165,20 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                 v[u] = 0.f;
                 if (c < c_in) v[u] = k < FE ? We[(int64_t)c * FE + k] : (k == FE ? be[c] : 0.f);
             }
-            split3(v[0], v[1], ph[d], pm[d], pl[d]);
+            if constexpr (FSP == 2) split2h(v[0] * sWe, v[1] * sWe, ph[d], pl[d]);
+            else split3(v[0], v[1], ph[d], pm[d], pl[d]);
         }
-        uint4* dst = reinterpret_cast<uint4*>(bpbuf + ((cb * 3) * 48 + gj) * 16);
+        uint4* dst = reinterpret_cast<uint4*>(bpbuf + ((cb * FSP) * 48 + gj) * 16);
         dst[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
-        dst[48] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
-        dst[96] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+        if constexpr (FSP == 3) dst[48] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+        dst[48 * (FSP - 1)] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
     }
 
     // ---- dense-phase role: (column slice cs, K part kh, row group rg); this wave's share of K resident as 3 bf16 parts
     const int cs = w % C::NSLICE, kh = KS == 2 ? (w / C::NSLICE) & 1 : 0, rg = w / (KS * C::NSLICE);
     const int col = cs * 32 + l31;
     const int partner = w ^ C::NSLICE;
-    bf16x8 wb[NWB][3];
+    bf16x8 wb[NWB][DSP];  // DSP == 2: fp16 bit patterns of (hi, lo) of W * sW
     {
 #pragma unroll
         for (int S = 0; S < NWB; ++S) {
@@ -156,11 +192,12 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                 const int k = 16 * S_ + 8 * h + 2 * d;
                 const float v0 = Wsrc[(int64_t)col * c_in + (k < c_in ? k : 0)];
                 const float v1 = Wsrc[(int64_t)col * c_in + (k + 1 < c_in ? k + 1 : 0)];
-                split3(k < c_in ? v0 : 0.f, k + 1 < c_in ? v1 : 0.f, ph[d], pm[d], pl[d]);
+                if constexpr (DSP == 2) split2h(k < c_in ? v0 * sW : 0.f, k + 1 < c_in ? v1 * sW : 0.f, ph[d], pl[d]);
+                else split3(k < c_in ? v0 : 0.f, k + 1 < c_in ? v1 : 0.f, ph[d], pm[d], pl[d]);
             }
             wb[S][0] = pack8(ph);
-            wb[S][1] = pack8(pm);
-            wb[S][2] = pack8(pl);
+            if constexpr (DSP == 3) wb[S][1] = pack8(pm);
+            wb[S][DSP - 1] = pack8(pl);
         }
     }
     const float bb = bj ? bj[col] : 0.f;
@@ -247,36 +284,54 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         ok2 = load_rowptr(it_next + 1, vbeg2, nv2);
     };
     // one finished (tet row, NB channels) segment -> A-tile: columns [c0, c0+NB) of the mean half and of the own-row half
-    auto put_seg = [&](int buf, int row, const float (&av)[NB], const float (&xv)[NB]) {
-        char* dst = abuf + buf * C::A_BYTES + row * ROWB + (c0 >> 3) * 48 + (c0 & 7) * 2;
-        char* dsx = dst + (CIN_PAD / 8) * 48;
+    auto put_seg = [&](int64_t it, int row, const float (&av)[NB], const float (&xv)[NB]) {
+        const int buf = (int)(it & 1);
+        char* dst = abuf + buf * C::A_BYTES + row * ROWB + (c0 >> 3) * OCT + (c0 & 7) * 2;
+        char* dsx = dst + (CIN_PAD / 8) * OCT;
         uint32_t ph[NB / 2], pm[NB / 2], pl[NB / 2], qh[NB / 2], qm[NB / 2], ql[NB / 2];
+        if constexpr (DSP == 2) {
+            // row scale: the 16 lanes of this tet hold the whole [mean | own] row between them
+            uint32_t m = 0u;
 #pragma unroll
-        for (int d = 0; d < NB / 2; ++d) {
-            split3(av[2 * d], av[2 * d + 1], ph[d], pm[d], pl[d]);
-            split3(xv[2 * d], xv[2 * d + 1], qh[d], qm[d], ql[d]);
+            for (int i = 0; i < NB; ++i) m = umax(m, umax(absbits(av[i]), absbits(xv[i])));
+            m = row16_umax(m);
+            float s_, inv_;
+            pow2_scales(m, s_, inv_);
+            if (jcol == 0) rowf[(int)(it & 3) * TILE + row] = inv_ * inv_sW;
+#pragma unroll
+            for (int d = 0; d < NB / 2; ++d) {
+                split2h(av[2 * d] * s_, av[2 * d + 1] * s_, ph[d], pl[d]);
+                split2h(xv[2 * d] * s_, xv[2 * d + 1] * s_, qh[d], ql[d]);
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < NB / 2; ++d) {
+                split3(av[2 * d], av[2 * d + 1], ph[d], pm[d], pl[d]);
+                split3(xv[2 * d], xv[2 * d + 1], qh[d], qm[d], ql[d]);
+            }
         }
+        constexpr int LO = 16 * (DSP - 1);
         if (NB == 8) {
             *reinterpret_cast<uint4*>(dst) = make_uint4(ph[0], ph[1], ph[2 % (NB / 2)], ph[3 % (NB / 2)]);
-            *reinterpret_cast<uint4*>(dst + 16) = make_uint4(pm[0], pm[1], pm[2 % (NB / 2)], pm[3 % (NB / 2)]);
-            *reinterpret_cast<uint4*>(dst + 32) = make_uint4(pl[0], pl[1], pl[2 % (NB / 2)], pl[3 % (NB / 2)]);
+            if constexpr (DSP == 3) *reinterpret_cast<uint4*>(dst + 16) = make_uint4(pm[0], pm[1], pm[2 % (NB / 2)], pm[3 % (NB / 2)]);
+            *reinterpret_cast<uint4*>(dst + LO) = make_uint4(pl[0], pl[1], pl[2 % (NB / 2)], pl[3 % (NB / 2)]);
             *reinterpret_cast<uint4*>(dsx) = make_uint4(qh[0], qh[1], qh[2 % (NB / 2)], qh[3 % (NB / 2)]);
-            *reinterpret_cast<uint4*>(dsx + 16) = make_uint4(qm[0], qm[1], qm[2 % (NB / 2)], qm[3 % (NB / 2)]);
-            *reinterpret_cast<uint4*>(dsx + 32) = make_uint4(ql[0], ql[1], ql[2 % (NB / 2)], ql[3 % (NB / 2)]);
+            if constexpr (DSP == 3) *reinterpret_cast<uint4*>(dsx + 16) = make_uint4(qm[0], qm[1], qm[2 % (NB / 2)], qm[3 % (NB / 2)]);
+            *reinterpret_cast<uint4*>(dsx + LO) = make_uint4(ql[0], ql[1], ql[2 % (NB / 2)], ql[3 % (NB / 2)]);
         } else if (NB == 4) {
             *reinterpret_cast<uint2*>(dst) = make_uint2(ph[0], ph[1 % (NB / 2)]);
-            *reinterpret_cast<uint2*>(dst + 16) = make_uint2(pm[0], pm[1 % (NB / 2)]);
-            *reinterpret_cast<uint2*>(dst + 32) = make_uint2(pl[0], pl[1 % (NB / 2)]);
+            if constexpr (DSP == 3) *reinterpret_cast<uint2*>(dst + 16) = make_uint2(pm[0], pm[1 % (NB / 2)]);
+            *reinterpret_cast<uint2*>(dst + LO) = make_uint2(pl[0], pl[1 % (NB / 2)]);
             *reinterpret_cast<uint2*>(dsx) = make_uint2(qh[0], qh[1 % (NB / 2)]);
-            *reinterpret_cast<uint2*>(dsx + 16) = make_uint2(qm[0], qm[1 % (NB / 2)]);
-            *reinterpret_cast<uint2*>(dsx + 32) = make_uint2(ql[0], ql[1 % (NB / 2)]);
+            if constexpr (DSP == 3) *reinterpret_cast<uint2*>(dsx + 16) = make_uint2(qm[0], qm[1 % (NB / 2)]);
+            *reinterpret_cast<uint2*>(dsx + LO) = make_uint2(ql[0], ql[1 % (NB / 2)]);
         } else {
             *reinterpret_cast<uint32_t*>(dst) = ph[0];
-            *reinterpret_cast<uint32_t*>(dst + 16) = pm[0];
-            *reinterpret_cast<uint32_t*>(dst + 32) = pl[0];
+            if constexpr (DSP == 3) *reinterpret_cast<uint32_t*>(dst + 16) = pm[0];
+            *reinterpret_cast<uint32_t*>(dst + LO) = pl[0];
             *reinterpret_cast<uint32_t*>(dsx) = qh[0];
-            *reinterpret_cast<uint32_t*>(dsx + 16) = qm[0];
-            *reinterpret_cast<uint32_t*>(dsx + 32) = ql[0];
+            if constexpr (DSP == 3) *reinterpret_cast<uint32_t*>(dsx + 16) = qm[0];
+            *reinterpret_cast<uint32_t*>(dsx + LO) = ql[0];
         }
     };
 
@@ -313,36 +368,55 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                     }
                     if (tq == 2) av[4] = 1.0f;
                     uint32_t ph[4], pm[4], pl[4];
+                    float fmean = 0.25f;  // 1/4 (regular group) times the inverse scales of the filter product
+                    if constexpr (FSP == 2) {
+                        // one scale for the 16-edge block (the constant 1 of the bias column is part of it)
+                        uint32_t m = 0u;
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) split3(av[2 * d], av[2 * d + 1], ph[d], pm[d], pl[d]);
-                    const bf16x8 ah = pack8(ph), am = pack8(pm), al = pack8(pl);
+                        for (int i = 0; i < 8; ++i) m = umax(m, absbits(av[i]));
+                        float sA, inv_sA;
+                        pow2_scales(wave_umax(m), sA, inv_sA);
+                        fmean = 0.25f * inv_sA * inv_sWe;
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) split2h(av[2 * d] * sA, av[2 * d + 1] * sA, ph[d], pl[d]);
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) split3(av[2 * d], av[2 * d + 1], ph[d], pm[d], pl[d]);
+                    }
+                    const bf16x8 ah = pack8(ph), am = pack8(FSP == 3 ? pm : ph), al = pack8(pl);
 
                     float aout[NB], xv[NB];
 #pragma unroll
                     for (int cb = 0; cb < NB; ++cb) {
-                        const char* bp = bpbuf + ((cb * 3) * 48 + (tq < 3 ? tq : 0) * 16 + jcol) * 16;
+                        const char* bp = bpbuf + ((cb * FSP) * 48 + (tq < 3 ? tq : 0) * 16 + jcol) * 16;
                         // k-group 3 re-reads group 0: its A operand is all zero, so any finite B will do (saves 12 selects)
                         const uint4 u0 = *reinterpret_cast<const uint4*>(bp), u1 = *reinterpret_cast<const uint4*>(bp + 768),
-                                    u2 = *reinterpret_cast<const uint4*>(bp + 1536);
+                                    u2 = *reinterpret_cast<const uint4*>(bp + 768 * (FSP - 1));
                         const bf16x8 bh = __builtin_bit_cast(bf16x8, u0), bm = __builtin_bit_cast(bf16x8, u1),
                                      bl = __builtin_bit_cast(bf16x8, u2);
                         f32x4_t d = {0.f, 0.f, 0.f, 0.f};
-                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d, 0, 0, 0);
-                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d, 0, 0, 0);
-                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, d, 0, 0, 0);
-                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, d, 0, 0, 0);
-                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, d, 0, 0, 0);
-                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d, 0, 0, 0);
+                        if constexpr (FSP == 2) {
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(H8(al), H8(bh), d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(H8(ah), H8(bl), d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(H8(ah), H8(bh), d, 0, 0, 0);
+                        } else {
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d, 0, 0, 0);
+                        }
                         // d[r] = phi of edge 4*tq + r (the r-th in-edge of this lane's tet), channel c0 + cb
                         // in-order sum over the tet's 4 in-edges.  Lanes past c_in need no masking: their filter
                         // operand and their rows of Wj|Wi are zero, and what they loaded (channel 0..) is finite.
                         float a = __fmul_rn(xr[rb][0][cb], d[0]);
 #pragma unroll
                         for (int r = 1; r < 4; ++r) a = __fmaf_rn(xr[rb][r][cb], d[r], a);
-                        aout[cb] = a * 0.25f;
+                        aout[cb] = a * fmean;
                         xv[cb] = xd[rb][cb];
                     }
-                    put_seg((int)(it & 1), w * TPW + rb * 4 + tq, aout, xv);
+                    put_seg(it, w * TPW + rb * 4 + tq, aout, xv);
                 }
             } else {
                 // generic path (a group with any in-degree other than 4, or past the end): plain fp32 per lane, one edge at a time (rare)
@@ -370,7 +444,7 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
 #pragma unroll
                         for (int cb = 0; cb < NB; ++cb) aout[cb] = __fdiv_rn(aout[cb], cnt);
                     }
-                    put_seg((int)(it & 1), w * TPW + rb * 4 + tq, aout, xv);
+                    put_seg(it, w * TPW + rb * 4 + tq, aout, xv);
                 }
             }
             stamp(trace, trace_cap, it, w, 2);
@@ -394,10 +468,17 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
             const float* red = redbuf + ((it - 1) & 1) * (C::RED_BYTES / 4) + partner * 512 + lane;
             const int64_t row0 = tile * TILE + rg * 32 + 4 * h + 16 * kh;
             float* o = out + row0 * ldo + col;
-            float v[8];
+            float v[8], rf[8];
+            if constexpr (DSP == 2) {
+                const float* rfp = rowf + (int)((it - 1) & 3) * TILE + rg * 32 + 4 * h + 16 * kh;
+                const f32x4_t r0 = *reinterpret_cast<const f32x4_t*>(rfp), r1 = *reinterpret_cast<const f32x4_t*>(rfp + 8);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { rf[r] = r0[r]; rf[4 + r] = r1[r]; }
+            }
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                v[r] = (mine[r] + red[r * 64]) + bb;
+                if constexpr (DSP == 2) v[r] = __fmaf_rn(mine[r] + red[r * 64], rf[r], bb);
+                else v[r] = (mine[r] + red[r * 64]) + bb;
                 if (has_scale) v[r] = __fmaf_rn(v[r], sc, sh);
                 if (relu) v[r] = fmaxf(v[r], 0.f);
             }
@@ -417,18 +498,24 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-            const char* A = abuf + (it & 1) * C::A_BYTES + (rg * 32 + l31) * ROWB + (kh * (CIN_PAD / 8) + h) * 48;
+            const char* A = abuf + (it & 1) * C::A_BYTES + (rg * 32 + l31) * ROWB + (kh * (CIN_PAD / 8) + h) * OCT;
 #pragma unroll
             for (int S = 0; S < NWB; ++S) {
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(A + S * 96);
-                const bf16x8 am = *reinterpret_cast<const bf16x8*>(A + S * 96 + 16);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(A + S * 96 + 32);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wb[S][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wb[S][2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wb[S][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wb[S][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wb[S][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wb[S][0], acc, 0, 0, 0);
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(A + S * 2 * OCT);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(A + S * 2 * OCT + 16 * (DSP - 1));
+                if constexpr (DSP == 2) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(al), H8(wb[S][0]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(ah), H8(wb[S][1]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(ah), H8(wb[S][0]), acc, 0, 0, 0);
+                } else {
+                    const bf16x8 am = *reinterpret_cast<const bf16x8*>(A + S * 2 * OCT + 16);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wb[S][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wb[S][DSP - 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wb[S][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wb[S][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wb[S][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wb[S][0], acc, 0, 0, 0);
+                }
             }
             if constexpr (KS == 2) {
                 float* red = redbuf + (it & 1) * (C::RED_BYTES / 4) + w * 512 + lane;
@@ -443,9 +530,19 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                 const int64_t row0 = tile * TILE + rg * 32 + 4 * h;
                 float* o = out + row0 * ldo + col;
                 const bool full = (tile + 1) * TILE <= n_dst;
+                float rf[16];
+                if constexpr (DSP == 2) {
+                    const float* rfp = rowf + (int)(it & 3) * TILE + rg * 32 + 4 * h;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4_t t = *reinterpret_cast<const f32x4_t*>(rfp + 8 * q);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) rf[4 * q + r] = t[r];
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float v = acc[r] + bb;
+                    float v = DSP == 2 ? __fmaf_rn(acc[r], rf[r], bb) : acc[r] + bb;
                     if (has_scale) v = __fmaf_rn(v, sc, sh);
                     if (relu) v = fmaxf(v, 0.f);
                     const int rr = (r & 3) + 8 * (r >> 2);
@@ -460,22 +557,22 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     }
 }
 
-template <int CIN_PAD, int COUT>
+template <int CIN_PAD, int COUT, int DSP, int FSP>
 int launch2(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x, const float* xdst, int64_t ldx, int c_in, const float* ea,
             int64_t lde, const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
             const float* scale, const float* shift, int relu, float* out, int64_t ldo, int xvec, hipStream_t stream) {
     // C_in <= 64: four-wave workgroups, two per CU (see Cfg2); C_in = 128: eight waves with the K split
     // (64 -> 64 would need 16 tets per wave with 4 channels per lane: 110 spilled registers -- it keeps the 8-wave form)
     constexpr int NW = (CIN_PAD <= 64 && !(CIN_PAD == 64 && COUT == 64)) ? DGNN_SMALL_NW : 8, KS = NW == 8 ? 2 : 1;
-    using C = Cfg2<CIN_PAD, COUT, NW, KS>;
+    using C = Cfg2<CIN_PAD, COUT, NW, KS, DSP, FSP>;
     const int64_t ntiles = dgnn_cdiv(n_dst, C::TILE);
     const size_t smem = C::SMEM_BYTES;
     static bool attr_set[DGNN_MAX_DEVICES] = {};
-    dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_mfma<CIN_PAD, COUT, NW, KS>), smem, attr_set);
+    dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_mfma<CIN_PAD, COUT, NW, KS, DSP, FSP>), smem, attr_set);
     const int wg_max = DGNN_NUM_CU * (NW == 8 ? 1 : 2);
     int grid = (int)(ntiles < wg_max ? ntiles : wg_max);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((k_sage_fused_mfma<CIN_PAD, COUT, NW, KS>), dim3(grid), dim3(64 * NW), smem, stream, rowptr, src, eid, n_dst, x, xdst,
+    hipLaunchKernelGGL((k_sage_fused_mfma<CIN_PAD, COUT, NW, KS, DSP, FSP>), dim3(grid), dim3(64 * NW), smem, stream, rowptr, src, eid, n_dst, x, xdst,
                        ldx, c_in, ea, lde, We, be, Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles, xvec, g_dgnn_trace_buf,
                        g_dgnn_trace_cap);
     return dgnn_check_launch("sage_layer_fused_fwd(mfma filter)");
@@ -487,16 +584,24 @@ int launch2(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64
 int dgnn_sage_layer_fused_mfma_try(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src,
                                    const float* x_dst, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, const float* We, const float* be,
                                    const float* Wj, const float* bj, const float* Wi, const float* scale, const float* shift,
-                                   int relu, int c_out, float* out, int64_t ldo, hipStream_t stream) {
+                                   int relu, int c_out, float* out, int64_t ldo, int f16_parts, hipStream_t stream) {
     const int cin_pad = c_in <= 32 ? 32 : (c_in <= 64 ? 64 : 128);
     const int nb = cin_pad / 16;
     if (c_in % nb != 0 || (c_out != 64 && c_out != 128) || (cin_pad == 128 && c_out != 128)) return DGNN_E_UNSUPPORTED;
     const int xvec = ((((uintptr_t)x_src | (uintptr_t)x_dst) % 16) == 0 && ldx % 4 == 0) ? 1 : 0;
     if (nb >= 4 && !xvec) return DGNN_E_UNSUPPORTED;
-#define GO2(CP, CO) return launch2<CP, CO>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, \
-                                           shift, relu, out, ldo, xvec, stream)
+    // f16_parts: 0 = bf16 x 3 everywhere, 1 = dense product on fp16 x 2 (filter product bf16 x 3), 2 = both on fp16 x 2
+#define GO3(CP, CO, D, F) return launch2<CP, CO, D, F>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, \
+                                                       shift, relu, out, ldo, xvec, stream)
+#define GO2(CP, CO)                            \
+    do {                                       \
+        if (f16_parts == 2) GO3(CP, CO, 2, 2); \
+        if (f16_parts == 1) GO3(CP, CO, 2, 3); \
+        GO3(CP, CO, 3, 3);                     \
+    } while (0)
     if (cin_pad == 32) { if (c_out == 64) GO2(32, 64); else GO2(32, 128); }
     if (cin_pad == 64) { if (c_out == 64) GO2(64, 64); else GO2(64, 128); }
     GO2(128, 128);
 #undef GO2
+#undef GO3
 }

@@ -329,11 +329,13 @@ def fused_layer_supported(c_in: int, c_out: int, f_e: int, x: torch.Tensor = Non
 
 
 FUSED_ENABLED = True
-GEMM_F32, GEMM_BF16X3, GEMM_BF16X3_FILTER = 0, 1, 2
+GEMM_F32, GEMM_BF16X3, GEMM_BF16X3_FILTER, GEMM_F16X2_DENSE, GEMM_F16X2 = 0, 1, 2, 3, 4
+GEMM_MODE_NAMES = {"f32": GEMM_F32, "bf16x3": GEMM_BF16X3, "bf16x3f": GEMM_BF16X3_FILTER, "f16x2d": GEMM_F16X2_DENSE, "f16x2": GEMM_F16X2}
 # how the fused layer uses the matrix cores: exact-fp32 MFMA for the dense part ("f32"), 3-way split-bf16 MFMA for the
 # dense part ("bf16x3"), or split-bf16 MFMA for the dense part AND the filter MLP ("bf16x3f"); all fp32-class accuracy
-GEMM_MODE = {"f32": GEMM_F32, "bf16x3": GEMM_BF16X3, "bf16x3f": GEMM_BF16X3_FILTER}[
-    __import__("os").environ.get("DGNN_GEMM_MODE", "bf16x3f")]
+# "f16x2d" / "f16x2": the dense product (and the filter MLP) on fp16 x 2 with power-of-two group scales (22 significand bits, 3 products:
+# the 3xTF32 scheme) -- half the matrix work of the bf16 x 3 forms; GEMM entry points outside the fused layer keep bf16 x 3
+GEMM_MODE = GEMM_MODE_NAMES[__import__("os").environ.get("DGNN_GEMM_MODE", "bf16x3f")]
 # whole-graph inference: fused layers read the caller's edge_attr in place (rows DMA-gathered by the plan's eid) instead of
 # staging a plan-ordered copy once per scene; DGNN_EDGE_STAGING=1 restores the staged copy
 EDGE_GATHER_IN_KERNEL = __import__("os").environ.get("DGNN_EDGE_STAGING", "0") != "1"

@@ -203,6 +203,12 @@ int dgnn_sage_aggregate_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const
 #define DGNN_GEMM_BF16X3_FILTER 2 /* as BF16X3, and the 20-tap filter MLP runs on v_mfma_f32_16x16x32_bf16 too (same exact
                                      3-part split, 6 products, fp32 accumulate); falls back to BF16X3 for shapes it
                                      does not cover (c_in not a multiple of c_in_pad/16, unaligned wide rows) */
+#define DGNN_GEMM_F16X2_DENSE 3 /* dense product: fp32 operands scaled by a power of two per tet row / per weight pair and split into
+                                  2 fp16 parts (22 significand bits), 3 products on v_mfma_f32_32x32x16_f16, fp32 accumulate (the
+                                  "3xTF32" scheme; dropped terms <= 2^-22 relative); filter MLP as BF16X3_FILTER */
+#define DGNN_GEMM_F16X2 4       /* as F16X2_DENSE, and the filter MLP on v_mfma_f32_16x16x32_f16 in the same form (one power-of-two
+                                  scale per 16-edge attribute block and per [We|be]); falls back like BF16X3_FILTER.  The GEMM entry
+                                  points (dgnn_linear_*_x3, training) treat both F16X2 values as BF16X3 */
 int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src,
                               const float* x_dst, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e,
                               const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,

@@ -508,7 +508,7 @@ def test_fused_layer_gemm_modes_vs_fp64(c_in, c_out):
     plan = GraphPlan(ei.to(DEV), n, n)
     eas = plan.sorted_edge_attr(ea.to(DEV))
     errs = {}
-    for mode in (ops.GEMM_F32, ops.GEMM_BF16X3, ops.GEMM_BF16X3_FILTER):
+    for mode in (ops.GEMM_F32, ops.GEMM_BF16X3, ops.GEMM_BF16X3_FILTER, ops.GEMM_F16X2_DENSE, ops.GEMM_F16X2):
         out = ops.sage_layer_fused_fwd(plan.rowptr, plan.src, n, x.to(DEV), eas, We.to(DEV), be.to(DEV), Wj.to(DEV), bj.to(DEV),
                                        Wi.to(DEV), sc.to(DEV), sh.to(DEV), True, gemm_mode=mode)
         errs[mode] = rel_err(out, ref)
@@ -519,6 +519,10 @@ def test_fused_layer_gemm_modes_vs_fp64(c_in, c_out):
         assert torch.equal(out_g, out), mode
     assert errs[ops.GEMM_BF16X3] < 3 * errs[ops.GEMM_F32] + 2e-7, errs
     assert errs[ops.GEMM_BF16X3_FILTER] < 3 * errs[ops.GEMM_F32] + 2e-7, errs
+    # fp16 x 2 (22 significand bits per operand, lo.lo dropped): within a small multiple of the fp32 chain's own rounding
+    print("fused %d->%d rel. err vs fp64 by mode:" % (c_in, c_out), {k: "%.2e" % v for k, v in errs.items()})
+    assert errs[ops.GEMM_F16X2_DENSE] < 4 * errs[ops.GEMM_F32] + 2e-7, errs
+    assert errs[ops.GEMM_F16X2] < 4 * errs[ops.GEMM_F32] + 2e-7, errs
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])

@@ -68,7 +68,7 @@ def test_metric_graph_1m_vs_oracle_all_gemm_modes():
     data = Config(x=s["x"].to(DEV), edge_attr=s["ea"].to(DEV), edge_index=s["ei"].to(DEV))
     old = ops.GEMM_MODE
     try:
-        for mode in (ops.GEMM_BF16X3_FILTER, ops.GEMM_BF16X3, ops.GEMM_F32):
+        for mode in (ops.GEMM_F16X2, ops.GEMM_F16X2_DENSE, ops.GEMM_BF16X3_FILTER, ops.GEMM_BF16X3, ops.GEMM_F32):
             ops.GEMM_MODE = mode
             logits = net.inference_layer(data).cpu().numpy()
             err = logit_check(logits, ref)
@@ -125,7 +125,7 @@ def test_ignatius_full_scene_vs_reference_logits():
     net = hip_static()
     old = ops.GEMM_MODE
     try:
-        for mode in (ops.GEMM_BF16X3_FILTER, ops.GEMM_BF16X3, ops.GEMM_F32):
+        for mode in (ops.GEMM_F16X2, ops.GEMM_F16X2_DENSE, ops.GEMM_BF16X3_FILTER, ops.GEMM_BF16X3, ops.GEMM_F32):
             ops.GEMM_MODE = mode
             logits = net.inference_layer(data).cpu().numpy()
             err = logit_check(logits, g["logits"], g["logits64"])
