@@ -26,6 +26,15 @@
 #ifndef DGNN_SMALL_NW
 #define DGNN_SMALL_NW 4  // wavefronts per workgroup for C_in <= 64 (4: two independent workgroups per CU; 8: one)
 #endif
+#ifndef DGNN_EARLY_ISSUE
+#define DGNN_EARLY_ISSUE 0  // measured: the tile period does not move (5.03 -> 5.19 us): the issue phase is address arithmetic and index shuffles, not memory stalls, and it costs ~100 register moves
+#endif
+#ifndef DGNN_DENSE_PREFETCH
+#define DGNN_DENSE_PREFETCH 2
+#endif
+#ifndef DGNN_FILTER_PIPE
+#define DGNN_FILTER_PIPE 1
+#endif
 #ifndef DGNN_PHASE_PRIO
 #define DGNN_PHASE_PRIO 0  // measured: balances the barrier waits (0.6/0.4 us instead of 1.4/0.2) but the tile period does not move
 #endif
@@ -38,6 +47,7 @@ using namespace fused;
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define H8(v) __builtin_bit_cast(f16x8, v)
+template <int V> struct IC { static constexpr int value = V; };
 
 // NW wavefronts per workgroup, KS = how many ways the dense phase splits K between wavefronts.
 //   (8, 2): 8 waves = (32-column slice) x (K half) [x row group]; the only arrangement whose resident weights fit at C_in = 128.
@@ -68,18 +78,28 @@ struct Cfg2 {
     static constexpr int ROWF_BYTES = DSP == 2 ? 4 * TILE * 4 : 0;  // per-row inverse scales, 4 tiles deep (written in P(it), read up to the
                                                                     // delayed epilogue after barrier it+1 while P(it+2) may already write)
     static constexpr int SC_BYTES = 16;                   // launch-wide weight maxima (prologue)
-    static constexpr int SMEM_BYTES = 2 * A_BYTES + NW * EA_BYTES + 2 * RED_BYTES + BP_BYTES + ROWF_BYTES + SC_BYTES;
+    static constexpr int COLP_BYTES = DSP == 2 ? 3 * COUT * 4 : 0;  // [bias | scale | shift][COUT]: the transposed epilogue's lanes own 8 / 16 columns
+    static constexpr int SMEM_BYTES = 2 * A_BYTES + NW * EA_BYTES + 2 * RED_BYTES + BP_BYTES + ROWF_BYTES + SC_BYTES + COLP_BYTES;
     static constexpr int NWB = K / 16 / KS;               // dense part: k-steps of 16 per wave
     static_assert(EA_BYTES % 256 == 0, "attribute block must be DMA-able");
     static_assert(RG >= 1 && NQ <= 64, "wave roles");
 };
 
-template <int NB>
+// part: -1 = the lane's NB channels; 0 / 1 = their first / second half (NB == 8, where the row piece is two 16-byte loads)
+template <int NB, int part = -1>
 __device__ __forceinline__ void ld_vec(float (&v)[NB], const float* p, bool vec) {
-    if (NB == 8 && vec) {
-        const f32x4_t a = *reinterpret_cast<const f32x4_t*>(p), b = *reinterpret_cast<const f32x4_t*>(p + 4);
+    if (NB == 8 && (vec || part >= 0)) {
+        if (part != 1) {
+            const f32x4_t a = *reinterpret_cast<const f32x4_t*>(p);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[(4 + i) % NB] = b[i]; }
+            for (int i = 0; i < 4; ++i) v[i] = a[i];
+        }
+        if (part != 0) {
+            const f32x4_t b = *reinterpret_cast<const f32x4_t*>(p + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[(4 + i) % NB] = b[i];
+        }
+    } else if (part == 1) {
     } else if (NB == 4 && vec) {
         const f32x4_t a = *reinterpret_cast<const f32x4_t*>(p);
 #pragma unroll
@@ -100,6 +120,9 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                   int xvec, int64_t* __restrict__ trace, int64_t trace_cap) {
     using C = Cfg2<CIN_PAD, COUT, NW, KS, DSP, FSP>;
     constexpr int ROWB = C::ROWB, TILE = C::TILE, TPW = C::TPW, RB = C::RB, NB = C::NB, NWB = C::NWB, OCT = C::OCT;
+    // the next tile's gathers are issued between the pieces of the filter phase (fp16 forms: the bf16 x 3 form at 128 -> 128 has no
+    // registers left for the overlap of old and new rows) or as one burst at its end
+    constexpr bool EARLY = DSP == 2 && DGNN_EARLY_ISSUE;
     extern __shared__ __attribute__((aligned(16))) char smem2[];
     char* const abuf = smem2;                                        // [2][A_BYTES]
     char* const eabuf = smem2 + 2 * C::A_BYTES;                      // [NW][EA_BYTES] fp32 attribute strips
@@ -107,6 +130,11 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     char* const bpbuf = reinterpret_cast<char*>(redbuf) + 2 * C::RED_BYTES;       // filter operand parts
     float* const rowf = reinterpret_cast<float*>(bpbuf + C::BP_BYTES);            // [4][TILE] (DSP == 2 only)
     uint32_t* const scbuf = reinterpret_cast<uint32_t*>(bpbuf + C::BP_BYTES + C::ROWF_BYTES);
+    float* const colp = reinterpret_cast<float*>(bpbuf + C::BP_BYTES + C::ROWF_BYTES + C::SC_BYTES);
+    // DSP == 2: the dense product is taken transposed (weights as the A operand, tet rows as the B operand -- the per-lane fragments are the
+    // same either way), so a lane ends up with ONE tet row and 4-column runs of it: the result leaves as 16-byte stores (2 or 4 per lane and
+    // tile instead of 8 or 16 dword stores whose addresses each cost 64-bit arithmetic), the row's inverse scale is one LDS word per lane.
+    constexpr bool TR = DSP == 2;
 
     const int lane = lane_id(), w = wave_id_uniform();
 #if DGNN_YOUNG_PRIO
@@ -117,7 +145,8 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     const int h = lane >> 5, l31 = lane & 31;
     const int jcol = lane & 15, tq = lane >> 4;  // filter phase: channel group / tet within a row block; also MFMA (col, k-group)
     const int ldx32 = (int)ldx;
-    const bool vec = xvec != 0;
+    constexpr bool vec = NB >= 4;  // the host side only takes rows that can be read as 16-byte pieces when NB >= 4 (xvec); NB == 2 reads 8 bytes
+    (void)xvec;
 
     const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wg_per_xcd = (nwg + 7 - xcd) >> 3;
     const int64_t per = (ntiles + 7) / 8;
@@ -129,6 +158,13 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     // ---- fp16 forms: power-of-two scales of the two weight groups from their largest magnitudes (every workgroup reads both
     // matrices once, coalesced; they are L2-resident)
     float sW = 1.f, inv_sW = 1.f, sWe = 1.f, inv_sWe = 1.f;
+    if constexpr (TR) {
+        for (int c = threadIdx.x; c < COUT; c += blockDim.x) {
+            colp[c] = bj ? bj[c] : 0.f;
+            colp[COUT + c] = scale ? scale[c] : 1.f;
+            colp[2 * COUT + c] = scale ? shift[c] : 0.f;
+        }
+    }
     if constexpr (DSP == 2 || FSP == 2) {
         if (threadIdx.x < 2) scbuf[threadIdx.x] = 0u;
         __syncthreads();
@@ -214,12 +250,15 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
 
     float xd[RB][NB], xr[RB][4][NB];
     bool regular = false;
-    int vbeg1 = 0, vbeg2 = 0, vsrc1 = 0, veid1 = 0;  // index pipeline, see fused.hip
-    bool ok1 = false, ok2 = false;
+    // Index pipeline, three tiles deep.  When P(it) starts (after its vmcnt(0)):  S1 = tile it+1: row starts, sources and edge ids have
+    // landed, so its gathers can be issued at any point of P(it);  S2 = tile it+2: row starts landed, sources / edge ids are requested
+    // now;  S3 = tile it+3: row starts requested now.
+    int vbeg1 = 0, vbeg2 = 0, vbeg3 = 0, vsrc1 = 0, vsrc2 = 0, veid1 = 0, veid2 = 0;
+    bool ok1 = false, ok2 = false, ok3 = false;
     // nv = valid tets of this wave's group (TPW except in the last tile).  A short group still takes the matrix-core
     // path with clamped (duplicated) rows so that a tet's result does not depend on where the tile grid cuts the
     // graph: whole-graph and partitioned runs stay bit-identical on 4-regular scenes.
-    int nv1 = 0, nv2 = 0;
+    int nv1 = 0, nv2 = 0, nv3 = 0;
 
     auto load_rowptr = [&](int64_t it, int& vb, int& nv) -> bool {
         if (it >= my_n) return false;
@@ -229,81 +268,97 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         vb = rowptr[i0 + (lane < nv ? lane : nv)];
         return true;
     };
-    auto load_src = [&]() {
-        if (ok1) {
-            const int b0 = __builtin_amdgcn_readfirstlane(vbeg1);
-            ok1 = __all(vbeg1 == b0 + 4 * (lane < nv1 ? lane : nv1)) != 0;
-            if (ok1) {
-                vsrc1 = src[b0 + (lane < 4 * nv1 ? lane : 4 * nv1 - 1)];
-                if (eid) veid1 = eid[b0 + (lane < 4 * nv1 ? lane : 4 * nv1 - 1)];
+    auto load_src = [&](bool& ok, int nv, int vbeg, int& vsrc, int& veid) {
+        if (ok) {
+            const int b0 = __builtin_amdgcn_readfirstlane(vbeg);
+            ok = __all(vbeg == b0 + 4 * (lane < nv ? lane : nv)) != 0;
+            if (ok) {
+                vsrc = src[b0 + (lane < 4 * nv ? lane : 4 * nv - 1)];
+                if (eid) veid = eid[b0 + (lane < 4 * nv ? lane : 4 * nv - 1)];
             }
         }
     };
-    auto issue_loads = [&](int64_t it) {
-        regular = ok1;
-        if (regular) {
-            const int i0 = (int)(tile_of(it) * TILE) + w * TPW;
+    // Gathers of tile `it` (S1), in pieces so that they can be issued between the pieces of P(it-1)'s arithmetic instead of as one
+    // burst in front of the barrier (the CU's vector-memory front end takes ~0.6 us per tile to accept them: 92 KB at 64 B/clk).
+    //   issue_x(it, rb, part): own row + the 4 neighbour rows of row block rb (part: see ld_vec)
+    //   issue_ea(it): LDS-DMA of the attribute block into the private strip -- the strip's reads of the current tile must have returned
+    int sidx[RB][4];
+    auto issue_x = [&](int64_t it, int rb, auto part_c) {
+        constexpr int part = decltype(part_c)::value;
+        if (!regular) return;
+        const int i0 = (int)(tile_of(it) * TILE) + w * TPW;
+        const int tl = rb * 4 + tq;  // this lane's tet within the wave
+        ld_vec<NB, part>(xd[rb], xdst + (uint32_t)((i0 + (tl < nv1 ? tl : nv1 - 1)) * ldx32) + c0l, vec);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (part != 1) sidx[rb][r] = __shfl(vsrc1, tl * 4 + r);
+            ld_vec<NB, part>(xr[rb][r], x + (uint32_t)(sidx[rb][r] * ldx32) + c0l, vec);
+        }
+    };
+    auto issue_ea = [&](int64_t it) {
+        if (!regular) return;
+        // eid == nullptr: the rows are in plan order, one contiguous block.  Otherwise every 80-byte row is
+        // fetched from its place in the caller's edge_attr (row eid[k]) -- no staging copy of the edge features.
+        if (eid) {
+            auto row_ptr = [&](int fi) -> const float* {     // float index within the strip -> global address
+                const int e = (fi * 0xCCD) >> 16;             // fi / 20 for fi < 8192
+                return ea + (int64_t)__shfl(veid1, e) * FE + (fi - e * FE);
+            };
+#pragma unroll
+            for (int q = 0; q < C::EA_FULL; ++q) glds16(row_ptr(q * 256 + lane * 4), myea + q * 256);
+#pragma unroll
+            for (int q = 0; q < C::EA_TAIL; ++q) glds4(row_ptr(C::EA_FULL * 256 + q * 64 + lane), myea + C::EA_FULL * 256 + q * 64);
+        } else {
             const float* eab = ea + (int64_t)__builtin_amdgcn_readfirstlane(vbeg1) * lde;
             const int ea_last = nv1 * 4 * FE - 4;  // last 16-byte chunk of the group's attribute block
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
-                const int tl = rb * 4 + tq;  // this lane's tet within the wave
-                ld_vec<NB>(xd[rb], xdst + (uint32_t)((i0 + (tl < nv1 ? tl : nv1 - 1)) * ldx32) + c0l, vec);
+            for (int q = 0; q < C::EA_FULL; ++q) glds16(eab + min(q * 256 + lane * 4, ea_last), myea + q * 256);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int s_ = __shfl(vsrc1, tl * 4 + r);
-                    ld_vec<NB>(xr[rb][r], x + (uint32_t)(s_ * ldx32) + c0l, vec);
-                }
-            }
-            // attribute block of this wave's tets: LDS-DMA into the private strip (issued last, see fused.hip).
-            // eid == nullptr: the rows are in plan order, one contiguous block.  Otherwise every 80-byte row is
-            // fetched from its place in the caller's edge_attr (row eid[k]) -- no staging copy of the edge features.
-            if (eid) {
-                auto row_ptr = [&](int fi) -> const float* {     // float index within the strip -> global address
-                    const int e = (fi * 0xCCD) >> 16;             // fi / 20 for fi < 8192
-                    return ea + (int64_t)__shfl(veid1, e) * FE + (fi - e * FE);
-                };
-#pragma unroll
-                for (int q = 0; q < C::EA_FULL; ++q) glds16(row_ptr(q * 256 + lane * 4), myea + q * 256);
-#pragma unroll
-                for (int q = 0; q < C::EA_TAIL; ++q) glds4(row_ptr(C::EA_FULL * 256 + q * 64 + lane), myea + C::EA_FULL * 256 + q * 64);
-            } else {
-#pragma unroll
-                for (int q = 0; q < C::EA_FULL; ++q) glds16(eab + min(q * 256 + lane * 4, ea_last), myea + q * 256);
-#pragma unroll
-                for (int q = 0; q < C::EA_TAIL; ++q)
-                    glds4(eab + min(C::EA_FULL * 256 + q * 64 + lane, ea_last + 3), myea + C::EA_FULL * 256 + q * 64);
-            }
+            for (int q = 0; q < C::EA_TAIL; ++q)
+                glds4(eab + min(C::EA_FULL * 256 + q * 64 + lane, ea_last + 3), myea + C::EA_FULL * 256 + q * 64);
         }
     };
-    auto advance_idx = [&](int64_t it_next) {
-        ok1 = ok2;
-        vbeg1 = vbeg2;
-        nv1 = nv2;
-        load_src();
-        ok2 = load_rowptr(it_next + 1, vbeg2, nv2);
+    auto issue_loads = [&](int64_t it) {  // everything at once (prologue, and after a group that took the generic path)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) issue_x(it, rb, IC<-1>{});
+        issue_ea(it);
+    };
+    // start of P(it), everything requested so far has landed: the stages move up, then S2's sources and S3's row starts are requested
+    auto advance_idx = [&](int64_t it) {
+        ok1 = ok2; nv1 = nv2; vbeg1 = vbeg2; vsrc1 = vsrc2; veid1 = veid2;
+        ok2 = ok3; nv2 = nv3; vbeg2 = vbeg3;
+        load_src(ok2, nv2, vbeg2, vsrc2, veid2);
+        ok3 = load_rowptr(it + 3, vbeg3, nv3);
     };
     // one finished (tet row, NB channels) segment -> A-tile: columns [c0, c0+NB) of the mean half and of the own-row half
-    auto put_seg = [&](int64_t it, int row, const float (&av)[NB], const float (&xv)[NB]) {
+    // av = araw * fpre, fpre a power of two (the 1/4 of the mean times the inverse scales of the filter product; 1 on the generic path)
+    auto put_seg = [&](int64_t it, int row, const float (&araw)[NB], const float (&xv)[NB], float fpre) {
         const int buf = (int)(it & 1);
         char* dst = abuf + buf * C::A_BYTES + row * ROWB + (c0 >> 3) * OCT + (c0 & 7) * 2;
         char* dsx = dst + (CIN_PAD / 8) * OCT;
         uint32_t ph[NB / 2], pm[NB / 2], pl[NB / 2], qh[NB / 2], qm[NB / 2], ql[NB / 2];
         if constexpr (DSP == 2) {
             // row scale: the 16 lanes of this tet hold the whole [mean | own] row between them
-            uint32_t m = 0u;
+            float ma = 0.f, mx = 0.f;  // v_max3_f32 with |.| source modifiers: one instruction per two values
 #pragma unroll
-            for (int i = 0; i < NB; ++i) m = umax(m, umax(absbits(av[i]), absbits(xv[i])));
-            m = row16_umax(m);
+            for (int i = 0; i < NB; i += 2) {
+                ma = fmaxf(fmaxf(ma, fabsf(araw[i])), fabsf(araw[i + 1]));
+                mx = fmaxf(fmaxf(mx, fabsf(xv[i])), fabsf(xv[i + 1]));
+            }
+            const uint32_t m = row16_umax(__builtin_bit_cast(uint32_t, fmaxf(ma * fpre, mx)));
             float s_, inv_;
             pow2_scales(m, s_, inv_);
             if (jcol == 0) rowf[(int)(it & 3) * TILE + row] = inv_ * inv_sW;
+            const float sa = fpre * s_;  // powers of two: the scaling of the mean and of the row in one exact multiplication
 #pragma unroll
             for (int d = 0; d < NB / 2; ++d) {
-                split2h(av[2 * d] * s_, av[2 * d + 1] * s_, ph[d], pl[d]);
+                split2h(araw[2 * d] * sa, araw[2 * d + 1] * sa, ph[d], pl[d]);
                 split2h(xv[2 * d] * s_, xv[2 * d + 1] * s_, qh[d], ql[d]);
             }
         } else {
+            float av[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) av[i] = araw[i] * fpre;
 #pragma unroll
             for (int d = 0; d < NB / 2; ++d) {
                 split3(av[2 * d], av[2 * d + 1], ph[d], pm[d], pl[d]);
@@ -336,9 +391,12 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     };
 
     ok1 = load_rowptr(0, vbeg1, nv1);
-    load_src();
     ok2 = load_rowptr(1, vbeg2, nv2);
+    ok3 = load_rowptr(2, vbeg3, nv3);
+    load_src(ok1, nv1, vbeg1, vsrc1, veid1);
+    regular = ok1;
     issue_loads(0);
+    load_src(ok2, nv2, vbeg2, vsrc2, veid2);  // state as at the end of a P phase: S1 = tile 0 (gathers issued), S2 = tile 1, S3 = tile 2
     float mine[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) mine[r] = 0.f;
@@ -348,9 +406,12 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
             // ================================================================ P: filter on the matrix cores + mean
             const int64_t i0 = tile_of(it) * TILE + w * TPW;
             stamp(trace, trace_cap, it, w, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // rows + LDS-DMA'd strip of this tile
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // rows + LDS-DMA'd strip of this tile, index loads of the tiles behind it
+            // the index loads are consumed HERE (the compiler would otherwise place its own, conservative, waits at their later uses)
+            asm volatile("" : "+v"(vbeg2), "+v"(vbeg3), "+v"(vsrc2), "+v"(veid2));
             const bool was_regular = regular;
-            advance_idx(it + 1);
+            advance_idx(it);
+            regular = ok1;  // tile it+1: its gathers are issued during this P
             stamp(trace, trace_cap, it, w, 1);
             if (was_regular) {
 #pragma unroll
@@ -367,15 +428,20 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                         av[4 + i] = tq < 2 ? q1[i] : 0.f;
                     }
                     if (tq == 2) av[4] = 1.0f;
+                    if (EARLY && rb == RB - 1) {
+                        // the strip has been read for the last time: the next tile's attribute block may land in it
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        issue_ea(it + 1);
+                    }
                     uint32_t ph[4], pm[4], pl[4];
                     float fmean = 0.25f;  // 1/4 (regular group) times the inverse scales of the filter product
                     if constexpr (FSP == 2) {
                         // one scale for the 16-edge block (the constant 1 of the bias column is part of it)
-                        uint32_t m = 0u;
+                        float mf = 0.f;
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) m = umax(m, absbits(av[i]));
+                        for (int i = 0; i < 8; i += 2) mf = fmaxf(fmaxf(mf, fabsf(av[i])), fabsf(av[i + 1]));
                         float sA, inv_sA;
-                        pow2_scales(wave_umax(m), sA, inv_sA);
+                        pow2_scales(wave_umax(__builtin_bit_cast(uint32_t, mf)), sA, inv_sA);
                         fmean = 0.25f * inv_sA * inv_sWe;
 #pragma unroll
                         for (int d = 0; d < 4; ++d) split2h(av[2 * d] * sA, av[2 * d + 1] * sA, ph[d], pl[d]);
@@ -413,10 +479,26 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                         float a = __fmul_rn(xr[rb][0][cb], d[0]);
 #pragma unroll
                         for (int r = 1; r < 4; ++r) a = __fmaf_rn(xr[rb][r][cb], d[r], a);
-                        aout[cb] = a * fmean;
+                        aout[cb] = a;
                         xv[cb] = xd[rb][cb];
+                        // the registers of this row block are free again: request its rows of the next tile right here, between
+                        // the arithmetic (NB == 8: in two halves, the first as soon as channels 0..3 are through)
+                        if (EARLY && RB == 1 && NB == 8 && cb == 3) issue_x(it + 1, rb, IC<0>{});
                     }
-                    put_seg(it, w * TPW + rb * 4 + tq, aout, xv);
+                    if (EARLY) issue_x(it + 1, rb, IC<(RB == 1 && NB == 8) ? 1 : -1>{});
+                    if constexpr (FSP == 2 && DGNN_FILTER_PIPE) {
+                        // instruction order of the channel-block loop: operand reads two blocks ahead of their products, the x.phi sums of a
+                        // block behind the next block's products (left alone, every read is waited for right where it is issued)
+                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                        for (int cb = 0; cb < NB; ++cb) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                            if (cb + 2 < NB) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                            if (cb > 0) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    }
+                    put_seg(it, w * TPW + rb * 4 + tq, aout, xv, fmean);
                 }
             } else {
                 // generic path (a group with any in-degree other than 4, or past the end): plain fp32 per lane, one edge at a time (rare)
@@ -444,13 +526,14 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
 #pragma unroll
                         for (int cb = 0; cb < NB; ++cb) aout[cb] = __fdiv_rn(aout[cb], cnt);
                     }
-                    put_seg(it, w * TPW + rb * 4 + tq, aout, xv);
+                    put_seg(it, w * TPW + rb * 4 + tq, aout, xv, 1.f);
                 }
             }
             stamp(trace, trace_cap, it, w, 2);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // strip reads returned before the next DMA may land
-            asm volatile("" : "+v"(vbeg2), "+v"(vsrc1), "+v"(vbeg1), "+v"(veid1));  // consume the index loads here (see fused.hip)
-            issue_loads(it + 1);
+            if (!was_regular || !EARLY) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // strip reads returned before the next DMA may land
+                issue_loads(it + 1);
+            }
             stamp(trace, trace_cap, it, w, 3);
         }
         tile_barrier();  // A-tile `it` complete; partial sums of tile `it-1` complete
@@ -466,6 +549,31 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
             // ============================================================ delayed epilogue of tile it-1
             const int64_t tile = tile_of(it - 1);
             const float* red = redbuf + ((it - 1) & 1) * (C::RED_BYTES / 4) + partner * 512 + lane;
+            if constexpr (TR) {
+                // this wave finishes columns cs*32 + 16*kh + 4h + 8g + c (g < 2, c < 4) of tet row rg*32 + l31
+                const int row = rg * 32 + l31, cbase = cs * 32 + 16 * kh + 4 * h;
+                const int64_t grow = tile * TILE + row;
+                const float rf = rowf[(int)((it - 1) & 3) * TILE + row];
+                float* o = out + grow * ldo + cbase;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(colp + cbase + 8 * g);
+                    f32x4_t v;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = __fmaf_rn(mine[4 * g + c] + red[(4 * g + c) * 64], rf, b4[c]);
+                    if (has_scale) {
+                        const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(colp + COUT + cbase + 8 * g);
+                        const f32x4_t h4 = *reinterpret_cast<const f32x4_t*>(colp + 2 * COUT + cbase + 8 * g);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] = __fmaf_rn(v[c], s4[c], h4[c]);
+                    }
+                    if (relu) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+                    }
+                    if (grow < n_dst) *reinterpret_cast<f32x4_t*>(o + 8 * g) = v;
+                }
+            } else {
             const int64_t row0 = tile * TILE + rg * 32 + 4 * h + 16 * kh;
             float* o = out + row0 * ldo + col;
             float v[8], rf[8];
@@ -492,7 +600,9 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                     if (row0 + rr < n_dst) o[(int64_t)rr * ldo] = v[r];
                 }
             }
+            }
         }
+        stamp(trace, trace_cap, it, w, 6);
         if (it < my_n) {
             // ================================================================ C: dense part, split-bf16, K half
             f32x16 acc;
@@ -504,9 +614,12 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(A + S * 2 * OCT);
                 const bf16x8 al = *reinterpret_cast<const bf16x8*>(A + S * 2 * OCT + 16 * (DSP - 1));
                 if constexpr (DSP == 2) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(al), H8(wb[S][0]), acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(ah), H8(wb[S][1]), acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(ah), H8(wb[S][0]), acc, 0, 0, 0);
+                    // first product: C = inline constant 0 (no 16 register moves to clear the accumulator)
+                    // (weights are the A operand: the accumulator holds the block transposed, see TR)
+                    if (S == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(wb[S][0]), H8(al), f32x16{}, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(wb[S][0]), H8(al), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(wb[S][1]), H8(ah), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(wb[S][0]), H8(ah), acc, 0, 0, 0);
                 } else {
                     const bf16x8 am = *reinterpret_cast<const bf16x8*>(A + S * 2 * OCT + 16);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wb[S][0], acc, 0, 0, 0);
@@ -515,6 +628,16 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wb[S][0], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wb[S][1], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wb[S][0], acc, 0, 0, 0);
+                }
+            }
+            if constexpr (DSP == 2 && DGNN_DENSE_PREFETCH > 0) {
+                // instruction order of the block above: the A fragments of DGNN_DENSE_PREFETCH k-steps are requested ahead of the products
+                // that use them (left alone, the scheduler requests each pair right in front of its use and every k-step pays an LDS round trip)
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * DGNN_DENSE_PREFETCH, 0);
+#pragma unroll
+                for (int S = 0; S < NWB; ++S) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                    if (S + DGNN_DENSE_PREFETCH < NWB) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 }
             }
             if constexpr (KS == 2) {
@@ -527,6 +650,31 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
             } else {
                 // full K in this wave: finish the 32 x 32 block right away (row (r&3) + 8(r>>2) + 4h, column `col`)
                 const int64_t tile = tile_of(it);
+                if constexpr (TR) {
+                    // transposed block: columns cs*32 + 4h + 8g + c (g < 4, c < 4) of tet row rg*32 + l31
+                    const int row = rg * 32 + l31, cbase = cs * 32 + 4 * h;
+                    const int64_t grow = tile * TILE + row;
+                    const float rf = rowf[(int)(it & 3) * TILE + row];
+                    float* o = out + grow * ldo + cbase;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(colp + cbase + 8 * g);
+                        f32x4_t v;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] = __fmaf_rn(acc[4 * g + c], rf, b4[c]);
+                        if (has_scale) {
+                            const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(colp + COUT + cbase + 8 * g);
+                            const f32x4_t h4 = *reinterpret_cast<const f32x4_t*>(colp + 2 * COUT + cbase + 8 * g);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) v[c] = __fmaf_rn(v[c], s4[c], h4[c]);
+                        }
+                        if (relu) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+                        }
+                        if (grow < n_dst) *reinterpret_cast<f32x4_t*>(o + 8 * g) = v;
+                    }
+                } else {
                 const int64_t row0 = tile * TILE + rg * 32 + 4 * h;
                 float* o = out + row0 * ldo + col;
                 const bool full = (tile + 1) * TILE <= n_dst;
@@ -547,6 +695,7 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                     if (relu) v = fmaxf(v, 0.f);
                     const int rr = (r & 3) + 8 * (r >> 2);
                     if (full || row0 + rr < n_dst) o[(int64_t)rr * ldo] = v;
+                }
                 }
             }
             stamp(trace, trace_cap, it, w, 5);
@@ -590,6 +739,7 @@ int dgnn_sage_layer_fused_mfma_try(const int32_t* rowptr, const int32_t* src, co
     if (c_in % nb != 0 || (c_out != 64 && c_out != 128) || (cin_pad == 128 && c_out != 128)) return DGNN_E_UNSUPPORTED;
     const int xvec = ((((uintptr_t)x_src | (uintptr_t)x_dst) % 16) == 0 && ldx % 4 == 0) ? 1 : 0;
     if (nb >= 4 && !xvec) return DGNN_E_UNSUPPORTED;
+    if (f16_parts && (ldo % 4 != 0 || ((uintptr_t)out % 16) != 0)) f16_parts = 0;  // the fp16 forms store 16-byte pieces of the output rows
     // f16_parts: 0 = bf16 x 3 everywhere, 1 = dense product on fp16 x 2 (filter product bf16 x 3), 2 = both on fp16 x 2
 #define GO3(CP, CO, D, F) return launch2<CP, CO, D, F>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, \
                                                        shift, relu, out, ldo, xvec, stream)

@@ -37,6 +37,7 @@ np.set_printoptions(linewidth=200, precision=2, suppress=True)
 sl = slice(5, 35)
 print("tile period (us): %.2f" % np.nanmean(np.diff(t[sl, 0, 4])))
 for w in (0, 3, 4, 7):
-    print("w%d: wait-loads %.2f  gather-compute %.2f  issue-next %.2f  barrier wait %.2f  epilogue+mfma %.2f" % (
+    ep = np.nanmean(t[sl, w, 6] - t[sl, w, 4]) if np.isfinite(t[sl, w, 6]).any() else float("nan")   # phase 6: delayed epilogue done (fused_mfma.hip)
+    print("w%d: wait-loads %.2f  gather-compute %.2f  issue-next %.2f  barrier wait %.2f  epilogue+mfma %.2f (epilogue %.2f)  next P starts %.2f after" % (
         w, np.nanmean(t[sl, w, 1] - t[sl, w, 0]), np.nanmean(t[sl, w, 2] - t[sl, w, 1]), np.nanmean(t[sl, w, 3] - t[sl, w, 2]),
-        np.nanmean(t[sl, w, 4] - t[sl, w, 3]), np.nanmean(t[sl, w, 5] - t[sl, w, 4])))
+        np.nanmean(t[sl, w, 4] - t[sl, w, 3]), np.nanmean(t[sl, w, 5] - t[sl, w, 4]), ep, np.nanmean(t[sl, w, 0][1:] - t[sl, w, 5][:-1])))
