@@ -35,6 +35,9 @@
 #ifndef DGNN_FILTER_PIPE
 #define DGNN_FILTER_PIPE 1
 #endif
+#ifndef DGNN_SKEW
+#define DGNN_SKEW 0  // measured: 0.52 -> 0.84 ms at 128 -> 128.  A lone filter-phase wavefront per SIMD takes as long as two interleaved ones (1.14 us: the phase is a chain of LDS -> matrix core -> vector ALU dependencies, latency-bound per wavefront), so a slot lasts a whole P and the tile two of them
+#endif
 #ifndef DGNN_PHASE_PRIO
 #define DGNN_PHASE_PRIO 0  // measured: balances the barrier waits (0.6/0.4 us instead of 1.4/0.2) but the tile period does not move
 #endif
@@ -135,6 +138,13 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     // same either way), so a lane ends up with ONE tet row and 4-column runs of it: the result leaves as 16-byte stores (2 or 4 per lane and
     // tile instead of 8 or 16 dword stores whose addresses each cost 64-bit arithmetic), the row's inverse scale is one LDS word per lane.
     constexpr bool TR = DSP == 2;
+    // Skewed schedule (128 -> 128, fp16 dense form): the eight waves are two groups, A = the K-half-0 waves 0..3 and B = the K-half-1 waves
+    // 4..7, one of each per SIMD, and at any time one group is in its filter phase P (vector ALU, LDS, gathers) while the other is in its dense
+    // phase C (matrix cores, stores).  In the plain schedule both wavefronts of a SIMD are always in the SAME phase and queue for the same
+    // unit -- the memory front end in front of the barrier, the matrix cores behind it -- and the phases' latencies have nobody to hide them.
+    // Costs a second barrier per tile.  The tile's rows 0..15 come from group A, rows 16..31 from group B; C(t) of either group runs only
+    // after both have delivered (two slots after P_A(t), one after P_B(t)).
+    constexpr bool SKEW = DGNN_SKEW && DSP == 2 && KS == 2 && C::NSLICE == 4 && NW == 8;
 
     const int lane = lane_id(), w = wave_id_uniform();
 #if DGNN_YOUNG_PRIO
@@ -401,166 +411,262 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
 #pragma unroll
     for (int r = 0; r < 8; ++r) mine[r] = 0.f;
 
-    for (int64_t it = 0; it <= my_n; ++it) {
-        if (it < my_n) {
-            // ================================================================ P: filter on the matrix cores + mean
-            const int64_t i0 = tile_of(it) * TILE + w * TPW;
-            stamp(trace, trace_cap, it, w, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // rows + LDS-DMA'd strip of this tile, index loads of the tiles behind it
-            // the index loads are consumed HERE (the compiler would otherwise place its own, conservative, waits at their later uses)
-            asm volatile("" : "+v"(vbeg2), "+v"(vbeg3), "+v"(vsrc2), "+v"(veid2));
-            const bool was_regular = regular;
-            advance_idx(it);
-            regular = ok1;  // tile it+1: its gathers are issued during this P
-            stamp(trace, trace_cap, it, w, 1);
-            if (was_regular) {
+    // ---- the three pieces of a tile
+    // P(it): filter product on the matrix cores, mean, the wave's rows of A-tile `it`; requests the gathers of tile it+1
+    auto phaseP = [&](int64_t it) {
+        // ================================================================ P: filter on the matrix cores + mean
+        const int64_t i0 = tile_of(it) * TILE + w * TPW;
+        stamp(trace, trace_cap, it, w, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // rows + LDS-DMA'd strip of this tile, index loads of the tiles behind it
+        // the index loads are consumed HERE (the compiler would otherwise place its own, conservative, waits at their later uses)
+        asm volatile("" : "+v"(vbeg2), "+v"(vbeg3), "+v"(vsrc2), "+v"(veid2));
+        const bool was_regular = regular;
+        advance_idx(it);
+        regular = ok1;  // tile it+1: its gathers are issued during this P
+        stamp(trace, trace_cap, it, w, 1);
+        if (was_regular) {
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb) {
-                    // A operand: lane (edge i = lane&15, k-group g = lane>>4) holds attributes 8g..8g+7 of its edge;
-                    // k = 20 is the constant 1 multiplying the bias row, everything beyond is 0
-                    const float* er = myea + (rb * 16 + jcol) * FE;
-                    const f32x4_t q0 = *reinterpret_cast<const f32x4_t*>(er + 8 * (tq < 2 ? tq : 2));
-                    const f32x4_t q1 = *reinterpret_cast<const f32x4_t*>(er + 8 * (tq < 1 ? tq : 1) + 4);
-                    float av[8];
+            for (int rb = 0; rb < RB; ++rb) {
+                // A operand: lane (edge i = lane&15, k-group g = lane>>4) holds attributes 8g..8g+7 of its edge;
+                // k = 20 is the constant 1 multiplying the bias row, everything beyond is 0
+                const float* er = myea + (rb * 16 + jcol) * FE;
+                const f32x4_t q0 = *reinterpret_cast<const f32x4_t*>(er + 8 * (tq < 2 ? tq : 2));
+                const f32x4_t q1 = *reinterpret_cast<const f32x4_t*>(er + 8 * (tq < 1 ? tq : 1) + 4);
+                float av[8];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        av[i] = tq < 3 ? q0[i] : 0.f;
-                        av[4 + i] = tq < 2 ? q1[i] : 0.f;
-                    }
-                    if (tq == 2) av[4] = 1.0f;
-                    if (EARLY && rb == RB - 1) {
-                        // the strip has been read for the last time: the next tile's attribute block may land in it
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        issue_ea(it + 1);
-                    }
-                    uint32_t ph[4], pm[4], pl[4];
-                    float fmean = 0.25f;  // 1/4 (regular group) times the inverse scales of the filter product
-                    if constexpr (FSP == 2) {
-                        // one scale for the 16-edge block (the constant 1 of the bias column is part of it)
-                        float mf = 0.f;
+                for (int i = 0; i < 4; ++i) {
+                    av[i] = tq < 3 ? q0[i] : 0.f;
+                    av[4 + i] = tq < 2 ? q1[i] : 0.f;
+                }
+                if (tq == 2) av[4] = 1.0f;
+                if (EARLY && rb == RB - 1) {
+                    // the strip has been read for the last time: the next tile's attribute block may land in it
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    issue_ea(it + 1);
+                }
+                uint32_t ph[4], pm[4], pl[4];
+                float fmean = 0.25f;  // 1/4 (regular group) times the inverse scales of the filter product
+                if constexpr (FSP == 2) {
+                    // one scale for the 16-edge block (the constant 1 of the bias column is part of it)
+                    float mf = 0.f;
 #pragma unroll
-                        for (int i = 0; i < 8; i += 2) mf = fmaxf(fmaxf(mf, fabsf(av[i])), fabsf(av[i + 1]));
-                        float sA, inv_sA;
-                        pow2_scales(wave_umax(__builtin_bit_cast(uint32_t, mf)), sA, inv_sA);
-                        fmean = 0.25f * inv_sA * inv_sWe;
+                    for (int i = 0; i < 8; i += 2) mf = fmaxf(fmaxf(mf, fabsf(av[i])), fabsf(av[i + 1]));
+                    float sA, inv_sA;
+                    pow2_scales(wave_umax(__builtin_bit_cast(uint32_t, mf)), sA, inv_sA);
+                    fmean = 0.25f * inv_sA * inv_sWe;
 #pragma unroll
-                        for (int d = 0; d < 4; ++d) split2h(av[2 * d] * sA, av[2 * d + 1] * sA, ph[d], pl[d]);
-                    } else {
+                    for (int d = 0; d < 4; ++d) split2h(av[2 * d] * sA, av[2 * d + 1] * sA, ph[d], pl[d]);
+                } else {
 #pragma unroll
-                        for (int d = 0; d < 4; ++d) split3(av[2 * d], av[2 * d + 1], ph[d], pm[d], pl[d]);
-                    }
-                    const bf16x8 ah = pack8(ph), am = pack8(FSP == 3 ? pm : ph), al = pack8(pl);
+                    for (int d = 0; d < 4; ++d) split3(av[2 * d], av[2 * d + 1], ph[d], pm[d], pl[d]);
+                }
+                const bf16x8 ah = pack8(ph), am = pack8(FSP == 3 ? pm : ph), al = pack8(pl);
 
-                    float aout[NB], xv[NB];
+                float aout[NB], xv[NB];
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb) {
+                    const char* bp = bpbuf + ((cb * FSP) * 48 + (tq < 3 ? tq : 0) * 16 + jcol) * 16;
+                    // k-group 3 re-reads group 0: its A operand is all zero, so any finite B will do (saves 12 selects)
+                    const uint4 u0 = *reinterpret_cast<const uint4*>(bp), u1 = *reinterpret_cast<const uint4*>(bp + 768),
+                                u2 = *reinterpret_cast<const uint4*>(bp + 768 * (FSP - 1));
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, u0), bm = __builtin_bit_cast(bf16x8, u1),
+                                 bl = __builtin_bit_cast(bf16x8, u2);
+                    f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (FSP == 2) {
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(H8(al), H8(bh), d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(H8(ah), H8(bl), d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(H8(ah), H8(bh), d, 0, 0, 0);
+                    } else {
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d, 0, 0, 0);
+                    }
+                    // d[r] = phi of edge 4*tq + r (the r-th in-edge of this lane's tet), channel c0 + cb
+                    // in-order sum over the tet's 4 in-edges.  Lanes past c_in need no masking: their filter
+                    // operand and their rows of Wj|Wi are zero, and what they loaded (channel 0..) is finite.
+                    float a = __fmul_rn(xr[rb][0][cb], d[0]);
+#pragma unroll
+                    for (int r = 1; r < 4; ++r) a = __fmaf_rn(xr[rb][r][cb], d[r], a);
+                    aout[cb] = a;
+                    xv[cb] = xd[rb][cb];
+                    // the registers of this row block are free again: request its rows of the next tile right here, between
+                    // the arithmetic (NB == 8: in two halves, the first as soon as channels 0..3 are through)
+                    if (EARLY && RB == 1 && NB == 8 && cb == 3) issue_x(it + 1, rb, IC<0>{});
+                }
+                if (EARLY) issue_x(it + 1, rb, IC<(RB == 1 && NB == 8) ? 1 : -1>{});
+                if constexpr (FSP == 2 && DGNN_FILTER_PIPE) {
+                    // instruction order of the channel-block loop: operand reads two blocks ahead of their products, the x.phi sums of a
+                    // block behind the next block's products (left alone, every read is waited for right where it is issued)
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
                     for (int cb = 0; cb < NB; ++cb) {
-                        const char* bp = bpbuf + ((cb * FSP) * 48 + (tq < 3 ? tq : 0) * 16 + jcol) * 16;
-                        // k-group 3 re-reads group 0: its A operand is all zero, so any finite B will do (saves 12 selects)
-                        const uint4 u0 = *reinterpret_cast<const uint4*>(bp), u1 = *reinterpret_cast<const uint4*>(bp + 768),
-                                    u2 = *reinterpret_cast<const uint4*>(bp + 768 * (FSP - 1));
-                        const bf16x8 bh = __builtin_bit_cast(bf16x8, u0), bm = __builtin_bit_cast(bf16x8, u1),
-                                     bl = __builtin_bit_cast(bf16x8, u2);
-                        f32x4_t d = {0.f, 0.f, 0.f, 0.f};
-                        if constexpr (FSP == 2) {
-                            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(H8(al), H8(bh), d, 0, 0, 0);
-                            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(H8(ah), H8(bl), d, 0, 0, 0);
-                            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(H8(ah), H8(bh), d, 0, 0, 0);
-                        } else {
-                            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d, 0, 0, 0);
-                            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d, 0, 0, 0);
-                            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, d, 0, 0, 0);
-                            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, d, 0, 0, 0);
-                            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, d, 0, 0, 0);
-                            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d, 0, 0, 0);
-                        }
-                        // d[r] = phi of edge 4*tq + r (the r-th in-edge of this lane's tet), channel c0 + cb
-                        // in-order sum over the tet's 4 in-edges.  Lanes past c_in need no masking: their filter
-                        // operand and their rows of Wj|Wi are zero, and what they loaded (channel 0..) is finite.
-                        float a = __fmul_rn(xr[rb][0][cb], d[0]);
-#pragma unroll
-                        for (int r = 1; r < 4; ++r) a = __fmaf_rn(xr[rb][r][cb], d[r], a);
-                        aout[cb] = a;
-                        xv[cb] = xd[rb][cb];
-                        // the registers of this row block are free again: request its rows of the next tile right here, between
-                        // the arithmetic (NB == 8: in two halves, the first as soon as channels 0..3 are through)
-                        if (EARLY && RB == 1 && NB == 8 && cb == 3) issue_x(it + 1, rb, IC<0>{});
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                        if (cb + 2 < NB) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        if (cb > 0) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                     }
-                    if (EARLY) issue_x(it + 1, rb, IC<(RB == 1 && NB == 8) ? 1 : -1>{});
-                    if constexpr (FSP == 2 && DGNN_FILTER_PIPE) {
-                        // instruction order of the channel-block loop: operand reads two blocks ahead of their products, the x.phi sums of a
-                        // block behind the next block's products (left alone, every read is waited for right where it is issued)
-                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
+                put_seg(it, w * TPW + rb * 4 + tq, aout, xv, fmean);
+            }
+        } else {
+            // generic path (a group with any in-degree other than 4, or past the end): plain fp32 per lane, one edge at a time (rare)
+#pragma unroll 1
+            for (int rb = 0; rb < RB; ++rb) {
+                const int64_t i = i0 + rb * 4 + tq;
+                float aout[NB], xv[NB];
 #pragma unroll
+                for (int cb = 0; cb < NB; ++cb) aout[cb] = xv[cb] = 0.f;
+                if (i < n_dst && on) {
+                    const int b = rowptr[i], e_end = rowptr[i + 1];
+#pragma unroll
+                    for (int cb = 0; cb < NB; ++cb) xv[cb] = xdst[i * ldx + c0 + cb];
+                    for (int k = b; k < e_end; ++k) {
+                        const int s_ = src[k];
+                        const float* ar = ea + (int64_t)(eid ? eid[k] : k) * lde;
+#pragma unroll 1
                         for (int cb = 0; cb < NB; ++cb) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                            if (cb + 2 < NB) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                            if (cb > 0) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                            float p = be[c0 + cb];
+                            for (int f = 0; f < FE; ++f) p = __fmaf_rn(We[(int64_t)(c0 + cb) * FE + f], ar[f], p);
+                            aout[cb] = __fadd_rn(aout[cb], __fmul_rn(x[(int64_t)s_ * ldx + c0 + cb], p));
                         }
-                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                     }
-                    put_seg(it, w * TPW + rb * 4 + tq, aout, xv, fmean);
+                    const float cnt = (float)max(e_end - b, 1);
+#pragma unroll
+                    for (int cb = 0; cb < NB; ++cb) aout[cb] = __fdiv_rn(aout[cb], cnt);
                 }
-            } else {
-                // generic path (a group with any in-degree other than 4, or past the end): plain fp32 per lane, one edge at a time (rare)
-#pragma unroll 1
-                for (int rb = 0; rb < RB; ++rb) {
-                    const int64_t i = i0 + rb * 4 + tq;
-                    float aout[NB], xv[NB];
-#pragma unroll
-                    for (int cb = 0; cb < NB; ++cb) aout[cb] = xv[cb] = 0.f;
-                    if (i < n_dst && on) {
-                        const int b = rowptr[i], e_end = rowptr[i + 1];
-#pragma unroll
-                        for (int cb = 0; cb < NB; ++cb) xv[cb] = xdst[i * ldx + c0 + cb];
-                        for (int k = b; k < e_end; ++k) {
-                            const int s_ = src[k];
-                            const float* ar = ea + (int64_t)(eid ? eid[k] : k) * lde;
-#pragma unroll 1
-                            for (int cb = 0; cb < NB; ++cb) {
-                                float p = be[c0 + cb];
-                                for (int f = 0; f < FE; ++f) p = __fmaf_rn(We[(int64_t)(c0 + cb) * FE + f], ar[f], p);
-                                aout[cb] = __fadd_rn(aout[cb], __fmul_rn(x[(int64_t)s_ * ldx + c0 + cb], p));
-                            }
-                        }
-                        const float cnt = (float)max(e_end - b, 1);
-#pragma unroll
-                        for (int cb = 0; cb < NB; ++cb) aout[cb] = __fdiv_rn(aout[cb], cnt);
-                    }
-                    put_seg(it, w * TPW + rb * 4 + tq, aout, xv, 1.f);
-                }
+                put_seg(it, w * TPW + rb * 4 + tq, aout, xv, 1.f);
             }
-            stamp(trace, trace_cap, it, w, 2);
-            if (!was_regular || !EARLY) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // strip reads returned before the next DMA may land
-                issue_loads(it + 1);
-            }
-            stamp(trace, trace_cap, it, w, 3);
         }
-        tile_barrier();  // A-tile `it` complete; partial sums of tile `it-1` complete
-        stamp(trace, trace_cap, it, w, 4);
-#if DGNN_PHASE_PRIO
-        // Arbitration between the two waves of a SIMD is oldest-first, so waves 0..3 win BOTH phases, reach the barrier
-        // early and leave their SIMD to a lone wave with nobody to hide its latencies.  Giving the younger four the
-        // dense phase and the older four (by age) the filter phase makes both reach the barrier together.
-        if (w >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
-
-        if (KS == 2 && it > 0) {
-            // ============================================================ delayed epilogue of tile it-1
-            const int64_t tile = tile_of(it - 1);
-            const float* red = redbuf + ((it - 1) & 1) * (C::RED_BYTES / 4) + partner * 512 + lane;
+        stamp(trace, trace_cap, it, w, 2);
+        if (!was_regular || !EARLY) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // strip reads returned before the next DMA may land
+            issue_loads(it + 1);
+        }
+        stamp(trace, trace_cap, it, w, 3);
+    };
+    // C(it): this wave's block of the dense product over its share of K
+    auto phaseC = [&](int64_t it, f32x16& acc) {
+        // ================================================================ C: dense part, split-bf16, K half
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const char* A = abuf + (it & 1) * C::A_BYTES + (rg * 32 + l31) * ROWB + (kh * (CIN_PAD / 8) + h) * OCT;
+#pragma unroll
+        for (int S = 0; S < NWB; ++S) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(A + S * 2 * OCT);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(A + S * 2 * OCT + 16 * (DSP - 1));
+            if constexpr (DSP == 2) {
+                // first product: C = inline constant 0 (no 16 register moves to clear the accumulator)
+                // (weights are the A operand: the accumulator holds the block transposed, see TR)
+                if (S == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(wb[S][0]), H8(al), f32x16{}, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(wb[S][0]), H8(al), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(wb[S][1]), H8(ah), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(wb[S][0]), H8(ah), acc, 0, 0, 0);
+            } else {
+                const bf16x8 am = *reinterpret_cast<const bf16x8*>(A + S * 2 * OCT + 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wb[S][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wb[S][DSP - 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wb[S][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wb[S][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wb[S][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wb[S][0], acc, 0, 0, 0);
+            }
+        }
+        if constexpr (DSP == 2 && DGNN_DENSE_PREFETCH > 0) {
+            // instruction order of the block above: the A fragments of DGNN_DENSE_PREFETCH k-steps are requested ahead of the products
+            // that use them (left alone, the scheduler requests each pair right in front of its use and every k-step pays an LDS round trip)
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * DGNN_DENSE_PREFETCH, 0);
+#pragma unroll
+            for (int S = 0; S < NWB; ++S) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                if (S + DGNN_DENSE_PREFETCH < NWB) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+        }
+    };
+    // K split between wave pairs: the sums of tile `ie` are finished from this wave's half (`mine`) and the partner's (LDS)
+    auto epilogueK2 = [&](int64_t ie) {
+        // ============================================================ delayed epilogue of tile it-1
+        const int64_t tile = tile_of(ie);
+        const float* red = redbuf + (ie & 1) * (C::RED_BYTES / 4) + partner * 512 + lane;
+        if constexpr (TR) {
+            // this wave finishes columns cs*32 + 16*kh + 4h + 8g + c (g < 2, c < 4) of tet row rg*32 + l31
+            const int row = rg * 32 + l31, cbase = cs * 32 + 16 * kh + 4 * h;
+            const int64_t grow = tile * TILE + row;
+            const float rf = rowf[(int)(ie & 3) * TILE + row];
+            float* o = out + grow * ldo + cbase;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(colp + cbase + 8 * g);
+                f32x4_t v;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = __fmaf_rn(mine[4 * g + c] + red[(4 * g + c) * 64], rf, b4[c]);
+                if (has_scale) {
+                    const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(colp + COUT + cbase + 8 * g);
+                    const f32x4_t h4 = *reinterpret_cast<const f32x4_t*>(colp + 2 * COUT + cbase + 8 * g);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = __fmaf_rn(v[c], s4[c], h4[c]);
+                }
+                if (relu) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+                }
+                if (grow < n_dst) *reinterpret_cast<f32x4_t*>(o + 8 * g) = v;
+            }
+        } else {
+        const int64_t row0 = tile * TILE + rg * 32 + 4 * h + 16 * kh;
+        float* o = out + row0 * ldo + col;
+        float v[8], rf[8];
+        if constexpr (DSP == 2) {
+            const float* rfp = rowf + (int)(ie & 3) * TILE + rg * 32 + 4 * h + 16 * kh;
+            const f32x4_t r0 = *reinterpret_cast<const f32x4_t*>(rfp), r1 = *reinterpret_cast<const f32x4_t*>(rfp + 8);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { rf[r] = r0[r]; rf[4 + r] = r1[r]; }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if constexpr (DSP == 2) v[r] = __fmaf_rn(mine[r] + red[r * 64], rf[r], bb);
+            else v[r] = (mine[r] + red[r * 64]) + bb;
+            if (has_scale) v[r] = __fmaf_rn(v[r], sc, sh);
+            if (relu) v[r] = fmaxf(v[r], 0.f);
+        }
+        if ((tile + 1) * TILE <= n_dst) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) o[(int64_t)((r & 3) + 8 * (r >> 2)) * ldo] = v[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                if (row0 + rr < n_dst) o[(int64_t)rr * ldo] = v[r];
+            }
+        }
+        }
+    };
+    // what follows the products of tile `it`: hand the partner its half (K split) or finish the block right away (full K)
+    auto finishC = [&](int64_t it, f32x16& acc) {
+        if constexpr (KS == 2) {
+            float* red = redbuf + (it & 1) * (C::RED_BYTES / 4) + w * 512 + lane;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                mine[r] = kh ? acc[8 + r] : acc[r];
+                red[r * 64] = kh ? acc[r] : acc[8 + r];
+            }
+        } else {
+            // full K in this wave: finish the 32 x 32 block right away (row (r&3) + 8(r>>2) + 4h, column `col`)
+            const int64_t tile = tile_of(it);
             if constexpr (TR) {
-                // this wave finishes columns cs*32 + 16*kh + 4h + 8g + c (g < 2, c < 4) of tet row rg*32 + l31
-                const int row = rg * 32 + l31, cbase = cs * 32 + 16 * kh + 4 * h;
+                // transposed block: columns cs*32 + 4h + 8g + c (g < 4, c < 4) of tet row rg*32 + l31
+                const int row = rg * 32 + l31, cbase = cs * 32 + 4 * h;
                 const int64_t grow = tile * TILE + row;
-                const float rf = rowf[(int)((it - 1) & 3) * TILE + row];
+                const float rf = rowf[(int)(it & 3) * TILE + row];
                 float* o = out + grow * ldo + cbase;
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
+                for (int g = 0; g < 4; ++g) {
                     const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(colp + cbase + 8 * g);
                     f32x4_t v;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = __fmaf_rn(mine[4 * g + c] + red[(4 * g + c) * 64], rf, b4[c]);
+                    for (int c = 0; c < 4; ++c) v[c] = __fmaf_rn(acc[4 * g + c], rf, b4[c]);
                     if (has_scale) {
                         const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(colp + COUT + cbase + 8 * g);
                         const f32x4_t h4 = *reinterpret_cast<const f32x4_t*>(colp + 2 * COUT + cbase + 8 * g);
@@ -574,135 +680,85 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                     if (grow < n_dst) *reinterpret_cast<f32x4_t*>(o + 8 * g) = v;
                 }
             } else {
-            const int64_t row0 = tile * TILE + rg * 32 + 4 * h + 16 * kh;
+            const int64_t row0 = tile * TILE + rg * 32 + 4 * h;
             float* o = out + row0 * ldo + col;
-            float v[8], rf[8];
+            const bool full = (tile + 1) * TILE <= n_dst;
+            float rf[16];
             if constexpr (DSP == 2) {
-                const float* rfp = rowf + (int)((it - 1) & 3) * TILE + rg * 32 + 4 * h + 16 * kh;
-                const f32x4_t r0 = *reinterpret_cast<const f32x4_t*>(rfp), r1 = *reinterpret_cast<const f32x4_t*>(rfp + 8);
+                const float* rfp = rowf + (int)(it & 3) * TILE + rg * 32 + 4 * h;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { rf[r] = r0[r]; rf[4 + r] = r1[r]; }
-            }
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4_t t = *reinterpret_cast<const f32x4_t*>(rfp + 8 * q);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                if constexpr (DSP == 2) v[r] = __fmaf_rn(mine[r] + red[r * 64], rf[r], bb);
-                else v[r] = (mine[r] + red[r * 64]) + bb;
-                if (has_scale) v[r] = __fmaf_rn(v[r], sc, sh);
-                if (relu) v[r] = fmaxf(v[r], 0.f);
-            }
-            if ((tile + 1) * TILE <= n_dst) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) o[(int64_t)((r & 3) + 8 * (r >> 2)) * ldo] = v[r];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const int rr = (r & 3) + 8 * (r >> 2);
-                    if (row0 + rr < n_dst) o[(int64_t)rr * ldo] = v[r];
+                    for (int r = 0; r < 4; ++r) rf[4 * q + r] = t[r];
                 }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = DSP == 2 ? __fmaf_rn(acc[r], rf[r], bb) : acc[r] + bb;
+                if (has_scale) v = __fmaf_rn(v, sc, sh);
+                if (relu) v = fmaxf(v, 0.f);
+                const int rr = (r & 3) + 8 * (r >> 2);
+                if (full || row0 + rr < n_dst) o[(int64_t)rr * ldo] = v;
             }
             }
         }
+    };
+
+    if constexpr (SKEW) {
+        // Skewed schedule (see SKEW above).  Slot 2t+1: group A runs P(t+1), group B runs C(t) and finishes tile t-1;
+        // slot 2t+2: group A runs C(t) and finishes tile t, group B runs P(t+1).  One barrier per slot.
+        const bool grpA = kh == 0;
+        if (my_n > 0) phaseP(0);
+        tile_barrier();
+        for (int64_t slot = 1; slot <= 2 * my_n + 1; ++slot) {
+            const int64_t t = (slot - 1) >> 1;
+            const bool doP = ((slot & 1) != 0) == grpA;
+            if (doP) {
+                if (t + 1 < my_n) phaseP(t + 1);
+            } else {
+                const bool hasC = t < my_n;
+                f32x16 acc;
+                stamp(trace, trace_cap, t, w, 4);
+                if (hasC) {
+                    phaseC(t, acc);
+                    stamp(trace, trace_cap, t, w, 6);
+                    float* red = redbuf + (t & 1) * (C::RED_BYTES / 4) + w * 512 + lane;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) red[r * 64] = kh ? acc[r] : acc[8 + r];
+                }
+                if (grpA) {
+                    // the partner's half of tile t was written in the previous slot
+                    if (hasC) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) mine[r] = acc[r];
+                        epilogueK2(t);
+                    }
+                } else {
+                    if (t >= 1) epilogueK2(t - 1);
+                    if (hasC) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) mine[r] = acc[8 + r];
+                    }
+                }
+                stamp(trace, trace_cap, t, w, 5);
+            }
+            tile_barrier();
+        }
+    } else {
+    for (int64_t it = 0; it <= my_n; ++it) {
+        if (it < my_n) phaseP(it);
+        tile_barrier();  // A-tile `it` complete; partial sums of tile `it-1` complete
+        stamp(trace, trace_cap, it, w, 4);
+        if (KS == 2 && it > 0) epilogueK2(it - 1);  // delayed epilogue of tile it-1
         stamp(trace, trace_cap, it, w, 6);
         if (it < my_n) {
-            // ================================================================ C: dense part, split-bf16, K half
             f32x16 acc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-            const char* A = abuf + (it & 1) * C::A_BYTES + (rg * 32 + l31) * ROWB + (kh * (CIN_PAD / 8) + h) * OCT;
-#pragma unroll
-            for (int S = 0; S < NWB; ++S) {
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(A + S * 2 * OCT);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(A + S * 2 * OCT + 16 * (DSP - 1));
-                if constexpr (DSP == 2) {
-                    // first product: C = inline constant 0 (no 16 register moves to clear the accumulator)
-                    // (weights are the A operand: the accumulator holds the block transposed, see TR)
-                    if (S == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(wb[S][0]), H8(al), f32x16{}, 0, 0, 0);
-                    else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(wb[S][0]), H8(al), acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(wb[S][1]), H8(ah), acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(wb[S][0]), H8(ah), acc, 0, 0, 0);
-                } else {
-                    const bf16x8 am = *reinterpret_cast<const bf16x8*>(A + S * 2 * OCT + 16);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wb[S][0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wb[S][DSP - 1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wb[S][1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wb[S][0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wb[S][1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wb[S][0], acc, 0, 0, 0);
-                }
-            }
-            if constexpr (DSP == 2 && DGNN_DENSE_PREFETCH > 0) {
-                // instruction order of the block above: the A fragments of DGNN_DENSE_PREFETCH k-steps are requested ahead of the products
-                // that use them (left alone, the scheduler requests each pair right in front of its use and every k-step pays an LDS round trip)
-                __builtin_amdgcn_sched_group_barrier(0x100, 2 * DGNN_DENSE_PREFETCH, 0);
-#pragma unroll
-                for (int S = 0; S < NWB; ++S) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                    if (S + DGNN_DENSE_PREFETCH < NWB) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                }
-            }
-            if constexpr (KS == 2) {
-                float* red = redbuf + (it & 1) * (C::RED_BYTES / 4) + w * 512 + lane;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    mine[r] = kh ? acc[8 + r] : acc[r];
-                    red[r * 64] = kh ? acc[r] : acc[8 + r];
-                }
-            } else {
-                // full K in this wave: finish the 32 x 32 block right away (row (r&3) + 8(r>>2) + 4h, column `col`)
-                const int64_t tile = tile_of(it);
-                if constexpr (TR) {
-                    // transposed block: columns cs*32 + 4h + 8g + c (g < 4, c < 4) of tet row rg*32 + l31
-                    const int row = rg * 32 + l31, cbase = cs * 32 + 4 * h;
-                    const int64_t grow = tile * TILE + row;
-                    const float rf = rowf[(int)(it & 3) * TILE + row];
-                    float* o = out + grow * ldo + cbase;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(colp + cbase + 8 * g);
-                        f32x4_t v;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) v[c] = __fmaf_rn(acc[4 * g + c], rf, b4[c]);
-                        if (has_scale) {
-                            const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(colp + COUT + cbase + 8 * g);
-                            const f32x4_t h4 = *reinterpret_cast<const f32x4_t*>(colp + 2 * COUT + cbase + 8 * g);
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) v[c] = __fmaf_rn(v[c], s4[c], h4[c]);
-                        }
-                        if (relu) {
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
-                        }
-                        if (grow < n_dst) *reinterpret_cast<f32x4_t*>(o + 8 * g) = v;
-                    }
-                } else {
-                const int64_t row0 = tile * TILE + rg * 32 + 4 * h;
-                float* o = out + row0 * ldo + col;
-                const bool full = (tile + 1) * TILE <= n_dst;
-                float rf[16];
-                if constexpr (DSP == 2) {
-                    const float* rfp = rowf + (int)(it & 3) * TILE + rg * 32 + 4 * h;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4_t t = *reinterpret_cast<const f32x4_t*>(rfp + 8 * q);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) rf[4 * q + r] = t[r];
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = DSP == 2 ? __fmaf_rn(acc[r], rf[r], bb) : acc[r] + bb;
-                    if (has_scale) v = __fmaf_rn(v, sc, sh);
-                    if (relu) v = fmaxf(v, 0.f);
-                    const int rr = (r & 3) + 8 * (r >> 2);
-                    if (full || row0 + rr < n_dst) o[(int64_t)rr * ldo] = v;
-                }
-                }
-            }
+            phaseC(it, acc);
+            finishC(it, acc);
             stamp(trace, trace_cap, it, w, 5);
         }
-#if DGNN_PHASE_PRIO
-        if (w >= 4) __builtin_amdgcn_s_setprio(0);
-#endif
+    }
     }
 }
 

@@ -335,7 +335,7 @@ GEMM_MODE_NAMES = {"f32": GEMM_F32, "bf16x3": GEMM_BF16X3, "bf16x3f": GEMM_BF16X
 # dense part ("bf16x3"), or split-bf16 MFMA for the dense part AND the filter MLP ("bf16x3f"); all fp32-class accuracy
 # "f16x2d" / "f16x2": the dense product (and the filter MLP) on fp16 x 2 with power-of-two group scales (22 significand bits, 3 products:
 # the 3xTF32 scheme) -- half the matrix work of the bf16 x 3 forms; GEMM entry points outside the fused layer keep bf16 x 3
-GEMM_MODE = GEMM_MODE_NAMES[__import__("os").environ.get("DGNN_GEMM_MODE", "bf16x3f")]
+GEMM_MODE = GEMM_MODE_NAMES[__import__("os").environ.get("DGNN_GEMM_MODE", "f16x2")]
 # whole-graph inference: fused layers read the caller's edge_attr in place (rows DMA-gathered by the plan's eid) instead of
 # staging a plan-ordered copy once per scene; DGNN_EDGE_STAGING=1 restores the staged copy
 EDGE_GATHER_IN_KERNEL = __import__("os").environ.get("DGNN_EDGE_STAGING", "0") != "1"
