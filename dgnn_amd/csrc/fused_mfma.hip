@@ -30,13 +30,23 @@
 #define DGNN_EARLY_ISSUE 0  // measured: the tile period does not move (5.03 -> 5.19 us): the issue phase is address arithmetic and index shuffles, not memory stalls, and it costs ~100 register moves
 #endif
 #ifndef DGNN_DENSE_PREFETCH
-#define DGNN_DENSE_PREFETCH 2
+#define DGNN_DENSE_PREFETCH 0  // measured: no gain (0.527 vs 0.521 ms): the second wavefront of the SIMD already covers the LDS round trips
 #endif
 #ifndef DGNN_FILTER_PIPE
-#define DGNN_FILTER_PIPE 1
+#define DGNN_FILTER_PIPE 0  // measured: no gain (0.531 vs 0.527 ms at 128 -> 128)
 #endif
 #ifndef DGNN_SKEW
 #define DGNN_SKEW 0  // measured: 0.52 -> 0.84 ms at 128 -> 128.  A lone filter-phase wavefront per SIMD takes as long as two interleaved ones (1.14 us: the phase is a chain of LDS -> matrix core -> vector ALU dependencies, latency-bound per wavefront), so a slot lasts a whole P and the tile two of them
+#endif
+#ifndef DGNN_FILTER_BREG
+#define DGNN_FILTER_BREG 0  // measured: slower on both small layers (0.24 -> 0.25, 0.36 -> 0.38 ms; 16 / 32 more live registers, spills at 64 -> 128)
+#endif
+#ifndef DGNN_SMALL_OCC
+#define DGNN_SMALL_OCC 2
+#endif
+#ifndef DGNN_TR
+#define DGNN_TR 0  // measured (tools/variants.py, same box): 16-byte stores of 32-byte row pieces cost the small layers 7 % (0.229 -> 0.247, 0.360 -> 0.380 ms: each store
+                   // instruction touches 32 cache lines instead of 2) and leave 128 -> 128 where it was
 #endif
 #ifndef DGNN_PHASE_PRIO
 #define DGNN_PHASE_PRIO 0  // measured: balances the barrier waits (0.6/0.4 us instead of 1.4/0.2) but the tile period does not move
@@ -81,7 +91,7 @@ struct Cfg2 {
     static constexpr int ROWF_BYTES = DSP == 2 ? 4 * TILE * 4 : 0;  // per-row inverse scales, 4 tiles deep (written in P(it), read up to the
                                                                     // delayed epilogue after barrier it+1 while P(it+2) may already write)
     static constexpr int SC_BYTES = 16;                   // launch-wide weight maxima (prologue)
-    static constexpr int COLP_BYTES = DSP == 2 ? 3 * COUT * 4 : 0;  // [bias | scale | shift][COUT]: the transposed epilogue's lanes own 8 / 16 columns
+    static constexpr int COLP_BYTES = (DSP == 2 && DGNN_TR) ? 3 * COUT * 4 : 0;  // [bias | scale | shift][COUT]: the transposed epilogue's lanes own 8 / 16 columns
     static constexpr int SMEM_BYTES = 2 * A_BYTES + NW * EA_BYTES + 2 * RED_BYTES + BP_BYTES + ROWF_BYTES + SC_BYTES + COLP_BYTES;
     static constexpr int NWB = K / 16 / KS;               // dense part: k-steps of 16 per wave
     static_assert(EA_BYTES % 256 == 0, "attribute block must be DMA-able");
@@ -113,8 +123,13 @@ __device__ __forceinline__ void ld_vec(float (&v)[NB], const float* p, bool vec)
     }
 }
 
+// wavefronts per SIMD the register allocation aims at: 2 (eight-wave workgroup, or two four-wave ones per CU); DGNN_SMALL_OCC = 3 asks for three
+// four-wave workgroups per CU where their LDS allows it (<= 53 KB each)
 template <int CIN_PAD, int COUT, int NW, int KS, int DSP, int FSP>
-__global__ void __launch_bounds__(64 * NW, 2)
+constexpr int occ_of() { return (NW == 4 && Cfg2<CIN_PAD, COUT, NW, KS, DSP, FSP>::SMEM_BYTES <= 53 * 1024) ? DGNN_SMALL_OCC : 2; }
+
+template <int CIN_PAD, int COUT, int NW, int KS, int DSP, int FSP>
+__global__ void __launch_bounds__(64 * NW, (occ_of<CIN_PAD, COUT, NW, KS, DSP, FSP>()))
 k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid, int64_t n_dst,
                   const float* __restrict__ x, const float* __restrict__ xdst, int64_t ldx, int c_in, const float* __restrict__ ea, int64_t lde,
                   const float* __restrict__ We, const float* __restrict__ be, const float* __restrict__ Wj,
@@ -137,7 +152,7 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     // DSP == 2: the dense product is taken transposed (weights as the A operand, tet rows as the B operand -- the per-lane fragments are the
     // same either way), so a lane ends up with ONE tet row and 4-column runs of it: the result leaves as 16-byte stores (2 or 4 per lane and
     // tile instead of 8 or 16 dword stores whose addresses each cost 64-bit arithmetic), the row's inverse scale is one LDS word per lane.
-    constexpr bool TR = DSP == 2;
+    constexpr bool TR = DSP == 2 && DGNN_TR;
     // Skewed schedule (128 -> 128, fp16 dense form): the eight waves are two groups, A = the K-half-0 waves 0..3 and B = the K-half-1 waves
     // 4..7, one of each per SIMD, and at any time one group is in its filter phase P (vector ALU, LDS, gathers) while the other is in its dense
     // phase C (matrix cores, stores).  In the plain schedule both wavefronts of a SIMD are always in the SAME phase and queue for the same
@@ -251,6 +266,19 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     const float sh = scale ? shift[col] : 0.f;
     const bool has_scale = scale != nullptr;
     __syncthreads();  // filter operand parts visible
+
+    // ---- filter operand parts of this lane kept in registers where they fit (NB <= 4: 8 registers per channel block): no LDS reads
+    // inside the channel-block loop
+    constexpr bool BREG = DGNN_FILTER_BREG && FSP == 2 && NB <= 4;
+    uint4 breg[BREG ? NB : 1][2];
+    if constexpr (BREG) {
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            const char* bp = bpbuf + ((cb * FSP) * 48 + (tq < 3 ? tq : 0) * 16 + jcol) * 16;
+            breg[cb][0] = *reinterpret_cast<const uint4*>(bp);
+            breg[cb][1] = *reinterpret_cast<const uint4*>(bp + 768);
+        }
+    }
 
     // ---- filter-phase role
     const int c0 = NB * jcol;            // this lane's NB contiguous channels
@@ -467,8 +495,14 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                 for (int cb = 0; cb < NB; ++cb) {
                     const char* bp = bpbuf + ((cb * FSP) * 48 + (tq < 3 ? tq : 0) * 16 + jcol) * 16;
                     // k-group 3 re-reads group 0: its A operand is all zero, so any finite B will do (saves 12 selects)
-                    const uint4 u0 = *reinterpret_cast<const uint4*>(bp), u1 = *reinterpret_cast<const uint4*>(bp + 768),
-                                u2 = *reinterpret_cast<const uint4*>(bp + 768 * (FSP - 1));
+                    uint4 u0, u1, u2;
+                    if constexpr (BREG) {
+                        u0 = breg[cb][0];
+                        u1 = u2 = breg[cb][1];
+                    } else {
+                        u0 = *reinterpret_cast<const uint4*>(bp), u1 = *reinterpret_cast<const uint4*>(bp + 768),
+                        u2 = *reinterpret_cast<const uint4*>(bp + 768 * (FSP - 1));
+                    }
                     const bf16x8 bh = __builtin_bit_cast(bf16x8, u0), bm = __builtin_bit_cast(bf16x8, u1),
                                  bl = __builtin_bit_cast(bf16x8, u2);
                     f32x4_t d = {0.f, 0.f, 0.f, 0.f};
@@ -559,11 +593,17 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
             const bf16x8 al = *reinterpret_cast<const bf16x8*>(A + S * 2 * OCT + 16 * (DSP - 1));
             if constexpr (DSP == 2) {
                 // first product: C = inline constant 0 (no 16 register moves to clear the accumulator)
-                // (weights are the A operand: the accumulator holds the block transposed, see TR)
-                if (S == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(wb[S][0]), H8(al), f32x16{}, 0, 0, 0);
-                else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(wb[S][0]), H8(al), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(wb[S][1]), H8(ah), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(wb[S][0]), H8(ah), acc, 0, 0, 0);
+                if constexpr (TR) {  // weights as the A operand: the accumulator holds the block transposed
+                    if (S == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(wb[S][0]), H8(al), f32x16{}, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(wb[S][0]), H8(al), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(wb[S][1]), H8(ah), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(wb[S][0]), H8(ah), acc, 0, 0, 0);
+                } else {
+                    if (S == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(al), H8(wb[S][0]), f32x16{}, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(al), H8(wb[S][0]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(ah), H8(wb[S][1]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(ah), H8(wb[S][0]), acc, 0, 0, 0);
+                }
             } else {
                 const bf16x8 am = *reinterpret_cast<const bf16x8*>(A + S * 2 * OCT + 16);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wb[S][0], acc, 0, 0, 0);
@@ -774,7 +814,7 @@ int launch2(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64
     const size_t smem = C::SMEM_BYTES;
     static bool attr_set[DGNN_MAX_DEVICES] = {};
     dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_mfma<CIN_PAD, COUT, NW, KS, DSP, FSP>), smem, attr_set);
-    const int wg_max = DGNN_NUM_CU * (NW == 8 ? 1 : 2);
+    const int wg_max = DGNN_NUM_CU * (NW == 8 ? 1 : occ_of<CIN_PAD, COUT, NW, KS, DSP, FSP>());
     int grid = (int)(ntiles < wg_max ? ntiles : wg_max);
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL((k_sage_fused_mfma<CIN_PAD, COUT, NW, KS, DSP, FSP>), dim3(grid), dim3(64 * NW), smem, stream, rowptr, src, eid, n_dst, x, xdst,
