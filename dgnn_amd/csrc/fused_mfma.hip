@@ -48,6 +48,15 @@
 #define DGNN_TR 0  // measured (tools/variants.py, same box): 16-byte stores of 32-byte row pieces cost the small layers 7 % (0.229 -> 0.247, 0.360 -> 0.380 ms: each store
                    // instruction touches 32 cache lines instead of 2) and leave 128 -> 128 where it was
 #endif
+// What-if builds (tools/build_variant.sh <name> -DDGNN_WHATIF=<bits>): one ingredient removed, results garbage, only the time matters.
+//   1 no dense-phase products, 2 no filter products, 4 no output stores (K-split kernels), 8 neighbour rows = own row (no gathers),
+//   16 no attribute DMA.  Reading them needs care: removing the DMA made every layer 17-27 % faster, yet neither requesting it a whole
+//   phase earlier (double-buffered strips) nor replacing it by coalesced reads of a pre-split operand cache written by the first layer
+//   moved the time at all -- with the DMA gone the filter operand no longer changes from tile to tile, and this part clocks visibly
+//   higher on quieter operands.
+#ifndef DGNN_WHATIF
+#define DGNN_WHATIF 0
+#endif
 #ifndef DGNN_PHASE_PRIO
 #define DGNN_PHASE_PRIO 0  // measured: balances the barrier waits (0.6/0.4 us instead of 1.4/0.2) but the tile period does not move
 #endif
@@ -329,12 +338,12 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         ld_vec<NB, part>(xd[rb], xdst + (uint32_t)((i0 + (tl < nv1 ? tl : nv1 - 1)) * ldx32) + c0l, vec);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (part != 1) sidx[rb][r] = __shfl(vsrc1, tl * 4 + r);
+            if (part != 1) sidx[rb][r] = (DGNN_WHATIF & 8) ? i0 + (tl < nv1 ? tl : nv1 - 1) : __shfl(vsrc1, tl * 4 + r);
             ld_vec<NB, part>(xr[rb][r], x + (uint32_t)(sidx[rb][r] * ldx32) + c0l, vec);
         }
     };
     auto issue_ea = [&](int64_t it) {
-        if (!regular) return;
+        if (!regular || (DGNN_WHATIF & 16)) return;
         // eid == nullptr: the rows are in plan order, one contiguous block.  Otherwise every 80-byte row is
         // fetched from its place in the caller's edge_attr (row eid[k]) -- no staging copy of the edge features.
         if (eid) {
@@ -506,7 +515,12 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                     const bf16x8 bh = __builtin_bit_cast(bf16x8, u0), bm = __builtin_bit_cast(bf16x8, u1),
                                  bl = __builtin_bit_cast(bf16x8, u2);
                     f32x4_t d = {0.f, 0.f, 0.f, 0.f};
-                    if constexpr (FSP == 2) {
+                    if (DGNN_WHATIF & 2) {
+                        d[0] = __builtin_bit_cast(float, u0.x) + __builtin_bit_cast(float, ph[0]);
+                        d[1] = __builtin_bit_cast(float, u2.y);
+                        d[2] = __builtin_bit_cast(float, u0.z);
+                        d[3] = __builtin_bit_cast(float, pl[1]);
+                    } else if constexpr (FSP == 2) {
                         d = __builtin_amdgcn_mfma_f32_16x16x32_f16(H8(al), H8(bh), d, 0, 0, 0);
                         d = __builtin_amdgcn_mfma_f32_16x16x32_f16(H8(ah), H8(bl), d, 0, 0, 0);
                         d = __builtin_amdgcn_mfma_f32_16x16x32_f16(H8(ah), H8(bh), d, 0, 0, 0);
@@ -588,7 +602,7 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
         const char* A = abuf + (it & 1) * C::A_BYTES + (rg * 32 + l31) * ROWB + (kh * (CIN_PAD / 8) + h) * OCT;
 #pragma unroll
-        for (int S = 0; S < NWB; ++S) {
+        for (int S = 0; S < ((DGNN_WHATIF & 1) ? 1 : NWB); ++S) {
             const bf16x8 ah = *reinterpret_cast<const bf16x8*>(A + S * 2 * OCT);
             const bf16x8 al = *reinterpret_cast<const bf16x8*>(A + S * 2 * OCT + 16 * (DSP - 1));
             if constexpr (DSP == 2) {
@@ -671,7 +685,12 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
             if (has_scale) v[r] = __fmaf_rn(v[r], sc, sh);
             if (relu) v[r] = fmaxf(v[r], 0.f);
         }
-        if ((tile + 1) * TILE <= n_dst) {
+        if (DGNN_WHATIF & 4) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t += v[r];
+            if (t == 123.456f) o[0] = t;
+        } else if ((tile + 1) * TILE <= n_dst) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) o[(int64_t)((r & 3) + 8 * (r >> 2)) * ldo] = v[r];
         } else {
