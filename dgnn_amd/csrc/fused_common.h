@@ -83,7 +83,7 @@ __device__ __forceinline__ bf16x8 pack8(const uint32_t (&d)[4]) {
 // Three products hi.hi + hi.lo + lo.hi on v_mfma_f32_*_f16 with fp32 accumulation drop only lo.lo (<= 2^-22 relative) -- the
 // "3xTF32" scheme (TF32 and fp16 both carry 11 significant bits) at half the matrix work and a third of the split instructions of
 // the bf16 x 3 form.  fp16 has 5 exponent bits, so every operand is first multiplied by a power of two s (exact) that puts the
-// largest magnitude of its scaling group into [2^14, 2^15): elements down to 2^-15 of that maximum keep all 22 bits AND split
+// largest magnitude of its scaling group (one row of an operand, or one weight matrix) into [2^14, 2^15): elements down to 2^-15 of that maximum keep all 22 bits AND split
 // identically under any other s with the same property; smaller ones are quantised to 2^-24 (fp16 subnormals, honoured by the
 // MFMA: tools/ubench_f16_denorm.hip), i.e. to <= 2^-39 of the group maximum.  The inverse powers of two are applied to the fp32
 // accumulator (exact).
@@ -124,6 +124,14 @@ __device__ __forceinline__ uint32_t wave_umax(uint32_t m) {
     const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)m, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)m, 16),
                    c = (uint32_t)__builtin_amdgcn_readlane((int)m, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)m, 48);
     return umax(umax(a, b), umax(c, d));
+}
+// maximum over the four lanes l, l^16, l^32, l^48 (the k-groups of one row of a 16x16x32 A operand), left in all four:
+// v_permlane16_swap / v_permlane32_swap exchange whole 16- / 32-lane rows between two registers without going through LDS
+__device__ __forceinline__ uint32_t cross_row_umax(uint32_t m) {
+    const auto r = __builtin_amdgcn_permlane16_swap(m, m, false, false);
+    m = umax(r[0], r[1]);
+    const auto q = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+    return umax(q[0], q[1]);
 }
 __device__ __forceinline__ f16x8 pack8h(const uint32_t (&d)[4]) {
     return __builtin_bit_cast(f16x8, f32x4{__builtin_bit_cast(float, d[0]), __builtin_bit_cast(float, d[1]),

@@ -482,17 +482,22 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                     issue_ea(it + 1);
                 }
                 uint32_t ph[4], pm[4], pl[4];
-                float fmean = 0.25f;  // 1/4 (regular group) times the inverse scales of the filter product
+                float fmean = 0.25f;  // 1/4 (regular group) times the inverse scale of the filter weights
+                float inv_e[4];       // FSP == 2: inverse scales of the 4 in-edges of this lane's tet
                 if constexpr (FSP == 2) {
-                    // one scale for the 16-edge block (the constant 1 of the bias column is part of it)
+                    // one scale per EDGE (a row of the A operand; the constant 1 of the bias column is part of it): an edge's phi is as accurate
+                    // as its own attributes allow whatever the other 15 edges of the block look like.  The row's 4 k-group lanes are 16 apart.
                     float mf = 0.f;
 #pragma unroll
                     for (int i = 0; i < 8; i += 2) mf = fmaxf(fmaxf(mf, fabsf(av[i])), fabsf(av[i + 1]));
                     float sA, inv_sA;
-                    pow2_scales(wave_umax(__builtin_bit_cast(uint32_t, mf)), sA, inv_sA);
-                    fmean = 0.25f * inv_sA * inv_sWe;
+                    pow2_scales(cross_row_umax(__builtin_bit_cast(uint32_t, mf)), sA, inv_sA);
+                    fmean = 0.25f * inv_sWe;
 #pragma unroll
                     for (int d = 0; d < 4; ++d) split2h(av[2 * d] * sA, av[2 * d + 1] * sA, ph[d], pl[d]);
+                    // lane (tet tq, channel group): edge 4 tq + r is row 4 tq + r of the operand, whose scale lanes 4 tq + r (+16, +32, +48) hold
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) inv_e[r] = __shfl(inv_sA, 4 * tq + r);
                 } else {
 #pragma unroll
                     for (int d = 0; d < 4; ++d) split3(av[2 * d], av[2 * d + 1], ph[d], pm[d], pl[d]);
@@ -535,6 +540,10 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                     // d[r] = phi of edge 4*tq + r (the r-th in-edge of this lane's tet), channel c0 + cb
                     // in-order sum over the tet's 4 in-edges.  Lanes past c_in need no masking: their filter
                     // operand and their rows of Wj|Wi are zero, and what they loaded (channel 0..) is finite.
+                    if constexpr (FSP == 2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) d[r] *= inv_e[r];  // exact: powers of two
+                    }
                     float a = __fmul_rn(xr[rb][0][cb], d[0]);
 #pragma unroll
                     for (int r = 1; r < 4; ++r) a = __fmaf_rn(xr[rb][r][cb], d[r], a);

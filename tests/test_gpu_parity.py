@@ -761,3 +761,78 @@ def test_bn_fold_cache_follows_parameter_updates():
     net.load_state_dict(kf96_state_dict())
     c = net.inference_layer(data)
     assert torch.equal(a, c)
+
+
+def _fused_case(n_pts, c_in, c_out, seed):
+    from dgnn_amd.graph import GraphPlan
+    from dgnn_amd.synthetic import delaunay_tet_graph
+    adj, _, _ = delaunay_tet_graph(n_pts, seed=seed)
+    n = adj.shape[0] // 4
+    ei = torch.from_numpy(adj.T.astype(np.int64))
+    g = torch.Generator().manual_seed(seed)
+    t = dict(x=torch.randn(n, c_in, generator=g), ea=torch.randn(4 * n, 20, generator=g), We=torch.randn(c_in, 20, generator=g) * 0.3,
+             be=torch.randn(c_in, generator=g), Wj=torch.randn(c_out, c_in, generator=g) * 0.2, Wi=torch.randn(c_out, c_in, generator=g) * 0.2,
+             bj=torch.randn(c_out, generator=g))
+    return n, ei, GraphPlan(ei.to(DEV), n, n), t
+
+
+def _fused_run(plan, n, t, mode):
+    from dgnn_amd import ops
+    d = {k: v.to(DEV) for k, v in t.items()}
+    return ops.sage_layer_fused_fwd(plan.rowptr, plan.src, n, d["x"], d["ea"], d["We"], d["be"], d["Wj"], d["bj"], d["Wi"], None, None, False,
+                                    gemm_mode=mode, eid=plan.eid).cpu().double()
+
+
+def _fused_ref(n, ei, t):
+    from oracle.pyg_semantics import propagate_mean
+    phi = t["ea"].double() @ t["We"].double().t() + t["be"].double()
+    a = propagate_mean(t["x"].double(), n, ei, phi)
+    return a @ t["Wj"].double().t() + t["bj"].double() + t["x"].double() @ t["Wi"].double().t()
+
+
+@pytest.mark.parametrize("c_in,c_out", [(28, 64), (64, 128), (128, 128)])
+def test_f16x2_group_scales_cover_the_fp32_range(c_in, c_out):
+    """The fp16 two-part form scales every operand group by a power of two first (fp16 has 5 exponent bits).  Rows, attribute blocks and weight
+    matrices spread over 60 binades must come out as accurately, row by row, as in the bf16 x 3 form (which needs no scaling)."""
+    from dgnn_amd import ops
+    n, ei, plan, t = _fused_case(900, c_in, c_out, seed=c_in + 1)
+    g = torch.Generator().manual_seed(5)
+    # every cell's feature row and every edge's attribute row gets its own magnitude, 2^-30 .. 2^30; the weights sit at 1e-6 and 1e+4
+    t["x"] = t["x"] * torch.exp2(torch.randint(-30, 31, (n, 1), generator=g).float())
+    t["ea"] = t["ea"] * torch.exp2(torch.randint(-30, 31, (4 * n, 1), generator=g).float())
+    t["Wj"], t["Wi"], t["We"] = t["Wj"] * 1e-6, t["Wi"] * 1e-6, t["We"] * 1e4
+    ref = _fused_ref(n, ei, t)
+    # error of a row relative to the magnitude of the terms that make it up (its own row and its neighbours' messages differ by up to 2^60)
+    phi = (t["ea"].double() @ t["We"].double().t() + t["be"].double()).abs()
+    from oracle.pyg_semantics import propagate_mean
+    mag = propagate_mean(t["x"].double().abs(), n, ei, phi) @ t["Wj"].double().abs().t() + t["x"].double().abs() @ t["Wi"].double().abs().t() + t["bj"].double().abs()
+    errs = {}
+    for mode in (ops.GEMM_BF16X3_FILTER, ops.GEMM_F16X2):
+        out = _fused_run(plan, n, t, mode)
+        assert torch.isfinite(out).all()
+        errs[mode] = ((out - ref).abs() / mag).max().item()
+    print("rows over 60 binades, %d->%d: max err / sum|terms|  bf16x3 %.2e  f16x2 %.2e" % (c_in, c_out, errs[ops.GEMM_BF16X3_FILTER], errs[ops.GEMM_F16X2]))
+    assert errs[ops.GEMM_F16X2] < 1e-6 and errs[ops.GEMM_F16X2] < 4 * errs[ops.GEMM_BF16X3_FILTER] + 1e-7, errs
+
+
+def test_f16x2_zero_rows_tiny_rows_and_nan_stay_local():
+    from dgnn_amd import ops
+    n, ei, plan, t = _fused_case(700, 128, 128, seed=3)
+    t["x"][5] = 0.0                       # an all-zero cell
+    t["x"][6] = 1e-38                     # a cell at the bottom of the fp32 range
+    t["x"][7] = 1e30                      # and one near the top (its products with the weights stay below the fp32 maximum)
+    t["ea"][40:44] = 0.0                  # a cell whose in-edges carry no attributes
+    ref = _fused_ref(n, ei, t)
+    out = _fused_run(plan, n, t, ops.GEMM_F16X2)
+    finite = torch.isfinite(ref).all(1)
+    assert torch.isfinite(out[finite]).all()
+    scale = ref[finite].abs().max(1, keepdim=True).values.clamp_min(1.0)
+    assert ((out[finite] - ref[finite]).abs() / scale).max().item() < 2e-6
+    # a NaN feature row poisons its own output row and those of the cells that aggregate it -- nothing else
+    t["x"][100, 3] = float("nan")
+    out = _fused_run(plan, n, t, ops.GEMM_F16X2)
+    touched = torch.zeros(n, dtype=torch.bool)
+    touched[100] = True
+    touched[ei[1][ei[0] == 100]] = True
+    assert torch.isnan(out[touched]).any(1).all()
+    assert torch.isfinite(out[~touched & finite]).all()
