@@ -373,10 +373,15 @@ def main():
             fl = layer_flops(dom[0], dom[1]) * rows / (n_layers_dom * args.steps)
             tf = fl / (dom_ms * 1e-3) / 1e12
             x3 = ops.GEMM_MODE != ops.GEMM_F32
+            x2h = ops.GEMM_MODE == ops.GEMM_F16X2 and dom[1] > 256   # ops.linear_fwd: the fp16 two-part GEMM takes the layers wider than 256
+            nprod = 3 if x2h else 6
             roof.update({"bound": "mfma", "achieved": round(tf, 1), "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / FP32_MATRIX_PEAK_TF, 4),
                          "algorithmic_flops_per_launch": int(fl), "hbm_frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "note": ("fp32-class arithmetic executed as 6 bf16 MFMA products per fp32 product: %.0f TFLOP/s on the bf16 pipe = %.3f of its %.0f TFLOP/s dense peak"
-                                  % (6 * tf, 6 * tf / BF16_MATRIX_PEAK_TF, BF16_MATRIX_PEAK_TF)) if x3 else "bit-faithful fp32 MFMA (v_mfma_f32_32x32x2_f32)"})
+                         "note": ("fp32-class arithmetic executed as %d %s MFMA products per fp32 product: %.0f TFLOP/s on that pipe = %.3f of its %.0f TFLOP/s dense peak"
+                                  % (nprod, "fp16 (2 parts per operand, power-of-two row scales)" if x2h else "bf16 (3 parts per operand)", nprod * tf,
+                                     nprod * tf / BF16_MATRIX_PEAK_TF, BF16_MATRIX_PEAK_TF)) if x3 else "bit-faithful fp32 MFMA (v_mfma_f32_32x32x2_f32)"})
+            if x2h:
+                roof["kernel"] = roof["kernel"].replace("k_linear_fwd", "k_linear_fwd_x2h_big")
 
     # ---- CPU baseline (the oracle on the host cores) + self-check of the GPU logits against it ----
     cpu, check, failed = None, None, False

@@ -28,6 +28,8 @@ SIGNATURES = {
     "dgnn_sage_aggregate_fwd": (i32, [vp, vp, vp, i64, vp, i64, i32, vp, i64, i32, vp, vp, vp, i64, vp, i64, vp, i64, vp]),
     "dgnn_linear_fwd": (i32, [vp, i64, i32, vp, i64, vp, i64, i32, vp, i64, vp, vp, vp, i32, i64, i32, vp, i64, vp]),
     "dgnn_linear_fwd_x3": (i32, [vp, i64, i32, vp, i64, vp, i64, i32, vp, i64, vp, vp, vp, i32, i64, i32, vp, i64, vp]),
+    "dgnn_linear_fwd_x2h": (i32, [vp, i64, i32, vp, i64, vp, i64, i32, vp, i64, vp, vp, vp, i32, i64, i32, vp, i64, vp, vp]),
+    "dgnn_linear_fwd_x2h_scratch_elems": (i64, [i64, i32]),
     "dgnn_linear_wgrad_x3": (i32, [vp, i64, i32, vp, i64, i32, i64, vp, i64, i32, vp, vp]),
     "dgnn_linear_wgrad_scratch_elems": (i64, [i64, i32, i32]),
     "dgnn_linear_wgrad": (i32, [vp, i64, i32, vp, i64, i32, i64, vp, i64, i32, vp, vp]),

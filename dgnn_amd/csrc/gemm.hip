@@ -879,6 +879,212 @@ __global__ void __launch_bounds__(YT, 1) k_linear_fwd_x3_big(const float* __rest
     }
 }
 
+// =====================================================================================================================
+// "x2h": the same GEMM on the fp16 matrix cores in the fused layers' fp16 form (fused_common.h): every ROW of [A1 | A2] and every
+// row of [W1 | W2] (= output column) is multiplied by its own power of two so that its largest magnitude lies in [2^14, 2^15), split
+// into (hi, lo) fp16 parts while staged into LDS, 3 products per fp32 product (lo.lo dropped, <= 2^-22 relative), fp32 accumulation,
+// the two inverse powers of two applied to the accumulator in the epilogue (exact).  Half the matrix instructions and a third of the
+// split instructions of x3; a first pass over the operands writes the row scales (one extra read of A).
+// Large problems only (the 256 x 256 tile of k_linear_fwd_x3_big; M >= 8192, n_out > 128) -- the wide conv layers.
+// =====================================================================================================================
+#ifndef DGNN_X2H_K
+#define DGNN_X2H_K 32
+#endif
+constexpr int HK = DGNN_X2H_K;
+constexpr int HLD = 2 * HK * 2 + 16;   // LDS row: [hi | lo] x HK fp16 + 16 B pad (an odd number of 16-byte slots)
+constexpr int HTPR = HK / 4;           // threads per staged row (4 floats each)
+
+template <int NP>
+__device__ __forceinline__ void y2h_load(f32x4 (&v)[NP], const float* __restrict__ src, int64_t ld, int64_t row0, int64_t nrows, int k0, int kmax,
+                                         bool vec) {
+    constexpr int RPP = YT / HTPR;   // rows per pass
+    const int t = threadIdx.x, r = t / HTPR, c = (t % HTPR) * 4;
+    if (vec && k0 + HK <= kmax) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int64_t gr = row0 + r + p * RPP;
+            v[p] = *reinterpret_cast<const f32x4*>(src + (gr < nrows ? gr : nrows - 1) * ld + k0 + c);
+        }
+        return;
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int64_t gr = row0 + r + p * RPP;
+        const float* g = src + (gr < nrows ? gr : nrows - 1) * ld;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + c + j;
+            const float val = g[k < kmax ? k : kmax - 1];
+            v[p][j] = k < kmax ? val : 0.f;
+        }
+    }
+}
+
+typedef _Float16 h16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void x2h_split(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{x0, x1}, h2));
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(x1));
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{r0, r1}, h2));
+}
+// s = 2^(141 - E) for the row maximum's biased exponent E (clamped to [14, 254]); 1/s from s without a division
+__device__ __forceinline__ float x2h_scale_of(float rowmax) {
+    uint32_t E = (__builtin_bit_cast(uint32_t, rowmax) & 0x7FFFFFFFu) >> 23;
+    E = E < 14u ? 14u : (E > 254u ? 254u : E);
+    return __builtin_bit_cast(float, (268u - E) << 23);
+}
+__device__ __forceinline__ float x2h_inv(float s) { return __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(uint32_t, s)); }
+
+// one wavefront per row of [A1 | A2] (rows 0 .. M) and of [W1 | W2] (rows M .. M + n_out): scales[row] = its power-of-two scale
+__global__ void __launch_bounds__(256) k_x2h_row_scales(const float* __restrict__ A1, int64_t lda1, int k1, const float* __restrict__ A2, int64_t lda2,
+                                                        int k2, int64_t M, const float* __restrict__ W1, int64_t ldw1, const float* __restrict__ W2,
+                                                        int64_t ldw2, int n_out, float* __restrict__ scales) {
+    const int lane = lane_id();
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < M + n_out; row += nwaves) {
+        const bool isw = row >= M;
+        const float* p1 = isw ? W1 + (row - M) * ldw1 : A1 + row * lda1;
+        const float* p2 = isw ? (W2 ? W2 + (row - M) * ldw2 : nullptr) : (A2 ? A2 + row * lda2 : nullptr);
+        float m = 0.f;
+        if ((((uintptr_t)p1) & 15) == 0 && (k1 & 3) == 0) {
+            for (int k = lane * 4; k < k1; k += 256) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p1 + k);
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            }
+        } else {
+            for (int k = lane; k < k1; k += 64) m = fmaxf(m, fabsf(p1[k]));
+        }
+        if (p2) {
+            if ((((uintptr_t)p2) & 15) == 0 && (k2 & 3) == 0) {
+                for (int k = lane * 4; k < k2; k += 256) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(p2 + k);
+                    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                }
+            } else {
+                for (int k = lane; k < k2; k += 64) m = fmaxf(m, fabsf(p2[k]));
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if (lane == 0) scales[row] = x2h_scale_of(m);
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ void y2h_store(char* __restrict__ dst, const f32x4 (&v)[NP], const float (&s)[NP]) {
+    constexpr int RPP = YT / HTPR;
+    const int t = threadIdx.x, r = t / HTPR, c = (t % HTPR) * 4;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        uint32_t h0, l0, h1, l1;
+        x2h_split(v[p][0] * s[p], v[p][1] * s[p], h0, l0);
+        x2h_split(v[p][2] * s[p], v[p][3] * s[p], h1, l1);
+        char* d = dst + (r + p * RPP) * HLD + c * 2;
+        *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(d + 2 * HK) = make_uint2(l0, l1);
+    }
+}
+
+__global__ void __launch_bounds__(YT, 1) k_linear_fwd_x2h_big(const float* __restrict__ A1, int64_t lda1, int k1, const float* __restrict__ W1,
+                                                              int64_t ldw1, bool vec1, const float* __restrict__ A2, int64_t lda2, int k2,
+                                                              const float* __restrict__ W2, int64_t ldw2, bool vec2,
+                                                              const float* __restrict__ bias, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int relu, int64_t M, int n_out,
+                                                              float* __restrict__ out, int64_t ldo, const float* __restrict__ scales) {
+    extern __shared__ __attribute__((aligned(16))) char y2h_smem[];
+    char* const As = y2h_smem;
+    char* const Ws = y2h_smem + YM * HLD;
+    const int lane = lane_id(), w = wave_id_uniform();
+    const int wr = w >> 2, wc = w & 3, h = lane >> 5, l31 = lane & 31;
+    const int ncb = (n_out + YN - 1) / YN;   // XCD-aware tile map (see k_linear_fwd_x3)
+    const int64_t rb = (int64_t)((blockIdx.x >> 3) / ncb) * 8 + (blockIdx.x & 7);
+    if (rb * YM >= M) return;
+    const int64_t row0 = rb * YM;
+    const int col0 = (int)((blockIdx.x >> 3) % ncb) * YN;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    const int nch1 = (k1 + HK - 1) / HK, nch2 = A2 ? (k2 + HK - 1) / HK : 0, nch = nch1 + nch2;
+    constexpr int NP = YM / (YT / HTPR);
+    f32x4 ra[NP], rw[NP];
+    float sa[NP], sw[NP];   // scales of the rows this thread stages (fixed for the whole K walk)
+    {
+        const int r = threadIdx.x / HTPR;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int64_t ga = row0 + r + p * (YT / HTPR);
+            const int gw = col0 + r + p * (YT / HTPR);
+            sa[p] = scales[ga < M ? ga : M - 1];
+            sw[p] = scales[M + (gw < n_out ? gw : n_out - 1)];
+        }
+    }
+    auto load_chunk = [&](int ch) {
+        const bool first = ch < nch1;
+        const int kk = first ? k1 : k2, k0 = (first ? ch : ch - nch1) * HK;
+        y2h_load<NP>(ra, first ? A1 : A2, first ? lda1 : lda2, row0, M, k0, kk, first ? vec1 : vec2);
+        y2h_load<NP>(rw, first ? W1 : W2, first ? ldw1 : ldw2, col0, n_out, k0, kk, first ? vec1 : vec2);
+    };
+    load_chunk(0);
+    for (int ch = 0; ch < nch; ++ch) {
+        __syncthreads();
+        y2h_store<NP>(As, ra, sa);
+        y2h_store<NP>(Ws, rw, sw);
+        __syncthreads();
+        if (ch + 1 < nch) load_chunk(ch + 1);   // in flight under the MFMAs below
+        const char* ap = As + (wr * 128 + l31) * HLD + h * 16;
+        const char* bp = Ws + (wc * 64 + l31) * HLD + h * 16;
+#pragma unroll
+        for (int S = 0; S < HK / 16; ++S) {
+            h16x8_t bf[2][2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) bf[m][p] = *reinterpret_cast<const h16x8_t*>(bp + m * 32 * HLD + p * 2 * HK + S * 32);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                h16x8_t af[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) af[p] = *reinterpret_cast<const h16x8_t*>(ap + a * 32 * HLD + p * 2 * HK + S * 32);
+                // small terms first; the two column blocks alternate product by product
+                constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[PA[q]], bf[b][PB[q]], acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int col = col0 + wc * 64 + b * 32 + l31;
+        if (col >= n_out) continue;
+        const float bb = bias ? bias[col] : 0.f;
+        const float sc = scale ? scale[col] : 1.f;
+        const float sh = scale ? shift[col] : 0.f;
+        const float iw = x2h_inv(scales[M + col]);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + wr * 128 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= M) continue;
+                float v = __fmaf_rn(acc[a][b][r], x2h_inv(scales[row]) * iw, bb);
+                if (scale) v = __fmaf_rn(v, sc, sh);
+                if (relu & 1) v = fmaxf(v, 0.f);
+                if (relu & DGNN_LINEAR_ACCUMULATE) v += out[row * ldo + col];
+                out[row * ldo + col] = v;
+            }
+    }
+}
+
 // dW[na, nb] = sum_rows A[r, :]^T B[r, :], fp32 operands split in 3 bf16 parts while they are staged TRANSPOSED ([column][row]):
 // a thread takes 2 consecutive rows x 4 columns, so that a packed bf16 pair is two consecutive k (= rows) of one column.
 // 64 x 64 tile per block, wave (wa, wb) owns a 32 x 32 block; row slices of 32.
@@ -1080,6 +1286,32 @@ extern "C" int dgnn_linear_fwd_x3(const float* A1, int64_t lda1, int k1, const f
     hipLaunchKernelGGL(k_linear_fwd_x3, grid, dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2, lda2, k2, W2, ldw2, v2, bias,
                        scale, shift, relu, M, n_out, out, ldo);
     return dgnn_check_launch("linear_fwd_x3");
+}
+
+extern "C" int64_t dgnn_linear_fwd_x2h_scratch_elems(int64_t M, int n_out) { return M + n_out; }
+
+// fp16 two-part form of dgnn_linear_fwd_x3 (see k_linear_fwd_x2h_big).  Covers M >= 8192 with n_out > 128 -- the wide conv layers; other shapes
+// return DGNN_E_UNSUPPORTED (callers use dgnn_linear_fwd_x3).  scratch: dgnn_linear_fwd_x2h_scratch_elems(M, n_out) floats.
+extern "C" int dgnn_linear_fwd_x2h(const float* A1, int64_t lda1, int k1, const float* W1, int64_t ldw1, const float* A2, int64_t lda2, int k2,
+                                   const float* W2, int64_t ldw2, const float* bias, const float* scale, const float* shift, int relu,
+                                   int64_t M, int n_out, float* out, int64_t ldo, float* scratch, void* stream) {
+    DGNN_REQUIRE(M >= 0 && n_out > 0 && k1 > 0, DGNN_E_INVALID, "linear_fwd_x2h: bad sizes M=%lld n_out=%d k1=%d", (long long)M, n_out, k1);
+    if (M == 0) return DGNN_OK;
+    DGNN_REQUIRE(A1 && W1 && out && scratch, DGNN_E_INVALID, "linear_fwd_x2h: null pointer");
+    DGNN_REQUIRE((A2 == nullptr) == (W2 == nullptr) && (!A2 || k2 > 0), DGNN_E_INVALID, "linear_fwd_x2h: A2/W2 must come together");
+    DGNN_REQUIRE((scale == nullptr) == (shift == nullptr), DGNN_E_INVALID, "linear_fwd_x2h: scale/shift must come together");
+    if (!(M >= 8192 && n_out > XN)) return DGNN_E_UNSUPPORTED;
+    const bool v1 = vec_ok(A1, lda1) && vec_ok(W1, ldw1);
+    const bool v2 = A2 && vec_ok(A2, lda2) && vec_ok(W2, ldw2);
+    hipLaunchKernelGGL(k_x2h_row_scales, dim3((unsigned)dgnn_grid_cap(dgnn_cdiv(M + n_out, 4), 16)), dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, A2,
+                       lda2, k2, M, W1, ldw1, W2, ldw2, n_out, scratch);
+    static bool attr_set[DGNN_MAX_DEVICES];
+    constexpr size_t lds = (size_t)(YM + YN) * HLD;
+    dgnn_allow_dynamic_lds((const void*)k_linear_fwd_x2h_big, lds, attr_set);
+    dim3 grid((unsigned)(dgnn_cdiv(dgnn_cdiv(M, YM), 8) * 8 * dgnn_cdiv(n_out, YN)));
+    hipLaunchKernelGGL(k_linear_fwd_x2h_big, grid, dim3(YT), lds, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2, lda2, k2, W2, ldw2, v2, bias,
+                       scale, shift, relu, M, n_out, out, ldo, (const float*)scratch);
+    return dgnn_check_launch("linear_fwd_x2h");
 }
 
 extern "C" int dgnn_linear_wgrad_x3(const float* A, int64_t lda, int n_a, const float* B, int64_t ldb, int n_b, int64_t M, float* dW,

@@ -9,6 +9,8 @@ import torch
 
 from ._lib import DgnnError, check, lib, on_device_of, ptr, stream_ptr
 
+DGNN_E_UNSUPPORTED = -2  # include/dgnn_hip.h
+
 
 def _req(t: torch.Tensor, name: str, dtype=torch.float32, dim=None, any_stride=False):
     if not isinstance(t, torch.Tensor):
@@ -225,6 +227,16 @@ def linear_fwd(A1, W1, A2=None, W2=None, bias=None, scale=None, shift=None, relu
             "dgnn_linear_fwd_bf16")
         return out
     # fp32 operands: bit-faithful fp32 MFMA ("f32" mode) or the fused layers' exact-split bf16 arithmetic (fp32-class, 6/16 of the time)
+    if GEMM_MODE == GEMM_F16X2 and M >= 8192 and n_out > 256:  # (at n_out <= 256 the extra pass over A for the row scales costs what the products save)
+        # the wide conv layers in the fused layers' fp16 two-part form (row scales in a scratch vector)
+        scratch = torch.empty(int(lib().dgnn_linear_fwd_x2h_scratch_elems(M, n_out)), dtype=torch.float32, device=A1.device)
+        rc = lib().dgnn_linear_fwd_x2h(
+            ptr(A1), _ld(A1), A1.size(1), ptr(W1), W1.size(1),
+            ptr(A2), _ld(A2) if A2 is not None else 0, A2.size(1) if A2 is not None else 0, ptr(W2), W2.size(1) if W2 is not None else 0,
+            ptr(bias), ptr(scale), ptr(shift), int(bool(relu)), M, n_out, ptr(out), n_out, ptr(scratch), stream_ptr())
+        if rc != DGNN_E_UNSUPPORTED:
+            check(rc, "dgnn_linear_fwd_x2h")
+            return out
     fn = lib().dgnn_linear_fwd if GEMM_MODE == GEMM_F32 else lib().dgnn_linear_fwd_x3
     check(fn(
         ptr(A1), _ld(A1), A1.size(1), ptr(W1), W1.size(1),

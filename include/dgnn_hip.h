@@ -129,6 +129,14 @@ int dgnn_linear_fwd(const float* A1, int64_t lda1, int k1, const float* W1, int6
 int dgnn_linear_fwd_x3(const float* A1, int64_t lda1, int k1, const float* W1, int64_t ldw1, const float* A2, int64_t lda2, int k2,
                        const float* W2, int64_t ldw2, const float* bias, const float* scale, const float* shift, int relu, int64_t M,
                        int n_out, float* out, int64_t ldo, void* stream);
+/* The same product in the fp16 form of DGNN_GEMM_F16X2 (below): every row of [A1 | A2] and of [W1 | W2] scaled by its own power of two,
+ * split into 2 fp16 parts, 3 products per fp32 product on v_mfma_f32_32x32x16_f16, fp32 accumulate (dropped terms <= 2^-22 relative).
+ * Covers M >= 8192 with n_out > 128 (the wide conv layers); other shapes return DGNN_E_UNSUPPORTED -- use dgnn_linear_fwd_x3.
+ * scratch: dgnn_linear_fwd_x2h_scratch_elems(M, n_out) floats (the row scales, written by a first pass over the operands). */
+int64_t dgnn_linear_fwd_x2h_scratch_elems(int64_t M, int n_out);
+int dgnn_linear_fwd_x2h(const float* A1, int64_t lda1, int k1, const float* W1, int64_t ldw1, const float* A2, int64_t lda2, int k2,
+                        const float* W2, int64_t ldw2, const float* bias, const float* scale, const float* shift, int relu,
+                        int64_t M, int n_out, float* out, int64_t ldo, float* scratch, void* stream);
 int dgnn_linear_wgrad_x3(const float* A, int64_t lda, int n_a, const float* B, int64_t ldb, int n_b, int64_t M, float* dW, int64_t lddw,
                          int accumulate, float* partials, void* stream);
 

@@ -836,3 +836,31 @@ def test_f16x2_zero_rows_tiny_rows_and_nan_stay_local():
     touched[ei[1][ei[0] == 100]] = True
     assert torch.isnan(out[touched]).any(1).all()
     assert torch.isfinite(out[~touched & finite]).all()
+
+
+@pytest.mark.parametrize("k1,k2,n_out", [(256, 256, 512), (128, 128, 256), (100, 0, 200), (512, 512, 1024)])
+def test_linear_fwd_x2h_vs_fp64(k1, k2, n_out):
+    """The wide layers' GEMM in the fp16 two-part form (row scales, 3 products) against fp64 and against the bf16 x 3 form: rows of A over
+    40 binades, weight rows over 20, BatchNorm / ReLU epilogue, a ragged last tile."""
+    from dgnn_amd import ops
+    M = 8192 + 77
+    g = torch.Generator().manual_seed(k1 + n_out)
+    A1 = torch.randn(M, k1, generator=g) * torch.exp2(torch.randint(-20, 21, (M, 1), generator=g).float())
+    W1 = torch.randn(n_out, k1, generator=g) * 0.1 * torch.exp2(torch.randint(-10, 11, (n_out, 1), generator=g).float())
+    A2 = torch.randn(M, k2, generator=g) * A1.abs().max(1, keepdim=True).values * 0.5 if k2 else None
+    W2 = torch.randn(n_out, k2, generator=g) * 0.1 if k2 else None
+    b, sc, sh = torch.randn(n_out, generator=g), torch.rand(n_out, generator=g) + 0.5, torch.randn(n_out, generator=g)
+    z = A1.double() @ W1.double().t() + (A2.double() @ W2.double().t() if k2 else 0.0) + b.double()
+    ref = torch.relu(z * sc.double() + sh.double())
+    mag = (A1.double().abs() @ W1.double().abs().t() + (A2.double().abs() @ W2.double().abs().t() if k2 else 0.0) + b.double().abs()) * sc.double() + sh.double().abs()
+    dev = lambda t: None if t is None else t.to(DEV)
+    errs, old = {}, ops.GEMM_MODE
+    try:
+        for mode in (ops.GEMM_BF16X3_FILTER, ops.GEMM_F16X2):
+            ops.GEMM_MODE = mode
+            out = ops.linear_fwd(dev(A1), dev(W1), dev(A2), dev(W2), dev(b), dev(sc), dev(sh), True).cpu().double()
+            errs[mode] = ((out - ref).abs() / mag).max().item()
+    finally:
+        ops.GEMM_MODE = old
+    print("x2h GEMM K=%d+%d N=%d: max err / sum|terms|  x3 %.2e  x2h %.2e" % (k1, k2, n_out, errs[ops.GEMM_BF16X3_FILTER], errs[ops.GEMM_F16X2]))
+    assert errs[ops.GEMM_F16X2] < 1e-6 and errs[ops.GEMM_F16X2] < 4 * errs[ops.GEMM_BF16X3_FILTER] + 1e-7, errs

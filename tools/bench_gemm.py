@@ -15,7 +15,7 @@ for M, k1, k2, n in shapes:
     flop = 2.0 * M * (k1 + k2) * n
     ref = None
     line = "M=%8d K=%3d+%3d N=%4d:" % (M, k1, k2, n)
-    for name, mode in (("f32", ops.GEMM_F32), ("x3", ops.GEMM_BF16X3_FILTER)):
+    for name, mode in (("f32", ops.GEMM_F32), ("x3", ops.GEMM_BF16X3_FILTER), ("x2h", ops.GEMM_F16X2)):
         ops.GEMM_MODE = mode
         f = lambda: ops.linear_fwd(A1, W1, A2, W2, b, relu=True)
         out = f(); torch.cuda.synchronize()
