@@ -890,7 +890,8 @@ __global__ void __launch_bounds__(YT, 1) k_linear_fwd_x3_big(const float* __rest
 #ifndef DGNN_X2H_K
 #define DGNN_X2H_K 32
 #endif
-constexpr int HK = DGNN_X2H_K;
+constexpr int HK = DGNN_X2H_K;          // K chunk per barrier pair.  Measured (tools/bench_gemm_x2h.py, M = 1M): 64 halves the barriers but needs 64 staging
+                                        // registers next to the 128 accumulators -- 52 spilled, 4.26 ms against 2.67 ms with 32 (K = 512, N = 512)
 constexpr int HLD = 2 * HK * 2 + 16;   // LDS row: [hi | lo] x HK fp16 + 16 B pad (an odd number of 16-byte slots)
 constexpr int HTPR = HK / 4;           // threads per staged row (4 floats each)
 
