@@ -211,12 +211,17 @@ int dgnn_sage_aggregate_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const
 #define DGNN_GEMM_BF16X3_FILTER 2 /* as BF16X3, and the 20-tap filter MLP runs on v_mfma_f32_16x16x32_bf16 too (same exact
                                      3-part split, 6 products, fp32 accumulate); falls back to BF16X3 for shapes it
                                      does not cover (c_in not a multiple of c_in_pad/16, unaligned wide rows) */
-#define DGNN_GEMM_F16X2_DENSE 3 /* dense product: fp32 operands scaled by a power of two per tet row / per weight pair and split into
-                                  2 fp16 parts (22 significand bits), 3 products on v_mfma_f32_32x32x16_f16, fp32 accumulate (the
-                                  "3xTF32" scheme; dropped terms <= 2^-22 relative); filter MLP as BF16X3_FILTER */
-#define DGNN_GEMM_F16X2 4       /* as F16X2_DENSE, and the filter MLP on v_mfma_f32_16x16x32_f16 in the same form (one power-of-two
-                                  scale per 16-edge attribute block and per [We|be]); falls back like BF16X3_FILTER.  The GEMM entry
-                                  points (dgnn_linear_*_x3, training) treat both F16X2 values as BF16X3 */
+#define DGNN_GEMM_F16X2_DENSE 3 /* dense product in the fp16 two-part form: every [mean | own] row of a tet and the [Wj | Wi] pair are multiplied
+                                  by a power of two (exact) that puts their largest magnitude into [2^14, 2^15), split into (hi, lo) fp16
+                                  parts (22 significand bits), 3 products hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16 with fp32
+                                  accumulation (lo.lo dropped: <= 2^-22 relative -- the "3xTF32" scheme, TF32 and fp16 both carry 11
+                                  significant bits), inverse scales applied to the accumulator; filter MLP as BF16X3_FILTER */
+#define DGNN_GEMM_F16X2 4       /* (library default of the Python host) as F16X2_DENSE, and the filter MLP on v_mfma_f32_16x16x32_f16 in the
+                                  same form: one scale per EDGE (its 20 attributes and the constant 1 of the bias column) and one for
+                                  [We | be].  Half the matrix instructions and a third of the split instructions of BF16X3_FILTER; measured
+                                  error against fp64 at the level of the other modes, also with rows / edges / weights spread over 60
+                                  binades (tests/test_gpu_parity.py).  Falls back like BF16X3_FILTER.  The training entry points and
+                                  dgnn_linear_*_x3 treat both F16X2 values as BF16X3; dgnn_linear_fwd_x2h is the GEMM in this form */
 int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src,
                               const float* x_dst, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e,
                               const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,

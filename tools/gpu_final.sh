@@ -1,6 +1,6 @@
 # end-of-round measurement set: rocprofv3 passes (fp32, bf16), bench lines (default, bf16, bf16 single, wide, 10M), training traces + bench lines
 cd $GRAFT_REPO_ROOT
-T=${1:-r3z}
+T=${1:-r9z}
 bash tools/prof_round2.sh ${T}_f32
 bash tools/prof_round2.sh ${T}_bf16 --dtype bf16
 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
@@ -8,7 +8,7 @@ python bench.py --dtype bf16 > gpurun_out/${T}_bench_bf16.json 2> gpurun_out/${T
 DGNN_BF16_MODE=single python bench.py --dtype bf16 --no-train > gpurun_out/${T}_bench_bf16_single.json 2> /dev/null
 python bench.py --widths 64,128,256,512 --no-train > gpurun_out/${T}_bench_w512.json 2> gpurun_out/${T}_bench_w512.err
 python bench.py --widths 128,256,512,1024 --no-train > gpurun_out/${T}_bench_w1024.json 2> gpurun_out/${T}_bench_w1024.err
-python bench.py --points 1485000 --steps 5 --warmup 4 --no-train > gpurun_out/${T}_bench_10m.json 2> gpurun_out/${T}_bench_10m.err
+python bench.py --points 1485000 --steps 20 --warmup 10 --no-train > gpurun_out/${T}_bench_10m.json 2> gpurun_out/${T}_bench_10m.err
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 for a in "" "--updated" "--updated --dtype bf16"; do
