@@ -85,7 +85,7 @@ __device__ __forceinline__ bf16x8 pack8(const uint32_t (&d)[4]) {
 // the bf16 x 3 form.  fp16 has 5 exponent bits, so every operand is first multiplied by a power of two s (exact) that puts the
 // largest magnitude of its scaling group (one row of an operand, or one weight matrix) into [2^14, 2^15): elements down to 2^-15 of that maximum keep all 22 bits AND split
 // identically under any other s with the same property; smaller ones are quantised to 2^-24 (fp16 subnormals, honoured by the
-// MFMA: tools/ubench_f16_denorm.hip), i.e. to <= 2^-39 of the group maximum.  The inverse powers of two are applied to the fp32
+// MFMA: tools/ubench_f16_denorm.hip), i.e. to <= 2^-38 of the group maximum.  The inverse powers of two are applied to the fp32
 // accumulator (exact).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));

@@ -21,6 +21,11 @@
 // phase; the dense part is the 32x32x16 split-bf16 product -- K split between wave pairs with a delayed epilogue at
 // C_in = 128 (8 waves), full K per wave and an immediate epilogue for C_in <= 64 (4 waves, two workgroups per CU; Cfg2).
 // Edge attributes are read in the caller's order through the plan's eid (per-lane DMA addresses) when eid is given.
+//
+// Template parameters DSP / FSP choose the arithmetic of the dense / filter product: 3 = the exact 3-part bf16 split described above
+// (6 products), 2 = the fp16 two-part form of fused_common.h (power-of-two scale per A-tile row, per edge and per weight matrix, 3 products;
+// gemm modes DGNN_GEMM_F16X2_DENSE / DGNN_GEMM_F16X2, the Python host's default).  The compile-time switches below record what was measured
+// and not kept; DGNN_WHATIF builds remove one ingredient at a time.
 #include "fused_common.h"
 
 #ifndef DGNN_SMALL_NW
@@ -56,6 +61,9 @@
 //   higher on quieter operands.
 #ifndef DGNN_WHATIF
 #define DGNN_WHATIF 0
+#endif
+#ifndef DGNN_PLANAR
+#define DGNN_PLANAR 1
 #endif
 #ifndef DGNN_PHASE_PRIO
 #define DGNN_PHASE_PRIO 0  // measured: balances the barrier waits (0.6/0.4 us instead of 1.4/0.2) but the tile period does not move
@@ -162,6 +170,7 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     // same either way), so a lane ends up with ONE tet row and 4-column runs of it: the result leaves as 16-byte stores (2 or 4 per lane and
     // tile instead of 8 or 16 dword stores whose addresses each cost 64-bit arithmetic), the row's inverse scale is one LDS word per lane.
     constexpr bool TR = DSP == 2 && DGNN_TR;
+    constexpr bool PLANAR = DSP == 2 && DGNN_PLANAR;
     // Skewed schedule (128 -> 128, fp16 dense form): the eight waves are two groups, A = the K-half-0 waves 0..3 and B = the K-half-1 waves
     // 4..7, one of each per SIMD, and at any time one group is in its filter phase P (vector ALU, LDS, gathers) while the other is in its dense
     // phase C (matrix cores, stores).  In the plain schedule both wavefronts of a SIMD are always in the SAME phase and queue for the same
@@ -381,8 +390,10 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     // av = araw * fpre, fpre a power of two (the 1/4 of the mean times the inverse scales of the filter product; 1 on the generic path)
     auto put_seg = [&](int64_t it, int row, const float (&araw)[NB], const float (&xv)[NB], float fpre) {
         const int buf = (int)(it & 1);
-        char* dst = abuf + buf * C::A_BYTES + row * ROWB + (c0 >> 3) * OCT + (c0 & 7) * 2;
-        char* dsx = dst + (CIN_PAD / 8) * OCT;
+        // PLANAR (fp16 form): a row is [hi of all K | lo of all K], so the 16 lanes of a tet write 16 x NB*2 contiguous bytes per part
+        // (octet-interleaved [hi|lo] pieces put lanes j and j+8 on the same banks: 2-way conflicts on every A-tile write)
+        char* dst = abuf + buf * C::A_BYTES + row * ROWB + (PLANAR ? c0 * 2 : (c0 >> 3) * OCT + (c0 & 7) * 2);
+        char* dsx = dst + (PLANAR ? CIN_PAD * 2 : (CIN_PAD / 8) * OCT);
         uint32_t ph[NB / 2], pm[NB / 2], pl[NB / 2], qh[NB / 2], qm[NB / 2], ql[NB / 2];
         if constexpr (DSP == 2) {
             // row scale: the 16 lanes of this tet hold the whole [mean | own] row between them
@@ -412,7 +423,7 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                 split3(xv[2 * d], xv[2 * d + 1], qh[d], qm[d], ql[d]);
             }
         }
-        constexpr int LO = 16 * (DSP - 1);
+        constexpr int LO = PLANAR ? C::K * 2 : 16 * (DSP - 1);
         if (NB == 8) {
             *reinterpret_cast<uint4*>(dst) = make_uint4(ph[0], ph[1], ph[2 % (NB / 2)], ph[3 % (NB / 2)]);
             if constexpr (DSP == 3) *reinterpret_cast<uint4*>(dst + 16) = make_uint4(pm[0], pm[1], pm[2 % (NB / 2)], pm[3 % (NB / 2)]);
@@ -609,11 +620,12 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         // ================================================================ C: dense part, split-bf16, K half
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        const char* A = abuf + (it & 1) * C::A_BYTES + (rg * 32 + l31) * ROWB + (kh * (CIN_PAD / 8) + h) * OCT;
+        const char* A = abuf + (it & 1) * C::A_BYTES + (rg * 32 + l31) * ROWB + (PLANAR ? (kh * CIN_PAD + 8 * h) * 2 : (kh * (CIN_PAD / 8) + h) * OCT);
+        constexpr int SSTEP = PLANAR ? 32 : 2 * OCT, LOFF = PLANAR ? C::K * 2 : 16 * (DSP - 1);
 #pragma unroll
         for (int S = 0; S < ((DGNN_WHATIF & 1) ? 1 : NWB); ++S) {
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(A + S * 2 * OCT);
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(A + S * 2 * OCT + 16 * (DSP - 1));
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(A + S * SSTEP);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(A + S * SSTEP + LOFF);
             if constexpr (DSP == 2) {
                 // first product: C = inline constant 0 (no 16 register moves to clear the accumulator)
                 if constexpr (TR) {  // weights as the A operand: the accumulator holds the block transposed

@@ -17,7 +17,7 @@ h=x[:,1:]
 acts=[h]
 for i in range(4):
     h=net._eval_layers_one(i,h,ea,plan); acts.append(h)
-for mode in (0,1,2):
+for mode in (0,1,2,3,4):
     ops.GEMM_MODE=mode
     for i in range(4):
         tot=0; pos=[]
