@@ -65,6 +65,9 @@
 #ifndef DGNN_PLANAR
 #define DGNN_PLANAR 1
 #endif
+#ifndef DGNN_ROW_SHIFT
+#define DGNN_ROW_SHIFT 1
+#endif
 #ifndef DGNN_PHASE_PRIO
 #define DGNN_PHASE_PRIO 0  // measured: balances the barrier waits (0.6/0.4 us instead of 1.4/0.2) but the tile period does not move
 #endif
@@ -188,6 +191,9 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     const int h = lane >> 5, l31 = lane & 31;
     const int jcol = lane & 15, tq = lane >> 4;  // filter phase: channel group / tet within a row block; also MFMA (col, k-group)
     const int ldx32 = (int)ldx;
+    // row offset = row * ldx: a shift when the stride is a power of two (64 / 128 floats in layers 1..3; v_mul_lo_u32 runs at a quarter of the rate)
+    const int ldx_sh = (DGNN_ROW_SHIFT && (ldx32 & (ldx32 - 1)) == 0) ? __builtin_ctz((unsigned)ldx32) : -1;
+    auto row_off = [&](int row) -> uint32_t { return ldx_sh >= 0 ? (uint32_t)row << ldx_sh : (uint32_t)(row * ldx32); };
     constexpr bool vec = NB >= 4;  // the host side only takes rows that can be read as 16-byte pieces when NB >= 4 (xvec); NB == 2 reads 8 bytes
     (void)xvec;
 
@@ -344,11 +350,11 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         if (!regular) return;
         const int i0 = (int)(tile_of(it) * TILE) + w * TPW;
         const int tl = rb * 4 + tq;  // this lane's tet within the wave
-        ld_vec<NB, part>(xd[rb], xdst + (uint32_t)((i0 + (tl < nv1 ? tl : nv1 - 1)) * ldx32) + c0l, vec);
+        ld_vec<NB, part>(xd[rb], xdst + row_off(i0 + (tl < nv1 ? tl : nv1 - 1)) + c0l, vec);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (part != 1) sidx[rb][r] = (DGNN_WHATIF & 8) ? i0 + (tl < nv1 ? tl : nv1 - 1) : __shfl(vsrc1, tl * 4 + r);
-            ld_vec<NB, part>(xr[rb][r], x + (uint32_t)(sidx[rb][r] * ldx32) + c0l, vec);
+            ld_vec<NB, part>(xr[rb][r], x + row_off(sidx[rb][r]) + c0l, vec);
         }
     };
     auto issue_ea = [&](int64_t it) {
