@@ -1,6 +1,6 @@
 # end-of-round measurement set: rocprofv3 passes (fp32, bf16), bench lines (default, bf16, bf16 single, wide, 10M), training traces + bench lines
 cd $GRAFT_REPO_ROOT
-T=${1:-r9z}
+T=${1:-r9w}
 bash tools/prof_round2.sh ${T}_f32
 bash tools/prof_round2.sh ${T}_bf16 --dtype bf16
 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err

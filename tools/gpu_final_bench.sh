@@ -1,6 +1,6 @@
 # bench-line part of tools/gpu_final.sh (re-taken when a run of the full set caught the box throttling its MFMA-heavy kernels after the PMC passes)
 cd $GRAFT_REPO_ROOT
-T=${1:-r9y}
+T=${1:-r9v}
 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
 python bench.py --dtype bf16 > gpurun_out/${T}_bench_bf16.json 2> gpurun_out/${T}_bench_bf16.err
 DGNN_BF16_MODE=single python bench.py --dtype bf16 --no-train > gpurun_out/${T}_bench_bf16_single.json 2> /dev/null
