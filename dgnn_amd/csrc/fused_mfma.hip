@@ -68,6 +68,12 @@
 #ifndef DGNN_ROW_SHIFT
 #define DGNN_ROW_SHIFT 1
 #endif
+#ifndef DGNN_NT_STORES
+#define DGNN_NT_STORES 1
+#endif
+#ifndef DGNN_NT_ATTR
+#define DGNN_NT_ATTR 0  // measured: streaming the attribute DMA past the caches costs 1.7 % (1.764 -> 1.795 ms per step)
+#endif
 #ifndef DGNN_PHASE_PRIO
 #define DGNN_PHASE_PRIO 0  // measured: balances the barrier waits (0.6/0.4 us instead of 1.4/0.2) but the tile period does not move
 #endif
@@ -81,6 +87,24 @@ using namespace fused;
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define H8(v) __builtin_bit_cast(f16x8, v)
 template <int V> struct IC { static constexpr int value = V; };
+// output rows are written once and read by the NEXT launch: streamed past the caches (DGNN_NT_STORES) they do not evict the feature rows
+// the gathers of this launch hit in L2 / Infinity Cache
+// the edge attributes are read once per launch: non-temporal DMA (aux bit 1 = nt) keeps them from displacing feature rows
+__device__ __forceinline__ void glds16_s(const float* g, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0,
+                                     DGNN_NT_ATTR ? 2 : 0);
+}
+__device__ __forceinline__ void glds4_s(const float* g, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0,
+                                     DGNN_NT_ATTR ? 2 : 0);
+}
+__device__ __forceinline__ void st_out(float* p, float v) {
+#if DGNN_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 
 // NW wavefronts per workgroup, KS = how many ways the dense phase splits K between wavefronts.
 //   (8, 2): 8 waves = (32-column slice) x (K half) [x row group]; the only arrangement whose resident weights fit at C_in = 128.
@@ -367,17 +391,17 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                 return ea + (int64_t)__shfl(veid1, e) * FE + (fi - e * FE);
             };
 #pragma unroll
-            for (int q = 0; q < C::EA_FULL; ++q) glds16(row_ptr(q * 256 + lane * 4), myea + q * 256);
+            for (int q = 0; q < C::EA_FULL; ++q) glds16_s(row_ptr(q * 256 + lane * 4), myea + q * 256);
 #pragma unroll
-            for (int q = 0; q < C::EA_TAIL; ++q) glds4(row_ptr(C::EA_FULL * 256 + q * 64 + lane), myea + C::EA_FULL * 256 + q * 64);
+            for (int q = 0; q < C::EA_TAIL; ++q) glds4_s(row_ptr(C::EA_FULL * 256 + q * 64 + lane), myea + C::EA_FULL * 256 + q * 64);
         } else {
             const float* eab = ea + (int64_t)__builtin_amdgcn_readfirstlane(vbeg1) * lde;
             const int ea_last = nv1 * 4 * FE - 4;  // last 16-byte chunk of the group's attribute block
 #pragma unroll
-            for (int q = 0; q < C::EA_FULL; ++q) glds16(eab + min(q * 256 + lane * 4, ea_last), myea + q * 256);
+            for (int q = 0; q < C::EA_FULL; ++q) glds16_s(eab + min(q * 256 + lane * 4, ea_last), myea + q * 256);
 #pragma unroll
             for (int q = 0; q < C::EA_TAIL; ++q)
-                glds4(eab + min(C::EA_FULL * 256 + q * 64 + lane, ea_last + 3), myea + C::EA_FULL * 256 + q * 64);
+                glds4_s(eab + min(C::EA_FULL * 256 + q * 64 + lane, ea_last + 3), myea + C::EA_FULL * 256 + q * 64);
         }
     };
     auto issue_loads = [&](int64_t it) {  // everything at once (prologue, and after a group that took the generic path)
@@ -719,12 +743,12 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
             if (t == 123.456f) o[0] = t;
         } else if ((tile + 1) * TILE <= n_dst) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) o[(int64_t)((r & 3) + 8 * (r >> 2)) * ldo] = v[r];
+            for (int r = 0; r < 8; ++r) st_out(&o[(int64_t)((r & 3) + 8 * (r >> 2)) * ldo], v[r]);
         } else {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2);
-                if (row0 + rr < n_dst) o[(int64_t)rr * ldo] = v[r];
+                if (row0 + rr < n_dst) st_out(&o[(int64_t)rr * ldo], v[r]);
             }
         }
         }
@@ -785,7 +809,7 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                 if (has_scale) v = __fmaf_rn(v, sc, sh);
                 if (relu) v = fmaxf(v, 0.f);
                 const int rr = (r & 3) + 8 * (r >> 2);
-                if (full || row0 + rr < n_dst) o[(int64_t)rr * ldo] = v;
+                if (full || row0 + rr < n_dst) st_out(&o[(int64_t)rr * ldo], v);
             }
             }
         }
