@@ -217,7 +217,6 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     const int ldx32 = (int)ldx;
     // row offset = row * ldx: a shift when the stride is a power of two (64 / 128 floats in layers 1..3; v_mul_lo_u32 runs at a quarter of the rate)
     const int ldx_sh = (DGNN_ROW_SHIFT && (ldx32 & (ldx32 - 1)) == 0) ? __builtin_ctz((unsigned)ldx32) : -1;
-    auto row_off = [&](int row) -> uint32_t { return ldx_sh >= 0 ? (uint32_t)row << ldx_sh : (uint32_t)(row * ldx32); };
     constexpr bool vec = NB >= 4;  // the host side only takes rows that can be read as 16-byte pieces when NB >= 4 (xvec); NB == 2 reads 8 bytes
     (void)xvec;
 
@@ -374,26 +373,48 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         if (!regular) return;
         const int i0 = (int)(tile_of(it) * TILE) + w * TPW;
         const int tl = rb * 4 + tq;  // this lane's tet within the wave
-        ld_vec<NB, part>(xd[rb], xdst + row_off(i0 + (tl < nv1 ? tl : nv1 - 1)) + c0l, vec);
+        const int own = i0 + (tl < nv1 ? tl : nv1 - 1);
+        // all index shuffles first, then every row offset under ONE wave-uniform choice of shift / multiply, then the loads back to back
+        // (a per-row choice compiles to a branch and an LDS wait in front of every pair of loads)
+        if (part != 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (part != 1) sidx[rb][r] = (DGNN_WHATIF & 8) ? i0 + (tl < nv1 ? tl : nv1 - 1) : __shfl(vsrc1, tl * 4 + r);
-            ld_vec<NB, part>(xr[rb][r], x + row_off(sidx[rb][r]) + c0l, vec);
+            for (int r = 0; r < 4; ++r) sidx[rb][r] = (DGNN_WHATIF & 8) ? own : __shfl(vsrc1, tl * 4 + r);
         }
+        uint32_t off[5];
+        if (ldx_sh >= 0) {
+            off[4] = (uint32_t)own << ldx_sh;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) off[r] = (uint32_t)sidx[rb][r] << ldx_sh;
+        } else {
+            off[4] = (uint32_t)(own * ldx32);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) off[r] = (uint32_t)(sidx[rb][r] * ldx32);
+        }
+        ld_vec<NB, part>(xd[rb], xdst + off[4] + c0l, vec);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ld_vec<NB, part>(xr[rb][r], x + off[r] + c0l, vec);
     };
     auto issue_ea = [&](int64_t it) {
         if (!regular || (DGNN_WHATIF & 16)) return;
         // eid == nullptr: the rows are in plan order, one contiguous block.  Otherwise every 80-byte row is
         // fetched from its place in the caller's edge_attr (row eid[k]) -- no staging copy of the edge features.
         if (eid) {
-            auto row_ptr = [&](int fi) -> const float* {     // float index within the strip -> global address
-                const int e = (fi * 0xCCD) >> 16;             // fi / 20 for fi < 8192
-                return ea + (int64_t)__shfl(veid1, e) * FE + (fi - e * FE);
-            };
+            // float index within the strip -> (edge of the wave, offset in its row); the edge ids are shuffled in one batch
+            const float* gp[C::EA_FULL + C::EA_TAIL];
+            int er[C::EA_FULL + C::EA_TAIL], fo[C::EA_FULL + C::EA_TAIL];
 #pragma unroll
-            for (int q = 0; q < C::EA_FULL; ++q) glds16_s(row_ptr(q * 256 + lane * 4), myea + q * 256);
+            for (int q = 0; q < C::EA_FULL + C::EA_TAIL; ++q) {
+                const int fi = q < C::EA_FULL ? q * 256 + lane * 4 : C::EA_FULL * 256 + (q - C::EA_FULL) * 64 + lane;
+                const int e = (fi * 0xCCD) >> 16;  // fi / 20 for fi < 8192
+                fo[q] = fi - e * FE;
+                er[q] = __shfl(veid1, e);
+            }
 #pragma unroll
-            for (int q = 0; q < C::EA_TAIL; ++q) glds4_s(row_ptr(C::EA_FULL * 256 + q * 64 + lane), myea + C::EA_FULL * 256 + q * 64);
+            for (int q = 0; q < C::EA_FULL + C::EA_TAIL; ++q) gp[q] = ea + (int64_t)er[q] * FE + fo[q];
+#pragma unroll
+            for (int q = 0; q < C::EA_FULL; ++q) glds16_s(gp[q], myea + q * 256);
+#pragma unroll
+            for (int q = 0; q < C::EA_TAIL; ++q) glds4_s(gp[C::EA_FULL + q], myea + C::EA_FULL * 256 + q * 64);
         } else {
             const float* eab = ea + (int64_t)__builtin_amdgcn_readfirstlane(vbeg1) * lde;
             const int ea_last = nv1 * 4 * FE - 4;  // last 16-byte chunk of the group's attribute block

@@ -466,9 +466,212 @@ def main():
     ingest_fixture(np.random.default_rng(5))
 
 
+# ---- round 3: rows 8f-2 (loss / regulariser / lr schedule / train step) and 8f-4 (labels -> interface) pinned to the reference ----
+HOST_STANDIN = {
+    # packages learning/runModel.py and processing/generate_mesh.py import at module level but this image lacks.  They are OUR
+    # throw-away stubs (nothing of them is called on the recorded paths except trimesh.Trimesh, which only records its arguments).
+    "trimesh/__init__.py": """
+        import numpy as np
+        class Trimesh:
+            def __init__(self, vertices=None, faces=None, process=True, **k):
+                self.vertices, self.faces, self.process = np.asarray(vertices), np.asarray(faces), process
+        class repair:
+            @staticmethod
+            def fix_normals(mesh): mesh.fix_normals_called = True
+    """,
+    "libmesh.py": "def check_mesh_contains(*a, **k): raise NotImplementedError\n",
+    "gco.py": "class GCO:\n    def __init__(self): raise NotImplementedError('gco is not installed')\n",
+    "evaluate_mesh.py": "def compute_iou(*a, **k): raise NotImplementedError\ndef compute_chamfer(*a, **k): raise NotImplementedError\n",
+    "tqdm.py": "def tqdm(it, *a, **k): return it\n",
+}
+
+
+def load_ref_host():
+    """imports the reference's processing/generate_mesh.py and learning/runModel.py UNMODIFIED under HOST_STANDIN"""
+    d = tempfile.mkdtemp(prefix="host_standin_")
+    for rel, src in HOST_STANDIN.items():
+        q = os.path.join(d, rel)
+        os.makedirs(os.path.dirname(q), exist_ok=True)
+        with open(q, "w") as f:
+            f.write(textwrap.dedent(src))
+    sys.path.insert(0, d)
+    mods = {}
+    for name, rel in (("generate_mesh", "processing/generate_mesh.py"), ("runModel", "learning/runModel.py")):
+        spec = importlib.util.spec_from_file_location(name if name == "generate_mesh" else "ref_runModel", os.path.join(REF, rel))
+        m = importlib.util.module_from_spec(spec)
+        if name == "generate_mesh":
+            sys.modules["generate_mesh"] = m   # runModel does `import generate_mesh as gm`
+        spec.loader.exec_module(m)
+        mods[name] = m
+    return mods
+
+
+def small_3dt(n_points=60, seed=17):
+    """the arrays of a `<gtfile>_3dt.npz` (processing/generate_mesh.py:78-84) for a seeded Delaunay scene: vertices, finite
+    tetrahedra, every facet once with its two cells (finite-cell numbering, -1 = the infinite side), plus the per-cell
+    `infinite` flag in the graph's cell order (finite cells first, one infinite cell per hull facet)."""
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(seed)
+    pts = rng.random((n_points, 3))
+    tri = Delaunay(pts)
+    simp, nbr = tri.simplices.astype(np.int64), tri.neighbors.astype(np.int64)
+    facets, nfacets = [], []
+    for c in range(simp.shape[0]):
+        for k in range(4):
+            o = nbr[c, k]
+            if o < 0 or c < o:
+                facets.append(np.delete(simp[c], k))
+                nfacets.append((c, o if o >= 0 else -1))
+    n_inf = int((nbr < 0).sum())
+    infinite = np.concatenate([np.zeros(simp.shape[0], np.int32), np.ones(n_inf, np.int32)])
+    return dict(vertices=pts, tetrahedra=simp.astype(np.int32), facets=np.asarray(facets, np.int32),
+                nfacets=np.asarray(nfacets, np.int32), infinite=infinite)
+
+
+def genmesh_fixture(host):
+    """Row 8f-4: the reference's generate(data, prediction, clf) (graph cut off, no metrics) on a small scene; the stub Trimesh
+    records the vertices and the interface triangles the reference hands it (:107)."""
+    gm = host["generate_mesh"]
+    t = small_3dt()
+    n = t["infinite"].shape[0]
+    g = torch.Generator().manual_seed(23)
+    prediction = torch.randn(n, 2, generator=g)
+    prediction[::7] = 0.5                       # exact ties -> class 0, as argmax does
+    d = tempfile.mkdtemp(prefix="genmesh_")
+    os.makedirs(os.path.join(d, "gt"))
+    np.savez(os.path.join(d, "gt", "0_3dt.npz"), vertices=t["vertices"], tetrahedra=t["tetrahedra"], facets=t["facets"], nfacets=t["nfacets"])
+    data = AD(path=d, gtfile="gt/0", filename="0", id="", category="", infinite=torch.from_numpy(t["infinite"]))
+    out = {}
+    for fix in (0, 1):
+        clf = AD(temp=AD(graph_cut=0, fix_orientation=fix, metrics=[]))
+        mesh, ev = gm.generate(data, prediction.clone(), clf)
+        assert ev == {} and mesh.process is True and bool(getattr(mesh, "fix_normals_called", False)) == bool(fix)
+        out["faces_fix%d" % fix] = mesh.faces
+        out["vertices_out"] = mesh.vertices
+    assert np.array_equal(out["faces_fix0"], out["faces_fix1"])
+    # graph cut requested but unavailable: the reference warns and falls back to the raw labels (:88-91)
+    mesh, _ = gm.generate(data, prediction.clone(), AD(temp=AD(graph_cut=1, fix_orientation=0, metrics=[])))
+    assert np.array_equal(mesh.faces, out["faces_fix0"])
+    np.savez_compressed(os.path.join(HERE, "genmesh_f4_small.npz"), prediction=prediction.numpy(), faces=out["faces_fix0"],
+                        vertices_out=out["vertices_out"], **t)
+    print("genmesh: %d cells, %d facets, %d interface triangles" % (n, t["facets"].shape[0], out["faces_fix0"].shape[0]))
+
+
+def trainer_fixture(ref, host, sd):
+    """Row 8f-2: Trainer.calcLossAndOA (:163-259; kl / bce / mse x cell_norm None / log / sqrt), calcRegularization (:109-160; both
+    branches), adjust_learning_rate (:95-99) and three Trainer.train steps (:264-282, Adam) of the reference itself."""
+    rm = host["runModel"]
+    from collections import namedtuple
+    Adj = namedtuple("Adj", ["edge_index", "e_id", "size"])   # PyG's EdgeIndex triple: the reference reads .size / .edge_index
+    g = torch.Generator().manual_seed(31)
+    n = 157
+    gt = torch.rand(n, 4, generator=g)
+    gt[:, 1] = 1 - gt[:, 0]
+    gt[::9, 0], gt[::9, 1] = 0.5, 0.5                              # ties in the OA comparison
+    gt[:, 3] = (torch.rand(n, generator=g) < 0.4).float()           # graph-cut label column of the bce loss
+    bx = torch.rand(n, 29, generator=g)
+    bx[:, 0] = torch.exp(3 * torch.randn(n, generator=g))           # cell volumes over several decades
+    out = dict(batch_gt=gt.numpy(), batch_x=bx.numpy())
+    model = AD(num_layers=4)
+    tr = rm.Trainer(model)
+    for loss_name, cols in (("kl", 2), ("bce", 1), ("mse", 1)):
+        logits0 = torch.randn(n, cols, generator=g) * 2
+        out["logits_%s" % loss_name] = logits0.numpy()
+        for norm in (None, "log", "sqrt"):
+            clf = AD(training=AD(loss=loss_name), regularization=AD(cell_type=1, cell_norm=norm, edge_epoch=None),
+                     temp=AD(device="cpu", current_epoch=1), graph=AD(additional_num_hops=0))
+            logits = logits0.clone().requires_grad_(True)
+            m = rm.Metrics()
+            data = AD(batch_gt=gt, batch_x=bx, batch_adjs=[])
+            loss = tr.calcLossAndOA(logits, None, data, clf, m)
+            loss.backward()
+            tag = "%s_%s" % (loss_name, norm)
+            out["loss_" + tag] = np.asarray(loss.item(), np.float64)
+            out["grad_" + tag] = logits.grad.numpy()
+            out["metrics_" + tag] = np.asarray([m.OA_sum, m.samples_sum, m.cell_sum, m.weight_sum], np.float64)
+            if loss_name != "mse":
+                out["OA_" + tag] = np.asarray(m.getOA(), np.float64)
+            out["cellloss_" + tag] = np.asarray(m.getCellLoss(), np.float64)
+    # regulariser: sampled-batch branch (extra hop's block) and whole-graph branch
+    n_in = 90
+    ei = torch.randint(0, n_in, (2, 300), generator=g)
+    adjs = [Adj(None, None, (0, 0))] * 4 + [Adj(ei, None, (n_in, 40))]
+    logits0 = torch.randn(n, 2, generator=g)
+    out["reg_logits"], out["reg_edge_index"], out["reg_n_inner"] = logits0.numpy(), ei.numpy(), np.asarray(n_in)
+    for tag, data in (("batch", AD(batch_gt=gt, batch_x=bx, batch_adjs=adjs)),
+                      ("whole", AD(batch_gt=gt, batch_x=bx, batch_adjs=[], edge_index=torch.randint(0, n, (2, 500), generator=g)))):
+        clf = AD(training=AD(loss="kl"), regularization=AD(cell_type=1, cell_norm=None, edge_epoch=2, edge_weight=0.37),
+                 temp=AD(device="cpu", current_epoch=3), graph=AD(additional_num_hops=1))
+        if tag == "whole":
+            out["reg_whole_edge_index"] = data.edge_index.numpy()
+        logits = logits0.clone().requires_grad_(True)
+        m = rm.Metrics()
+        reg = tr.calcRegularization(logits, data, clf, m)
+        out["reg_" + tag] = np.asarray(reg.item(), np.float64)
+        out["reg_metrics_" + tag] = np.asarray([m.reg_sum, m.edges_sum, m.getRegLoss()], np.float64)
+        logits = logits0.clone().requires_grad_(True)
+        m = rm.Metrics()
+        total = tr.calcLossAndOA(logits, None, data, clf, m)
+        total.backward()
+        out["total_" + tag] = np.asarray(total.item(), np.float64)
+        out["total_grad_" + tag] = logits.grad.numpy()
+        clf.temp.current_epoch = 1   # before edge_epoch: no regulariser
+        m = rm.Metrics()
+        out["total_early_" + tag] = np.asarray(tr.calcLossAndOA(logits0.clone(), None, data, clf, m).item(), np.float64)
+    # lr schedule
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=1.0)
+    lrs = []
+    for ep in range(1, 26):
+        clf = AD(training=AD(learning_rate=0.005, adjust_lr_every=10), temp=AD(current_epoch=ep))
+        rm.adjust_learning_rate(opt, clf)
+        lrs.append(opt.param_groups[0]["lr"])
+    out["lr_by_epoch"] = np.asarray(lrs, np.float64)
+    # three optimisation steps of the reference's Trainer.train on the F3 blocks (reference model, shipped weights, Adam lr 0.005)
+    f3 = np.load(os.path.join(HERE, "static_f3_train_blocks.npz"))
+    x3, ea3 = torch.from_numpy(f3["x"]), torch.from_numpy(f3["edge_attr"])
+    adjs3 = [Adj(torch.from_numpy(f3["adj%d_edge_index" % i]), torch.from_numpy(f3["adj%d_e_id" % i]),
+                 tuple(int(v) for v in f3["adj%d_size" % i])) for i in range(4)]
+    y3 = torch.rand(x3.shape[0], 2, generator=g)
+    y3[:, 1] = 1 - y3[:, 0]
+    clf = static_clf()
+    net = ref["surfaceNetStaticEdgeFilters"].SurfaceNet(clf)
+    net.load_state_dict(sd)
+    tr = rm.Trainer(net)
+    tclf = AD(model=AD(edge_prediction=0), training=AD(loss="kl", metrics=rm.Metrics()),
+              regularization=AD(cell_type=1, cell_norm=None, edge_epoch=None), temp=AD(device="cpu", current_epoch=1),
+              graph=AD(additional_num_hops=0))
+    opt = torch.optim.Adam(net.parameters(), lr=0.005)
+    losses = []
+    for step in range(3):
+        data = AD(all=AD(x=x3, edge_attr=ea3, y=y3), batch_n_id=torch.from_numpy(f3["n_id"]), batch_adjs=adjs3)
+        tclf.training.metrics = rm.Metrics()
+        tr.train(data, opt, tclf)
+        losses.append(tclf.training.metrics.getCellLoss())
+    out["train_y"] = y3.numpy()
+    out["train_losses"] = np.asarray(losses, np.float64)
+    out["train_OA_last"] = np.asarray(tclf.training.metrics.getOA(), np.float64)
+    for k in ("convs.0.conv.lin_j.weight", "convs.3.conv.lin_e.bias", "decoder.3.weight", "convs.1.norm.module.running_mean"):
+        out["train_param." + k] = net.state_dict()[k].numpy()
+    np.savez_compressed(os.path.join(HERE, "trainer_f2.npz"), **out)
+    print("trainer: losses", losses, "lr", lrs[0], lrs[10], lrs[20])
+
+
+def round3():
+    torch.manual_seed(0)
+    torch.set_num_threads(1)
+    ref = load_ref()
+    host = load_ref_host()
+    sd = torch.load(os.path.join(REF, "data/models/kf96/model_best.ptm"), map_location="cpu")
+    genmesh_fixture(host)
+    trainer_fixture(ref, host, sd)
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["ingest"]:      # only the 8f-3 fixture (independent seed)
         ingest_fixture(np.random.default_rng(5))
+    elif sys.argv[1:] == ["round3"]:    # only the fixtures added in round 3 (8f-2 trainer, 8f-4 interface; reference host code under stubs)
+        round3()
     elif sys.argv[1:] == ["round2"]:    # only the fixtures added in round 2 (F4 full Ignatius scene, F5 layer_batch)
         torch.set_num_threads(1)
         _ref = load_ref()
@@ -481,3 +684,4 @@ if __name__ == "__main__":
         _sd = torch.load(os.path.join(REF, "data/models/kf96/model_best.ptm"), map_location="cpu")
         ignatius_full(_ref, _sd)
         layer_batch_fixture(_ref, _sd)
+        round3()
