@@ -376,23 +376,34 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         const int own = i0 + (tl < nv1 ? tl : nv1 - 1);
         // all index shuffles first, then every row offset under ONE wave-uniform choice of shift / multiply, then the loads back to back
         // (a per-row choice compiles to a branch and an LDS wait in front of every pair of loads)
-        if (part != 1) {
+        constexpr bool BATCH = !(DSP == 3 && CIN_PAD == 128);  // the bf16 x 3 form at 128 -> 128 has no registers for five offsets at once (2 spills)
+        auto off_of = [&](int row) -> uint32_t { return ldx_sh >= 0 ? (uint32_t)row << ldx_sh : (uint32_t)(row * ldx32); };
+        if constexpr (BATCH) {
+            if (part != 1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sidx[rb][r] = (DGNN_WHATIF & 8) ? own : __shfl(vsrc1, tl * 4 + r);
-        }
-        uint32_t off[5];
-        if (ldx_sh >= 0) {
-            off[4] = (uint32_t)own << ldx_sh;
+                for (int r = 0; r < 4; ++r) sidx[rb][r] = (DGNN_WHATIF & 8) ? own : __shfl(vsrc1, tl * 4 + r);
+            }
+            uint32_t off[5];
+            if (ldx_sh >= 0) {
+                off[4] = (uint32_t)own << ldx_sh;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) off[r] = (uint32_t)sidx[rb][r] << ldx_sh;
+                for (int r = 0; r < 4; ++r) off[r] = (uint32_t)sidx[rb][r] << ldx_sh;
+            } else {
+                off[4] = (uint32_t)(own * ldx32);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) off[r] = (uint32_t)(sidx[rb][r] * ldx32);
+            }
+            ld_vec<NB, part>(xd[rb], xdst + off[4] + c0l, vec);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ld_vec<NB, part>(xr[rb][r], x + off[r] + c0l, vec);
         } else {
-            off[4] = (uint32_t)(own * ldx32);
+            ld_vec<NB, part>(xd[rb], xdst + off_of(own) + c0l, vec);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) off[r] = (uint32_t)(sidx[rb][r] * ldx32);
+            for (int r = 0; r < 4; ++r) {
+                if (part != 1) sidx[rb][r] = (DGNN_WHATIF & 8) ? own : __shfl(vsrc1, tl * 4 + r);
+                ld_vec<NB, part>(xr[rb][r], x + off_of(sidx[rb][r]) + c0l, vec);
+            }
         }
-        ld_vec<NB, part>(xd[rb], xdst + off[4] + c0l, vec);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ld_vec<NB, part>(xr[rb][r], x + off[r] + c0l, vec);
     };
     auto issue_ea = [&](int64_t it) {
         if (!regular || (DGNN_WHATIF & 16)) return;
@@ -400,21 +411,25 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         // fetched from its place in the caller's edge_attr (row eid[k]) -- no staging copy of the edge features.
         if (eid) {
             // float index within the strip -> (edge of the wave, offset in its row); the edge ids are shuffled in one batch
-            const float* gp[C::EA_FULL + C::EA_TAIL];
-            int er[C::EA_FULL + C::EA_TAIL], fo[C::EA_FULL + C::EA_TAIL];
-#pragma unroll
-            for (int q = 0; q < C::EA_FULL + C::EA_TAIL; ++q) {
-                const int fi = q < C::EA_FULL ? q * 256 + lane * 4 : C::EA_FULL * 256 + (q - C::EA_FULL) * 64 + lane;
+            auto row_ptr = [&](int fi) -> const float* {
                 const int e = (fi * 0xCCD) >> 16;  // fi / 20 for fi < 8192
-                fo[q] = fi - e * FE;
-                er[q] = __shfl(veid1, e);
+                return ea + (int64_t)__shfl(veid1, e) * FE + (fi - e * FE);
+            };
+            if constexpr (DSP == 3 && CIN_PAD == 128) {  // no registers to hold all addresses at once
+#pragma unroll
+                for (int q = 0; q < C::EA_FULL; ++q) glds16_s(row_ptr(q * 256 + lane * 4), myea + q * 256);
+#pragma unroll
+                for (int q = 0; q < C::EA_TAIL; ++q) glds4_s(row_ptr(C::EA_FULL * 256 + q * 64 + lane), myea + C::EA_FULL * 256 + q * 64);
+            } else {
+                const float* gp[C::EA_FULL + C::EA_TAIL];
+#pragma unroll
+                for (int q = 0; q < C::EA_FULL + C::EA_TAIL; ++q)
+                    gp[q] = row_ptr(q < C::EA_FULL ? q * 256 + lane * 4 : C::EA_FULL * 256 + (q - C::EA_FULL) * 64 + lane);
+#pragma unroll
+                for (int q = 0; q < C::EA_FULL; ++q) glds16_s(gp[q], myea + q * 256);
+#pragma unroll
+                for (int q = 0; q < C::EA_TAIL; ++q) glds4_s(gp[C::EA_FULL + q], myea + C::EA_FULL * 256 + q * 64);
             }
-#pragma unroll
-            for (int q = 0; q < C::EA_FULL + C::EA_TAIL; ++q) gp[q] = ea + (int64_t)er[q] * FE + fo[q];
-#pragma unroll
-            for (int q = 0; q < C::EA_FULL; ++q) glds16_s(gp[q], myea + q * 256);
-#pragma unroll
-            for (int q = 0; q < C::EA_TAIL; ++q) glds4_s(gp[C::EA_FULL + q], myea + C::EA_FULL * 256 + q * 64);
         } else {
             const float* eab = ea + (int64_t)__builtin_amdgcn_readfirstlane(vbeg1) * lde;
             const int ea_last = nv1 * 4 * FE - 4;  // last 16-byte chunk of the group's attribute block
