@@ -294,7 +294,12 @@ class SurfaceNet(nn.Module):
         cache[id(bn)] = (key, out)
         return out
 
-    def _eval_layers(self, x, n_dst0, xe, plans, sorted_attr, only=None, out=None, rows=None):
+    def fuses_decoder(self, i):
+        """True when layer i's launch also carries the decoder (the last conv layer of the shipped widths, fp32 storage: the finished tile goes
+        through Linear-BN-ReLU-Linear in the same kernel and only the logits are written, reference :180-187 applied at :350-351)"""
+        return False
+
+    def _eval_layers(self, x, n_dst0, xe, plans, sorted_attr, only=None, out=None, rows=None, decode=False):
         """Eval-mode conv stack: per layer one fused launch when the widths allow it, else the
         aggregate + linear pair; BatchNorm(eval) and ReLU always ride in the GEMM epilogue.
         `sorted_attr`: True = xe rows follow the caller's edge_index order (gathered by eid in the kernel or staged once),

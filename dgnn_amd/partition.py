@@ -236,12 +236,14 @@ class PartitionedScene:
         self._xe_stripped = None
 
     @staticmethod
-    def build_synthetic(points: int, seed: int, rank: int, world: int, device) -> "PartitionedScene":
+    def build_synthetic(points: int, seed: int, rank: int, world: int, device, keep_global: bool = False) -> "PartitionedScene":
         """The seeded Delaunay scene of bench.py cut into `world` parts.  Rank 0 runs the tetrahedralisation and the
         coordinate bisection ONCE and broadcasts the adjacency column and the owner map (two int32 arrays) when a process
         group exists -- every rank repeating scipy.spatial.Delaunay on the whole scene costs minutes at 10M tets; without
         a process group (tests, world == 1) the rank builds them itself.  Each rank then derives its own index structures
-        and materialises only the feature rows it needs (hashed N(0,1) values, identical across ranks for shared rows)."""
+        and materialises only the feature rows it needs (hashed N(0,1) values, identical across ranks for shared rows).
+        `keep_global`: the whole scene's adjacency column (int32 [4N]) stays attached as `scene.global_dst` (bench.py's check at N > 1 runs
+        the same scene as one graph on rank 0)."""
         import torch.distributed as dist
         from .synthetic import delaunay_tet_graph, hashed_normal
         shared = world > 1 and dist.is_available() and dist.is_initialized()
@@ -271,7 +273,9 @@ class PartitionedScene:
         rows = np.concatenate([lp.own_gid, lp.halo_gid])
         x_local = hashed_normal(rows, 29, seed=1, device=device)
         ea_local = hashed_normal(lp.edge_gid, 20, seed=2, device=device)
-        return PartitionedScene(lp, x_local, ea_local, device)
+        scene = PartitionedScene(lp, x_local, ea_local, device)
+        scene.global_dst = np.ascontiguousarray(dst, dtype=np.int32) if keep_global else None
+        return scene
 
     @torch.no_grad()
     def inference_layer(self, net, rebuild_plan: bool = True) -> torch.Tensor:

@@ -1,0 +1,125 @@
+"""The multi-rank entry points as the driver launches them -- `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` -- run as
+fresh child processes on the test box's single GPU (DGNN_BENCH_BACKEND=gloo: the ranks share the device, halo rows / gradients are staged through
+host memory; the stream choreography, the partition, the plan builder and every kernel are the product's), and BASELINE config 4 at its size:
+the 10 026 136-tet scene cut 8 ways, ranks emulated in one process, against the whole-graph run."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from dgnn_amd.config import Config
+from test_gpu_parity import DEV, hip_static
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def torchrun(script, args, nproc=2, timeout=900):
+    env = dict(os.environ, DGNN_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), script] + args
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_bench_py_two_ranks_as_the_driver_launches_it(scaling):
+    """bench.py --gpus 2: ONE JSON line from rank 0, the contract's keys, and a `check` at N > 1: the logits of both ranks' cells, gathered on rank 0,
+    are bit-identical to the same scene run as one whole graph by a single rank and agree with the CPU oracle; the other scaling mode is nested
+    with its own check."""
+    d = torchrun("bench.py", ["--gpus", "2", "--scaling", scaling, "--steps", "2", "--warmup", "1", "--no-train", "--points", "30000"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "check", "other_scaling"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == scaling and d["unit"] == "tets/s" and d["vs_baseline"] is None
+    n_one = 201062                                     # 30000 points
+    n_main = d["check"]["n_tets"]
+    assert (n_main == n_one) == (scaling == "strong") and abs(d["value"] - n_main / d["ms_per_step"] * 1e3) <= 1e-3 * d["value"]
+    c = d["check"]
+    assert c["ok"] and c["bit_identical_to_single_rank"] and c["cells_covered"] == n_main and c["max_abs_diff_vs_single_rank"] == 0.0
+    assert c["vs_cpu_oracle"]["ok"] and c["vs_cpu_oracle"]["max_abs_err"] <= 1e-4
+    o = d["other_scaling"]
+    assert o["scaling"] == ("weak" if scaling == "strong" else "strong") and o["check"]["ok"] and o["check"]["bit_identical_to_single_rank"]
+    assert "host-staged gloo" in d["config"]["workload"]          # says what it was: a validation run, not a benchmark
+    assert 0.2 < d["config"]["tets_per_gpu"] / (n_main / 2) < 1.8
+
+
+@pytest.mark.parametrize("extra", [["--updated"], ["--updated", "--dtype", "bf16"], []])
+def test_bench_train_two_ranks_data_parallel(extra):
+    """BASELINE config 5's shape of work at world 2 (UpdatedEdgeFilters, one scene shard per rank, one flat all-reduce per step; also the Static
+    model): the launch line of the driver, replicas equal after the all-reduced steps, finite loss"""
+    d = torchrun(os.path.join("tools", "bench_train.py"), ["--gpus", "2", "--points", "12000", "--batch", "256", "--steps", "4", "--warmup", "3", "--no-roofline"] + extra)
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and np.isfinite(d["final_loss"]) and d["final_loss"] > 0
+    assert d["replicas"]["equal"], d["replicas"]
+    assert ("Updated" in d["model"]) == ("--updated" in extra)
+
+
+def test_config4_10m_tets_eight_parts_equal_the_whole_graph():
+    """BASELINE config 4 at its size on ONE GPU: the 1 485 000-point scene (10 026 136 tets) resident in HBM, rcb_partition(.., 8), every part's
+    layers run as the partitioned forward runs them (interior cells, then boundary cells, halo rows delivered as the exchange delivers them) --
+    the union of the 8 parts' logits must equal the whole-graph inference_layer BIT FOR BIT; halo sizes against SURVEY 8e's estimate."""
+    from dgnn_amd.graph import GraphPlan
+    from dgnn_amd.partition import build_local_part, rcb_partition
+    from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal
+    world = 8
+    adj, cent, _ = delaunay_tet_graph(1485000, 0)
+    n = adj.shape[0] // 4
+    assert n == 10026136
+    ei = np.empty((2, 4 * n), np.int64)
+    ei[0] = np.repeat(np.arange(n, dtype=np.int64), 4)
+    ei[1] = adj[:, 1]
+    del adj
+    x = hashed_normal(np.arange(n), 29, seed=1, device=DEV)
+    ea = hashed_normal(np.arange(4 * n), 20, seed=2, device=DEV)
+    net = hip_static()
+    ei_d = torch.from_numpy(ei).to(DEV)
+    full = net.inference_layer(Config(x=x, edge_attr=ea, edge_index=ei_d))
+    del ei_d
+    part = rcb_partition(cent, world)
+    lps = [build_local_part(ei, part, r, world) for r in range(world)]
+    del ei
+    # ~1.25M cells per rank, halo ~1.7 % of the owned rows (3.65 % at 1M tets scaled by 10^(-1/3)), every cell owned exactly once
+    assert sum(lp.n_own for lp in lps) == n
+    for lp in lps:
+        assert abs(lp.n_own - n / world) <= 2 and 0.008 <= lp.n_halo / lp.n_own <= 0.03, (lp.n_own, lp.n_halo)
+        assert sum(lp.send_counts) > 0 and lp.n_interior / lp.n_own > 0.93
+    print("halo rows per rank:", [lp.n_halo for lp in lps], "= %.2f %% of the owned rows" % (100 * np.mean([lp.n_halo / lp.n_own for lp in lps])))
+    plans = [GraphPlan(torch.from_numpy(lp.edge_index).to(DEV), lp.n_own + lp.n_halo, lp.n_own, hint=1) for lp in lps]
+    eas = [ea[torch.from_numpy(lp.edge_gid).to(DEV)] for lp in lps]     # a rank's edge rows, already in plan order
+    del ea
+    hs = [x[torch.from_numpy(np.concatenate([lp.own_gid, lp.halo_gid])).to(DEV)][:, 1:] for lp in lps]
+    del x
+    widths = [64, 128, 128, 128]
+    own = [torch.from_numpy(lp.own_gid).to(DEV) for lp in lps]
+    halo = [torch.from_numpy(lp.halo_gid).to(DEV) for lp in lps]
+    for i in range(net.num_layers):
+        bufs = []
+        for r, lp in enumerate(lps):
+            buf = torch.full((lp.n_own + lp.n_halo, widths[i]), float("nan"), device=DEV)
+            for b, e in ((0, lp.n_interior), (lp.n_interior, lp.n_own)):
+                net._eval_layers(hs[r], lp.n_own, eas[r], [plans[r]] * 4, False, only=i, out=buf, rows=(b, e))
+            bufs.append(buf)
+        glob = torch.empty(n, widths[i], device=DEV)
+        for r in range(world):
+            glob[own[r]] = bufs[r][:lps[r].n_own]
+        for r in range(world):           # what the exchange delivers
+            bufs[r][lps[r].n_own:] = glob[halo[r]]
+        del glob
+        hs = bufs
+    logits = torch.full((n, 2), float("nan"), device=DEV)
+    for r in range(world):
+        logits[own[r]] = net._eval_decoder(hs[r][:lps[r].n_own])
+    assert torch.equal(logits, full)

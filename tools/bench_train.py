@@ -187,6 +187,13 @@ def replay_roofline():
                      "peak_note": "dense bf16 MFMA 2.5 PFLOP/s / 6 partial products per fp32-class product; launches of 2k..70k rows are latency-bound"}}
 
 
+replicas = None
+if world > 1:
+    # data-parallel replicas must hold the same weights after every all-reduced step: one fp64 checksum per rank, compared on rank 0
+    cs = torch.stack([p.detach().double().abs().sum() for p in net.parameters()]).sum().reshape(1).cpu()
+    sums = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(sums, cs, group=dist.new_group(backend="gloo"))
+    replicas = {"param_abs_sum_per_rank": [float(v) for v in sums], "equal": all(float(v) == float(sums[0]) for v in sums)}
 roof = None
 if rank == 0 and not args.no_roofline and not args.updated and args.dtype == "f32":
     roof = replay_roofline()
@@ -196,6 +203,6 @@ if rank == 0:
                       "parallelism": "data-parallel replicas, one scene shard per GPU, flat RCCL all-reduce" if world > 1 else "single GPU",
                       "targets_per_s": round(batch * steps * world / dt, 1), "block_tets_per_s": round(block / dt, 1),
                       "ms_per_step": round(dt / steps * 1e3, 3), "batch_targets_per_gpu": batch,
-                      "avg_block_tets": round(block / steps / world, 1), "steps": steps, "block_builder": args.prefetch, "scene_tets_per_gpu": n, "final_loss": float(loss), "roofline": roof}))
+                      "avg_block_tets": round(block / steps / world, 1), "steps": steps, "block_builder": args.prefetch, "scene_tets_per_gpu": n, "final_loss": float(loss), "replicas": replicas, "roofline": roof}))
 if world > 1:
     dist.destroy_process_group()
