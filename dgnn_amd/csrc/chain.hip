@@ -32,7 +32,13 @@ __global__ void k_chain_map(const int64_t* __restrict__ e_cur, int64_t n_cur, in
             dgnn_raise_async(aflag, DGNN_ASYNC_OTHER_RANGE);
             continue;
         }
-        pos[e] = value_is_index ? (int32_t)k : -1;
+        // PRECONDITION: the ids of a block's e_id are unique (PyG's NeighborSampler and dgnn_khop_* emit every edge once).  A duplicate would keep
+        // one position and drop the other's gradient in the backward pass -- it is reported through the asynchronous error word instead.
+        if (value_is_index) {
+            if (atomicExch(&pos[e], (int32_t)k) >= 0) dgnn_raise_async(aflag, DGNN_ASYNC_DUPLICATE);
+        } else {
+            pos[e] = -1;
+        }
     }
 }
 
@@ -60,7 +66,7 @@ __global__ void k_chain_gather(const T* __restrict__ phi, int64_t ldphi, int c, 
                 for (int q = 0; q < V; ++q)
                     if (!positive(dgnn_ld(&o.v[q]))) o.v[q] = T(0);
             }
-            if (j == 0) inv[row] = (int32_t)k;
+            if (j == 0 && atomicExch(&inv[row], (int32_t)k) >= 0) dgnn_raise_async(aflag, DGNN_ASYNC_DUPLICATE);   // e_id_next names this edge twice
         } else {
 #pragma unroll
             for (int q = 0; q < V; ++q) o.v[q] = T(0);

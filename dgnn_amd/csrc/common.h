@@ -40,9 +40,9 @@ static inline void dgnn_allow_dynamic_lds(const void* kernel, size_t bytes, bool
         (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         return;
     }
-    if (!done[dev]) {
+    if (!__atomic_load_n(&done[dev], __ATOMIC_ACQUIRE)) {   // two threads may both set it (idempotent); neither may see `done` before the attribute is set
         (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        done[dev] = true;
+        __atomic_store_n(&done[dev], true, __ATOMIC_RELEASE);
     }
 }
 
@@ -52,6 +52,7 @@ static inline void dgnn_allow_dynamic_lds(const void* kernel, size_t bytes, bool
 // sync) turns it into DGNN_E_INDEX.  Like HIP's own asynchronous errors it surfaces at a later call, not at the launch.
 #define DGNN_ASYNC_KEY_RANGE 1   /* plan_build: sort-key endpoint outside [0, n_key) */
 #define DGNN_ASYNC_OTHER_RANGE 2 /* plan_build: other endpoint outside [0, n_other) */
+#define DGNN_ASYNC_DUPLICATE 4   /* edge_chain: an edge id occurs twice in e_id_cur / e_id_next (the one-to-one maps of chain.hip need unique ids) */
 int32_t* dgnn_async_flag_dev();  // device-visible pointer, NULL if pinned memory is unavailable (then errors are only skipped)
 __device__ __forceinline__ void dgnn_raise_async(int32_t* flag, int32_t bits) {
     if (flag) atomicOr(flag, bits);

@@ -14,6 +14,7 @@
 #include <stdarg.h>
 
 #include "common.h"
+#include <mutex>
 
 static thread_local char g_err[512] = "ok";
 void dgnn_set_error(const char* fmt, ...) {
@@ -27,9 +28,9 @@ extern "C" const char* dgnn_last_error_string(void) { return g_err; }
 static int32_t* g_async_host = nullptr;
 static int32_t* g_async_dev = nullptr;
 int32_t* dgnn_async_flag_dev() {
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    // first use may come from the Python thread and from the library's block-builder thread at once
+    static std::once_flag once;
+    std::call_once(once, [] {
         void* h = nullptr;
         if (hipHostMalloc(&h, 64, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess && h) {
             *reinterpret_cast<volatile int32_t*>(h) = 0;
@@ -42,7 +43,7 @@ int32_t* dgnn_async_flag_dev() {
             }
         }
         (void)hipGetLastError();
-    }
+    });
     return g_async_dev;
 }
 extern "C" int dgnn_poll_async_error(void) {
@@ -52,6 +53,10 @@ extern "C" int dgnn_poll_async_error(void) {
     dgnn_set_error("asynchronous kernel error 0x%x:%s%s (edges with such endpoints were skipped; the reference's scatter raises an "
                    "index error for them)", bits, (bits & DGNN_ASYNC_KEY_RANGE) ? " edge_index sort-key endpoint out of range;" : "",
                    (bits & DGNN_ASYNC_OTHER_RANGE) ? " edge_index other endpoint out of range;" : "");
+    if (bits & DGNN_ASYNC_DUPLICATE)
+        dgnn_set_error("asynchronous kernel error 0x%x: edge_chain: an edge id occurs more than once in e_id_cur / e_id_next of a block; the sparse chaining "
+                       "keeps one position per edge (the reference's index / scatter autograd would sum the duplicates' gradients) -- use DGNN_CHAIN_DENSE=1 "
+                       "for such blocks", bits);
     return DGNN_E_INDEX;
 }
 extern "C" int dgnn_version(void) { return DGNN_VERSION; }

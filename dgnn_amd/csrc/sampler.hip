@@ -222,6 +222,16 @@ bool slots_init() {
     return ok;
 }
 
+inline void cpu_relax() {   // spin-wait hint of the host architecture (the library also builds on non-x86 hosts)
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
+}
+
 struct Mailbox {   // one slot for the duration of a call
     int idx = -1;
     Mailbox() {
@@ -256,9 +266,11 @@ bool read_back(const int32_t* dev_value, int32_t* out, const Mailbox& mb, hipStr
                     *out = s->value;
                     return true;
                 }
-                __builtin_ia32_pause();
+                cpu_relax();
                 if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;   // a hung queue
             }
+            // timed out: the queued k_publish still targets this slot.  It is only handed back (Mailbox destructor) after the stream has drained,
+            // which the synchronising copy below does before this function returns.
         }
     }
     return hipMemcpyAsync(out, dev_value, sizeof(int32_t), hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;

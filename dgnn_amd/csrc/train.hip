@@ -123,10 +123,14 @@ hipEvent_t next_event(Aux* a) {
 // OFF by default: interleaved A/B runs (tools/ab_train.py aux=1 aux=0) put the two-stream backward 2-8 % BEHIND the one-stream one --
 // the event hand-offs cost what the overlap of ~10 us kernels buys.  Kept as an option (DGNN_TRAIN_AUX_STREAM=1,
 // dgnn_train_set_aux_stream) because the balance shifts with block size.
-int g_aux_on = -1;
+int g_aux_on = -1;   // read / written with atomics: the first call may race between the caller's thread and the block-builder thread
 bool aux_enabled() {
-    if (g_aux_on < 0) g_aux_on = (getenv("DGNN_TRAIN_AUX_STREAM") && getenv("DGNN_TRAIN_AUX_STREAM")[0] == '1') ? 1 : 0;
-    return g_aux_on != 0;
+    int v = __atomic_load_n(&g_aux_on, __ATOMIC_ACQUIRE);
+    if (v < 0) {
+        v = (getenv("DGNN_TRAIN_AUX_STREAM") && getenv("DGNN_TRAIN_AUX_STREAM")[0] == '1') ? 1 : 0;
+        __atomic_store_n(&g_aux_on, v, __ATOMIC_RELEASE);
+    }
+    return v != 0;
 }
 // partial-sum scratch of one layer's backward on the main stream (column reductions, aggregate backward slabs; also the weight
 // gradients when there is no second stream)
@@ -155,7 +159,7 @@ int layer_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
                   : dgnn_linear_fwd(A, lda, k, W, ldw, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, flags, M, n, out, ldo, stream_);
     };
     void* wstream = aux ? (void*)aux->stream : stream_;
-    float* wtmp = aux ? tmp_w : tmp;
+    float* wtmp = tmp_w;   // always the region that both callers size for the weight-gradient partials (`tmp` is sized for the main chain's only)
     auto wgrad = [&](const float* A, int64_t lda, int na, const float* B, int64_t ldb, int nb, float* dW) {
         return x3 ? dgnn_linear_wgrad_x3(A, lda, na, B, ldb, nb, n_dst, dW, nb, 0, wtmp, wstream)
                   : dgnn_linear_wgrad(A, lda, na, B, ldb, nb, n_dst, dW, nb, 0, wtmp, wstream);
@@ -531,7 +535,7 @@ extern "C" int dgnn_static_train_bwd(int n_layers, const int32_t* const* t_rowpt
 // Whether the composite backward entry points run the weight gradients on the library's second stream (default: no).
 extern "C" int dgnn_train_set_aux_stream(int on) {
     const int was = aux_enabled() ? 1 : 0;
-    g_aux_on = on ? 1 : 0;
+    __atomic_store_n(&g_aux_on, on ? 1 : 0, __ATOMIC_RELEASE);
     return was;
 }
 

@@ -138,7 +138,7 @@ class _SageTrainLayer(torch.autograd.Function):
         # -- the values of edge_attr[e_id] without the per-layer copy
         parts = (plan.rowptr, plan.src, plan.edge_rows if scene_rows else plan.eid) if plan is not None else None
         y, a, z, stats = ops.sage_layer_train_fwd(parts, n_dst, x, edge_attr, We, be, Wj, bj, Wi, gamma, beta, bn.running_mean, bn.running_var,
-                                                  bn.momentum if bn.momentum is not None else 0.1, bn.eps, relu)
+                                                  bn.momentum, bn.eps, relu)   # numeric momentum: sage_train_layer_supported
         ctx.plan = plan
         ctx.edge_index = plan.edge_index if plan is not None else None   # the lazily built transposed plan (backward) reads it
         ctx.cfg = (float(bn.eps), bool(relu), bj is not None, bool(scene_rows))
@@ -177,7 +177,8 @@ def sage_train_layer_supported(x, lin_e, bn) -> bool:
     with affine parameters and running buffers; everything else runs through the separate Functions."""
     return (ops.TRAIN_COMPOSITE and x.dtype in ops.ACT and x.dim() == 2 and x.stride(1) == 1 and x.size(0) > 0
             and (lin_e is None or (isinstance(lin_e, torch.nn.Linear) and lin_e.in_features <= 32 and lin_e.bias is not None))
-            and isinstance(bn, torch.nn.BatchNorm1d) and bn.training and bn.affine and bn.running_mean is not None)
+            and isinstance(bn, torch.nn.BatchNorm1d) and bn.training and bn.affine and bn.running_mean is not None
+            and bn.momentum is not None)   # momentum=None (cumulative average, factor 1/num_batches_tracked) runs through batch_norm_act
 
 
 class _StaticTrainModel(torch.autograd.Function):
@@ -312,10 +313,12 @@ def to_bf16(x):
 
 
 def batch_norm_act(x, bn: torch.nn.BatchNorm1d, relu: bool):
+    momentum = bn.momentum if bn.momentum is not None else 0.0
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    return _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training,
-                               bn.momentum if bn.momentum is not None else 0.1, bn.eps, relu)
+        if bn.momentum is None:   # torch.nn.BatchNorm1d: cumulative moving average, factor 1 / num_batches_tracked (after this batch)
+            momentum = 1.0 / float(bn.num_batches_tracked)
+    return _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, momentum, bn.eps, relu)
 
 
 class _ReLU(torch.autograd.Function):

@@ -204,7 +204,10 @@ class Trainer:
         data.validation.all through `inference`; chamfer / iou only when the reference's mesh post-processing imports),
         `models/model_best.ptm` whenever the validation metric improves and `models/model_<epoch>.ptm` every `export_every`
         iterations -- plain state_dicts, exactly what run.py:148-157 / :102-113 load.  Rows of the results table go to
-        clf.files.results (csv) when that is configured.  With `group` (data-parallel replicas) only rank 0 writes."""
+        clf.files.results (csv) when that is configured.  With `group` (data-parallel replicas) only rank 0 writes; every epoch runs as many
+        steps as the rank with the fewest batches has (`_agreed_steps`); parameters are identical on all ranks after every step, BatchNorm
+        running statistics are NOT synchronised (each rank's follow its own shard, as a single process's follow its scene) and the
+        checkpoints hold rank 0's."""
         if not getattr(clf.temp, "device", None):
             clf.temp.device = "cuda:" + str(clf.temp.args.gpu)
         from ..partition import broadcast_parameters
@@ -226,13 +229,18 @@ class Trainer:
         for current_epoch in range(1, clf.training.epochs + 1):
             clf.temp.current_epoch = current_epoch
             adjust_learning_rate(optimizer, clf)
-            for data.train.batch_size, data.train.batch_n_id, data.train.batch_adjs in data.train.batches:
+            for data.train.batch_size, data.train.batch_n_id, data.train.batch_adjs in _agreed_steps(data.train.batches, group):
                 iterations += 1
                 self.train(data.train, optimizer, clf, group)
-                m = clf.training.metrics
-                row.update(iteration=iterations, epoch=current_epoch, train_loss_cell=m.getCellLoss(), train_loss_reg=m.getRegLoss(),
-                           train_loss_total=m.getRegLoss() + m.getCellLoss(), train_OA=m.getOA())
-                if (iterations % clf.training.print_every) == 0 or iterations == 1:
+                printing = (iterations % clf.training.print_every) == 0 or iterations == 1
+                validating = (iterations % clf.training.val_every) == 0 and getattr(data, "validation", None) is not None
+                if printing or validating:
+                    # the running sums live on the device (Metrics): they are read back only at the cadence at which they are consumed, so the
+                    # iterations in between enqueue without draining the GPU (the block builder's prefetch then overlaps them)
+                    m = clf.training.metrics
+                    row.update(iteration=iterations, epoch=current_epoch, train_loss_cell=m.getCellLoss(), train_loss_reg=m.getRegLoss(),
+                               train_loss_total=m.getRegLoss() + m.getCellLoss(), train_OA=m.getOA())
+                if printing:
                     if writer:
                         print('%s[%3d] Epoch %3d -> Train Loss (cell): %1.4f,  Train Loss (reg): %1.4f, Train Loss (total): %1.4f,  Train OA: %3.2f%%'
                               % (datetime.now().strftime("[%H:%M:%S]"), iterations, current_epoch, row['train_loss_cell'],
@@ -313,6 +321,38 @@ class Trainer:
         if clf.training.loss == "mse":
             logits_cell = torch.cat((1 - logits_cell, logits_cell), dim=1)
         return logits_cell.to('cpu')
+
+
+def _agreed_steps(batches, group=None):
+    """Iterates `batches`, but with data-parallel replicas (an initialised process group of more than one rank) only for as many steps as
+    EVERY rank has: each step holds one gradient all-reduce, so a rank whose shard yields more batches than another's would wait in a
+    collective nobody else enters.  With a length the ranks agree on min(len) once per epoch; without one they agree step by step on
+    whether all of them still have a batch (a 1-element all-reduce).  Surplus batches of the longer shards are dropped -- what
+    DistributedSampler(drop_last=True) does.  A single process iterates `batches` unchanged."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        yield from batches
+        return
+    on_gpu = dist.get_backend(group) == "nccl"     # RCCL reduces device tensors only
+    if hasattr(batches, "__len__"):
+        n = torch.tensor([len(batches)], dtype=torch.int64, device="cuda" if on_gpu else "cpu")
+        dist.all_reduce(n, op=dist.ReduceOp.MIN, group=group)
+        steps = int(n.item())
+        it = iter(batches)
+        for _ in range(steps):
+            yield next(it)
+        close = getattr(it, "close", None)
+        if close is not None:
+            close()
+        return
+    it = iter(batches)
+    while True:
+        item = next(it, None)
+        have = torch.tensor([0 if item is None else 1], dtype=torch.int64, device="cuda" if on_gpu else "cpu")
+        dist.all_reduce(have, op=dist.ReduceOp.MIN, group=group)
+        if int(have.item()) == 0:
+            return
+        yield item
 
 
 def load_epoch(model, clf):

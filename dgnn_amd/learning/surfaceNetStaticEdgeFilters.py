@@ -253,7 +253,7 @@ class SurfaceNet(nn.Module):
                              bn=norm.module))
             n_src = size[1]
         if len(dec) == 4:
-            if not dec[1].module.training:
+            if not dec[1].module.training or dec[1].module.momentum is None:
                 return None
             spec.append(dict(plan=None, n_rows=n_src, edge_attr=None, scene_rows=False, lin_e=None, lin_j=dec[0], lin_i=None, bn=dec[1].module))
         h = Fn.static_train_model(x, spec)

@@ -694,7 +694,7 @@ def static_train_fwd(x0, layers):
         key("We"), key("be"), key("Wj"), key("bj"), key("Wi"), key("gamma"), key("beta"),
         _parr([l["bn"].running_mean for l in layers]), _parr([l["bn"].running_var for l in layers]),
         _parr([(l["bn"].num_batches_tracked if l["bn"].track_running_stats else None) for l in layers]),
-        _iarr([(l["bn"].momentum if l["bn"].momentum is not None else 0.1) for l in layers], C.c_float), _iarr([l["bn"].eps for l in layers], C.c_float),
+        _iarr([l["bn"].momentum for l in layers], C.c_float), _iarr([l["bn"].eps for l in layers], C.c_float),
         _parr([at(m["a"]) for m in meta]), _parr([at(m["z"]) for m in meta]), _parr([at(m["stats"]) for m in meta]), _parr([at(m["y"]) for m in meta]),
         ptr(scratch), GEMM_MODE, stream_ptr()), "dgnn_static_train_fwd")
     n, co = layers[-1]["n_dst"], widths[-1]

@@ -726,6 +726,24 @@ def test_interface_extraction_matches_reference_loops():
     assert np.array_equal(got_if.cpu().numpy(), np.asarray(interfaces, dtype=np.int32))
 
 
+@pytest.mark.parametrize("fix", [0, 1])
+def test_generate_matches_the_reference_run(tmp_path, fix):
+    """processing/generate_mesh.generate(data, prediction, clf) against what the REFERENCE's generate handed to trimesh.Trimesh on the same inputs
+    (tests/golden/genmesh_f4_small.npz, make_golden.py round3: graph cut off / unavailable, exact ties in the logits, hull facets with the
+    infinite cell on one side): same vertices, same interface triangles in the same order."""
+    import os
+    from dgnn_amd.processing.generate_mesh import generate
+    g = gold("genmesh_f4_small.npz")
+    os.makedirs(os.path.join(str(tmp_path), "gt"))
+    np.savez(os.path.join(str(tmp_path), "gt", "0_3dt.npz"), vertices=g["vertices"], tetrahedra=g["tetrahedra"], facets=g["facets"], nfacets=g["nfacets"])
+    data = Config(path=str(tmp_path), gtfile="gt/0", filename="0", id="", category="", infinite=torch.from_numpy(g["infinite"]))
+    for graph_cut in (0, 1):     # 1: gco is not installed here either -> the reference's warning and the raw labels
+        clf = Config(temp=Config(graph_cut=graph_cut, fix_orientation=fix, metrics=[], device=DEV), graph_cut=Config(unary_weight=10.0, binary_weight=1.0, binary_type=0))
+        mesh, ev = generate(data, torch.from_numpy(g["prediction"]).to(DEV) if graph_cut == 0 else torch.from_numpy(g["prediction"]), clf)
+        assert ev == {}
+        assert np.array_equal(np.asarray(mesh.faces), g["faces"]) and np.array_equal(np.asarray(mesh.vertices), g["vertices_out"])
+
+
 def test_npz_ingest_matches_reference_loader_and_feeds_inference():
     """8f-3: dgnn_amd.processing.data.dataLoader (device fp64 standardisation) == the reference dataLoader's tensors on
     the small scene; the loaded scene then runs through inference_layer and matches the oracle on the fixture tensors."""

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from dgnn_amd.config import Config
-from helpers import oracle_static
+from helpers import gold, oracle_static
 from test_gpu_parity import DEV, hip_static
 from test_trainer_cpu import blocks, make_clf, small_scene
 
@@ -521,3 +521,24 @@ def test_buffer_ring_blocks_are_correct_when_consumed_in_order_across_epochs_and
             check(k, blk)
             seen += 1
         assert seen == len(ref) == 15
+
+
+# ---- rows 8f-2 against values the REFERENCE's own learning/runModel.py produced (tests/golden/trainer_f2.npz) -----------------------
+@pytest.mark.parametrize("loss,norm", [(l, n) for l in ("kl", "bce", "mse") for n in (None, "log", "sqrt")])
+def test_trainer_loss_on_gpu_matches_the_reference_run(loss, norm):
+    """Trainer.calcLossAndOA on GPU tensors (kl: the fused dgnn_kl_cell_loss kernels; bce / mse: torch ops on the device) against loss, d loss / d logits
+    and the Metrics sums recorded from the reference's Trainer (make_golden.py round3)"""
+    from test_reference_host_cpu import check_loss_case
+    check_loss_case(gold("trainer_f2.npz"), loss, norm, torch.device(DEV))
+
+
+def test_trainer_regularizer_on_gpu_matches_the_reference_run():
+    from test_reference_host_cpu import check_regularizer
+    check_regularizer(gold("trainer_f2.npz"), torch.device(DEV))
+
+
+def test_trainer_train_steps_hip_model_match_the_reference_run():
+    """three Trainer.train steps (block forward / loss / backward / Adam) of the HIP model against the reference's own three steps on the same
+    blocks and targets: running cell loss per step (the 2nd and 3rd see the updated weights), OA, and tensors of the final state_dict"""
+    from test_reference_host_cpu import check_train_steps
+    check_train_steps(gold("trainer_f2.npz"), hip_static(train=True), torch.device(DEV), 2e-4)

@@ -170,6 +170,60 @@ def test_dp_training_two_ranks_equals_mean_gradient_step(tmp_path):
         assert torch.equal(p.detach(), sd[0][k]), k
 
 
+def _dp_unequal_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dgnn_amd.learning.runModel import Trainer
+    torch.set_num_threads(1)
+    clf = make_clf(os.path.join(out_dir, "r%d" % rank))
+    clf.training.epochs, clf.training.val_every, clf.training.export_every = 2, 1000, 1000
+    adj, n, x, ea, y = small_scene()
+    # shards of different size: rank 0 has 4 batches per epoch, rank 1 only 2 -- as a list (has a length) or as a generator (has none)
+    starts = (0, 24, 48, 72) if rank == 0 else (100, 124)
+    batches = [(24,) + blocks(adj, n, range(s, s + 24)) for s in starts]
+
+    class NoLen:
+        def __iter__(self):
+            return iter(batches)
+    data = Config(train=Config(all=Config(x=x, y=y, edge_attr=ea), batches=batches if "list" in out_dir else NoLen()))
+    net = oracle_static(train=True, load=False, seed=rank)      # replicas start different: train_test broadcasts rank 0's weights
+    steps = []
+    tr = Trainer(net)
+    orig = tr.train
+    tr.train = lambda *a, **k: (steps.append(1), orig(*a, **k))[1]
+    tr.train_test(data, clf)
+    torch.save({"sd": net.state_dict(), "steps": len(steps)}, os.path.join(out_dir, "r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["list", "generator"])
+def test_dp_train_test_with_unequal_shards_runs_the_same_number_of_steps_on_every_rank(tmp_path, kind):
+    """Two ranks whose shards hold 4 and 2 batches per epoch: every epoch runs min = 2 all-reduced steps on BOTH ranks (no rank is left
+    alone in a collective), for batch sources with and without a length; the replicas' parameters end bit-equal."""
+    import torch.multiprocessing as mp
+    out = os.path.join(str(tmp_path), kind)
+    os.makedirs(out)
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    mp.spawn(_dp_unequal_worker, args=(2, port, out), nprocs=2, join=True)
+    r = [torch.load(os.path.join(out, "r%d.pt" % k)) for k in range(2)]
+    assert r[0]["steps"] == r[1]["steps"] == 4          # 2 epochs x min(4, 2)
+    for k, _ in oracle_static().named_parameters():
+        assert torch.equal(r[0]["sd"][k], r[1]["sd"][k]), k
+
+
+def test_batch_norm_momentum_none_is_the_cumulative_average():
+    """torch.nn.BatchNorm1d(momentum=None): running statistics = cumulative average over the batches seen (factor 1 / num_batches_tracked);
+    the composite training entry points decline such a layer (they take a fixed factor) and batch_norm_act computes the factor per call."""
+    from dgnn_amd import functional as Fn
+    bn = torch.nn.BatchNorm1d(8, momentum=None)
+    assert not Fn.sage_train_layer_supported(torch.zeros(4, 8), None, bn) or not torch.cuda.is_available()
+    import inspect
+    src = inspect.getsource(Fn.batch_norm_act)
+    assert "1.0 / float(bn.num_batches_tracked)" in src and "0.1" not in src
+
+
 def test_metrics_running_sums_equal_the_reference_formulas():
     """Metrics (reference learning/runModel.py:48-80): OA = 100 * sum(correct) / sum(samples), cell loss = sum(cell) / sum(weight),
     reg loss = sum(reg) / sum(edges); items may be Python numbers or tensors (tensors on a GPU are summed there, see the class
