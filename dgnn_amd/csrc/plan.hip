@@ -67,10 +67,10 @@ constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 8;  // per thread
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 
-// deg[0..n) = 0, *big_count = 0, need = (a, b): one launch
+// deg[0..n) = 0 (n = 0: the persistent fallback zeroes it itself), *big_count = 0, need = (a, b, barrier counter 0): one launch
 __global__ void k_plan_init(int32_t* deg, int64_t n, int32_t* big_count, int32_t* need, int32_t a, int32_t b) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) deg[i] = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { *big_count = 0; need[0] = a; need[1] = b; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *big_count = 0; need[0] = a; need[1] = b; need[2] = 0; }
 }
 
 __global__ void k_zero_i32(int32_t* p, int64_t n) {
@@ -84,25 +84,27 @@ __device__ __forceinline__ bool plan_skip(const int32_t* need) { return need != 
 
 // An edge whose key is outside [0, n_key) is left out of the plan (count and fill agree on that) and reported through the
 // asynchronous error word: torch's scatter raises an index error there, silently corrupting scratch memory is not an option.
-__global__ void k_plan_count(const int64_t* __restrict__ key, int64_t sc, int64_t E, int64_t n_key, int32_t* __restrict__ deg,
-                             const int32_t* __restrict__ need, int32_t* __restrict__ aflag) {
-    if (plan_skip(need)) return;
+// The generic builder's passes are device functions of (block id, grid size): each is a kernel of its own when no fast path is tried, and
+// a phase of the single persistent k_plan_fallback (grid-wide barriers in between) when it only stands by behind a fast path.
+__device__ __forceinline__ void plan_count(int64_t bid, int64_t nblk, const int64_t* __restrict__ key, int64_t sc, int64_t E, int64_t n_key,
+                                           int32_t* __restrict__ deg, int32_t* __restrict__ aflag) {
     bool bad = false;
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t e = bid * (int64_t)blockDim.x + threadIdx.x; e < E; e += nblk * blockDim.x) {
         const int64_t k = key[e * sc];
         if (k < 0 || k >= n_key) { bad = true; continue; }
         atomicAdd(&deg[k], 1);
     }
     if (__any(bad) && (threadIdx.x & 63) == 0) dgnn_raise_async(aflag, DGNN_ASYNC_KEY_RANGE);
 }
+__global__ void k_plan_count(const int64_t* __restrict__ key, int64_t sc, int64_t E, int64_t n_key, int32_t* __restrict__ deg,
+                             int32_t* __restrict__ aflag) {
+    plan_count(blockIdx.x, gridDim.x, key, sc, E, n_key, deg, aflag);
+}
 
-// block-local exclusive scan of SCAN_TILE items; block total -> sums[blockIdx.x]
-__global__ void __launch_bounds__(SCAN_THREADS) k_scan_tile(const int32_t* __restrict__ in, int64_t n,
-                                                            int32_t* __restrict__ out, int32_t* __restrict__ sums,
-                                                            const int32_t* __restrict__ need) {
-    if (plan_skip(need)) return;
-    __shared__ int32_t wsum[SCAN_THREADS / 64];
-    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+// block-local exclusive scan of SCAN_TILE items (tile `tile`); tile total -> sums[tile].  SCAN_THREADS threads.
+__device__ __forceinline__ void scan_tile(int64_t tile, const int32_t* __restrict__ in, int64_t n, int32_t* __restrict__ out,
+                                          int32_t* __restrict__ sums, int32_t* wsum) {
+    const int64_t base = tile * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     int32_t v[SCAN_ITEMS];
     int32_t t = 0;
 #pragma unroll
@@ -129,18 +131,23 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_tile(const int32_t* __res
         if (base + i < n) out[base + i] = run;
         run += v[i];
     }
-    if (threadIdx.x == SCAN_THREADS - 1) sums[blockIdx.x] = run;
+    if (threadIdx.x == SCAN_THREADS - 1) sums[tile] = run;
+    __syncthreads();   // wsum is reused by the caller's next tile
+}
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_tile(const int32_t* __restrict__ in, int64_t n, int32_t* __restrict__ out,
+                                                            int32_t* __restrict__ sums) {
+    __shared__ int32_t wsum[SCAN_THREADS / 64];
+    scan_tile(blockIdx.x, in, n, out, sums, wsum);
 }
 
-// single block: exclusive scan of the tile sums in place; total -> sums[nb]
-__global__ void __launch_bounds__(1024) k_scan_sums(int32_t* __restrict__ sums, int nb, const int32_t* __restrict__ need) {
-    if (plan_skip(need)) return;
-    __shared__ int32_t wsum[16];
-    __shared__ int32_t carry;
+// one block (any size that is a multiple of 64, <= 1024): exclusive scan of the tile sums in place; total -> sums[nb]
+__device__ __forceinline__ void scan_sums(int32_t* __restrict__ sums, int nb, int32_t* wsum, int32_t* carry_p) {
+    int32_t& carry = *carry_p;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int base = 0; base < nb; base += 1024) {
+    const int nt = (int)blockDim.x;
+    for (int base = 0; base < nb; base += nt) {
         int i = base + threadIdx.x;
         int32_t t = i < nb ? sums[i] : 0;
         int32_t incl = t;
@@ -155,33 +162,41 @@ __global__ void __launch_bounds__(1024) k_scan_sums(int32_t* __restrict__ sums, 
         for (int k = 0; k < w; ++k) woff += wsum[k];
         if (i < nb) sums[i] = woff + incl - t;
         __syncthreads();
-        if (threadIdx.x == 1023) carry = woff + incl;
+        if ((int)threadIdx.x == nt - 1) carry = woff + incl;
         __syncthreads();
     }
     if (threadIdx.x == 0) sums[nb] = carry;
 }
+__global__ void __launch_bounds__(1024) k_scan_sums(int32_t* __restrict__ sums, int nb) {
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry;
+    scan_sums(sums, nb, wsum, &carry);
+}
 
-__global__ void __launch_bounds__(SCAN_THREADS) k_scan_add(int32_t* __restrict__ out, int64_t n,
-                                                           const int32_t* __restrict__ sums, int nb,
-                                                           const int32_t* __restrict__ need) {
-    if (plan_skip(need)) return;
-    const int32_t add = sums[blockIdx.x];
-    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+__device__ __forceinline__ void scan_add(int64_t tile, int32_t* __restrict__ out, int64_t n, const int32_t* __restrict__ sums, int nb) {
+    const int32_t add = sums[tile];
+    const int64_t base = tile * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i)
         if (base + i < n) out[base + i] += add;
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = sums[nb];
+    if (tile == 0 && threadIdx.x == 0) out[n] = sums[nb];
+}
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_add(int32_t* __restrict__ out, int64_t n, const int32_t* __restrict__ sums, int nb) {
+    scan_add(blockIdx.x, out, n, sums, nb);
 }
 
-__global__ void k_plan_fill(const int64_t* __restrict__ key, int64_t sc, int64_t E, int64_t n_key, const int32_t* __restrict__ rowptr,
-                            int32_t* __restrict__ deg, int32_t* __restrict__ tmp, const int32_t* __restrict__ need) {
-    if (plan_skip(need)) return;
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+__device__ __forceinline__ void plan_fill(int64_t bid, int64_t nblk, const int64_t* __restrict__ key, int64_t sc, int64_t E, int64_t n_key,
+                                          const int32_t* __restrict__ rowptr, int32_t* __restrict__ deg, int32_t* __restrict__ tmp) {
+    for (int64_t e = bid * (int64_t)blockDim.x + threadIdx.x; e < E; e += nblk * blockDim.x) {
         const int64_t d = key[e * sc];
         if (d < 0 || d >= n_key) continue;  // reported by k_plan_count
         const int32_t slot = rowptr[d] + atomicSub(&deg[d], 1) - 1;
         tmp[slot] = (int32_t)e;
     }
+}
+__global__ void k_plan_fill(const int64_t* __restrict__ key, int64_t sc, int64_t E, int64_t n_key, const int32_t* __restrict__ rowptr,
+                            int32_t* __restrict__ deg, int32_t* __restrict__ tmp) {
+    plan_fill(blockIdx.x, gridDim.x, key, sc, E, n_key, rowptr, deg, tmp);
 }
 
 // other endpoint of sorted edge `pos`, range-checked against n_other (0 = unknown, unchecked): a bad id becomes 0 (memory-safe)
@@ -204,12 +219,11 @@ __device__ __forceinline__ void cswap(int32_t& a, int32_t& b) {
 
 // one thread per key: sort its segment of `tmp` ascending and emit eid/other.
 // Segments longer than 32 are queued for k_plan_emit_big.
-__global__ void k_plan_emit(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ tmp,
-                            const int64_t* __restrict__ other_row, int64_t sc, int64_t n_key, int32_t* __restrict__ eid,
-                            int32_t* __restrict__ other, int32_t* __restrict__ big_count,
-                            int32_t* __restrict__ big_list, const int32_t* __restrict__ need, int64_t n_other, int32_t* aflag) {
-    if (plan_skip(need)) return;
-    for (int64_t d = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; d < n_key; d += (int64_t)gridDim.x * blockDim.x) {
+__device__ __forceinline__ void plan_emit(int64_t bid, int64_t nblk, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ tmp,
+                                          const int64_t* __restrict__ other_row, int64_t sc, int64_t n_key, int32_t* __restrict__ eid,
+                                          int32_t* __restrict__ other, int32_t* __restrict__ big_count, int32_t* __restrict__ big_list,
+                                          int64_t n_other, int32_t* aflag) {
+    for (int64_t d = bid * (int64_t)blockDim.x + threadIdx.x; d < n_key; d += nblk * blockDim.x) {
         const int32_t beg = rowptr[d], n = rowptr[d + 1] - beg;
         if (n <= 4) {
             int32_t v0 = n > 0 ? tmp[beg] : INT32_MAX, v1 = n > 1 ? tmp[beg + 1] : INT32_MAX;
@@ -232,6 +246,11 @@ __global__ void k_plan_emit(const int32_t* __restrict__ rowptr, const int32_t* _
             big_list[atomicAdd(big_count, 1)] = (int32_t)d;
         }
     }
+}
+__global__ void k_plan_emit(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ tmp, const int64_t* __restrict__ other_row, int64_t sc,
+                            int64_t n_key, int32_t* __restrict__ eid, int32_t* __restrict__ other, int32_t* __restrict__ big_count,
+                            int32_t* __restrict__ big_list, int64_t n_other, int32_t* aflag) {
+    plan_emit(blockIdx.x, gridDim.x, rowptr, tmp, other_row, sc, n_key, eid, other, big_count, big_list, n_other, aflag);
 }
 
 // ---- fast path 1: the edge list is already grouped by key (ascending) -------------------------------------------
@@ -323,16 +342,12 @@ __global__ void __launch_bounds__(256) k_plan_regular(const int64_t* __restrict_
 }
 
 // one block per queued long segment: rank sort (edge positions are distinct)
-__global__ void __launch_bounds__(256) k_plan_emit_big(const int32_t* __restrict__ rowptr,
-                                                       const int32_t* __restrict__ tmp,
-                                                       const int64_t* __restrict__ other_row, int64_t sc,
-                                                       int32_t* __restrict__ eid, int32_t* __restrict__ other,
-                                                       const int32_t* __restrict__ big_count,
-                                                       const int32_t* __restrict__ big_list, const int32_t* __restrict__ need,
-                                                       int64_t n_other, int32_t* aflag) {
-    if (plan_skip(need)) return;
+__device__ __forceinline__ void plan_emit_big(int bid, int nblk, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ tmp,
+                                              const int64_t* __restrict__ other_row, int64_t sc, int32_t* __restrict__ eid,
+                                              int32_t* __restrict__ other, const int32_t* __restrict__ big_count,
+                                              const int32_t* __restrict__ big_list, int64_t n_other, int32_t* aflag) {
     const int nbig = *big_count;
-    for (int b = blockIdx.x; b < nbig; b += gridDim.x) {
+    for (int b = bid; b < nbig; b += nblk) {
         const int32_t d = big_list[b];
         const int32_t beg = rowptr[d], n = rowptr[d + 1] - beg;
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -343,6 +358,110 @@ __global__ void __launch_bounds__(256) k_plan_emit_big(const int32_t* __restrict
             other[beg + rank] = checked_other(other_row, x, sc, n_other, aflag);
         }
     }
+}
+__global__ void __launch_bounds__(256) k_plan_emit_big(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ tmp,
+                                                       const int64_t* __restrict__ other_row, int64_t sc, int32_t* __restrict__ eid,
+                                                       int32_t* __restrict__ other, const int32_t* __restrict__ big_count,
+                                                       const int32_t* __restrict__ big_list, int64_t n_other, int32_t* aflag) {
+    plan_emit_big(blockIdx.x, gridDim.x, rowptr, tmp, other_row, sc, eid, other, big_count, big_list, n_other, aflag);
+}
+
+// ---- the generic builder as ONE launch: stands by behind the verified fast paths -----------------------------------------------------
+// When a fast path produced the plan (need[0] == 0 or need[1] == 0, final before this kernel starts) every block returns on its first
+// instruction -- one skipped launch instead of seven.  Otherwise the passes above run as phases of this persistent grid (at most
+// 2 blocks per CU: all co-resident), separated by grid-wide barriers on a counter in the scratch area; agent-scope release / acquire
+// around each barrier makes one phase's stores visible to the next phase's plain loads on every XCD (the per-XCD L2s are not coherent).
+__device__ __forceinline__ void grid_sync(int32_t* counter, int nblk, int& phase) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int target = (phase + 1) * nblk;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // every wave's vector L1
+    ++phase;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_plan_fallback(const int64_t* __restrict__ key, const int64_t* __restrict__ oth, int64_t sc, int64_t E,
+                                                                int64_t n_key, int64_t n_other, int32_t* __restrict__ rowptr,
+                                                                int32_t* __restrict__ other, int32_t* __restrict__ eid, int32_t* __restrict__ deg,
+                                                                int32_t* __restrict__ tmp, int32_t* __restrict__ sums, int nb,
+                                                                int32_t* __restrict__ big_count, int32_t* __restrict__ big_list,
+                                                                const int32_t* __restrict__ need, int32_t* gsync, int32_t* aflag) {
+    if (plan_skip(need)) return;
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry;
+    const int64_t bid = blockIdx.x, nblk = gridDim.x;
+    int phase = 0;
+    for (int64_t i = bid * (int64_t)blockDim.x + threadIdx.x; i < n_key; i += nblk * blockDim.x) deg[i] = 0;
+    grid_sync(gsync, (int)nblk, phase);
+    plan_count(bid, nblk, key, sc, E, n_key, deg, aflag);
+    grid_sync(gsync, (int)nblk, phase);
+    for (int64_t t = bid; t < nb; t += nblk) scan_tile(t, deg, n_key, rowptr, sums, wsum);
+    grid_sync(gsync, (int)nblk, phase);
+    if (bid == 0) scan_sums(sums, nb, wsum, &carry);
+    grid_sync(gsync, (int)nblk, phase);
+    for (int64_t t = bid; t < nb; t += nblk) scan_add(t, rowptr, n_key, sums, nb);
+    grid_sync(gsync, (int)nblk, phase);
+    plan_fill(bid, nblk, key, sc, E, n_key, rowptr, deg, tmp);
+    grid_sync(gsync, (int)nblk, phase);
+    plan_emit(bid, nblk, rowptr, tmp, oth, sc, n_key, eid, other, big_count, big_list, n_other, aflag);
+    grid_sync(gsync, (int)nblk, phase);
+    plan_emit_big((int)bid, (int)nblk, rowptr, tmp, oth, sc, eid, other, big_count, big_list, n_other, aflag);
+}
+
+// The same pass with FOUR LANES PER CELL when the (src, dst) pairs are interleaved in memory (edge_index = the reference's transposed view of
+// its [E,2] int64 array: row stride 1, column stride 2): lane q of a cell loads pair 4t+q with one 16-byte load (coalesced: a wave reads 1 KB
+// contiguous) and, for each of the cell's 4 neighbours, pair q of the neighbour's 4 rows -- a quad reads one contiguous 64-byte chunk per
+// neighbour, i.e. 5 sector requests per cell instead of the 24 eight-byte lane loads of the one-thread-per-cell form.  Hits are combined
+// inside the quad with a ballot.  Same checks, same output.
+__global__ void __launch_bounds__(256) k_plan_regular_q(const int64_t* __restrict__ pairs, int64_t n_key, int32_t* __restrict__ rowptr,
+                                                        int32_t* __restrict__ other, int32_t* __restrict__ eid, int32_t* __restrict__ need) {
+    if (need[0] == 0) return;  // fast path 1 already produced the plan
+    typedef long long ll2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63, q = lane & 3;
+    const int64_t E = 4 * n_key;
+    bool bad = false;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = e >> 2;
+        const ll2 p = *reinterpret_cast<const ll2*>(pairs + 2 * e);
+        bad |= p.x != t || p.y < 0 || p.y >= n_key;
+        const int32_t d = (int32_t)(p.y < 0 ? 0 : (p.y >= n_key ? n_key - 1 : p.y));
+        int32_t dj[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dj[j] = __shfl(d, (lane & 60) + j);
+        int rank = 0, occ = 0, mult = 0;   // position of this lane's neighbour in the stable ascending order; which of its duplicates it is
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            rank += (dj[j] < d) || (dj[j] == d && j < q);
+            occ += dj[j] == d && j < q;
+            mult += dj[j] == d;
+        }
+        uint32_t mine = 0;   // slots of neighbour d's rows that point back at t (4-bit mask)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const ll2 w = *reinterpret_cast<const ll2*>(pairs + 2 * (4 * (int64_t)dj[j] + q));
+            const uint64_t b = __ballot(w.y == t);
+            const uint32_t m = (uint32_t)(b >> (lane & 60)) & 15u;
+            if (j == q) mine = m;
+        }
+        int cnt = 0, slot = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool hit = (mine >> r) & 1u;
+            if (hit && cnt == occ) slot = r;
+            cnt += hit;
+        }
+        bad |= cnt != mult;
+        other[4 * t + rank] = d;
+        eid[4 * t + rank] = 4 * d + slot;
+        if (q == 0) rowptr[t] = (int32_t)(4 * t);
+        if (e == E - 1) rowptr[n_key] = (int32_t)E;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0 && *reinterpret_cast<volatile int32_t*>(&need[1]) == 0) atomicOr(&need[1], 1);
 }
 
 __global__ void k_gather_rows(const float* __restrict__ in, int64_t ld_in, const int32_t* __restrict__ idx, int64_t n,
@@ -394,17 +513,16 @@ int dgnn_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, int32_t*
         return DGNN_OK;
     }
     const int nb = (int)dgnn_cdiv(n, SCAN_TILE);
-    const int32_t* none = nullptr;
-    hipLaunchKernelGGL(k_scan_tile, dim3(nb), dim3(SCAN_THREADS), 0, stream, in, n, out, sums_scratch, none);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums_scratch, nb, none);
-    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_THREADS), 0, stream, out, n, sums_scratch, nb, none);
+    hipLaunchKernelGGL(k_scan_tile, dim3(nb), dim3(SCAN_THREADS), 0, stream, in, n, out, sums_scratch);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums_scratch, nb);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_THREADS), 0, stream, out, n, sums_scratch, nb);
     return DGNN_OK;
 }
 
-// scratch layout (int32): deg[n_key] | tmp[E] | sums[nb+2] | big_count[1] | big_list[E/33+2] | need[2]
+// scratch layout (int32): deg[n_key] | tmp[E] | sums[nb+2] | big_count[1] | big_list[E/33+2] | need[2] | grid-barrier counter[1] (+1 pad)
 extern "C" int64_t dgnn_plan_scratch_elems(int64_t E, int64_t n_key) {
     if (E < 0 || n_key < 0) return 0;
-    return n_key + E + (dgnn_cdiv(n_key, SCAN_TILE) + 2) + 1 + (E / 33 + 2) + 2;
+    return n_key + E + (dgnn_cdiv(n_key, SCAN_TILE) + 2) + 1 + (E / 33 + 2) + 4;
 }
 
 extern "C" int dgnn_plan_build(const int64_t* edge_index, int64_t stride_row, int64_t stride_col, int64_t E, int64_t n_key,
@@ -440,33 +558,40 @@ extern "C" int dgnn_plan_build(const int64_t* edge_index, int64_t stride_row, in
     const bool can_regular = by == 1 && E == 4 * n_key && E > 0;
     const bool try_sorted = E > 0 && hint != DGNN_PLAN_HINT_GENERIC && !(hint == DGNN_PLAN_HINT_REFERENCE && can_regular);
     const bool try_regular = can_regular && hint != DGNN_PLAN_HINT_GROUPED && hint != DGNN_PLAN_HINT_GENERIC;
-    hipLaunchKernelGGL(k_plan_init, dim3(dgnn_grid_cap(dgnn_cdiv(n_key, 256))), dim3(256), 0, stream, deg, n_key, big_count, need,
-                       try_sorted ? 0 : 1, try_regular ? 0 : 1);
-    const int32_t* flag = nullptr;
-    int cap = 1 << 30;
+    const bool standby = try_sorted || try_regular;   // the generic builder only stands by: one persistent launch (k_plan_fallback)
+    hipLaunchKernelGGL(k_plan_init, dim3(standby ? 1 : dgnn_grid_cap(dgnn_cdiv(n_key, 256))), dim3(standby ? 64 : 256), 0, stream, deg,
+                       standby ? (int64_t)0 : n_key, big_count, need, try_sorted ? 0 : 1, try_regular ? 0 : 1);
     if (try_sorted) {
         const dim3 g(dgnn_grid_cap(dgnn_cdiv(E, 256)));
         hipLaunchKernelGGL(k_plan_sorted_check, g, dim3(256), 0, stream, key, sc, E, n_key, need);
         hipLaunchKernelGGL(k_plan_sorted, g, dim3(256), 0, stream, key, oth, sc, E, n_key, rowptr, other, eid, need, n_other, aflag);
     }
-    if (try_regular)
-        hipLaunchKernelGGL(k_plan_regular, dim3(dgnn_grid_cap(dgnn_cdiv(n_key, 256))), dim3(256), 0, stream, key, oth, sc, n_key, rowptr,
-                           other, eid, need);
-    if (try_sorted || try_regular) {
-        flag = need;
-        cap = 4 * DGNN_NUM_CU;
+    if (try_regular) {
+        // (src, dst) pairs interleaved in memory (the reference's transposed view of its [E,2] array): four lanes per cell, 16-byte loads
+        if (stride_row == 1 && sc == 2 && ((uintptr_t)edge_index % 16) == 0)
+            hipLaunchKernelGGL(k_plan_regular_q, dim3(dgnn_grid_cap(dgnn_cdiv(E, 256))), dim3(256), 0, stream, edge_index, n_key, rowptr, other, eid, need);
+        else
+            hipLaunchKernelGGL(k_plan_regular, dim3(dgnn_grid_cap(dgnn_cdiv(n_key, 256))), dim3(256), 0, stream, key, oth, sc, n_key, rowptr,
+                               other, eid, need);
     }
-    auto grid_for = [&](int64_t n) { const int64_t g = dgnn_grid_cap(dgnn_cdiv(n, 256)); return dim3((unsigned)(g < cap ? g : cap)); };
-    if (E > 0) hipLaunchKernelGGL(k_plan_count, grid_for(E), dim3(256), 0, stream, key, sc, E, n_key, deg, flag, aflag);
-    hipLaunchKernelGGL(k_scan_tile, dim3(nb), dim3(SCAN_THREADS), 0, stream, deg, n_key, rowptr, sums, flag);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums, nb, flag);
-    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_THREADS), 0, stream, rowptr, n_key, sums, nb, flag);
+    if (standby) {
+        const int64_t want = dgnn_cdiv(E > n_key ? E : n_key, (int64_t)SCAN_THREADS * 8);
+        const int grid = (int)(want < 1 ? 1 : (want < 2 * DGNN_NUM_CU ? want : 2 * DGNN_NUM_CU));
+        hipLaunchKernelGGL(k_plan_fallback, dim3(grid), dim3(SCAN_THREADS), 0, stream, key, oth, sc, E, n_key, n_other, rowptr, other, eid, deg, tmp,
+                           sums, nb, big_count, big_list, need, need + 2, aflag);
+        return dgnn_check_launch("plan_build");
+    }
+    auto grid_for = [&](int64_t n) { return dim3((unsigned)dgnn_grid_cap(dgnn_cdiv(n, 256))); };
+    if (E > 0) hipLaunchKernelGGL(k_plan_count, grid_for(E), dim3(256), 0, stream, key, sc, E, n_key, deg, aflag);
+    hipLaunchKernelGGL(k_scan_tile, dim3(nb), dim3(SCAN_THREADS), 0, stream, deg, n_key, rowptr, sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums, nb);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_THREADS), 0, stream, rowptr, n_key, sums, nb);
     if (E > 0) {
-        hipLaunchKernelGGL(k_plan_fill, grid_for(E), dim3(256), 0, stream, key, sc, E, n_key, rowptr, deg, tmp, flag);
-        hipLaunchKernelGGL(k_plan_emit, grid_for(n_key), dim3(256), 0, stream, rowptr, tmp, oth, sc, n_key, eid, other, big_count,
-                           big_list, flag, n_other, aflag);
-        hipLaunchKernelGGL(k_plan_emit_big, dim3(256), dim3(256), 0, stream, rowptr, tmp, oth, sc, eid, other, big_count, big_list,
-                           flag, n_other, aflag);
+        hipLaunchKernelGGL(k_plan_fill, grid_for(E), dim3(256), 0, stream, key, sc, E, n_key, rowptr, deg, tmp);
+        hipLaunchKernelGGL(k_plan_emit, grid_for(n_key), dim3(256), 0, stream, rowptr, tmp, oth, sc, n_key, eid, other, big_count, big_list,
+                           n_other, aflag);
+        hipLaunchKernelGGL(k_plan_emit_big, dim3(256), dim3(256), 0, stream, rowptr, tmp, oth, sc, eid, other, big_count, big_list, n_other,
+                           aflag);
     }
     return dgnn_check_launch("plan_build");
 }

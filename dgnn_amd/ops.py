@@ -21,7 +21,7 @@ def _req(t: torch.Tensor, name: str, dtype=torch.float32, dim=None, any_stride=F
         raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
     if dim is not None and t.dim() != dim:
         raise ValueError("%s must be %d-D, got shape %s" % (name, dim, tuple(t.shape)))
-    if t.dim() == 2 and t.numel() and t.stride(1) != 1 and not any_stride:
+    if t.dim() == 2 and t.numel() and t.size(1) > 1 and t.stride(1) != 1 and not any_stride:   # (a single column has no column stride to speak of)
         raise ValueError("%s must have a contiguous last dimension (stride %s)" % (name, t.stride()))
     return t
 
