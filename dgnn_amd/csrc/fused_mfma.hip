@@ -115,7 +115,9 @@ __device__ __forceinline__ void st_out(float* p, float v) {
 //   power-of-two group scales (3 products; fused_common.h).  Scaling groups: one per A-tile row (a tet's [mean | own] row, so a tet's
 //   result does not depend on its neighbours in the tile), one per weight matrix pair [Wj | Wi], one per [We | be], one per 16-edge
 //   attribute block of the filter product (FSP == 2).
-template <int CIN_PAD, int COUT, int NW = 8, int KS = 2, int DSP = 3, int FSP = 3>
+//   DEC (128 -> 128, fp16 forms only): the launch also carries the decoder Linear(128 -> 64) - BN - ReLU - Linear(64 -> 2) and writes logits
+//   instead of the layer's rows (see the DEC block in the kernel).
+template <int CIN_PAD, int COUT, int NW = 8, int KS = 2, int DSP = 3, int FSP = 3, bool DEC = false>
 struct Cfg2 {
     static constexpr int K = 2 * CIN_PAD;
     static constexpr int NSLICE = COUT / 32;
@@ -135,8 +137,14 @@ struct Cfg2 {
     static constexpr int ROWF_BYTES = DSP == 2 ? 4 * TILE * 4 : 0;  // per-row inverse scales, 4 tiles deep (written in P(it), read up to the
                                                                     // delayed epilogue after barrier it+1 while P(it+2) may already write)
     static constexpr int SC_BYTES = 16;                   // launch-wide weight maxima (prologue)
-    static constexpr int COLP_BYTES = (DSP == 2 && DGNN_TR) ? 3 * COUT * 4 : 0;  // [bias | scale | shift][COUT]: the transposed epilogue's lanes own 8 / 16 columns
-    static constexpr int SMEM_BYTES = 2 * A_BYTES + NW * EA_BYTES + 2 * RED_BYTES + BP_BYTES + ROWF_BYTES + SC_BYTES + COLP_BYTES;
+    static constexpr int COLP_BYTES = (DSP == 2 && (DGNN_TR || DEC)) ? 3 * COUT * 4 : 0;  // [bias | scale | shift][COUT]: the transposed epilogue's lanes own 8 / 16 columns
+    // decoder stage: W0 as matrix-core fragments [2 output blocks][8 column slabs][hi | lo][64 lanes] x 16 B, then A1 | B1 [64] (folded bias / BatchNorm),
+    // W3 [2][64], b3 [2] (+2 pad), per-(slab, row) inverse scales [8][32], the second output block's partial logits [32][2], a hand-off flag
+    static constexpr int DEC_W0 = 2 * 8 * 2 * 1024, DEC_CONST = (64 + 64 + 128 + 4) * 4, DEC_SCALE = 8 * 32 * 4, DEC_PBUF = 32 * 2 * 4 + 16;
+    static constexpr int DEC_BYTES = DEC ? DEC_W0 + DEC_CONST + DEC_SCALE + DEC_PBUF : 0;
+    static constexpr int SMEM_BYTES = 2 * A_BYTES + NW * EA_BYTES + 2 * RED_BYTES + BP_BYTES + ROWF_BYTES + SC_BYTES + COLP_BYTES + DEC_BYTES;
+    static_assert(!DEC || (CIN_PAD == 128 && COUT == 128 && NW == 8 && KS == 2 && DSP == 2), "decoder stage: 128 -> 128, eight waves, fp16 dense form");
+    static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
     static constexpr int NWB = K / 16 / KS;               // dense part: k-steps of 16 per wave
     static_assert(EA_BYTES % 256 == 0, "attribute block must be DMA-able");
     static_assert(RG >= 1 && NQ <= 64, "wave roles");
@@ -172,15 +180,26 @@ __device__ __forceinline__ void ld_vec(float (&v)[NB], const float* p, bool vec)
 template <int CIN_PAD, int COUT, int NW, int KS, int DSP, int FSP>
 constexpr int occ_of() { return (NW == 4 && Cfg2<CIN_PAD, COUT, NW, KS, DSP, FSP>::SMEM_BYTES <= 53 * 1024) ? DGNN_SMALL_OCC : 2; }
 
-template <int CIN_PAD, int COUT, int NW, int KS, int DSP, int FSP>
+// parameters of the decoder stage (DEC): reference learning/surfaceNetStaticEdgeFilters.py:180-187, applied at :350-351
+struct DecArgs {
+    const float* W0;      // [64, 128]
+    const float* b0;      // [64]
+    const float* scale1;  // [64] folded BatchNorm(eval) of the decoder, or NULL
+    const float* shift1;  // [64]
+    const float* W3;      // [2, 64]
+    const float* b3;      // [2]
+    float* logits;        // [n_dst, 2] (row stride 2)
+};
+
+template <int CIN_PAD, int COUT, int NW, int KS, int DSP, int FSP, bool DEC = false>
 __global__ void __launch_bounds__(64 * NW, (occ_of<CIN_PAD, COUT, NW, KS, DSP, FSP>()))
 k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid, int64_t n_dst,
                   const float* __restrict__ x, const float* __restrict__ xdst, int64_t ldx, int c_in, const float* __restrict__ ea, int64_t lde,
                   const float* __restrict__ We, const float* __restrict__ be, const float* __restrict__ Wj,
                   const float* __restrict__ bj, const float* __restrict__ Wi, const float* __restrict__ scale,
                   const float* __restrict__ shift, int relu, float* __restrict__ out, int64_t ldo, int64_t ntiles,
-                  int xvec, int64_t* __restrict__ trace, int64_t trace_cap) {
-    using C = Cfg2<CIN_PAD, COUT, NW, KS, DSP, FSP>;
+                  int xvec, int64_t* __restrict__ trace, int64_t trace_cap, DecArgs dec) {
+    using C = Cfg2<CIN_PAD, COUT, NW, KS, DSP, FSP, DEC>;
     constexpr int ROWB = C::ROWB, TILE = C::TILE, TPW = C::TPW, RB = C::RB, NB = C::NB, NWB = C::NWB, OCT = C::OCT;
     // the next tile's gathers are issued between the pieces of the filter phase (fp16 forms: the bf16 x 3 form at 128 -> 128 has no
     // registers left for the overlap of old and new rows) or as one burst at its end
@@ -196,7 +215,13 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     // DSP == 2: the dense product is taken transposed (weights as the A operand, tet rows as the B operand -- the per-lane fragments are the
     // same either way), so a lane ends up with ONE tet row and 4-column runs of it: the result leaves as 16-byte stores (2 or 4 per lane and
     // tile instead of 8 or 16 dword stores whose addresses each cost 64-bit arithmetic), the row's inverse scale is one LDS word per lane.
-    constexpr bool TR = DSP == 2 && DGNN_TR;
+    constexpr bool TR = DSP == 2 && (DGNN_TR || DEC);
+    // decoder stage buffers (DEC)
+    char* const w0buf = reinterpret_cast<char*>(colp) + C::COLP_BYTES;                 // [2][8][2][64] x 16 B
+    float* const dconst = reinterpret_cast<float*>(w0buf + C::DEC_W0);                 // A1[64] | B1[64] | W3[2][64] | b3[2]
+    float* const dscale = dconst + C::DEC_CONST / 4;                                   // [8 slabs][32 rows]
+    float* const pbuf = dscale + C::DEC_SCALE / 4;                                     // [32 rows][2]
+    volatile int32_t* const pflag = reinterpret_cast<volatile int32_t*>(pbuf + 64);
     constexpr bool PLANAR = DSP == 2 && DGNN_PLANAR;
     // Skewed schedule (128 -> 128, fp16 dense form): the eight waves are two groups, A = the K-half-0 waves 0..3 and B = the K-half-1 waves
     // 4..7, one of each per SIMD, and at any time one group is in its filter phase P (vector ALU, LDS, gathers) while the other is in its dense
@@ -280,6 +305,45 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         dst[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
         if constexpr (FSP == 3) dst[48] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
         dst[48 * (FSP - 1)] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+    }
+
+    // ---- decoder stage (DEC): W0 scaled by one power of two and split into (hi, lo) fp16 fragments, once per launch.
+    // Fragment (ob, sl, part, lane): output ob*32 + (lane & 31), k-group h = lane >> 5, element e = 0..7 <-> column
+    // 32*(sl >> 1) + 16*(sl & 1) + 4*h + 8*(e >> 2) + (e & 3) -- the order in which a lane of the transposed epilogue holds its 8 finished
+    // values of slab sl, so that a wave's finished rows ARE the other operand of v_mfma_f32_32x32x16_f16 (no transposition through LDS).
+    if constexpr (DEC) {
+        if (threadIdx.x == 0) scbuf[2] = 0u;
+        if (threadIdx.x == 1) *pflag = 0;
+        __syncthreads();
+        uint32_t m0 = 0u;
+        for (int e = threadIdx.x; e < 64 * 128; e += blockDim.x) m0 = umax(m0, absbits(dec.W0[e]));
+        m0 = wave_umax(m0);
+        if (lane_id() == 0) atomicMax(&scbuf[2], m0);
+        __syncthreads();
+        float sW0, inv_sW0;
+        pow2_scales(scbuf[2], sW0, inv_sW0);
+        for (int e = threadIdx.x; e < 2 * 8 * 64; e += blockDim.x) {
+            const int ln = e & 63, sl = (e >> 6) & 7, ob = e >> 9;
+            const int n_ = ob * 32 + (ln & 31), hh = ln >> 5, cb_ = 32 * (sl >> 1) + 16 * (sl & 1) + 4 * hh;
+            uint32_t ph[4], pl[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int e0 = 2 * d, e1 = 2 * d + 1;
+                const float v0 = dec.W0[n_ * 128 + cb_ + 8 * (e0 >> 2) + (e0 & 3)], v1 = dec.W0[n_ * 128 + cb_ + 8 * (e1 >> 2) + (e1 & 3)];
+                split2h(v0 * sW0, v1 * sW0, ph[d], pl[d]);
+            }
+            uint4* dst = reinterpret_cast<uint4*>(w0buf + ((ob * 8 + sl) * 2) * 1024 + ln * 16);
+            dst[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+            dst[64] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+        }
+        for (int n_ = threadIdx.x; n_ < 64; n_ += blockDim.x) {
+            const float s1 = dec.scale1 ? dec.scale1[n_] : 1.f, h1 = dec.scale1 ? dec.shift1[n_] : 0.f;
+            dconst[n_] = inv_sW0 * s1;                              // h1 = relu(acc * A1 + B1), acc in units of 1 / sW0
+            dconst[64 + n_] = __fmaf_rn(dec.b0[n_], s1, h1);
+            dconst[128 + n_] = dec.W3[n_];
+            dconst[192 + n_] = dec.W3[64 + n_];
+        }
+        if (threadIdx.x < 2) dconst[256 + threadIdx.x] = dec.b3[threadIdx.x];
     }
 
     // ---- dense-phase role: (column slice cs, K part kh, row group rg); this wave's share of K resident as 3 bf16 parts
@@ -737,6 +801,7 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
             const int64_t grow = tile * TILE + row;
             const float rf = rowf[(int)(ie & 3) * TILE + row];
             float* o = out + grow * ldo + cbase;
+            float v8[8];
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(colp + cbase + 8 * g);
@@ -753,7 +818,33 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
 #pragma unroll
                     for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
                 }
-                if (grow < n_dst) *reinterpret_cast<f32x4_t*>(o + 8 * g) = v;
+                if constexpr (DEC) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v8[4 * g + c] = v[c];
+                } else {
+                    if (grow < n_dst) *reinterpret_cast<f32x4_t*>(o + 8 * g) = v;
+                }
+            }
+            if constexpr (DEC) {
+                // The finished rows do not leave the CU: this lane's 8 values of (tet row l31, slab 2*cs + kh) become one fragment of the
+                // decoder's first product -- scaled by a power of two of their own (the slab's 16 values of this row live in lanes l31 and
+                // l31 + 32), split into (hi, lo) and parked in the partner's region of the partial-sum buffer, which this wave alone has
+                // just read.  The slab's inverse scale goes to dscale.
+                float mx = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) mx = fmaxf(fmaxf(mx, fabsf(v8[i])), fabsf(v8[i + 1]));
+                uint32_t mb = __builtin_bit_cast(uint32_t, mx);
+                const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+                mb = umax(sw[0], sw[1]);
+                float s_, inv_;
+                pow2_scales(mb, s_, inv_);
+                if (h == 0) dscale[(2 * cs + kh) * 32 + l31] = inv_;
+                uint32_t ph[4], pl[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) split2h(v8[2 * d] * s_, v8[2 * d + 1] * s_, ph[d], pl[d]);
+                uint4* dst = reinterpret_cast<uint4*>(redbuf + (ie & 1) * (C::RED_BYTES / 4) + partner * 512) + lane;
+                dst[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+                dst[64] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
             }
         } else {
         const int64_t row0 = tile * TILE + rg * 32 + 4 * h + 16 * kh;
@@ -787,6 +878,64 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                 if (row0 + rr < n_dst) st_out(&o[(int64_t)rr * ldo], v[r]);
             }
         }
+        }
+    };
+    // D(ie) (DEC; waves 0 and 1, one per output block of 32): h1 = relu(BN(W0 . y + b0)) for the tile's 32 rows, then this block's share of
+    // W3 . h1.  Per slab: 3 products on the matrix cores from zero, times the slab's inverse scale into the fp32 sum (slabs of one row carry
+    // different powers of two).  Wave 1 hands its partial logits to wave 0 through LDS; wave 0 adds, adds b3 and stores 8 bytes per tet.
+    auto decoderD = [&](int64_t ie) {
+        if constexpr (DEC) {
+            const int ob = w;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const char* fb = reinterpret_cast<const char*>(redbuf + (ie & 1) * (C::RED_BYTES / 4));
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) {
+                const int wp = (sl >> 1) + C::NSLICE * (sl & 1);          // the wave that finished slab sl; its fragments sit in its partner's region
+                const char* fr = fb + (wp ^ C::NSLICE) * 2048 + lane * 16;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(fr), bl = *reinterpret_cast<const bf16x8*>(fr + 1024);
+                const char* wr = w0buf + ((ob * 8 + sl) * 2) * 1024 + lane * 16;
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(wr), al = *reinterpret_cast<const bf16x8*>(wr + 1024);
+                f32x16 pr = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(al), H8(bh), f32x16{}, 0, 0, 0);
+                pr = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(ah), H8(bl), pr, 0, 0, 0);
+                pr = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(ah), H8(bh), pr, 0, 0, 0);
+                const float inv = dscale[sl * 32 + l31];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = __fmaf_rn(pr[r], inv, acc[r]);
+            }
+            // acc[r] = pre-activation of decoder output ob*32 + (r&3) + 8(r>>2) + 4h for tet row l31
+            float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n0 = ob * 32 + 8 * q + 4 * h;
+                const f32x4_t a1 = *reinterpret_cast<const f32x4_t*>(dconst + n0), b1 = *reinterpret_cast<const f32x4_t*>(dconst + 64 + n0);
+                const f32x4_t u0 = *reinterpret_cast<const f32x4_t*>(dconst + 128 + n0), u1 = *reinterpret_cast<const f32x4_t*>(dconst + 192 + n0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float hv = fmaxf(__fmaf_rn(acc[4 * q + c], a1[c], b1[c]), 0.f);
+                    p0 = __fmaf_rn(hv, u0[c], p0);
+                    p1 = __fmaf_rn(hv, u1[c], p1);
+                }
+            }
+            // the two k-group lanes of a row (l31, l31 + 32) hold disjoint halves of the block's outputs
+            const float q0 = __shfl_xor(p0, 32), q1 = __shfl_xor(p1, 32);
+            p0 = h == 0 ? p0 + q0 : q0 + p0;
+            p1 = h == 0 ? p1 + q1 : q1 + p1;
+            const int32_t ticket = (int32_t)(ie + 1);
+            if (ob == 1) {
+                if (h == 0) *reinterpret_cast<float2*>(pbuf + 2 * l31) = make_float2(p0, p1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) *pflag = ticket;
+            } else {
+                while (*pflag != ticket) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+                const volatile float* pv = pbuf + 2 * l31;
+                const float o10 = pv[0], o11 = pv[1];
+                const int64_t grow = tile_of(ie) * TILE + l31;
+                if (h == 0 && grow < n_dst)
+                    *reinterpret_cast<float2*>(dec.logits + grow * 2) = make_float2((p0 + o10) + dconst[256], (p1 + o11) + dconst[257]);
+            }
         }
     };
     // what follows the products of tile `it`: hand the partner its half (K split) or finish the block right away (full K)
@@ -896,7 +1045,13 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         if (it < my_n) phaseP(it);
         tile_barrier();  // A-tile `it` complete; partial sums of tile `it-1` complete
         stamp(trace, trace_cap, it, w, 4);
-        if (KS == 2 && it > 0) epilogueK2(it - 1);  // delayed epilogue of tile it-1
+        if (KS == 2 && it > 0) {
+            epilogueK2(it - 1);  // delayed epilogue of tile it-1
+            if constexpr (DEC) {
+                tile_barrier();  // every wave's fragments of tile it-1 are in LDS
+                if (w < 2) decoderD(it - 1);
+            }
+        }
         stamp(trace, trace_cap, it, w, 6);
         if (it < my_n) {
             f32x16 acc;
@@ -908,25 +1063,25 @@ k_sage_fused_mfma(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     }
 }
 
-template <int CIN_PAD, int COUT, int DSP, int FSP>
+template <int CIN_PAD, int COUT, int DSP, int FSP, bool DEC = false>
 int launch2(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x, const float* xdst, int64_t ldx, int c_in, const float* ea,
             int64_t lde, const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
-            const float* scale, const float* shift, int relu, float* out, int64_t ldo, int xvec, hipStream_t stream) {
+            const float* scale, const float* shift, int relu, float* out, int64_t ldo, int xvec, hipStream_t stream, DecArgs dec = DecArgs{}) {
     // C_in <= 64: four-wave workgroups, two per CU (see Cfg2); C_in = 128: eight waves with the K split
     // (64 -> 64 would need 16 tets per wave with 4 channels per lane: 110 spilled registers -- it keeps the 8-wave form)
     constexpr int NW = (CIN_PAD <= 64 && !(CIN_PAD == 64 && COUT == 64)) ? DGNN_SMALL_NW : 8, KS = NW == 8 ? 2 : 1;
-    using C = Cfg2<CIN_PAD, COUT, NW, KS, DSP, FSP>;
+    using C = Cfg2<CIN_PAD, COUT, NW, KS, DSP, FSP, DEC>;
     const int64_t ntiles = dgnn_cdiv(n_dst, C::TILE);
     const size_t smem = C::SMEM_BYTES;
     static bool attr_set[DGNN_MAX_DEVICES] = {};
-    dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_mfma<CIN_PAD, COUT, NW, KS, DSP, FSP>), smem, attr_set);
+    dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_mfma<CIN_PAD, COUT, NW, KS, DSP, FSP, DEC>), smem, attr_set);
     const int wg_max = DGNN_NUM_CU * (NW == 8 ? 1 : occ_of<CIN_PAD, COUT, NW, KS, DSP, FSP>());
     int grid = (int)(ntiles < wg_max ? ntiles : wg_max);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((k_sage_fused_mfma<CIN_PAD, COUT, NW, KS, DSP, FSP>), dim3(grid), dim3(64 * NW), smem, stream, rowptr, src, eid, n_dst, x, xdst,
+    hipLaunchKernelGGL((k_sage_fused_mfma<CIN_PAD, COUT, NW, KS, DSP, FSP, DEC>), dim3(grid), dim3(64 * NW), smem, stream, rowptr, src, eid, n_dst, x, xdst,
                        ldx, c_in, ea, lde, We, be, Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles, xvec, g_dgnn_trace_buf,
-                       g_dgnn_trace_cap);
-    return dgnn_check_launch("sage_layer_fused_fwd(mfma filter)");
+                       g_dgnn_trace_cap, dec);
+    return dgnn_check_launch(DEC ? "sage_layer_fused_decoder_fwd" : "sage_layer_fused_fwd(mfma filter)");
 }
 
 }  // namespace
@@ -956,4 +1111,32 @@ int dgnn_sage_layer_fused_mfma_try(const int32_t* rowptr, const int32_t* src, co
     GO2(128, 128);
 #undef GO2
 #undef GO3
+}
+
+// The last conv layer of the shipped model together with the decoder (reference :180-187 applied at :350-351) in ONE launch: the finished
+// 32-tet tile goes through Linear(128 -> 64) - BatchNorm(eval, folded) - ReLU - Linear(64 -> 2) inside the workgroup and only the logits are
+// written (8 B per tet instead of 512 B out and 512 B back in).  Shapes: c_in <= 128 padded to 128 with c_in % 8 == 0, c_out = 128, f_e = 20,
+// decoder 128 -> 64 -> 2; fp16 two-part arithmetic (gemm mode DGNN_GEMM_F16X2) throughout.  Anything else: DGNN_E_UNSUPPORTED (the caller
+// then runs the layer and dgnn_decoder_fused_fwd as two launches).
+extern "C" int dgnn_sage_layer_fused_decoder_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src,
+                                                 const float* x_dst, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e,
+                                                 const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
+                                                 const float* scale, const float* shift, int relu, int c_out, const float* W0, const float* b0,
+                                                 const float* scale1, const float* shift1, int c_hidden, const float* W3, const float* b3, int n_logits,
+                                                 float* logits, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DGNN_REQUIRE(n_dst >= 0, DGNN_E_INVALID, "sage_layer_fused_decoder_fwd: bad sizes");
+    if (n_dst == 0) return DGNN_OK;
+    DGNN_REQUIRE(rowptr && src && x_src && edge_attr && We && be && Wj && Wi && W0 && b0 && W3 && b3 && logits, DGNN_E_INVALID,
+                 "sage_layer_fused_decoder_fwd: null pointer");
+    DGNN_REQUIRE((scale == nullptr) == (shift == nullptr) && (scale1 == nullptr) == (shift1 == nullptr), DGNN_E_INVALID,
+                 "sage_layer_fused_decoder_fwd: scale/shift must come together");
+    if (x_dst == nullptr) x_dst = x_src;
+    const bool ok = c_out == 128 && c_in > 64 && c_in <= 128 && c_in % 8 == 0 && f_e == fused::FE && lde == fused::FE && c_hidden == 64 && n_logits == 2 &&
+                    ((((uintptr_t)x_src | (uintptr_t)x_dst | (uintptr_t)edge_attr) % 16) == 0) && ldx % 4 == 0 && ((uintptr_t)logits % 8) == 0 &&
+                    n_dst * ldx < ((int64_t)1 << 31);
+    if (!ok) return DGNN_E_UNSUPPORTED;
+    DecArgs dec{W0, b0, scale1, shift1, W3, b3, logits};
+    return launch2<128, 128, 2, 2, true>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, shift, relu, nullptr, 0, 1,
+                                         stream, dec);
 }

@@ -275,8 +275,14 @@ class SurfaceNet(nn.Module):
             # whole scene as processing/data.py delivers it: 4 adjacency rows per cell (verified on the device, any
             # other layout falls through to the generic builder)
             plan = plan_for(edge_index, x.size(0), x.size(0), hint=ops.PLAN_HINT_REFERENCE)
+        if self.fuses_decoder(self.num_layers - 1) and self._fusable_rows(x, self.num_layers - 1):
+            return self._eval_layers(x, x.size(0), xe, [plan] * self.num_layers, sorted_attr=True, decode=True)   # last launch writes the logits
         x = self._eval_layers(x, x.size(0), xe, [plan] * self.num_layers, sorted_attr=True)
         return self._eval_decoder(x)
+
+    def _fusable_rows(self, x, i):
+        """the fused launches take packed 20-column fp32 edge rows and 16-byte aligned feature rows; other inputs run layer and decoder apart"""
+        return x.dtype == torch.float32 and not self.clf.regularization.edge_type
 
     def _fold(self, norm, c, device):
         """BatchNorm(eval) as a per-channel (scale, shift) pair, cached until one of its tensors is written to
@@ -297,7 +303,16 @@ class SurfaceNet(nn.Module):
     def fuses_decoder(self, i):
         """True when layer i's launch also carries the decoder (the last conv layer of the shipped widths, fp32 storage: the finished tile goes
         through Linear-BN-ReLU-Linear in the same kernel and only the logits are written, reference :180-187 applied at :350-351)"""
-        return False
+        if i != self.num_layers - 1 or self.storage_dtype != torch.float32 or not self.clf.model.decoder or len(self.decoder) != 4:
+            return False
+        conv, dec = self.convs[i][0], self.decoder
+        le = conv.lin_e
+        if not (isinstance(le, Linear) and isinstance(dec[0], nn.Linear) and isinstance(dec[3], nn.Linear) and isinstance(dec[2], nn.ReLU)):
+            return False
+        if not isinstance(self.convs[i][2], nn.ReLU) or (dec[1] is not None and not isinstance(dec[1], BatchNorm)):
+            return False
+        return ops.fused_layer_decoder_supported(conv.lin_j.in_features, conv.lin_j.out_features, le.in_features, dec[0].out_features,
+                                                 dec[3].out_features) and dec[0].in_features == conv.lin_j.out_features
 
     def _eval_layers(self, x, n_dst0, xe, plans, sorted_attr, only=None, out=None, rows=None, decode=False):
         """Eval-mode conv stack: per layer one fused launch when the widths allow it, else the
@@ -305,21 +320,36 @@ class SurfaceNet(nn.Module):
         `sorted_attr`: True = xe rows follow the caller's edge_index order (gathered by eid in the kernel or staged once),
         False = xe rows are already in plan order.  `only=i` runs just layer i (the partitioned forward exchanges halos between layers), `out` then
         optionally names the [>= n_dst, C_out] buffer to write into and `rows=(b, e)` restricts the launch to
-        the destinations [b, e) (written to out[b:e]; interior / boundary cells of a partition)."""
+        the destinations [b, e) (written to out[b:e]; interior / boundary cells of a partition).  `decode`: when the last layer of the
+        range `fuses_decoder`, its launch carries the decoder and LOGITS come back (`out`, if given, is then the [>= n_dst, 2] logits buffer)."""
         for i in (range(self.num_layers) if only is None else [only]):
             hook = ops.LAYER_HOOK
             conv_i = self.convs[i][0]
             n_rows = plans[i].n_dst if rows is None else rows[1] - rows[0]
-            tok = hook(None, x.size(1), conv_i.lin_j.out_features, n_rows) if hook is not None else None
-            x = self._eval_layer(i, x, xe, plans[i], sorted_attr, out, rows)
+            dec_i = bool(decode) and self.fuses_decoder(i)
+            tok = hook(None, x.size(1), conv_i.lin_j.out_features, n_rows, not dec_i) if hook is not None else None
+            x = self._eval_layer(i, x, xe, plans[i], sorted_attr, out, rows, dec_i)
             if hook is not None:
-                hook(tok, conv_i.lin_i.in_features, conv_i.lin_j.out_features, n_rows)
+                hook(tok, conv_i.lin_i.in_features, conv_i.lin_j.out_features, n_rows, not dec_i)
         return x
 
-    def _eval_layer(self, i, x, xe, plan, sorted_attr, out, rows):
-        """One eval-mode conv layer + BN + ReLU (see _eval_layers)."""
+    def _eval_layer(self, i, x, xe, plan, sorted_attr, out, rows, decode=False):
+        """One eval-mode conv layer + BN + ReLU (see _eval_layers); `decode`: + the decoder, logits come back."""
         layer = self.convs[i]
         conv = layer[0]
+        if decode:
+            le_ = conv.lin_e
+            fusable = (x.dtype == torch.float32 and isinstance(le_, Linear) and le_.in_features == 20
+                       and ops.fused_layer_supported(x.size(1), conv.lin_j.out_features, 20, x)
+                       and ops.fused_layer_decoder_supported(x.size(1), conv.lin_j.out_features, 20, self.decoder[0].out_features,
+                                                             self.decoder[3].out_features, x))
+            if not fusable:     # this input cannot take the one-launch form (alignment, strides ...): layer and decoder apart, same interface
+                lg = self._eval_decoder(self._eval_layer(i, x, xe, plan, sorted_attr, None, rows, False))
+                if out is None:
+                    return lg
+                b_, e_ = (0, plan.n_dst) if rows is None else rows
+                out[b_:e_] = lg
+                return out
         norm = layer[1] if isinstance(layer[1], BatchNorm) else None
         scale, shift = self._fold(norm, conv.lin_j.out_features, x.device)
         le = conv.lin_e
@@ -356,6 +386,21 @@ class SurfaceNet(nn.Module):
                 raise ops.DgnnError("fused layer: source rows beyond 2^32 elements (%d x %d); partition the scene "
                                     "(dgnn_amd.partition)" % (x.size(0), x.stride(0)))
             chunk = max(1, (ops.FUSED_MAX_ELEMS - 1) // max(x.stride(0), 1))
+            if decode and ops.fused_layer_decoder_supported(x.size(1), conv.lin_j.out_features, 20, self.decoder[0].out_features,
+                                                            self.decoder[3].out_features, x):
+                dec = self.decoder
+                s1, h1 = self._fold(dec[1] if isinstance(dec[1], BatchNorm) else None, dec[0].out_features, x.device)
+                if out_v is None:
+                    out_v = torch.empty((n, 2), dtype=torch.float32, device=x.device)
+                for s0 in range(0, n, chunk):
+                    s1_ = min(n, s0 + chunk)
+                    ops.sage_layer_fused_decoder_fwd(rowptr[s0:s1_ + 1] if (s0 or s1_ < n) else rowptr, plan.src, s1_ - s0, x, ea, le.weight, le.bias,
+                                                     conv.lin_j.weight, conv.lin_j.bias, conv.lin_i.weight, scale, shift, True, dec[0].weight, dec[0].bias,
+                                                     s1, h1, dec[3].weight, dec[3].bias, out=out_v[s0:s1_], eid=eid,
+                                                     x_dst=x_dst[s0:s1_] if (b or s0) else None)
+                return out_v
+            if decode:
+                raise ops.DgnnError("decode=True on a layer whose launch cannot carry the decoder (check fuses_decoder first)")
             if n <= chunk:
                 x = ops.sage_layer_fused_fwd(rowptr, plan.src, n, x, ea, le.weight, le.bias, conv.lin_j.weight,
                                              conv.lin_j.bias, conv.lin_i.weight, scale, shift, True, out=out_v, eid=eid,

@@ -384,6 +384,37 @@ def sage_layer_fused_fwd(rowptr, src, n_dst, x_src, edge_attr, We, be, Wj, bj, W
     return out
 
 
+# the last conv layer and the decoder in one launch (dgnn_sage_layer_fused_decoder_fwd); DGNN_FUSE_DECODER=0 keeps them apart
+FUSE_DECODER = __import__("os").environ.get("DGNN_FUSE_DECODER", "1") != "0"
+
+
+def fused_layer_decoder_supported(c_in: int, c_out: int, f_e: int, hidden: int, n_out: int, x=None) -> bool:
+    """shipped shape only: 64 < c_in <= 128, c_out 128, 20 edge attributes, decoder 128 -> 64 -> 2, default arithmetic, fp32 rows"""
+    ok = (FUSE_DECODER and FUSED_ENABLED and GEMM_MODE == GEMM_F16X2 and 64 < c_in <= 128 and c_in % 8 == 0 and c_out == 128 and f_e == 20
+          and hidden == 64 and n_out == 2)
+    if ok and x is not None:
+        ok = x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+    return ok
+
+
+@on_device_of
+def sage_layer_fused_decoder_fwd(rowptr, src, n_dst, x_src, edge_attr, We, be, Wj, bj, Wi, scale, shift, relu, W0, b0, scale1, shift1, W3, b3,
+                                 out=None, eid=None, x_dst=None):
+    """Last conv layer + decoder, one launch -> logits [n_dst, 2] (written into `out` when given: a contiguous [>= n_dst, 2] fp32 buffer)."""
+    _req(x_src, "x_src", dim=2)
+    if out is None:
+        out = torch.empty((n_dst, 2), dtype=torch.float32, device=x_src.device)
+    else:
+        _req(out, "out", dim=2)
+        if out.size(0) < n_dst or out.size(1) != 2 or out.stride(0) != 2:
+            raise ValueError("out must be a contiguous [>= n_dst, 2] buffer")
+    check(lib().dgnn_sage_layer_fused_decoder_fwd(
+        ptr(rowptr), ptr(src), ptr(eid), n_dst, ptr(x_src), ptr(x_dst), _ld(x_src), x_src.size(1), ptr(edge_attr), _ld(edge_attr), We.size(1),
+        ptr(We), ptr(be), ptr(Wj), ptr(bj), ptr(Wi), ptr(scale), ptr(shift), int(bool(relu)), Wj.size(0), ptr(W0.contiguous()), ptr(b0),
+        ptr(scale1), ptr(shift1), W0.size(0), ptr(W3.contiguous()), ptr(b3), W3.size(0), ptr(out), stream_ptr()), "dgnn_sage_layer_fused_decoder_fwd")
+    return out
+
+
 def decoder_fused_supported(k: int, hidden: int, n_out: int) -> bool:
     return k == 128 and hidden == 64 and n_out in (1, 2)
 

@@ -228,6 +228,22 @@ int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* src, const i
                               const float* scale, const float* shift, int relu, int c_out, float* out, int64_t ldo,
                               int gemm_mode, void* stream);
 
+/* The LAST conv layer + BatchNorm(eval) + ReLU of SurfaceNet.inference_layer (learning/surfaceNetStaticEdgeFilters.py:343-347) together with the
+ * decoder Linear(c_out -> c_hidden) - BatchNorm(eval, folded into scale1 / shift1, NULL = none) - ReLU - Linear(c_hidden -> n_logits)
+ * (:180-187, applied :350-351) in ONE launch: a finished tile of 32 tets stays in the compute unit, goes through the decoder there and
+ * only logits [n_dst, n_logits] (row stride n_logits) are written -- 8 bytes per tet instead of 512 out and 512 back in.
+ * Layer arguments as dgnn_sage_layer_fused_fwd.  Covers the shipped shape: 64 < c_in <= 128 (c_in % 8 == 0), c_out = 128, f_e = 20 (packed rows),
+ * c_hidden = 64, n_logits = 2, rows 16-byte aligned; arithmetic = DGNN_GEMM_F16X2 throughout (the decoder's first product: one power-of-two
+ * scale per tet row and 16-column slab, applied to the fp32 sum).  Any other shape: DGNN_E_UNSUPPORTED, nothing launched -- the caller then
+ * runs dgnn_sage_layer_fused_fwd and dgnn_decoder_fused_fwd.  A tet's logits depend on its own inputs only (destination sub-ranges of a
+ * partitioned scene give bit-identical results). */
+int dgnn_sage_layer_fused_decoder_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src,
+                                      const float* x_dst, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e,
+                                      const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
+                                      const float* scale, const float* shift, int relu, int c_out, const float* W0, const float* b0,
+                                      const float* scale1, const float* shift1, int c_hidden, const float* W3, const float* b3, int n_logits,
+                                      float* logits, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Training-mode conv layer, one call each way (SurfaceNet.forward :214-219 and its autograd, learning/runModel.py:279):
  *   forward : a = aggregate(x)  ->  z = a.Wj^T + x[:n_dst].Wi^T + bj  ->  BatchNorm1d with batch statistics (running buffers

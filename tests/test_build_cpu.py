@@ -36,4 +36,5 @@ def test_default_fused_kernels_use_no_scratch(tmp_path):
             seen += 1
             assert int(scratch) == 0 and int(spills) == 0, (name, scratch, spills)
             assert int(vgprs) <= 256, (name, vgprs)
-    assert seen >= 10, seen
+    assert seen >= 11, seen
+    assert any("ELb1E" in k[0] for k in kernels), "the decoder-carrying instantiation (DEC) of the 128 -> 128 layer is missing"

@@ -105,13 +105,18 @@ def test_config4_10m_tets_eight_parts_equal_the_whole_graph():
     widths = [64, 128, 128, 128]
     own = [torch.from_numpy(lp.own_gid).to(DEV) for lp in lps]
     halo = [torch.from_numpy(lp.halo_gid).to(DEV) for lp in lps]
+    fuse = net.fuses_decoder(3)        # the last layer's launches then carry the decoder and write logits (as PartitionedScene.inference_layer runs them)
     for i in range(net.num_layers):
         bufs = []
         for r, lp in enumerate(lps):
-            buf = torch.full((lp.n_own + lp.n_halo, widths[i]), float("nan"), device=DEV)
+            dec = fuse and i == 3
+            buf = torch.full((lp.n_own, 2) if dec else (lp.n_own + lp.n_halo, widths[i]), float("nan"), device=DEV)
             for b, e in ((0, lp.n_interior), (lp.n_interior, lp.n_own)):
-                net._eval_layers(hs[r], lp.n_own, eas[r], [plans[r]] * 4, False, only=i, out=buf, rows=(b, e))
+                net._eval_layers(hs[r], lp.n_own, eas[r], [plans[r]] * 4, False, only=i, out=buf, rows=(b, e), decode=dec)
             bufs.append(buf)
+        if dec:
+            hs = bufs
+            break
         glob = torch.empty(n, widths[i], device=DEV)
         for r in range(world):
             glob[own[r]] = bufs[r][:lps[r].n_own]
@@ -121,5 +126,5 @@ def test_config4_10m_tets_eight_parts_equal_the_whole_graph():
         hs = bufs
     logits = torch.full((n, 2), float("nan"), device=DEV)
     for r in range(world):
-        logits[own[r]] = net._eval_decoder(hs[r][:lps[r].n_own])
+        logits[own[r]] = hs[r] if fuse else net._eval_decoder(hs[r][:lps[r].n_own])
     assert torch.equal(logits, full)

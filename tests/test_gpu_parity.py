@@ -326,6 +326,50 @@ def test_batch_layer_and_layer_batch_schedules():
     assert (full - lb).abs().max().item() <= TOL_LOGIT
 
 
+@pytest.mark.parametrize("points,heavy", [(12, False), (333, False), (3000, True)])
+def test_last_layer_and_decoder_in_one_launch(points, heavy):
+    """dgnn_sage_layer_fused_decoder_fwd (the last conv layer's launch carries Linear-BN-ReLU-Linear and writes logits, reference :180-187 / :350-351):
+    against the oracle, against the two-launch form, on graphs smaller than a tile and not a multiple of one, with heavy-tailed inputs (the
+    per-slab power-of-two scales), and in destination sub-ranges (bit-identical to the whole launch, as a partitioned scene needs)."""
+    from dgnn_amd import ops
+    from dgnn_amd.graph import GraphPlan
+    from dgnn_amd.synthetic import delaunay_tet_graph
+    net = hip_static()
+    assert net.fuses_decoder(3) and not net.fuses_decoder(2)
+    adj, _, _ = delaunay_tet_graph(points, seed=points)
+    n = adj.shape[0] // 4
+    g = torch.Generator().manual_seed(points)
+    x, ea = torch.randn(n, 29, generator=g), torch.randn(4 * n, 20, generator=g)
+    if heavy:
+        x[::17] *= 40.0
+        ea[::23] *= 25.0
+    ei = torch.from_numpy(adj.T.astype(np.int64))
+    with torch.no_grad():
+        ref = oracle_static().inference_layer(Config(x=x, edge_attr=ea, edge_index=ei))
+    data = Config(x=x.to(DEV), edge_attr=ea.to(DEV), edge_index=ei.to(DEV))
+    one = net.inference_layer(data)
+    old, ops.FUSE_DECODER = ops.FUSE_DECODER, False
+    try:
+        assert not net.fuses_decoder(3)
+        two = net.inference_layer(data)
+    finally:
+        ops.FUSE_DECODER = old
+    tol = TOL_LOGIT * max(1.0, ref.abs().max().item())
+    assert (one.cpu() - ref).abs().max().item() <= tol and (two.cpu() - ref).abs().max().item() <= tol
+    assert (one - two).abs().max().item() <= 0.3 * tol
+    assert torch.equal(one, net.inference_layer(data))                       # run to run
+    # destination sub-ranges of the last layer (interior / boundary launches of a partition): the same logits bit for bit
+    plan = GraphPlan(data.edge_index, n, n)
+    h = data.x[:, 1:]
+    for i in range(3):
+        h = net._eval_layers(h, n, data.edge_attr, [plan] * 4, True, only=i)
+    cut = [0, n // 3, n // 3 + 1, n]
+    out = torch.full((n, 2), float("nan"), device=DEV)
+    for b, e in zip(cut[:-1], cut[1:]):
+        net._eval_layers(h, n, data.edge_attr, [plan] * 4, True, only=3, out=out, rows=(b, e), decode=True)
+    assert torch.equal(out, one)
+
+
 def test_other_widths_random_init():
     """[64,128,256,512] (configs/aerial.yaml:57) exercises the non-fused path and wide channel tiling."""
     from oracle.static_edge_filters import SurfaceNet as ONet
@@ -369,14 +413,19 @@ def test_partitioned_hip_forward_equals_whole_graph(world):
     eas = [ea[torch.from_numpy(lp.edge_gid).to(DEV)] for lp in lps]     # already in plan order
     hs = [x[torch.from_numpy(np.concatenate([lp.own_gid, lp.halo_gid])).to(DEV)][:, 1:] for lp in lps]
     widths = [64, 128, 128, 128]
+    fuse = net.fuses_decoder(3)        # the last layer's launches then carry the decoder and write logits (as PartitionedScene.inference_layer runs them)
     for i in range(net.num_layers):
         bufs = []
         for r, lp in enumerate(lps):
             # as run_partitioned_layers does: interior cells, then (after the halo landed) boundary cells, as two launches
-            buf = torch.full((lp.n_own + lp.n_halo, widths[i]), float("nan"), device=DEV)
+            dec = fuse and i == 3
+            buf = torch.full((lp.n_own, 2) if dec else (lp.n_own + lp.n_halo, widths[i]), float("nan"), device=DEV)
             for b, e in ((0, lp.n_interior), (lp.n_interior, lp.n_own)):
-                net._eval_layers(hs[r], lp.n_own, eas[r], [plans[r]] * 4, False, only=i, out=buf, rows=(b, e))
+                net._eval_layers(hs[r], lp.n_own, eas[r], [plans[r]] * 4, False, only=i, out=buf, rows=(b, e), decode=dec)
             bufs.append(buf)
+        if fuse and i == 3:
+            hs = bufs
+            break
         glob = torch.empty(n, widths[i], device=DEV)
         for r in range(world):
             glob[torch.from_numpy(lps[r].own_gid).to(DEV)] = bufs[r][:lps[r].n_own]
@@ -385,7 +434,7 @@ def test_partitioned_hip_forward_equals_whole_graph(world):
         hs = bufs
     logits = torch.empty(n, 2, device=DEV)
     for r in range(world):
-        logits[torch.from_numpy(lps[r].own_gid).to(DEV)] = net._eval_decoder(hs[r][:lps[r].n_own])
+        logits[torch.from_numpy(lps[r].own_gid).to(DEV)] = hs[r] if fuse else net._eval_decoder(hs[r][:lps[r].n_own])
     assert torch.equal(logits, full)
 
 
