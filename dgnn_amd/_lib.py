@@ -30,6 +30,8 @@ SIGNATURES = {
     "dgnn_linear_fwd_x3": (i32, [vp, i64, i32, vp, i64, vp, i64, i32, vp, i64, vp, vp, vp, i32, i64, i32, vp, i64, vp]),
     "dgnn_linear_fwd_x2h": (i32, [vp, i64, i32, vp, i64, vp, i64, i32, vp, i64, vp, vp, vp, i32, i64, i32, vp, i64, vp, vp]),
     "dgnn_linear_fwd_x2h_scratch_elems": (i64, [i64, i32]),
+    "dgnn_linear_fwd_x2hp": (i32, [vp, i64, i32, vp, i64, vp, i64, i32, vp, i64, vp, vp, vp, i32, i64, i32, vp, i64, vp, vp]),
+    "dgnn_linear_fwd_x2hp_scratch_elems": (i64, [i64, i32, i32, i32]),
     "dgnn_linear_wgrad_x3": (i32, [vp, i64, i32, vp, i64, i32, i64, vp, i64, i32, vp, vp]),
     "dgnn_linear_wgrad_scratch_elems": (i64, [i64, i32, i32]),
     "dgnn_linear_wgrad": (i32, [vp, i64, i32, vp, i64, i32, i64, vp, i64, i32, vp, vp]),

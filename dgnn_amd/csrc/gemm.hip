@@ -1086,6 +1086,155 @@ __global__ void __launch_bounds__(YT, 1) k_linear_fwd_x2h_big(const float* __res
     }
 }
 
+// =====================================================================================================================
+// "x2hp": the x2h GEMM with operands split ONCE, by a pass of their own, instead of by every workgroup that stages them.
+//   pass 1 (k_x2hp_presplit): one wavefront per row of [A1 | A2] and of [W1 | W2]: row maximum -> power-of-two scale (as k_x2h_row_scales), then
+//       the scaled row as (hi, lo) fp16 in the GEMM's own staging format: per 32-wide K chunk 128 bytes = [hi x 32 | lo x 32]; k1 and k2 are
+//       padded to whole chunks with zeros.  Costs one more write + read of the operand (4 B per element, what the fp32 operand weighs).
+//   pass 2 (k_linear_fwd_x2hp_big): the 256 x 256 tile of x2h; a K chunk of both operands goes global -> LDS by DMA (global_load_lds, 16 bytes per
+//       lane, no registers, no VALU), double-buffered: ONE barrier per chunk, the next chunk's DMA in flight under the 48 products of the current one.
+//       LDS rows are 128 bytes without padding; the 16-byte pieces of a row are stored at slot (piece ^ (row & 7)) -- chosen through the DMA's
+//       per-lane SOURCE address -- so that the 32 rows a fragment read touches spread over all banks.
+// Same scaling groups, same chunk / k-step / product order as x2h: bit-identical results (tested).  What it removes is the ~220 split / address
+// VALU instructions per chunk that stand between the matrix instructions of x2h / x3 and the second barrier (DESIGN 7 "Next 2").
+// =====================================================================================================================
+constexpr int PCH = 128;   // bytes of one row's K chunk: [hi x 32 | lo x 32] fp16
+
+__global__ void __launch_bounds__(256) k_x2hp_presplit(const float* __restrict__ A1, int64_t lda1, int k1, const float* __restrict__ A2, int64_t lda2, int k2,
+                                                       int64_t M, const float* __restrict__ W1, int64_t ldw1, const float* __restrict__ W2, int64_t ldw2,
+                                                       int n_out, float* __restrict__ scales, char* __restrict__ As, char* __restrict__ Ws) {
+    const int lane = lane_id();
+    const int nch1 = (k1 + HK - 1) / HK, nch2 = A2 ? (k2 + HK - 1) / HK : 0;
+    const int64_t rowb = (int64_t)(nch1 + nch2) * PCH;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < M + n_out; row += nwaves) {
+        const bool isw = row >= M;
+        const float* p1 = isw ? W1 + (row - M) * ldw1 : A1 + row * lda1;
+        const float* p2 = isw ? (W2 ? W2 + (row - M) * ldw2 : nullptr) : (A2 ? A2 + row * lda2 : nullptr);
+        float m = 0.f;
+        for (int k = lane; k < k1; k += 64) m = fmaxf(m, fabsf(p1[k]));
+        if (p2)
+            for (int k = lane; k < k2; k += 64) m = fmaxf(m, fabsf(p2[k]));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        const float s_ = x2h_scale_of(m);
+        if (lane == 0) scales[row] = s_;
+        char* dst = (isw ? Ws + (row - M) * rowb : As + row * rowb);
+        // 4 chunks per sweep: lane -> (chunk, pair of consecutive k); the row was read a moment ago and comes from the caches
+        const int pr = lane & 15, cq = lane >> 4;
+        for (int ch = cq; ch < nch1 + nch2; ch += 4) {
+            const bool first = ch < nch1;
+            const float* src_ = first ? p1 : p2;
+            const int kk = first ? k1 : k2, k = (first ? ch : ch - nch1) * HK + 2 * pr;
+            const float v0 = k < kk ? src_[k] : 0.f, v1 = k + 1 < kk ? src_[k + 1] : 0.f;
+            uint32_t hi, lo;
+            x2h_split(v0 * s_, v1 * s_, hi, lo);
+            uint32_t* d = reinterpret_cast<uint32_t*>(dst + (int64_t)ch * PCH) + pr;
+            d[0] = hi;
+            d[16] = lo;
+        }
+    }
+}
+
+__device__ __forceinline__ void x2hp_dma16(const char* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__global__ void __launch_bounds__(YT, 1) k_linear_fwd_x2hp_big(const char* __restrict__ As, const char* __restrict__ Ws, int nch,
+                                                               const float* __restrict__ bias, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, int relu, int64_t M, int n_out,
+                                                               float* __restrict__ out, int64_t ldo, const float* __restrict__ scales) {
+    extern __shared__ __attribute__((aligned(16))) char y2p_smem[];   // [2 buffers][A 256 rows | W 256 rows] x 128 B
+    constexpr int BUF = (YM + YN) * PCH;
+    const int lane = lane_id(), w = wave_id_uniform();
+    const int wr = w >> 2, wc = w & 3, h = lane >> 5, l31 = lane & 31;
+    const int ncb = (n_out + YN - 1) / YN;   // XCD-aware tile map (see k_linear_fwd_x3)
+    const int64_t rb = (int64_t)((blockIdx.x >> 3) / ncb) * 8 + (blockIdx.x & 7);
+    if (rb * YM >= M) return;
+    const int64_t row0 = rb * YM;
+    const int col0 = (int)((blockIdx.x >> 3) % ncb) * YN;
+    const int64_t rowb = (int64_t)nch * PCH;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    // DMA roles: one instruction moves 8 rows x 128 B (1 KB of LDS, contiguous); this wave takes instructions w, w + 8, ... of the 32 (A) + 32 (W).
+    // lane -> (row of the group rr = lane >> 3, LDS slot q = lane & 7); slot q of row r holds logical piece q ^ (r & 7)
+    const int rr = lane >> 3, q = lane & 7;
+    const char* gsrc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ins = w + 8 * j;                 // 0..31: A rows, 32..63: W rows
+        const int r_t = (ins & 31) * 8 + rr;       // row within the tile
+        const int piece = q ^ (r_t & 7);
+        if (ins < 32) {
+            const int64_t gr = row0 + r_t;
+            gsrc[j] = As + (gr < M ? gr : M - 1) * rowb + piece * 16;
+        } else {
+            const int gc = col0 + r_t;
+            gsrc[j] = Ws + (int64_t)(gc < n_out ? gc : n_out - 1) * rowb + piece * 16;
+        }
+    }
+    auto dma_chunk = [&](int ch) {
+        char* buf = y2p_smem + (ch & 1) * BUF;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x2hp_dma16(gsrc[j] + (int64_t)ch * PCH, buf + (w + 8 * j) * 1024);
+    };
+    dma_chunk(0);
+    for (int ch = 0; ch < nch; ++ch) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of chunk ch has landed
+        __syncthreads();                                     // everybody's has; everybody is done with the other buffer (chunk ch - 1)
+        if (ch + 1 < nch) dma_chunk(ch + 1);                 // in flight under the products below
+        const char* Ab = y2p_smem + (ch & 1) * BUF;
+        const char* Wb = Ab + YM * PCH;
+        const int ar0 = wr * 128 + l31, br0 = wc * 64 + l31;   // rows are multiples of 32 apart: (row & 7) = (l31 & 7) for all of them
+        const int sw = l31 & 7;
+#pragma unroll
+        for (int S = 0; S < HK / 16; ++S) {
+            h16x8_t bf[2][2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) bf[m][p] = *reinterpret_cast<const h16x8_t*>(Wb + (br0 + m * 32) * PCH + (((4 * p + 2 * S + h) ^ sw) << 4));
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                h16x8_t af[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) af[p] = *reinterpret_cast<const h16x8_t*>(Ab + (ar0 + a * 32) * PCH + (((4 * p + 2 * S + h) ^ sw) << 4));
+                constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};   // small terms first; the two column blocks alternate product by product (as x2h)
+#pragma unroll
+                for (int qq = 0; qq < 3; ++qq)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[PA[qq]], bf[b][PB[qq]], acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int col = col0 + wc * 64 + b * 32 + l31;
+        if (col >= n_out) continue;
+        const float bb = bias ? bias[col] : 0.f;
+        const float sc = scale ? scale[col] : 1.f;
+        const float sh = scale ? shift[col] : 0.f;
+        const float iw = x2h_inv(scales[M + col]);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + wr * 128 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= M) continue;
+                float v = __fmaf_rn(acc[a][b][r], x2h_inv(scales[row]) * iw, bb);
+                if (scale) v = __fmaf_rn(v, sc, sh);
+                if (relu & 1) v = fmaxf(v, 0.f);
+                if (relu & DGNN_LINEAR_ACCUMULATE) v += out[row * ldo + col];
+                out[row * ldo + col] = v;
+            }
+    }
+}
+
 // dW[na, nb] = sum_rows A[r, :]^T B[r, :], fp32 operands split in 3 bf16 parts while they are staged TRANSPOSED ([column][row]):
 // a thread takes 2 consecutive rows x 4 columns, so that a packed bf16 pair is two consecutive k (= rows) of one column.
 // 64 x 64 tile per block, wave (wa, wb) owns a 32 x 32 block; row slices of 32.
@@ -1313,6 +1462,40 @@ extern "C" int dgnn_linear_fwd_x2h(const float* A1, int64_t lda1, int k1, const 
     hipLaunchKernelGGL(k_linear_fwd_x2h_big, grid, dim3(YT), lds, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2, lda2, k2, W2, ldw2, v2, bias,
                        scale, shift, relu, M, n_out, out, ldo, (const float*)scratch);
     return dgnn_check_launch("linear_fwd_x2h");
+}
+
+// scratch of dgnn_linear_fwd_x2hp, in floats: row scales [M + n_out] (padded to 16 bytes), then the pre-split operands
+// (M + n_out) rows x (ceil(k1/32) + ceil(k2/32)) chunks x 128 bytes
+extern "C" int64_t dgnn_linear_fwd_x2hp_scratch_elems(int64_t M, int n_out, int k1, int k2) {
+    if (M < 0 || n_out <= 0 || k1 <= 0 || k2 < 0) return 0;
+    const int64_t nch = (k1 + HK - 1) / HK + (k2 + HK - 1) / HK;
+    return ((M + n_out + 3) / 4) * 4 + (M + n_out) * nch * (PCH / 4);
+}
+
+// dgnn_linear_fwd_x2h with the operands split once by a pass of their own and staged by DMA (see k_x2hp_presplit / k_linear_fwd_x2hp_big): same
+// arguments, same results bit for bit, scratch = dgnn_linear_fwd_x2hp_scratch_elems(M, n_out, k1, k2) floats (16-byte aligned).
+extern "C" int dgnn_linear_fwd_x2hp(const float* A1, int64_t lda1, int k1, const float* W1, int64_t ldw1, const float* A2, int64_t lda2, int k2,
+                                    const float* W2, int64_t ldw2, const float* bias, const float* scale, const float* shift, int relu,
+                                    int64_t M, int n_out, float* out, int64_t ldo, float* scratch, void* stream) {
+    DGNN_REQUIRE(M >= 0 && n_out > 0 && k1 > 0, DGNN_E_INVALID, "linear_fwd_x2hp: bad sizes M=%lld n_out=%d k1=%d", (long long)M, n_out, k1);
+    if (M == 0) return DGNN_OK;
+    DGNN_REQUIRE(A1 && W1 && out && scratch && ((uintptr_t)scratch % 16) == 0, DGNN_E_INVALID, "linear_fwd_x2hp: null / unaligned pointer");
+    DGNN_REQUIRE((A2 == nullptr) == (W2 == nullptr) && (!A2 || k2 > 0), DGNN_E_INVALID, "linear_fwd_x2hp: A2/W2 must come together");
+    DGNN_REQUIRE((scale == nullptr) == (shift == nullptr), DGNN_E_INVALID, "linear_fwd_x2hp: scale/shift must come together");
+    if (!(M >= 8192 && n_out > XN)) return DGNN_E_UNSUPPORTED;
+    const int nch = (k1 + HK - 1) / HK + (A2 ? (k2 + HK - 1) / HK : 0);
+    float* scales = scratch;
+    char* As = reinterpret_cast<char*>(scratch + ((M + n_out + 3) / 4) * 4);
+    char* Ws = As + M * (int64_t)nch * PCH;
+    hipLaunchKernelGGL(k_x2hp_presplit, dim3((unsigned)dgnn_grid_cap(dgnn_cdiv(M + n_out, 4), 16)), dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, A2, lda2,
+                       A2 ? k2 : 0, M, W1, ldw1, W2, ldw2, n_out, scales, As, Ws);
+    static bool attr_set[DGNN_MAX_DEVICES];
+    constexpr size_t lds = (size_t)2 * (YM + YN) * PCH;
+    dgnn_allow_dynamic_lds((const void*)k_linear_fwd_x2hp_big, lds, attr_set);
+    dim3 grid((unsigned)(dgnn_cdiv(dgnn_cdiv(M, YM), 8) * 8 * dgnn_cdiv(n_out, YN)));
+    hipLaunchKernelGGL(k_linear_fwd_x2hp_big, grid, dim3(YT), lds, (hipStream_t)stream, (const char*)As, (const char*)Ws, nch, bias, scale, shift, relu, M, n_out,
+                       out, ldo, (const float*)scales);
+    return dgnn_check_launch("linear_fwd_x2hp");
 }
 
 extern "C" int dgnn_linear_wgrad_x3(const float* A, int64_t lda, int n_a, const float* B, int64_t ldb, int n_b, int64_t M, float* dW,

@@ -228,14 +228,20 @@ def linear_fwd(A1, W1, A2=None, W2=None, bias=None, scale=None, shift=None, relu
         return out
     # fp32 operands: bit-faithful fp32 MFMA ("f32" mode) or the fused layers' exact-split bf16 arithmetic (fp32-class, 6/16 of the time)
     if GEMM_MODE == GEMM_F16X2 and M >= 8192 and n_out > 256:  # (at n_out <= 256 the extra pass over A for the row scales costs what the products save)
-        # the wide conv layers in the fused layers' fp16 two-part form (row scales in a scratch vector)
-        scratch = torch.empty(int(lib().dgnn_linear_fwd_x2h_scratch_elems(M, n_out)), dtype=torch.float32, device=A1.device)
-        rc = lib().dgnn_linear_fwd_x2h(
-            ptr(A1), _ld(A1), A1.size(1), ptr(W1), W1.size(1),
-            ptr(A2), _ld(A2) if A2 is not None else 0, A2.size(1) if A2 is not None else 0, ptr(W2), W2.size(1) if W2 is not None else 0,
+        # the wide conv layers in the fused layers' fp16 two-part form (X2HP: see above)
+        k1, k2 = A1.size(1), (A2.size(1) if A2 is not None else 0)
+        if X2HP:
+            scratch = torch.empty(int(lib().dgnn_linear_fwd_x2hp_scratch_elems(M, n_out, k1, k2)), dtype=torch.float32, device=A1.device)
+            entry, name = lib().dgnn_linear_fwd_x2hp, "dgnn_linear_fwd_x2hp"
+        else:
+            scratch = torch.empty(int(lib().dgnn_linear_fwd_x2h_scratch_elems(M, n_out)), dtype=torch.float32, device=A1.device)
+            entry, name = lib().dgnn_linear_fwd_x2h, "dgnn_linear_fwd_x2h"
+        rc = entry(
+            ptr(A1), _ld(A1), k1, ptr(W1), W1.size(1),
+            ptr(A2), _ld(A2) if A2 is not None else 0, k2, ptr(W2), W2.size(1) if W2 is not None else 0,
             ptr(bias), ptr(scale), ptr(shift), int(bool(relu)), M, n_out, ptr(out), n_out, ptr(scratch), stream_ptr())
         if rc != DGNN_E_UNSUPPORTED:
-            check(rc, "dgnn_linear_fwd_x2h")
+            check(rc, name)
             return out
     fn = lib().dgnn_linear_fwd if GEMM_MODE == GEMM_F32 else lib().dgnn_linear_fwd_x3
     check(fn(
@@ -342,6 +348,10 @@ def fused_layer_supported(c_in: int, c_out: int, f_e: int, x: torch.Tensor = Non
 
 FUSED_ENABLED = True
 GEMM_F32, GEMM_BF16X3, GEMM_BF16X3_FILTER, GEMM_F16X2_DENSE, GEMM_F16X2 = 0, 1, 2, 3, 4
+# wide GEMMs with operands pre-split by a pass of their own and staged by DMA (dgnn_linear_fwd_x2hp, bit-identical to x2h).  OFF by default: the GEMM
+# itself runs 1.3-1.5x faster (317 vs 200-260 TFLOP/s fp32-equivalent at M = 1M) but the extra write + read of the split operand costs more
+# than that saves (512 -> 1024 layer 11.7 vs 10.8 ms, 256 -> 512 4.8 vs 4.2 ms; profiles/r03_wide.md)
+X2HP = __import__("os").environ.get("DGNN_X2HP", "0") != "0"
 GEMM_MODE_NAMES = {"f32": GEMM_F32, "bf16x3": GEMM_BF16X3, "bf16x3f": GEMM_BF16X3_FILTER, "f16x2d": GEMM_F16X2_DENSE, "f16x2": GEMM_F16X2}
 # how the fused layer uses the matrix cores: exact-fp32 MFMA for the dense part ("f32"), 3-way split-bf16 MFMA for the
 # dense part ("bf16x3"), or split-bf16 MFMA for the dense part AND the filter MLP ("bf16x3f"); all fp32-class accuracy

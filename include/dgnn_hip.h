@@ -137,6 +137,15 @@ int64_t dgnn_linear_fwd_x2h_scratch_elems(int64_t M, int n_out);
 int dgnn_linear_fwd_x2h(const float* A1, int64_t lda1, int k1, const float* W1, int64_t ldw1, const float* A2, int64_t lda2, int k2,
                         const float* W2, int64_t ldw2, const float* bias, const float* scale, const float* shift, int relu,
                         int64_t M, int n_out, float* out, int64_t ldo, float* scratch, void* stream);
+/* dgnn_linear_fwd_x2h with both operands split ONCE by a pass of their own (row scale, (hi, lo) fp16 in the GEMM's staging format) and staged
+ * global -> LDS by DMA: same arguments, results bit-identical to dgnn_linear_fwd_x2h, no split arithmetic between the matrix instructions.
+ * scratch: dgnn_linear_fwd_x2hp_scratch_elems(M, n_out, k1, k2) floats, 16-byte aligned (row scales + the pre-split operands, 4 bytes per
+ * element of [A1 | A2] and [W1 | W2] with k1, k2 rounded up to multiples of 32). */
+int64_t dgnn_linear_fwd_x2hp_scratch_elems(int64_t M, int n_out, int k1, int k2);
+int dgnn_linear_fwd_x2hp(const float* A1, int64_t lda1, int k1, const float* W1, int64_t ldw1, const float* A2, int64_t lda2, int k2,
+                         const float* W2, int64_t ldw2, const float* bias, const float* scale, const float* shift, int relu,
+                         int64_t M, int n_out, float* out, int64_t ldo, float* scratch, void* stream);
+
 int dgnn_linear_wgrad_x3(const float* A, int64_t lda, int n_a, const float* B, int64_t ldb, int n_b, int64_t M, float* dW, int64_t lddw,
                          int accumulate, float* partials, void* stream);
 
