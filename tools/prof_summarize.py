@@ -28,7 +28,8 @@ ap.add_argument("--bench", nargs="*", default=[])
 a = ap.parse_args()
 G = os.path.join(ROOT, "gpurun_out")
 shape = tuple(int(v) for v in a.shape.split(","))
-DOM = a.kernel or ("k_sage_fused_bf16<%d, %d" % shape if a.dtype == "bf16" else "k_sage_fused_mfma<%d, %d" % shape)
+# (fp32: the plain layer kernel -- template argument DEC = false; the last layer's launch that also carries the decoder is the `true` instantiation)
+DOM = a.kernel or ("k_sage_fused_bf16<%d, %d" % shape if a.dtype == "bf16" else "k_sage_fused_mfma<%d, %d, 8, 2, 2, 2, f" % shape)
 elem = 2 if a.dtype == "bf16" else 4
 N = 1010078
 
@@ -91,7 +92,8 @@ if fetch and write:
             "* effective clock: GRBM_GUI_ACTIVE %.3g / 8 XCDs / %.0f us = %.2f GHz" % (gui, dur, clk),
             "* matrix pipe: SQ_VALU_MFMA_BUSY_CYCLES %.4g / 1024 SIMDs = %.3g busy cycles per SIMD of %.3g elapsed -> %.0f %% busy" % (
                 busy, busy / 1024, cyc, 100 * busy / 1024 / cyc),
-            "* VALU: SQ_INSTS_VALU %.4g wave instructions x 4 cycles / 1024 SIMDs -> %.0f %% of SIMD cycles" % (valu, 100 * valu * 4 / 1024 / cyc),
+            "* VALU: SQ_INSTS_VALU %.4g wave instructions x 2 cycles (SIMD-32, MI355X_MICROARCH.md; rounds 1-2 priced them at 4) / 1024 SIMDs -> %.0f %% of SIMD cycles" % (
+                valu, 100 * valu * 2 / 1024 / cyc),
             "* waves: %.0f %% of wave cycles parked at s_waitcnt / s_barrier (SQ_WAIT_ANY), %.0f %% stalled at issue (SQ_WAIT_INST_ANY), %.0f %% issuing" % (
                 100 * wany / wc, 100 * winst / wc, 100 * act / wc),
             "* L2: TCC hit rate %.0f %%" % (100 * hit / (hit + miss)),
@@ -106,7 +108,7 @@ if fetch and write:
     if not commit:
         commit = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or None
     json.dump({"kernel": DOM, "dtype": a.dtype, "shape": list(shape), "n_tets": N, "traffic_bytes_per_launch": traffic, "fetch_kib": fetch,
-               "write_kib": write, "mfma_busy_frac": round(busy / 1024 / cyc, 4), "valu_busy_frac": round(valu * 4 / 1024 / cyc, 4),
+               "write_kib": write, "mfma_busy_frac": round(busy / 1024 / cyc, 4), "valu_busy_frac": round(valu * 2 / 1024 / cyc, 4),
                "tcc_hit_rate": round(hit / (hit + miss), 4), "clock_ghz": round(clk, 3), "avg_launch_us_profiled": dur,
                "avg_launch_us_kernel_trace": trace_ns / 1e3 if trace_ns else None, "commit": commit, "csrc_sha": bench.csrc_sha(),
                "source": "profiles/%s.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH doubled per the guide)" % a.name},
