@@ -407,28 +407,17 @@ def main():
         else:
             breakdown["decoder_ms"] = timed(lambda: net._eval_decoder(h))
 
-    f_in = 28
-    shapes = list(zip([f_in] + list(convs)[:-1], convs))
-    if breakdown:
-        per_shape = {}
-        for i, sh_ in enumerate(shapes):
-            per_shape[sh_] = per_shape.get(sh_, 0.0) + breakdown.get("layer%d_ms" % i, breakdown.get("layer%d_and_decoder_ms" % i, 0.0))
-        dom = max(per_shape, key=per_shape.get)
-    else:
-        dom = max(shapes, key=lambda s_: layer_bytes(*s_))
-    # HIP events around the launches of the dominant conv layer shape (the one the replays above found to take the most
-    # time) INSIDE the timed region, recorded on the stream the kernels are launched on (torch's current stream).  A launch that
-    # also carries the decoder (last layer, fused epilogue) is not a launch of the plain layer kernel and is not counted.
+    # HIP events around EVERY conv layer launch inside the timed region, recorded on the stream the kernels are launched on (torch's current stream),
+    # keyed by (c_in, c_out, plain): `plain` = the layer kernel proper, not plain = the last layer's launch that also carries the decoder.  The roofline
+    # object describes the kind of launch with the largest share of the step; the other kind of the same shape is nested under `roofline.also`.
     layer_events = {}
 
     def hook(tok, c_in, c_out, n_dst, plain=True):
-        if (c_in, c_out) != dom or not plain:
-            return None
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         if tok is None:
             return ev
-        layer_events.setdefault((c_in, c_out), []).append((tok, ev, n_dst))
+        layer_events.setdefault((c_in, c_out, bool(plain)), []).append((tok, ev, n_dst))
         return None
     ops.LAYER_HOOK = hook
     dt, per_step = timed_steps(step, args.steps, sync, world, dev)
@@ -436,72 +425,98 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = n_total * args.steps / dt
 
-    # ---- roofline of the dominant conv layer shape: HIP events on the launch stream, inside the timed steps ----
+    # ---- roofline of the dominant kind of launch: HIP events on the launch stream, inside the timed steps ----
+    def kind_stats(key):
+        evs = layer_events[key]
+        tot = sum(a.elapsed_time(b) for a, b, _ in evs)
+        rows = sum(r for _, _, r in evs)
+        # launches of this kind per step (a partitioned layer is two launches, interior + boundary cells: `rows` adds them up so that bytes and
+        # time cover the same cells)
+        n_l = max(1, round(rows / (n_local * args.steps)))
+        ms = tot / (n_l * args.steps)
+        c_in, c_out, plain = key
+        # SURVEY 8d per-unit figure of what this launch executes: the layer's row, plus the decoder's row (elem * C + 8) when it rides along
+        per_tet = layer_bytes(c_in, c_out, elem) + (0 if plain else elem * c_out + 8)
+        algo = int(per_tet * rows / (n_l * args.steps))
+        return {"total_ms": tot, "launches_per_step": n_l, "ms": ms, "algo": algo, "per_tet": per_tet, "rows_per_launch": rows / (n_l * args.steps), "n_events": len(evs)}
+
     roof = None
     if layer_events:
-        tot = {k: sum(a.elapsed_time(b) for a, b, _ in v) for k, v in layer_events.items()}
-        evs = layer_events[dom]
-        rows = sum(r for _, _, r in evs)
-        # launches of the plain layer kernel on this shape per step (a partitioned layer is two launches, interior + boundary cells: `rows`
-        # adds them up so that bytes and time cover the same cells)
-        n_layers_dom = max(1, round(rows / (n_local * args.steps)))
-        dom_ms = tot[dom] / (n_layers_dom * args.steps)
-        algo = int(layer_bytes(dom[0], dom[1], elem) * rows / (n_layers_dom * args.steps))
-        achieved = algo / (dom_ms * 1e-3) / 1e9
-        fused = ops.fused_layer_supported(dom[0], dom[1], 20)
-        if bf16:
-            kname = net.dominant_kernel_name(dom)
-        elif fused:
-            kname = {0: "k_sage_fused<%d,%d,0>", 1: "k_sage_fused<%d,%d,1>", 2: "k_sage_fused_mfma<%d,%d>", 3: "k_sage_fused_mfma<%d,%d,dense f16x2>",
-                     4: "k_sage_fused_mfma<%d,%d,f16x2>"}[ops.GEMM_MODE] % (
-                32 if dom[0] <= 32 else (64 if dom[0] <= 64 else 128), dom[1])
-        else:
-            kname = "k_agg_fwd + k_linear_fwd (unfused aggregate + GEMM pair, %d->%d)" % dom
-        # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE),
-        # valid only for the kernel sources they were measured on and for the shape that was profiled
-        traffic, pmc, tsrc = None, {}, None
+        stats = {k: kind_stats(k) for k in layer_events}
+        dom_key = max(stats, key=lambda k: stats[k]["total_ms"])
+        traffic_json = None
         try:
             cands = [c_ for c_ in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
                      if json.load(open(c_)).get("dtype", "f32") == args.dtype]
-            tj = json.load(open(cands[-1]))
-            tsrc = {"file": os.path.relpath(cands[-1], ROOT), "commit": tj.get("commit"), "csrc_sha": tj.get("csrc_sha")}
-            same_kernel = tj.get("csrc_sha") == csrc_sha()
-            same_shape = tuple(tj.get("shape", (128, 128))) == dom and tj.get("dtype", "f32") == args.dtype and fused
-            tsrc["matches_this_build"] = bool(same_kernel)
-            if same_shape and same_kernel:
-                traffic = round(tj["traffic_bytes_per_launch"] * (rows / (n_layers_dom * args.steps)) / tj.get("n_tets", 1010078))
-                pmc = {k: tj[k] for k in ("mfma_busy_frac", "valu_busy_frac", "tcc_hit_rate", "clock_ghz") if k in tj}
-            elif same_shape:
-                sys.stderr.write("bench: %s was measured on other kernel sources (csrc %s, now %s): roofline.traffic left null\n" % (
-                    tsrc["file"], tj.get("csrc_sha"), csrc_sha()))
+            traffic_json = (cands[-1], json.load(open(cands[-1])))
         except Exception:  # noqa: BLE001
             pass
-        roof = {"bound": "hbm", "kernel": "%s (%d launch%s per step)" % (kname, n_layers_dom, "" if n_layers_dom == 1 else "es"),
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(dom_ms, 4),
-                "timing": "HIP events around each layer's launches inside the timed steps (%d launches)" % len(evs),
-                "pmc": pmc or None,
-                "whole_path_frac": round(value * path_bytes(f_in, convs, elem) / 1e9 / HBM_PEAK_GBS / world, 4)}
-        if not fused and not bf16:
-            # a wide layer (aggregate + GEMM pair): 4*C_in*C_out FLOPs per tet against ~4*(C_in+C_out) bytes -- the matrix cores
-            # bound it, not HBM.  The yardstick is the rate the arithmetic that actually runs can reach: fp32-class products executed
-            # as 6 bf16 (exact 3-way split) or 3 fp16 (2 parts, power-of-two row scales) matrix products each -> dense 16-bit peak / 6
-            # or / 3 in fp32-equivalent TFLOP/s; the bit-faithful mode runs on the fp32 matrix pipe itself.
-            fl = layer_flops(dom[0], dom[1]) * rows / (n_layers_dom * args.steps)
-            tf = fl / (dom_ms * 1e-3) / 1e12
-            x3 = ops.GEMM_MODE != ops.GEMM_F32
-            x2h = ops.GEMM_MODE == ops.GEMM_F16X2 and dom[1] > 256   # ops.linear_fwd: the fp16 two-part GEMM takes the layers wider than 256
-            nprod = 3 if x2h else 6
-            peak = BF16_MATRIX_PEAK_TF / nprod if x3 else FP32_MATRIX_PEAK_TF
-            roof.update({"bound": "mfma", "achieved": round(tf, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-                         "algorithmic_flops_per_launch": int(fl), "hbm_frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "note": ("fp32-class arithmetic executed as %d %s MFMA products per fp32 product; peak = %.0f TFLOP/s dense 16-bit matrix peak / %d "
-                                  "(fp32-equivalent); for scale: %.2f of the %.1f TFLOP/s fp32 matrix pipe"
-                                  % (nprod, "fp16 (2 parts per operand, power-of-two row scales)" if x2h else "bf16 (3 parts per operand)",
-                                     BF16_MATRIX_PEAK_TF, nprod, tf / FP32_MATRIX_PEAK_TF, FP32_MATRIX_PEAK_TF)) if x3
-                         else "bit-faithful fp32 MFMA (v_mfma_f32_32x32x2_f32)"})
-            if x2h:
-                roof["kernel"] = roof["kernel"].replace("k_linear_fwd", "k_linear_fwd_x2h_big")
+
+        def describe(key):
+            st = stats[key]
+            c_in, c_out, plain = key
+            shape = (c_in, c_out)
+            achieved = st["algo"] / (st["ms"] * 1e-3) / 1e9
+            fused = ops.fused_layer_supported(c_in, c_out, 20)
+            if bf16:
+                kname = net.dominant_kernel_name(shape)
+            elif fused:
+                kname = {0: "k_sage_fused<%d,%d,0>", 1: "k_sage_fused<%d,%d,1>", 2: "k_sage_fused_mfma<%d,%d>", 3: "k_sage_fused_mfma<%d,%d,dense f16x2>",
+                         4: "k_sage_fused_mfma<%d,%d,f16x2>"}[ops.GEMM_MODE] % (32 if c_in <= 32 else (64 if c_in <= 64 else 128), c_out)
+                if not plain:
+                    kname = kname[:-1] + ",DEC> (last conv layer + decoder in one launch)"
+            else:
+                kname = "k_agg_fwd + k_linear_fwd (unfused aggregate + GEMM pair, %d->%d)" % shape
+            # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE), valid only for
+            # the kernel sources they were measured on and for the shape that was profiled
+            traffic, pmc, tsrc = None, {}, None
+            if traffic_json is not None:
+                path, tj = traffic_json
+                tsrc = {"file": os.path.relpath(path, ROOT), "commit": tj.get("commit"), "csrc_sha": tj.get("csrc_sha")}
+                same_kernel = tj.get("csrc_sha") == csrc_sha()
+                same_shape = tuple(tj.get("shape", (128, 128))) == shape and tj.get("dtype", "f32") == args.dtype and fused
+                tsrc["matches_this_build"] = bool(same_kernel)
+                src_ = tj if plain else (tj.get("with_decoder") or {})
+                if same_shape and same_kernel and src_.get("traffic_bytes_per_launch"):
+                    traffic = round(src_["traffic_bytes_per_launch"] * st["rows_per_launch"] / tj.get("n_tets", 1010078))
+                    pmc = {k: src_[k] for k in ("mfma_busy_frac", "valu_busy_frac", "wait_any_frac", "tcc_hit_rate", "clock_ghz") if k in src_}
+                elif same_shape and not same_kernel:
+                    sys.stderr.write("bench: %s was measured on other kernel sources (csrc %s, now %s): roofline.traffic left null\n" % (
+                        tsrc["file"], tj.get("csrc_sha"), csrc_sha()))
+            r = {"bound": "hbm", "kernel": "%s (%d launch%s per step)" % (kname, st["launches_per_step"], "" if st["launches_per_step"] == 1 else "es"),
+                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                 "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": st["algo"], "algorithmic_bytes_per_tet": st["per_tet"],
+                 "avg_launch_ms": round(st["ms"], 4), "share_of_step": round(st["total_ms"] / args.steps / ms_per_step, 4),
+                 "timing": "HIP events around each launch inside the timed steps (%d launches)" % st["n_events"], "pmc": pmc or None}
+            if not plain:
+                r["algorithmic_bytes_note"] = ("SURVEY 8d rows this launch executes: last conv layer %d B/tet + decoder %d B/tet (the contract figure; the launch itself moves "
+                                               "%d B/tet less: the layer's output never leaves the compute unit)" % (layer_bytes(c_in, c_out, elem), elem * c_out + 8, 2 * elem * c_out))
+            if not fused and not bf16:
+                # a wide layer (aggregate + GEMM pair): 4*C_in*C_out FLOPs per tet against ~4*(C_in+C_out) bytes -- the matrix cores
+                # bound it, not HBM.  The yardstick is the rate the arithmetic that actually runs can reach: fp32-class products executed
+                # as 6 bf16 (exact 3-way split) or 3 fp16 (2 parts, power-of-two row scales) matrix products each -> dense 16-bit peak / 6
+                # or / 3 in fp32-equivalent TFLOP/s; the bit-faithful mode runs on the fp32 matrix pipe itself.
+                fl = layer_flops(c_in, c_out) * st["rows_per_launch"]
+                tf = fl / (st["ms"] * 1e-3) / 1e12
+                x3 = ops.GEMM_MODE != ops.GEMM_F32
+                x2h = ops.GEMM_MODE == ops.GEMM_F16X2 and c_out > 256   # ops.linear_fwd: the fp16 two-part GEMM takes the layers wider than 256
+                nprod = 3 if x2h else 6
+                peak = BF16_MATRIX_PEAK_TF / nprod if x3 else FP32_MATRIX_PEAK_TF
+                r.update({"bound": "mfma", "achieved": round(tf, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                          "algorithmic_flops_per_launch": int(fl), "hbm_frac": round(achieved / HBM_PEAK_GBS, 4),
+                          "note": ("fp32-class arithmetic executed as %d %s MFMA products per fp32 product; peak = %.0f TFLOP/s dense 16-bit matrix peak / %d "
+                                   "(fp32-equivalent); for scale: %.2f of the %.1f TFLOP/s fp32 matrix pipe"
+                                   % (nprod, "fp16 (2 parts per operand, power-of-two row scales)" if x2h else "bf16 (3 parts per operand)",
+                                      BF16_MATRIX_PEAK_TF, nprod, tf / FP32_MATRIX_PEAK_TF, FP32_MATRIX_PEAK_TF)) if x3
+                          else "bit-faithful fp32 MFMA (v_mfma_f32_32x32x2_f32)"})
+                if x2h:
+                    r["kernel"] = r["kernel"].replace("k_linear_fwd", "k_linear_fwd_x2h_big")
+            return r
+        roof = describe(dom_key)
+        twin = (dom_key[0], dom_key[1], not dom_key[2])
+        if twin in stats:
+            roof["also"] = describe(twin)     # the same shape's other kind of launch (plain layer <-> layer + decoder)
+        roof["whole_path_frac"] = round(value * path_bytes(28, convs, elem) / 1e9 / HBM_PEAK_GBS / world, 4)
 
     # ---- side measurements, outside the timed region (nested objects; never `value`) ----
     extras = {}

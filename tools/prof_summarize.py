@@ -50,6 +50,7 @@ trace_ns = None
 if ks:
     d = pd.read_csv(ks[0])
     d["Name"] = d["Name"].map(short)
+    d_stats = d
     out += ["## kernel stats (kernel-trace --stats)\n", "```", d[["Name", "Calls", "AverageNs", "Percentage"]].head(16).to_string(index=False), "```\n"]
     rows = d[d["Name"].str.contains(DOM, regex=False)]
     if len(rows):
@@ -69,12 +70,32 @@ for i in (1, 2, 3, 4):
     out += ["## pmc%d (mean per dispatch)\n" % i, "```", t.round(0).to_string(), "```\n"]
 
 
-def get(i, col):
+def get(i, col, dom=None):
     t = means.get(i)
     if t is None:
         return None
-    rows = [r for r in t.index if DOM in r]
+    rows = [r for r in t.index if (dom or DOM) in r]
     return float(t.loc[rows[0], col]) if rows and col in t.columns else None
+
+
+def dec_stats():
+    """the same counters for the instantiation of the 128 -> 128 layer that also carries the decoder (template argument DEC = true), fp32 only"""
+    dom = "k_sage_fused_mfma<128, 128, 8, 2, 2, 2, t"
+    f, wr, du = get(3, "FETCH_SIZE", dom), get(4, "WRITE_SIZE", dom), get(3, "dur_us", dom)
+    if not (f and wr is not None and du):
+        return None
+    gui, busy, valu = get(3, "GRBM_GUI_ACTIVE", dom), get(1, "SQ_VALU_MFMA_BUSY_CYCLES", dom), get(1, "SQ_INSTS_VALU", dom)
+    hit, miss = get(4, "TCC_HIT_sum", dom), get(4, "TCC_MISS_sum", dom)
+    wc, wany = get(1, "SQ_WAVE_CYCLES", dom), get(1, "SQ_WAIT_ANY", dom)
+    clk = gui / 8 / du / 1e3
+    cyc = clk * 1e3 * du
+    tr = None
+    if ks:
+        rr = d_stats[d_stats["Name"].str.contains(dom, regex=False)]
+        tr = float(rr.iloc[0]["AverageNs"]) / 1e3 if len(rr) else None
+    return {"kernel": dom + "rue>", "traffic_bytes_per_launch": (2 * f + wr) * 1024, "fetch_kib": f, "write_kib": wr, "avg_launch_us_profiled": du,
+            "avg_launch_us_kernel_trace": tr, "mfma_busy_frac": round(busy / 1024 / cyc, 4), "valu_busy_frac": round(valu * 2 / 1024 / cyc, 4),
+            "tcc_hit_rate": round(hit / (hit + miss), 4), "clock_ghz": round(clk, 3), "wait_any_frac": round(wany / wc, 4)}
 
 
 fetch, write, dur = get(3, "FETCH_SIZE"), get(4, "WRITE_SIZE"), get(3, "dur_us")
@@ -101,6 +122,15 @@ if fetch and write:
             % (fetch, write),
             "  = %.3f GB against %.3f GB algorithmic (%d B/tet) -> %.2fx; at %.0f us that is %.2f TB/s through the L2 <-> fabric interface "
             "(Infinity-Cache hits are counted there, MI355X_MICROARCH.md)\n" % (traffic / 1e9, algo / 1e9, per_tet, traffic / algo, dur, traffic / dur / 1e6)]
+    ds = dec_stats() if a.dtype == "f32" else None
+    if ds:
+        cb = (bench.layer_bytes(128, 128) + 520) * N
+        out += ["## reading (%s: the last layer's launch with the decoder inside, %.0f us per launch under the profiler)\n" % (ds["kernel"], ds["avg_launch_us_profiled"]),
+                "* fabric traffic per launch (2 x FETCH_SIZE %.0f KiB + WRITE_SIZE %.0f KiB) x 1024 = %.3f GB: the layer's 0.52 GB of output and the decoder's 0.52 GB read are gone "
+                "(plain layer: %.3f GB); against the contract's algorithmic figure for what this launch executes (SURVEY 8d: layer row 1360 + decoder row 520 = 1880 B/tet = "
+                "%.3f GB) that is %.2fx" % (ds["fetch_kib"], ds["write_kib"], ds["traffic_bytes_per_launch"] / 1e9, traffic / 1e9, cb / 1e9, ds["traffic_bytes_per_launch"] / cb),
+                "* matrix pipe %.0f %% busy, VALU %.0f %%, %.0f %% of wave cycles parked, L2 hit rate %.0f %%, clock %.2f GHz\n" % (
+                    100 * ds["mfma_busy_frac"], 100 * ds["valu_busy_frac"], 100 * ds["wait_any_frac"], 100 * ds["tcc_hit_rate"], ds["clock_ghz"])]
     try:
         commit = open(os.path.join(G, a.tag + "_commit.txt")).read().strip()
     except OSError:
@@ -110,7 +140,8 @@ if fetch and write:
     json.dump({"kernel": DOM, "dtype": a.dtype, "shape": list(shape), "n_tets": N, "traffic_bytes_per_launch": traffic, "fetch_kib": fetch,
                "write_kib": write, "mfma_busy_frac": round(busy / 1024 / cyc, 4), "valu_busy_frac": round(valu * 2 / 1024 / cyc, 4),
                "tcc_hit_rate": round(hit / (hit + miss), 4), "clock_ghz": round(clk, 3), "avg_launch_us_profiled": dur,
-               "avg_launch_us_kernel_trace": trace_ns / 1e3 if trace_ns else None, "commit": commit, "csrc_sha": bench.csrc_sha(),
+               "avg_launch_us_kernel_trace": trace_ns / 1e3 if trace_ns else None, "wait_any_frac": round(wany / wc, 4),
+               "with_decoder": dec_stats() if a.dtype == "f32" else None, "commit": commit, "csrc_sha": bench.csrc_sha(),
                "source": "profiles/%s.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH doubled per the guide)" % a.name},
               open(os.path.join(ROOT, "profiles", a.name + "_traffic.json"), "w"))
 open(os.path.join(ROOT, "profiles", a.name + ".md"), "w").write("\n".join(out))
