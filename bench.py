@@ -89,7 +89,7 @@ def csrc_sha():
 
 def cpu_oracle(net_sd, convs, x, ea, ei, threads, runs):
     """Times the CPU oracle (plain-PyTorch restatement of the reference path; test infrastructure, used here only as the
-    timed CPU baseline and as the checker).  -> (median seconds, logits)."""
+    timed CPU baseline and as the checker).  -> (median seconds, logits).  runs = -1: ONE call, timed as it is (no warm-up)."""
     from dgnn_amd.config import Config, reconbench_pretrained
     from oracle.static_edge_filters import SurfaceNet as OracleNet
     net = OracleNet(reconbench_pretrained(device="cpu", convs=convs))
@@ -100,7 +100,10 @@ def cpu_oracle(net_sd, convs, x, ea, ei, threads, runs):
     torch.set_num_threads(threads)
     times = []
     with torch.no_grad():
+        t0 = time.perf_counter()
         out = net.inference_layer(data)                 # warm-up (also the checker's reference logits)
+        if runs < 0:
+            times.append(time.perf_counter() - t0)
         for _ in range(runs):
             t0 = time.perf_counter()
             net.inference_layer(data)
@@ -580,10 +583,10 @@ def main():
                "single_thread_sample": "same generator at %d points -> %d tets, 1 thread, 1 warm-up + 1 run" % (args.cpu_points, x_1.shape[0])}
         all_cores = os.cpu_count() or 1
         if all_cores > cores and not args.no_extras:
-            t_all, _ = cpu_oracle(net_sd, convs, x_c, ea_c, ei_c, all_cores, runs=1)
+            t_all, _ = cpu_oracle(net_sd, convs, x_c, ea_c, ei_c, all_cores, runs=-1)
             cpu["all_cores_value"] = round(n_full / t_all, 1)
             cpu["all_cores"] = all_cores
-            cpu["all_cores_sample"] = "same graph, torch.set_num_threads(%d) = every host core, 1 warm-up + 1 run (more threads than %d only add contention here)" % (all_cores, cores)
+            cpu["all_cores_sample"] = "same graph, torch.set_num_threads(%d) = every host core, one run (the 16-thread leg before it has warmed the allocator; more threads than %d only add contention here)" % (all_cores, cores)
         # the check: GPU logits of the same graph against the oracle's
         if big:
             got = net.inference_layer(Config(x=x_c.to(dev), edge_attr=ea_c.to(dev), edge_index=ei_c.to(dev))).float().cpu()
