@@ -73,7 +73,9 @@ int dgnn_poll_async_error(void);
  *   REFERENCE - by destination, E == 4*n_key, row 4t+r = r-th neighbour of cell t, symmetric relation (what
  *               processing/data.py hands the model): in-edges are the reversed out-edges, no atomics/scan/sort.
  * `hint` only selects which of them is attempted (AUTO: both).  Each checks its precondition on the device;
- * when it does not hold, the generic kernels queued behind it rebuild the plan.  Same result in every case.
+ * when it does not hold, the generic builder queued behind it -- ONE persistent launch that returns at once when a fast path
+ * produced the plan -- rebuilds it.  Same result in every case.  (REFERENCE with the (src, dst) pairs interleaved in memory,
+ * stride_row 1 / stride_col 2 and a 16-byte aligned base: four lanes per cell, 16-byte loads.)
  * ---------------------------------------------------------------------------------------------- */
 #define DGNN_PLAN_HINT_AUTO 0
 #define DGNN_PLAN_HINT_GROUPED 1
