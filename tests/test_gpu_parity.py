@@ -946,17 +946,6 @@ def test_f16x2_group_scales_cover_the_fp32_range(c_in, c_out):
         errs[mode] = ((out - ref).abs() / mag).max().item()
     print("rows over 60 binades, %d->%d: max err / sum|terms|  bf16x3 %.2e  f16x2 %.2e" % (c_in, c_out, errs[ops.GEMM_BF16X3_FILTER], errs[ops.GEMM_F16X2]))
     assert errs[ops.GEMM_F16X2] < 1e-6 and errs[ops.GEMM_F16X2] < 4 * errs[ops.GEMM_BF16X3_FILTER] + 1e-7, errs
-    if n_out > 256:
-        # operands split once by their own pass + DMA staging (x2hp, the default) == split inside the GEMM's K loop (x2h): bit for bit
-        outs = []
-        old_hp = ops.X2HP
-        try:
-            for hp in (True, False):
-                ops.X2HP = hp
-                outs.append(ops.linear_fwd(dev(A1), dev(W1), dev(A2), dev(W2), dev(b), dev(sc), dev(sh), True))
-        finally:
-            ops.X2HP = old_hp
-        assert torch.equal(outs[0], outs[1])
 
 
 def test_f16x2_zero_rows_tiny_rows_and_nan_stay_local():
@@ -1008,3 +997,14 @@ def test_linear_fwd_x2h_vs_fp64(k1, k2, n_out):
         ops.GEMM_MODE = old
     print("x2h GEMM K=%d+%d N=%d: max err / sum|terms|  x3 %.2e  x2h %.2e" % (k1, k2, n_out, errs[ops.GEMM_BF16X3_FILTER], errs[ops.GEMM_F16X2]))
     assert errs[ops.GEMM_F16X2] < 1e-6 and errs[ops.GEMM_F16X2] < 4 * errs[ops.GEMM_BF16X3_FILTER] + 1e-7, errs
+    if n_out > 256:
+        # operands split once by their own pass + DMA staging (x2hp, opt-in DGNN_X2HP=1) == split inside the GEMM's K loop (x2h): bit for bit
+        outs = []
+        old_hp = ops.X2HP
+        try:
+            for hp in (True, False):
+                ops.X2HP = hp
+                outs.append(ops.linear_fwd(dev(A1), dev(W1), dev(A2), dev(W2), dev(b), dev(sc), dev(sh), True))
+        finally:
+            ops.X2HP = old_hp
+        assert torch.equal(outs[0], outs[1]) and (outs[0].cpu().double() - ref).abs().max().item() > 0      # (and it is the fp16 two-part arithmetic, not fp64)
