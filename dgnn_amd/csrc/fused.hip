@@ -493,7 +493,8 @@ int dgnn_sage_layer_fused_mfma_try(const int32_t* rowptr, const int32_t* src, co
                                    const float* x_dst, int64_t ldx,
                                    int c_in, const float* edge_attr, int64_t lde, const float* We, const float* be,
                                    const float* Wj, const float* bj, const float* Wi, const float* scale, const float* shift,
-                                   int relu, int c_out, float* out, int64_t ldo, int f16_parts, hipStream_t stream);  // fused_mfma.hip
+                                   int relu, int c_out, float* out, int64_t ldo, int f16_parts, hipStream_t stream, void* prep = nullptr,
+                                   int prep_mode = 0);  // fused_mfma.hip (prep: prepared parameters, see dgnn_sage_layer_prepare)
 
 extern "C" int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src,
                                          const float* x_dst, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e,

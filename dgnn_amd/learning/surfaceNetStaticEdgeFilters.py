@@ -300,6 +300,31 @@ class SurfaceNet(nn.Module):
         cache[id(bn)] = (key, out)
         return out
 
+    def _prepared(self, i, with_decoder):
+        """Prepared parameters of conv layer i for the fused launches (ops.sage_layer_prepare), cached until one of the tensors they were made from is
+        written to (same version-counter key as `_fold`); None when there is no prepared form (other arithmetic, other shapes, DGNN_PREPARED=0)."""
+        if not ops.PREPARED_PARAMS or ops.GEMM_MODE != ops.GEMM_F16X2:
+            return None
+        conv = self.convs[i][0]
+        le = conv.lin_e
+        if not isinstance(le, Linear) or le.in_features != 20:
+            return None
+        ts = [le.weight, le.bias, conv.lin_j.weight, conv.lin_i.weight]
+        dec_args = None
+        if with_decoder:
+            dec = self.decoder
+            s1, h1 = self._fold(dec[1] if isinstance(dec[1], BatchNorm) else None, dec[0].out_features, le.weight.device)
+            dec_args = (dec[0].weight, dec[0].bias, s1, h1, dec[3].weight, dec[3].bias)
+            ts += [t for t in dec_args if t is not None]
+        key = (bool(with_decoder),) + tuple((t.data_ptr(), t._version) for t in ts)
+        cache = self.__dict__.setdefault("_prep_cache", {})
+        hit = cache.get((i, bool(with_decoder)))
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        buf = ops.sage_layer_prepare(le.weight, le.bias, conv.lin_j.weight, conv.lin_i.weight, dec_args)
+        cache[(i, bool(with_decoder))] = (key, buf)
+        return buf
+
     def fuses_decoder(self, i):
         """True when layer i's launch also carries the decoder (the last conv layer of the shipped widths, fp32 storage: the finished tile goes
         through Linear-BN-ReLU-Linear in the same kernel and only the logits are written, reference :180-187 applied at :350-351)"""
@@ -397,14 +422,14 @@ class SurfaceNet(nn.Module):
                     ops.sage_layer_fused_decoder_fwd(rowptr[s0:s1_ + 1] if (s0 or s1_ < n) else rowptr, plan.src, s1_ - s0, x, ea, le.weight, le.bias,
                                                      conv.lin_j.weight, conv.lin_j.bias, conv.lin_i.weight, scale, shift, True, dec[0].weight, dec[0].bias,
                                                      s1, h1, dec[3].weight, dec[3].bias, out=out_v[s0:s1_], eid=eid,
-                                                     x_dst=x_dst[s0:s1_] if (b or s0) else None)
+                                                     x_dst=x_dst[s0:s1_] if (b or s0) else None, prepared=self._prepared(i, True))
                 return out_v
             if decode:
                 raise ops.DgnnError("decode=True on a layer whose launch cannot carry the decoder (check fuses_decoder first)")
             if n <= chunk:
                 x = ops.sage_layer_fused_fwd(rowptr, plan.src, n, x, ea, le.weight, le.bias, conv.lin_j.weight,
                                              conv.lin_j.bias, conv.lin_i.weight, scale, shift, True, out=out_v, eid=eid,
-                                             x_dst=x_dst if b else None)
+                                             x_dst=x_dst if b else None, prepared=self._prepared(i, False))
             else:
                 if out_v is None:
                     out_v = torch.empty((n, conv.lin_j.out_features), dtype=torch.float32, device=x.device)
@@ -412,7 +437,7 @@ class SurfaceNet(nn.Module):
                     s1 = min(n, s0 + chunk)
                     ops.sage_layer_fused_fwd(rowptr[s0:s1 + 1], plan.src, s1 - s0, x, ea, le.weight, le.bias, conv.lin_j.weight,
                                              conv.lin_j.bias, conv.lin_i.weight, scale, shift, True, out=out_v[s0:s1], eid=eid,
-                                             x_dst=x_dst[s0:s1])
+                                             x_dst=x_dst[s0:s1], prepared=self._prepared(i, False))
                 x = out_v
             return x
         if simple:

@@ -373,7 +373,7 @@ LAYER_HOOK = None
 
 @on_device_of
 def sage_layer_fused_fwd(rowptr, src, n_dst, x_src, edge_attr, We, be, Wj, bj, Wi, scale, shift, relu, gemm_mode=None,
-                         out=None, eid=None, x_dst=None):
+                         out=None, eid=None, x_dst=None, prepared=None):
     """`x_dst` (optional): own rows of the destinations when they are not x_src[:n_dst] (a destination sub-range).
     `eid` (the plan's edge ids): edge_attr is the caller's tensor in its own row order and rows are gathered inside the
     kernel; eid=None: edge_attr is already in plan order.
@@ -387,11 +387,43 @@ def sage_layer_fused_fwd(rowptr, src, n_dst, x_src, edge_attr, We, be, Wj, bj, W
         _req(out, "out", dim=2)
         if out.size(0) < n_dst or out.size(1) != c_out or out.stride(0) != c_out:
             raise ValueError("out must be a contiguous [>= n_dst, c_out] buffer")
+    mode = GEMM_MODE if gemm_mode is None else gemm_mode
+    if prepared is not None and mode == GEMM_F16X2:
+        # `prepared` (sage_layer_prepare): the launch skips its parameter prologue; a shape the prepared kernels do not take falls through
+        rc = lib().dgnn_sage_layer_fused_fwd_p(
+            ptr(rowptr), ptr(src), ptr(eid), n_dst, ptr(x_src), ptr(x_dst), _ld(x_src), c_in, ptr(edge_attr), _ld(edge_attr), We.size(1),
+            ptr(We), ptr(be), ptr(Wj), ptr(bj), ptr(Wi), ptr(scale), ptr(shift), int(bool(relu)), c_out, ptr(out), c_out, ptr(prepared), stream_ptr())
+        if rc != DGNN_E_UNSUPPORTED:
+            check(rc, "dgnn_sage_layer_fused_fwd_p")
+            return out
     check(lib().dgnn_sage_layer_fused_fwd(
         ptr(rowptr), ptr(src), ptr(eid), n_dst, ptr(x_src), ptr(x_dst), _ld(x_src), c_in, ptr(edge_attr), _ld(edge_attr), We.size(1),
         ptr(We), ptr(be), ptr(Wj), ptr(bj), ptr(Wi), ptr(scale), ptr(shift), int(bool(relu)), c_out, ptr(out), c_out,
-        GEMM_MODE if gemm_mode is None else gemm_mode, stream_ptr()), "dgnn_sage_layer_fused_fwd")
+        mode, stream_ptr()), "dgnn_sage_layer_fused_fwd")
     return out
+
+
+# parameters of the fused layers prepared once per set of weights (dgnn_sage_layer_prepare); DGNN_PREPARED=0: every launch derives them itself
+PREPARED_PARAMS = __import__("os").environ.get("DGNN_PREPARED", "1") != "0"
+
+
+@on_device_of
+def sage_layer_prepare(We, be, Wj, Wi, decoder=None):
+    """-> uint8 buffer for `prepared=` of sage_layer_fused_fwd / sage_layer_fused_decoder_fwd, or None when the shape has no prepared form.
+    `decoder` = (W0, b0, scale1, shift1, W3, b3) for the last layer's launch that carries the decoder."""
+    c_in, c_out = Wj.size(1), Wj.size(0)
+    nbytes = int(lib().dgnn_sage_layer_prepared_bytes(c_in, c_out, int(decoder is not None)))
+    if nbytes <= 0 or We.size(1) != 20:
+        return None
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=Wj.device)
+    d = decoder if decoder is not None else (None,) * 6
+    rc = lib().dgnn_sage_layer_prepare(c_in, c_out, ptr(We.contiguous()), ptr(be), ptr(Wj.contiguous()), ptr(Wi.contiguous()),
+                                       ptr(d[0].contiguous() if d[0] is not None else None), ptr(d[1]), ptr(d[2]), ptr(d[3]),
+                                       ptr(d[4].contiguous() if d[4] is not None else None), ptr(d[5]), ptr(buf), stream_ptr())
+    if rc == DGNN_E_UNSUPPORTED:
+        return None
+    check(rc, "dgnn_sage_layer_prepare")
+    return buf
 
 
 # the last conv layer and the decoder in one launch (dgnn_sage_layer_fused_decoder_fwd); DGNN_FUSE_DECODER=0 keeps them apart
@@ -409,7 +441,7 @@ def fused_layer_decoder_supported(c_in: int, c_out: int, f_e: int, hidden: int, 
 
 @on_device_of
 def sage_layer_fused_decoder_fwd(rowptr, src, n_dst, x_src, edge_attr, We, be, Wj, bj, Wi, scale, shift, relu, W0, b0, scale1, shift1, W3, b3,
-                                 out=None, eid=None, x_dst=None):
+                                 out=None, eid=None, x_dst=None, prepared=None):
     """Last conv layer + decoder, one launch -> logits [n_dst, 2] (written into `out` when given: a contiguous [>= n_dst, 2] fp32 buffer)."""
     _req(x_src, "x_src", dim=2)
     if out is None:
@@ -418,10 +450,13 @@ def sage_layer_fused_decoder_fwd(rowptr, src, n_dst, x_src, edge_attr, We, be, W
         _req(out, "out", dim=2)
         if out.size(0) < n_dst or out.size(1) != 2 or out.stride(0) != 2:
             raise ValueError("out must be a contiguous [>= n_dst, 2] buffer")
-    check(lib().dgnn_sage_layer_fused_decoder_fwd(
-        ptr(rowptr), ptr(src), ptr(eid), n_dst, ptr(x_src), ptr(x_dst), _ld(x_src), x_src.size(1), ptr(edge_attr), _ld(edge_attr), We.size(1),
-        ptr(We), ptr(be), ptr(Wj), ptr(bj), ptr(Wi), ptr(scale), ptr(shift), int(bool(relu)), Wj.size(0), ptr(W0.contiguous()), ptr(b0),
-        ptr(scale1), ptr(shift1), W0.size(0), ptr(W3.contiguous()), ptr(b3), W3.size(0), ptr(out), stream_ptr()), "dgnn_sage_layer_fused_decoder_fwd")
+    head = (ptr(rowptr), ptr(src), ptr(eid), n_dst, ptr(x_src), ptr(x_dst), _ld(x_src), x_src.size(1), ptr(edge_attr), _ld(edge_attr), We.size(1),
+            ptr(We), ptr(be), ptr(Wj), ptr(bj), ptr(Wi), ptr(scale), ptr(shift), int(bool(relu)), Wj.size(0), ptr(W0.contiguous()), ptr(b0),
+            ptr(scale1), ptr(shift1), W0.size(0), ptr(W3.contiguous()), ptr(b3), W3.size(0), ptr(out))
+    if prepared is not None:
+        check(lib().dgnn_sage_layer_fused_decoder_fwd_p(*head, ptr(prepared), stream_ptr()), "dgnn_sage_layer_fused_decoder_fwd_p")
+    else:
+        check(lib().dgnn_sage_layer_fused_decoder_fwd(*head, stream_ptr()), "dgnn_sage_layer_fused_decoder_fwd")
     return out
 
 

@@ -255,6 +255,29 @@ int dgnn_sage_layer_fused_decoder_fwd(const int32_t* rowptr, const int32_t* src,
                                       const float* scale1, const float* shift1, int c_hidden, const float* W3, const float* b3, int n_logits,
                                       float* logits, void* stream);
 
+/* Prepared parameters of the fused layers (fp16 two-part arithmetic, DGNN_GEMM_F16X2).  What a fused launch derives from the layer's parameters
+ * before its first tile -- two power-of-two scales, the split filter operand [We | be], every wavefront's resident fragments of [Wj | Wi], the
+ * decoder's W0 fragments and folded constants -- costs each of the 256 workgroups a column-wise read of the weights and their split: 15-20 us per
+ * launch.  dgnn_sage_layer_prepare runs that prologue once and parks the result in `prepared` (dgnn_sage_layer_prepared_bytes(c_in, c_out,
+ * with_decoder) bytes, 16-byte aligned; 0 = shape not covered); dgnn_sage_layer_fused_fwd_p / dgnn_sage_layer_fused_decoder_fwd_p are the two
+ * entry points above reading it back (coalesced 16-byte loads).  The values are the same: results are bit-identical to the unprepared calls.
+ * The buffer belongs to the parameter VALUES it was made from (W0 .. b3: the decoder's, NULL for a plain layer); prepare again when they change.
+ * BatchNorm(eval) scale / shift and bj are still passed per call.  Shapes outside the all-matrix-core kernel: DGNN_E_UNSUPPORTED. */
+int64_t dgnn_sage_layer_prepared_bytes(int c_in, int c_out, int with_decoder);
+int dgnn_sage_layer_prepare(int c_in, int c_out, const float* We, const float* be, const float* Wj, const float* Wi, const float* W0,
+                            const float* b0, const float* scale1, const float* shift1, const float* W3, const float* b3, void* prepared,
+                            void* stream);
+int dgnn_sage_layer_fused_fwd_p(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src,
+                                const float* x_dst, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e, const float* We,
+                                const float* be, const float* Wj, const float* bj, const float* Wi, const float* scale, const float* shift,
+                                int relu, int c_out, float* out, int64_t ldo, const void* prepared, void* stream);
+int dgnn_sage_layer_fused_decoder_fwd_p(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src,
+                                        const float* x_dst, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e,
+                                        const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
+                                        const float* scale, const float* shift, int relu, int c_out, const float* W0, const float* b0,
+                                        const float* scale1, const float* shift1, int c_hidden, const float* W3, const float* b3, int n_logits,
+                                        float* logits, const void* prepared, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Training-mode conv layer, one call each way (SurfaceNet.forward :214-219 and its autograd, learning/runModel.py:279):
  *   forward : a = aggregate(x)  ->  z = a.Wj^T + x[:n_dst].Wi^T + bj  ->  BatchNorm1d with batch statistics (running buffers

@@ -372,6 +372,57 @@ def test_last_layer_and_decoder_in_one_launch(points, heavy):
     assert torch.equal(out, one)
 
 
+def test_prepared_parameters_give_the_same_bits_and_follow_the_weights():
+    """dgnn_sage_layer_prepare + the *_p entry points (the launch reads the scales / split filter operand / resident weight fragments / decoder
+    fragments instead of deriving them): bit-identical to the launches that derive them, for every fused shape of the shipped model and for the
+    launch that carries the decoder; the cache follows in-place updates of the weights (version counters) and load_state_dict."""
+    from dgnn_amd import ops
+    from dgnn_amd.synthetic import delaunay_tet_graph
+    if ops.GEMM_MODE != ops.GEMM_F16X2:
+        pytest.skip("prepared parameters exist for the default arithmetic")
+    adj, _, _ = delaunay_tet_graph(1500, seed=2)
+    n = adj.shape[0] // 4
+    g = torch.Generator().manual_seed(4)
+    data = Config(x=torch.randn(n, 29, generator=g).to(DEV), edge_attr=torch.randn(4 * n, 20, generator=g).to(DEV),
+                  edge_index=torch.from_numpy(adj.T.astype(np.int64)).to(DEV))
+    net = hip_static()
+    old = ops.PREPARED_PARAMS
+    try:
+        ops.PREPARED_PARAMS = False
+        plain = net.inference_layer(data)
+        ops.PREPARED_PARAMS = True
+        prep = net.inference_layer(data)
+        assert torch.equal(plain, prep)
+        cache = net.__dict__["_prep_cache"]
+        assert sorted(cache) == [(0, False), (1, False), (2, False), (3, True)] and all(v[1] is not None for v in cache.values())
+        bufs = {k: v[1].data_ptr() for k, v in cache.items()}
+        assert torch.equal(net.inference_layer(data), prep) and {k: v[1].data_ptr() for k, v in cache.items()} == bufs      # cache hit: nothing re-made
+        # an in-place update of one layer's weights re-prepares that layer only, and the result follows the new weights
+        with torch.no_grad():
+            net.convs[1][0].lin_j.weight.mul_(1.5)
+        upd = net.inference_layer(data)
+        ops.PREPARED_PARAMS = False
+        assert torch.equal(upd, net.inference_layer(data)) and not torch.equal(upd, prep)
+        ops.PREPARED_PARAMS = True
+        # each layer on its own, sub-ranges included (the partitioned forward's launches)
+        from dgnn_amd.graph import GraphPlan
+        plan = GraphPlan(data.edge_index, n, n)
+        h = data.x[:, 1:]
+        for i in range(4):
+            outs = []
+            for flag in (False, True):
+                ops.PREPARED_PARAMS = flag
+                o = torch.full((n, 2 if i == 3 else net.convs[i][0].lin_j.out_features), float("nan"), device=DEV)
+                for b, e in ((0, n // 2), (n // 2, n)):
+                    net._eval_layers(h, n, data.edge_attr, [plan] * 4, True, only=i, out=o, rows=(b, e), decode=i == 3)
+                outs.append(o)
+            assert torch.equal(outs[0], outs[1]), i
+            if i < 3:
+                h = outs[0]
+    finally:
+        ops.PREPARED_PARAMS = old
+
+
 def test_other_widths_random_init():
     """[64,128,256,512] (configs/aerial.yaml:57) exercises the non-fused path and wide channel tiling."""
     from oracle.static_edge_filters import SurfaceNet as ONet
