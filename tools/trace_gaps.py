@@ -40,3 +40,17 @@ for n, g in gapby.most_common(25):
 print("kernel time (us/step):")
 for n, g in tot.most_common(30):
     print("   %-28s %8.1f" % (n, g / nst / 1e3))
+if "--seq" in sys.argv:   # the main queue's launches of one step in order: start offset, duration, gap before, grid, name
+    k = first + nst // 2
+    a, b = adam[k], adam[k + 1]
+    t0 = rows[a]["e"]
+    prev = t0
+    print("sequence of step %d on the main queue (us from the previous Adam's end):" % k)
+    i = 0
+    for r in rows[a + 1:b + 1]:
+        if r["Queue_Id"] != mainq:
+            continue
+        i += 1
+        print("  %3d  t=%7.1f  dur=%6.1f  gap=%5.1f  grid=%-8s %s" % (i, (r["s"] - t0) / 1e3, (r["e"] - r["s"]) / 1e3, (r["s"] - prev) / 1e3,
+                                                                    r.get("Grid_Size", "?"), r["Kernel_Name"][:90]))
+        prev = r["e"]
