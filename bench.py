@@ -78,10 +78,11 @@ def make_scene(points, seed):
 
 
 def csrc_sha():
-    """Hash of the kernel sources: the PMC-derived fields of `roofline` are only valid for the kernels they were
+    """Hash of the fused layer kernels' sources: the PMC-derived fields of `roofline` are only valid for the kernels they were
     measured on (profiles/*_traffic.json carries the hash of the sources it profiled)."""
     h = hashlib.sha256()
-    for p in sorted(glob.glob(os.path.join(ROOT, "dgnn_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "dgnn_amd", "csrc", "*.h"))):
+    # the sources the profiled launches are compiled from: the fused layer kernels (fp32 / bf16 storage) and the headers they include
+    for p in sorted(glob.glob(os.path.join(ROOT, "dgnn_amd", "csrc", "fused*.hip")) + glob.glob(os.path.join(ROOT, "dgnn_amd", "csrc", "*.h"))):
         h.update(os.path.basename(p).encode())
         h.update(open(p, "rb").read())
     return h.hexdigest()[:16]
