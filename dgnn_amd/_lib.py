@@ -33,6 +33,9 @@ SIGNATURES = {
     "dgnn_linear_fwd_x2hp": (i32, [vp, i64, i32, vp, i64, vp, i64, i32, vp, i64, vp, vp, vp, i32, i64, i32, vp, i64, vp, vp]),
     "dgnn_linear_fwd_x2hp_scratch_elems": (i64, [i64, i32, i32, i32]),
     "dgnn_linear_wgrad_x3": (i32, [vp, i64, i32, vp, i64, i32, i64, vp, i64, i32, vp, vp]),
+    "dgnn_linear_wgrad_cat_scratch_elems": (i64, [i64, i32, i32, i32]),
+    "dgnn_linear_wgrad_x3_cat": (i32, [vp, i64, i32, vp, i64, i32, vp, i64, i32, i64, vp, vp, vp, vp, vp]),
+    "dgnn_sage_aggregate_bwd_add": (i32, [vp, vp, vp, i64, vp, vp, i64, i32, vp, i64, i32, vp, vp, vp, i64, vp, i64, vp, i64, i64, vp, vp, vp, vp]),
     "dgnn_linear_wgrad_scratch_elems": (i64, [i64, i32, i32]),
     "dgnn_linear_wgrad": (i32, [vp, i64, i32, vp, i64, i32, i64, vp, i64, i32, vp, vp]),
     "dgnn_bn_fold": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp]),

@@ -329,14 +329,19 @@ __device__ __forceinline__ float rlf(float v, int l) { return __builtin_bit_cast
 
 constexpr int CH_ROWS = 16;   // rows per chunk at most (row pointers in lanes 0 .. 16)
 
-template <int CPL, int FE, typename T, int SLOTS>
+// ADD: dx[row] = (the row's sum) + add[row] for row < n_add -- the `dx[:n_dst] += dz . Wi` of a conv layer's backward without a
+// launch of its own (same rounding as the GEMM epilogue that used to accumulate into dx: fl(sum + addend)).  The chunk's addend rows are
+// parked in the wavefront's part of `red` when the chunk starts (16 independent loads) so that no row waits for its own.
+template <int CPL, int FE, typename T, int SLOTS, bool ADD = false>
 __global__ void __launch_bounds__(256) k_agg_bwd_c(const int32_t* __restrict__ t_rowptr, const int32_t* __restrict__ t_dst,
                                                    const int32_t* __restrict__ t_eid, int64_t n_src, const int32_t* __restrict__ rowptr_dst,
                                                    const T* __restrict__ x, int64_t ldx, int c_in, const float* __restrict__ ea, int64_t lde,
                                                    const float* __restrict__ We, const float* __restrict__ be, const T* __restrict__ phi,
                                                    int64_t ldphi, const T* __restrict__ da, int64_t ldda, T* __restrict__ dx, int64_t lddx,
-                                                   T* __restrict__ dphi_out, int64_t lddphi, float* __restrict__ slabs, int rows_per_chunk) {
+                                                   T* __restrict__ dphi_out, int64_t lddphi, float* __restrict__ slabs, int rows_per_chunk,
+                                                   const T* __restrict__ add, int64_t ldadd, int64_t n_add) {
     constexpr int NW = FE > 0 ? FE : 1;
+    static_assert(!ADD || FE >= CH_ROWS - 1, "the addend rows of a chunk are parked in the wavefront's slab region");
     __shared__ float red[FE > 0 ? 4 * 64 * CPL * (FE + 1) : 1];
     const int lane = lane_id();
     const int c0 = (blockIdx.y * 64 + lane) * CPL;
@@ -370,12 +375,26 @@ __global__ void __launch_bounds__(256) k_agg_bwd_c(const int32_t* __restrict__ t
         float acc[CPL];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) acc[j] = 0.f;
+        float* const park = red + (wv * 64 + lane) * CPL * (FE + 1);   // ADD: [row of the chunk][CPL] of this lane
+        if (ADD && on) {
+            Vec<CPL, T> av[CH_ROWS];
+#pragma unroll
+            for (int r = 0; r < CH_ROWS; ++r) {
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) av[r].v[j] = 0.f;
+                if (r < nr && rb + r < n_add) av[r].load(add + (rb + r) * ldadd + c0);
+            }
+#pragma unroll
+            for (int r = 0; r < CH_ROWS; ++r)
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) park[r * CPL + j] = av[r].v[j];
+        }
         auto finish_until = [&](int r) {   // rows without out-edges get dx = 0 like the others get their sum
             while (cur < r) {
                 if (on && dx) {
                     Vec<CPL, T> o;
 #pragma unroll
-                    for (int j = 0; j < CPL; ++j) o.v[j] = acc[j];
+                    for (int j = 0; j < CPL; ++j) o.v[j] = (ADD && rb + cur < n_add) ? __fadd_rn(acc[j], park[cur * CPL + j]) : acc[j];
                     o.store(dx + (rb + cur) * lddx + c0);
                 }
 #pragma unroll
@@ -516,7 +535,8 @@ template <typename T>
 int agg_bwd_t(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, int64_t n_src, const int32_t* rowptr_dst,
               const T* x_src, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e, const float* We, const float* be,
               const T* phi, int64_t ldphi, const T* da, int64_t ldda, T* dx_src, int64_t lddx, float* dWe, float* dbe, T* dphi_out,
-              int64_t lddphi, float* partials, hipStream_t stream) {
+              int64_t lddphi, float* partials, hipStream_t stream, const T* add = nullptr, int64_t ldadd = 0, int64_t n_add = 0,
+              bool reduce_slabs = true) {
     DGNN_REQUIRE(n_src >= 0 && c_in > 0, DGNN_E_INVALID, "aggregate_bwd: bad sizes");
     if (n_src == 0) {   // nothing to sum: the parameter gradients are zero (they are written, not accumulated, otherwise)
         if (We && dWe && dbe) {
@@ -536,14 +556,21 @@ int agg_bwd_t(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
     const int cpl = v2 ? 2 : 1;
     const int chunks = (int)dgnn_cdiv(c_in, 64 * cpl);
     const bool chunked = agg_chunked();
+    DGNN_REQUIRE(!add || (chunked && We != nullptr && f_e == 20 && dx_src), DGNN_E_UNSUPPORTED,
+                 "aggregate_bwd: the addend form needs the chunked kernel, the fused 20-attribute filter and dx");
     const int rw = chunk_rows(n_src);
     const int64_t want = chunked ? dgnn_cdiv(dgnn_cdiv(n_src, rw), 4) : dgnn_cdiv(n_src, 4);
     const int nblocks = (int)(want < BWD_BLOCKS ? want : BWD_BLOCKS);
     dim3 grid(nblocks, chunks), block(256);
 #define LAUNCH(CPL, FE)                                                                                               \
-    do { if (chunked)                                                                                                \
+    do { if (chunked && add && FE == 20)                                                                              \
+        hipLaunchKernelGGL((k_agg_bwd_c<CPL, FE == 20 ? 20 : 20, T, (CPL == 2 && sizeof(T) == 4) ? 4 : 8, true>), grid, block, 0, stream, t_rowptr, t_dst, \
+                           t_eid, n_src, rowptr_dst, x_src, ldx, c_in, edge_attr, lde, We, be, phi, ldphi, da, ldda, dx_src, lddx, dphi_out, lddphi, \
+                           partials, rw, add, ldadd, n_add);                                                          \
+    else if (chunked)                                                                                                 \
         hipLaunchKernelGGL((k_agg_bwd_c<CPL, FE, T, (CPL == 2 && sizeof(T) == 4) ? 4 : 8>), grid, block, 0, stream, t_rowptr, t_dst, t_eid, n_src, \
-                           rowptr_dst, x_src, ldx, c_in, edge_attr, lde, We, be, phi, ldphi, da, ldda, dx_src, lddx, dphi_out, lddphi, partials, rw); \
+                           rowptr_dst, x_src, ldx, c_in, edge_attr, lde, We, be, phi, ldphi, da, ldda, dx_src, lddx, dphi_out, lddphi, partials, rw, \
+                           (const T*)nullptr, (int64_t)0, (int64_t)0);                                                \
     else                                                                                                              \
         hipLaunchKernelGGL((k_agg_bwd<CPL, FE, T>), grid, block, 0, stream, t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, ldx, \
                            c_in, edge_attr, lde, We, be, phi, ldphi, da, ldda, dx_src, lddx, dphi_out, lddphi, partials); } while (0)
@@ -552,7 +579,7 @@ int agg_bwd_t(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
     else if (given) { if (v2) LAUNCH(2, 0); else LAUNCH(1, 0); }
     else { if (v2) LAUNCH(2, -1); else LAUNCH(1, -1); }
 #undef LAUNCH
-    if (fused) {
+    if (fused && reduce_slabs) {
         const int per = 64 * cpl * (f_e + 1);
         hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)dgnn_cdiv((int64_t)chunks * per, 16)), dim3(16 * RS_SLICES), 0, stream, partials,
                            nblocks, chunks, per, c_in, f_e, cpl, dWe, dbe);
@@ -604,4 +631,15 @@ extern "C" int dgnn_sage_aggregate_bwd_bf16(const int32_t* t_rowptr, const int32
                                             float* partials, void* stream) {
     return agg_bwd_t<uint16_t>(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, ldx, c_in, edge_attr, lde, f_e, We, be, phi, ldphi, da, ldda,
                                dx_src, lddx, dWe, dbe, dphi_out, lddphi, partials, (hipStream_t)stream);
+}
+
+// dgnn_sage_aggregate_bwd (fused 20-attribute filter, fp32) with dx_src[row] += add[row] for row < n_add folded into the store of dx
+extern "C" int dgnn_sage_aggregate_bwd_add(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, int64_t n_src,
+                                           const int32_t* rowptr_dst, const float* x_src, int64_t ldx, int c_in, const float* edge_attr,
+                                           int64_t lde, int f_e, const float* We, const float* be, const float* da, int64_t ldda, float* dx_src,
+                                           int64_t lddx, const float* add, int64_t ldadd, int64_t n_add, float* dWe, float* dbe, float* partials,
+                                           void* stream) {
+    DGNN_REQUIRE(add && n_add >= 0 && n_add <= n_src, DGNN_E_INVALID, "aggregate_bwd_add: bad addend");
+    return agg_bwd_t<float>(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, ldx, c_in, edge_attr, lde, f_e, We, be, nullptr, 0, da, ldda, dx_src, lddx,
+                            dWe, dbe, nullptr, 0, partials, (hipStream_t)stream, add, ldadd, n_add);
 }

@@ -1307,6 +1307,128 @@ __global__ void __launch_bounds__(256) k_linear_wgrad_x3(const float* __restrict
     }
 }
 
+// Both weight gradients of a conv layer and the bias gradient in one launch: dW1 = A^T B1, dW2 = A^T B2 (B2 optional), dbias = column
+// sums of A.  Block column y takes its 64 columns from B1 (y < nby1) or B2; every output element runs k_linear_wgrad_x3's loop on the
+// same row splits (bit-identical dW1 / dW2).  The bias sums ride on the staging of A in the blocks of column 0: every thread adds the
+// values it stages (fp64), the 16 row-pair threads of a column are summed in a fixed order through LDS, one partial per row split.
+struct WgradCat {
+    const float* B[2];
+    int64_t ldb[2];
+    int nb[2];
+};
+
+__global__ void __launch_bounds__(256) k_linear_wgrad_x3_cat(const float* __restrict__ A, int64_t lda, int na, WgradCat c, int nby1, int64_t M,
+                                                             int64_t rows_per_split, float* __restrict__ partials, double* __restrict__ bias_partials) {
+    __shared__ __attribute__((aligned(16))) char At[WT * XLDT];
+    __shared__ __attribute__((aligned(16))) char Bt[WT * XLDT];
+    const int lane = lane_id(), w = wave_id_uniform();
+    const int wa = w >> 1, wb = w & 1, h = lane >> 5, l31 = lane & 31;
+    const int which = (int)blockIdx.y >= nby1 ? 1 : 0;
+    const float* __restrict__ B = c.B[which];
+    const int64_t ldb = c.ldb[which];
+    const int nb = c.nb[which], nbt = c.nb[0] + c.nb[1], colbase = which ? c.nb[0] : 0;
+    const int a0 = blockIdx.x * WT, b0 = ((int)blockIdx.y - (which ? nby1 : 0)) * WT;
+    const int64_t r_beg = (int64_t)blockIdx.z * rows_per_split;
+    const int64_t r_end = min(M, r_beg + rows_per_split);
+    const bool do_bias = bias_partials != nullptr && blockIdx.y == 0;
+    const int t = threadIdx.x, tp = t >> 4, tc = (t & 15) * 4;
+    double bs[4] = {0.0, 0.0, 0.0, 0.0};
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int64_t r0 = r_beg; r0 < r_end; r0 += XRK) {
+        __syncthreads();
+        stage_t_x3(At, A, lda, r0, r_end, a0, na);
+        stage_t_x3(Bt, B, ldb, r0, r_end, b0, nb);
+        if (do_bias) {   // the values stage_t_x3 has just read (L1 hits): rows r0 + 2 tp, + 1, columns a0 + tc .. + 3
+            const int64_t ra = r0 + 2 * tp, rb = ra + 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cc = a0 + tc + j;
+                if (cc < na) {
+                    if (ra < r_end) bs[j] += (double)A[ra * lda + cc];
+                    if (rb < r_end) bs[j] += (double)A[rb * lda + cc];
+                }
+            }
+        }
+        __syncthreads();
+        const char* ap = At + (wa * 32 + l31) * XLDT + h * 16;
+        const char* bp = Bt + (wb * 32 + l31) * XLDT + h * 16;
+#pragma unroll
+        for (int S = 0; S < XRK / 16; ++S) {
+            bf16x8_t af[3], bf[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                af[p] = *reinterpret_cast<const bf16x8_t*>(ap + p * 64 + S * 32);
+                bf[p] = *reinterpret_cast<const bf16x8_t*>(bp + p * 64 + S * 32);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc, 0, 0, 0);
+        }
+    }
+    float* P = partials + (int64_t)blockIdx.z * na * nbt;
+    const int col = b0 + wb * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = a0 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < na && col < nb) P[(int64_t)row * nbt + colbase + col] = acc[r];
+    }
+    if (do_bias) {
+        __syncthreads();                                 // the fragments of the last slice have been read
+        double* red = reinterpret_cast<double*>(At);     // [16 row pairs][64 columns] = 8 KB of the 13 KB tile
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[tp * 64 + tc + j] = bs[j];
+        __syncthreads();
+        if (t < 64 && a0 + t < na) {
+            double sum = 0.0;
+            for (int k = 0; k < 16; ++k) sum += red[k * 64 + t];
+            bias_partials[(int64_t)blockIdx.z * na + a0 + t] = sum;
+        }
+    }
+}
+
+// dW1 / dW2 / dbias = sums over the row splits in k_wgrad_reduce's order; the blocks behind the matrix elements take the bias columns
+__global__ void __launch_bounds__(256) k_wgrad_reduce_cat(const float* __restrict__ partials, const double* __restrict__ bias_partials, int splits, int na,
+                                                          int nb1, int nb2, float* __restrict__ dW1, float* __restrict__ dW2, float* __restrict__ dbias) {
+    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int nbt = nb1 + nb2, nmat = na * nbt, nblk_mat = (nmat + 15) / 16;
+    if ((int)blockIdx.x < nblk_mat) {
+        __shared__ float red[16][17];
+        const int i = blockIdx.x * 16 + o;
+        const bool live = i < nmat;
+        float p = 0.f;
+        if (live)
+            for (int z = sl; z < splits; z += 16) p += partials[(int64_t)z * nmat + i];
+        red[sl][o] = p;
+        __syncthreads();
+        if (sl != 0 || !live) return;
+        float s = 0.f;
+        for (int k = 0; k < 16; ++k) s += red[k][o];
+        const int row = i / nbt, col = i - row * nbt;
+        if (col < nb1)
+            dW1[(int64_t)row * nb1 + col] = s;
+        else
+            dW2[(int64_t)row * nb2 + (col - nb1)] = s;
+    } else {
+        __shared__ double redd[16][17];
+        const int i = ((int)blockIdx.x - nblk_mat) * 16 + o;
+        const bool live = i < na;
+        double p = 0.0;
+        if (live)
+            for (int z = sl; z < splits; z += 16) p += bias_partials[(int64_t)z * na + i];
+        redd[sl][o] = p;
+        __syncthreads();
+        if (sl != 0 || !live) return;
+        double s = 0.0;
+        for (int k = 0; k < 16; ++k) s += redd[k][o];
+        dbias[i] = (float)s;
+    }
+}
+
 int wgrad_splits(int64_t M) {
     int64_t s = dgnn_cdiv(M, 4 * RK);  // at least 128 rows per split
     if (s > WGRAD_SPLITS) s = WGRAD_SPLITS;
@@ -1510,4 +1632,32 @@ extern "C" int dgnn_linear_wgrad_x3(const float* A, int64_t lda, int n_a, const 
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)dgnn_cdiv((int64_t)n_a * n_b, 16)), dim3(256), 0, stream, partials, splits, n_a, n_b, dW, lddw,
                        accumulate);
     return dgnn_check_launch("linear_wgrad_x3");
+}
+
+// fp32 partials [splits][n_a][n_b1 + n_b2], then fp64 bias partials [splits][n_a] (8-byte aligned inside the float scratch)
+extern "C" int64_t dgnn_linear_wgrad_cat_scratch_elems(int64_t M, int n_a, int n_b1, int n_b2) {
+    if (M < 0 || n_a <= 0 || n_b1 <= 0 || n_b2 < 0) return 4;
+    const int64_t splits = wgrad_splits(M);
+    return splits * n_a * (n_b1 + n_b2) + 2 * splits * n_a + 4;
+}
+
+extern "C" int dgnn_linear_wgrad_x3_cat(const float* A, int64_t lda, int n_a, const float* B1, int64_t ldb1, int n_b1, const float* B2, int64_t ldb2,
+                                        int n_b2, int64_t M, float* dW1, float* dW2, float* dbias, float* scratch, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DGNN_REQUIRE(M >= 0 && n_a > 0 && n_b1 > 0 && n_b2 >= 0, DGNN_E_INVALID, "linear_wgrad_x3_cat: bad sizes");
+    DGNN_REQUIRE(dW1 && scratch && (M == 0 || (A && B1)) && ((n_b2 == 0) == (B2 == nullptr)) && (n_b2 == 0 || dW2), DGNN_E_INVALID,
+                 "linear_wgrad_x3_cat: null pointer");
+    const int splits = wgrad_splits(M);
+    const int64_t rps = dgnn_cdiv(dgnn_cdiv(M, splits), XRK) * XRK;
+    const int nby1 = (int)dgnn_cdiv(n_b1, WT), nby2 = (int)dgnn_cdiv(n_b2, WT);
+    float* partials = scratch;
+    double* bias_partials = reinterpret_cast<double*>(((uintptr_t)(scratch + (int64_t)splits * n_a * (n_b1 + n_b2)) + 7) & ~(uintptr_t)7);
+    WgradCat c;
+    c.B[0] = B1, c.B[1] = B2, c.ldb[0] = ldb1, c.ldb[1] = ldb2, c.nb[0] = n_b1, c.nb[1] = n_b2;
+    dim3 grid((unsigned)dgnn_cdiv(n_a, WT), (unsigned)(nby1 + nby2), splits);
+    hipLaunchKernelGGL(k_linear_wgrad_x3_cat, grid, dim3(256), 0, stream, A, lda, n_a, c, nby1, M, rps < XRK ? XRK : rps, partials,
+                       dbias ? bias_partials : nullptr);
+    const int nblk = (int)dgnn_cdiv((int64_t)n_a * (n_b1 + n_b2), 16) + (dbias ? (int)dgnn_cdiv(n_a, 16) : 0);
+    hipLaunchKernelGGL(k_wgrad_reduce_cat, dim3((unsigned)nblk), dim3(256), 0, stream, partials, bias_partials, splits, n_a, n_b1, n_b2, dW1, dW2, dbias);
+    return dgnn_check_launch("linear_wgrad_x3_cat");
 }

@@ -42,6 +42,39 @@ __global__ void k_transpose2(const float* __restrict__ in0, const float* __restr
 
 inline int64_t align4(int64_t v) { return (v + 3) & ~(int64_t)3; }
 
+// every layer's lin_j / lin_i transposed by ONE launch at the start of a backward pass (was one or two launches per layer)
+struct TrJobs {
+    const float* in[16];
+    float* out[16];
+    int rows[16], cols[16], end[16];   // end[j] = elements of jobs 0 .. j
+    int n;
+};
+__global__ void k_transpose_many(TrJobs jobs) {
+    const int total = jobs.end[jobs.n - 1];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int j = 0;
+        while (i >= jobs.end[j]) ++j;
+        const int e = i - (j ? jobs.end[j - 1] : 0);
+        const int r = e / jobs.cols[j], c = e - r * jobs.cols[j];
+        jobs.out[j][c * jobs.rows[j] + r] = jobs.in[j][e];
+    }
+}
+
+// DGNN_TRAIN_FUSED=0: the launch chain of the separate entry points (one launch per weight gradient, bias sum, transpose and
+// input-gradient GEMM).  Default: dWj / dWi / dbj from one launch pair (dgnn_linear_wgrad_x3_cat), da and dz.Wi from one GEMM against
+// the stacked [Wj^T ; Wi^T], the latter added where the aggregate backward stores dx (dgnn_sage_aggregate_bwd_add), all transposes of a
+// backward pass in one launch.  Same arithmetic per element; only dbj is summed in another (fp64) order.
+int g_fused_on = -1;
+bool fused_enabled() {
+    int v = __atomic_load_n(&g_fused_on, __ATOMIC_ACQUIRE);
+    if (v < 0) {
+        v = (getenv("DGNN_TRAIN_FUSED") && getenv("DGNN_TRAIN_FUSED")[0] == '0') ? 0 : 1;
+        if (getenv("DGNN_AGG_CHUNKED") && getenv("DGNN_AGG_CHUNKED")[0] == '0') v = 0;   // the addend form lives in the chunked kernel
+        __atomic_store_n(&g_fused_on, v, __ATOMIC_RELEASE);
+    }
+    return v != 0;
+}
+
 }  // namespace
 
 #define TRY(call)                 \
@@ -59,7 +92,8 @@ extern "C" int64_t dgnn_sage_layer_train_scratch_elems(int64_t n_src, int64_t n_
     // gradients run on a second stream with their own partials)
     int64_t big = stats > wg ? stats : wg;
     if (ab > big) big = ab;
-    return align4(n_dst * c_out) + align4(n_dst * c_in) + 2 * align4((int64_t)c_in * c_out) + 2 * align4(big) + 64;
+    const int64_t wc = dgnn_linear_wgrad_cat_scratch_elems(n_dst, c_out, c_in, c_in);
+    return align4(n_dst * c_out) + 2 * align4(n_dst * c_in) + 2 * align4((int64_t)c_in * c_out) + align4(big) + align4(big > wc ? big : wc) + 64;
 }
 
 extern "C" int dgnn_sage_layer_train_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x,
@@ -150,10 +184,12 @@ int layer_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
               int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e, const float* We, const float* be, const float* Wj, const float* Wi, int c_out,
               const float* gamma, const float* mean, const float* var, float eps, int relu, const float* a, const float* z, const float* y, const float* dy,
               float* dx, float* dWe, float* dbe, float* dWj, float* dbj, float* dWi, float* dgamma, float* dbeta, float* dz, float* da, float* WjT, float* WiT,
-              float* tmp, float* tmp_w, int gemm_mode, hipStream_t stream, Aux* aux, hipEvent_t* done) {
+              float* tmp, float* tmp_w, int gemm_mode, hipStream_t stream, Aux* aux, hipEvent_t* done, bool pre_t = false) {
     void* stream_ = (void*)stream;
     const bool agg = t_rowptr != nullptr;
     const bool x3 = gemm_mode != DGNN_GEMM_F32;
+    // fused chain (see fused_enabled): `da` holds [n_dst, 2 c_in] floats, WiT == WjT + c_in * c_out (the stacked transposes)
+    const bool fused = x3 && !aux && fused_enabled();
     auto gemm = [&](const float* A, int64_t lda, int k, const float* W, int64_t ldw, int flags, int64_t M, int n, float* out, int64_t ldo) {
         return x3 ? dgnn_linear_fwd_x3(A, lda, k, W, ldw, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, flags, M, n, out, ldo, stream_)
                   : dgnn_linear_fwd(A, lda, k, W, ldw, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, flags, M, n, out, ldo, stream_);
@@ -173,9 +209,14 @@ int layer_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
     }
     const float* A1 = agg ? a : x;
     const int64_t lda1 = agg ? c_in : ldx;
-    TRY(wgrad(dz, c_out, c_out, A1, lda1, c_in, dWj));
-    if (dbj) TRY(dgnn_colsum(dz, c_out, n_dst, c_out, dbj, 0, wtmp, wstream));
-    if (agg && Wi && dWi) TRY(wgrad(dz, c_out, c_out, x, ldx, c_in, dWi));
+    if (fused) {
+        const float* B2 = (agg && Wi && dWi) ? x : nullptr;
+        TRY(dgnn_linear_wgrad_x3_cat(dz, c_out, c_out, A1, lda1, c_in, B2, ldx, B2 ? c_in : 0, n_dst, dWj, dWi, dbj, wtmp, stream_));
+    } else {
+        TRY(wgrad(dz, c_out, c_out, A1, lda1, c_in, dWj));
+        if (dbj) TRY(dgnn_colsum(dz, c_out, n_dst, c_out, dbj, 0, wtmp, wstream));
+        if (agg && Wi && dWi) TRY(wgrad(dz, c_out, c_out, x, ldx, c_in, dWi));
+    }
     if (aux) {
         *done = next_event(aux);
         (void)hipEventRecord(*done, aux->stream);
@@ -183,10 +224,19 @@ int layer_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
     const bool need_dx = dx != nullptr;
     const bool need_da = agg ? (need_dx || We != nullptr) : need_dx;
     const bool both = need_da && agg && need_dx && Wi;
-    if (both)
+    if (both && !pre_t)
         hipLaunchKernelGGL(k_transpose2, dim3(dgnn_grid_cap(dgnn_cdiv((int64_t)2 * c_in * c_out, 256))), dim3(256), 0, stream, Wj, Wi, c_out, c_in, WjT, WiT);
+    if (fused && both && We && f_e == 20) {
+        // [da | dz.Wi] = dz . [Wj^T ; Wi^T]^T in one GEMM (every output column is the separate GEMMs' own dot product), the second half added to
+        // the aggregate's sums where dx is stored
+        if (We) DGNN_REQUIRE(dWe && dbe, DGNN_E_INVALID, "sage_layer_train_bwd: dWe / dbe missing");
+        TRY(gemm(dz, c_out, c_out, WjT, c_out, 0, n_dst, 2 * c_in, da, 2 * c_in));
+        TRY(dgnn_sage_aggregate_bwd_add(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x, ldx, c_in, edge_attr, lde, f_e, We, be, da, 2 * c_in, dx, c_in, da + c_in,
+                                        2 * c_in, n_dst, dWe, dbe, tmp, stream_));
+        return dgnn_check_launch("sage_layer_train_bwd");
+    }
     if (need_da) {
-        if (!both) hipLaunchKernelGGL(k_transpose, dim3(dgnn_grid_cap(dgnn_cdiv((int64_t)c_in * c_out, 256))), dim3(256), 0, stream, Wj, c_out, c_in, WjT);
+        if (!both && !pre_t) hipLaunchKernelGGL(k_transpose, dim3(dgnn_grid_cap(dgnn_cdiv((int64_t)c_in * c_out, 256))), dim3(256), 0, stream, Wj, c_out, c_in, WjT);
         // plain Linear block: the gradient of the input is da itself
         TRY(gemm(dz, c_out, c_out, WjT, c_out, 0, n_dst, c_in, agg ? da : dx, c_in));
     }
@@ -196,7 +246,7 @@ int layer_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
             TRY(dgnn_sage_aggregate_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x, ldx, c_in, edge_attr, lde, f_e, We, be, nullptr, 0, da, c_in, dx,
                                         c_in, dWe, dbe, nullptr, 0, tmp, stream_));
         if (need_dx && Wi) {
-            if (!both) hipLaunchKernelGGL(k_transpose, dim3(dgnn_grid_cap(dgnn_cdiv((int64_t)c_in * c_out, 256))), dim3(256), 0, stream, Wi, c_out, c_in, WiT);
+            if (!both && !pre_t) hipLaunchKernelGGL(k_transpose, dim3(dgnn_grid_cap(dgnn_cdiv((int64_t)c_in * c_out, 256))), dim3(256), 0, stream, Wi, c_out, c_in, WiT);
             TRY(gemm(dz, c_out, c_out, WiT, c_out, DGNN_LINEAR_ACCUMULATE, n_dst, c_in, dx, c_in));
         }
     }
@@ -216,9 +266,9 @@ extern "C" int dgnn_sage_layer_train_bwd(const int32_t* t_rowptr, const int32_t*
     hipStream_t stream = (hipStream_t)stream_;
     float* dz = scratch;
     float* da = dz + align4(n_dst * c_out);
-    float* WjT = da + align4(n_dst * c_in);
-    float* WiT = WjT + align4((int64_t)c_in * c_out);
-    float* tmp = WiT + align4((int64_t)c_in * c_out);
+    float* WjT = da + 2 * align4(n_dst * c_in);
+    float* WiT = WjT + (int64_t)c_in * c_out;            // stacked: [Wj^T ; Wi^T] is one [2 c_in, c_out] matrix
+    float* tmp = WjT + 2 * align4((int64_t)c_in * c_out);
     float* tmp_w = tmp + layer_tmp_elems(n_src, n_dst, c_in, c_out, f_e);
     Aux* aux = aux_enabled() ? aux_of_current_device() : nullptr;
     hipEvent_t done = nullptr;
@@ -454,22 +504,38 @@ extern "C" int dgnn_static_train_fwd(int n_layers, const int32_t* const* rowptr,
 
 // dy: gradient of the last layer's y.  dx_buf[0], dx_buf[1]: two work buffers of max_l n_src[l] * widths[l] floats (layer l writes
 // its dx into dx_buf[l & 1], layer l-1 reads it as dy); layer 0's input is data (no dx).  Parameter gradients per layer.
-extern "C" int64_t dgnn_static_train_scratch_elems(int n_layers, const int64_t* n_src, const int64_t* n_dst, const int32_t* widths, int f_e) {
-    if (n_layers < 1 || !n_src || !n_dst || !widths) return 16;
-    int64_t dz = 0, da = 0, wt = 0, tmp = 0, tw = 0;
+namespace {
+// scratch of dgnn_static_train_bwd: dz ping-pong | da ([n_dst, 2 c_in]: da next to dz.Wi) | every layer's [Wj^T ; Wi^T] | main-stream partials |
+// weight-gradient partials
+struct StaticScratch {
+    int64_t dz = 0, da = 0, wt_total = 0, tmp = 0, tw = 0, wt_off[8] = {};
+};
+StaticScratch static_scratch(int n_layers, const int64_t* n_src, const int64_t* n_dst, const int32_t* widths, int f_e) {
+    StaticScratch r;
     for (int l = 0; l < n_layers; ++l) {
         const int ci = widths[l], co = widths[l + 1];
-        const int64_t a1 = align4(n_dst[l] * co), a2 = align4(n_dst[l] * ci), a3 = align4((int64_t)ci * co);
+        const int64_t a1 = align4(n_dst[l] * co), a2 = 2 * align4(n_dst[l] * ci), a3 = 2 * align4((int64_t)ci * co);
         const int64_t stats = dgnn_colstats_scratch_elems(n_dst[l], co > ci ? co : ci), wg = dgnn_linear_wgrad_scratch_elems(n_dst[l], co, ci),
-                      ab = dgnn_sage_aggregate_bwd_scratch_elems(n_src[l], ci, f_e > 0 ? f_e : 1);
-        if (a1 > dz) dz = a1;
-        if (a2 > da) da = a2;
-        if (a3 > wt) wt = a3;
-        const int64_t t1 = align4(stats > ab ? stats : ab), t2 = align4(stats > wg ? stats : wg);
-        if (t1 > tmp) tmp = t1;
-        if (t2 > tw) tw = t2;
+                      wc = dgnn_linear_wgrad_cat_scratch_elems(n_dst[l], co, ci, ci), ab = dgnn_sage_aggregate_bwd_scratch_elems(n_src[l], ci, f_e > 0 ? f_e : 1);
+        if (a1 > r.dz) r.dz = a1;
+        if (a2 > r.da) r.da = a2;
+        r.wt_off[l] = r.wt_total;
+        r.wt_total += a3;
+        const int64_t t1 = align4(stats > ab ? stats : ab);
+        int64_t t2 = stats > wg ? stats : wg;
+        if (wc > t2) t2 = wc;
+        t2 = align4(t2);
+        if (t1 > r.tmp) r.tmp = t1;
+        if (t2 > r.tw) r.tw = t2;
     }
-    return 2 * dz + da + 2 * wt + tmp + tw + 64;   // dz ping-pong | da | WjT, WiT | main-stream partials | weight-gradient partials
+    return r;
+}
+}  // namespace
+
+extern "C" int64_t dgnn_static_train_scratch_elems(int n_layers, const int64_t* n_src, const int64_t* n_dst, const int32_t* widths, int f_e) {
+    if (n_layers < 1 || n_layers > 8 || !n_src || !n_dst || !widths) return 16;
+    const StaticScratch r = static_scratch(n_layers, n_src, n_dst, widths, f_e);
+    return 2 * r.dz + r.da + r.wt_total + r.tmp + r.tw + 64;
 }
 
 // dy: gradient of the last layer's y.  dx_buf[0], dx_buf[1]: two work buffers of max_l n_src[l] * widths[l] floats (layer l writes
@@ -489,23 +555,35 @@ extern "C" int dgnn_static_train_bwd(int n_layers, const int32_t* const* t_rowpt
                  DGNN_E_INVALID, "static_train_bwd: bad args");
     hipStream_t stream = (hipStream_t)stream_;
     Aux* aux = aux_enabled() ? aux_of_current_device() : nullptr;
-    int64_t dzn = 0, dan = 0, wtn = 0, tmpn = 0;
-    for (int l = 0; l < n_layers; ++l) {
-        const int ci = widths[l], co = widths[l + 1];
-        const int64_t a1 = align4(n_dst[l] * co), a2 = align4(n_dst[l] * ci), a3 = align4((int64_t)ci * co);
-        const int64_t st = dgnn_colstats_scratch_elems(n_dst[l], co > ci ? co : ci), ab = dgnn_sage_aggregate_bwd_scratch_elems(n_src[l], ci, f_e > 0 ? f_e : 1);
-        const int64_t t1 = align4(st > ab ? st : ab);
-        if (a1 > dzn) dzn = a1;
-        if (a2 > dan) dan = a2;
-        if (a3 > wtn) wtn = a3;
-        if (t1 > tmpn) tmpn = t1;
+    const StaticScratch lay = static_scratch(n_layers, n_src, n_dst, widths, f_e);
+    float* dzb[2] = {scratch, scratch + lay.dz};
+    float* da = scratch + 2 * lay.dz;
+    float* wt = da + lay.da;
+    float* tmp = wt + lay.wt_total;
+    float* tmp_w = tmp + lay.tmp;
+    // all transposes of the pass in one launch (fused chain), into per-layer regions; otherwise every layer transposes into the first region
+    const bool pre_t = gemm_mode != DGNN_GEMM_F32 && !aux && fused_enabled();
+    if (pre_t) {
+        TrJobs jobs;
+        jobs.n = 0;
+        int total = 0;
+        for (int l = 0; l < n_layers; ++l) {
+            const int ci = widths[l], co = widths[l + 1];
+            const bool agg = t_rowptr[l] != nullptr, need_dx = l > 0;
+            const bool need_da = agg ? (need_dx || We[l] != nullptr) : need_dx;
+            if (!need_da) continue;
+            const bool both = agg && need_dx && Wi[l];
+            for (int k = 0; k < (both ? 2 : 1); ++k) {
+                const int j = jobs.n++;
+                jobs.in[j] = k == 0 ? Wj[l] : Wi[l];
+                jobs.out[j] = wt + lay.wt_off[l] + (int64_t)k * ci * co;
+                jobs.rows[j] = co, jobs.cols[j] = ci;
+                total += ci * co;
+                jobs.end[j] = total;
+            }
+        }
+        if (jobs.n) hipLaunchKernelGGL(k_transpose_many, dim3(dgnn_grid_cap(dgnn_cdiv(total, 256))), dim3(256), 0, stream, jobs);
     }
-    float* dzb[2] = {scratch, scratch + dzn};
-    float* da = scratch + 2 * dzn;
-    float* WjT = da + dan;
-    float* WiT = WjT + wtn;
-    float* tmp = WiT + wtn;
-    float* tmp_w = tmp + tmpn;
     hipEvent_t done[8] = {};
     if (aux) {   // the second stream starts after everything already queued on `stream` (its inputs, and last step's use of the scratch)
         hipEvent_t e = next_event(aux);
@@ -521,9 +599,10 @@ extern "C" int dgnn_static_train_bwd(int n_layers, const int32_t* const* t_rowpt
         float* dx = l == 0 ? nullptr : dx_buf[l & 1];
         const float* st = stats[l];
         if (aux && l + 2 < n_layers && done[l + 2]) (void)hipStreamWaitEvent(stream, done[l + 2], 0);   // dz[l & 1] is still read by layer l+2's weight gradients
+        float* WjT = wt + (pre_t ? lay.wt_off[l] : 0);
         rc = layer_bwd(t_rowptr[l], t_dst[l], t_eid[l], rowptr_dst[l], n_src[l], n_dst[l], x, ldx, c_in, edge_attr[l], lde[l], We[l] ? f_e : 0, We[l], be[l], Wj[l],
                        Wi[l], c_out, gamma[l], st, st + c_out, eps[l], 1, a[l], z[l], y[l], g, dx, dWe[l], dbe[l], dWj[l], dbj[l], dWi[l], dgamma[l], dbeta[l],
-                       dzb[l & 1], da, WjT, WiT, tmp, tmp_w, gemm_mode, stream, aux, aux ? &done[l] : nullptr);
+                       dzb[l & 1], da, WjT, WjT + (int64_t)c_in * c_out, tmp, tmp_w, gemm_mode, stream, aux, aux ? &done[l] : nullptr, pre_t);
         g = dx;
     }
     if (aux)   // the gradients are consumed on `stream` (optimizer step): join.  In-order on the second stream: the last event covers all.

@@ -271,6 +271,37 @@ def linear_wgrad(A, B):
 
 
 @on_device_of
+def linear_wgrad_cat(A, B1, B2=None, bias=True):
+    """(dW1 = A^T . B1, dW2 = A^T . B2 | None, column sums of A | None) from one launch pair (dgnn_linear_wgrad_x3_cat; fp32, x3 arithmetic)"""
+    _req(A, "A", dim=2)
+    _req(B1, "B1", dim=2)
+    M, na, nb1 = A.size(0), A.size(1), B1.size(1)
+    nb2 = B2.size(1) if B2 is not None else 0
+    dW1 = torch.empty((na, nb1), dtype=torch.float32, device=A.device)
+    dW2 = torch.empty((na, nb2), dtype=torch.float32, device=A.device) if B2 is not None else None
+    db = torch.empty(na, dtype=torch.float32, device=A.device) if bias else None
+    scratch = _f32(lib().dgnn_linear_wgrad_cat_scratch_elems(M, na, nb1, nb2), A.device)
+    check(lib().dgnn_linear_wgrad_x3_cat(ptr(A), _ld(A), na, ptr(B1), _ld(B1), nb1, ptr(B2), _ld(B2) if B2 is not None else 0, nb2, M, ptr(dW1), ptr(dW2),
+                                         ptr(db), ptr(scratch), stream_ptr()), "dgnn_linear_wgrad_x3_cat")
+    return dW1, dW2, db
+
+
+@on_device_of
+def aggregate_bwd_add(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, da, edge_attr, We, be, add):
+    """aggregate_bwd (fused 20-attribute filter) with dx[:add.size(0)] += add folded into the store -> (dx, dWe, dbe)"""
+    _req(x_src, "x_src", dim=2)
+    c_in = x_src.size(1)
+    dx = torch.empty((n_src, c_in), dtype=torch.float32, device=x_src.device)
+    We, be = We.contiguous(), be.contiguous()
+    dWe, dbe = torch.empty_like(We), torch.empty_like(be)
+    partials = _f32(lib().dgnn_sage_aggregate_bwd_scratch_elems(n_src, c_in, We.size(1)), x_src.device)
+    check(lib().dgnn_sage_aggregate_bwd_add(ptr(t_rowptr), ptr(t_dst), ptr(t_eid), n_src, ptr(rowptr_dst), ptr(x_src), _ld(x_src), c_in, ptr(edge_attr),
+                                            _ld(edge_attr), We.size(1), ptr(We), ptr(be), ptr(da), _ld(da), ptr(dx), c_in, ptr(add), _ld(add), add.size(0),
+                                            ptr(dWe), ptr(dbe), ptr(partials), stream_ptr()), "dgnn_sage_aggregate_bwd_add")
+    return dx, dWe, dbe
+
+
+@on_device_of
 def colsum(x):
     _req(x, "x", ACT, dim=2)
     out = torch.empty(x.size(1), dtype=torch.float32, device=x.device)

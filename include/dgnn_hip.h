@@ -151,6 +151,14 @@ int dgnn_linear_fwd_x2hp(const float* A1, int64_t lda1, int k1, const float* W1,
 int dgnn_linear_wgrad_x3(const float* A, int64_t lda, int n_a, const float* B, int64_t ldb, int n_b, int64_t M, float* dW, int64_t lddw,
                          int accumulate, float* partials, void* stream);
 
+/* Both weight gradients of a conv layer and its bias gradient in one launch pair (autograd of :81-86 for lin_j, lin_i and lin_j.bias):
+ * dW1[n_a, n_b1] = A^T . B1, dW2[n_a, n_b2] = A^T . B2 (B2 NULL / n_b2 0: none), dbias[n_a] = column sums of A (NULL: none), all
+ * WRITTEN, contiguous.  dW1 / dW2 are bit-identical to two dgnn_linear_wgrad_x3 calls (same row splits, same products); dbias is summed
+ * in fp64 like dgnn_colsum, in another order.  scratch: dgnn_linear_wgrad_cat_scratch_elems floats. */
+int64_t dgnn_linear_wgrad_cat_scratch_elems(int64_t M, int n_a, int n_b1, int n_b2);
+int dgnn_linear_wgrad_x3_cat(const float* A, int64_t lda, int n_a, const float* B1, int64_t ldb1, int n_b1, const float* B2, int64_t ldb2,
+                             int n_b2, int64_t M, float* dW1, float* dW2, float* dbias, float* scratch, void* stream);
+
 /* dW[n_a, n_b] (+)= A^T . B over M rows (weight gradients of the Linears above: autograd of :81-86).
  * Deterministic two-stage reduction; `partials` holds dgnn_linear_wgrad_scratch_elems floats. */
 int64_t dgnn_linear_wgrad_scratch_elems(int64_t M, int n_a, int n_b);
@@ -202,6 +210,15 @@ int dgnn_sage_aggregate_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const
                             const float* phi, int64_t ldphi, const float* da, int64_t ldda, float* dx_src,
                             int64_t lddx, float* dWe, float* dbe, float* dphi_out, int64_t lddphi, float* partials,
                             void* stream);
+
+/* dgnn_sage_aggregate_bwd in fused mode (f_e = 20, fp32) with `dx_src[row] += add[row]` for row < n_add folded into the store of dx_src:
+ * the x_dst = x[:n_dst] branch of a conv layer (:217, lin_i) sends its gradient dz . Wi to the first n_dst rows of dx; the addend is
+ * added to the finished sum in one fp32 addition, like an accumulating GEMM epilogue after the aggregate would. */
+int dgnn_sage_aggregate_bwd_add(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, int64_t n_src,
+                                const int32_t* rowptr_dst, const float* x_src, int64_t ldx, int c_in, const float* edge_attr,
+                                int64_t lde, int f_e, const float* We, const float* be, const float* da, int64_t ldda, float* dx_src,
+                                int64_t lddx, const float* add, int64_t ldadd, int64_t n_add, float* dWe, float* dbe, float* partials,
+                                void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused inference layer (the timed path, surfaceNetStaticEdgeFilters.py:343-346, one call per

@@ -186,6 +186,50 @@ def test_linear_wgrad_and_colsum(M, na, nb):
     assert rel_err(ops.colsum(A.to(DEV)), A.double().sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("M,na,nb1,nb2", [(5000, 128, 128, 128), (333, 64, 28, 28), (70000, 128, 64, 64), (64, 130, 37, 0), (2048, 64, 128, 0), (1, 2, 3, 3)])
+def test_merged_weight_gradient_launch_matches_the_separate_calls(M, na, nb1, nb2):
+    """dgnn_linear_wgrad_x3_cat: dW1 / dW2 bit for bit the two dgnn_linear_wgrad_x3 calls it replaces, the bias sums against fp64"""
+    from dgnn_amd import ops
+    if ops.GEMM_MODE == ops.GEMM_F32:
+        pytest.skip("x3 arithmetic only")
+    g = torch.Generator().manual_seed(M + nb2)
+    A, B1 = torch.randn(M, na, generator=g).to(DEV), torch.randn(M, nb1 + 3, generator=g).to(DEV)[:, 3:]   # B1: a strided view
+    B2 = torch.randn(M, nb2, generator=g).to(DEV) if nb2 else None
+    dW1, dW2, db = ops.linear_wgrad_cat(A, B1, B2)
+    assert torch.equal(dW1, ops.linear_wgrad(A, B1))
+    if nb2:
+        assert torch.equal(dW2, ops.linear_wgrad(A, B2))
+    ref = A.double().sum(0)
+    assert (db.double() - ref).abs().max().item() <= 1e-6 * A.double().abs().sum(0).max().item()
+    dW1b, _, none = ops.linear_wgrad_cat(A, B1, B2, bias=False)
+    assert none is None and torch.equal(dW1b, dW1)
+
+
+@pytest.mark.parametrize("c_in,n_src,n_dst", [(64, 900, 600), (128, 5000, 1777), (28, 333, 333), (128, 40, 7)])
+def test_aggregate_backward_with_addend_matches_the_two_steps(c_in, n_src, n_dst):
+    """dgnn_sage_aggregate_bwd_add: dx = aggregate backward, then dx[:n_add] += add in one fp32 addition per element -- bit for bit; dWe / dbe
+    untouched by the addend"""
+    from dgnn_amd import ops
+    g = torch.Generator().manual_seed(c_in + n_src)
+    E = 4 * n_dst
+    ei = torch.stack([torch.randint(0, n_src, (E,), generator=g), torch.arange(n_dst).repeat_interleave(4)])
+    if n_src > 100:
+        ei[0, : E // 3] = ei[0, : E // 3] % 50          # a few sources with dozens of out-edges, most of the others with none or a few
+    x, da, ea = torch.randn(n_src, c_in, generator=g).to(DEV), torch.randn(n_dst, c_in, generator=g).to(DEV), torch.randn(E, 20, generator=g).to(DEV)
+    We, be = (torch.randn(c_in, 20, generator=g) * 0.3).to(DEV), torch.randn(c_in, generator=g).to(DEV)
+    rowptr, _, _ = ops.plan_build(ei.to(DEV), n_dst, 1)
+    t_rowptr, t_dst, t_eid = ops.plan_build(ei.to(DEV), n_src, 0)
+    n_add = n_dst if n_dst <= n_src else n_src
+    wide = torch.randn(n_add, 2 * c_in, generator=g).to(DEV)
+    add = wide[:, c_in:]                                 # the second half of a [n_dst, 2 c_in] GEMM output, as the training step passes it
+    dx0, dWe0, dbe0, _ = ops.aggregate_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr, x, da, ea, We, be)
+    dx1, dWe1, dbe1 = ops.aggregate_bwd_add(t_rowptr, t_dst, t_eid, n_src, rowptr, x, da, ea, We, be, add)
+    want = dx0.clone()
+    want[:n_add] += add
+    assert torch.equal(dx1, want)
+    assert torch.equal(dWe1, dWe0) and torch.equal(dbe1, dbe0)
+
+
 def test_batchnorm_train_eval_and_backward():
     from dgnn_amd import functional as Fn
     g = torch.Generator().manual_seed(3)

@@ -188,6 +188,16 @@ def test_generate_signature_labels_and_interface(tmp_path):
     assert np.array_equal(np.asarray(mesh2.faces), np.asarray(mesh.faces))
 
 
+def _same_grad(k, a, b):
+    """Gradients of two launch chains over the same kernels: bit for bit -- except the bias of a Linear that a BatchNorm follows (lin_j, the
+    decoder's first Linear) when one chain sums dz's columns inside the merged weight-gradient launch (dgnn_linear_wgrad_x3_cat) and the other
+    with dgnn_colsum: both sum in fp64, in different orders, and behind a batch-statistics BatchNorm that sum cancels to rounding noise
+    (its exact value is 0), so the two roundings of the noise differ.  Bound: a few fp64 ulps of the sum of magnitudes."""
+    if k.endswith("lin_j.bias") or k == "decoder.0.bias":
+        return (a - b).abs().max().item() <= 1e-9
+    return torch.equal(a, b)
+
+
 def test_composite_train_layer_is_bit_identical_to_the_separate_calls(monkeypatch):
     """dgnn_sage_layer_train_fwd / _bwd (one library call per layer each way) issue the kernels of the separate entry points in
     the same order: logits, every gradient and every BatchNorm buffer must match bit for bit."""
@@ -224,7 +234,7 @@ def test_composite_train_layer_is_bit_identical_to_the_separate_calls(monkeypatc
             la, ga, ba = run(True, data, G, whole)
             assert torch.equal(la, lb)
             for k in ga:
-                assert torch.equal(ga[k], gb[k]), (case, whole, k, (ga[k] - gb[k]).abs().max().item())
+                assert _same_grad(k, ga[k], gb[k]), (case, whole, k, (ga[k] - gb[k]).abs().max().item())
             for k in ba:
                 assert torch.equal(ba[k], bb[k]), (case, whole, k)
 
@@ -414,7 +424,7 @@ def test_aux_stream_backward_gives_identical_gradients():
     finally:
         lib().dgnn_train_set_aux_stream(was)
     for k in res[0]:
-        assert torch.equal(res[0][k], res[1][k]) and torch.equal(res[0][k], res[2][k]), k
+        assert _same_grad(k, res[0][k], res[1][k]) and torch.equal(res[1][k], res[2][k]), k
 
 
 def test_block_builder_buffer_ring_gives_the_same_training_run():
