@@ -34,6 +34,9 @@ SIGNATURES = {
     "dgnn_linear_fwd_x2hp_scratch_elems": (i64, [i64, i32, i32, i32]),
     "dgnn_linear_wgrad_x3": (i32, [vp, i64, i32, vp, i64, i32, i64, vp, i64, i32, vp, vp]),
     "dgnn_linear_wgrad_cat_scratch_elems": (i64, [i64, i32, i32, i32]),
+    "dgnn_train_set_fused": (i32, [i32]),
+    "dgnn_linear_fwd_x3_stats": (i32, [vp, i64, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp, i64, vp, vp]),
+    "dgnn_bn_stats_finalize_fold": (i32, [vp, i64, i64, i32, vp, vp, vp, vp, f32, vp, vp, f32, vp, vp, vp]),
     "dgnn_linear_wgrad_x3_cat": (i32, [vp, i64, i32, vp, i64, i32, vp, i64, i32, i64, vp, vp, vp, vp, vp]),
     "dgnn_sage_aggregate_bwd_add": (i32, [vp, vp, vp, i64, vp, vp, i64, i32, vp, i64, i32, vp, vp, vp, i64, vp, i64, vp, i64, i64, vp, vp, vp, vp]),
     "dgnn_linear_wgrad_scratch_elems": (i64, [i64, i32, i32]),

@@ -429,12 +429,30 @@ __device__ __forceinline__ void x3_store(char* __restrict__ dst, const f32x4 (&v
     }
 }
 
+// BatchNorm batch statistics from the GEMM that produces z (training forward): every wavefront adds the 32 x 32 accumulator block it is
+// about to store (bias included) into fp64 column sums / sums of squares and writes them as partial row `row / 32` of
+// colstats[ceil(M / 32)][2][n_out] -- the layout k_stats_finalize reads; the launch that used to read z back for them is gone.
+__device__ __forceinline__ double shfl_xor32_f64(double v) {
+    const uint64_t b = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)b, 32), hi = (uint32_t)__shfl_xor((int)(uint32_t)(b >> 32), 32);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ void stats_block_store(double* __restrict__ colstats, int64_t row_first, int64_t M, int n_out, int col, int h, double s, double q) {
+    s += shfl_xor32_f64(s);     // rows 4h .. of the block sit in the two half-waves
+    q += shfl_xor32_f64(q);
+    if (h == 0 && col < n_out && row_first < M) {
+        const int64_t rbk = row_first >> 5;
+        colstats[(rbk * 2 + 0) * n_out + col] = s;
+        colstats[(rbk * 2 + 1) * n_out + col] = q;
+    }
+}
+
 __global__ void __launch_bounds__(256, 2) k_linear_fwd_x3(const float* __restrict__ A1, int64_t lda1, int k1, const float* __restrict__ W1,
                                                           int64_t ldw1, bool vec1, const float* __restrict__ A2, int64_t lda2, int k2,
                                                           const float* __restrict__ W2, int64_t ldw2, bool vec2,
                                                           const float* __restrict__ bias, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int relu, int64_t M, int n_out,
-                                                          float* __restrict__ out, int64_t ldo) {
+                                                          float* __restrict__ out, int64_t ldo, double* __restrict__ colstats) {
     __shared__ __attribute__((aligned(16))) char As[XM * XLD];
     __shared__ __attribute__((aligned(16))) char Ws[XN * XLD];
     const int lane = lane_id(), w = wave_id_uniform();
@@ -510,22 +528,29 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_x3(const float* __restric
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int col = col0 + wc * 64 + b * 32 + l31;
-        if (col >= n_out) continue;
-        const float bb = bias ? bias[col] : 0.f;
-        const float sc = scale ? scale[col] : 1.f;
-        const float sh = scale ? shift[col] : 0.f;
+        const int colc = col < n_out ? col : n_out - 1;
+        const float bb = bias ? bias[colc] : 0.f;
+        const float sc = scale ? scale[colc] : 1.f;
+        const float sh = scale ? shift[colc] : 0.f;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a) {
+            double s = 0.0, q = 0.0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = row0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row >= M) continue;
+                if (row >= M || col >= n_out) continue;
                 float v = acc[a][b][r] + bb;
+                if (colstats) {
+                    s += v;
+                    q += (double)v * v;
+                }
                 if (scale) v = __fmaf_rn(v, sc, sh);
                 if (relu & 1) v = fmaxf(v, 0.f);
                 if (relu & DGNN_LINEAR_ACCUMULATE) v += out[row * ldo + col];
                 out[row * ldo + col] = v;
             }
+            if (colstats) stats_block_store(colstats, row0 + wr * 64 + a * 32, M, n_out, col, h, s, q);
+        }
     }
 }
 
@@ -538,7 +563,7 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_x3_n64(const float* __res
                                                               const float* __restrict__ W2, int64_t ldw2, bool vec2,
                                                               const float* __restrict__ bias, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, int relu, int64_t M, int n_out,
-                                                              float* __restrict__ out, int64_t ldo) {
+                                                              float* __restrict__ out, int64_t ldo, double* __restrict__ colstats) {
     __shared__ __attribute__((aligned(16))) char As[XM * XLD];
     __shared__ __attribute__((aligned(16))) char Ws[ZN * XLD];
     const int lane = lane_id(), w = wave_id_uniform();
@@ -621,22 +646,30 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_x3_n64(const float* __res
         }
     }
     const int col = wc * 32 + l31;
-    if (col < n_out) {
-        const float bb = bias ? bias[col] : 0.f;
-        const float sc = scale ? scale[col] : 1.f;
-        const float sh = scale ? shift[col] : 0.f;
+    {
+        const int colc = col < n_out ? col : n_out - 1;
+        const float bb = bias ? bias[colc] : 0.f;
+        const float sc = scale ? scale[colc] : 1.f;
+        const float sh = scale ? shift[colc] : 0.f;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a) {
+            double s = 0.0, q = 0.0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = row0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row >= M) continue;
+                if (row >= M || col >= n_out) continue;
                 float v = acc[a][r] + bb;
+                if (colstats) {
+                    s += v;
+                    q += (double)v * v;
+                }
                 if (scale) v = __fmaf_rn(v, sc, sh);
                 if (relu & 1) v = fmaxf(v, 0.f);
                 if (relu & DGNN_LINEAR_ACCUMULATE) v += out[row * ldo + col];
                 out[row * ldo + col] = v;
             }
+            if (colstats) stats_block_store(colstats, row0 + wr * 64 + a * 32, M, n_out, col, h, s, q);
+        }
     }
 }
 
@@ -650,7 +683,7 @@ __global__ void __launch_bounds__(256) k_linear_fwd_x3_small(const float* __rest
                                                              const float* __restrict__ W2, int64_t ldw2, bool vec2,
                                                              const float* __restrict__ bias, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, int relu, int64_t M, int n_out,
-                                                             float* __restrict__ out, int64_t ldo) {
+                                                             float* __restrict__ out, int64_t ldo, double* __restrict__ colstats) {
     const int lane = lane_id(), w = wave_id_uniform();
     const int h = lane >> 5, l31 = lane & 31;
     const int nct = (n_out + 31) / 32;                      // column tiles; a workgroup = 4 consecutive (row tile, column tile) pairs
@@ -729,20 +762,26 @@ __global__ void __launch_bounds__(256) k_linear_fwd_x3_small(const float* __rest
             if (st + 3 < nst) mul_step(r3);
         }
     }
-    if (col < n_out) {
-        const float bb = bias ? bias[col] : 0.f;
-        const float sc = scale ? scale[col] : 1.f;
-        const float sh = scale ? shift[col] : 0.f;
+    {
+        const float bb = bias ? bias[colc] : 0.f;
+        const float sc = scale ? scale[colc] : 1.f;
+        const float sh = scale ? shift[colc] : 0.f;
+        double s = 0.0, q = 0.0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int64_t orow = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (orow >= M) continue;
+            if (orow >= M || col >= n_out) continue;
             float v = acc[r] + bb;
+            if (colstats) {
+                s += v;
+                q += (double)v * v;
+            }
             if (scale) v = __fmaf_rn(v, sc, sh);
             if (relu & 1) v = fmaxf(v, 0.f);
             if (relu & DGNN_LINEAR_ACCUMULATE) v += out[orow * ldo + col];
             out[orow * ldo + col] = v;
         }
+        if (colstats) stats_block_store(colstats, rt * 32, M, n_out, col, h, s, q);
     }
 }
 
@@ -1520,9 +1559,10 @@ extern "C" int dgnn_linear_wgrad_bf16(const void* A, int a_f32, int64_t lda, int
 
 
 // ---- fp32-class GEMMs on the bf16 matrix cores (3-way exact split, 6 products) ---------------------------------------------
-extern "C" int dgnn_linear_fwd_x3(const float* A1, int64_t lda1, int k1, const float* W1, int64_t ldw1, const float* A2, int64_t lda2, int k2,
-                                  const float* W2, int64_t ldw2, const float* bias, const float* scale, const float* shift, int relu,
-                                  int64_t M, int n_out, float* out, int64_t ldo, void* stream) {
+namespace {
+int linear_fwd_x3_impl(const float* A1, int64_t lda1, int k1, const float* W1, int64_t ldw1, const float* A2, int64_t lda2, int k2, const float* W2,
+                       int64_t ldw2, const float* bias, const float* scale, const float* shift, int relu, int64_t M, int n_out, float* out, int64_t ldo,
+                       double* colstats, void* stream) {
     DGNN_REQUIRE(M >= 0 && n_out > 0 && k1 > 0, DGNN_E_INVALID, "linear_fwd_x3: bad sizes M=%lld n_out=%d k1=%d", (long long)M, n_out, k1);
     if (M == 0) return DGNN_OK;
     DGNN_REQUIRE(A1 && W1 && out, DGNN_E_INVALID, "linear_fwd_x3: null pointer");
@@ -1532,6 +1572,7 @@ extern "C" int dgnn_linear_fwd_x3(const float* A1, int64_t lda1, int k1, const f
     const bool v2 = A2 && vec_ok(A2, lda2) && vec_ok(W2, ldw2);
     static const bool big_ok = !(getenv("DGNN_X3_BIG") && getenv("DGNN_X3_BIG")[0] == '0');
     if (big_ok && M >= 8192 && n_out > XN) {   // same arithmetic per output element (chunk order, product order): identical results
+        if (colstats) return DGNN_E_UNSUPPORTED;   // the wide tile has no statistics epilogue: the caller reduces z in a launch of its own
         static bool attr_set[DGNN_MAX_DEVICES];
         constexpr size_t lds = (size_t)(YM + YN) * XLD;
         dgnn_allow_dynamic_lds((const void*)k_linear_fwd_x3_big, lds, attr_set);
@@ -1545,19 +1586,36 @@ extern "C" int dgnn_linear_fwd_x3(const float* A1, int64_t lda1, int k1, const f
     if (small_ok && M <= small_m) {
         const int64_t tiles = dgnn_cdiv(M, 32) * dgnn_cdiv(n_out, 32);
         hipLaunchKernelGGL(k_linear_fwd_x3_small, dim3((unsigned)dgnn_cdiv(tiles, 4)), dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2, lda2,
-                           k2, W2, ldw2, v2, bias, scale, shift, relu, M, n_out, out, ldo);
+                           k2, W2, ldw2, v2, bias, scale, shift, relu, M, n_out, out, ldo, colstats);
         return dgnn_check_launch("linear_fwd_x3");
     }
     static const bool n64_ok = !(getenv("DGNN_X3_N64") && getenv("DGNN_X3_N64")[0] == '0');
     if (n64_ok && n_out <= ZN) {
         hipLaunchKernelGGL(k_linear_fwd_x3_n64, dim3((unsigned)dgnn_cdiv(M, XM)), dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2, lda2, k2,
-                           W2, ldw2, v2, bias, scale, shift, relu, M, n_out, out, ldo);
+                           W2, ldw2, v2, bias, scale, shift, relu, M, n_out, out, ldo, colstats);
         return dgnn_check_launch("linear_fwd_x3");
     }
     dim3 grid((unsigned)(dgnn_cdiv(dgnn_cdiv(M, XM), 8) * 8 * dgnn_cdiv(n_out, XN)));
     hipLaunchKernelGGL(k_linear_fwd_x3, grid, dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2, lda2, k2, W2, ldw2, v2, bias,
-                       scale, shift, relu, M, n_out, out, ldo);
+                       scale, shift, relu, M, n_out, out, ldo, colstats);
     return dgnn_check_launch("linear_fwd_x3");
+}
+}  // namespace
+
+extern "C" int dgnn_linear_fwd_x3(const float* A1, int64_t lda1, int k1, const float* W1, int64_t ldw1, const float* A2, int64_t lda2, int k2,
+                                  const float* W2, int64_t ldw2, const float* bias, const float* scale, const float* shift, int relu,
+                                  int64_t M, int n_out, float* out, int64_t ldo, void* stream) {
+    return linear_fwd_x3_impl(A1, lda1, k1, W1, ldw1, A2, lda2, k2, W2, ldw2, bias, scale, shift, relu, M, n_out, out, ldo, nullptr, stream);
+}
+
+// dgnn_linear_fwd_x3 that also leaves the fp64 column sums and sums of squares of `out` per block of 32 rows in
+// colstats[ceil(M / 32)][2][n_out] (8-byte aligned) for dgnn_bn_stats_finalize_fold.  DGNN_E_UNSUPPORTED (nothing launched) for the
+// shapes that take the 256 x 256 tile (M >= 8192 and n_out > 128).
+extern "C" int dgnn_linear_fwd_x3_stats(const float* A1, int64_t lda1, int k1, const float* W1, int64_t ldw1, const float* A2, int64_t lda2, int k2,
+                                        const float* W2, int64_t ldw2, const float* bias, int64_t M, int n_out, float* out, int64_t ldo,
+                                        double* colstats, void* stream) {
+    DGNN_REQUIRE(colstats && ((uintptr_t)colstats & 7) == 0, DGNN_E_INVALID, "linear_fwd_x3_stats: colstats missing or unaligned");
+    return linear_fwd_x3_impl(A1, lda1, k1, W1, ldw1, A2, lda2, k2, W2, ldw2, bias, nullptr, nullptr, 0, M, n_out, out, ldo, colstats, stream);
 }
 
 extern "C" int64_t dgnn_linear_fwd_x2h_scratch_elems(int64_t M, int n_out) { return M + n_out; }

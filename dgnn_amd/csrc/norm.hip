@@ -265,7 +265,8 @@ int red_blocks(int64_t M) {
 // scratch (floats): partials as doubles [blocks][2][c] -> 4*blocks*c floats, + 2*c floats of sums
 extern "C" int64_t dgnn_colstats_scratch_elems(int64_t M, int c) {
     if (c <= 0) return 2;
-    return (int64_t)red_blocks(M < 0 ? 0 : M) * 4 * c + 2 * c + 2;
+    const int64_t own = red_blocks(M < 0 ? 0 : M), gemm = M > 0 ? (M + 31) / 32 : 0;   // partial rows of the reducing kernels | of a GEMM's epilogue
+    return (own > gemm ? own : gemm) * 4 * c + 2 * c + 2;
 }
 
 static double* as_f64(float* scratch) { return reinterpret_cast<double*>(((uintptr_t)scratch + 7) & ~(uintptr_t)7); }
@@ -353,6 +354,17 @@ extern "C" int dgnn_bn_batch_stats_fold(const float* x, int64_t ldx, int64_t M, 
                                         float* shift, float* scratch, void* stream) {
     DGNN_REQUIRE(scale && shift, DGNN_E_INVALID, "bn_batch_stats_fold: scale / shift missing");
     return bn_batch_stats_t<float>(x, ldx, M, c, mean, var, running_mean, running_var, momentum, scratch, (hipStream_t)stream, gamma, beta, eps, scale, shift);
+}
+// The finalising half of dgnn_bn_batch_stats_fold on partial sums that are already there: colstats[nblk][2][c] doubles (sums, sums of
+// squares per block of rows), as dgnn_linear_fwd_x3_stats leaves them with nblk = ceil(M / 32).
+extern "C" int dgnn_bn_stats_finalize_fold(const double* colstats, int64_t nblk, int64_t M, int c, float* mean, float* var, float* running_mean,
+                                           float* running_var, float momentum, const float* gamma, const float* beta, float eps, float* scale,
+                                           float* shift, void* stream) {
+    DGNN_REQUIRE(colstats && nblk > 0 && M > 0 && c > 0 && mean && var, DGNN_E_INVALID, "bn_stats_finalize_fold: bad arguments");
+    DGNN_REQUIRE((scale == nullptr) == (shift == nullptr), DGNN_E_INVALID, "bn_stats_finalize_fold: scale / shift must come together");
+    hipLaunchKernelGGL(k_stats_finalize, dim3((c + 15) / 16), dim3(FIN_THREADS), 0, (hipStream_t)stream, colstats, (int)nblk, M, c, mean, var, running_mean,
+                       running_var, momentum, gamma, beta, eps, scale, shift);
+    return dgnn_check_launch("bn_stats_finalize_fold");
 }
 extern "C" int dgnn_bn_batch_stats_bf16(const uint16_t* x, int64_t ldx, int64_t M, int c, float* mean, float* var,
                                         float* running_mean, float* running_var, float momentum, float* scratch, void* stream) {

@@ -64,16 +64,20 @@ __global__ void k_transpose_many(TrJobs jobs) {
 // input-gradient GEMM).  Default: dWj / dWi / dbj from one launch pair (dgnn_linear_wgrad_x3_cat), da and dz.Wi from one GEMM against
 // the stacked [Wj^T ; Wi^T], the latter added where the aggregate backward stores dx (dgnn_sage_aggregate_bwd_add), all transposes of a
 // backward pass in one launch.  Same arithmetic per element; only dbj is summed in another (fp64) order.
-int g_fused_on = -1;
-bool fused_enabled() {
+int g_fused_on = -1;   // bit 0: the backward chain, bit 1: batch statistics from the forward GEMM's epilogue
+int fused_mask() {
     int v = __atomic_load_n(&g_fused_on, __ATOMIC_ACQUIRE);
     if (v < 0) {
-        v = (getenv("DGNN_TRAIN_FUSED") && getenv("DGNN_TRAIN_FUSED")[0] == '0') ? 0 : 1;
-        if (getenv("DGNN_AGG_CHUNKED") && getenv("DGNN_AGG_CHUNKED")[0] == '0') v = 0;   // the addend form lives in the chunked kernel
+        const char* e = getenv("DGNN_TRAIN_FUSED");
+        v = e ? atoi(e) & 3 : 3;
+        if (e && e[0] == '1' && e[1] == 0) v = 3;
+        if (getenv("DGNN_AGG_CHUNKED") && getenv("DGNN_AGG_CHUNKED")[0] == '0') v &= ~1;   // the addend form lives in the chunked kernel
         __atomic_store_n(&g_fused_on, v, __ATOMIC_RELEASE);
     }
-    return v != 0;
+    return v;
 }
+bool fused_enabled() { return (fused_mask() & 1) != 0; }
+bool fused_stats_enabled() { return (fused_mask() & 2) != 0; }
 
 }  // namespace
 
@@ -113,6 +117,18 @@ extern "C" int dgnn_sage_layer_train_fwd(const int32_t* rowptr, const int32_t* s
         lda1 = c_in;
     }
     const float* A2 = (rowptr && Wi) ? x : nullptr;   // x_dst = x[:n_dst] (reference :217)
+    if (gemm_mode != DGNN_GEMM_F32 && fused_stats_enabled()) {
+        // the GEMM's epilogue leaves the column sums of z per block of 32 rows: no launch that reads z back for the batch statistics
+        double* cs = reinterpret_cast<double*>(((uintptr_t)scratch + 7) & ~(uintptr_t)7);
+        const int rc = dgnn_linear_fwd_x3_stats(A1, lda1, c_in, Wj, c_in, A2, ldx, A2 ? c_in : 0, A2 ? Wi : nullptr, c_in, bj, n_dst, c_out, z, c_out, cs, stream);
+        if (rc == DGNN_OK) {
+            TRY(dgnn_bn_stats_finalize_fold(cs, (n_dst + 31) / 32, n_dst, c_out, mean, var, running_mean, running_var, momentum, gamma, beta, eps, scale, shift,
+                                            stream));
+            TRY(dgnn_scale_shift_act(z, c_out, scale, shift, relu, n_dst, c_out, y, c_out, stream));
+            return DGNN_OK;
+        }
+        if (rc != DGNN_E_UNSUPPORTED) return rc;
+    }
     if (gemm_mode == DGNN_GEMM_F32)
         TRY(dgnn_linear_fwd(A1, lda1, c_in, Wj, c_in, A2, ldx, A2 ? c_in : 0, A2 ? Wi : nullptr, c_in, bj, nullptr, nullptr, 0, n_dst, c_out, z, c_out,
                             stream));
@@ -183,8 +199,8 @@ int64_t layer_tmp_elems(int64_t n_src, int64_t n_dst, int c_in, int c_out, int f
 int layer_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, const int32_t* rowptr_dst, int64_t n_src, int64_t n_dst, const float* x,
               int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e, const float* We, const float* be, const float* Wj, const float* Wi, int c_out,
               const float* gamma, const float* mean, const float* var, float eps, int relu, const float* a, const float* z, const float* y, const float* dy,
-              float* dx, float* dWe, float* dbe, float* dWj, float* dbj, float* dWi, float* dgamma, float* dbeta, float* dz, float* da, float* WjT, float* WiT,
-              float* tmp, float* tmp_w, int gemm_mode, hipStream_t stream, Aux* aux, hipEvent_t* done, bool pre_t = false) {
+              float* dx, float* dWe, float* dbe, float* dWj, float* dbj, float* dWi, float* dgamma, float* dbeta, float* dz_buf, float* da, float* WjT, float* WiT,
+              float* tmp, float* tmp_w, int gemm_mode, hipStream_t stream, Aux* aux, hipEvent_t* done, bool pre_t = false, bool has_bn = true) {
     void* stream_ = (void*)stream;
     const bool agg = t_rowptr != nullptr;
     const bool x3 = gemm_mode != DGNN_GEMM_F32;
@@ -201,7 +217,9 @@ int layer_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
                   : dgnn_linear_wgrad(A, lda, na, B, ldb, nb, n_dst, dW, nb, 0, wtmp, wstream);
     };
     // BatchNorm (batch statistics) + ReLU backward: dz, dgamma, dbeta
-    TRY(dgnn_bn_relu_bwd(z, c_out, y, c_out, dy, c_out, gamma, mean, var, eps, 1, relu, n_dst, c_out, dz, c_out, dgamma, dbeta, tmp, stream_));
+    // (has_bn == false: a plain Linear -- the decoder's output layer -- whose dz is dy itself)
+    if (has_bn) TRY(dgnn_bn_relu_bwd(z, c_out, y, c_out, dy, c_out, gamma, mean, var, eps, 1, relu, n_dst, c_out, dz_buf, c_out, dgamma, dbeta, tmp, stream_));
+    const float* const dz = has_bn ? dz_buf : dy;
     if (aux) {
         hipEvent_t e = next_event(aux);
         (void)hipEventRecord(e, stream);
@@ -488,6 +506,16 @@ extern "C" int dgnn_static_train_fwd(int n_layers, const int32_t* const* rowptr,
     for (int l = 0; l < n_layers; ++l) {
         const int c_in = widths[l], c_out = widths[l + 1];
         float* st = stats[l];
+        if (!st) {   // a plain Linear (the decoder's output layer, :187): y = x . Wj^T + bj, no BatchNorm, no ReLU
+            DGNN_REQUIRE(!rowptr[l] && Wj[l] && y[l], DGNN_E_INVALID, "static_train_fwd: a layer without statistics is a plain Linear");
+            if (gemm_mode == DGNN_GEMM_F32)
+                TRY(dgnn_linear_fwd(x, ldx, c_in, Wj[l], c_in, nullptr, 0, 0, nullptr, 0, bj[l], nullptr, nullptr, 0, n_dst[l], c_out, y[l], c_out, stream));
+            else
+                TRY(dgnn_linear_fwd_x3(x, ldx, c_in, Wj[l], c_in, nullptr, 0, 0, nullptr, 0, bj[l], nullptr, nullptr, 0, n_dst[l], c_out, y[l], c_out, stream));
+            x = y[l];
+            ldx = c_out;
+            continue;
+        }
         TRY(dgnn_sage_layer_train_fwd(rowptr[l], src[l], eid[l], n_dst[l], x, ldx, c_in, edge_attr[l], lde[l], We[l] ? f_e : 0, We[l], be[l], Wj[l], bj[l],
                                       Wi[l], c_out, gamma[l], beta[l], running_mean[l], running_var[l], momentum[l], eps[l], 1, a[l], z[l], st, st + c_out,
                                       st + 2 * c_out, st + 3 * c_out, y[l], scratch, gemm_mode, stream));
@@ -601,14 +629,24 @@ extern "C" int dgnn_static_train_bwd(int n_layers, const int32_t* const* t_rowpt
         if (aux && l + 2 < n_layers && done[l + 2]) (void)hipStreamWaitEvent(stream, done[l + 2], 0);   // dz[l & 1] is still read by layer l+2's weight gradients
         float* WjT = wt + (pre_t ? lay.wt_off[l] : 0);
         rc = layer_bwd(t_rowptr[l], t_dst[l], t_eid[l], rowptr_dst[l], n_src[l], n_dst[l], x, ldx, c_in, edge_attr[l], lde[l], We[l] ? f_e : 0, We[l], be[l], Wj[l],
-                       Wi[l], c_out, gamma[l], st, st + c_out, eps[l], 1, a[l], z[l], y[l], g, dx, dWe[l], dbe[l], dWj[l], dbj[l], dWi[l], dgamma[l], dbeta[l],
-                       dzb[l & 1], da, WjT, WjT + (int64_t)c_in * c_out, tmp, tmp_w, gemm_mode, stream, aux, aux ? &done[l] : nullptr, pre_t);
+                       Wi[l], c_out, gamma[l], st, st ? st + c_out : nullptr, eps[l], 1, a[l], z[l], y[l], g, dx, dWe[l], dbe[l], dWj[l], dbj[l], dWi[l], dgamma[l],
+                       dbeta[l], dzb[l & 1], da, WjT, WjT + (int64_t)c_in * c_out, tmp, tmp_w, gemm_mode, stream, aux, aux ? &done[l] : nullptr, pre_t, st != nullptr);
         g = dx;
     }
     if (aux)   // the gradients are consumed on `stream` (optimizer step): join.  In-order on the second stream: the last event covers all.
         for (int l = 0; l < n_layers; ++l)
             if (done[l]) (void)hipStreamWaitEvent(stream, done[l], 0);
     return rc;
+}
+
+// Which of the training step's fused launch chains run (bit 0: backward chain, bit 1: batch statistics from the forward GEMM's epilogue;
+// default 3, DGNN_TRAIN_FUSED in the environment).  Returns the previous mask.
+extern "C" int dgnn_train_set_fused(int mask) {
+    const int was = fused_mask();
+    int v = mask & 3;
+    if (getenv("DGNN_AGG_CHUNKED") && getenv("DGNN_AGG_CHUNKED")[0] == '0') v &= ~1;
+    __atomic_store_n(&g_fused_on, v, __ATOMIC_RELEASE);
+    return was;
 }
 
 // Whether the composite backward entry points run the weight gradients on the library's second stream (default: no).

@@ -218,12 +218,12 @@ class _StaticTrainModel(torch.autograd.Function):
 
 
 def static_train_model(x0, spec):
-    """spec: per layer dict(plan | None, n_rows (plain block), edge_attr, scene_rows, lin_e | None, lin_j, lin_i | None, bn)"""
+    """spec: per layer dict(plan | None, n_rows (plain block), edge_attr, scene_rows, lin_e | None, lin_j, lin_i | None, bn | None)"""
     params = []
     for sp in spec:
         le, lj, li, bn = sp["lin_e"], sp["lin_j"], sp["lin_i"], sp["bn"]
         params += [le.weight if le is not None else None, le.bias if le is not None else None, lj.weight, lj.bias, li.weight if li is not None else None,
-                   bn.weight, bn.bias]
+                   bn.weight if bn is not None else None, bn.bias if bn is not None else None]   # bn None: a plain Linear (decoder output)
     return _StaticTrainModel.apply(x0, spec, *params)
 
 

@@ -179,11 +179,20 @@ class Trainer:
                 loss = loss + self.calcRegularization(logits_cell, data, clf, metrics)
         return loss
 
+    def _all_training(self):
+        """model.train() (reference :266) writes the flag of ~40 modules through nn.Module.__setattr__ on every step; when every flag is
+        already set it has nothing to do -- reading them costs a fifth of that."""
+        for m in self.model.modules():
+            if not m.training:
+                return False
+        return True
+
     def train(self, data_train, optimizer, clf, group=None):
         """One optimisation step on one sampled batch, reference :264-282.  `group`: data-parallel replicas (one scene shard
         per rank): the flat gradient is all-reduced (mean) between backward() and step(); None + an initialised default
         process group of size > 1 uses that group, a single process changes nothing."""
-        self.model.train()
+        if not self._all_training():
+            self.model.train()
         logits_cell = self.model(data_train)
         n_sup = data_train.batch_adjs[self.model.num_layers - 1].size[1] if hasattr(data_train.batch_adjs[0], "size") \
             else data_train.batch_adjs[self.model.num_layers - 1][2][1]

@@ -231,7 +231,7 @@ class SurfaceNet(nn.Module):
         entry points: fp32 rows, lin_e a Linear over <= 32 attributes, BatchNorm in training mode after every conv and inside the
         decoder.  Returns the logits, or None (the per-layer path then runs)."""
         from .. import ops
-        if not (ops.TRAIN_COMPOSITE and ops.TRAIN_WHOLE_MODEL) or x.dtype != torch.float32 or self.num_layers + 1 > 8:
+        if not (ops.TRAIN_COMPOSITE and ops.TRAIN_WHOLE_MODEL) or x.dtype != torch.float32 or self.num_layers + 2 > 8:
             return None
         dec = self.decoder if self.clf.model.decoder else ()
         if len(dec) not in (0, 4) or (len(dec) == 4 and not isinstance(dec[1], BatchNorm)):
@@ -256,6 +256,10 @@ class SurfaceNet(nn.Module):
             if not dec[1].module.training or dec[1].module.momentum is None:
                 return None
             spec.append(dict(plan=None, n_rows=n_src, edge_attr=None, scene_rows=False, lin_e=None, lin_j=dec[0], lin_i=None, bn=dec[1].module))
+            if ops.TRAIN_DECODER_OUTPUT_IN_CALL and isinstance(dec[3], torch.nn.Linear) and dec[3].bias is not None:
+                # the decoder's output Linear rides in the same two library calls (a layer without BatchNorm / ReLU)
+                spec.append(dict(plan=None, n_rows=n_src, edge_attr=None, scene_rows=False, lin_e=None, lin_j=dec[3], lin_i=None, bn=None))
+                return Fn.static_train_model(x, spec)
         h = Fn.static_train_model(x, spec)
         if len(dec) == 4:
             h = Fn.linear2(h, dec[3].weight, bias=dec[3].bias, out_f32=True)

@@ -271,6 +271,29 @@ def linear_wgrad(A, B):
 
 
 @on_device_of
+def linear_fwd_with_batch_stats(A1, W1, A2=None, W2=None, bias=None, gamma=None, beta=None, eps=1e-5):
+    """z = A1 . W1^T + A2 . W2^T + bias and the BatchNorm batch statistics of z from the GEMM's own epilogue (dgnn_linear_fwd_x3_stats +
+    dgnn_bn_stats_finalize_fold) -> (z, mean, var, scale, shift), or None where the GEMM takes the tile without that epilogue."""
+    _req(A1, "A1", dim=2)
+    M, n_out = A1.size(0), W1.size(0)
+    z = torch.empty((M, n_out), dtype=torch.float32, device=A1.device)
+    scratch = _f32(lib().dgnn_colstats_scratch_elems(M, n_out) + 2, A1.device)
+    cs = (scratch.data_ptr() + 7) & ~7
+    W1 = W1.contiguous()
+    W2 = W2.contiguous() if W2 is not None else None
+    rc = lib().dgnn_linear_fwd_x3_stats(ptr(A1), _ld(A1), A1.size(1), ptr(W1), W1.size(1), ptr(A2), _ld(A2) if A2 is not None else 0,
+                                        A2.size(1) if A2 is not None else 0, ptr(W2), W2.size(1) if W2 is not None else 0, ptr(bias), M, n_out, ptr(z), n_out,
+                                        cs, stream_ptr())
+    if rc == DGNN_E_UNSUPPORTED:
+        return None
+    check(rc, "dgnn_linear_fwd_x3_stats")
+    st = torch.empty((4, n_out), dtype=torch.float32, device=A1.device)
+    check(lib().dgnn_bn_stats_finalize_fold(cs, (M + 31) // 32, M, n_out, ptr(st[0]), ptr(st[1]), None, None, 0.0, ptr(gamma), ptr(beta), eps, ptr(st[2]),
+                                            ptr(st[3]), stream_ptr()), "dgnn_bn_stats_finalize_fold")
+    return z, st[0], st[1], st[2], st[3]
+
+
+@on_device_of
 def linear_wgrad_cat(A, B1, B2=None, bias=True):
     """(dW1 = A^T . B1, dW2 = A^T . B2 | None, column sums of A | None) from one launch pair (dgnn_linear_wgrad_x3_cat; fp32, x3 arithmetic)"""
     _req(A, "A", dim=2)
@@ -585,6 +608,7 @@ def decoder_fused_fwd_bf16(y, W0, b0, scale, shift, W3, b3):
 # ---- training-mode conv layer, one call each way (csrc/train.hip) -----------------------------------------------------------
 TRAIN_COMPOSITE = __import__("os").environ.get("DGNN_TRAIN_COMPOSITE", "1") != "0"
 TRAIN_WHOLE_MODEL = __import__("os").environ.get("DGNN_TRAIN_WHOLE_MODEL", "1") != "0"   # Static fp32: all layers in one call each way
+TRAIN_DECODER_OUTPUT_IN_CALL = __import__("os").environ.get("DGNN_TRAIN_DECODER_IN_CALL", "1") != "0"   # ... the decoder's output Linear too
 
 
 @on_device_of
@@ -784,14 +808,18 @@ def static_train_fwd(x0, layers):
             raise ValueError("layer %d: lin_j %s does not take %d channels" % (i, tuple(l["Wj"].shape), ci))
         m = dict(a=off if l["plan_parts"] is not None else None)
         off += n * ci if l["plan_parts"] is not None else 0
-        m["z"], off = off, off + n * co
-        m["y"], off = off, off + n * co
-        m["stats"], off = off, off + 4 * co
+        if l["bn"] is None:      # a plain Linear (the decoder's output layer): y only
+            m["z"] = m["stats"] = None
+            m["y"], off = off, off + n * co
+        else:
+            m["z"], off = off, off + n * co
+            m["y"], off = off, off + n * co
+            m["stats"], off = off, off + 4 * co
         meta.append(m)
     buf = _f32_work(off, dev)
     base = buf.data_ptr()
     at = lambda o: None if o is None else base + 4 * o
-    scratch = _f32_work(max(lib().dgnn_colstats_scratch_elems(l["n_dst"], widths[i + 1]) for i, l in enumerate(layers)), dev)
+    scratch = _f32_work(max(lib().dgnn_colstats_scratch_elems(l["n_dst"], widths[i + 1]) for i, l in enumerate(layers)) + 2, dev)
     pp = lambda k: _parr([(l["plan_parts"][k] if l["plan_parts"] is not None else None) for l in layers])
     key = lambda k: _parr([l[k] for l in layers])
     f_e = max([l["We"].size(1) for l in layers if l["We"] is not None] or [0])
@@ -799,9 +827,11 @@ def static_train_fwd(x0, layers):
         L, pp(0), pp(1), pp(2), _iarr([l["n_dst"] for l in layers], C.c_int64), ptr(x0), _ld(x0), _iarr(widths, C.c_int32),
         key("edge_attr"), _iarr([(_ld(l["edge_attr"]) if l["edge_attr"] is not None else 0) for l in layers], C.c_int64), f_e,
         key("We"), key("be"), key("Wj"), key("bj"), key("Wi"), key("gamma"), key("beta"),
-        _parr([l["bn"].running_mean for l in layers]), _parr([l["bn"].running_var for l in layers]),
-        _parr([(l["bn"].num_batches_tracked if l["bn"].track_running_stats else None) for l in layers]),
-        _iarr([l["bn"].momentum for l in layers], C.c_float), _iarr([l["bn"].eps for l in layers], C.c_float),
+        _parr([(l["bn"].running_mean if l["bn"] is not None else None) for l in layers]),
+        _parr([(l["bn"].running_var if l["bn"] is not None else None) for l in layers]),
+        _parr([(l["bn"].num_batches_tracked if l["bn"] is not None and l["bn"].track_running_stats else None) for l in layers]),
+        _iarr([(l["bn"].momentum if l["bn"] is not None else 0.0) for l in layers], C.c_float),
+        _iarr([(l["bn"].eps if l["bn"] is not None else 0.0) for l in layers], C.c_float),
         _parr([at(m["a"]) for m in meta]), _parr([at(m["z"]) for m in meta]), _parr([at(m["stats"]) for m in meta]), _parr([at(m["y"]) for m in meta]),
         ptr(scratch), GEMM_MODE, stream_ptr()), "dgnn_static_train_fwd")
     n, co = layers[-1]["n_dst"], widths[-1]
@@ -822,7 +852,8 @@ def static_train_bwd(x0, layers, buf, meta_widths, dy):
         ci, co = widths[i], widths[i + 1]
         fe = l["We"].size(1) if l["We"] is not None else 0
         row = []
-        for sz in (ci * fe, ci if fe else 0, co * ci, co if l["bj"] is not None else 0, co * ci if l["Wi"] is not None else 0, co, co):
+        nbn = co if l["bn"] is not None else 0
+        for sz in (ci * fe, ci if fe else 0, co * ci, co if l["bj"] is not None else 0, co * ci if l["Wi"] is not None else 0, nbn, nbn):
             row.append((off, sz) if sz else None)
             off += sz
         sizes.append(row)
@@ -843,7 +874,8 @@ def static_train_bwd(x0, layers, buf, meta_widths, dy):
         L, tp(0), tp(1), tp(2), _parr([(l["plan_parts"][0] if l["plan_parts"] is not None else None) for l in layers]), _iarr(n_src, C.c_int64),
         _iarr([l["n_dst"] for l in layers], C.c_int64), ptr(x0), _ld(x0), _iarr(widths, C.c_int32), key("edge_attr"),
         _iarr([(_ld(l["edge_attr"]) if l["edge_attr"] is not None else 0) for l in layers], C.c_int64), f_e, key("We"), key("be"), key("Wj"), key("Wi"),
-        key("gamma"), _parr([at(m["stats"]) for m in meta]), _iarr([l["bn"].eps for l in layers], C.c_float), _parr([at(m["a"]) for m in meta]),
+        key("gamma"), _parr([at(m["stats"]) for m in meta]), _iarr([(l["bn"].eps if l["bn"] is not None else 0.0) for l in layers], C.c_float),
+        _parr([at(m["a"]) for m in meta]),
         _parr([at(m["z"]) for m in meta]), _parr([at(m["y"]) for m in meta]), ptr(dy), col(0), col(1), col(2), col(3), col(4), col(5), col(6),
         _parr([dxb[0], dxb[1]]), ptr(scratch), GEMM_MODE, stream_ptr()), "dgnn_static_train_bwd")
     grads = []
@@ -851,5 +883,6 @@ def static_train_bwd(x0, layers, buf, meta_widths, dy):
         ci, co = widths[i], widths[i + 1]
         fe = l["We"].size(1) if l["We"] is not None else 0
         v = lambda e, *shape: None if e is None else flat[e[0]:e[0] + e[1]].view(*shape)
-        grads.append((v(row[0], ci, fe) if fe else None, v(row[1], ci) if fe else None, v(row[2], co, ci), v(row[3], co), v(row[4], co, ci), v(row[5], co), v(row[6], co)))
+        grads.append((v(row[0], ci, fe) if fe else None, v(row[1], ci) if fe else None, v(row[2], co, ci), v(row[3], co), v(row[4], co, ci),
+                      v(row[5], co), v(row[6], co)))
     return grads

@@ -151,6 +151,18 @@ int dgnn_linear_fwd_x2hp(const float* A1, int64_t lda1, int k1, const float* W1,
 int dgnn_linear_wgrad_x3(const float* A, int64_t lda, int n_a, const float* B, int64_t ldb, int n_b, int64_t M, float* dW, int64_t lddw,
                          int accumulate, float* partials, void* stream);
 
+/* Training forward of `lin_j(a) + lin_i(x_dst)` with the BatchNorm that follows (:217-218): dgnn_linear_fwd_x3 (no scale / shift / relu) whose
+ * epilogue also leaves the fp64 column sums and sums of squares of `out` per block of 32 rows in colstats[ceil(M / 32)][2][n_out]
+ * (8-byte aligned; dgnn_colstats_scratch_elems floats hold it); dgnn_bn_stats_finalize_fold turns them into mean / var / running
+ * statistics / folded scale and shift like dgnn_bn_batch_stats_fold does from its own partial sums.  DGNN_E_UNSUPPORTED (nothing
+ * launched) where the GEMM takes its 256 x 256 tile (M >= 8192 and n_out > 128). */
+int dgnn_linear_fwd_x3_stats(const float* A1, int64_t lda1, int k1, const float* W1, int64_t ldw1, const float* A2, int64_t lda2, int k2,
+                             const float* W2, int64_t ldw2, const float* bias, int64_t M, int n_out, float* out, int64_t ldo,
+                             double* colstats, void* stream);
+int dgnn_bn_stats_finalize_fold(const double* colstats, int64_t nblk, int64_t M, int c, float* mean, float* var, float* running_mean,
+                                float* running_var, float momentum, const float* gamma, const float* beta, float eps, float* scale,
+                                float* shift, void* stream);
+
 /* Both weight gradients of a conv layer and its bias gradient in one launch pair (autograd of :81-86 for lin_j, lin_i and lin_j.bias):
  * dW1[n_a, n_b1] = A^T . B1, dW2[n_a, n_b2] = A^T . B2 (B2 NULL / n_b2 0: none), dbias[n_a] = column sums of A (NULL: none), all
  * WRITTEN, contiguous.  dW1 / dW2 are bit-identical to two dgnn_linear_wgrad_x3 calls (same row splits, same products); dbias is summed
@@ -373,6 +385,11 @@ int dgnn_static_train_fwd(int n_layers, const int32_t* const* rowptr, const int3
  * weight gradients on the library's second stream (default 0 -- measured 2-8 % slower than one stream at the reference's block sizes;
  * environment DGNN_TRAIN_AUX_STREAM=1 starts with 1).  Returns the previous setting.  Results do not depend on it. */
 int dgnn_train_set_aux_stream(int on);
+/* The training step's fused launch chains: bit 0 = backward (dgnn_linear_wgrad_x3_cat, the stacked input-gradient GEMM with
+ * dgnn_sage_aggregate_bwd_add, one transpose launch per pass), bit 1 = BatchNorm statistics from the forward GEMM's epilogue
+ * (dgnn_linear_fwd_x3_stats).  Default 3 (environment: DGNN_TRAIN_FUSED=<mask>); 0 = the launch chain of the separate entry points.
+ * Returns the previous mask. */
+int dgnn_train_set_fused(int mask);
 int64_t dgnn_static_train_scratch_elems(int n_layers, const int64_t* n_src, const int64_t* n_dst, const int32_t* widths, int f_e);
 int dgnn_static_train_bwd(int n_layers, const int32_t* const* t_rowptr, const int32_t* const* t_dst, const int32_t* const* t_eid,
                           const int32_t* const* rowptr_dst, const int64_t* n_src, const int64_t* n_dst, const float* x0, int64_t ldx0,

@@ -205,6 +205,39 @@ def test_merged_weight_gradient_launch_matches_the_separate_calls(M, na, nb1, nb
     assert none is None and torch.equal(dW1b, dW1)
 
 
+@pytest.mark.parametrize("M,k1,k2,n_out", [(70001, 28, 28, 64), (30011, 64, 64, 128), (10007, 128, 128, 128), (2048, 128, 0, 64), (33, 128, 128, 128),
+                                          (31, 64, 0, 2), (20000, 64, 64, 256)])
+def test_batch_statistics_from_the_gemm_epilogue(M, k1, k2, n_out):
+    """dgnn_linear_fwd_x3_stats: z bit for bit dgnn_linear_fwd_x3's; mean / var / folded scale and shift equal to what dgnn_bn_batch_stats_fold
+    derives from z (both sum in fp64; the orders differ, so a last-bit difference is possible at an exact rounding tie and tolerated)."""
+    from dgnn_amd import ops
+    from dgnn_amd._lib import lib
+    if ops.GEMM_MODE == ops.GEMM_F32:
+        pytest.skip("x3 arithmetic only")
+    g = torch.Generator().manual_seed(M)
+    A1, W1 = (torch.randn(M, k1, generator=g) * 2 + 0.3).to(DEV), torch.randn(n_out, k1, generator=g).to(DEV)
+    A2 = torch.randn(M, k2, generator=g).to(DEV) if k2 else None
+    W2 = torch.randn(n_out, k2, generator=g).to(DEV) if k2 else None
+    bias, gamma, beta = torch.randn(n_out, generator=g).to(DEV), (torch.rand(n_out, generator=g) + 0.5).to(DEV), torch.randn(n_out, generator=g).to(DEV)
+    got = ops.linear_fwd_with_batch_stats(A1, W1, A2, W2, bias, gamma, beta)
+    if M >= 8192 and n_out > 128:
+        assert got is None
+        return
+    z, mean, var, scale, shift = got
+    z_ref = torch.empty_like(z)
+    ops.check(lib().dgnn_linear_fwd_x3(ops.ptr(A1), k1, k1, ops.ptr(W1), k1, ops.ptr(A2), k2, k2, ops.ptr(W2), k2, ops.ptr(bias), None, None, 0, M, n_out,
+                                       ops.ptr(z_ref), n_out, ops.stream_ptr()), "dgnn_linear_fwd_x3")
+    assert torch.equal(z, z_ref)
+    st = torch.empty(4, n_out, device=DEV)
+    scratch = torch.empty(int(lib().dgnn_colstats_scratch_elems(M, n_out)), device=DEV)
+    ops.check(lib().dgnn_bn_batch_stats_fold(ops.ptr(z_ref), n_out, M, n_out, ops.ptr(st[0]), ops.ptr(st[1]), None, None, 0.0, ops.ptr(gamma), ops.ptr(beta), 1e-5,
+                                             ops.ptr(st[2]), ops.ptr(st[3]), ops.ptr(scratch), ops.stream_ptr()), "dgnn_bn_batch_stats_fold")
+    for a, b in zip((mean, var, scale, shift), st):
+        assert (a - b).abs().max().item() <= 2.4e-7 * b.abs().max().item()
+    zd = z_ref.double()
+    assert (mean.double() - zd.mean(0)).abs().max().item() < 1e-5 and (var.double() - zd.var(0, unbiased=False)).abs().max().item() < 1e-4 * zd.var(0).max().item()
+
+
 @pytest.mark.parametrize("c_in,n_src,n_dst", [(64, 900, 600), (128, 5000, 1777), (28, 333, 333), (128, 40, 7)])
 def test_aggregate_backward_with_addend_matches_the_two_steps(c_in, n_src, n_dst):
     """dgnn_sage_aggregate_bwd_add: dx = aggregate backward, then dx[:n_add] += add in one fp32 addition per element -- bit for bit; dWe / dbe

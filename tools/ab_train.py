@@ -2,7 +2,8 @@
 alternate between the settings, the median segment time per setting is reported.
     python tools/ab_train.py whole=1 whole=0 composite=0     all layers in one call | one call per layer | separate Functions
     python tools/ab_train.py aux=0 aux=1                      weight gradients on the second stream
-Every setting starts from the defaults (composite=1, whole=1, aux=0); several flags: "whole=0,aux=1"."""
+    python tools/ab_train.py fused=3 fused=1 fused=0          fused launch chains (bit 0 backward, bit 1 forward statistics)
+Every setting starts from the defaults (composite=1, whole=1, aux=0, fused=3); several flags: "whole=0,aux=1"."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -44,11 +45,13 @@ def apply(s):
     from dgnn_amd._lib import lib
     ops.TRAIN_COMPOSITE, ops.TRAIN_WHOLE_MODEL = True, True
     lib().dgnn_train_set_aux_stream(0)
+    lib().dgnn_train_set_fused(3)
     for part in s.split(","):
         k, v = part.split("=")
         if k == "whole": ops.TRAIN_WHOLE_MODEL = v == "1"
         elif k == "composite": ops.TRAIN_COMPOSITE = v == "1"
         elif k == "aux": lib().dgnn_train_set_aux_stream(int(v))
+        elif k == "fused": lib().dgnn_train_set_fused(int(v))     # bit 0: backward chain, bit 1: statistics from the GEMM epilogue
         else: raise SystemExit("unknown setting " + s)
 def seg(nsteps):
     torch.cuda.synchronize(); t0 = time.perf_counter()
