@@ -1346,6 +1346,39 @@ __global__ void __launch_bounds__(256) k_linear_wgrad_x3(const float* __restrict
     }
 }
 
+// stage_t_x3 in two halves, so that the next row slice's values travel while the matrix instructions of the current one run
+__device__ __forceinline__ void load_t_x3(float (&va)[4], float (&vb)[4], const float* __restrict__ src, int64_t ld, bool vec, int64_t r0, int64_t r_end,
+                                          int c0, int nc) {
+    const int t = threadIdx.x, tp = t >> 4, tc = (t & 15) * 4;
+    const int64_t ra = r0 + 2 * tp, rb = ra + 1;
+    if (vec && c0 + tc + 4 <= nc) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 a = ra < r_end ? *reinterpret_cast<const f32x4*>(src + ra * ld + c0 + tc) : z;
+        const f32x4 b = rb < r_end ? *reinterpret_cast<const f32x4*>(src + rb * ld + c0 + tc) : z;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) va[j] = a[j], vb[j] = b[j];
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int cc = c0 + tc + j;
+        va[j] = (ra < r_end && cc < nc) ? src[ra * ld + cc] : 0.f;
+        vb[j] = (rb < r_end && cc < nc) ? src[rb * ld + cc] : 0.f;
+    }
+}
+__device__ __forceinline__ void store_t_x3(char* __restrict__ dst, const float (&va)[4], const float (&vb)[4]) {
+    const int t = threadIdx.x, tp = t >> 4, tc = (t & 15) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t hh, mm, ll;
+        x3_split(va[j], vb[j], hh, mm, ll);
+        char* d = dst + (tc + j) * XLDT + tp * 4;
+        *reinterpret_cast<uint32_t*>(d) = hh;
+        *reinterpret_cast<uint32_t*>(d + 64) = mm;
+        *reinterpret_cast<uint32_t*>(d + 128) = ll;
+    }
+}
+
 // Both weight gradients of a conv layer and the bias gradient in one launch: dW1 = A^T B1, dW2 = A^T B2 (B2 optional), dbias = column
 // sums of A.  Block column y takes its 64 columns from B1 (y < nby1) or B2; every output element runs k_linear_wgrad_x3's loop on the
 // same row splits (bit-identical dW1 / dW2).  The bias sums ride on the staging of A in the blocks of column 0: every thread adds the
@@ -1371,26 +1404,32 @@ __global__ void __launch_bounds__(256) k_linear_wgrad_x3_cat(const float* __rest
     const int64_t r_end = min(M, r_beg + rows_per_split);
     const bool do_bias = bias_partials != nullptr && blockIdx.y == 0;
     const int t = threadIdx.x, tp = t >> 4, tc = (t & 15) * 4;
+    const bool vecA = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0), vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
     double bs[4] = {0.0, 0.0, 0.0, 0.0};
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float aa[4], ab[4], ba[4], bb[4];   // the slice in flight: rows r0 + 2 tp (.a) and + 1 (.b), columns tc .. tc + 3 of the A and B tiles
+    if (r_beg < r_end) {
+        load_t_x3(aa, ab, A, lda, vecA, r_beg, r_end, a0, na);
+        load_t_x3(ba, bb, B, ldb, vecB, r_beg, r_end, b0, nb);
+    }
     for (int64_t r0 = r_beg; r0 < r_end; r0 += XRK) {
         __syncthreads();
-        stage_t_x3(At, A, lda, r0, r_end, a0, na);
-        stage_t_x3(Bt, B, ldb, r0, r_end, b0, nb);
-        if (do_bias) {   // the values stage_t_x3 has just read (L1 hits): rows r0 + 2 tp, + 1, columns a0 + tc .. + 3
-            const int64_t ra = r0 + 2 * tp, rb = ra + 1;
+        store_t_x3(At, aa, ab);
+        store_t_x3(Bt, ba, bb);
+        if (do_bias) {   // rows beyond the split and columns beyond na arrive as zeros
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int cc = a0 + tc + j;
-                if (cc < na) {
-                    if (ra < r_end) bs[j] += (double)A[ra * lda + cc];
-                    if (rb < r_end) bs[j] += (double)A[rb * lda + cc];
-                }
+                bs[j] += (double)aa[j];
+                bs[j] += (double)ab[j];
             }
         }
         __syncthreads();
+        if (r0 + XRK < r_end) {   // in flight under the matrix instructions below
+            load_t_x3(aa, ab, A, lda, vecA, r0 + XRK, r_end, a0, na);
+            load_t_x3(ba, bb, B, ldb, vecB, r0 + XRK, r_end, b0, nb);
+        }
         const char* ap = At + (wa * 32 + l31) * XLDT + h * 16;
         const char* bp = Bt + (wb * 32 + l31) * XLDT + h * 16;
 #pragma unroll
@@ -1571,7 +1610,10 @@ int linear_fwd_x3_impl(const float* A1, int64_t lda1, int k1, const float* W1, i
     const bool v1 = vec_ok(A1, lda1) && vec_ok(W1, ldw1);
     const bool v2 = A2 && vec_ok(A2, lda2) && vec_ok(W2, ldw2);
     static const bool big_ok = !(getenv("DGNN_X3_BIG") && getenv("DGNN_X3_BIG")[0] == '0');
-    if (big_ok && M >= 8192 && n_out > XN) {   // same arithmetic per output element (chunk order, product order): identical results
+    // the 256 x 256 tile pays once its grid fills most of the chip (192 tiles; the merged input-gradient GEMM of a training block, M = 10k,
+    // n_out = 256, has 40: 42 us there against 29 us for the small tiles); same arithmetic per output element (chunk order, product
+    // order) in every variant: identical results
+    if (big_ok && M >= 8192 && n_out > XN && dgnn_cdiv(M, YM) * dgnn_cdiv(n_out, YN) >= 192) {
         if (colstats) return DGNN_E_UNSUPPORTED;   // the wide tile has no statistics epilogue: the caller reduces z in a launch of its own
         static bool attr_set[DGNN_MAX_DEVICES];
         constexpr size_t lds = (size_t)(YM + YN) * XLD;
@@ -1610,7 +1652,7 @@ extern "C" int dgnn_linear_fwd_x3(const float* A1, int64_t lda1, int k1, const f
 
 // dgnn_linear_fwd_x3 that also leaves the fp64 column sums and sums of squares of `out` per block of 32 rows in
 // colstats[ceil(M / 32)][2][n_out] (8-byte aligned) for dgnn_bn_stats_finalize_fold.  DGNN_E_UNSUPPORTED (nothing launched) for the
-// shapes that take the 256 x 256 tile (M >= 8192 and n_out > 128).
+// shapes that take the 256 x 256 tile (n_out > 128 and at least 192 such tiles).
 extern "C" int dgnn_linear_fwd_x3_stats(const float* A1, int64_t lda1, int k1, const float* W1, int64_t ldw1, const float* A2, int64_t lda2, int k2,
                                         const float* W2, int64_t ldw2, const float* bias, int64_t M, int n_out, float* out, int64_t ldo,
                                         double* colstats, void* stream) {

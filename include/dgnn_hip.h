@@ -155,7 +155,7 @@ int dgnn_linear_wgrad_x3(const float* A, int64_t lda, int n_a, const float* B, i
  * epilogue also leaves the fp64 column sums and sums of squares of `out` per block of 32 rows in colstats[ceil(M / 32)][2][n_out]
  * (8-byte aligned; dgnn_colstats_scratch_elems floats hold it); dgnn_bn_stats_finalize_fold turns them into mean / var / running
  * statistics / folded scale and shift like dgnn_bn_batch_stats_fold does from its own partial sums.  DGNN_E_UNSUPPORTED (nothing
- * launched) where the GEMM takes its 256 x 256 tile (M >= 8192 and n_out > 128). */
+ * launched) where the GEMM takes its 256 x 256 tile (n_out > 128 and at least 192 such tiles). */
 int dgnn_linear_fwd_x3_stats(const float* A1, int64_t lda1, int k1, const float* W1, int64_t ldw1, const float* A2, int64_t lda2, int k2,
                              const float* W2, int64_t ldw2, const float* bias, int64_t M, int n_out, float* out, int64_t ldo,
                              double* colstats, void* stream);

@@ -206,7 +206,7 @@ def test_merged_weight_gradient_launch_matches_the_separate_calls(M, na, nb1, nb
 
 
 @pytest.mark.parametrize("M,k1,k2,n_out", [(70001, 28, 28, 64), (30011, 64, 64, 128), (10007, 128, 128, 128), (2048, 128, 0, 64), (33, 128, 128, 128),
-                                          (31, 64, 0, 2), (20000, 64, 64, 256)])
+                                          (31, 64, 0, 2), (20000, 64, 64, 256), (50000, 64, 64, 256)])
 def test_batch_statistics_from_the_gemm_epilogue(M, k1, k2, n_out):
     """dgnn_linear_fwd_x3_stats: z bit for bit dgnn_linear_fwd_x3's; mean / var / folded scale and shift equal to what dgnn_bn_batch_stats_fold
     derives from z (both sum in fp64; the orders differ, so a last-bit difference is possible at an exact rounding tie and tolerated)."""
@@ -220,7 +220,7 @@ def test_batch_statistics_from_the_gemm_epilogue(M, k1, k2, n_out):
     W2 = torch.randn(n_out, k2, generator=g).to(DEV) if k2 else None
     bias, gamma, beta = torch.randn(n_out, generator=g).to(DEV), (torch.rand(n_out, generator=g) + 0.5).to(DEV), torch.randn(n_out, generator=g).to(DEV)
     got = ops.linear_fwd_with_batch_stats(A1, W1, A2, W2, bias, gamma, beta)
-    if M >= 8192 and n_out > 128:
+    if n_out > 128 and -(-M // 256) * -(-n_out // 256) >= 192:      # the 256 x 256 tile has no statistics epilogue
         assert got is None
         return
     z, mean, var, scale, shift = got
