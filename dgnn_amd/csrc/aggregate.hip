@@ -15,6 +15,7 @@
 // in plan order starting from 0, i.e. the order of torch_scatter's CPU scatter_add_ that the
 // reference runs (surfaceNetStaticEdgeFilters.py:80 -> aggr='mean').  Division is IEEE.
 #include "common.h"
+#include "reduce_common.h"
 
 namespace {
 
@@ -287,28 +288,9 @@ __global__ void __launch_bounds__(256) k_agg_bwd(const int32_t* __restrict__ t_r
 
 // out[chunk][i] = sum_b slabs[b][chunk][i] (written, not accumulated: callers need no zero fill); 16 outputs x 64 slices per block: slice s adds slabs s, s+64, ... in order,
 // the 64 slice sums are then added in slice order (deterministic, and not a 1024-long dependent chain per output).
-constexpr int RS_SLICES = 64;
-__global__ void __launch_bounds__(16 * RS_SLICES) k_reduce_slabs(const float* __restrict__ slabs, int nblocks, int nchunks, int per, int c_in,
-                                                                 int fe, int cpl, float* __restrict__ dWe, float* __restrict__ dbe) {
+__global__ void __launch_bounds__(16 * RS_SLICES) k_reduce_slabs(SlabReduceDesc d) {
     __shared__ float red[RS_SLICES][17];
-    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + o;
-    const bool live = i < nchunks * per;
-    const int chunk = live ? i / per : 0, r = live ? i - chunk * per : 0;
-    float p = 0.f;
-    if (live)
-        for (int b = sl; b < nblocks; b += RS_SLICES) p += slabs[((int64_t)b * nchunks + chunk) * per + r];
-    red[sl][o] = p;
-    __syncthreads();
-    if (sl != 0 || !live) return;
-    const int c = chunk * 64 * cpl + r / (fe + 1), f = r % (fe + 1);
-    if (c >= c_in) return;
-    float s = 0.f;
-    for (int k = 0; k < RS_SLICES; ++k) s += red[k][o];
-    if (f < fe)
-        dWe[(int64_t)c * fe + f] = s;
-    else
-        dbe[c] = s;
+    reduce_slabs_block(d, blockIdx.x, red);
 }
 
 // =====================================================================================================================
@@ -536,7 +518,7 @@ int agg_bwd_t(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
               const T* x_src, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e, const float* We, const float* be,
               const T* phi, int64_t ldphi, const T* da, int64_t ldda, T* dx_src, int64_t lddx, float* dWe, float* dbe, T* dphi_out,
               int64_t lddphi, float* partials, hipStream_t stream, const T* add = nullptr, int64_t ldadd = 0, int64_t n_add = 0,
-              bool reduce_slabs = true) {
+              SlabReduceDesc* deferred = nullptr) {
     DGNN_REQUIRE(n_src >= 0 && c_in > 0, DGNN_E_INVALID, "aggregate_bwd: bad sizes");
     if (n_src == 0) {   // nothing to sum: the parameter gradients are zero (they are written, not accumulated, otherwise)
         if (We && dWe && dbe) {
@@ -579,10 +561,13 @@ int agg_bwd_t(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
     else if (given) { if (v2) LAUNCH(2, 0); else LAUNCH(1, 0); }
     else { if (v2) LAUNCH(2, -1); else LAUNCH(1, -1); }
 #undef LAUNCH
-    if (fused && reduce_slabs) {
-        const int per = 64 * cpl * (f_e + 1);
-        hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)dgnn_cdiv((int64_t)chunks * per, 16)), dim3(16 * RS_SLICES), 0, stream, partials,
-                           nblocks, chunks, per, c_in, f_e, cpl, dWe, dbe);
+    if (fused) {
+        SlabReduceDesc d;
+        d.slabs = partials, d.nblocks = nblocks, d.nchunks = chunks, d.per = 64 * cpl * (f_e + 1), d.c_in = c_in, d.fe = f_e, d.cpl = cpl, d.dWe = dWe, d.dbe = dbe;
+        if (deferred)
+            *deferred = d;
+        else
+            hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)slab_reduce_blocks(d)), dim3(16 * RS_SLICES), 0, stream, d);
     }
     return dgnn_check_launch("aggregate_bwd");
 }
@@ -642,4 +627,13 @@ extern "C" int dgnn_sage_aggregate_bwd_add(const int32_t* t_rowptr, const int32_
     DGNN_REQUIRE(add && n_add >= 0 && n_add <= n_src, DGNN_E_INVALID, "aggregate_bwd_add: bad addend");
     return agg_bwd_t<float>(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, ldx, c_in, edge_attr, lde, f_e, We, be, nullptr, 0, da, ldda, dx_src, lddx,
                             dWe, dbe, nullptr, 0, partials, (hipStream_t)stream, add, ldadd, n_add);
+}
+
+int dgnn_sage_aggregate_bwd_add_deferred(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, int64_t n_src, const int32_t* rowptr_dst,
+                                         const float* x_src, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e, const float* We,
+                                         const float* be, const float* da, int64_t ldda, float* dx_src, int64_t lddx, const float* add, int64_t ldadd,
+                                         int64_t n_add, float* dWe, float* dbe, float* partials, void* stream, SlabReduceDesc* desc) {
+    DGNN_REQUIRE(desc && We && n_src > 0, DGNN_E_INVALID, "aggregate_bwd_add_deferred: bad arguments");
+    return agg_bwd_t<float>(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, ldx, c_in, edge_attr, lde, f_e, We, be, nullptr, 0, da, ldda, dx_src, lddx,
+                            dWe, dbe, nullptr, 0, partials, (hipStream_t)stream, add, ldadd, n_add, desc);
 }

@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "reduce_common.h"
 
 namespace {
 
@@ -1470,41 +1471,12 @@ __global__ void __launch_bounds__(256) k_linear_wgrad_x3_cat(const float* __rest
 }
 
 // dW1 / dW2 / dbias = sums over the row splits in k_wgrad_reduce's order; the blocks behind the matrix elements take the bias columns
-__global__ void __launch_bounds__(256) k_wgrad_reduce_cat(const float* __restrict__ partials, const double* __restrict__ bias_partials, int splits, int na,
-                                                          int nb1, int nb2, float* __restrict__ dW1, float* __restrict__ dW2, float* __restrict__ dbias) {
-    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int nbt = nb1 + nb2, nmat = na * nbt, nblk_mat = (nmat + 15) / 16;
-    if ((int)blockIdx.x < nblk_mat) {
-        __shared__ float red[16][17];
-        const int i = blockIdx.x * 16 + o;
-        const bool live = i < nmat;
-        float p = 0.f;
-        if (live)
-            for (int z = sl; z < splits; z += 16) p += partials[(int64_t)z * nmat + i];
-        red[sl][o] = p;
-        __syncthreads();
-        if (sl != 0 || !live) return;
-        float s = 0.f;
-        for (int k = 0; k < 16; ++k) s += red[k][o];
-        const int row = i / nbt, col = i - row * nbt;
-        if (col < nb1)
-            dW1[(int64_t)row * nb1 + col] = s;
-        else
-            dW2[(int64_t)row * nb2 + (col - nb1)] = s;
-    } else {
-        __shared__ double redd[16][17];
-        const int i = ((int)blockIdx.x - nblk_mat) * 16 + o;
-        const bool live = i < na;
-        double p = 0.0;
-        if (live)
-            for (int z = sl; z < splits; z += 16) p += bias_partials[(int64_t)z * na + i];
-        redd[sl][o] = p;
-        __syncthreads();
-        if (sl != 0 || !live) return;
-        double s = 0.0;
-        for (int k = 0; k < 16; ++k) s += redd[k][o];
-        dbias[i] = (float)s;
-    }
+__global__ void __launch_bounds__(256) k_wgrad_reduce_cat(WgradReduceDesc d) {
+    __shared__ float redf[16][17];
+    __shared__ double redd[16][17];
+    wgrad_reduce_cat_phase(d, blockIdx.x, threadIdx.x, redf, redd, 0);
+    __syncthreads();
+    wgrad_reduce_cat_phase(d, blockIdx.x, threadIdx.x, redf, redd, 1);
 }
 
 int wgrad_splits(int64_t M) {
@@ -1741,8 +1713,8 @@ extern "C" int64_t dgnn_linear_wgrad_cat_scratch_elems(int64_t M, int n_a, int n
     return splits * n_a * (n_b1 + n_b2) + 2 * splits * n_a + 4;
 }
 
-extern "C" int dgnn_linear_wgrad_x3_cat(const float* A, int64_t lda, int n_a, const float* B1, int64_t ldb1, int n_b1, const float* B2, int64_t ldb2,
-                                        int n_b2, int64_t M, float* dW1, float* dW2, float* dbias, float* scratch, void* stream_) {
+int dgnn_linear_wgrad_x3_cat_deferred(const float* A, int64_t lda, int n_a, const float* B1, int64_t ldb1, int n_b1, const float* B2, int64_t ldb2, int n_b2,
+                                      int64_t M, float* dW1, float* dW2, float* dbias, float* scratch, void* stream_, WgradReduceDesc* desc) {
     hipStream_t stream = (hipStream_t)stream_;
     DGNN_REQUIRE(M >= 0 && n_a > 0 && n_b1 > 0 && n_b2 >= 0, DGNN_E_INVALID, "linear_wgrad_x3_cat: bad sizes");
     DGNN_REQUIRE(dW1 && scratch && (M == 0 || (A && B1)) && ((n_b2 == 0) == (B2 == nullptr)) && (n_b2 == 0 || dW2), DGNN_E_INVALID,
@@ -1757,7 +1729,16 @@ extern "C" int dgnn_linear_wgrad_x3_cat(const float* A, int64_t lda, int n_a, co
     dim3 grid((unsigned)dgnn_cdiv(n_a, WT), (unsigned)(nby1 + nby2), splits);
     hipLaunchKernelGGL(k_linear_wgrad_x3_cat, grid, dim3(256), 0, stream, A, lda, n_a, c, nby1, M, rps < XRK ? XRK : rps, partials,
                        dbias ? bias_partials : nullptr);
-    const int nblk = (int)dgnn_cdiv((int64_t)n_a * (n_b1 + n_b2), 16) + (dbias ? (int)dgnn_cdiv(n_a, 16) : 0);
-    hipLaunchKernelGGL(k_wgrad_reduce_cat, dim3((unsigned)nblk), dim3(256), 0, stream, partials, bias_partials, splits, n_a, n_b1, n_b2, dW1, dW2, dbias);
+    WgradReduceDesc d;
+    d.partials = partials, d.bias_partials = bias_partials, d.splits = splits, d.na = n_a, d.nb1 = n_b1, d.nb2 = n_b2, d.dW1 = dW1, d.dW2 = dW2, d.dbias = dbias;
+    if (desc)
+        *desc = d;
+    else
+        hipLaunchKernelGGL(k_wgrad_reduce_cat, dim3((unsigned)wgrad_reduce_blocks(d)), dim3(256), 0, stream, d);
     return dgnn_check_launch("linear_wgrad_x3_cat");
+}
+
+extern "C" int dgnn_linear_wgrad_x3_cat(const float* A, int64_t lda, int n_a, const float* B1, int64_t ldb1, int n_b1, const float* B2, int64_t ldb2,
+                                        int n_b2, int64_t M, float* dW1, float* dW2, float* dbias, float* scratch, void* stream) {
+    return dgnn_linear_wgrad_x3_cat_deferred(A, lda, n_a, B1, ldb1, n_b1, B2, ldb2, n_b2, M, dW1, dW2, dbias, scratch, stream, nullptr);
 }

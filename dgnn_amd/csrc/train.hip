@@ -19,6 +19,7 @@
 #include <mutex>
 
 #include "common.h"
+#include "reduce_common.h"
 
 namespace {
 
@@ -60,6 +61,24 @@ __global__ void k_transpose_many(TrJobs jobs) {
     }
 }
 
+// both reductions of a conv layer's backward in one launch of 1024-thread blocks: blocks [0, ns) sum the aggregate backward's slabs
+// (dWe, dbe), every later block runs four 256-thread blocks of the weight-gradient reduction (dWj, dWi, dbj)
+__global__ void __launch_bounds__(1024) k_reduce_layer(SlabReduceDesc sd, WgradReduceDesc wd, int ns) {
+    __shared__ float red[RS_SLICES][17];
+    __shared__ float redf[4][16][17];
+    __shared__ double redd[4][16][17];
+    if ((int)blockIdx.x < ns) {
+        reduce_slabs_block(sd, blockIdx.x, red);
+        return;
+    }
+    const int sub = threadIdx.x >> 8, t = threadIdx.x & 255;
+    const int blk = ((int)blockIdx.x - ns) * 4 + sub;
+    const bool on = blk < wgrad_reduce_blocks(wd);
+    if (on) wgrad_reduce_cat_phase(wd, blk, t, redf[sub], redd[sub], 0);
+    __syncthreads();
+    if (on) wgrad_reduce_cat_phase(wd, blk, t, redf[sub], redd[sub], 1);
+}
+
 // DGNN_TRAIN_FUSED=0: the launch chain of the separate entry points (one launch per weight gradient, bias sum, transpose and
 // input-gradient GEMM).  Default: dWj / dWi / dbj from one launch pair (dgnn_linear_wgrad_x3_cat), da and dz.Wi from one GEMM against
 // the stacked [Wj^T ; Wi^T], the latter added where the aggregate backward stores dx (dgnn_sage_aggregate_bwd_add), all transposes of a
@@ -70,7 +89,6 @@ int fused_mask() {
     if (v < 0) {
         const char* e = getenv("DGNN_TRAIN_FUSED");
         v = e ? atoi(e) & 3 : 3;
-        if (e && e[0] == '1' && e[1] == 0) v = 3;
         if (getenv("DGNN_AGG_CHUNKED") && getenv("DGNN_AGG_CHUNKED")[0] == '0') v &= ~1;   // the addend form lives in the chunked kernel
         __atomic_store_n(&g_fused_on, v, __ATOMIC_RELEASE);
     }
@@ -227,9 +245,15 @@ int layer_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
     }
     const float* A1 = agg ? a : x;
     const int64_t lda1 = agg ? c_in : ldx;
+    const bool need_dx = dx != nullptr;
+    const bool need_da = agg ? (need_dx || We != nullptr) : need_dx;
+    const bool both = need_da && agg && need_dx && Wi;
+    const bool one_gemm = fused && both && We && f_e == 20;   // [da | dz.Wi] from one GEMM, the layer's two reductions from one launch
+    WgradReduceDesc wdesc;
     if (fused) {
         const float* B2 = (agg && Wi && dWi) ? x : nullptr;
-        TRY(dgnn_linear_wgrad_x3_cat(dz, c_out, c_out, A1, lda1, c_in, B2, ldx, B2 ? c_in : 0, n_dst, dWj, dWi, dbj, wtmp, stream_));
+        TRY(dgnn_linear_wgrad_x3_cat_deferred(dz, c_out, c_out, A1, lda1, c_in, B2, ldx, B2 ? c_in : 0, n_dst, dWj, dWi, dbj, wtmp, stream_,
+                                              one_gemm ? &wdesc : nullptr));
     } else {
         TRY(wgrad(dz, c_out, c_out, A1, lda1, c_in, dWj));
         if (dbj) TRY(dgnn_colsum(dz, c_out, n_dst, c_out, dbj, 0, wtmp, wstream));
@@ -239,18 +263,18 @@ int layer_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
         *done = next_event(aux);
         (void)hipEventRecord(*done, aux->stream);
     }
-    const bool need_dx = dx != nullptr;
-    const bool need_da = agg ? (need_dx || We != nullptr) : need_dx;
-    const bool both = need_da && agg && need_dx && Wi;
     if (both && !pre_t)
         hipLaunchKernelGGL(k_transpose2, dim3(dgnn_grid_cap(dgnn_cdiv((int64_t)2 * c_in * c_out, 256))), dim3(256), 0, stream, Wj, Wi, c_out, c_in, WjT, WiT);
-    if (fused && both && We && f_e == 20) {
+    if (one_gemm) {
         // [da | dz.Wi] = dz . [Wj^T ; Wi^T]^T in one GEMM (every output column is the separate GEMMs' own dot product), the second half added to
         // the aggregate's sums where dx is stored
-        if (We) DGNN_REQUIRE(dWe && dbe, DGNN_E_INVALID, "sage_layer_train_bwd: dWe / dbe missing");
+        DGNN_REQUIRE(dWe && dbe, DGNN_E_INVALID, "sage_layer_train_bwd: dWe / dbe missing");
         TRY(gemm(dz, c_out, c_out, WjT, c_out, 0, n_dst, 2 * c_in, da, 2 * c_in));
-        TRY(dgnn_sage_aggregate_bwd_add(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x, ldx, c_in, edge_attr, lde, f_e, We, be, da, 2 * c_in, dx, c_in, da + c_in,
-                                        2 * c_in, n_dst, dWe, dbe, tmp, stream_));
+        SlabReduceDesc sdesc;
+        TRY(dgnn_sage_aggregate_bwd_add_deferred(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x, ldx, c_in, edge_attr, lde, f_e, We, be, da, 2 * c_in, dx, c_in,
+                                                 da + c_in, 2 * c_in, n_dst, dWe, dbe, tmp, stream_, &sdesc));
+        const int ns = slab_reduce_blocks(sdesc), nw = (wgrad_reduce_blocks(wdesc) + 3) / 4;
+        hipLaunchKernelGGL(k_reduce_layer, dim3((unsigned)(ns + nw)), dim3(1024), 0, stream, sdesc, wdesc, ns);
         return dgnn_check_launch("sage_layer_train_bwd");
     }
     if (need_da) {

@@ -220,9 +220,11 @@ def test_batch_statistics_from_the_gemm_epilogue(M, k1, k2, n_out):
     W2 = torch.randn(n_out, k2, generator=g).to(DEV) if k2 else None
     bias, gamma, beta = torch.randn(n_out, generator=g).to(DEV), (torch.rand(n_out, generator=g) + 0.5).to(DEV), torch.randn(n_out, generator=g).to(DEV)
     got = ops.linear_fwd_with_batch_stats(A1, W1, A2, W2, bias, gamma, beta)
-    if n_out > 128 and -(-M // 256) * -(-n_out // 256) >= 192:      # the 256 x 256 tile has no statistics epilogue
-        assert got is None
+    big = n_out > 128 and -(-M // 256) * -(-n_out // 256) >= 192      # the 256 x 256 tile has no statistics epilogue (DGNN_X3_BIG=0: never taken)
+    if got is None:
+        assert big
         return
+    assert not big or os.environ.get("DGNN_X3_BIG") == "0"
     z, mean, var, scale, shift = got
     z_ref = torch.empty_like(z)
     ops.check(lib().dgnn_linear_fwd_x3(ops.ptr(A1), k1, k1, ops.ptr(W1), k1, ops.ptr(A2), k2, k2, ops.ptr(W2), k2, ops.ptr(bias), None, None, 0, M, n_out,
@@ -243,6 +245,8 @@ def test_aggregate_backward_with_addend_matches_the_two_steps(c_in, n_src, n_dst
     """dgnn_sage_aggregate_bwd_add: dx = aggregate backward, then dx[:n_add] += add in one fp32 addition per element -- bit for bit; dWe / dbe
     untouched by the addend"""
     from dgnn_amd import ops
+    if os.environ.get("DGNN_AGG_CHUNKED") == "0":
+        pytest.skip("the addend form lives in the chunked kernel")
     g = torch.Generator().manual_seed(c_in + n_src)
     E = 4 * n_dst
     ei = torch.stack([torch.randint(0, n_src, (E,), generator=g), torch.arange(n_dst).repeat_interleave(4)])
@@ -471,7 +475,8 @@ def test_prepared_parameters_give_the_same_bits_and_follow_the_weights():
         prep = net.inference_layer(data)
         assert torch.equal(plain, prep)
         cache = net.__dict__["_prep_cache"]
-        assert sorted(cache) == [(0, False), (1, False), (2, False), (3, True)] and all(v[1] is not None for v in cache.values())
+        last = (3, bool(ops.FUSE_DECODER))        # DGNN_FUSE_DECODER=0: the last layer is a plain launch too
+        assert sorted(cache) == [(0, False), (1, False), (2, False), last] and all(v[1] is not None for v in cache.values())
         bufs = {k: v[1].data_ptr() for k, v in cache.items()}
         assert torch.equal(net.inference_layer(data), prep) and {k: v[1].data_ptr() for k, v in cache.items()} == bufs      # cache hit: nothing re-made
         # an in-place update of one layer's weights re-prepares that layer only, and the result follows the new weights

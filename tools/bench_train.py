@@ -125,6 +125,7 @@ for _ in range(steps):
     bs, n_id, adjs = next(it)
     block += int(n_id.numel())
     loss = tr.train(Config(all=all_, batch_n_id=n_id, batch_adjs=adjs), opt, clf)
+host_dt = time.perf_counter() - t0      # the main thread has issued every step; what is left until sync() returns is the GPU's backlog
 sync()
 dt = time.perf_counter() - t0
 if world > 1:
@@ -202,7 +203,7 @@ if rank == 0:
                       "model": "UpdatedEdgeFilters sage+" if args.updated else "StaticEdgeFilters", "dtype": args.dtype, "n_gpus": world,
                       "parallelism": "data-parallel replicas, one scene shard per GPU, flat RCCL all-reduce" if world > 1 else "single GPU",
                       "targets_per_s": round(batch * steps * world / dt, 1), "block_tets_per_s": round(block / dt, 1),
-                      "ms_per_step": round(dt / steps * 1e3, 3), "batch_targets_per_gpu": batch,
+                      "ms_per_step": round(dt / steps * 1e3, 3), "host_issue_ms_per_step": round(host_dt / steps * 1e3, 3), "batch_targets_per_gpu": batch,
                       "avg_block_tets": round(block / steps / world, 1), "steps": steps, "block_builder": args.prefetch, "scene_tets_per_gpu": n, "final_loss": float(loss), "replicas": replicas, "roofline": roof}))
 if world > 1:
     dist.destroy_process_group()

@@ -1,10 +1,12 @@
 #!/bin/bash
 # Every alternate code path behind an environment switch through the GPU suites that cover it (run on the GPU box through gpurun):
 # the separate autograd Functions instead of the composite training calls, the dense edge chaining, the multi-launch block builder, the
-# unfused loss, the bit-faithful fp32 matrix-core mode, the second training stream, the small GEMM tiles, the layer and the decoder as two launches.
+# unfused loss, the bit-faithful fp32 matrix-core mode, the second training stream, the small GEMM tiles, the layer and the decoder as two launches,
+# unprepared parameters, the training step's unfused launch chains, the row-at-a-time aggregate backward, the decoder's output Linear as its own Function.
 cd $GRAFT_REPO_ROOT
 for e in "DGNN_TRAIN_COMPOSITE=0" "DGNN_TRAIN_WHOLE_MODEL=0" "DGNN_KHOP_ONE_CALL=0" "DGNN_CHAIN_DENSE=1" "DGNN_FUSED_LOSS=0" "DGNN_GEMM_MODE=f32" \
-         "DGNN_TRAIN_AUX_STREAM=1" "DGNN_X3_BIG=0 DGNN_X3_N64=0" "DGNN_KHOP_MAILBOX=0" "DGNN_FUSE_DECODER=0" "DGNN_PREPARED=0"; do
+         "DGNN_TRAIN_AUX_STREAM=1" "DGNN_X3_BIG=0 DGNN_X3_N64=0" "DGNN_KHOP_MAILBOX=0" "DGNN_FUSE_DECODER=0" "DGNN_PREPARED=0" \
+         "DGNN_TRAIN_FUSED=0" "DGNN_TRAIN_FUSED=1" "DGNN_AGG_CHUNKED=0" "DGNN_TRAIN_DECODER_IN_CALL=0"; do
   echo "== $e"
   env $e python -m pytest tests/test_gpu_train.py tests/test_gpu_parity.py tests/test_gpu_bf16.py -m gpu -q -x 2>&1 | tail -2
 done
