@@ -192,8 +192,8 @@ class _StaticTrainModel(torch.autograd.Function):
         for i, sp in enumerate(spec):
             We, be, Wj, bj, Wi, gamma, beta = params[7 * i:7 * i + 7]
             plan = sp["plan"]
-            rows = plan.edge_rows if (plan is not None and sp["scene_rows"]) else None
-            layers.append(dict(plan_parts=(plan.rowptr, plan.src, rows if rows is not None else plan.eid) if plan is not None else None,
+            # addresses only (the library calls take pointers and counts): no views of the block builder's buffers are cut for them
+            layers.append(dict(plan_parts=plan.part_ptrs(bool(sp["scene_rows"])) if plan is not None else None,
                                n_dst=plan.n_dst if plan is not None else sp["n_rows"], n_src=plan.n_src if plan is not None else sp["n_rows"],
                                edge_attr=sp["edge_attr"] if We is not None else None, We=We, be=be, Wj=Wj, bj=bj, Wi=Wi, gamma=gamma, beta=beta, bn=sp["bn"]))
         y, buf, meta = ops.static_train_fwd(x0, layers)
@@ -208,8 +208,7 @@ class _StaticTrainModel(torch.autograd.Function):
         for l, sp in zip(ctx.layers, ctx.spec):
             plan = sp["plan"]
             if plan is not None:
-                t = plan.transposed
-                l["t_parts"] = (t[0], t[1], plan.transposed_edge_rows if sp["scene_rows"] else t[2])
+                l["t_parts"] = plan.transposed_ptrs(bool(sp["scene_rows"]))
         grads = ops.static_train_bwd(x0, ctx.layers, buf, ctx.meta, dy.contiguous())
         out = [None, None]
         for g in grads:

@@ -31,14 +31,57 @@ class GraphPlan:
         self._ei_ref = weakref.ref(edge_index)
         self._ei_own = edge_index if converted else None
         self.n_src, self.n_dst, self.E = int(n_src), int(n_dst), int(edge_index.size(1))
-        self.rowptr, self.src, self.eid = parts if parts is not None else ops.plan_build(edge_index, self.n_dst, by=1, hint=hint, n_other=self.n_src)
+        # Every array of a plan is held as a tensor OR as (buffer, length): the block builder hands out prefixes of preallocated buffers, and
+        # cutting the ~12 views of a block costs the training loop's main thread more than the library calls that only need the ADDRESSES
+        # (`*_ptrs`).  A view is cut when somebody asks for the tensor.
+        self._parts = list(parts if parts is not None else ops.plan_build(edge_index, self.n_dst, by=1, hint=hint, n_other=self.n_src))
         self._grouped = parts is not None or hint == ops.PLAN_HINT_GROUPED
-        self._t = None
+        self._t = None            # transposed plan: [t_rowptr, t_dst, t_eid], same convention
         self._sorted_attr = None  # (weakref to edge_attr, version, sorted copy)
         # optional, set by producers whose eid is the identity (the k-hop block builder): int32 [E], row of the SCENE's edge_attr
         # behind block edge k, so that kernels gather attribute rows from the scene tensor instead of a per-block copy
-        self.edge_rows = None
+        self._edge_rows = None
         self._t_rows = None
+
+    @staticmethod
+    def _tensor(holder, i):
+        v = holder[i]
+        if isinstance(v, tuple):
+            v = holder[i] = v[0][:v[1]]
+        return v
+
+    @staticmethod
+    def _address(v):
+        return (v[0] if isinstance(v, tuple) else v).data_ptr()      # a prefix starts where its buffer starts
+
+    rowptr = property(lambda self: self._tensor(self._parts, 0))
+    src = property(lambda self: self._tensor(self._parts, 1))
+    eid = property(lambda self: self._tensor(self._parts, 2))
+
+    @property
+    def edge_rows(self):
+        if isinstance(self._edge_rows, tuple):
+            self._edge_rows = self._edge_rows[0][:self._edge_rows[1]]
+        return self._edge_rows
+
+    @edge_rows.setter
+    def edge_rows(self, v):
+        self._edge_rows = v
+
+    @property
+    def has_edge_rows(self):
+        return self._edge_rows is not None
+
+    def part_ptrs(self, scene_rows: bool = False):
+        """addresses of (rowptr, src, eid | edge_rows) for library calls; no views are cut"""
+        return (self._address(self._parts[0]), self._address(self._parts[1]), self._address(self._edge_rows if scene_rows else self._parts[2]))
+
+    def transposed_ptrs(self, scene_rows: bool = False):
+        """addresses of (t_rowptr, t_dst, t_eid | transposed edge_rows); builds the transposed plan when the producer did not supply it"""
+        if self._t is None or (scene_rows and self._t_rows is None):
+            t = self.transposed
+            return (t[0].data_ptr(), t[1].data_ptr(), (self.transposed_edge_rows if scene_rows else t[2]).data_ptr())
+        return (self._address(self._t[0]), self._address(self._t[1]), self._address(self._t_rows if scene_rows else self._t[2]))
 
     @property
     def edge_index(self):
@@ -55,15 +98,17 @@ class GraphPlan:
                 raise RuntimeError("GraphPlan.transposed: the edge_index tensor this plan was built from has been freed")
             # an edge list grouped by destination is not grouped by source (unless it is the reference layout): skip the
             # fast-path attempts there
-            self._t = ops.plan_build(edge_index, self.n_src, by=0, hint=ops.PLAN_HINT_GENERIC if self._grouped else ops.PLAN_HINT_AUTO,
-                                      n_other=self.n_dst)
-        return self._t
+            self._t = list(ops.plan_build(edge_index, self.n_src, by=0, hint=ops.PLAN_HINT_GENERIC if self._grouped else ops.PLAN_HINT_AUTO,
+                                           n_other=self.n_dst))
+        return tuple(self._tensor(self._t, i) for i in range(3))
 
     @property
     def transposed_edge_rows(self):
         """edge_rows in the transposed plan's order (None without edge_rows)"""
         if self._t_rows is None and self.edge_rows is not None:
             self._t_rows = torch.index_select(self.edge_rows, 0, self.transposed[2])
+        if isinstance(self._t_rows, tuple):
+            self._t_rows = self._t_rows[0][:self._t_rows[1]]
         return self._t_rows
 
     def sorted_edge_attr(self, edge_attr: torch.Tensor) -> torch.Tensor:

@@ -213,7 +213,7 @@ class SurfaceNet(nn.Module):
             if isinstance(norm, BatchNorm) and Fn.sage_train_layer_supported(x, conv.lin_e, norm.module):
                 # conv + norm + ReLU as one library call forward, one backward
                 plan = plan_for(edge_index, x.size(0), size[1])
-                in_place = plan.edge_rows is not None and ea_all.is_cuda and ea_all.device == x.device and ea_all.dtype == torch.float32 \
+                in_place = plan.has_edge_rows and ea_all.is_cuda and ea_all.device == x.device and ea_all.dtype == torch.float32 \
                     and ea_all.dim() == 2 and ea_all.stride(1) == 1
                 # a block whose plan carries edge_rows (the GPU block builder): edge_attr[e_id] (:215) is read in place
                 ea = ea_all if in_place else _dev_f32(ea_all[e_id.to(ea_all.device)], dev)
@@ -244,7 +244,7 @@ class SurfaceNet(nn.Module):
             if not isinstance(norm, BatchNorm) or not Fn.sage_train_layer_supported(x, conv.lin_e, norm.module) or size[0] != n_src:
                 return None
             plan = plan_for(edge_index.to(dev), size[0], size[1])
-            in_place = plan.edge_rows is not None and ea_all.is_cuda and ea_all.device == x.device and ea_all.dtype == torch.float32 \
+            in_place = plan.has_edge_rows and ea_all.is_cuda and ea_all.device == x.device and ea_all.dtype == torch.float32 \
                 and ea_all.dim() == 2 and ea_all.stride(1) == 1
             ea = None
             if conv.lin_e is not None:

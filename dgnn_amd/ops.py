@@ -792,6 +792,31 @@ def _iarr(vals, ty):
     return (ty * len(vals))(*vals)
 
 
+_PARAM_ARRAYS = {}      # pointer tables of a model's parameters and BatchNorm buffers, rebuilt only when one of the pointers has moved
+
+
+def _param_arrays(layers):
+    """ctypes tables (one entry per layer) of everything in `layers` that belongs to the MODEL, not to the batch: built once and reused while
+    the tensors keep their addresses (40 data_ptr() reads a step instead of a dozen table constructions)."""
+    import ctypes as C
+    names = ("We", "be", "Wj", "bj", "Wi", "gamma", "beta")
+    key = tuple((l[k].data_ptr() if l[k] is not None else 0) for l in layers for k in names) + tuple(
+        ((bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr() if bn.track_running_stats else 0, bn.momentum, bn.eps)
+         if bn is not None else None) for bn in (l["bn"] for l in layers))
+    hit = _PARAM_ARRAYS.get(len(layers))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    t = {k: _parr([l[k] for l in layers]) for k in names}
+    bns = [l["bn"] for l in layers]
+    t["rm"] = _parr([(bn.running_mean if bn is not None else None) for bn in bns])
+    t["rv"] = _parr([(bn.running_var if bn is not None else None) for bn in bns])
+    t["nbt"] = _parr([(bn.num_batches_tracked if bn is not None and bn.track_running_stats else None) for bn in bns])
+    t["momentum"] = _iarr([(bn.momentum if bn is not None else 0.0) for bn in bns], C.c_float)
+    t["eps"] = _iarr([(bn.eps if bn is not None else 0.0) for bn in bns], C.c_float)
+    _PARAM_ARRAYS[len(layers)] = (key, t)
+    return t
+
+
 @on_device_of
 def static_train_fwd(x0, layers):
     """`layers`: list of dicts (one per conv layer, then optionally the decoder's Linear + BN block with plan None) with keys
@@ -823,19 +848,15 @@ def static_train_fwd(x0, layers):
     pp = lambda k: _parr([(l["plan_parts"][k] if l["plan_parts"] is not None else None) for l in layers])
     key = lambda k: _parr([l[k] for l in layers])
     f_e = max([l["We"].size(1) for l in layers if l["We"] is not None] or [0])
+    pa = _param_arrays(layers)
     check(lib().dgnn_static_train_fwd(
         L, pp(0), pp(1), pp(2), _iarr([l["n_dst"] for l in layers], C.c_int64), ptr(x0), _ld(x0), _iarr(widths, C.c_int32),
         key("edge_attr"), _iarr([(_ld(l["edge_attr"]) if l["edge_attr"] is not None else 0) for l in layers], C.c_int64), f_e,
-        key("We"), key("be"), key("Wj"), key("bj"), key("Wi"), key("gamma"), key("beta"),
-        _parr([(l["bn"].running_mean if l["bn"] is not None else None) for l in layers]),
-        _parr([(l["bn"].running_var if l["bn"] is not None else None) for l in layers]),
-        _parr([(l["bn"].num_batches_tracked if l["bn"] is not None and l["bn"].track_running_stats else None) for l in layers]),
-        _iarr([(l["bn"].momentum if l["bn"] is not None else 0.0) for l in layers], C.c_float),
-        _iarr([(l["bn"].eps if l["bn"] is not None else 0.0) for l in layers], C.c_float),
+        pa["We"], pa["be"], pa["Wj"], pa["bj"], pa["Wi"], pa["gamma"], pa["beta"], pa["rm"], pa["rv"], pa["nbt"], pa["momentum"], pa["eps"],
         _parr([at(m["a"]) for m in meta]), _parr([at(m["z"]) for m in meta]), _parr([at(m["stats"]) for m in meta]), _parr([at(m["y"]) for m in meta]),
         ptr(scratch), GEMM_MODE, stream_ptr()), "dgnn_static_train_fwd")
     n, co = layers[-1]["n_dst"], widths[-1]
-    return buf[meta[-1]["y"]:meta[-1]["y"] + n * co].view(n, co), buf, (meta, widths)
+    return torch.as_strided(buf, (n, co), (co, 1), meta[-1]["y"]), buf, (meta, widths, pa)
 
 
 @on_device_of
@@ -843,7 +864,7 @@ def static_train_bwd(x0, layers, buf, meta_widths, dy):
     """-> per-layer parameter gradients [(dWe, dbe, dWj, dbj, dWi, dgamma, dbeta), ...] (views of one buffer; None where the layer has
     no such parameter)"""
     import ctypes as C
-    meta, widths = meta_widths
+    meta, widths, pa = meta_widths
     dev, L = x0.device, len(layers)
     base = buf.data_ptr()
     at = lambda o: None if o is None else base + 4 * o
@@ -873,16 +894,16 @@ def static_train_bwd(x0, layers, buf, meta_widths, dy):
     check(lib().dgnn_static_train_bwd(
         L, tp(0), tp(1), tp(2), _parr([(l["plan_parts"][0] if l["plan_parts"] is not None else None) for l in layers]), _iarr(n_src, C.c_int64),
         _iarr([l["n_dst"] for l in layers], C.c_int64), ptr(x0), _ld(x0), _iarr(widths, C.c_int32), key("edge_attr"),
-        _iarr([(_ld(l["edge_attr"]) if l["edge_attr"] is not None else 0) for l in layers], C.c_int64), f_e, key("We"), key("be"), key("Wj"), key("Wi"),
-        key("gamma"), _parr([at(m["stats"]) for m in meta]), _iarr([(l["bn"].eps if l["bn"] is not None else 0.0) for l in layers], C.c_float),
-        _parr([at(m["a"]) for m in meta]),
+        _iarr([(_ld(l["edge_attr"]) if l["edge_attr"] is not None else 0) for l in layers], C.c_int64), f_e, pa["We"], pa["be"], pa["Wj"], pa["Wi"],
+        pa["gamma"], _parr([at(m["stats"]) for m in meta]), pa["eps"], _parr([at(m["a"]) for m in meta]),
         _parr([at(m["z"]) for m in meta]), _parr([at(m["y"]) for m in meta]), ptr(dy), col(0), col(1), col(2), col(3), col(4), col(5), col(6),
         _parr([dxb[0], dxb[1]]), ptr(scratch), GEMM_MODE, stream_ptr()), "dgnn_static_train_bwd")
     grads = []
+    st = torch.as_strided      # one view op per gradient (a slice + .view pair costs 2.5 x as much on the host, 34 times a step)
     for i, (l, row) in enumerate(zip(layers, sizes)):
         ci, co = widths[i], widths[i + 1]
         fe = l["We"].size(1) if l["We"] is not None else 0
-        v = lambda e, *shape: None if e is None else flat[e[0]:e[0] + e[1]].view(*shape)
-        grads.append((v(row[0], ci, fe) if fe else None, v(row[1], ci) if fe else None, v(row[2], co, ci), v(row[3], co), v(row[4], co, ci),
-                      v(row[5], co), v(row[6], co)))
+        m = lambda e, r, c: None if e is None else st(flat, (r, c), (c, 1), e[0])
+        v = lambda e, n: None if e is None else st(flat, (n,), (1,), e[0])
+        grads.append((m(row[0], ci, fe), v(row[1], ci), m(row[2], co, ci), v(row[3], co), m(row[4], co, ci), v(row[5], co), v(row[6], co)))
     return grads

@@ -78,10 +78,14 @@ class NeighborSampler:
         rp = self.plan.rowptr
         self._regular = bool(((rp[1:] - rp[:-1]) == 4).all().item()) if n > 0 else False
 
-    def _arange(self, n):
+    def _arange_full(self, n):
+        """the shared 0, 1, 2, ... buffer, at least n long"""
         if self._iota.numel() < n:
             self._iota = torch.arange(max(n, 2 * self._iota.numel()), dtype=torch.int32, device=self.device)
-        return self._iota[:n]
+        return self._iota
+
+    def _arange(self, n):
+        return self._arange_full(n)[:n]
 
     def __len__(self):
         m = self.node_idx.numel()
@@ -288,12 +292,13 @@ class NeighborSampler:
             n_t, n_all = int(counts[h]), int(counts[h + 1])
             n_e = 4 * n_t
             e = b["ei"][h][:, :n_e]     # a strided view: plans and kernels read edge lists in place
-            plan = GraphPlan(e, n_all, n_t, parts=(b["off"][h][:n_t + 1], b["src32"][h][:n_e], self._arange(n_e)))
+            # (buffer, length) pairs: the plan cuts a view when a tensor is asked for; the training step's library calls take the addresses
+            plan = GraphPlan(e, n_all, n_t, parts=((b["off"][h], n_t + 1), (b["src32"][h], n_e), (self._arange_full(n_e), n_e)))
             # plan position k <-> block edge k <-> row e_id[k] of the scene's edge_attr: consumers may read those rows in place
-            plan.edge_rows = b["e_id32"][h][:n_e]
+            plan.edge_rows = (b["e_id32"][h], n_e)
             if b["want_t"]:
-                plan._t = (b["t_rowptr"][h][:n_all + 1], b["t_dst"][h][:n_e], b["t_eid"][h][:n_e])
-                plan._t_rows = b["t_rows"][h][:n_e]
+                plan._t = [(b["t_rowptr"][h], n_all + 1), (b["t_dst"][h], n_e), (b["t_eid"][h], n_e)]
+                plan._t_rows = (b["t_rows"][h], n_e)
                 if self._escaped is not None:
                     self._escaped += [b[k][h] for k in ("t_rowptr", "t_dst", "t_eid", "t_rows")]
             register_plan(e, plan)
