@@ -82,7 +82,7 @@ def csrc_sha():
     measured on (profiles/*_traffic.json carries the hash of the sources it profiled)."""
     h = hashlib.sha256()
     # the sources the profiled launches are compiled from: the fused layer kernels (fp32 / bf16 storage) and the headers they include
-    for p in sorted(glob.glob(os.path.join(ROOT, "dgnn_amd", "csrc", "fused*.hip")) + glob.glob(os.path.join(ROOT, "dgnn_amd", "csrc", "*.h"))):
+    for p in sorted(glob.glob(os.path.join(ROOT, "dgnn_amd", "csrc", "fused*.hip")) + [os.path.join(ROOT, "dgnn_amd", "csrc", h) for h in ("common.h", "fused_common.h")]):
         h.update(os.path.basename(p).encode())
         h.update(open(p, "rb").read())
     return h.hexdigest()[:16]

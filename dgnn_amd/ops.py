@@ -655,9 +655,10 @@ def sage_layer_train_bwd(t_parts, rowptr_dst, n_src, n_dst, x, edge_attr, We, be
     f_e = We.size(1) if (agg and We is not None) else 0
     sizes = [c_in * f_e, c_in if f_e else 0, c_out * c_in, c_out if has_bias else 0, c_out * c_in if (agg and Wi is not None) else 0, c_out, c_out]
     flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+    shapes = [(c_in, f_e), (c_in,), (c_out, c_in), (c_out,), (c_out, c_in), (c_out,), (c_out,)]
     parts, o = [], 0
-    for s in sizes:
-        parts.append(flat[o:o + s] if s else None)
+    for s, sh in zip(sizes, shapes):       # one view op per gradient, already in its final shape
+        parts.append(torch.as_strided(flat, sh, (sh[1], 1) if len(sh) == 2 else (1,), o) if s else None)
         o += s
     dWe, dbe, dWj, dbj, dWi, dgamma, dbeta = parts
     dx = torch.empty((n_src if agg else n_dst, c_in), dtype=dt, device=dev) if need_dx else None
@@ -672,8 +673,7 @@ def sage_layer_train_bwd(t_parts, rowptr_dst, n_src, n_dst, x, edge_attr, We, be
         check(lib().dgnn_sage_layer_train_bwd_bf16(*head, ptr(dz), ptr(da), ptr(scratch), stream_ptr()), "dgnn_sage_layer_train_bwd_bf16")
     else:
         check(lib().dgnn_sage_layer_train_bwd(*head, ptr(scratch), GEMM_MODE, stream_ptr()), "dgnn_sage_layer_train_bwd")
-    return (dx, dWe.view(c_in, f_e) if f_e else None, dbe, dWj.view(c_out, c_in), dbj, dWi.view(c_out, c_in) if dWi is not None else None,
-            dgamma, dbeta)
+    return (dx, dWe, dbe, dWj, dbj, dWi, dgamma, dbeta)
 
 
 # ---- edge-embedding chaining of the Updated variant (csrc/chain.hip) ---------------------------------------------------------
@@ -763,9 +763,10 @@ def sage_updated_train_bwd(t_parts, rowptr_dst, n_src, n_dst, x, ea, We, Wl, Wr,
     dev, dt = x.device, x.dtype
     sizes = [c_in * k_e, c_in, c_out * c_in, c_out if has_bias else 0, c_out * c_in if Wr is not None else 0]
     flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+    shapes = [(c_in, k_e), (c_in,), (c_out, c_in), (c_out,), (c_out, c_in)]
     parts, o = [], 0
-    for sz in sizes:
-        parts.append(flat[o:o + sz] if sz else None)
+    for sz, sh in zip(sizes, shapes):      # one view op per gradient, already in its final shape
+        parts.append(torch.as_strided(flat, sh, (sh[1], 1) if len(sh) == 2 else (1,), o) if sz else None)
         o += sz
     dWe, dbe, dWl, dbl, dWr = parts
     dx = torch.empty((n_src, c_in), dtype=dt, device=dev) if need_dx else None
@@ -779,7 +780,7 @@ def sage_updated_train_bwd(t_parts, rowptr_dst, n_src, n_dst, x, ea, We, Wl, Wr,
                                             ptr(We), ptr(Wl), ptr(Wr), c_out, int(bool(relu)), ptr(phi), ptr(a), ptr(y), ptr(dy), ptr(dphi_ext), ptr(dx), ptr(d_ea),
                                             ptr(dWe), ptr(dbe), ptr(dWl), ptr(dbl), ptr(dWr), ptr(dz), ptr(da), ptr(dphi), ptr(scratch),
                                             int(dt == torch.bfloat16), GEMM_MODE, stream_ptr()), "dgnn_sage_updated_train_bwd")
-    return (dx, d_ea, dWe.view(c_in, k_e), dbe, dWl.view(c_out, c_in), dbl, dWr.view(c_out, c_in) if dWr is not None else None)
+    return (dx, d_ea, dWe, dbe, dWl, dbl, dWr)
 
 
 # ---- Static model in training mode, all layers per call (csrc/train.hip) -------------------------------------------------------
