@@ -35,6 +35,12 @@ SIGNATURES = {
     "dgnn_linear_wgrad_x3": (i32, [vp, i64, i32, vp, i64, i32, i64, vp, i64, i32, vp, vp]),
     "dgnn_linear_wgrad_cat_scratch_elems": (i64, [i64, i32, i32, i32]),
     "dgnn_train_set_fused": (i32, [i32]),
+    "dgnn_updated_stack_fwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                    i32, i32, vp]),
+    "dgnn_updated_stack_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                    vp, vp, vp, vp, vp, i32, i32, vp]),
+    "dgnn_linear_wgrad_bf16_cat": (i32, [vp, i32, i64, i32, vp, i64, i32, vp, i64, i32, i32, i64, vp, vp, vp, vp, vp]),
+    "dgnn_sage_aggregate_bwd_phi_add": (i32, [vp, vp, vp, i64, vp, vp, i64, i32, vp, i64, vp, i64, vp, i64, vp, i64, i64, vp, i64, vp, i32, vp]),
     "dgnn_linear_fwd_x3_stats": (i32, [vp, i64, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp, i64, vp, vp]),
     "dgnn_bn_stats_finalize_fold": (i32, [vp, i64, i64, i32, vp, vp, vp, vp, f32, vp, vp, f32, vp, vp, vp]),
     "dgnn_linear_wgrad_x3_cat": (i32, [vp, i64, i32, vp, i64, i32, vp, i64, i32, i64, vp, vp, vp, vp, vp]),

@@ -321,10 +321,14 @@ __global__ void __launch_bounds__(256) k_agg_bwd_c(const int32_t* __restrict__ t
                                                    const float* __restrict__ We, const float* __restrict__ be, const T* __restrict__ phi,
                                                    int64_t ldphi, const T* __restrict__ da, int64_t ldda, T* __restrict__ dx, int64_t lddx,
                                                    T* __restrict__ dphi_out, int64_t lddphi, float* __restrict__ slabs, int rows_per_chunk,
-                                                   const T* __restrict__ add, int64_t ldadd, int64_t n_add) {
+                                                   const T* __restrict__ add, int64_t ldadd, int64_t n_add, const T* __restrict__ dphi_ext) {
     constexpr int NW = FE > 0 ? FE : 1;
-    static_assert(!ADD || FE >= CH_ROWS - 1, "the addend rows of a chunk are parked in the wavefront's slab region");
-    __shared__ float red[FE > 0 ? 4 * 64 * CPL * (FE + 1) : 1];
+    // ADD: the addend rows of a chunk are parked in the wavefront's part of `red` (the slab region when the filter is fused, a region of its own
+    // in the given-phi form, which has no slabs).  dphi_ext (given-phi form): dphi_out[e] = dphi_e + dphi_ext[e] -- the gradient the NEXT layer sent
+    // to this layer's phi through its own edge input (Updated variant), added where dphi is stored instead of by a launch over [E, c_in].
+    constexpr int PARK = FE > 0 ? FE + 1 : CH_ROWS;
+    static_assert(!ADD || PARK >= CH_ROWS, "the addend rows of a chunk fit the wavefront's region");
+    __shared__ float red[FE > 0 ? 4 * 64 * CPL * (FE + 1) : (ADD ? 4 * 64 * CPL * CH_ROWS : 1)];
     const int lane = lane_id();
     const int c0 = (blockIdx.y * 64 + lane) * CPL;
     const bool on = c0 < c_in;
@@ -357,7 +361,7 @@ __global__ void __launch_bounds__(256) k_agg_bwd_c(const int32_t* __restrict__ t
         float acc[CPL];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) acc[j] = 0.f;
-        float* const park = red + (wv * 64 + lane) * CPL * (FE + 1);   // ADD: [row of the chunk][CPL] of this lane
+        float* const park = red + (wv * 64 + lane) * CPL * PARK;   // ADD: [row of the chunk][CPL] of this lane
         if (ADD && on) {
             Vec<CPL, T> av[CH_ROWS];
 #pragma unroll
@@ -394,7 +398,7 @@ __global__ void __launch_bounds__(256) k_agg_bwd_c(const int32_t* __restrict__ t
             }
             for (int m = 1; m <= nr; ++m) rowv += (rl(rp, m) <= wpos + lane) ? 1 : 0;
             for (int k0 = 0; k0 < nw; k0 += SLOTS) {
-                Vec<CPL, T> gq[SLOTS], xq[SLOTS], pr[SLOTS];
+                Vec<CPL, T> gq[SLOTS], xq[SLOTS], pr[SLOTS], pe[SLOTS];
                 float Av[SLOTS];
 #pragma unroll
                 for (int j = 0; j < SLOTS; ++j) {
@@ -408,6 +412,7 @@ __global__ void __launch_bounds__(256) k_agg_bwd_c(const int32_t* __restrict__ t
                     }
                     if (FE > 0) Av[j] = lane < FE ? ea[e * lde + lane] : 0.f;
                     if (FE == 0 && on) pr[j].load(phi + e * ldphi + c0);
+                    if (FE == 0 && on && dphi_ext) pe[j].load(dphi_ext + e * lddphi + c0);
                 }
 #pragma unroll
                 for (int j = 0; j < SLOTS; ++j) {
@@ -444,7 +449,13 @@ __global__ void __launch_bounds__(256) k_agg_bwd_c(const int32_t* __restrict__ t
                                 for (int f = 0; f < NW; ++f) gw[jj][f] = __fmaf_rn(dph.v[jj], af[f], gw[jj][f]);
                             }
                         }
-                        if (FE == 0 && dphi_out) dph.store(dphi_out + (int64_t)rl(ev, k0 + j) * lddphi + c0);
+                        if (FE == 0 && dphi_out) {
+                            if (dphi_ext) {
+#pragma unroll
+                                for (int jj = 0; jj < CPL; ++jj) dph.v[jj] = __fadd_rn(dph.v[jj], pe[j].v[jj]);
+                            }
+                            dph.store(dphi_out + (int64_t)rl(ev, k0 + j) * lddphi + c0);
+                        }
                     }
                 }
             }
@@ -518,7 +529,7 @@ int agg_bwd_t(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
               const T* x_src, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e, const float* We, const float* be,
               const T* phi, int64_t ldphi, const T* da, int64_t ldda, T* dx_src, int64_t lddx, float* dWe, float* dbe, T* dphi_out,
               int64_t lddphi, float* partials, hipStream_t stream, const T* add = nullptr, int64_t ldadd = 0, int64_t n_add = 0,
-              SlabReduceDesc* deferred = nullptr) {
+              SlabReduceDesc* deferred = nullptr, const T* dphi_ext = nullptr) {
     DGNN_REQUIRE(n_src >= 0 && c_in > 0, DGNN_E_INVALID, "aggregate_bwd: bad sizes");
     if (n_src == 0) {   // nothing to sum: the parameter gradients are zero (they are written, not accumulated, otherwise)
         if (We && dWe && dbe) {
@@ -538,21 +549,23 @@ int agg_bwd_t(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
     const int cpl = v2 ? 2 : 1;
     const int chunks = (int)dgnn_cdiv(c_in, 64 * cpl);
     const bool chunked = agg_chunked();
-    DGNN_REQUIRE(!add || (chunked && We != nullptr && f_e == 20 && dx_src), DGNN_E_UNSUPPORTED,
-                 "aggregate_bwd: the addend form needs the chunked kernel, the fused 20-attribute filter and dx");
+    DGNN_REQUIRE(!add || (chunked && dx_src && ((We != nullptr && f_e == 20) || (We == nullptr && phi != nullptr))), DGNN_E_UNSUPPORTED,
+                 "aggregate_bwd: the addend form needs the chunked kernel, dx, and the fused 20-attribute filter or a given phi");
+    DGNN_REQUIRE(!dphi_ext || (chunked && We == nullptr && phi != nullptr && dphi_out), DGNN_E_UNSUPPORTED,
+                 "aggregate_bwd: dphi_ext needs the chunked kernel in the given-phi form");
     const int rw = chunk_rows(n_src);
     const int64_t want = chunked ? dgnn_cdiv(dgnn_cdiv(n_src, rw), 4) : dgnn_cdiv(n_src, 4);
     const int nblocks = (int)(want < BWD_BLOCKS ? want : BWD_BLOCKS);
     dim3 grid(nblocks, chunks), block(256);
 #define LAUNCH(CPL, FE)                                                                                               \
-    do { if (chunked && add && FE == 20)                                                                              \
-        hipLaunchKernelGGL((k_agg_bwd_c<CPL, FE == 20 ? 20 : 20, T, (CPL == 2 && sizeof(T) == 4) ? 4 : 8, true>), grid, block, 0, stream, t_rowptr, t_dst, \
+    do { if (chunked && add && (FE == 20 || FE == 0))                                                                 \
+        hipLaunchKernelGGL((k_agg_bwd_c<CPL, FE == 0 ? 0 : 20, T, (CPL == 2 && sizeof(T) == 4) ? 4 : 8, true>), grid, block, 0, stream, t_rowptr, t_dst, \
                            t_eid, n_src, rowptr_dst, x_src, ldx, c_in, edge_attr, lde, We, be, phi, ldphi, da, ldda, dx_src, lddx, dphi_out, lddphi, \
-                           partials, rw, add, ldadd, n_add);                                                          \
+                           partials, rw, add, ldadd, n_add, dphi_ext);                                                \
     else if (chunked)                                                                                                 \
         hipLaunchKernelGGL((k_agg_bwd_c<CPL, FE, T, (CPL == 2 && sizeof(T) == 4) ? 4 : 8>), grid, block, 0, stream, t_rowptr, t_dst, t_eid, n_src, \
                            rowptr_dst, x_src, ldx, c_in, edge_attr, lde, We, be, phi, ldphi, da, ldda, dx_src, lddx, dphi_out, lddphi, partials, rw, \
-                           (const T*)nullptr, (int64_t)0, (int64_t)0);                                                \
+                           (const T*)nullptr, (int64_t)0, (int64_t)0, dphi_ext);                                      \
     else                                                                                                              \
         hipLaunchKernelGGL((k_agg_bwd<CPL, FE, T>), grid, block, 0, stream, t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, ldx, \
                            c_in, edge_attr, lde, We, be, phi, ldphi, da, ldda, dx_src, lddx, dphi_out, lddphi, partials); } while (0)
@@ -636,4 +649,20 @@ int dgnn_sage_aggregate_bwd_add_deferred(const int32_t* t_rowptr, const int32_t*
     DGNN_REQUIRE(desc && We && n_src > 0, DGNN_E_INVALID, "aggregate_bwd_add_deferred: bad arguments");
     return agg_bwd_t<float>(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, ldx, c_in, edge_attr, lde, f_e, We, be, nullptr, 0, da, ldda, dx_src, lddx,
                             dWe, dbe, nullptr, 0, partials, (hipStream_t)stream, add, ldadd, n_add, desc);
+}
+
+// given-phi form (Updated variant) with the two additions of a conv layer's backward folded into the stores: dx_src[row] += add[row] for
+// row < n_add (add may be NULL), dphi_out[e] = dphi_e + dphi_ext[e] (dphi_ext may be NULL).  bf16: storage 1, fp32: 0.
+extern "C" int dgnn_sage_aggregate_bwd_phi_add(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, int64_t n_src, const int32_t* rowptr_dst,
+                                               const void* x_src, int64_t ldx, int c_in, const void* phi, int64_t ldphi, const void* da, int64_t ldda,
+                                               void* dx_src, int64_t lddx, const void* add, int64_t ldadd, int64_t n_add, void* dphi_out, int64_t lddphi,
+                                               const void* dphi_ext, int bf16, void* stream) {
+    DGNN_REQUIRE(n_add >= 0 && n_add <= n_src, DGNN_E_INVALID, "aggregate_bwd_phi_add: bad addend");
+    if (bf16)
+        return agg_bwd_t<uint16_t>(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, (const uint16_t*)x_src, ldx, c_in, nullptr, 0, 0, nullptr, nullptr,
+                                   (const uint16_t*)phi, ldphi, (const uint16_t*)da, ldda, (uint16_t*)dx_src, lddx, nullptr, nullptr, (uint16_t*)dphi_out, lddphi,
+                                   nullptr, (hipStream_t)stream, (const uint16_t*)add, ldadd, n_add, nullptr, (const uint16_t*)dphi_ext);
+    return agg_bwd_t<float>(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, (const float*)x_src, ldx, c_in, nullptr, 0, 0, nullptr, nullptr, (const float*)phi, ldphi,
+                            (const float*)da, ldda, (float*)dx_src, lddx, nullptr, nullptr, (float*)dphi_out, lddphi, nullptr, (hipStream_t)stream,
+                            (const float*)add, ldadd, n_add, nullptr, (const float*)dphi_ext);
 }

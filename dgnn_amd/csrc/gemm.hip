@@ -308,6 +308,99 @@ __global__ void __launch_bounds__(256) k_linear_fwd_b(const uint16_t* __restrict
     }
 }
 
+// Small problems (M <= 16384 rows: the inner blocks of a training step, the decoder) in bf16 storage: k_linear_fwd_b's 128-row tiles leave most
+// of the chip idle there and walk K behind two barriers per 64 columns (13-20 us per launch for 0.1 GFLOP; the bf16-storage training step spent
+// 0.3 ms in 22 such launches).  Like k_linear_fwd_x3_small, ONE WAVEFRONT owns a 32 x 32 output block and takes its fragments straight from
+// global memory in the MFMA's layout (A: 8 consecutive bf16 of a row = one 16-byte load; W: 8 fp32 rounded to bf16 in registers), four k-steps
+// of loads in flight, no LDS, no barrier.  k-steps in k_linear_fwd_b's order: bit-identical results.
+template <typename TO>
+__global__ void __launch_bounds__(256) k_linear_fwd_b_small(const uint16_t* __restrict__ A1, int64_t lda1, int k1, const float* __restrict__ W1,
+                                                            int64_t ldw1, bool va1, bool vw1, const uint16_t* __restrict__ A2, int64_t lda2, int k2,
+                                                            const float* __restrict__ W2, int64_t ldw2, bool va2, bool vw2,
+                                                            const float* __restrict__ bias, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int relu, int64_t M, int n_out, TO* __restrict__ out,
+                                                            int64_t ldo) {
+    const int lane = lane_id(), w = wave_id_uniform();
+    const int h = lane >> 5, l31 = lane & 31;
+    const int nct = (n_out + 31) / 32;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + w;
+    const int64_t rt = tile / nct;
+    const int ct = (int)(tile - rt * nct);
+    if (rt * 32 >= M) return;
+    const int64_t row = rt * 32 + l31, rowc = row < M ? row : M - 1;
+    const int col = ct * 32 + l31, colc = col < n_out ? col : n_out - 1;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int part = 0; part < 2; ++part) {
+        const uint16_t* A = part == 0 ? A1 : A2;
+        if (!A) break;
+        const float* W = part == 0 ? W1 : W2;
+        const int kk = part == 0 ? k1 : k2;
+        const bool va = part == 0 ? va1 : va2, vw = part == 0 ? vw1 : vw2;
+        const uint16_t* ap = A + rowc * (part == 0 ? lda1 : lda2) + 8 * h;
+        const float* wp = W + (int64_t)colc * (part == 0 ? ldw1 : ldw2) + 8 * h;
+        const int nst = (kk + 15) / 16;
+        struct Frag {
+            uint4 a;
+            f32x4 w0, w1;
+        };
+        auto load_step = [&](Frag& f, int st) {       // k = 16 st + 8 h .. + 7
+            const int k0 = 16 * st + 8 * h;
+            if (va && k0 + 8 <= kk) {
+                f.a = *reinterpret_cast<const uint4*>(ap + 16 * st);
+            } else {
+                uint32_t e[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] = (k0 + j < kk) ? (uint32_t)ap[16 * st + j] : 0u;
+                f.a = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+            }
+            if (vw && k0 + 8 <= kk) {
+                f.w0 = *reinterpret_cast<const f32x4*>(wp + 16 * st);
+                f.w1 = *reinterpret_cast<const f32x4*>(wp + 16 * st + 4);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f.w0[j] = (k0 + j < kk) ? wp[16 * st + j] : 0.f;
+                    f.w1[j] = (k0 + 4 + j < kk) ? wp[16 * st + 4 + j] : 0.f;
+                }
+            }
+        };
+        auto mul_step = [&](const Frag& f) {
+            const bf16x8_t av = __builtin_bit_cast(bf16x8_t, f.a);
+            const bf16x8_t bv = __builtin_bit_cast(bf16x8_t, make_uint4(pk_bf16(f.w0[0], f.w0[1]), pk_bf16(f.w0[2], f.w0[3]), pk_bf16(f.w1[0], f.w1[1]),
+                                                                        pk_bf16(f.w1[2], f.w1[3])));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+        };
+        Frag r0, r1, r2, r3;
+        for (int st = 0; st < nst; st += 4) {
+            load_step(r0, st);
+            if (st + 1 < nst) load_step(r1, st + 1);
+            if (st + 2 < nst) load_step(r2, st + 2);
+            if (st + 3 < nst) load_step(r3, st + 3);
+            mul_step(r0);
+            if (st + 1 < nst) mul_step(r1);
+            if (st + 2 < nst) mul_step(r2);
+            if (st + 3 < nst) mul_step(r3);
+        }
+    }
+    if (col < n_out) {
+        const float bb = bias ? bias[col] : 0.f;
+        const float sc = scale ? scale[col] : 1.f;
+        const float sh = scale ? shift[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t orow = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (orow >= M) continue;
+            float v = acc[r] + bb;
+            if (scale) v = __fmaf_rn(v, sc, sh);
+            if (relu & 1) v = fmaxf(v, 0.f);
+            if (relu & DGNN_LINEAR_ACCUMULATE) v += dgnn_ld(out + orow * ldo + col);
+            dgnn_st(out + orow * ldo + col, v);
+        }
+    }
+}
+
 // dW[na, nb] = sum_rows A[r, :]^T B[r, :] with bf16 A and B (TA/TB: uint16_t = bf16 storage, float = fp32 rounded to bf16 here).
 // Row slices of 64 rows are staged TRANSPOSED ([column][row], 144-byte rows) so that a lane's MFMA fragment -- 8 consecutive
 // rows of one column -- is one 16-byte LDS read.
@@ -359,6 +452,137 @@ __global__ void __launch_bounds__(256) k_linear_wgrad_b(const TA* __restrict__ A
     for (int r = 0; r < 16; ++r) {
         const int row = a0 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row < na && col < nb) P[(int64_t)row * nb + col] = acc[r];
+    }
+}
+
+// ---- merged form for the bf16-storage training step (the Updated variant's conv: dWl = dz^T a, dWr = dz^T x, dbl = sum dz; dWe = dphi^T ea,
+// dbe = sum dphi): k_linear_wgrad_b's products on the same row splits (bit-identical dW), both B matrices and the column sums of A from one
+// launch.  Staging by 16-byte loads: a thread takes 8 consecutive columns of a ROW PAIR and writes eight 4-byte (row pair) entries of the
+// transposed image (k_linear_wgrad_b: sixteen 2-byte loads and stores per thread); the next 64-row slice is loaded under the matrix instructions.
+template <typename T>
+__device__ __forceinline__ void load_t_b(float (&va)[8], float (&vb)[8], const T* __restrict__ src, int64_t ld, bool vec, int64_t r0, int64_t r_end, int c0,
+                                         int nc) {
+    const int t = threadIdx.x, tp = t >> 3, tc = (t & 7) * 8;
+    const int64_t ra = r0 + 2 * tp, rb = ra + 1;
+    if (vec && c0 + tc + 8 <= nc) {
+        if constexpr (sizeof(T) == 2) {
+            uint4 a = make_uint4(0, 0, 0, 0), b = a;
+            if (ra < r_end) a = *reinterpret_cast<const uint4*>(src + ra * ld + c0 + tc);
+            if (rb < r_end) b = *reinterpret_cast<const uint4*>(src + rb * ld + c0 + tc);
+            const uint32_t wa[4] = {a.x, a.y, a.z, a.w}, wb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                va[2 * j] = __builtin_bit_cast(float, wa[j] << 16), va[2 * j + 1] = __builtin_bit_cast(float, wa[j] & 0xFFFF0000u);
+                vb[2 * j] = __builtin_bit_cast(float, wb[j] << 16), vb[2 * j + 1] = __builtin_bit_cast(float, wb[j] & 0xFFFF0000u);
+            }
+        } else {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const float* pa = reinterpret_cast<const float*>(src) + ra * ld + c0 + tc;
+            const float* pb = reinterpret_cast<const float*>(src) + rb * ld + c0 + tc;
+            const f32x4 a0 = ra < r_end ? *reinterpret_cast<const f32x4*>(pa) : z, a1 = ra < r_end ? *reinterpret_cast<const f32x4*>(pa + 4) : z;
+            const f32x4 b0 = rb < r_end ? *reinterpret_cast<const f32x4*>(pb) : z, b1 = rb < r_end ? *reinterpret_cast<const f32x4*>(pb + 4) : z;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) va[j] = a0[j], va[4 + j] = a1[j], vb[j] = b0[j], vb[4 + j] = b1[j];
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int cc = c0 + tc + j;
+        va[j] = (ra < r_end && cc < nc) ? dgnn_ld(src + ra * ld + cc) : 0.f;
+        vb[j] = (rb < r_end && cc < nc) ? dgnn_ld(src + rb * ld + cc) : 0.f;
+    }
+}
+__device__ __forceinline__ void store_t_b(char* __restrict__ dst, const float (&va)[8], const float (&vb)[8]) {
+    const int t = threadIdx.x, tp = t >> 3, tc = (t & 7) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        uint16_t lo, hi;
+        dgnn_st(&lo, va[j]);      // round to nearest even like stage_t (exact for bf16 storage)
+        dgnn_st(&hi, vb[j]);
+        *reinterpret_cast<uint32_t*>(dst + (tc + j) * LDTB + tp * 4) = (uint32_t)lo | ((uint32_t)hi << 16);
+    }
+}
+
+struct WgradCatB {
+    const void* B[2];
+    int64_t ldb[2];
+    int nb[2];
+};
+
+template <typename TA, typename TB>
+__global__ void __launch_bounds__(256) k_linear_wgrad_b_cat(const TA* __restrict__ A, int64_t lda, int na, WgradCatB c, int nby1, int64_t M,
+                                                            int64_t rows_per_split, float* __restrict__ partials, double* __restrict__ bias_partials) {
+    __shared__ __attribute__((aligned(16))) char At[WT * LDTB];
+    __shared__ __attribute__((aligned(16))) char Bt[WT * LDTB];
+    const int lane = lane_id(), w = wave_id_uniform();
+    const int wa = w >> 1, wb = w & 1, h = lane >> 5, l31 = lane & 31;
+    const int which = (int)blockIdx.y >= nby1 ? 1 : 0;
+    const TB* __restrict__ B = reinterpret_cast<const TB*>(c.B[which]);
+    const int64_t ldb = c.ldb[which];
+    const int nb = c.nb[which], nbt = c.nb[0] + c.nb[1], colbase = which ? c.nb[0] : 0;
+    const int a0 = blockIdx.x * WT, b0 = ((int)blockIdx.y - (which ? nby1 : 0)) * WT;
+    const int64_t r_beg = (int64_t)blockIdx.z * rows_per_split;
+    const int64_t r_end = min(M, r_beg + rows_per_split);
+    const bool do_bias = bias_partials != nullptr && blockIdx.y == 0;
+    const int t = threadIdx.x, tp = t >> 3, tc = (t & 7) * 8;
+    const bool vecA = ((uintptr_t)A % 16 == 0) && (lda % (16 / sizeof(TA)) == 0), vecB = ((uintptr_t)B % 16 == 0) && (ldb % (16 / sizeof(TB)) == 0);
+    double bs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bs[j] = 0.0;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float aa[8], ab[8], ba[8], bb[8];
+    if (r_beg < r_end) {
+        load_t_b<TA>(aa, ab, A, lda, vecA, r_beg, r_end, a0, na);
+        load_t_b<TB>(ba, bb, B, ldb, vecB, r_beg, r_end, b0, nb);
+    }
+    for (int64_t r0 = r_beg; r0 < r_end; r0 += RKB) {
+        __syncthreads();
+        store_t_b(At, aa, ab);
+        store_t_b(Bt, ba, bb);
+        if (do_bias) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bs[j] += (double)aa[j];
+                bs[j] += (double)ab[j];
+            }
+        }
+        __syncthreads();
+        if (r0 + RKB < r_end) {
+            load_t_b<TA>(aa, ab, A, lda, vecA, r0 + RKB, r_end, a0, na);
+            load_t_b<TB>(ba, bb, B, ldb, vecB, r0 + RKB, r_end, b0, nb);
+        }
+        const char* ap = At + (wa * 32 + l31) * LDTB + h * 16;
+        const char* bp = Bt + (wb * 32 + l31) * LDTB + h * 16;
+#pragma unroll
+        for (int S = 0; S < RKB / 16; ++S)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(ap + 32 * S),
+                                                          *reinterpret_cast<const bf16x8_t*>(bp + 32 * S), acc, 0, 0, 0);
+    }
+    float* P = partials + (int64_t)blockIdx.z * na * nbt;
+    const int col = b0 + wb * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = a0 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < na && col < nb) P[(int64_t)row * nbt + colbase + col] = acc[r];
+    }
+    if (do_bias) {
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(At);     // [32 row pairs][64 columns] doubles = 16 KB > the 9 KB tile: two halves of 16 row pairs
+        double* red2 = reinterpret_cast<double*>(Bt);
+        double* mine = (tp < 16 ? red : red2) + (tp & 15) * 64;
+        static_assert(16 * 64 * 8 <= WT * LDTB, "bias scratch fits the tiles");
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mine[tc + j] = bs[j];
+        __syncthreads();
+        if (t < 64 && a0 + t < na) {
+            double sum = 0.0;
+            for (int k = 0; k < 16; ++k) sum += red[k * 64 + t];
+            for (int k = 0; k < 16; ++k) sum += red2[k * 64 + t];
+            bias_partials[(int64_t)blockIdx.z * na + a0 + t] = sum;
+        }
     }
 }
 
@@ -1538,6 +1762,17 @@ extern "C" int dgnn_linear_fwd_bf16(const uint16_t* A1, int64_t lda1, int k1, co
     DGNN_REQUIRE((scale == nullptr) == (shift == nullptr), DGNN_E_INVALID, "linear_fwd_bf16: scale/shift must come together");
     const bool va1 = vec16(A1, lda1, 2), vw1 = vec16(W1, ldw1, 4);
     const bool va2 = A2 && vec16(A2, lda2, 2), vw2 = W2 && vec16(W2, ldw2, 4);
+    static const bool small_ok = !(getenv("DGNN_BF16_SMALL") && getenv("DGNN_BF16_SMALL")[0] == '0');
+    if (small_ok && M <= 16384) {   // same k order per output element: identical results
+        dim3 sgrid((unsigned)dgnn_cdiv(dgnn_cdiv(M, 32) * dgnn_cdiv(n_out, 32), 4));
+        if (out_f32)
+            hipLaunchKernelGGL((k_linear_fwd_b_small<float>), sgrid, dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, va1, vw1, A2, lda2, k2, W2,
+                               ldw2, va2, vw2, bias, scale, shift, relu, M, n_out, (float*)out, ldo);
+        else
+            hipLaunchKernelGGL((k_linear_fwd_b_small<uint16_t>), sgrid, dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, va1, vw1, A2, lda2, k2,
+                               W2, ldw2, va2, vw2, bias, scale, shift, relu, M, n_out, (uint16_t*)out, ldo);
+        return dgnn_check_launch("linear_fwd_bf16");
+    }
     dim3 grid((unsigned)(dgnn_cdiv(M, BM) * dgnn_cdiv(n_out, BN)));
     if (out_f32)
         hipLaunchKernelGGL((k_linear_fwd_b<float>), grid, dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, va1, vw1, A2, lda2, k2, W2, ldw2,
@@ -1741,4 +1976,42 @@ int dgnn_linear_wgrad_x3_cat_deferred(const float* A, int64_t lda, int n_a, cons
 extern "C" int dgnn_linear_wgrad_x3_cat(const float* A, int64_t lda, int n_a, const float* B1, int64_t ldb1, int n_b1, const float* B2, int64_t ldb2,
                                         int n_b2, int64_t M, float* dW1, float* dW2, float* dbias, float* scratch, void* stream) {
     return dgnn_linear_wgrad_x3_cat_deferred(A, lda, n_a, B1, ldb1, n_b1, B2, ldb2, n_b2, M, dW1, dW2, dbias, scratch, stream, nullptr);
+}
+
+// bf16-storage form: A / B1 / B2 are bf16 (`*_f32` = 0) or fp32 rounded to bf16 when staged (1); dW1 / dW2 bit-identical to dgnn_linear_wgrad_bf16
+int dgnn_linear_wgrad_bf16_cat_deferred(const void* A, int a_f32, int64_t lda, int n_a, const void* B1, int64_t ldb1, int n_b1, const void* B2, int64_t ldb2,
+                                        int n_b2, int b_f32, int64_t M, float* dW1, float* dW2, float* dbias, float* scratch, void* stream_,
+                                        WgradReduceDesc* desc) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DGNN_REQUIRE(M >= 0 && n_a > 0 && n_b1 > 0 && n_b2 >= 0, DGNN_E_INVALID, "linear_wgrad_bf16_cat: bad sizes");
+    DGNN_REQUIRE(dW1 && scratch && (M == 0 || (A && B1)) && ((n_b2 == 0) == (B2 == nullptr)) && (n_b2 == 0 || dW2), DGNN_E_INVALID,
+                 "linear_wgrad_bf16_cat: null pointer");
+    const int splits = wgrad_splits(M);
+    int64_t rps = dgnn_cdiv(dgnn_cdiv(M, splits), RKB) * RKB;
+    if (rps < RKB) rps = RKB;
+    const int nby1 = (int)dgnn_cdiv(n_b1, WT), nby2 = (int)dgnn_cdiv(n_b2, WT);
+    float* partials = scratch;
+    double* bias_partials = reinterpret_cast<double*>(((uintptr_t)(scratch + (int64_t)splits * n_a * (n_b1 + n_b2)) + 7) & ~(uintptr_t)7);
+    WgradCatB c;
+    c.B[0] = B1, c.B[1] = B2, c.ldb[0] = ldb1, c.ldb[1] = ldb2, c.nb[0] = n_b1, c.nb[1] = n_b2;
+    dim3 grid((unsigned)dgnn_cdiv(n_a, WT), (unsigned)(nby1 + nby2), splits);
+#define WG(TA, TB) hipLaunchKernelGGL((k_linear_wgrad_b_cat<TA, TB>), grid, dim3(256), 0, stream, (const TA*)A, lda, n_a, c, nby1, M, rps, partials, \
+                                      dbias ? bias_partials : nullptr)
+    if (a_f32 && b_f32) WG(float, float);
+    else if (a_f32) WG(float, uint16_t);
+    else if (b_f32) WG(uint16_t, float);
+    else WG(uint16_t, uint16_t);
+#undef WG
+    WgradReduceDesc d;
+    d.partials = partials, d.bias_partials = bias_partials, d.splits = splits, d.na = n_a, d.nb1 = n_b1, d.nb2 = n_b2, d.dW1 = dW1, d.dW2 = dW2, d.dbias = dbias;
+    if (desc)
+        *desc = d;
+    else
+        hipLaunchKernelGGL(k_wgrad_reduce_cat, dim3((unsigned)wgrad_reduce_blocks(d)), dim3(256), 0, stream, d);
+    return dgnn_check_launch("linear_wgrad_bf16_cat");
+}
+
+extern "C" int dgnn_linear_wgrad_bf16_cat(const void* A, int a_f32, int64_t lda, int n_a, const void* B1, int64_t ldb1, int n_b1, const void* B2, int64_t ldb2,
+                                          int n_b2, int b_f32, int64_t M, float* dW1, float* dW2, float* dbias, float* scratch, void* stream) {
+    return dgnn_linear_wgrad_bf16_cat_deferred(A, a_f32, lda, n_a, B1, ldb1, n_b1, B2, ldb2, n_b2, b_f32, M, dW1, dW2, dbias, scratch, stream, nullptr);
 }

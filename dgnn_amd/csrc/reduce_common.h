@@ -88,6 +88,8 @@ __device__ __forceinline__ void wgrad_reduce_cat_phase(const WgradReduceDesc& d,
 // deferred forms (train.hip): the first launch of the pair only, the reduction described in *desc for the caller to run
 int dgnn_linear_wgrad_x3_cat_deferred(const float* A, int64_t lda, int n_a, const float* B1, int64_t ldb1, int n_b1, const float* B2, int64_t ldb2, int n_b2,
                                       int64_t M, float* dW1, float* dW2, float* dbias, float* scratch, void* stream, WgradReduceDesc* desc);
+int dgnn_linear_wgrad_bf16_cat_deferred(const void* A, int a_f32, int64_t lda, int n_a, const void* B1, int64_t ldb1, int n_b1, const void* B2, int64_t ldb2,
+                                        int n_b2, int b_f32, int64_t M, float* dW1, float* dW2, float* dbias, float* scratch, void* stream, WgradReduceDesc* desc);
 int dgnn_sage_aggregate_bwd_add_deferred(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, int64_t n_src, const int32_t* rowptr_dst,
                                          const float* x_src, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e, const float* We,
                                          const float* be, const float* da, int64_t ldda, float* dx_src, int64_t lddx, const float* add, int64_t ldadd,

@@ -354,6 +354,12 @@ struct F32 {
                                      : dgnn_linear_wgrad_x3(A, lda, na, B, ldb, nb, M, dW, nb, 0, tmp, st);
     }
     static int colsum(const T* x, int64_t ld, int64_t M, int c, float* out, float* tmp, void* st) { return dgnn_colsum(x, ld, M, c, out, 0, tmp, st); }
+    static bool can_fuse(int mode) { return mode != DGNN_GEMM_F32; }
+    static int wgrad_cat(const T* A, int64_t lda, int na, const T* B1, int64_t ldb1, int nb1, const T* B2, int64_t ldb2, int nb2, int64_t M, float* dW1,
+                         float* dW2, float* dbias, float* tmp, void* st) {
+        return dgnn_linear_wgrad_x3_cat(A, lda, na, B1, ldb1, nb1, B2, ldb2, nb2, M, dW1, dW2, dbias, tmp, st);
+    }
+    static constexpr int kBf16 = 0;
     static int relu_bwd(const T* y, const T* g, int64_t n, T* out, void* st) { return dgnn_relu_bwd(y, g, n, out, st); }
     static int agg_fwd(const int32_t* rp, const int32_t* src, const int32_t* eid, int64_t n_dst, const T* x, int64_t ldx, int c, const T* phi, T* a, void* st) {
         return dgnn_sage_aggregate_fwd(rp, src, eid, n_dst, x, ldx, c, nullptr, 0, 0, nullptr, nullptr, phi, c, nullptr, 0, a, c, st);
@@ -373,6 +379,12 @@ struct BF16 {
         return dgnn_linear_wgrad_bf16(A, 0, lda, na, B, 0, ldb, nb, M, dW, nb, 0, tmp, st);
     }
     static int colsum(const T* x, int64_t ld, int64_t M, int c, float* out, float* tmp, void* st) { return dgnn_colsum_bf16(x, ld, M, c, out, 0, tmp, st); }
+    static bool can_fuse(int) { return true; }
+    static int wgrad_cat(const T* A, int64_t lda, int na, const T* B1, int64_t ldb1, int nb1, const T* B2, int64_t ldb2, int nb2, int64_t M, float* dW1,
+                         float* dW2, float* dbias, float* tmp, void* st) {
+        return dgnn_linear_wgrad_bf16_cat(A, 0, lda, na, B1, ldb1, nb1, B2, ldb2, nb2, 0, M, dW1, dW2, dbias, tmp, st);
+    }
+    static constexpr int kBf16 = 1;
     static int relu_bwd(const T* y, const T* g, int64_t n, T* out, void* st) { return dgnn_relu_bwd_bf16(y, g, n, out, st); }
     static int agg_fwd(const int32_t* rp, const int32_t* src, const int32_t* eid, int64_t n_dst, const T* x, int64_t ldx, int c, const T* phi, T* a, void* st) {
         return dgnn_sage_aggregate_fwd_bf16(rp, src, eid, n_dst, x, ldx, c, nullptr, 0, 0, nullptr, nullptr, phi, c, nullptr, 0, a, c, st);
@@ -430,6 +442,46 @@ int updated_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_
         TRY(K::relu_bwd(y, dy, n_dst * c_out, dz, st));
         g = dz;
     }
+    if (!aux && fused_enabled() && K::can_fuse(mode)) {
+        // The launch chain of the Static layer's fused backward (layer_bwd) for this variant: dWl / dWr / dbl from one launch pair, the three
+        // transposes from one launch, [da | dz.Wr] from one GEMM against the stacked [Wl^T ; Wr^T] with the second half added where the
+        // aggregate backward stores dx and dphi_ext added where it stores dphi, dWe / dbe from one launch pair.  `da` holds [n_dst, 2 c_in].
+        const bool both = dx && Wr;
+        TrJobs jobs;
+        jobs.n = 0;
+        int total = 0;
+        auto job = [&](const float* in, float* out, int rows, int cols) {
+            const int j = jobs.n++;
+            jobs.in[j] = in, jobs.out[j] = out, jobs.rows[j] = rows, jobs.cols[j] = cols;
+            total += rows * cols;
+            jobs.end[j] = total;
+        };
+        float* WrS = WlT + (int64_t)c_in * c_out;      // stacked right under Wl^T (the region of WrT begins at or after it)
+        job(Wl, WlT, c_out, c_in);
+        if (both) job(Wr, WrS, c_out, c_in);
+        if (E > 0 && d_ea) job(We, WeT, c_in, k_e);
+        hipLaunchKernelGGL(k_transpose_many, dim3(dgnn_grid_cap(dgnn_cdiv(total, 256))), dim3(256), 0, stream, jobs);
+        const T* B2 = (Wr && dWr) ? x : nullptr;
+        TRY(K::wgrad_cat(g, c_out, c_out, a, c_in, c_in, B2, ldx, B2 ? c_in : 0, n_dst, dWl, dWr, dbl, tmp, st));
+        const T* ext = E > 0 ? dphi_ext : nullptr;
+        if (both) {
+            TRY(K::linear(g, c_out, c_out, WlT, c_out, nullptr, 0, 0, nullptr, 0, nullptr, 0, n_dst, 2 * c_in, da, 2 * c_in, mode, st));
+            TRY(dgnn_sage_aggregate_bwd_phi_add(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x, ldx, c_in, phi, c_in, da, 2 * c_in, dx, c_in, da + c_in, 2 * c_in,
+                                                n_dst, dphi, c_in, ext, K::kBf16, st));
+        } else {
+            TRY(K::linear(g, c_out, c_out, WlT, c_out, nullptr, 0, 0, nullptr, 0, nullptr, 0, n_dst, c_in, da, c_in, mode, st));
+            TRY(dgnn_sage_aggregate_bwd_phi_add(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x, ldx, c_in, phi, c_in, da, c_in, dx, c_in, nullptr, 0, 0, dphi, c_in,
+                                                ext, K::kBf16, st));
+        }
+        if (E > 0) {
+            TRY(K::wgrad_cat(dphi, c_in, c_in, ea, lde, k_e, nullptr, 0, 0, E, dWe, nullptr, dbe, tmp, st));
+            if (d_ea) TRY(K::linear(dphi, c_in, c_in, WeT, c_in, nullptr, 0, 0, nullptr, 0, nullptr, 0, E, k_e, d_ea, k_e, mode, st));
+        } else {
+            (void)hipMemsetAsync(dWe, 0, sizeof(float) * (size_t)c_in * k_e, stream);
+            (void)hipMemsetAsync(dbe, 0, sizeof(float) * (size_t)c_in, stream);
+        }
+        return dgnn_check_launch("sage_updated_train_bwd");
+    }
     fork();   // also orders the second stream behind whatever used `scratch` before on `stream`
     TRY(K::wgrad(g, c_out, c_out, a, c_in, c_in, n_dst, dWl, tmp, mode, ws));
     if (dbl) TRY(K::colsum(g, c_out, n_dst, c_out, dbl, tmp, ws));
@@ -468,7 +520,7 @@ int updated_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_
 extern "C" int64_t dgnn_sage_updated_train_scratch_elems(int64_t n_dst, int64_t E, int c_in, int c_out, int k_e) {
     if (n_dst < 0 || E < 0 || c_in <= 0 || c_out <= 0 || k_e <= 0) return 16;
     int64_t big = dgnn_colstats_scratch_elems(n_dst > E ? n_dst : E, c_in > c_out ? c_in : c_out);
-    const int64_t w1 = dgnn_linear_wgrad_scratch_elems(n_dst, c_out, c_in), w2 = dgnn_linear_wgrad_scratch_elems(E, c_in, k_e);
+    const int64_t w1 = dgnn_linear_wgrad_cat_scratch_elems(n_dst, c_out, c_in, c_in), w2 = dgnn_linear_wgrad_cat_scratch_elems(E, c_in, k_e, 0);
     if (w1 > big) big = w1;
     if (w2 > big) big = w2;
     return 2 * align4((int64_t)c_in * c_out) + align4((int64_t)c_in * k_e) + align4(big) + 64;
@@ -661,6 +713,95 @@ extern "C" int dgnn_static_train_bwd(int n_layers, const int32_t* const* t_rowpt
         for (int l = 0; l < n_layers; ++l)
             if (done[l]) (void)hipStreamWaitEvent(stream, done[l], 0);
     return rc;
+}
+
+// =====================================================================================================================
+// All conv layers of the Updated variant per call (surfaceNetUpdatedEdgeFilters.py:229-243 and its autograd): the per-layer composite calls
+// above and the edge chaining between them (chain.hip) issued back to back from C++ -- one autograd node for the stack instead of three per
+// layer (edge rows, cast, conv): the step was bound by the ~16 Python-level nodes each way.  The same kernels in the same order as the
+// per-layer path (bit-identical results).
+//   ea_0 = edge_attr_all[rows0, :edge_in_0]                        (:237; bf16 storage: cast once)
+//   ea_l = relu(zeros[E_all, C]; [e_id_{l-1}] = phi_{l-1})[e_id_l, :edge_in_l]      (:233-241, only the rows that are read)
+//   (y_l, phi_l) = conv_l(x_l, ea_l), x_{l+1} = relu?(y_l)
+// Backward: layer l's d_ea goes through the chaining's backward into dphi_ext of layer l-1.
+// =====================================================================================================================
+extern "C" int dgnn_updated_stack_fwd(int n_layers, const int32_t* const* rowptr, const int32_t* const* src, const int32_t* const* eid,
+                                      const int64_t* const* e_id, const int32_t* rows0, const int64_t* n_dst, const int64_t* E, const void* x0,
+                                      int64_t ldx0, const int32_t* widths, const int32_t* edge_in, const float* edge_attr_all, int64_t lde_all,
+                                      int64_t E_all, int32_t* pos, const float* const* We, const float* const* be, const float* const* Wl,
+                                      const float* const* bl, const float* const* Wr, const int32_t* relu, void* const* ea, const int64_t* ld_ea,
+                                      float* ea0_f32, void* const* phi, void* const* a, void* const* y, int32_t* const* inv, int bf16, int gemm_mode,
+                                      void* stream) {
+    DGNN_REQUIRE(n_layers >= 1 && n_layers <= 8 && rowptr && src && eid && e_id && rows0 && n_dst && E && x0 && widths && edge_in && edge_attr_all && pos &&
+                     We && be && Wl && bl && Wr && relu && ea && ld_ea && phi && a && y && inv && (!bf16 || ea0_f32),
+                 DGNN_E_INVALID, "updated_stack_fwd: bad args (at most 8 layers)");
+    const void* x = x0;
+    int64_t ldx = ldx0;
+    for (int l = 0; l < n_layers; ++l) {
+        const int c_in = widths[l], c_out = widths[l + 1], k = edge_in[l];
+        if (l == 0) {
+            if (E[0] > 0) {
+                if (bf16) {
+                    TRY(dgnn_gather_rows_f32(edge_attr_all, lde_all, rows0, E[0], k, ea0_f32, k, stream));
+                    TRY(dgnn_cast_f32_to_bf16(ea0_f32, k, E[0], k, (int)ld_ea[0], (uint16_t*)ea[0], ld_ea[0], stream));
+                } else {
+                    TRY(dgnn_gather_rows_f32(edge_attr_all, lde_all, rows0, E[0], k, (float*)ea[0], ld_ea[0], stream));
+                }
+            }
+        } else if (E[l] > 0 || E[l - 1] > 0) {
+            DGNN_REQUIRE(inv[l], DGNN_E_INVALID, "updated_stack_fwd: inv[%d] missing", l);
+            if (bf16)
+                TRY(dgnn_edge_chain_fwd_bf16((const uint16_t*)phi[l - 1], widths[l - 1], k, e_id[l - 1], E[l - 1], e_id[l], E[l], E_all, pos, 1, (uint16_t*)ea[l],
+                                             ld_ea[l], inv[l], stream));
+            else
+                TRY(dgnn_edge_chain_fwd((const float*)phi[l - 1], widths[l - 1], k, e_id[l - 1], E[l - 1], e_id[l], E[l], E_all, pos, 1, (float*)ea[l], ld_ea[l],
+                                        inv[l], stream));
+        }
+        TRY(dgnn_sage_updated_train_fwd(rowptr[l], src[l], eid[l], n_dst[l], x, ldx, c_in, ea[l], ld_ea[l], k, E[l], We[l], be[l], Wl[l], bl[l], Wr[l], c_out,
+                                        relu[l], phi[l], a[l], y[l], bf16, gemm_mode, stream));
+        x = y[l];
+        ldx = c_out;
+    }
+    return dgnn_check_launch("updated_stack_fwd");
+}
+
+// scratch: max over the layers of dgnn_sage_updated_train_scratch_elems.  Work buffers (storage type): dx_buf[0], dx_buf[1] (max n_src * c_in
+// over the layers l >= 1), d_ea (max E_l * edge_in_l, l >= 1), dphi_ext (max E_l * c_in_l, l < n_layers - 1), dz (max n_dst * c_out), da
+// (max 2 * n_dst * c_in), dphi (max E_l * c_in_l).
+extern "C" int dgnn_updated_stack_bwd(int n_layers, const int32_t* const* t_rowptr, const int32_t* const* t_dst, const int32_t* const* t_eid,
+                                      const int32_t* const* rowptr_dst, const int64_t* n_src, const int64_t* n_dst, const int64_t* E, const void* x0,
+                                      int64_t ldx0, const int32_t* widths, const int32_t* edge_in, const float* const* We, const float* const* Wl,
+                                      const float* const* Wr, const int32_t* relu, const void* const* ea, const int64_t* ld_ea, const void* const* phi,
+                                      const void* const* a, const void* const* y, const int32_t* const* inv, const void* dy, float* const* dWe,
+                                      float* const* dbe, float* const* dWl, float* const* dbl, float* const* dWr, void* const* dx_buf, void* d_ea,
+                                      void* dphi_ext, void* dz, void* da, void* dphi, float* scratch, int bf16, int gemm_mode, void* stream) {
+    DGNN_REQUIRE(n_layers >= 1 && n_layers <= 8 && t_rowptr && t_dst && t_eid && rowptr_dst && n_src && n_dst && E && x0 && widths && edge_in && We && Wl && Wr &&
+                     relu && ea && ld_ea && phi && a && y && inv && dy && dWe && dbe && dWl && dbl && dWr && dx_buf && dz && da && dphi && scratch &&
+                     (n_layers == 1 || (d_ea && dphi_ext && dx_buf[0] && dx_buf[1])),
+                 DGNN_E_INVALID, "updated_stack_bwd: bad args");
+    const void* g = dy;
+    bool have_ext = false;
+    for (int l = n_layers - 1; l >= 0; --l) {
+        const int c_in = widths[l], c_out = widths[l + 1], k = edge_in[l];
+        const void* x = l == 0 ? x0 : y[l - 1];
+        const int64_t ldx = l == 0 ? ldx0 : c_in;
+        void* dx = l == 0 ? nullptr : dx_buf[l & 1];
+        TRY(dgnn_sage_updated_train_bwd(t_rowptr[l], t_dst[l], t_eid[l], rowptr_dst[l], n_src[l], n_dst[l], E[l], x, ldx, c_in, ea[l], ld_ea[l], k, We[l], Wl[l],
+                                        Wr[l], c_out, relu[l], phi[l], a[l], y[l], g, have_ext ? dphi_ext : nullptr, dx, l > 0 ? d_ea : nullptr, dWe[l], dbe[l],
+                                        dWl[l], dbl[l], dWr[l], dz, da, dphi, scratch, bf16, gemm_mode, stream));
+        have_ext = false;
+        if (l > 0 && E[l - 1] > 0) {   // layer l's edge rows came out of phi_{l-1}: their gradient is what layer l-1 adds to its dphi
+            if (bf16)
+                TRY(dgnn_edge_chain_bwd_bf16((const uint16_t*)d_ea, k, (const uint16_t*)phi[l - 1], widths[l - 1], inv[l], E[l - 1], k, widths[l - 1], 1,
+                                             (uint16_t*)dphi_ext, widths[l - 1], stream));
+            else
+                TRY(dgnn_edge_chain_bwd((const float*)d_ea, k, (const float*)phi[l - 1], widths[l - 1], inv[l], E[l - 1], k, widths[l - 1], 1, (float*)dphi_ext,
+                                        widths[l - 1], stream));
+            have_ext = true;
+        }
+        g = dx;
+    }
+    return dgnn_check_launch("updated_stack_bwd");
 }
 
 // Which of the training step's fused launch chains run (bit 0: backward chain, bit 1: batch statistics from the forward GEMM's epilogue;

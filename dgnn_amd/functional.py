@@ -257,6 +257,42 @@ def sage_updated_layer(x, plan, ea, lin_e, lin_l, lin_r, relu):
     return _SageUpdatedLayer.apply(x, ea, lin_e.weight, lin_e.bias, lin_l.weight, lin_l.bias, lin_r.weight if lin_r is not None else None, plan, relu)
 
 
+class _UpdatedConvStack(torch.autograd.Function):
+    """All conv layers of the Updated variant with the edge chaining between them (reference surfaceNetUpdatedEdgeFilters.py:229-243): one library
+    call forward, one backward (dgnn_updated_stack_fwd / _bwd = the per-layer composite calls and the chaining issued back to back from C++).
+    Tensor inputs: x0, then (We, be, Wl, bl, Wr) per layer (None where a layer has none)."""
+
+    @staticmethod
+    def forward(ctx, x0, edge_attr_all, pos, spec, *params):
+        layers = []
+        for i, sp in enumerate(spec):
+            We, be, Wl, bl, Wr = params[5 * i:5 * i + 5]
+            layers.append(dict(plan=sp["plan"], e_id=sp["e_id"], rows0=sp.get("rows0"), edge_in=sp["edge_in"], relu=sp["relu"], We=We, be=be, Wl=Wl, bl=bl, Wr=Wr))
+        y, saved = ops.updated_stack_fwd(x0, edge_attr_all, pos, layers)
+        ctx.layers, ctx.saved = layers, saved
+        ctx.edge_indices = [sp["plan"].edge_index for sp in spec]     # lazily built transposed plans read them
+        ctx.save_for_backward(x0)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x0,) = ctx.saved_tensors
+        grads = ops.updated_stack_bwd(x0, ctx.layers, ctx.saved, dy.contiguous())
+        out = [None, None, None, None]
+        for g in grads:
+            out += list(g)
+        return tuple(out)
+
+
+def updated_conv_stack(x0, edge_attr_all, pos, spec):
+    """spec: per layer dict(plan, e_id int64 [E_l], rows0 (layer 0: e_id as int32), edge_in, relu, lin_e, lin_l, lin_r | None)"""
+    params = []
+    for sp in spec:
+        le, ll, lr = sp["lin_e"], sp["lin_l"], sp["lin_r"]
+        params += [le.weight, le.bias, ll.weight, ll.bias, lr.weight if lr is not None else None]
+    return _UpdatedConvStack.apply(x0, edge_attr_all, pos, spec, *params)
+
+
 def sage_updated_layer_supported(x, ea, lin_e) -> bool:
     return (ops.TRAIN_COMPOSITE and x.dim() == 2 and x.dtype in ops.ACT and x.stride(1) == 1 and x.size(0) > 0 and ea.dim() == 2 and ea.dtype == x.dtype
             and ea.stride(1) == 1 and lin_e.bias is not None and (x.dtype == torch.float32 or (x.size(1) % 2 == 0 and x.stride(0) % 2 == 0)))

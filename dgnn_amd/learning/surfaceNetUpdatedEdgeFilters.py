@@ -125,7 +125,8 @@ class SurfaceNet(nn.Module):
         n_edges = edge_attr.size(0)
         phi = e_prev = None
         plus = self.clf.training.model_name[-1] == "+"
-        for i in range(self.num_layers):
+        x_stack = self._conv_stack(x, edge_attr, data_all.adjs, dev, plus)
+        for i in range(self.num_layers if x_stack is None else 0):
             edge_index, e_id, size = data_all.adjs[i]
             e_id = e_id.to(dev)
             conv = self.convs[i]
@@ -148,12 +149,43 @@ class SurfaceNet(nn.Module):
                 if relu_after:
                     x = Fn.relu(x)  # after the last layer: F.relu(x) and out_net[0], another ReLU -- relu(relu(x)) == relu(x)
             e_prev = e_id
+        if x_stack is not None:
+            x = x_stack
         # (the last layer's new_edge_attr, :236-237, is never read)
         if plus:                                                                      # :245-247
             x = Fn.linear2(x, self.out_net[1].weight, bias=self.out_net[1].bias)
             x = Fn.relu(x)
             x = Fn.linear2(x, self.out_net[3].weight, bias=self.out_net[3].bias, out_f32=True)
         return x.float() if x.dtype == torch.bfloat16 else x
+
+    def _conv_stack(self, x, edge_attr, adjs, dev, plus):
+        """All conv layers and the edge chaining between them through ONE library call each way (Fn.updated_conv_stack) when every layer takes the
+        composite form: sparse chaining, no output normalisation, lin_e with a bias, even widths in bf16 storage.  Returns the last layer's
+        activations, or None (the per-layer path then runs)."""
+        from .. import ops
+        if not (ops.UPDATED_STACK and ops.TRAIN_COMPOSITE and CHAIN_SPARSE) or self.num_layers > 8 or x.dim() != 2 or x.size(0) == 0 or x.stride(1) != 1:
+            return None
+        bf = x.dtype == torch.bfloat16
+        if x.dtype not in ops.ACT or edge_attr.dtype != torch.float32 or edge_attr.dim() != 2 or edge_attr.stride(1) != 1 or not edge_attr.is_cuda:
+            return None
+        spec, c, n_src = [], x.size(1), x.size(0)
+        for i in range(self.num_layers):
+            edge_index, e_id, size = adjs[i]
+            conv = self.convs[i]
+            k = conv.edge_in_channels
+            if conv.normalize or conv.lin_e.bias is None or e_id is None or size[0] != n_src or conv.lin_l.in_features != c or (bf and (c % 2 or k % 2)) \
+                    or (i == 0 and k > edge_attr.size(1)) or (i > 0 and k > self.convs[i - 1].lin_l.in_features):
+                return None
+            if bf and i == 0 and x.stride(0) % 2:
+                return None
+            e_id = e_id.to(dev)
+            plan = plan_for(edge_index.to(dev), size[0], size[1])
+            sp = dict(plan=plan, e_id=e_id, edge_in=k, relu=(i < self.num_layers - 1) or plus, lin_e=conv.lin_e, lin_l=conv.lin_l, lin_r=conv.lin_r)
+            if i == 0:   # the block builder's plans carry e_id as int32 already
+                sp["rows0"] = plan.edge_rows if plan.has_edge_rows else e_id.to(torch.int32)
+            spec.append(sp)
+            c, n_src = conv.lin_l.out_features, size[1]
+        return Fn.updated_conv_stack(x, edge_attr, self._chain_table(edge_attr.size(0), dev), spec)
 
     def _unsupported(self, *a, **k):
         raise NotImplementedError("the reference's surfaceNetUpdatedEdgeFilters.inference_* methods call the conv without "

@@ -676,6 +676,107 @@ def sage_layer_train_bwd(t_parts, rowptr_dst, n_src, n_dst, x, edge_attr, We, be
     return (dx, dWe, dbe, dWj, dbj, dWi, dgamma, dbeta)
 
 
+# ---- all conv layers of the Updated variant per call (csrc/train.hip: dgnn_updated_stack_fwd / _bwd) ---------------------------------------
+UPDATED_STACK = __import__("os").environ.get("DGNN_UPDATED_STACK", "1") != "0"
+
+
+@on_device_of
+def updated_stack_fwd(x0, edge_attr_all, pos, layers):
+    """`layers`: per conv layer a dict with plan (GraphPlan), e_id (int64 [E_l], rows of the scene's edge tensor), rows0 (int32 form of e_id, layer 0),
+    edge_in, relu, We, be, Wl, bl, Wr.  -> (y_last, saved): every layer's ea / phi / a / y (+ the chaining's inverse maps) in one buffer."""
+    import ctypes as C
+    _req(x0, "x", ACT, dim=2)
+    _req(edge_attr_all, "edge_attr", dim=2)
+    dev, dt, L = x0.device, x0.dtype, len(layers)
+    bf = dt == torch.bfloat16
+    widths = [x0.size(1)] + [l["Wl"].size(0) for l in layers]
+    esz = 2 if bf else 4
+    offs, off = [], 0          # byte offsets into one buffer, every piece 16-byte aligned
+
+    def take(nbytes):
+        nonlocal off
+        o = off
+        off += (nbytes + 15) & ~15
+        return o
+    for i, l in enumerate(layers):
+        p = l["plan"]
+        E, n, ci, co, k = p.E, p.n_dst, widths[i], widths[i + 1], l["edge_in"]
+        if l["Wl"].size(1) != ci or l["We"].size(0) != ci or l["We"].size(1) != k:
+            raise ValueError("Updated conv %d: lin_e %s / lin_l %s do not match %d input channels, %d edge columns" % (i, tuple(l["We"].shape), tuple(l["Wl"].shape), ci, k))
+        ld_ea = (k + 1) // 2 * 2 if (bf and i == 0) else k
+        offs.append(dict(ea=take(max(E, 1) * ld_ea * esz), ld_ea=ld_ea, phi=take(max(E, 1) * ci * esz), a=take(n * ci * esz), y=take(n * co * esz),
+                         inv=take(4 * max(layers[i - 1]["plan"].E, 1)) if i else None))
+    ea0 = take(4 * max(layers[0]["plan"].E, 1) * layers[0]["edge_in"]) if bf else None
+    buf = torch.empty(off, dtype=torch.uint8, device=dev)
+    base = buf.data_ptr()
+    at = lambda o: None if o is None else base + o
+    parts = [l["plan"].part_ptrs(False) for l in layers]
+    arr = lambda k: _parr([l[k] for l in layers])
+    i64 = lambda v: _iarr(v, C.c_int64)
+    i32 = lambda v: _iarr(v, C.c_int32)
+    check(lib().dgnn_updated_stack_fwd(
+        L, _parr([p[0] for p in parts]), _parr([p[1] for p in parts]), _parr([p[2] for p in parts]), arr("e_id"), ptr(layers[0]["rows0"]),
+        i64([l["plan"].n_dst for l in layers]), i64([l["plan"].E for l in layers]), ptr(x0), _ld(x0), i32(widths), i32([l["edge_in"] for l in layers]),
+        ptr(edge_attr_all), _ld(edge_attr_all), edge_attr_all.size(0), ptr(pos), arr("We"), arr("be"), arr("Wl"), arr("bl"), arr("Wr"),
+        i32([int(bool(l["relu"])) for l in layers]), _parr([at(o["ea"]) for o in offs]), i64([o["ld_ea"] for o in offs]), at(ea0),
+        _parr([at(o["phi"]) for o in offs]), _parr([at(o["a"]) for o in offs]), _parr([at(o["y"]) for o in offs]), _parr([at(o["inv"]) for o in offs]),
+        int(bf), GEMM_MODE, stream_ptr()), "dgnn_updated_stack_fwd", poll=True)
+    n, co = layers[-1]["plan"].n_dst, widths[-1]
+    y = torch.as_strided(buf.view(dt), (n, co), (co, 1), offs[-1]["y"] // esz)
+    return y, (buf, offs, widths)
+
+
+@on_device_of
+def updated_stack_bwd(x0, layers, saved, dy):
+    """-> per layer (dWe, dbe, dWl, dbl | None, dWr | None): views of one fp32 buffer"""
+    import ctypes as C
+    buf, offs, widths = saved
+    dev, dt, L = x0.device, x0.dtype, len(layers)
+    bf = dt == torch.bfloat16
+    base = buf.data_ptr()
+    at = lambda o: None if o is None else base + o
+    sizes, off = [], 0
+    for i, l in enumerate(layers):
+        ci, co, k = widths[i], widths[i + 1], l["edge_in"]
+        row = []
+        for sz in (ci * k, ci, co * ci, co if l["bl"] is not None else 0, co * ci if l["Wr"] is not None else 0):
+            row.append((off, sz) if sz else None)
+            off += sz
+        sizes.append(row)
+    flat = torch.empty(off, dtype=torch.float32, device=dev)
+    gbase = flat.data_ptr()
+    gat = lambda e: None if e is None else gbase + 4 * e[0]
+    P = [l["plan"] for l in layers]
+    mx = lambda vals: max(list(vals) + [1])
+    work = lambda n: torch.empty(n, dtype=dt, device=dev)
+    dxb = [work(mx(P[i].n_src * widths[i] for i in range(1, L))) for _ in range(2)] if L > 1 else [None, None]
+    d_ea = work(mx(P[i].E * layers[i]["edge_in"] for i in range(1, L))) if L > 1 else None
+    dphi_ext = work(mx(P[i].E * widths[i] for i in range(L - 1))) if L > 1 else None
+    dz, da = work(mx(P[i].n_dst * widths[i + 1] for i in range(L))), work(mx(2 * P[i].n_dst * widths[i] for i in range(L)))
+    dphi = work(mx(P[i].E * widths[i] for i in range(L)))
+    scratch = _f32(max(lib().dgnn_sage_updated_train_scratch_elems(P[i].n_dst, P[i].E, widths[i], widths[i + 1], layers[i]["edge_in"]) for i in range(L)), dev)
+    tps = [p.transposed_ptrs(False) for p in P]
+    arr = lambda k: _parr([l[k] for l in layers])
+    i64 = lambda v: _iarr(v, C.c_int64)
+    i32 = lambda v: _iarr(v, C.c_int32)
+    col = lambda j: _parr([gat(r[j]) for r in sizes])
+    check(lib().dgnn_updated_stack_bwd(
+        L, _parr([t[0] for t in tps]), _parr([t[1] for t in tps]), _parr([t[2] for t in tps]), _parr([p.part_ptrs(False)[0] for p in P]),
+        i64([p.n_src for p in P]), i64([p.n_dst for p in P]), i64([p.E for p in P]), ptr(x0), _ld(x0), i32(widths), i32([l["edge_in"] for l in layers]),
+        arr("We"), arr("Wl"), arr("Wr"), i32([int(bool(l["relu"])) for l in layers]), _parr([at(o["ea"]) for o in offs]), i64([o["ld_ea"] for o in offs]),
+        _parr([at(o["phi"]) for o in offs]), _parr([at(o["a"]) for o in offs]), _parr([at(o["y"]) for o in offs]), _parr([at(o["inv"]) for o in offs]),
+        ptr(dy), col(0), col(1), col(2), col(3), col(4), _parr(dxb), ptr(d_ea), ptr(dphi_ext), ptr(dz), ptr(da), ptr(dphi), ptr(scratch), int(bf), GEMM_MODE,
+        stream_ptr()), "dgnn_updated_stack_bwd")
+    st = torch.as_strided
+    grads = []
+    for i, (l, row) in enumerate(zip(layers, sizes)):
+        ci, co, k = widths[i], widths[i + 1], l["edge_in"]
+        m = lambda e, r, c: None if e is None else st(flat, (r, c), (c, 1), e[0])
+        v = lambda e, n: None if e is None else st(flat, (n,), (1,), e[0])
+        grads.append((m(row[0], ci, k), v(row[1], ci), m(row[2], co, ci), v(row[3], co), m(row[4], co, ci)))
+    return grads
+
+
 # ---- edge-embedding chaining of the Updated variant (csrc/chain.hip) ---------------------------------------------------------
 @on_device_of
 def edge_chain_fwd(phi, e_id_cur, e_id_next, c, pos, relu):
@@ -772,7 +873,7 @@ def sage_updated_train_bwd(t_parts, rowptr_dst, n_src, n_dst, x, ea, We, Wl, Wr,
     dx = torch.empty((n_src, c_in), dtype=dt, device=dev) if need_dx else None
     d_ea = torch.empty((E, k_e), dtype=dt, device=dev) if need_dea else None
     dz = torch.empty((n_dst, c_out), dtype=dt, device=dev) if relu else None
-    da = torch.empty((n_dst, c_in), dtype=dt, device=dev)
+    da = torch.empty((n_dst, 2 * c_in), dtype=dt, device=dev)     # [da | dz . Wr] of the merged input-gradient GEMM
     dphi = torch.empty((max(E, 1), c_in), dtype=dt, device=dev)
     scratch = _f32(lib().dgnn_sage_updated_train_scratch_elems(n_dst, E, c_in, c_out, k_e), dev)
     t_rowptr, t_dst, t_eid = t_parts

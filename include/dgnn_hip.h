@@ -223,6 +223,20 @@ int dgnn_sage_aggregate_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const
                             int64_t lddx, float* dWe, float* dbe, float* dphi_out, int64_t lddphi, float* partials,
                             void* stream);
 
+/* bf16-storage form of dgnn_linear_wgrad_x3_cat (A, B1, B2 bf16, or fp32 rounded to bf16 when staged: a_f32 / b_f32 = 1): one bf16 product per
+ * element, dW1 / dW2 bit-identical to dgnn_linear_wgrad_bf16; same scratch size function. */
+int dgnn_linear_wgrad_bf16_cat(const void* A, int a_f32, int64_t lda, int n_a, const void* B1, int64_t ldb1, int n_b1, const void* B2, int64_t ldb2,
+                               int n_b2, int b_f32, int64_t M, float* dW1, float* dW2, float* dbias, float* scratch, void* stream);
+
+/* Given-phi form of the aggregate backward (the Updated variant, surfaceNetUpdatedEdgeFilters.py:147-170) with the two additions of its conv
+ * layer's backward folded into the stores: dx_src[row] += add[row] for row < n_add (add NULL: none) and dphi_out[e] = dphi_e + dphi_ext[e]
+ * (dphi_ext NULL: none; :233-241: the next layer takes this layer's phi as its edge input and sends a gradient back to it).  bf16 = 1: bf16
+ * storage of x, phi, da, dx, add, dphi. */
+int dgnn_sage_aggregate_bwd_phi_add(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, int64_t n_src, const int32_t* rowptr_dst,
+                                    const void* x_src, int64_t ldx, int c_in, const void* phi, int64_t ldphi, const void* da, int64_t ldda,
+                                    void* dx_src, int64_t lddx, const void* add, int64_t ldadd, int64_t n_add, void* dphi_out, int64_t lddphi,
+                                    const void* dphi_ext, int bf16, void* stream);
+
 /* dgnn_sage_aggregate_bwd in fused mode (f_e = 20, fp32) with `dx_src[row] += add[row]` for row < n_add folded into the store of dx_src:
  * the x_dst = x[:n_dst] branch of a conv layer (:217, lin_i) sends its gradient dz . Wi to the first n_dst rows of dx; the addend is
  * added to the finished sum in one fp32 addition, like an accumulating GEMM epilogue after the aggregate would. */
@@ -390,6 +404,29 @@ int dgnn_train_set_aux_stream(int on);
  * (dgnn_linear_fwd_x3_stats).  Default 3 (environment: DGNN_TRAIN_FUSED=<mask>); 0 = the launch chain of the separate entry points.
  * Returns the previous mask. */
 int dgnn_train_set_fused(int mask);
+
+/* All conv layers of the Updated variant (learning/surfaceNetUpdatedEdgeFilters.py:229-243) and the edge chaining between them per call: the
+ * per-layer composite calls (dgnn_sage_updated_train_fwd / _bwd) and dgnn_edge_chain_fwd / _bwd issued back to back, results bit-identical to
+ * calling them one by one.  Per layer l: plan (rowptr, src, eid), e_id[l] = the block edges' rows in the scene's edge tensor (int64; rows0 = e_id[0]
+ * as int32), n_dst, E; widths[0 .. n_layers], edge_in[l] = columns of the layer's edge input (layer 0: of edge_attr_all, layer l: of phi_{l-1});
+ * pos: the int32 [E_all] table of dgnn_edge_chain_fwd (all -1 between calls); relu[l]: the ReLU that follows conv l.  Saved for the backward:
+ * ea[l] [E_l, ld_ea[l]], phi[l] [E_l, widths[l]], a[l] [n_dst_l, widths[l]], y[l] [n_dst_l, widths[l+1]], inv[l] [E_{l-1}] (l >= 1).
+ * bf16 = 1: bf16 storage of x0 and of every saved tensor (ea0_f32: an [E_0, edge_in_0] fp32 work buffer for the cast).  Work buffers of the backward
+ * (storage type): dx_buf[0 / 1] [max_l>=1 n_src_l * widths[l]], d_ea [max_l>=1 E_l * edge_in_l], dphi_ext and dphi [max_l E_l * widths[l]],
+ * dz [max n_dst_l * widths[l+1]], da [max 2 * n_dst_l * widths[l]]; scratch: the largest dgnn_sage_updated_train_scratch_elems of the layers. */
+int dgnn_updated_stack_fwd(int n_layers, const int32_t* const* rowptr, const int32_t* const* src, const int32_t* const* eid, const int64_t* const* e_id,
+                           const int32_t* rows0, const int64_t* n_dst, const int64_t* E, const void* x0, int64_t ldx0, const int32_t* widths,
+                           const int32_t* edge_in, const float* edge_attr_all, int64_t lde_all, int64_t E_all, int32_t* pos, const float* const* We,
+                           const float* const* be, const float* const* Wl, const float* const* bl, const float* const* Wr, const int32_t* relu,
+                           void* const* ea, const int64_t* ld_ea, float* ea0_f32, void* const* phi, void* const* a, void* const* y, int32_t* const* inv,
+                           int bf16, int gemm_mode, void* stream);
+int dgnn_updated_stack_bwd(int n_layers, const int32_t* const* t_rowptr, const int32_t* const* t_dst, const int32_t* const* t_eid,
+                           const int32_t* const* rowptr_dst, const int64_t* n_src, const int64_t* n_dst, const int64_t* E, const void* x0, int64_t ldx0,
+                           const int32_t* widths, const int32_t* edge_in, const float* const* We, const float* const* Wl, const float* const* Wr,
+                           const int32_t* relu, const void* const* ea, const int64_t* ld_ea, const void* const* phi, const void* const* a,
+                           const void* const* y, const int32_t* const* inv, const void* dy, float* const* dWe, float* const* dbe, float* const* dWl,
+                           float* const* dbl, float* const* dWr, void* const* dx_buf, void* d_ea, void* dphi_ext, void* dz, void* da, void* dphi,
+                           float* scratch, int bf16, int gemm_mode, void* stream);
 int64_t dgnn_static_train_scratch_elems(int n_layers, const int64_t* n_src, const int64_t* n_dst, const int32_t* widths, int f_e);
 int dgnn_static_train_bwd(int n_layers, const int32_t* const* t_rowptr, const int32_t* const* t_dst, const int32_t* const* t_eid,
                           const int32_t* const* rowptr_dst, const int64_t* n_src, const int64_t* n_dst, const float* x0, int64_t ldx0,

@@ -10,6 +10,7 @@ Stated tolerance on logits against the fp32 reference (SURVEY 8c asks for 5e-2 a
 The plain single-product mode (DGNN_BF16_MODE=single) is ~2x further out (rms 1.0e-2, max 1.1e-1, 99.86 % agreement) and is
 held to 2x these bounds.  Kernel-level checks compare each bf16 op with the SAME op evaluated in fp64 on the inputs as the
 kernel sees them, so those bounds are tight."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -369,3 +370,83 @@ def test_updated_variant_bf16_forward_backward():
                     continue
                 cos = float((q @ r_) / (q.norm() * r_.norm()))
                 assert cos > 0.99 and 0.9 < float(q.norm() / r_.norm()) < 1.1, (k, cos, float(q.norm() / r_.norm()))
+
+
+@pytest.mark.parametrize("M,na,nb1,nb2,a_f32", [(5000, 128, 128, 128, 0), (333, 64, 28, 28, 0), (70000, 128, 64, 64, 0), (2048, 2, 64, 0, 1), (40000, 64, 20, 0, 0)])
+def test_merged_bf16_weight_gradient_launch_matches_the_separate_calls(M, na, nb1, nb2, a_f32):
+    """dgnn_linear_wgrad_bf16_cat: dW1 / dW2 bit for bit dgnn_linear_wgrad_bf16 (same row splits, same products), the bias sums against fp64"""
+    from dgnn_amd import ops
+    from dgnn_amd._lib import lib
+    g = torch.Generator().manual_seed(M + nb2)
+    A = torch.randn(M, na, generator=g).to(DEV)
+    A = A if a_f32 else A.to(torch.bfloat16)
+    B1 = torch.randn(M, nb1 + 8, generator=g).to(DEV).to(torch.bfloat16)[:, 8:]      # a strided view
+    B2 = torch.randn(M, nb2, generator=g).to(DEV).to(torch.bfloat16) if nb2 else None
+    dW1, dW2, db = (torch.empty(na, nb1, device=DEV), torch.empty(na, max(nb2, 1), device=DEV), torch.empty(na, device=DEV))
+    scratch = torch.empty(int(lib().dgnn_linear_wgrad_cat_scratch_elems(M, na, nb1, nb2)), device=DEV)
+    ops.check(lib().dgnn_linear_wgrad_bf16_cat(ops.ptr(A), a_f32, A.stride(0), na, ops.ptr(B1), B1.stride(0), nb1, ops.ptr(B2), B2.stride(0) if nb2 else 0, nb2, 0, M,
+                                               ops.ptr(dW1), ops.ptr(dW2) if nb2 else None, ops.ptr(db), ops.ptr(scratch), ops.stream_ptr()), "dgnn_linear_wgrad_bf16_cat")
+    assert torch.equal(dW1, ops.linear_wgrad(A, B1))
+    if nb2:
+        assert torch.equal(dW2, ops.linear_wgrad(A, B2))
+    Ad = A.double()
+    assert (db.double() - Ad.sum(0)).abs().max().item() <= 1e-6 * Ad.abs().sum(0).max().item()
+    assert (dW1.double() - (A.to(torch.bfloat16).double().t() @ B1.double())).abs().max().item() <= 1e-4 * (A.double().abs().t() @ B1.double().abs()).max().item()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("c_in,n_src,n_dst", [(64, 900, 600), (128, 5000, 1777), (32, 333, 333)])
+def test_given_phi_aggregate_backward_with_the_two_additions(dtype, c_in, n_src, n_dst):
+    """dgnn_sage_aggregate_bwd_phi_add against the launch chain it replaces (aggregate backward, then dx[:n] += add, then dphi += dphi_ext): fp32 bit for
+    bit; bf16 storage rounds the sums once instead of twice (within one bf16 ulp of the two-step result)"""
+    from dgnn_amd import ops
+    from dgnn_amd._lib import lib
+    if os.environ.get("DGNN_AGG_CHUNKED") == "0":
+        pytest.skip("the addend form lives in the chunked kernel")
+    g = torch.Generator().manual_seed(c_in + n_src)
+    E = 4 * n_dst
+    ei = torch.stack([torch.randint(0, n_src, (E,), generator=g), torch.arange(n_dst).repeat_interleave(4)])
+    ei[0, : E // 3] = ei[0, : E // 3] % 50
+    mk = lambda *sh: torch.randn(*sh, generator=g).to(DEV).to(dtype)
+    x, da_w, phi, ext = mk(n_src, c_in), mk(n_dst, 2 * c_in), mk(E, c_in), mk(E, c_in)
+    rowptr, _, _ = ops.plan_build(ei.to(DEV), n_dst, 1)
+    t_rowptr, t_dst, t_eid = ops.plan_build(ei.to(DEV), n_src, 0)
+    da, add = da_w[:, :c_in], da_w[:, c_in:]
+    dx0, _, _, dphi0 = ops.aggregate_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr, x, da.contiguous(), phi=phi)
+    dx1, dphi1 = torch.empty_like(dx0), torch.empty_like(dphi0)
+    ops.check(lib().dgnn_sage_aggregate_bwd_phi_add(ops.ptr(t_rowptr), ops.ptr(t_dst), ops.ptr(t_eid), n_src, ops.ptr(rowptr), ops.ptr(x), c_in, c_in, ops.ptr(phi), c_in,
+                                                    ops.ptr(da), 2 * c_in, ops.ptr(dx1), c_in, ops.ptr(add), 2 * c_in, n_dst, ops.ptr(dphi1), c_in, ops.ptr(ext),
+                                                    int(dtype == torch.bfloat16), ops.stream_ptr()), "dgnn_sage_aggregate_bwd_phi_add")
+    if dtype == torch.float32:
+        want_dx = dx0.clone()
+        want_dx[:n_dst] += add
+        assert torch.equal(dx1, want_dx) and torch.equal(dphi1, dphi0 + ext)
+    else:
+        want_dx = dx0.float()
+        want_dx[:n_dst] += add.float()
+        assert (dx1.float() - want_dx).abs().max().item() <= 2 ** -7 * want_dx.abs().max().item()
+        want = dphi0.float() + ext.float()
+        assert (dphi1.float() - want).abs().max().item() <= 2 ** -7 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("M,k1,k2,n_out,f32out", [(5000, 128, 128, 128, False), (2048, 64, 0, 2, True), (333, 20, 0, 64, False), (16384, 128, 0, 64, False), (77, 30, 28, 70, False)])
+def test_small_bf16_gemm_gives_the_bits_of_the_tiled_kernel(M, k1, k2, n_out, f32out):
+    """M <= 16384 takes the one-wavefront-per-block kernel: same k order per output element as the 128-row tiles, so the first M rows of a 20000-row
+    problem (tiled kernel) carry the same bits; and both agree with fp64 at bf16-product accuracy"""
+    from dgnn_amd import ops
+    g = torch.Generator().manual_seed(M + k2)
+    big = 20000
+    A1 = torch.randn(big, k1 + 8, generator=g).to(DEV).to(torch.bfloat16)[:, 8:] if k1 % 8 == 0 else torch.randn(big, k1, generator=g).to(DEV).to(torch.bfloat16)
+    W1 = torch.randn(n_out, k1, generator=g).to(DEV)
+    A2 = torch.randn(big, k2, generator=g).to(DEV).to(torch.bfloat16) if k2 else None
+    W2 = torch.randn(n_out, k2, generator=g).to(DEV) if k2 else None
+    bias = torch.randn(n_out, generator=g).to(DEV)
+    od = torch.float32 if f32out else None
+    ref = ops.linear_fwd(A1, W1, A2, W2, bias, relu=True, out_dtype=od)
+    got = ops.linear_fwd(A1[:M], W1, A2[:M] if k2 else None, W2, bias, relu=True, out_dtype=od)
+    assert torch.equal(got, ref[:M])
+    want = A1[:M].double() @ W1.to(torch.bfloat16).double().t() + bias.double()
+    if k2:
+        want = want + A2[:M].double() @ W2.to(torch.bfloat16).double().t()
+    want = torch.relu(want)
+    assert (got.double() - want).abs().max().item() <= (2 ** -7 if not f32out else 1e-4) * max(1.0, want.abs().max().item())

@@ -403,6 +403,47 @@ def test_updated_composite_layer_matches_the_separate_calls(monkeypatch, dtype, 
             assert (ga[k] - gb[k]).abs().max().item() <= 2e-2 * gb[k].abs().max().item() + 1e-6, (k, (ga[k] - gb[k]).abs().max().item(), gb[k].abs().max().item())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", ["sage+", "sage"])
+def test_updated_conv_stack_call_is_bit_identical_to_the_per_layer_calls(monkeypatch, dtype, name):
+    """dgnn_updated_stack_fwd / _bwd (all conv layers and the edge chaining per call) issue the per-layer composite calls and the chaining kernels
+    in the per-layer path's order: logits and every gradient bit for bit, fp32 and bf16 storage; the chaining table is left all -1."""
+    from dgnn_amd import ops
+    from dgnn_amd.learning import surfaceNetUpdatedEdgeFilters as U
+    from dgnn_amd.sampler import NeighborSampler
+    from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal
+    adj, _, _ = delaunay_tet_graph(3000, seed=4)
+    n = adj.shape[0] // 4
+    ei = torch.from_numpy(adj.T.astype(np.int64)).to(DEV)
+    x = hashed_normal(np.arange(n), 29, seed=5, device=DEV)
+    ea = hashed_normal(np.arange(4 * n), 20, seed=6, device=DEV)
+    _, n_id, adjs = NeighborSampler(ei, sizes=[-1] * 4, num_nodes=n, batch_size=257).sample(torch.arange(100, 357, device=DEV))
+    G = hashed_normal(np.arange(257), 2 if name == "sage+" else 128, seed=7, device=DEV)
+    clf = Config.wrap(dict(training=dict(model_params=[64, 128, 128, 128], model_name=name, loss="kl"),
+                           features=dict(normalization_feature=1, keep_normalization_feature=0), temp=dict(device=DEV)))
+    torch.manual_seed(1)
+    sd = U.SurfaceNet(28, clf).state_dict()
+    res = []
+    for stack in (True, False):
+        monkeypatch.setattr(ops, "UPDATED_STACK", stack)
+        net = U.SurfaceNet(28, clf)
+        net.load_state_dict(sd)
+        net = net.to(DEV).set_storage_dtype(dtype)
+        used = []
+        orig = ops.updated_stack_fwd
+        monkeypatch.setattr(ops, "updated_stack_fwd", lambda *a, **k: (used.append(1), orig(*a, **k))[1])
+        logits = net(Config(x=x, edge_attr=ea, n_id=n_id, adjs=adjs))
+        (logits * G).sum().backward()
+        monkeypatch.setattr(ops, "updated_stack_fwd", orig)
+        assert bool(used) == (stack and ops.TRAIN_COMPOSITE and U.CHAIN_SPARSE)
+        assert int((net._chain_pos != -1).sum()) == 0 if net._chain_pos is not None else True
+        res.append((logits.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()}))
+    (la, ga), (lb, gb) = res
+    assert torch.equal(la, lb)
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), (k, (ga[k] - gb[k]).abs().max().item())
+
+
 def test_aux_stream_backward_gives_identical_gradients():
     """dgnn_train_set_aux_stream(1): weight gradients on the library's second stream beside the dx chain -- same numbers"""
     from dgnn_amd._lib import lib
