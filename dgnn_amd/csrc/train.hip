@@ -463,16 +463,19 @@ int updated_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_
         hipLaunchKernelGGL(k_transpose_many, dim3(dgnn_grid_cap(dgnn_cdiv(total, 256))), dim3(256), 0, stream, jobs);
         const T* B2 = (Wr && dWr) ? x : nullptr;
         TRY(K::wgrad_cat(g, c_out, c_out, a, c_in, c_in, B2, ldx, B2 ? c_in : 0, n_dst, dWl, dWr, dbl, tmp, st));
-        const T* ext = E > 0 ? dphi_ext : nullptr;
+        // (dphi += dphi_ext stays a launch of its own: folded into the aggregate backward's dphi store -- dgnn_sage_aggregate_bwd_phi_add can do
+        // it -- the fourth row load per edge cost the kernel 60 % (72 -> 115 us on the outermost block) against the 7-9 us of k_add_inplace)
         if (both) {
             TRY(K::linear(g, c_out, c_out, WlT, c_out, nullptr, 0, 0, nullptr, 0, nullptr, 0, n_dst, 2 * c_in, da, 2 * c_in, mode, st));
             TRY(dgnn_sage_aggregate_bwd_phi_add(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x, ldx, c_in, phi, c_in, da, 2 * c_in, dx, c_in, da + c_in, 2 * c_in,
-                                                n_dst, dphi, c_in, ext, K::kBf16, st));
+                                                n_dst, dphi, c_in, nullptr, K::kBf16, st));
         } else {
             TRY(K::linear(g, c_out, c_out, WlT, c_out, nullptr, 0, 0, nullptr, 0, nullptr, 0, n_dst, c_in, da, c_in, mode, st));
             TRY(dgnn_sage_aggregate_bwd_phi_add(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x, ldx, c_in, phi, c_in, da, c_in, dx, c_in, nullptr, 0, 0, dphi, c_in,
-                                                ext, K::kBf16, st));
+                                                nullptr, K::kBf16, st));
         }
+        if (E > 0 && dphi_ext)
+            hipLaunchKernelGGL((k_add_inplace<T>), dim3(dgnn_grid_cap(dgnn_cdiv(E * c_in, 256))), dim3(256), 0, stream, dphi, dphi_ext, E * c_in);
         if (E > 0) {
             TRY(K::wgrad_cat(dphi, c_in, c_in, ea, lde, k_e, nullptr, 0, 0, E, dWe, nullptr, dbe, tmp, st));
             if (d_ea) TRY(K::linear(dphi, c_in, c_in, WeT, c_in, nullptr, 0, 0, nullptr, 0, nullptr, 0, E, k_e, d_ea, k_e, mode, st));
