@@ -10,4 +10,9 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$
 F=$(ls gpurun_out/${T}_ttrace/*/*kernel_trace.csv | head -1)
 python tools/trace_gaps.py $F 105 40 --seq > gpurun_out/${T}_train_seq.txt 2>&1
 rm -rf gpurun_out/${T}_ttrace
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${T}_utrace -- python3 tools/bench_train.py --steps 60 --warmup 100 --no-roofline --updated --dtype bf16 > gpurun_out/${T}_utrace.log 2>&1
+F=$(ls gpurun_out/${T}_utrace/*/*kernel_trace.csv | head -1)
+python tools/trace_gaps.py $F 105 40 --seq > gpurun_out/${T}_train_seq_updated_bf16.txt 2>&1
+rm -rf gpurun_out/${T}_utrace
+timeout 300 python tools/bench_train.py --updated --no-roofline > gpurun_out/${T}_bench_train_updated.json 2>> gpurun_out/${T}_bench_train.err
 tail -3 gpurun_out/${T}_ab_train.txt; sed -n 2,2p gpurun_out/${T}_train_seq.txt
