@@ -25,8 +25,9 @@ struct alignas(sizeof(T) * V) Pk {
 __device__ __forceinline__ bool positive(float x) { return x > 0.f; }
 
 __global__ void k_chain_map(const int64_t* __restrict__ e_cur, int64_t n_cur, int64_t n_edges, int32_t* __restrict__ pos, int32_t value_is_index,
-                            int32_t* aflag) {
+                            int32_t* aflag, int32_t* __restrict__ inv) {
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_cur; k += (int64_t)gridDim.x * blockDim.x) {
+        if (inv) inv[k] = -1;      // the inverse map starts empty (was a memset launch of its own)
         const int64_t e = e_cur[k];
         if (e < 0 || e >= n_edges) {
             dgnn_raise_async(aflag, DGNN_ASYNC_OTHER_RANGE);
@@ -114,8 +115,7 @@ int chain_fwd(const T* phi, int64_t ldphi, int c, const int64_t* e_cur, int64_t 
     int32_t* const aflag = dgnn_async_flag_dev();
     constexpr int VMAX = 16 / sizeof(T);
     if (n_cur > 0) {
-        hipLaunchKernelGGL(k_chain_map, dim3(dgnn_grid_cap(dgnn_cdiv(n_cur, 256))), dim3(256), 0, stream, e_cur, n_cur, n_edges, pos, 1, aflag);
-        (void)hipMemsetAsync(inv, 0xFF, sizeof(int32_t) * (size_t)n_cur, stream);
+        hipLaunchKernelGGL(k_chain_map, dim3(dgnn_grid_cap(dgnn_cdiv(n_cur, 256))), dim3(256), 0, stream, e_cur, n_cur, n_edges, pos, 1, aflag, inv);
     }
     const bool vec = c % VMAX == 0 && ldphi % VMAX == 0 && ldo % VMAX == 0 && aligned_to(phi, 16) && aligned_to(out, 16);
     if (vec)
@@ -125,7 +125,7 @@ int chain_fwd(const T* phi, int64_t ldphi, int c, const int64_t* e_cur, int64_t 
         hipLaunchKernelGGL((k_chain_gather<T, 1>), dim3(dgnn_grid_cap(dgnn_cdiv(n_next * c, 256))), dim3(256), 0, stream, phi, ldphi, c, e_next, n_next,
                            n_edges, pos, relu, out, ldo, inv, aflag);
     if (n_cur > 0)
-        hipLaunchKernelGGL(k_chain_map, dim3(dgnn_grid_cap(dgnn_cdiv(n_cur, 256))), dim3(256), 0, stream, e_cur, n_cur, n_edges, pos, 0, aflag);
+        hipLaunchKernelGGL(k_chain_map, dim3(dgnn_grid_cap(dgnn_cdiv(n_cur, 256))), dim3(256), 0, stream, e_cur, n_cur, n_edges, pos, 0, aflag, (int32_t*)nullptr);
     return dgnn_check_launch("edge_chain_fwd");
 }
 
