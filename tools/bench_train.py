@@ -140,7 +140,7 @@ def replay_roofline():
     """The step's dominant kernel by GPU time is the fp32-class GEMM (k_linear_fwd_x3, 15 launches per step: conv / decoder GEMMs
     forward, input gradients backward).  Its launches are replayed at the LAST block's shapes (HIP events on the current stream,
     10 launches each): achieved = their algorithmic flops / their time.  Peak: the dense bf16 MFMA rate / 6 (every fp32 product
-    is 6 bf16 partial products).  The HBM-bound aggregate backward (k_agg_bwd, the largest single launch) is reported next to it."""
+    is 6 bf16 partial products).  The HBM-bound aggregate backward (k_agg_bwd_c, the longest launches) is reported next to it."""
     from dgnn_amd import ops
     from dgnn_amd.graph import plan_for
 
@@ -178,8 +178,8 @@ def replay_roofline():
     peak = 2500.0 / 6
     # primary object: the HBM-bound gather / scatter kernel with the longest single launch; the GEMMs (largest share of the
     # step's GPU time, but 15 small launches: M <= 70k rows, K <= 256) are reported next to it
-    return {"bound": "hbm", "kernel": "k_agg_bwd<1,20> (64 channels: the longest single launch of the step; gathers da rows, recomputes the filter, "
-                                       "writes dx, dWe, dbe)", "achieved": round(bytes_b / t_b / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+    return {"bound": "hbm", "kernel": "k_agg_bwd_c<1,20> (aggregate backward of the 64-channel layer, chunked form: gathers da rows, recomputes the filter, "
+                                       "writes dx, dWe, dbe; the longest launches of the step are its instances)", "achieved": round(bytes_b / t_b / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
             "frac": round(bytes_b / t_b / 1e6 / 8000.0, 4), "traffic": None, "algorithmic_bytes_per_launch": bytes_b, "avg_launch_ms": round(t_b, 4),
             "timing": "each launch replayed 10x at the last block's shapes, HIP events on the launching stream",
             "gemm": {"bound": "mfma", "kernel": "k_linear_fwd_x3 (%d launches per step: conv / decoder GEMMs forward, input gradients backward)" % len(gemms),
