@@ -317,6 +317,14 @@ def _needs_host_staging(t: torch.Tensor, group) -> bool:
     return t.is_cuda and dist.get_backend(group) != "nccl"
 
 
+def _contiguous_strides(shape):
+    st, acc = [], 1
+    for d in reversed(tuple(shape)):
+        st.append(acc)
+        acc *= int(d)
+    return tuple(reversed(st))
+
+
 def allreduce_gradients(model: torch.nn.Module, group=None, average: bool = True) -> None:
     """Data-parallel training step helper (BASELINE config 5: one scene shard per GPU, weight replicas):
     ONE collective over the flat fp32 gradient (0.4 MB for the shipped widths, 6.6 MB for [128..1024]) --
@@ -340,14 +348,14 @@ def allreduce_gradients(model: torch.nn.Module, group=None, average: bool = True
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     if average:
         flat /= dist.get_world_size(group)
+    # the reduced gradients are handed over as views of the flat buffer (one view op per parameter; a copy_ per parameter was 34 launches a step)
     off = 0
     for p in params:
         n = p.numel()
-        g = flat[off:off + n].view_as(p).to(p.dtype)
-        if p.grad is None:
-            p.grad = g.clone()
+        if p.dtype == torch.float32:
+            p.grad = torch.as_strided(flat, tuple(p.shape), tuple(p.stride()) if p.is_contiguous() else _contiguous_strides(p.shape), off)
         else:
-            p.grad.copy_(g)
+            p.grad = flat[off:off + n].view_as(p).to(p.dtype)
         off += n
 
 
