@@ -478,6 +478,140 @@ __global__ void __launch_bounds__(256) k_agg_bwd_c(const int32_t* __restrict__ t
     }
 }
 
+// =====================================================================================================================
+// Lane-group form of the given-phi backward (the Updated variant's conv).  In the kernels above a lane is ONE channel (or two) and a
+// wavefront instruction serves one edge: at 28-64 channels half the lanes idle and every edge costs three row loads of a few dozen
+// bytes each -- the launch is bound by the number of memory instructions, not by bytes.  Here a lane owns 4 consecutive channels
+// (one 16-byte / 8-byte load), G = 8 / 16 / 32 lanes form a row, and the 64 / G groups of a wavefront work on 64 / G SOURCE ROWS
+// at once, each walking its own out-edges in ascending position with up to four edges' loads in flight.  Per channel the
+// arithmetic and its order are k_agg_bwd's (dx / dphi bit-identical).  The chunk's row pointers and edge indices are coalesced
+// loads as in k_agg_bwd_c; a group takes its edges' indices by ds_bpermute.  The addend (dx[row] += add[row]) is one more row load
+// at the start of a row.
+// =====================================================================================================================
+template <typename T>
+struct V4;
+template <>
+struct V4<float> {
+    float v[4];
+    __device__ __forceinline__ void load(const float* p) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
+    }
+    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <>
+struct V4<uint16_t> {
+    float v[4];
+    __device__ __forceinline__ void load(const uint16_t* p) {
+        const uint2 t = *reinterpret_cast<const uint2*>(p);
+        v[0] = bf2f(t.x & 0xFFFFu), v[1] = __builtin_bit_cast(float, t.x & 0xFFFF0000u);
+        v[2] = bf2f(t.y & 0xFFFFu), v[3] = __builtin_bit_cast(float, t.y & 0xFFFF0000u);
+    }
+    __device__ __forceinline__ void store(uint16_t* p) const {
+        *reinterpret_cast<uint2*>(p) = make_uint2((uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16));
+    }
+};
+
+template <int G, typename T, bool ADD>
+__global__ void __launch_bounds__(256) k_agg_bwd_g(const int32_t* __restrict__ t_rowptr, const int32_t* __restrict__ t_dst, const int32_t* __restrict__ t_eid,
+                                                   int64_t n_src, const int32_t* __restrict__ rowptr_dst, const T* __restrict__ x, int64_t ldx, int c_in,
+                                                   const T* __restrict__ phi, int64_t ldphi, const T* __restrict__ da, int64_t ldda, T* __restrict__ dx,
+                                                   int64_t lddx, T* __restrict__ dphi_out, int64_t lddphi, int rows_per_chunk, const T* __restrict__ add,
+                                                   int64_t ldadd, int64_t n_add) {
+    constexpr int R = 64 / G;
+    const int lane = lane_id(), g = lane / G, c0 = 4 * (lane % G);
+    const bool on = c0 < c_in;
+    const int RW = rows_per_chunk;
+    const int64_t nchunks = (n_src + RW - 1) / RW;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave_id_uniform(); chunk < nchunks; chunk += stride) {
+        const int64_t rb = chunk * RW;
+        const int nr = (int)(n_src - rb < RW ? n_src - rb : RW);
+        const int rp = t_rowptr[rb + (lane < nr ? lane : nr)];
+        const int beg0 = rl(rp, 0), ne = rl(rp, nr) - beg0;
+        const bool inw = ne <= 64;      // the chunk's edge indices fit the wavefront: one coalesced load each, handed out by ds_bpermute
+        int dv = 0, ev = 0, cv = 1;
+        if (inw && lane < ne) {
+            dv = t_dst[beg0 + lane];
+            ev = t_eid[beg0 + lane];
+            cv = max(rowptr_dst[dv + 1] - rowptr_dst[dv], 1);
+        }
+        for (int r0 = 0; r0 < nr; r0 += R) {
+            const int r = r0 + g;
+            const bool rv = r < nr;
+            const int rc = rv ? r : nr - 1;
+            const int b = __shfl(rp, rc), deg = rv ? __shfl(rp, rc + 1) - b : 0;
+            const int64_t row = rb + rc;
+            V4<T> xs, av;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xs.v[j] = av.v[j] = 0.f;
+            if (on && deg > 0) xs.load(x + row * ldx + c0);
+            const bool has_add = ADD && rv && row < n_add;
+            if (has_add && on) av.load(add + row * ldadd + c0);
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int t0 = 0; __any(t0 < deg); t0 += 4) {
+                int d[4], e[4];
+                float cnt[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    ok[u] = t0 + u < deg;
+                    const int k = b + (ok[u] ? t0 + u : 0);
+                    if (inw) {
+                        int sl = k - beg0;
+                        sl = sl < 0 ? 0 : (sl > 63 ? 63 : sl);
+                        d[u] = __shfl(dv, sl);
+                        e[u] = __shfl(ev, sl);
+                        cnt[u] = (float)__shfl(cv, sl);
+                    } else {
+                        d[u] = e[u] = 0;
+                        cnt[u] = 1.f;
+                        if (ok[u]) {
+                            d[u] = t_dst[k];
+                            e[u] = t_eid[k];
+                            cnt[u] = (float)max(rowptr_dst[d[u] + 1] - rowptr_dst[d[u]], 1);
+                        }
+                    }
+                }
+                V4<T> gq[4], pr[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ok[u] && on) {
+                        gq[u].load(da + (int64_t)d[u] * ldda + c0);
+                        pr[u].load(phi + (int64_t)e[u] * ldphi + c0);
+                    }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ok[u] && on) {
+                        V4<T> dph;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float dm = __fdiv_rn(gq[u].v[j], cnt[u]);
+                            acc[j] = __fadd_rn(acc[j], __fmul_rn(dm, pr[u].v[j]));
+                            dph.v[j] = __fmul_rn(dm, xs.v[j]);
+                        }
+                        if (dphi_out) dph.store(dphi_out + (int64_t)e[u] * lddphi + c0);
+                    }
+            }
+            if (on && rv && dx) {
+                V4<T> o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o.v[j] = has_add ? __fadd_rn(acc[j], av.v[j]) : acc[j];
+                o.store(dx + row * lddx + c0);
+            }
+        }
+    }
+}
+
+inline bool agg_grouped() {   // DGNN_AGG_GROUPED=0: the one-edge-per-instruction kernels for the given-phi backward too
+    static const bool on = !(getenv("DGNN_AGG_GROUPED") && getenv("DGNN_AGG_GROUPED")[0] == '0');
+    return on;
+}
+template <typename T>
+inline bool rows_of_4(const void* p, int64_t ld) {
+    return p == nullptr || (((uintptr_t)p % (4 * sizeof(T))) == 0 && ld % 4 == 0);
+}
+
 // rows per chunk: 16 when there are enough rows to give every CU its 16 wavefronts, fewer (down to 4) on the small inner blocks
 inline int chunk_rows(int64_t n_rows) {
     int64_t r = dgnn_cdiv(n_rows, (int64_t)DGNN_NUM_CU * 16);
@@ -554,6 +688,23 @@ int agg_bwd_t(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
     DGNN_REQUIRE(!dphi_ext || (chunked && We == nullptr && phi != nullptr && dphi_out), DGNN_E_UNSUPPORTED,
                  "aggregate_bwd: dphi_ext needs the chunked kernel in the given-phi form");
     const int rw = chunk_rows(n_src);
+    if (given && chunked && agg_grouped() && !dphi_ext && c_in % 4 == 0 && c_in <= 128 && rows_of_4<T>(x_src, ldx) && rows_of_4<T>(phi, ldphi) &&
+        rows_of_4<T>(da, ldda) && rows_of_4<T>(dx_src, lddx) && rows_of_4<T>(dphi_out, lddphi) && rows_of_4<T>(add, ldadd)) {
+        // lane-group form: 4 channels per lane, 64 / G source rows per wavefront at once
+        dim3 ggrid((unsigned)dgnn_grid_cap(dgnn_cdiv(dgnn_cdiv(n_src, rw), 4), 8));
+#define LAUNCH_G(GG)                                                                                                                          \
+        do { if (add)                                                                                                                         \
+            hipLaunchKernelGGL((k_agg_bwd_g<GG, T, true>), ggrid, dim3(256), 0, stream, t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, ldx, c_in, phi, \
+                               ldphi, da, ldda, dx_src, lddx, dphi_out, lddphi, rw, add, ldadd, n_add);                                      \
+        else                                                                                                                                  \
+            hipLaunchKernelGGL((k_agg_bwd_g<GG, T, false>), ggrid, dim3(256), 0, stream, t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, ldx, c_in, phi, \
+                               ldphi, da, ldda, dx_src, lddx, dphi_out, lddphi, rw, (const T*)nullptr, (int64_t)0, (int64_t)0); } while (0)
+        if (c_in <= 32) LAUNCH_G(8);
+        else if (c_in <= 64) LAUNCH_G(16);
+        else LAUNCH_G(32);
+#undef LAUNCH_G
+        return dgnn_check_launch("aggregate_bwd");
+    }
     const int64_t want = chunked ? dgnn_cdiv(dgnn_cdiv(n_src, rw), 4) : dgnn_cdiv(n_src, 4);
     const int nblocks = (int)(want < BWD_BLOCKS ? want : BWD_BLOCKS);
     dim3 grid(nblocks, chunks), block(256);

@@ -450,3 +450,33 @@ def test_small_bf16_gemm_gives_the_bits_of_the_tiled_kernel(M, k1, k2, n_out, f3
         want = want + A2[:M].double() @ W2.to(torch.bfloat16).double().t()
     want = torch.relu(want)
     assert (got.double() - want).abs().max().item() <= (2 ** -7 if not f32out else 1e-4) * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("c_in,n_src,n_dst", [(28, 5000, 1777), (64, 900, 600), (128, 3000, 2000), (32, 70, 70)])
+def test_lane_group_given_phi_backward_gives_the_bits_of_the_lane_per_channel_kernel(dtype, c_in, n_src, n_dst):
+    """k_agg_bwd_g (4 channels per lane, 64 / G source rows per wavefront) against k_agg_bwd_c (taken when a row stride is not a multiple of 4
+    elements): dx and dphi bit for bit; sources with dozens of out-edges (chunks beyond 64 edges), with none, degree-0 destinations' clamp"""
+    from dgnn_amd import ops
+    if os.environ.get("DGNN_AGG_CHUNKED") == "0" or os.environ.get("DGNN_AGG_GROUPED") == "0":
+        pytest.skip("compares the two default kernels")
+    g = torch.Generator().manual_seed(c_in + n_src)
+    E = 4 * n_dst
+    ei = torch.stack([torch.randint(0, n_src, (E,), generator=g), torch.arange(n_dst).repeat_interleave(4)])
+    ei[0, : E // 3] = ei[0, : E // 3] % 37          # 37 sources with dozens of out-edges each
+    mk = lambda *sh: torch.randn(*sh, generator=g).to(DEV).to(dtype)
+    x, da, phi = mk(n_src, c_in), mk(n_dst, c_in), mk(E, c_in)
+    rowptr, _, _ = ops.plan_build(ei.to(DEV), n_dst, 1)
+    t_rowptr, t_dst, t_eid = ops.plan_build(ei.to(DEV), n_src, 0)
+    dx_g, _, _, dphi_g = ops.aggregate_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr, x, da, phi=phi)
+    pad = 2 if dtype == torch.bfloat16 else 1        # even element counts keep bf16 pairs aligned; the stride is no multiple of 4 either way
+    xw = torch.zeros(n_src, c_in + pad, device=DEV, dtype=dtype)
+    xw[:, :c_in] = x
+    dx_c, _, _, dphi_c = ops.aggregate_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr, xw[:, :c_in], da, phi=phi)
+    assert torch.equal(dx_g, dx_c) and torch.equal(dphi_g, dphi_c)
+    # and against the definition in fp64 (on the storage-rounded inputs)
+    cnt = torch.bincount(ei[1], minlength=n_dst).clamp_min(1).to(DEV).double()
+    dm = da.double()[ei[1].to(DEV)] / cnt[ei[1].to(DEV)][:, None]
+    want = torch.zeros(n_src, c_in, device=DEV, dtype=torch.float64).index_add_(0, ei[0].to(DEV), dm * phi.double())
+    tol = 2 ** -7 if dtype == torch.bfloat16 else 1e-5
+    assert (dx_g.double() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
