@@ -603,6 +603,79 @@ __global__ void __launch_bounds__(256) k_agg_bwd_g(const int32_t* __restrict__ t
     }
 }
 
+// the forward in the same form: 64 / G DESTINATION rows per wavefront, each group sums its in-edges in plan order (k_agg_fwd's order: a bit-identical)
+template <int G, typename T>
+__global__ void __launch_bounds__(256) k_agg_fwd_g(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid,
+                                                   int64_t n_dst, const T* __restrict__ x, int64_t ldx, int c_in, const T* __restrict__ phi, int64_t ldphi,
+                                                   T* __restrict__ a, int64_t lda, int rows_per_chunk) {
+    constexpr int R = 64 / G;
+    const int lane = lane_id(), g = lane / G, c0 = 4 * (lane % G);
+    const bool on = c0 < c_in;
+    const int RW = rows_per_chunk;
+    const int64_t nchunks = (n_dst + RW - 1) / RW;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave_id_uniform(); chunk < nchunks; chunk += stride) {
+        const int64_t rb = chunk * RW;
+        const int nr = (int)(n_dst - rb < RW ? n_dst - rb : RW);
+        const int rp = rowptr[rb + (lane < nr ? lane : nr)];
+        const int beg0 = rl(rp, 0), ne = rl(rp, nr) - beg0;
+        const bool inw = ne <= 64;
+        int sv = 0, ev = 0;
+        if (inw && lane < ne) {
+            sv = src[beg0 + lane];
+            ev = eid ? eid[beg0 + lane] : beg0 + lane;
+        }
+        for (int r0 = 0; r0 < nr; r0 += R) {
+            const int r = r0 + g;
+            const bool rv = r < nr;
+            const int rc = rv ? r : nr - 1;
+            const int b = __shfl(rp, rc), deg = rv ? __shfl(rp, rc + 1) - b : 0;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int t0 = 0; __any(t0 < deg); t0 += 4) {
+                int sj[4], ej[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    ok[u] = t0 + u < deg;
+                    const int k = b + (ok[u] ? t0 + u : 0);
+                    if (inw) {
+                        int sl = k - beg0;
+                        sl = sl < 0 ? 0 : (sl > 63 ? 63 : sl);
+                        sj[u] = __shfl(sv, sl);
+                        ej[u] = __shfl(ev, sl);
+                    } else {
+                        sj[u] = ej[u] = 0;
+                        if (ok[u]) {
+                            sj[u] = src[k];
+                            ej[u] = eid ? eid[k] : k;
+                        }
+                    }
+                }
+                V4<T> xr[4], pr[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ok[u] && on) {
+                        xr[u].load(x + (int64_t)sj[u] * ldx + c0);
+                        pr[u].load(phi + (int64_t)ej[u] * ldphi + c0);
+                    }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ok[u] && on) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j] = __fadd_rn(acc[j], __fmul_rn(xr[u].v[j], pr[u].v[j]));
+                    }
+            }
+            if (on && rv) {
+                const float cnt = (float)max(deg, 1);
+                V4<T> o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o.v[j] = __fdiv_rn(acc[j], cnt);
+                o.store(a + (rb + rc) * lda + c0);
+            }
+        }
+    }
+}
+
 inline bool agg_grouped() {   // DGNN_AGG_GROUPED=0: the one-edge-per-instruction kernels for the given-phi backward too
     static const bool on = !(getenv("DGNN_AGG_GROUPED") && getenv("DGNN_AGG_GROUPED")[0] == '0');
     return on;
@@ -642,6 +715,18 @@ int agg_fwd_t(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int
     DGNN_REQUIRE(!fused || f_e == 20 || f_e == 2, DGNN_E_UNSUPPORTED,
                  "aggregate_fwd: fused filter supports f_e in {2,20} (got %d); materialise phi with dgnn_linear_fwd", f_e);
     const bool given = !fused && phi != nullptr;
+    if (given && !phi_out && agg_chunked() && agg_grouped() && c_in % 4 == 0 && c_in <= 128 && rows_of_4<T>(x_src, ldx) && rows_of_4<T>(phi, ldphi) &&
+        rows_of_4<T>(a, lda)) {
+        // lane-group form (see k_agg_bwd_g): 4 channels per lane, 64 / G destination rows per wavefront at once
+        const int rw = chunk_rows(n_dst);
+        dim3 ggrid((unsigned)dgnn_grid_cap(dgnn_cdiv(dgnn_cdiv(n_dst, rw), 4), 8));
+#define LAUNCH_G(GG) hipLaunchKernelGGL((k_agg_fwd_g<GG, T>), ggrid, dim3(256), 0, stream, rowptr, src, eid, n_dst, x_src, ldx, c_in, phi, ldphi, a, lda, rw)
+        if (c_in <= 32) LAUNCH_G(8);
+        else if (c_in <= 64) LAUNCH_G(16);
+        else LAUNCH_G(32);
+#undef LAUNCH_G
+        return dgnn_check_launch("aggregate_fwd");
+    }
     bool v2 = (c_in % 2 == 0) && (c_in > 64 || sizeof(T) == 2) && aligned_for<2, T>(x_src, ldx) && aligned_for<2, T>(a, lda) &&
               (!given || aligned_for<2, T>(phi, ldphi)) && (!phi_out || aligned_for<2, T>(phi_out, ldphi_out));
     const int cpl = v2 ? 2 : 1;

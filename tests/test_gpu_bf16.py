@@ -474,6 +474,14 @@ def test_lane_group_given_phi_backward_gives_the_bits_of_the_lane_per_channel_ke
     xw[:, :c_in] = x
     dx_c, _, _, dphi_c = ops.aggregate_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr, xw[:, :c_in], da, phi=phi)
     assert torch.equal(dx_g, dx_c) and torch.equal(dphi_g, dphi_c)
+    # the forward pair (k_agg_fwd_g vs k_agg_fwd), on a plan with ragged in-degrees (0 .. dozens) as well
+    ei2 = torch.stack([torch.randint(0, n_src, (E,), generator=g), torch.randint(0, n_dst, (E,), generator=g)])
+    ei2[1, : E // 4] = ei2[1, : E // 4] % 11
+    for edges in (ei, ei2):
+        rp2, src2, eid2 = ops.plan_build(edges.to(DEV), n_dst, 1)
+        a_g = ops.aggregate_fwd(rp2, src2, eid2, n_dst, x, phi=phi)
+        a_c = ops.aggregate_fwd(rp2, src2, eid2, n_dst, xw[:, :c_in], phi=phi)
+        assert torch.equal(a_g, a_c)
     # and against the definition in fp64 (on the storage-rounded inputs)
     cnt = torch.bincount(ei[1], minlength=n_dst).clamp_min(1).to(DEV).double()
     dm = da.double()[ei[1].to(DEV)] / cnt[ei[1].to(DEV)][:, None]
