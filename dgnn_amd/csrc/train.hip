@@ -807,6 +807,97 @@ extern "C" int dgnn_updated_stack_bwd(int n_layers, const int32_t* const* t_rowp
     return dgnn_check_launch("updated_stack_bwd");
 }
 
+// The Updated model's output network behind the conv stack ("sage+": out_net = ReLU, Linear(C, H), ReLU, Linear(H, n_out), reference
+// surfaceNetUpdatedEdgeFilters.py:210, 245-247; the first ReLU is the one after the last conv) as one call each way, for the same autograd node:
+//   h = relu(x . W1^T + b1)   (storage type)        logits = h . W3^T + b3   (fp32)
+// backward: dW3 / db3 and dW1 / db1 from one launch pair each, dh = g . W3, dz1 = dh * [h > 0], dx = dz1 . W1; one transpose launch.
+// scratch (floats): 2 * (C*H + H*n_out) + dgnn_linear_wgrad_cat_scratch_elems(n, H, C, 0) + n * n_out + 64.  dh: [n, H] work buffer (storage type).
+extern "C" int dgnn_updated_tail_fwd(int64_t n, const void* x, int64_t ldx, int c, const float* W1, const float* b1, int hdim, const float* W3, const float* b3,
+                                     int n_out, void* h, float* logits, int bf16, int gemm_mode, void* stream) {
+    DGNN_REQUIRE(n > 0 && c > 0 && hdim > 0 && n_out > 0 && x && W1 && W3 && h && logits, DGNN_E_INVALID, "updated_tail_fwd: bad arguments");
+    if (bf16) {
+        TRY(dgnn_linear_fwd_bf16((const uint16_t*)x, ldx, c, W1, c, nullptr, 0, 0, nullptr, 0, b1, nullptr, nullptr, 1, n, hdim, h, hdim, 0, stream));
+        TRY(dgnn_linear_fwd_bf16((const uint16_t*)h, hdim, hdim, W3, hdim, nullptr, 0, 0, nullptr, 0, b3, nullptr, nullptr, 0, n, n_out, logits, n_out, 1, stream));
+    } else if (gemm_mode == DGNN_GEMM_F32) {
+        TRY(dgnn_linear_fwd((const float*)x, ldx, c, W1, c, nullptr, 0, 0, nullptr, 0, b1, nullptr, nullptr, 1, n, hdim, (float*)h, hdim, stream));
+        TRY(dgnn_linear_fwd((const float*)h, hdim, hdim, W3, hdim, nullptr, 0, 0, nullptr, 0, b3, nullptr, nullptr, 0, n, n_out, logits, n_out, stream));
+    } else {
+        TRY(dgnn_linear_fwd_x3((const float*)x, ldx, c, W1, c, nullptr, 0, 0, nullptr, 0, b1, nullptr, nullptr, 1, n, hdim, (float*)h, hdim, stream));
+        TRY(dgnn_linear_fwd_x3((const float*)h, hdim, hdim, W3, hdim, nullptr, 0, 0, nullptr, 0, b3, nullptr, nullptr, 0, n, n_out, logits, n_out, stream));
+    }
+    return DGNN_OK;
+}
+
+extern "C" int64_t dgnn_updated_tail_scratch_elems(int64_t n, int c, int hdim, int n_out) {
+    if (n < 0 || c <= 0 || hdim <= 0 || n_out <= 0) return 64;
+    const int64_t w1 = dgnn_linear_wgrad_cat_scratch_elems(n, hdim, c, 0), w3 = dgnn_linear_wgrad_cat_scratch_elems(n, n_out, hdim, 0);
+    const int64_t cs = dgnn_colstats_scratch_elems(n, hdim > n_out ? hdim : n_out), wg = dgnn_linear_wgrad_scratch_elems(n, hdim, c);
+    int64_t big = w1 > w3 ? w1 : w3;
+    if (cs > big) big = cs;
+    if (wg > big) big = wg;
+    return 2 * (align4((int64_t)c * hdim) + align4((int64_t)hdim * n_out)) + align4(big) + align4(n * n_out) + 64;
+}
+
+extern "C" int dgnn_updated_tail_bwd(int64_t n, const void* x, int64_t ldx, int c, const float* W1, int hdim, const float* W3, int n_out, const void* h,
+                                     const float* g, float* dW1, float* db1, float* dW3, float* db3, void* dx, void* dh, float* scratch, int bf16,
+                                     int gemm_mode, void* stream_) {
+    DGNN_REQUIRE(n > 0 && c > 0 && hdim > 0 && n_out > 0 && x && W1 && W3 && h && g && dW1 && dW3 && dx && dh && scratch, DGNN_E_INVALID,
+                 "updated_tail_bwd: bad arguments");
+    hipStream_t stream = (hipStream_t)stream_;
+    float* W3T = scratch;                                        // [hdim, n_out]
+    float* W1T = W3T + align4((int64_t)hdim * n_out);            // [c, hdim]
+    float* tmp = W1T + align4((int64_t)c * hdim);
+    const int64_t w1 = dgnn_linear_wgrad_cat_scratch_elems(n, hdim, c, 0), w3 = dgnn_linear_wgrad_cat_scratch_elems(n, n_out, hdim, 0);
+    const int64_t cs = dgnn_colstats_scratch_elems(n, hdim > n_out ? hdim : n_out), wg = dgnn_linear_wgrad_scratch_elems(n, hdim, c);
+    int64_t big = w1 > w3 ? w1 : w3;
+    if (cs > big) big = cs;
+    if (wg > big) big = wg;
+    uint16_t* gb = reinterpret_cast<uint16_t*>(tmp + align4(big));   // bf16 copy of the logits' gradient (bf16 storage)
+    TrJobs jobs;
+    jobs.n = 2;
+    jobs.in[0] = W3, jobs.out[0] = W3T, jobs.rows[0] = n_out, jobs.cols[0] = hdim, jobs.end[0] = n_out * hdim;
+    jobs.in[1] = W1, jobs.out[1] = W1T, jobs.rows[1] = hdim, jobs.cols[1] = c, jobs.end[1] = jobs.end[0] + hdim * c;
+    hipLaunchKernelGGL(k_transpose_many, dim3(dgnn_grid_cap(dgnn_cdiv(jobs.end[1], 256))), dim3(256), 0, stream, jobs);
+    const bool fused = fused_enabled();
+    if (bf16) {
+        const int gp = (n_out + 1) / 2 * 2;
+        TRY(dgnn_cast_f32_to_bf16(g, n_out, n, n_out, gp, gb, gp, stream_));
+        if (fused) {
+            TRY(dgnn_linear_wgrad_bf16_cat(g, 1, n_out, n_out, h, hdim, hdim, nullptr, 0, 0, 0, n, dW3, nullptr, db3, tmp, stream_));
+        } else {
+            TRY(dgnn_linear_wgrad_bf16(g, 1, n_out, n_out, h, 0, hdim, hdim, n, dW3, hdim, 0, tmp, stream_));
+            if (db3) TRY(dgnn_colsum(g, n_out, n, n_out, db3, 0, tmp, stream_));
+        }
+        TRY(dgnn_linear_fwd_bf16(gb, gp, n_out, W3T, n_out, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, n, hdim, dh, hdim, 0, stream_));
+        TRY(dgnn_relu_bwd_bf16((const uint16_t*)h, (const uint16_t*)dh, n * hdim, (uint16_t*)dh, stream_));
+        if (fused) {
+            TRY(dgnn_linear_wgrad_bf16_cat(dh, 0, hdim, hdim, x, ldx, c, nullptr, 0, 0, 0, n, dW1, nullptr, db1, tmp, stream_));
+        } else {
+            TRY(dgnn_linear_wgrad_bf16(dh, 0, hdim, hdim, x, 0, ldx, c, n, dW1, c, 0, tmp, stream_));
+            if (db1) TRY(dgnn_colsum_bf16((const uint16_t*)dh, hdim, n, hdim, db1, 0, tmp, stream_));
+        }
+        TRY(dgnn_linear_fwd_bf16((const uint16_t*)dh, hdim, hdim, W1T, hdim, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, n, c, dx, c, 0, stream_));
+        return dgnn_check_launch("updated_tail_bwd");
+    }
+    const bool x3 = gemm_mode != DGNN_GEMM_F32;
+    auto gemm = [&](const float* A, int64_t lda, int k, const float* W, int64_t ldw, int64_t M, int no, float* out, int64_t ldo) {
+        return x3 ? dgnn_linear_fwd_x3(A, lda, k, W, ldw, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, M, no, out, ldo, stream_)
+                  : dgnn_linear_fwd(A, lda, k, W, ldw, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, M, no, out, ldo, stream_);
+    };
+    auto wgrad = [&](const float* A, int64_t lda, int na, const float* B, int64_t ldb, int nb, float* dW, float* dbias) {
+        if (x3 && fused) return dgnn_linear_wgrad_x3_cat(A, lda, na, B, ldb, nb, nullptr, 0, 0, n, dW, nullptr, dbias, tmp, stream_);
+        int rc = x3 ? dgnn_linear_wgrad_x3(A, lda, na, B, ldb, nb, n, dW, nb, 0, tmp, stream_) : dgnn_linear_wgrad(A, lda, na, B, ldb, nb, n, dW, nb, 0, tmp, stream_);
+        if (rc == DGNN_OK && dbias) rc = dgnn_colsum(A, lda, n, na, dbias, 0, tmp, stream_);
+        return rc;
+    };
+    TRY(wgrad(g, n_out, n_out, (const float*)h, hdim, hdim, dW3, db3));
+    TRY(gemm(g, n_out, n_out, W3T, n_out, n, hdim, (float*)dh, hdim));
+    TRY(dgnn_relu_bwd((const float*)h, (const float*)dh, n * hdim, (float*)dh, stream_));
+    TRY(wgrad((const float*)dh, hdim, hdim, (const float*)x, ldx, c, dW1, db1));
+    TRY(gemm((const float*)dh, hdim, hdim, W1T, hdim, n, c, (float*)dx, c));
+    return dgnn_check_launch("updated_tail_bwd");
+}
+
 // Which of the training step's fused launch chains run (bit 0: backward chain, bit 1: batch statistics from the forward GEMM's epilogue;
 // default 3, DGNN_TRAIN_FUSED in the environment).  Returns the previous mask.
 extern "C" int dgnn_train_set_fused(int mask) {

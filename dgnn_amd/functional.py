@@ -263,7 +263,7 @@ class _UpdatedConvStack(torch.autograd.Function):
     Tensor inputs: x0, then (We, be, Wl, bl, Wr) per layer (None where a layer has none)."""
 
     @staticmethod
-    def forward(ctx, x0, edge_attr_all, pos, spec, *params):
+    def forward(ctx, x0, edge_attr_all, pos, spec, tail, *params):
         layers = []
         for i, sp in enumerate(spec):
             We, be, Wl, bl, Wr = params[5 * i:5 * i + 5]
@@ -271,26 +271,42 @@ class _UpdatedConvStack(torch.autograd.Function):
         y, saved = ops.updated_stack_fwd(x0, edge_attr_all, pos, layers)
         ctx.layers, ctx.saved = layers, saved
         ctx.edge_indices = [sp["plan"].edge_index for sp in spec]     # lazily built transposed plans read them
+        ctx.tail = None
+        if tail:        # out_net (Linear, ReLU, Linear -> fp32 logits) inside the same node
+            W1, b1, W3, b3 = params[5 * len(spec):5 * len(spec) + 4]
+            logits, h = ops.updated_tail_fwd(y, W1, b1, W3, b3)
+            ctx.tail = (y, h, W1, W3)
+            ctx.save_for_backward(x0)
+            return logits
         ctx.save_for_backward(x0)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (x0,) = ctx.saved_tensors
-        grads = ops.updated_stack_bwd(x0, ctx.layers, ctx.saved, dy.contiguous())
-        out = [None, None, None, None]
+        tail_grads = []
+        dy = dy.contiguous()
+        if ctx.tail is not None:
+            y, h, W1, W3 = ctx.tail
+            dy, dW1, db1, dW3, db3 = ops.updated_tail_bwd(y, W1, W3, h, dy if dy.dtype == torch.float32 else dy.float())
+            tail_grads = [dW1, db1, dW3, db3]
+        grads = ops.updated_stack_bwd(x0, ctx.layers, ctx.saved, dy)
+        out = [None, None, None, None, None]
         for g in grads:
             out += list(g)
-        return tuple(out)
+        return tuple(out + tail_grads)
 
 
-def updated_conv_stack(x0, edge_attr_all, pos, spec):
-    """spec: per layer dict(plan, e_id int64 [E_l], rows0 (layer 0: e_id as int32), edge_in, relu, lin_e, lin_l, lin_r | None)"""
+def updated_conv_stack(x0, edge_attr_all, pos, spec, out_net=None):
+    """spec: per layer dict(plan, e_id int64 [E_l], rows0 (layer 0: e_id as int32), edge_in, relu, lin_e, lin_l, lin_r | None).
+    `out_net` = (Linear, Linear) with biases: the model's output network behind the stack (fp32 logits come back)."""
     params = []
     for sp in spec:
         le, ll, lr = sp["lin_e"], sp["lin_l"], sp["lin_r"]
         params += [le.weight, le.bias, ll.weight, ll.bias, lr.weight if lr is not None else None]
-    return _UpdatedConvStack.apply(x0, edge_attr_all, pos, spec, *params)
+    if out_net is not None:
+        params += [out_net[0].weight, out_net[0].bias, out_net[1].weight, out_net[1].bias]
+    return _UpdatedConvStack.apply(x0, edge_attr_all, pos, spec, out_net is not None, *params)
 
 
 def sage_updated_layer_supported(x, ea, lin_e) -> bool:

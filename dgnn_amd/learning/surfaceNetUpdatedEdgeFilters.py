@@ -125,6 +125,7 @@ class SurfaceNet(nn.Module):
         n_edges = edge_attr.size(0)
         phi = e_prev = None
         plus = self.clf.training.model_name[-1] == "+"
+        self._stack_did_tail = False
         x_stack = self._conv_stack(x, edge_attr, data_all.adjs, dev, plus)
         for i in range(self.num_layers if x_stack is None else 0):
             edge_index, e_id, size = data_all.adjs[i]
@@ -151,6 +152,8 @@ class SurfaceNet(nn.Module):
             e_prev = e_id
         if x_stack is not None:
             x = x_stack
+            if self._stack_did_tail:
+                return x
         # (the last layer's new_edge_attr, :236-237, is never read)
         if plus:                                                                      # :245-247
             x = Fn.linear2(x, self.out_net[1].weight, bias=self.out_net[1].bias)
@@ -185,7 +188,12 @@ class SurfaceNet(nn.Module):
                 sp["rows0"] = plan.edge_rows if plan.has_edge_rows else e_id.to(torch.int32)
             spec.append(sp)
             c, n_src = conv.lin_l.out_features, size[1]
-        return Fn.updated_conv_stack(x, edge_attr, self._chain_table(edge_attr.size(0), dev), spec)
+        out_net = None
+        if plus and ops.UPDATED_TAIL_IN_CALL and isinstance(self.out_net[1], nn.Linear) and isinstance(self.out_net[3], nn.Linear) \
+                and self.out_net[1].bias is not None and self.out_net[3].bias is not None and self.out_net[1].in_features == c:
+            out_net = (self.out_net[1], self.out_net[3])       # :245-247 inside the same library-call pair; fp32 logits come back
+            self._stack_did_tail = True
+        return Fn.updated_conv_stack(x, edge_attr, self._chain_table(edge_attr.size(0), dev), spec, out_net)
 
     def _unsupported(self, *a, **k):
         raise NotImplementedError("the reference's surfaceNetUpdatedEdgeFilters.inference_* methods call the conv without "

@@ -678,6 +678,7 @@ def sage_layer_train_bwd(t_parts, rowptr_dst, n_src, n_dst, x, edge_attr, We, be
 
 # ---- all conv layers of the Updated variant per call (csrc/train.hip: dgnn_updated_stack_fwd / _bwd) ---------------------------------------
 UPDATED_STACK = __import__("os").environ.get("DGNN_UPDATED_STACK", "1") != "0"
+UPDATED_TAIL_IN_CALL = __import__("os").environ.get("DGNN_UPDATED_TAIL_IN_CALL", "1") != "0"   # ... and the model's output network behind it
 
 
 @on_device_of
@@ -775,6 +776,33 @@ def updated_stack_bwd(x0, layers, saved, dy):
         v = lambda e, n: None if e is None else st(flat, (n,), (1,), e[0])
         grads.append((m(row[0], ci, k), v(row[1], ci), m(row[2], co, ci), v(row[3], co), m(row[4], co, ci)))
     return grads
+
+
+@on_device_of
+def updated_tail_fwd(x, W1, b1, W3, b3):
+    """out_net behind the conv stack: -> (logits fp32 [n, n_out], h [n, hdim] in x's type)"""
+    n, c, hd, no = x.size(0), x.size(1), W1.size(0), W3.size(0)
+    h = torch.empty((n, hd), dtype=x.dtype, device=x.device)
+    logits = torch.empty((n, no), dtype=torch.float32, device=x.device)
+    check(lib().dgnn_updated_tail_fwd(n, ptr(x), _ld(x), c, ptr(W1), ptr(b1), hd, ptr(W3), ptr(b3), no, ptr(h), ptr(logits), int(x.dtype == torch.bfloat16),
+                                      GEMM_MODE, stream_ptr()), "dgnn_updated_tail_fwd")
+    return logits, h
+
+
+@on_device_of
+def updated_tail_bwd(x, W1, W3, h, g):
+    """-> (dx [n, c] in x's type, dW1, db1, dW3, db3)"""
+    n, c, hd, no = x.size(0), x.size(1), W1.size(0), W3.size(0)
+    flat = torch.empty(hd * c + hd + no * hd + no, dtype=torch.float32, device=x.device)
+    st = torch.as_strided
+    dW1, db1 = st(flat, (hd, c), (c, 1), 0), st(flat, (hd,), (1,), hd * c)
+    dW3, db3 = st(flat, (no, hd), (hd, 1), hd * c + hd), st(flat, (no,), (1,), hd * c + hd + no * hd)
+    dx = torch.empty((n, c), dtype=x.dtype, device=x.device)
+    dh = torch.empty((n, hd), dtype=x.dtype, device=x.device)
+    scratch = _f32(lib().dgnn_updated_tail_scratch_elems(n, c, hd, no), x.device)
+    check(lib().dgnn_updated_tail_bwd(n, ptr(x), _ld(x), c, ptr(W1), hd, ptr(W3), no, ptr(h), ptr(g), ptr(dW1), ptr(db1), ptr(dW3), ptr(db3), ptr(dx), ptr(dh),
+                                      ptr(scratch), int(x.dtype == torch.bfloat16), GEMM_MODE, stream_ptr()), "dgnn_updated_tail_bwd")
+    return dx, dW1, db1, dW3, db3
 
 
 # ---- edge-embedding chaining of the Updated variant (csrc/chain.hip) ---------------------------------------------------------

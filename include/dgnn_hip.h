@@ -427,6 +427,16 @@ int dgnn_updated_stack_bwd(int n_layers, const int32_t* const* t_rowptr, const i
                            const void* const* y, const int32_t* const* inv, const void* dy, float* const* dWe, float* const* dbe, float* const* dWl,
                            float* const* dbl, float* const* dWr, void* const* dx_buf, void* d_ea, void* dphi_ext, void* dz, void* da, void* dphi,
                            float* scratch, int bf16, int gemm_mode, void* stream);
+/* The Updated model's output network behind the conv stack ("sage+": out_net, surfaceNetUpdatedEdgeFilters.py:210, 245-247), one call each way:
+ * h = relu(x . W1^T + b1) in the storage type, logits = h . W3^T + b3 in fp32.  Backward from g = d logits: dW3 / db3 and dW1 / db1 (one launch
+ * pair each), dx [n, c] in the storage type.  dh: an [n, hdim] work buffer (storage type); scratch: dgnn_updated_tail_scratch_elems floats. */
+int dgnn_updated_tail_fwd(int64_t n, const void* x, int64_t ldx, int c, const float* W1, const float* b1, int hdim, const float* W3, const float* b3,
+                          int n_out, void* h, float* logits, int bf16, int gemm_mode, void* stream);
+int64_t dgnn_updated_tail_scratch_elems(int64_t n, int c, int hdim, int n_out);
+int dgnn_updated_tail_bwd(int64_t n, const void* x, int64_t ldx, int c, const float* W1, int hdim, const float* W3, int n_out, const void* h,
+                          const float* g, float* dW1, float* db1, float* dW3, float* db3, void* dx, void* dh, float* scratch, int bf16,
+                          int gemm_mode, void* stream);
+
 int64_t dgnn_static_train_scratch_elems(int n_layers, const int64_t* n_src, const int64_t* n_dst, const int32_t* widths, int f_e);
 int dgnn_static_train_bwd(int n_layers, const int32_t* const* t_rowptr, const int32_t* const* t_dst, const int32_t* const* t_eid,
                           const int32_t* const* rowptr_dst, const int64_t* n_src, const int64_t* n_dst, const float* x0, int64_t ldx0,
