@@ -29,10 +29,11 @@ out = ["# Round 3: training step (block builder + forward + backward + Adam), St
        "* The step is host-bound now (`host_issue_ms_per_step` = `ms_per_step`): about 0.28 ms of it are the 70 launches themselves, the rest Python -- torch's optimizer",
        "  and autograd engine, three indexing ops, this package's argument marshalling (trimmed this round: gradient views by one `as_strided` each, cached pointer",
        "  tables, plans that cut views of the block builder's buffers only on demand: 1.0 -> 0.93-0.95 ms).",
-       "* Updated variant (bf16 storage): 129 launches / 1.29 ms of GPU time / 1.28-1.36 ms per step at the start of this work -> 96 launches / 0.97 ms / 1.0-1.1 ms:",
+       "* Updated variant (bf16 storage): 129 launches / 1.29 ms of GPU time / 1.28-1.36 ms per step at the start of this work -> 90 launches / 0.85 ms / 0.92-1.05 ms:",
        "  all conv layers and the edge chaining per library call (one autograd node instead of three per layer: the step was bound by ~16 Python-level nodes each",
        "  way), merged bf16 weight gradients with 16-byte staging (`k_linear_wgrad_b_cat`), one input-gradient GEMM with the sum folded into the aggregate backward,",
-       "  one transpose launch per layer, a one-wavefront-per-block bf16 GEMM for the small blocks (`k_linear_fwd_b_small`).  fp32 storage: 1.87 -> 1.11 ms.",
+       "  one transpose launch per layer, lane-group aggregate kernels (`k_agg_bwd_g` / `k_agg_fwd_g`: 4 channels per lane, 2-8 rows per wavefront instruction), the",
+       "  output network inside the same autograd node, a one-wavefront-per-block bf16 GEMM for the small blocks (`k_linear_fwd_b_small`).  fp32 storage: 1.87 -> 1.03 ms.",
        "* Largest GPU items: `k_agg_bwd_c` 0.15 ms and `k_agg_fwd` 0.09 ms (one edge per wavefront instruction: at 28-64 channels the filter's 20 fma per edge are",
        "  the kernel's time -- a lane-group mapping, 4 channels per lane and 2-8 edges per instruction, is the next step), the small fp32-class GEMMs 0.19 ms, the",
        "  BatchNorm backward's reduce / finalise / apply chain 0.13 ms, `k_linear_wgrad_x3_cat` + reduction 0.13 ms.", ""]
