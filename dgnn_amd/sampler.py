@@ -112,34 +112,46 @@ class NeighborSampler:
             ring, ring_free, k = self._ring, [None] * 3, 0   # reuse_buffers: three buffer sets, block j builds into set j % 3
             with torch.cuda.device(self.device):
                 self._caller_stream = torch.cuda.current_stream()
+            # the loop below runs once per training step on the thread that issues the step: with the buffer ring nothing in it launches or
+            # allocates, so it needs no stream / device context managers (the builder gets the side stream's handle) and its events are reused
+            free_ev = [torch.cuda.Event() for _ in range(3)]
+            self._done_ev, self._done_k = [torch.cuda.Event() for _ in range(4)], 0
             try:
                 for s in starts:
                     blk = self._finish_on_side(pending) if pending is not None else None
                     pending = None
-                    with torch.cuda.device(self.device), torch.cuda.stream(side):
-                        batch = idx[s:s + self.batch_size].contiguous()
-                        slot = None
-                        if ring is not None:
-                            # everything the caller enqueued up to now (the step on block k-2 and before) precedes this point on its
-                            # stream; set k % 3 was last handed out as block k-3: the builder may overwrite it once that point is passed
-                            slot = k % 3
-                            if ring[slot] is None or ring[slot]["cap_nb"] < batch.numel():
+                    batch = idx[s:s + self.batch_size]      # (a row range of a contiguous vector: contiguous)
+                    if not batch.is_contiguous():
+                        with torch.cuda.device(self.device), torch.cuda.stream(side):
+                            batch = batch.contiguous()
+                    slot = None
+                    if ring is not None:
+                        # everything the caller enqueued up to now (the step on block k-2 and before) precedes this point on its
+                        # stream; set k % 3 was last handed out as block k-3: the builder may overwrite it once that point is passed
+                        slot = k % 3
+                        if ring[slot] is None or ring[slot]["cap_nb"] < batch.numel():
+                            with torch.cuda.device(self.device), torch.cuda.stream(side):
                                 ring[slot] = self._alloc_regular(max(self.batch_size, batch.numel()), self.transposed_plans)
-                                for v in ring[slot].values():   # allocated on the builder's stream, read on the caller's for their whole life
-                                    for t in (v if isinstance(v, list) else [v]):
-                                        if isinstance(t, torch.Tensor):
-                                            t.record_stream(self._caller_stream)
-                            if ring_free[slot] is not None:
-                                side.wait_event(ring_free[slot])
-                        self._escaped = [] if ring is None else None
-                        pending = (self._start_regular(batch, background=True, b=ring[slot] if ring is not None else None), self._escaped)
+                            for v in ring[slot].values():   # allocated on the builder's stream, read on the caller's for their whole life
+                                for t in (v if isinstance(v, list) else [v]):
+                                    if isinstance(t, torch.Tensor):
+                                        t.record_stream(self._caller_stream)
+                        if ring_free[slot] is not None:
+                            side.wait_event(ring_free[slot])
                         self._escaped = None
-                        k += 1
+                        pending = (self._start_regular(batch, background=True, b=ring[slot], stream=side.cuda_stream), None)
+                    else:
+                        with torch.cuda.device(self.device), torch.cuda.stream(side):
+                            self._escaped = []
+                            pending = (self._start_regular(batch.contiguous(), background=True, b=None), self._escaped)
+                            self._escaped = None
+                    k += 1
                     if blk is not None:
                         if ring is not None:
                             # the caller is done enqueueing the step on the block before this one: mark that point on ITS stream
-                            with torch.cuda.device(self.device):
-                                ring_free[(k - 3) % 3] = torch.cuda.current_stream().record_event()
+                            ev = free_ev[(k - 3) % 3]
+                            ev.record(torch.cuda.current_stream())
+                            ring_free[(k - 3) % 3] = ev
                         yield self._hand_over(blk)
                 if pending is not None:
                     blk, pending = self._finish_on_side(pending), None
@@ -204,6 +216,13 @@ class NeighborSampler:
 
     def _finish_on_side(self, pending):
         b, escaped = pending
+        if escaped is None and getattr(self, "_done_ev", None) is not None:
+            # buffer ring: joining the builder and cutting the views launches nothing -- no stream switch; the event marks the side stream's tail
+            out = self._finish_regular(b)
+            ev = self._done_ev[self._done_k & 3]
+            self._done_k += 1
+            ev.record(self._side)
+            return (out, None, ev)
         with torch.cuda.device(self.device), torch.cuda.stream(self._side):
             self._escaped = escaped
             try:
@@ -223,10 +242,13 @@ class NeighborSampler:
     def _hand_over(self, pending):
         """makes a block built on the side stream usable on the caller's current stream"""
         out, tensors, ev = pending
+        if not tensors:                  # the block lives in the reuse ring (or escaped nothing): only the ordering is needed
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            return out
         with torch.cuda.device(self.device):
             cur = torch.cuda.current_stream()
             cur.wait_event(ev)
-            for t in tensors or ():     # (None: the block lives in the reuse ring, nothing is freed)
+            for t in tensors:
                 t.record_stream(cur)   # the allocator must not recycle them for the next block while this stream reads them
         return out
 
@@ -262,7 +284,7 @@ class NeighborSampler:
                           ptr(scratch[:-1]), ptr(scratch[-1:]), *t_arrs, caps(cap_all) if want_t else None, ptr(plan_scratch))
         return b
 
-    def _start_regular(self, n_id: torch.Tensor, background: bool, b=None):
+    def _start_regular(self, n_id: torch.Tensor, background: bool, b=None, stream=None):
         """every node has exactly 4 in-edges: all hops (and, when iterating with prefetch, the transposed plans) in one library
         call.  `background`: the call runs on a library-owned host thread (dgnn_khop_blocks_regular_start) and this returns at
         once; _finish_regular joins it and cuts the views.  `b`: buffers to build into (a slot of the reuse ring), default fresh ones."""
@@ -275,7 +297,7 @@ class NeighborSampler:
         L = lib()
         args = (ptr(p.rowptr), ptr(p.src), ptr(p.eid), 4, ptr(n_id), nb, b["hops"], ptr(self._pos), ptr(self._first)) + b["args_tail"]
         if background:
-            b["job"] = L.dgnn_khop_blocks_regular_start(*args, stream_ptr())
+            b["job"] = L.dgnn_khop_blocks_regular_start(*args, stream if stream is not None else stream_ptr())
             if not b["job"]:
                 check(-1, "dgnn_khop_blocks_regular_start")
         else:
