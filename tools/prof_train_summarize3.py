@@ -21,12 +21,12 @@ out = ["# Round 3: training step (block builder + forward + backward + Adam), St
        "## GPU timeline of the Static step", "", "```"] + seq[:cut] + ["```", "", "## launch sequence of one step (main queue)", "", "```"] + seq[cut:] + ["```", "",
        "## Updated variant, bf16 storage (BASELINE configs 3 and 5): GPU timeline and launch sequence", "", "```"] + rd("%s_train_seq_updated_bf16.txt" % T).split("\n") + ["```", "",
        "## reading", "",
-       "* Start of the round (`profiles/r02h_training.md`): 108 launches on the step's stream, 1.11 ms of GPU time, 1.17-1.24 ms per step.  Now 70 launches, 0.86-0.88 ms of",
+       "* Start of the round (`profiles/r02h_training.md`): 108 launches on the step's stream, 1.11 ms of GPU time, 1.17-1.24 ms per step.  Now 71 launches, 0.86-0.88 ms of",
        "  GPU time, 0.93-0.95 ms per step.  What went: per conv layer one weight-gradient launch pair instead of three (`k_linear_wgrad_x3_cat`), one input-gradient",
        "  GEMM instead of two with the sum folded into the aggregate backward's store (`k_agg_bwd_c<..., true>`), one reduction launch instead of two (`k_reduce_layer`),",
        "  no transposes (one `k_transpose_many` per pass), no column reduction for the forward statistics (GEMM epilogue), the decoder's output Linear inside the",
        "  whole-model calls.",
-       "* The step is host-bound now (`host_issue_ms_per_step` = `ms_per_step`): about 0.28 ms of it are the 70 launches themselves, the rest Python -- torch's optimizer",
+       "* The step is host-bound now (`host_issue_ms_per_step` = `ms_per_step`): about 0.28 ms of it are the 71 launches themselves, the rest Python -- torch's optimizer",
        "  and autograd engine, three indexing ops, this package's argument marshalling (trimmed this round: gradient views by one `as_strided` each, cached pointer",
        "  tables, plans that cut views of the block builder's buffers only on demand: 1.0 -> 0.93-0.95 ms).",
        "* Updated variant (bf16 storage): 129 launches / 1.29 ms of GPU time / 1.28-1.36 ms per step at the start of this work -> 90 launches / 0.85 ms / 0.92-1.05 ms:",
