@@ -15,7 +15,7 @@ adj, _, _ = delaunay_tet_graph(int(sys.argv[1]) if len(sys.argv) > 1 else 150000
 n = adj.shape[0] // 4
 ei = torch.from_numpy(adj.T.astype(np.int64)).to(dev)
 plan = GraphPlan(ei, n, n)
-c_in, c_out = 128, 128
+c_in, c_out = (int(v) for v in os.environ.get("SHAPE", "128,128").split(","))      # SHAPE=28,64 / 64,128: the first two layers
 g = torch.Generator(device=dev).manual_seed(0)
 x = torch.randn(n, c_in, device=dev, generator=g)
 ea = torch.randn(4 * n, 20, device=dev, generator=g)
