@@ -155,6 +155,30 @@ def test_aggregate_fused_filter(c_in, f_e):
     assert rel_err(phi, phi64) < 2e-6
 
 
+@pytest.mark.parametrize("c_in,n_src,n_dst", [(28, 5000, 1777), (64, 900, 600), (32, 70, 70), (128, 800, 500)])
+def test_lane_group_fused_filter_forward_gives_the_bits_of_the_lane_per_channel_kernel(c_in, n_src, n_dst):
+    """k_agg_fwd_g20 (rows of up to 32 channels, 4 channels per lane, 8 destination rows per wavefront instruction) against k_agg_fwd (taken when
+    the row stride of x is no multiple of 4): the aggregate bit for bit, regular and ragged in-degrees; wider rows keep the old kernel either way"""
+    from dgnn_amd import ops
+    if os.environ.get("DGNN_AGG_CHUNKED") == "0" or os.environ.get("DGNN_AGG_GROUPED") == "0":
+        pytest.skip("compares the two default kernels")
+    g = torch.Generator().manual_seed(c_in + n_src)
+    E = 4 * n_dst
+    x = torch.randn(n_src, c_in, generator=g).to(DEV)
+    xw = torch.zeros(n_src, c_in + 1, device=DEV)
+    xw[:, :c_in] = x
+    ea = torch.randn(E, 20, generator=g).to(DEV)
+    We, be = (torch.randn(c_in, 20, generator=g) * 0.3).to(DEV), torch.randn(c_in, generator=g).to(DEV)
+    ei = torch.stack([torch.randint(0, n_src, (E,), generator=g), torch.arange(n_dst).repeat_interleave(4)])
+    ei2 = torch.stack([torch.randint(0, n_src, (E,), generator=g), torch.randint(0, n_dst, (E,), generator=g)])
+    ei2[1, : E // 4] = ei2[1, : E // 4] % 11
+    for edges in (ei, ei2):
+        rp, src, eid = ops.plan_build(edges.to(DEV), n_dst, 1)
+        a_g = ops.aggregate_fwd(rp, src, eid, n_dst, x, ea, We, be)
+        a_c = ops.aggregate_fwd(rp, src, eid, n_dst, xw[:, :c_in], ea, We, be)
+        assert torch.equal(a_g, a_c)
+
+
 # ---- dense kernels ---------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,k1,k2,n_out", [(1000, 28, 28, 64), (777, 64, 64, 128), (2048, 128, 128, 128), (300, 128, 0, 2),
                                           (130, 37, 5, 70), (1, 128, 0, 64)])
