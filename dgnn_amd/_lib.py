@@ -35,6 +35,7 @@ SIGNATURES = {
     "dgnn_linear_wgrad_x3": (i32, [vp, i64, i32, vp, i64, i32, i64, vp, i64, i32, vp, vp]),
     "dgnn_linear_wgrad_cat_scratch_elems": (i64, [i64, i32, i32, i32]),
     "dgnn_train_set_fused": (i32, [i32]),
+    "dgnn_adam_step": (i32, [i32, vp, vp, vp, vp, vp, f32, f32, f32, f32, i64, vp]),
     "dgnn_updated_tail_fwd": (i32, [i64, vp, i64, i32, vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, vp]),
     "dgnn_updated_tail_scratch_elems": (i64, [i64, i32, i32, i32]),
     "dgnn_updated_tail_bwd": (i32, [i64, vp, i64, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),

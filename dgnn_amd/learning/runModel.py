@@ -104,6 +104,17 @@ class Metrics:
         return self.reg_sum / e if e else 0.0
 
 
+def make_adam(params, lr):
+    """the reference's optimizer (:290 torch.optim.Adam(model.parameters(), lr)); fp32 parameters on a GPU are stepped by one library launch
+    (dgnn_amd.optim.Adam: same rule and state), anything else -- and DGNN_TORCH_ADAM=1 -- by torch's own"""
+    import os
+    from ..optim import Adam
+    params = list(params)
+    if os.environ.get("DGNN_TORCH_ADAM") != "1" and params and Adam.supports(params):
+        return Adam(params, lr=lr)
+    return torch.optim.Adam(params, lr=lr)
+
+
 def adjust_learning_rate(optimizer, clf):
     """lr * 0.1 ** (epoch // adjust_lr_every), reference :95-99."""
     lr = clf.training.learning_rate * (0.1 ** (clf.temp.current_epoch // clf.training.adjust_lr_every))
@@ -221,7 +232,7 @@ class Trainer:
             clf.temp.device = "cuda:" + str(clf.temp.args.gpu)
         from ..partition import broadcast_parameters
         broadcast_parameters(self.model, group)   # data-parallel replicas start equal (no-op for a single process)
-        optimizer = torch.optim.Adam(self.model.parameters(), lr=clf.training.learning_rate)
+        optimizer = make_adam(self.model.parameters(), clf.training.learning_rate)
         import torch.distributed as dist
         writer = (not (dist.is_available() and dist.is_initialized())) or dist.get_rank(group) == 0
         models_dir = os.path.join(clf.paths.out, "models")

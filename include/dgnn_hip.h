@@ -405,6 +405,12 @@ int dgnn_train_set_aux_stream(int on);
  * Returns the previous mask. */
 int dgnn_train_set_fused(int mask);
 
+/* One Adam step over n_tensors fp32 parameter tensors in one launch (reference learning/runModel.py:290 torch.optim.Adam(model.parameters(), lr),
+ * stepped at :282; no amsgrad / weight decay): p, g, m (exp_avg), v (exp_avg_sq) are host arrays of device pointers, numel the element counts,
+ * step the 1-based step count (bias corrections are computed on the host in double precision). */
+int dgnn_adam_step(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* numel, float lr,
+                   float beta1, float beta2, float eps, int64_t step, void* stream);
+
 /* All conv layers of the Updated variant (learning/surfaceNetUpdatedEdgeFilters.py:229-243) and the edge chaining between them per call: the
  * per-layer composite calls (dgnn_sage_updated_train_fwd / _bwd) and dgnn_edge_chain_fwd / _bwd issued back to back, results bit-identical to
  * calling them one by one.  Per layer l: plan (rowptr, src, eid), e_id[l] = the block edges' rows in the scene's edge tensor (int64; rows0 = e_id[0]

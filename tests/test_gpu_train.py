@@ -448,6 +448,40 @@ def test_updated_conv_stack_call_is_bit_identical_to_the_per_layer_calls(monkeyp
             assert torch.equal(ga[k], gb[k]), (k, (ga[k] - gb[k]).abs().max().item())
 
 
+def test_library_adam_follows_torch_adam():
+    """dgnn_amd.optim.Adam (one launch per step) against torch.optim.Adam over several steps: same rule (no amsgrad / weight decay), a changing learning
+    rate, a parameter that gets no gradient on some steps (its own step count, as in torch), state_dict round trip"""
+    from dgnn_amd.optim import Adam
+    g = torch.Generator().manual_seed(0)
+    shapes = [(64, 28), (64,), (128, 64), (2,), (5000, 3), (1,)]
+    mk = lambda: [torch.nn.Parameter(torch.randn(*sh, generator=torch.Generator().manual_seed(i)).to(DEV)) for i, sh in enumerate(shapes)]
+    pa, pb = mk(), mk()
+    oa, ob = Adam(pa, lr=1e-3), torch.optim.Adam(pb, lr=1e-3)
+    for step in range(7):
+        if step == 4:
+            for o in (oa, ob):
+                for grp in o.param_groups:
+                    grp["lr"] = 3e-4
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i == 2 and step in (1, 2):          # no gradient for this one on two steps
+                a.grad = b.grad = None
+                continue
+            gr = (torch.randn(*shapes[i], generator=g) * (10.0 ** (i - 3))).to(DEV)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+    for a, b in zip(pa, pb):
+        assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item()) + 1e-7
+    assert oa.state[pa[2]]["step"] == 5 and oa.state[pa[0]]["step"] == 7
+    assert pa[0]._version >= 7 and pa[2]._version >= 5        # every step bumps the version counters (BatchNorm folds / prepared parameters key on them)
+    sd = oa.state_dict()
+    oc = Adam(mk(), lr=1.0)
+    oc.load_state_dict(sd)
+    assert oc.param_groups[0]["lr"] == 3e-4 and oc.state[oc.param_groups[0]["params"][0]]["step"] == 7
+    with pytest.raises(TypeError):
+        Adam([torch.nn.Parameter(torch.zeros(3))])          # a CPU parameter: the caller keeps torch.optim.Adam
+
+
 def test_aux_stream_backward_gives_identical_gradients():
     """dgnn_train_set_aux_stream(1): weight gradients on the library's second stream beside the dx chain -- same numbers"""
     from dgnn_amd._lib import lib

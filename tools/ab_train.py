@@ -27,7 +27,11 @@ clf = reconbench_pretrained(device=dev); clf.temp.current_epoch = 0; clf.trainin
 torch.manual_seed(0)
 net = SurfaceNet(clf).to(dev).train()
 tr = Trainer(net)
-opt = torch.optim.Adam(net.parameters(), lr=clf.training.learning_rate, fused=True)
+if os.environ.get("DGNN_TORCH_ADAM") == "1":
+    opt = torch.optim.Adam(net.parameters(), lr=clf.training.learning_rate, fused=True)
+else:
+    from dgnn_amd.learning.runModel import make_adam
+    opt = make_adam(net.parameters(), clf.training.learning_rate)
 adjust_learning_rate(opt, clf)
 per = (n // 2048) * 2048      # whole batches per permutation: no duplicate targets inside a batch
 need = 2048 * (ROUNDS * len(settings) * SEG + 5 * len(settings) + 8)

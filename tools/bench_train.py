@@ -98,7 +98,11 @@ if args.dtype == "bf16":
 if world > 1:
     from dgnn_amd.partition import broadcast_parameters
     broadcast_parameters(net)
-opt = torch.optim.Adam(net.parameters(), lr=clf.training.learning_rate, fused=True)  # one launch for all 49 tensors
+if os.environ.get("DGNN_TORCH_ADAM") == "1":
+    opt = torch.optim.Adam(net.parameters(), lr=clf.training.learning_rate, fused=True)
+else:
+    from dgnn_amd.learning.runModel import make_adam
+    opt = make_adam(net.parameters(), clf.training.learning_rate)      # what Trainer.train_test builds: one library launch per step
 adjust_learning_rate(opt, clf)
 g = torch.Generator().manual_seed(rank)
 per = (n // batch) * batch     # whole batches per permutation: no duplicate targets inside a batch

@@ -6,7 +6,7 @@
 cd $GRAFT_REPO_ROOT
 for e in "DGNN_TRAIN_COMPOSITE=0" "DGNN_TRAIN_WHOLE_MODEL=0" "DGNN_KHOP_ONE_CALL=0" "DGNN_CHAIN_DENSE=1" "DGNN_FUSED_LOSS=0" "DGNN_GEMM_MODE=f32" \
          "DGNN_TRAIN_AUX_STREAM=1" "DGNN_X3_BIG=0 DGNN_X3_N64=0" "DGNN_KHOP_MAILBOX=0" "DGNN_FUSE_DECODER=0" "DGNN_PREPARED=0" \
-         "DGNN_TRAIN_FUSED=0" "DGNN_TRAIN_FUSED=1" "DGNN_AGG_CHUNKED=0" "DGNN_TRAIN_DECODER_IN_CALL=0" "DGNN_UPDATED_STACK=0" "DGNN_BF16_SMALL=0" "DGNN_AGG_GROUPED=0" "DGNN_UPDATED_TAIL_IN_CALL=0"; do
+         "DGNN_TRAIN_FUSED=0" "DGNN_TRAIN_FUSED=1" "DGNN_AGG_CHUNKED=0" "DGNN_TRAIN_DECODER_IN_CALL=0" "DGNN_UPDATED_STACK=0" "DGNN_BF16_SMALL=0" "DGNN_AGG_GROUPED=0" "DGNN_UPDATED_TAIL_IN_CALL=0" "DGNN_TORCH_ADAM=1"; do
   echo "== $e"
   env $e python -m pytest tests/test_gpu_train.py tests/test_gpu_parity.py tests/test_gpu_bf16.py -m gpu -q -x 2>&1 | tail -2
 done

@@ -9,7 +9,7 @@ for r in rows:
     m = re.search(r"(k_\w+|multi_tensor_apply|vectorized_gather|index_elementwise|reduce_kernel|elementwise|fillBuffer|copyBuffer)", n)
     r["n"] = m.group(1) if m else n[:40]
 rows.sort(key=lambda r: r["s"])
-adam = [i for i, r in enumerate(rows) if "FusedAdam" in r["Kernel_Name"]]
+adam = [i for i, r in enumerate(rows) if "FusedAdam" in r["Kernel_Name"] or "k_adam" in r["Kernel_Name"]]   # torch's fused Adam | the library's
 print("kernels", len(rows), "adam launches", len(adam), "queues", collections.Counter(r["Queue_Id"] for r in rows))
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 nst = int(sys.argv[3]) if len(sys.argv) > 3 else 20
