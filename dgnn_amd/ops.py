@@ -346,6 +346,14 @@ def bn_fold(gamma, beta, mean, var, eps):
     return scale, shift
 
 
+def _written_behind_torch(*tensors):
+    """the library wrote these through raw addresses: bump their version counters so that anything cached against them (the eval-mode BatchNorm
+    folds, prepared parameters) is rebuilt"""
+    ts = [t for t in tensors if t is not None]
+    if ts:
+        torch.autograd.graph.increment_version(ts)
+
+
 @on_device_of
 def bn_batch_stats(x, running_mean=None, running_var=None, momentum=0.1):
     _req(x, "x", ACT, dim=2)
@@ -355,6 +363,7 @@ def bn_batch_stats(x, running_mean=None, running_var=None, momentum=0.1):
     scratch = _f32(lib().dgnn_colstats_scratch_elems(M, c), x.device)
     check(getattr(lib(), "dgnn_bn_batch_stats" + _sfx(x))(ptr(x), _ld(x), M, c, ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
                                     float(momentum), ptr(scratch), stream_ptr()), "dgnn_bn_batch_stats")
+    _written_behind_torch(running_mean, running_var)
     return mean, var
 
 
@@ -642,6 +651,7 @@ def sage_layer_train_fwd(plan_parts, n_dst, x, edge_attr, We, be, Wj, bj, Wi, ga
         check(lib().dgnn_sage_layer_train_fwd_bf16(*head, stream_ptr()), "dgnn_sage_layer_train_fwd_bf16")
     else:
         check(lib().dgnn_sage_layer_train_fwd(*head, GEMM_MODE, stream_ptr()), "dgnn_sage_layer_train_fwd")
+    _written_behind_torch(running_mean, running_var)
     return y, a, z, stats
 
 
@@ -985,6 +995,8 @@ def static_train_fwd(x0, layers):
         pa["We"], pa["be"], pa["Wj"], pa["bj"], pa["Wi"], pa["gamma"], pa["beta"], pa["rm"], pa["rv"], pa["nbt"], pa["momentum"], pa["eps"],
         _parr([at(m["a"]) for m in meta]), _parr([at(m["z"]) for m in meta]), _parr([at(m["stats"]) for m in meta]), _parr([at(m["y"]) for m in meta]),
         ptr(scratch), GEMM_MODE, stream_ptr()), "dgnn_static_train_fwd")
+    _written_behind_torch(*[t for l in layers if l["bn"] is not None
+                            for t in (l["bn"].running_mean, l["bn"].running_var, l["bn"].num_batches_tracked if l["bn"].track_running_stats else None)])
     n, co = layers[-1]["n_dst"], widths[-1]
     return torch.as_strided(buf, (n, co), (co, 1), meta[-1]["y"]), buf, (meta, widths, pa)
 

@@ -448,6 +448,30 @@ def test_updated_conv_stack_call_is_bit_identical_to_the_per_layer_calls(monkeyp
             assert torch.equal(ga[k], gb[k]), (k, (ga[k] - gb[k]).abs().max().item())
 
 
+def test_eval_after_training_forwards_sees_the_new_running_statistics():
+    """The library updates BatchNorm's running buffers through raw addresses; their version counters are bumped so that the eval-mode fold (cached
+    per BatchNorm against the versions) is rebuilt: eval after train-mode forwards WITHOUT an optimizer step must follow the new statistics."""
+    from test_gpu_parity import gold, f3_data
+    g = gold("static_f3_train_blocks.npz")
+    d = f3_data(g)
+    data = Config(all=Config(x=d.all.x.to(DEV), edge_attr=d.all.edge_attr.to(DEV)), batch_n_id=d.batch_n_id.to(DEV),
+                  batch_adjs=[(a.to(DEV), e.to(DEV), s) for a, e, s in d.batch_adjs])
+    net = hip_static(train=False)
+    adj, n, x, ea, y = small_scene(300, seed=3)
+    val = Config(x=x.to(DEV), edge_attr=ea.to(DEV), edge_index=torch.from_numpy(adj.T.astype(np.int64)).to(DEV))
+    before = net.inference_layer(val).clone()          # fills the fold / prepared caches
+    net.train()
+    with torch.no_grad():
+        for _ in range(3):
+            net(data)                                  # running statistics move, no parameter does
+    net.eval()
+    after = net.inference_layer(val)
+    assert not torch.equal(before, after)
+    ref = hip_static(train=False)
+    ref.load_state_dict(net.state_dict())              # a fresh model with the same tensors has no caches
+    assert torch.equal(ref.eval().inference_layer(val), after)
+
+
 def test_library_adam_follows_torch_adam():
     """dgnn_amd.optim.Adam (one launch per step) against torch.optim.Adam over several steps: same rule (no amsgrad / weight decay), a changing learning
     rate, a parameter that gets no gradient on some steps (its own step count, as in torch), state_dict round trip"""
