@@ -688,6 +688,7 @@ def sage_layer_train_bwd(t_parts, rowptr_dst, n_src, n_dst, x, edge_attr, We, be
 
 # ---- all conv layers of the Updated variant per call (csrc/train.hip: dgnn_updated_stack_fwd / _bwd) ---------------------------------------
 UPDATED_STACK = __import__("os").environ.get("DGNN_UPDATED_STACK", "1") != "0"
+_UPDATED_ARRAYS = {}
 UPDATED_TAIL_IN_CALL = __import__("os").environ.get("DGNN_UPDATED_TAIL_IN_CALL", "1") != "0"   # ... and the model's output network behind it
 
 
@@ -725,23 +726,32 @@ def updated_stack_fwd(x0, edge_attr_all, pos, layers):
     arr = lambda k: _parr([l[k] for l in layers])
     i64 = lambda v: _iarr(v, C.c_int64)
     i32 = lambda v: _iarr(v, C.c_int32)
+    # tables of what belongs to the MODEL (parameter addresses, widths, edge_in, relu flags): rebuilt only when an address has moved
+    names = ("We", "be", "Wl", "bl", "Wr")
+    key = tuple((l[k].data_ptr() if l[k] is not None else 0) for l in layers for k in names) + tuple((l["edge_in"], bool(l["relu"])) for l in layers) + (x0.size(1),)
+    hit = _UPDATED_ARRAYS.get(L)
+    if hit is None or hit[0] != key:
+        hit = (key, dict({k: arr(k) for k in names}, widths=i32(widths), edge_in=i32([l["edge_in"] for l in layers]),
+                         relu=i32([int(bool(l["relu"])) for l in layers])))
+        _UPDATED_ARRAYS[L] = hit
+    pa = hit[1]
     check(lib().dgnn_updated_stack_fwd(
         L, _parr([p[0] for p in parts]), _parr([p[1] for p in parts]), _parr([p[2] for p in parts]), arr("e_id"), ptr(layers[0]["rows0"]),
-        i64([l["plan"].n_dst for l in layers]), i64([l["plan"].E for l in layers]), ptr(x0), _ld(x0), i32(widths), i32([l["edge_in"] for l in layers]),
-        ptr(edge_attr_all), _ld(edge_attr_all), edge_attr_all.size(0), ptr(pos), arr("We"), arr("be"), arr("Wl"), arr("bl"), arr("Wr"),
-        i32([int(bool(l["relu"])) for l in layers]), _parr([at(o["ea"]) for o in offs]), i64([o["ld_ea"] for o in offs]), at(ea0),
+        i64([l["plan"].n_dst for l in layers]), i64([l["plan"].E for l in layers]), ptr(x0), _ld(x0), pa["widths"], pa["edge_in"],
+        ptr(edge_attr_all), _ld(edge_attr_all), edge_attr_all.size(0), ptr(pos), pa["We"], pa["be"], pa["Wl"], pa["bl"], pa["Wr"],
+        pa["relu"], _parr([at(o["ea"]) for o in offs]), i64([o["ld_ea"] for o in offs]), at(ea0),
         _parr([at(o["phi"]) for o in offs]), _parr([at(o["a"]) for o in offs]), _parr([at(o["y"]) for o in offs]), _parr([at(o["inv"]) for o in offs]),
         int(bf), GEMM_MODE, stream_ptr()), "dgnn_updated_stack_fwd", poll=True)
     n, co = layers[-1]["plan"].n_dst, widths[-1]
     y = torch.as_strided(buf.view(dt), (n, co), (co, 1), offs[-1]["y"] // esz)
-    return y, (buf, offs, widths)
+    return y, (buf, offs, widths, pa)
 
 
 @on_device_of
 def updated_stack_bwd(x0, layers, saved, dy):
     """-> per layer (dWe, dbe, dWl, dbl | None, dWr | None): views of one fp32 buffer"""
     import ctypes as C
-    buf, offs, widths = saved
+    buf, offs, widths, pa = saved
     dev, dt, L = x0.device, x0.dtype, len(layers)
     bf = dt == torch.bfloat16
     base = buf.data_ptr()
@@ -759,12 +769,19 @@ def updated_stack_bwd(x0, layers, saved, dy):
     gat = lambda e: None if e is None else gbase + 4 * e[0]
     P = [l["plan"] for l in layers]
     mx = lambda vals: max(list(vals) + [1])
-    work = lambda n: torch.empty(n, dtype=dt, device=dev)
-    dxb = [work(mx(P[i].n_src * widths[i] for i in range(1, L))) for _ in range(2)] if L > 1 else [None, None]
-    d_ea = work(mx(P[i].E * layers[i]["edge_in"] for i in range(1, L))) if L > 1 else None
-    dphi_ext = work(mx(P[i].E * widths[i] for i in range(L - 1))) if L > 1 else None
-    dz, da = work(mx(P[i].n_dst * widths[i + 1] for i in range(L))), work(mx(2 * P[i].n_dst * widths[i] for i in range(L)))
-    dphi = work(mx(P[i].E * widths[i] for i in range(L)))
+    # the seven work buffers of the backward (storage type) as pieces of one allocation, 16-byte aligned
+    esz = 2 if bf else 4
+    counts = [mx(P[i].n_src * widths[i] for i in range(1, L)) if L > 1 else 0] * 2 + [
+        mx(P[i].E * layers[i]["edge_in"] for i in range(1, L)) if L > 1 else 0, mx(P[i].E * widths[i] for i in range(L - 1)) if L > 1 else 0,
+        mx(P[i].n_dst * widths[i + 1] for i in range(L)), mx(2 * P[i].n_dst * widths[i] for i in range(L)), mx(P[i].E * widths[i] for i in range(L))]
+    woffs, wtot = [], 0
+    for c in counts:
+        woffs.append(wtot)
+        wtot += (c * esz + 15) & ~15
+    wbuf = torch.empty(max(wtot, 16), dtype=torch.uint8, device=dev)
+    wbase = wbuf.data_ptr()
+    wptr = [(wbase + o) if c else None for o, c in zip(woffs, counts)]
+    dxb, d_ea, dphi_ext, dz, da, dphi = wptr[0:2], wptr[2], wptr[3], wptr[4], wptr[5], wptr[6]
     scratch = _f32(max(lib().dgnn_sage_updated_train_scratch_elems(P[i].n_dst, P[i].E, widths[i], widths[i + 1], layers[i]["edge_in"]) for i in range(L)), dev)
     tps = [p.transposed_ptrs(False) for p in P]
     arr = lambda k: _parr([l[k] for l in layers])
@@ -773,10 +790,10 @@ def updated_stack_bwd(x0, layers, saved, dy):
     col = lambda j: _parr([gat(r[j]) for r in sizes])
     check(lib().dgnn_updated_stack_bwd(
         L, _parr([t[0] for t in tps]), _parr([t[1] for t in tps]), _parr([t[2] for t in tps]), _parr([p.part_ptrs(False)[0] for p in P]),
-        i64([p.n_src for p in P]), i64([p.n_dst for p in P]), i64([p.E for p in P]), ptr(x0), _ld(x0), i32(widths), i32([l["edge_in"] for l in layers]),
-        arr("We"), arr("Wl"), arr("Wr"), i32([int(bool(l["relu"])) for l in layers]), _parr([at(o["ea"]) for o in offs]), i64([o["ld_ea"] for o in offs]),
+        i64([p.n_src for p in P]), i64([p.n_dst for p in P]), i64([p.E for p in P]), ptr(x0), _ld(x0), pa["widths"], pa["edge_in"],
+        pa["We"], pa["Wl"], pa["Wr"], pa["relu"], _parr([at(o["ea"]) for o in offs]), i64([o["ld_ea"] for o in offs]),
         _parr([at(o["phi"]) for o in offs]), _parr([at(o["a"]) for o in offs]), _parr([at(o["y"]) for o in offs]), _parr([at(o["inv"]) for o in offs]),
-        ptr(dy), col(0), col(1), col(2), col(3), col(4), _parr(dxb), ptr(d_ea), ptr(dphi_ext), ptr(dz), ptr(da), ptr(dphi), ptr(scratch), int(bf), GEMM_MODE,
+        ptr(dy), col(0), col(1), col(2), col(3), col(4), _parr(dxb), d_ea, dphi_ext, dz, da, dphi, ptr(scratch), int(bf), GEMM_MODE,
         stream_ptr()), "dgnn_updated_stack_bwd")
     st = torch.as_strided
     grads = []
