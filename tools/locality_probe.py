@@ -27,7 +27,29 @@ def morton(c):
     return spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
 
 
-orders = {"generator": np.arange(n), "morton": np.argsort(morton(cent), kind="stable"), "random": np.random.default_rng(0).permutation(n)}
+rand = np.random.default_rng(0).permutation(n)
+
+
+def graph_orders(base):
+    """orders a plan could derive from the ADJACENCY alone (no coordinates), starting from the labelling `base` (a random one: the CGAL-ordered real
+    scene): reverse Cuthill-McKee, and plain breadth-first order from cell 0 -- as new -> old index vectors like the others"""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import breadth_first_order, reverse_cuthill_mckee
+    new_id = np.empty(n, np.int64)
+    new_id[base] = np.arange(n)
+    src = new_id[adj[:, 0]]
+    dst = new_id[adj[:, 1]]
+    A = sp.csr_matrix((np.ones(src.shape[0], np.int8), (dst, src)), shape=(n, n))
+    rcm = reverse_cuthill_mckee(A, symmetric_mode=True)
+    bfs = breadth_first_order(A, 0, directed=False, return_predecessors=False)
+    if bfs.shape[0] < n:      # unreachable cells (none on this graph) go last
+        bfs = np.concatenate([bfs, np.setdiff1d(np.arange(n), bfs)])
+    return base[rcm], base[bfs]
+
+
+orders = {"generator": np.arange(n), "morton": np.argsort(morton(cent), kind="stable"), "random": rand}
+if os.environ.get("GRAPH_ORDERS", "1") == "1":
+    orders["random->rcm"], orders["random->bfs"] = graph_orders(rand)
 g = torch.Generator().manual_seed(0)
 x = torch.randn(n, 29, generator=g)
 ea = torch.randn(4 * n, 20, generator=g)
@@ -56,4 +78,4 @@ for dtype in ("f32", "bf16"):
             e1.record(); torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) / 10)
             h = fn()
-        print("%-5s %-10s layers ms: %s  sum %.3f" % (dtype, name, " ".join("%.3f" % t for t in ts), sum(ts)), flush=True)
+        print("%-5s %-12s layers ms: %s  sum %.3f" % (dtype, name, " ".join("%.3f" % t for t in ts), sum(ts)), flush=True)
