@@ -519,6 +519,24 @@ int dgnn_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, int32_t*
     return DGNN_OK;
 }
 
+// How many blocks of k_plan_fallback the CURRENT device holds at once (2 per CU at most: the phases are bandwidth-bound); cached per device.
+static int plan_fallback_resident_blocks() {
+    static int cached[DGNN_MAX_DEVICES];   // 0 = not asked yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DGNN_MAX_DEVICES) dev = -1;
+    if (dev >= 0) {
+        const int c = __atomic_load_n(&cached[dev], __ATOMIC_ACQUIRE);
+        if (c > 0) return c;
+    }
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_plan_fallback), SCAN_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev < 0 ? 0 : dev) != hipSuccess || cus < 1) cus = 1;
+    (void)hipGetLastError();
+    const int blocks = (per_cu < 2 ? per_cu : 2) * cus;
+    if (dev >= 0) __atomic_store_n(&cached[dev], blocks, __ATOMIC_RELEASE);
+    return blocks;
+}
+
 // scratch layout (int32): deg[n_key] | tmp[E] | sums[nb+2] | big_count[1] | big_list[E/33+2] | need[2] | grid-barrier counter[1] (+1 pad)
 extern "C" int64_t dgnn_plan_scratch_elems(int64_t E, int64_t n_key) {
     if (E < 0 || n_key < 0) return 0;
@@ -575,10 +593,24 @@ extern "C" int dgnn_plan_build(const int64_t* edge_index, int64_t stride_row, in
                                other, eid, need);
     }
     if (standby) {
+        // The persistent kernel's grid barriers need every block resident at once: the grid is capped by what THIS device can hold
+        // (occupancy x its real CU count -- a CPX/SPX partition or another gfx9 part has fewer than 256), and the launch is a
+        // cooperative one, which the runtime refuses instead of hanging when the grid cannot be co-resident.
         const int64_t want = dgnn_cdiv(E > n_key ? E : n_key, (int64_t)SCAN_THREADS * 8);
-        const int grid = (int)(want < 1 ? 1 : (want < 2 * DGNN_NUM_CU ? want : 2 * DGNN_NUM_CU));
-        hipLaunchKernelGGL(k_plan_fallback, dim3(grid), dim3(SCAN_THREADS), 0, stream, key, oth, sc, E, n_key, n_other, rowptr, other, eid, deg, tmp,
-                           sums, nb, big_count, big_list, need, need + 2, aflag);
+        const int cap = plan_fallback_resident_blocks();
+        const int grid = (int)(want < 1 ? 1 : (want < cap ? want : cap));
+        int64_t sc_ = sc, E_ = E, nk_ = n_key, no_ = n_other;
+        int nb_ = nb;
+        int32_t* gsync = need + 2;
+        const int32_t* need_c = need;
+        void* args[] = {(void*)&key, (void*)&oth, &sc_, &E_, &nk_, &no_, &rowptr, &other, &eid, &deg, &tmp, &sums, &nb_, &big_count, &big_list,
+                        (void*)&need_c, &gsync, (void*)&aflag};
+        const hipError_t ce = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_plan_fallback), dim3(grid), dim3(SCAN_THREADS), args, 0, stream);
+        if (ce != hipSuccess) {
+            (void)hipGetLastError();
+            dgnn_set_error("plan_build: cooperative launch of the fallback builder: %s", hipGetErrorString(ce));
+            return DGNN_E_LAUNCH;
+        }
         return dgnn_check_launch("plan_build");
     }
     auto grid_for = [&](int64_t n) { return dim3((unsigned)dgnn_grid_cap(dgnn_cdiv(n, 256))); };

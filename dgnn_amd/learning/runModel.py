@@ -249,7 +249,7 @@ class Trainer:
         for current_epoch in range(1, clf.training.epochs + 1):
             clf.temp.current_epoch = current_epoch
             adjust_learning_rate(optimizer, clf)
-            for data.train.batch_size, data.train.batch_n_id, data.train.batch_adjs in _agreed_steps(data.train.batches, group):
+            for data.train.batch_size, data.train.batch_n_id, data.train.batch_adjs in _agreed_steps(data.train.batches, group, clf.temp.device):
                 iterations += 1
                 self.train(data.train, optimizer, clf, group)
                 printing = (iterations % clf.training.print_every) == 0 or iterations == 1
@@ -343,7 +343,7 @@ class Trainer:
         return logits_cell.to('cpu')
 
 
-def _agreed_steps(batches, group=None):
+def _agreed_steps(batches, group=None, device=None):
     """Iterates `batches`, but with data-parallel replicas (an initialised process group of more than one rank) only for as many steps as
     EVERY rank has: each step holds one gradient all-reduce, so a rank whose shard yields more batches than another's would wait in a
     collective nobody else enters.  With a length the ranks agree on min(len) once per epoch; without one they agree step by step on
@@ -354,8 +354,11 @@ def _agreed_steps(batches, group=None):
         yield from batches
         return
     on_gpu = dist.get_backend(group) == "nccl"     # RCCL reduces device tensors only
+    # ... on the TRAINER's GPU (clf.temp.device = "cuda:<n>", addressed without set_device as the reference does): a bare "cuda" is the thread's
+    # current device, which RCCL would take for a device mismatch
+    where = (device if (device is not None and str(device).startswith("cuda")) else "cuda") if on_gpu else "cpu"
     if hasattr(batches, "__len__"):
-        n = torch.tensor([len(batches)], dtype=torch.int64, device="cuda" if on_gpu else "cpu")
+        n = torch.tensor([len(batches)], dtype=torch.int64, device=where)
         dist.all_reduce(n, op=dist.ReduceOp.MIN, group=group)
         steps = int(n.item())
         it = iter(batches)
@@ -368,7 +371,7 @@ def _agreed_steps(batches, group=None):
     it = iter(batches)
     while True:
         item = next(it, None)
-        have = torch.tensor([0 if item is None else 1], dtype=torch.int64, device="cuda" if on_gpu else "cpu")
+        have = torch.tensor([0 if item is None else 1], dtype=torch.int64, device=where)
         dist.all_reduce(have, op=dist.ReduceOp.MIN, group=group)
         if int(have.item()) == 0:
             return

@@ -139,7 +139,16 @@ class NeighborSampler:
                         if ring_free[slot] is not None:
                             side.wait_event(ring_free[slot])
                         self._escaped = None
-                        pending = (self._start_regular(batch, background=True, b=ring[slot], stream=side.cuda_stream), None)
+                        # the library reads hipGetDevice() for its builder thread and the side stream belongs to self.device: make that device
+                        # current around the call when the caller's thread sits on another one (a bare setDevice pair, no context-manager objects)
+                        cur_dev, want_dev = torch._C._cuda_getDevice(), self.device.index
+                        if cur_dev != want_dev:
+                            torch._C._cuda_setDevice(want_dev)
+                        try:
+                            pending = (self._start_regular(batch, background=True, b=ring[slot], stream=side.cuda_stream), None)
+                        finally:
+                            if cur_dev != want_dev:
+                                torch._C._cuda_setDevice(cur_dev)
                     else:
                         with torch.cuda.device(self.device), torch.cuda.stream(side):
                             self._escaped = []
@@ -150,7 +159,7 @@ class NeighborSampler:
                         if ring is not None:
                             # the caller is done enqueueing the step on the block before this one: mark that point on ITS stream
                             ev = free_ev[(k - 3) % 3]
-                            ev.record(torch.cuda.current_stream())
+                            ev.record(torch.cuda.current_stream(self.device))   # (the sampler's device, whatever the thread's current one is)
                             ring_free[(k - 3) % 3] = ev
                         yield self._hand_over(blk)
                 if pending is not None:

@@ -506,6 +506,65 @@ def test_library_adam_follows_torch_adam():
         Adam([torch.nn.Parameter(torch.zeros(3))])          # a CPU parameter: the caller keeps torch.optim.Adam
 
 
+def test_library_adam_takes_over_a_torch_adam_state_mid_run():
+    """load_state_dict AFTER steps must switch the launch to the loaded moments (the pointer tables are cached), and a dict saved by
+    torch.optim.Adam (`step` a tensor) must load: three steps with torch's Adam, state handed over, four more steps on each -- same parameters"""
+    from dgnn_amd.optim import Adam
+    shapes = [(64, 28), (64,), (300, 7)]
+    mk = lambda: [torch.nn.Parameter(torch.randn(*sh, generator=torch.Generator().manual_seed(i)).to(DEV)) for i, sh in enumerate(shapes)]
+    pa, pb = mk(), mk()
+    oa, ob = Adam(pa, lr=2e-3), torch.optim.Adam(pb, lr=2e-3)
+    g = torch.Generator().manual_seed(5)
+
+    def grads():
+        for a, b in zip(pa, pb):
+            gr = torch.randn(*a.shape, generator=g).to(DEV)
+            a.grad, b.grad = gr.clone(), gr.clone()
+    grads()
+    oa.step()                                   # oa has stepped once on its OWN moments (tables cached) ...
+    for _ in range(3):
+        grads()
+        ob.step()
+    with torch.no_grad():
+        for a, b in zip(pa, pb):
+            a.copy_(b)
+    oa.load_state_dict(ob.state_dict())         # ... and now takes over torch's state: step tensors, torch's moment buffers
+    assert all(isinstance(oa.state[p]["step"], int) and oa.state[p]["step"] == 3 for p in pa)
+    for _ in range(4):
+        grads()
+        oa.step()
+        ob.step()
+    for a, b in zip(pa, pb):
+        assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item()) + 1e-7
+    assert oa.state[pa[0]]["step"] == 7
+    extra = torch.nn.Parameter(torch.ones(5, device=DEV))
+    oa.add_param_group(dict(params=[extra]))    # a new group invalidates the tables too
+    extra.grad = torch.ones(5, device=DEV)
+    oa.step()
+    assert oa.state[extra]["step"] == 1 and (extra < 1).all()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the reference addresses cuda:<n> without set_device)")
+def test_library_adam_and_block_builder_follow_their_tensors_device():
+    """parameters on cuda:1 while device 0 is current -- the step must launch on device 1's stream"""
+    from dgnn_amd.optim import Adam
+    assert torch.cuda.current_device() == 0
+    d1 = torch.device("cuda:1")
+    p = torch.nn.Parameter(torch.ones(1000, device=d1))
+    q = torch.nn.Parameter(torch.ones(1000, device=d1))
+    oa, ob = Adam([p], lr=1e-2), torch.optim.Adam([q], lr=1e-2)
+    for _ in range(3):
+        p.grad = torch.full((1000,), 0.5, device=d1)
+        q.grad = torch.full((1000,), 0.5, device=d1)
+        oa.step()
+        ob.step()
+    torch.cuda.synchronize(d1)
+    assert torch.cuda.current_device() == 0
+    assert (p - q).abs().max().item() <= 1e-6
+    with pytest.raises(ValueError):
+        Adam([torch.nn.Parameter(torch.ones(3, device="cuda:0")), torch.nn.Parameter(torch.ones(3, device=d1))])
+
+
 def test_aux_stream_backward_gives_identical_gradients():
     """dgnn_train_set_aux_stream(1): weight gradients on the library's second stream beside the dx chain -- same numbers"""
     from dgnn_amd._lib import lib
