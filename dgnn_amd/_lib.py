@@ -65,6 +65,13 @@ SIGNATURES = {
     "dgnn_fill_i32": (i32, [vp, i64, i32, vp]),
     "dgnn_standardize_scratch_doubles": (i64, [i32]),
     "dgnn_standardize_f64": (i32, [vp, i64, i64, i32, i32, vp, i64, vp, vp]),
+    "dgnn_cell_centroids_scratch_elems": (i64, [i64]),
+    "dgnn_cell_centroids_3dt": (i32, [vp, i64, vp, i64, vp, vp, i64, i64, i64, vp, vp, vp]),
+    "dgnn_cell_order_morton_scratch_elems": (i64, [i64]),
+    "dgnn_cell_order_morton": (i32, [vp, i64, vp, vp, vp, vp]),
+    "dgnn_cell_order_bfs_scratch_elems": (i64, [i64]),
+    "dgnn_cell_order_bfs": (i32, [vp, i64, i64, i64, vp, vp, vp, vp]),
+    "dgnn_reorder_edges_ref": (i32, [vp, i64, i64, i64, vp, vp, vp, vp, vp]),
     "dgnn_argmax_rows": (i32, [vp, i64, i64, i32, vp, vp]),
     "dgnn_compact_scratch_elems": (i64, [i64]),
     "dgnn_compact_i32": (i32, [vp, vp, i32, i64, vp, vp, vp, vp]),

@@ -7,6 +7,13 @@ un-scaled ``reg_<cell_type>`` copy in column 0), and leaves ``features`` [N, 1+F
 fp32, ``edge_lists`` int64 [2,E], ``gt``, ``infinite`` ON THE GPU.  Column selection is host-side bookkeeping on
 numpy arrays (no pandas); the per-scene StandardScaler (:471-506) runs on the device in fp64
 (dgnn_standardize_f64).  Only scaling 's' (all shipped configs) is implemented; others exit like the reference.
+
+Cell order (round 4): the reference builds ``edge_index`` straight from the file (:434-438), i.e. in CGAL's insertion order -- the 4
+neighbours of a cell are tens of thousands of rows apart and every neighbour gather of the conv layers misses L2.  ``run`` relabels the cells
+once per scene (``processing/reorder.py``: Morton order of the cell centroids from ``<scene>_3dt.npz``, breadth-first order of the adjacency when
+the scene has no coordinates), permutes ``features / edge_features / edge_lists / gt / infinite`` consistently and keeps the permutation as
+``cell_order``; ``exportScore`` and ``generate_mesh.generate`` put per-cell results back in file order.  ``clf.temp.cell_order`` = "auto" (default)
+| "morton" | "bfs" | "none" (or DGNN_CELL_ORDER in the environment).
 """
 from __future__ import annotations
 
@@ -17,6 +24,8 @@ import numpy as np
 import torch
 
 from .._lib import check, lib, ptr, stream_ptr
+from .. import ops
+from . import reorder
 
 
 def standardize(cols64: np.ndarray, c_first: int, device) -> torch.Tensor:
@@ -112,7 +121,9 @@ class dataLoader:
         self.infinite = torch.from_numpy(lab["infinite"]).to(dev).bool()
         self.node_feature_names, nodes = self._node_columns(base)
         adj = np.load(base + "_adjacencies.npz")["adjacencies"]
-        self.edge_lists = torch.from_numpy(np.ascontiguousarray(adj.T.astype(np.int64))).to(dev)
+        # the reference's own layout (:437-438): the [E,2] array on the device, handed on as its transposed view (strides (1,2)) -- read in place by the
+        # plan builder, whose four-lanes-per-cell pass takes exactly this view
+        self.edge_lists = torch.from_numpy(np.ascontiguousarray(adj.astype(np.int64))).to(dev).t()
         scaling = self.clf.features.scaling
         if scaling != "s" or self.clf.features.node_normalization_feature is not None \
                 or self.clf.features.edge_normalization_feature is not None:
@@ -128,6 +139,39 @@ class dataLoader:
         else:
             self.edge_features = torch.empty(1, 1, dtype=torch.float32, device=dev)
         self.n_nodes += self.features.size(0)
+        self.cell_order = None
+        kind = str(getattr(self.clf.temp, "cell_order", None) or os.environ.get("DGNN_CELL_ORDER", "auto")).lower()
+        if kind not in ("none", "0", "false", "off"):
+            self._reorder_cells(base, kind)
+
+    def _reorder_cells(self, base, kind):
+        """relabels the scene (module docstring); every per-cell / per-edge tensor of the loader moves with its cell"""
+        n = self.features.size(0)
+        ei = self.edge_lists
+        co = reorder.scene_order(ei, n, infinite=self.infinite, mfile=base + "_3dt.npz", kind=kind)
+        if co is None:
+            return
+        ei_new, edge_rows = reorder.reorder_edges(ei, co.order, co.rank)
+        self.features = ops.gather_rows(self.features, co.order)
+        if self.read_edge_features:
+            self.edge_features = ops.gather_rows(self.edge_features, edge_rows)
+        self.edge_lists = ei_new
+        self.gt = co.to_rows(self.gt)
+        self.infinite = co.to_rows(self.infinite)
+        self.cell_order = co
+        for t in (self.features, self.gt, self.infinite):      # an unmodified run.py:prepareSample copies these tensors, not the loader's fields
+            setattr(t, reorder.RANK_TAG, co)
+
+    def exportScore(self, prediction):
+        """reference :521-535 -- the scores of the cells in FILE order (the order every consumer of <out>/prediction/<scene>.npz knows)"""
+        outpath = os.path.join(self.clf.paths.out, "prediction")
+        os.makedirs(outpath, exist_ok=True)
+        if self.verbosity:
+            print("Export predictions to: ", outpath)
+        prediction = reorder.restore_cell_order(torch.as_tensor(prediction), self).detach().cpu()
+        with open(os.path.join(outpath, self.filename + ".npz"), "wb") as f:
+            np.savez(f, number_of_cells=int(len(prediction)), sigmoid=prediction.sigmoid().numpy(), logits=prediction.numpy(),
+                     softmax=prediction.softmax(dim=-1).numpy())
 
     def getInfo(self):
         """Sets clf.temp.num_{node,edge}_features as the reference does (:39-48)."""

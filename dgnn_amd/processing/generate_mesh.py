@@ -116,6 +116,10 @@ def generate(data, prediction, clf):
     dev = prediction.device if prediction.is_cuda else torch.device(getattr(clf.temp, "device", "cuda:0"))
     pred_dev = prediction.to(dev, torch.float32)
     infinite = torch.as_tensor(data.infinite)
+    # a scene the loader relabelled (processing/reorder.py): `_3dt.npz` knows the cells in FILE order -- logits and the infinite flags go back to it
+    from .reorder import restore_cell_order
+    pred_dev, prediction = restore_cell_order(pred_dev, data), restore_cell_order(prediction, data)
+    infinite = restore_cell_order(infinite, data)
     mfile = os.path.join(data.path, data.gtfile + "_3dt.npz")
     mdata = np.load(mfile)
     nfacets = np.ascontiguousarray(mdata["nfacets"]).astype(np.int32)

@@ -1,0 +1,124 @@
+"""Ingest-time cell locality order (csrc/reorder.hip).
+
+The reference hands the network a scene in the order its CGAL front end wrote the cells (``processing/data.py:434-438`` builds
+``edge_index`` straight from ``<scene>_adjacencies.npz``): the 4 neighbours of a cell are tens of thousands of rows apart, so every
+neighbour-row gather of the conv layers misses L2.  ``dataLoader.run`` (``processing/data.py`` of this package) therefore relabels
+the cells once per scene and remembers the permutation; per-cell results go back to file order where they leave
+(``dataLoader.exportScore``, ``generate_mesh.generate``) through ``restore_cell_order``.
+
+``order[i]`` = file-order id of the cell that sits in row i; ``rank`` = its inverse (``rank[order[i]] == i``).  Everything here
+is index work on the device; the permutation is deterministic.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .._lib import check, lib, on_device_of, ptr, stream_ptr
+
+RANK_TAG = "_dgnn_cell_rank"     # attribute the loader puts on its per-cell tensors so that an UNMODIFIED run.py:prepareSample still carries the order
+
+
+def _i32(n, dev):
+    return torch.empty(int(max(n, 1)), dtype=torch.int32, device=dev)
+
+
+@on_device_of
+def centroids_from_3dt(vertices: torch.Tensor, tetrahedra: torch.Tensor, infinite: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
+    """fp32 [n,3] centroids: finite cell i is tetrahedron number (count of finite cells before i) of `_3dt.npz` (generate_mesh.py:78-81),
+    an infinite cell sits on its finite neighbour."""
+    dev = edge_index.device
+    n = infinite.numel()
+    v = vertices.to(dev, torch.float32).contiguous()
+    t = tetrahedra.to(dev, torch.int32).contiguous()
+    inf = infinite.to(dev, torch.int32).contiguous()
+    cent = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    scratch = _i32(lib().dgnn_cell_centroids_scratch_elems(n), dev)
+    check(lib().dgnn_cell_centroids_3dt(ptr(v), v.size(0), ptr(t), t.size(0), ptr(inf), ptr(edge_index), edge_index.stride(0), edge_index.stride(1), n,
+                                        ptr(cent), ptr(scratch), stream_ptr()), "dgnn_cell_centroids_3dt", poll=True)
+    return cent
+
+
+@on_device_of
+def cell_order_morton(centroids: torch.Tensor):
+    """-> (order, rank) int32 [n]: cells sorted (stable) by the 48-bit Morton code of their centroid"""
+    c = centroids.to(torch.float32).contiguous()
+    n, dev = c.size(0), c.device
+    order, rank = _i32(n, dev)[:n], _i32(n, dev)[:n]
+    scratch = torch.empty(int(lib().dgnn_cell_order_morton_scratch_elems(n)) // 2 + 1, dtype=torch.int64, device=dev)   # 8-byte aligned
+    check(lib().dgnn_cell_order_morton(ptr(c), n, ptr(order), ptr(rank), ptr(scratch), stream_ptr()), "dgnn_cell_order_morton")
+    return order, rank
+
+
+@on_device_of
+def cell_order_bfs(edge_index: torch.Tensor, n: int):
+    """-> (order, rank) int32 [n] from the adjacency alone (reference layout: row 4t+k of edge_index leaves cell t): breadth-first order"""
+    if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2 or edge_index.size(1) != 4 * n:
+        raise ValueError("cell_order_bfs needs the reference layout: int64 [2, 4n]")
+    dev = edge_index.device
+    order, rank = _i32(n, dev)[:n], _i32(n, dev)[:n]
+    scratch = _i32(lib().dgnn_cell_order_bfs_scratch_elems(n), dev)
+    check(lib().dgnn_cell_order_bfs(ptr(edge_index), edge_index.stride(0), edge_index.stride(1), n, ptr(order), ptr(rank), ptr(scratch), stream_ptr()),
+          "dgnn_cell_order_bfs", poll=True)
+    return order, rank
+
+
+@on_device_of
+def reorder_edges(edge_index: torch.Tensor, order: torch.Tensor, rank: torch.Tensor):
+    """-> (edge_index' int64 [2,4n] = the transposed view of an [4n,2] array, as the reference's loader builds it (data.py:437-438),
+    edge_rows int32 [4n] = old row of every new edge row)"""
+    n, dev = order.numel(), edge_index.device
+    pairs = torch.empty((4 * n, 2), dtype=torch.int64, device=dev)
+    rows = _i32(4 * n, dev)[:4 * n]
+    check(lib().dgnn_reorder_edges_ref(ptr(edge_index), edge_index.stride(0), edge_index.stride(1), n, ptr(order), ptr(rank), ptr(pairs), ptr(rows),
+                                       stream_ptr()), "dgnn_reorder_edges_ref", poll=True)
+    return pairs.t(), rows
+
+
+class CellOrder:
+    """A scene's permutation: `order` (row -> file id), `rank` (file id -> row), both int32 on the device, and how it was made."""
+
+    def __init__(self, order, rank, kind):
+        self.order, self.rank, self.kind = order, rank, kind
+
+    def to_rows(self, t: torch.Tensor) -> torch.Tensor:
+        """per-cell tensor in file order -> row order"""
+        return t[self.order.to(t.device).long()]
+
+    def to_file(self, t: torch.Tensor) -> torch.Tensor:
+        """per-cell tensor in row order -> file order (where results leave)"""
+        return t[self.rank.to(t.device).long()]
+
+
+def scene_order(edge_index: torch.Tensor, n: int, infinite=None, mfile: str = None, centroids=None, kind: str = "auto"):
+    """The order `dataLoader.run` applies: Morton order of the cell centroids when the scene has coordinates (`centroids`, or
+    `<scene>_3dt.npz` at `mfile`), else breadth-first order of the adjacency.  kind: auto | morton | bfs.  None when the adjacency is not the reference
+    layout (nothing is reordered then)."""
+    import os
+    if edge_index.dim() != 2 or edge_index.size(1) != 4 * n or n == 0:
+        return None
+    if kind in ("auto", "morton"):
+        if centroids is None and mfile is not None and os.path.isfile(mfile) and infinite is not None:
+            m = np.load(mfile)
+            if "vertices" in m.files and "tetrahedra" in m.files and len(m["tetrahedra"]) == int((torch.as_tensor(infinite) == 0).sum()):
+                centroids = centroids_from_3dt(torch.from_numpy(np.ascontiguousarray(m["vertices"], dtype=np.float32)),
+                                               torch.from_numpy(np.ascontiguousarray(m["tetrahedra"]).astype(np.int32)),
+                                               torch.as_tensor(infinite), edge_index)
+        if centroids is not None:
+            return CellOrder(*cell_order_morton(centroids.to(edge_index.device)), "morton")
+        if kind == "morton":
+            raise ValueError("cell order 'morton' needs coordinates (<scene>_3dt.npz with as many tetrahedra as finite cells)")
+    return CellOrder(*cell_order_bfs(edge_index, n), "bfs")
+
+
+def restore_cell_order(t: torch.Tensor, data) -> torch.Tensor:
+    """Per-cell tensor `t` (rows in the order of `data`) back in FILE order; `data` is the loader, a dataset object carrying `cell_order`, or
+    one built by an unmodified `run.py:prepareSample` (the loader tags its per-cell tensors).  Unchanged when the scene was not reordered."""
+    co = getattr(data, "cell_order", None)
+    if co is None:
+        for name in ("infinite", "x", "features", "y", "gt"):
+            v = getattr(data, name, None) if not isinstance(data, dict) else data.get(name)
+            co = getattr(v, RANK_TAG, None) if v is not None else None
+            if co is not None:
+                break
+    return t if co is None else co.to_file(t)

@@ -619,6 +619,38 @@ int64_t dgnn_standardize_scratch_doubles(int c);
 int dgnn_standardize_f64(const double* x, int64_t ld, int64_t n, int c, int c_first, float* out, int64_t ldo, double* scratch,
                          void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Ingest-time cell locality order (sits where the reference builds edge_index, processing/data.py:434-438).
+ * CGAL writes the cells in insertion order (the 4 neighbours of a cell are tens of thousands of rows apart); the loader relabels them once
+ * per scene so that the conv layers' neighbour gathers hit L2, and keeps the permutation for the places where per-cell results leave
+ * (dataLoader.exportScore, generate_mesh.generate :75-81).  All int32 index work, deterministic:
+ *   dgnn_cell_centroids_3dt  centroids [n,3] from <scene>_3dt.npz: `vertices` fp32 [n_vertices,3], `tetrahedra` int32 [n_finite,4] = the
+ *                            FINITE cells in file order (generate_mesh.py:78-81 relies on the same correspondence); `infinite` int32 [n]
+ *                            (labels.npz, :202-208); an infinite cell takes its finite neighbour's centroid (edge_index rows 4i..4i+3).
+ *                            scratch: dgnn_cell_centroids_scratch_elems(n) int32
+ *   dgnn_cell_order_morton   order[i] = old id of new cell i (cells sorted, stable, by the 48-bit Morton code of their centroid: 16 bits per
+ *                            axis over the bounding box), rank = its inverse.  scratch (8-byte aligned): dgnn_cell_order_morton_scratch_elems(n) int32
+ *   dgnn_cell_order_bfs      the same from the adjacency alone (no coordinates): breadth-first order, every level in the order a serial
+ *                            queue produces (first discoverer wins, neighbours in slot order), components started at their lowest cell id.
+ *                            Reference layout required (row 4t+k leaves cell t).  SYNCHRONISES `stream` once per level (ingest-time call).
+ *                            scratch: dgnn_cell_order_bfs_scratch_elems(n) int32
+ *   dgnn_reorder_edges_ref   relabelled adjacency: pairs_out int64 [4n,2] = (new src, new dst) of new edge row e = old row 4*order[e/4] + e%4,
+ *                            i.e. the reference layout again (its transposed [2,4n] view with strides (1,2) is what dgnn_plan_build's
+ *                            REFERENCE fast path takes); edge_rows_out int32 [4n] = that old row (gathers edge_attr with dgnn_gather_rows_f32).
+ *                            A source that is not the reference layout raises the asynchronous index error.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t dgnn_cell_centroids_scratch_elems(int64_t n);
+int dgnn_cell_centroids_3dt(const float* vertices, int64_t n_vertices, const int32_t* tetrahedra, int64_t n_finite, const int32_t* infinite,
+                            const int64_t* edge_index, int64_t stride_row, int64_t stride_col, int64_t n, float* centroids, int32_t* scratch,
+                            void* stream);
+int64_t dgnn_cell_order_morton_scratch_elems(int64_t n);
+int dgnn_cell_order_morton(const float* centroids, int64_t n, int32_t* order, int32_t* rank, int32_t* scratch, void* stream);
+int64_t dgnn_cell_order_bfs_scratch_elems(int64_t n);
+int dgnn_cell_order_bfs(const int64_t* edge_index, int64_t stride_row, int64_t stride_col, int64_t n, int32_t* order, int32_t* rank,
+                        int32_t* scratch, void* stream);
+int dgnn_reorder_edges_ref(const int64_t* edge_index, int64_t stride_row, int64_t stride_col, int64_t n, const int32_t* order,
+                           const int32_t* rank, int64_t* pairs_out, int32_t* edge_rows_out, void* stream);
+
 /* elementwise helpers used by the Updated variant (F.relu at surfaceNetUpdatedEdgeFilters.py:239-241
  * and the scatter of phi rows into the zero [E_all,C] buffer at :236-237) */
 int dgnn_relu(const float* x, int64_t n, float* y, void* stream);

@@ -953,7 +953,7 @@ def test_generate_matches_the_reference_run(tmp_path, fix):
         assert np.array_equal(np.asarray(mesh.faces), g["faces"]) and np.array_equal(np.asarray(mesh.vertices), g["vertices_out"])
 
 
-def test_npz_ingest_matches_reference_loader_and_feeds_inference():
+def test_npz_ingest_matches_reference_loader_and_feeds_inference(tmp_path):
     """8f-3: dgnn_amd.processing.data.dataLoader (device fp64 standardisation) == the reference dataLoader's tensors on
     the small scene; the loaded scene then runs through inference_layer and matches the oracle on the fixture tensors."""
     import os
@@ -961,10 +961,12 @@ def test_npz_ingest_matches_reference_loader_and_feeds_inference():
     from dgnn_amd.processing.data import dataLoader, standardize
     g = gold("ingest_small.npz")
     clf = reconbench_pretrained()
+    clf.temp.cell_order = "none"          # the reference's order (file order); the relabelled scene is checked below
     dl = dataLoader(clf, verbosity=0)
     root = os.path.join(os.path.dirname(__file__), "golden", "scene_small")
     dl.run(dict(path=root, filename="0", category="", id="", scan_conf="", gtfile="gt/0", ioufile=""))
-    assert dl.features.is_cuda and dl.features.dtype == torch.float32
+    assert dl.features.is_cuda and dl.features.dtype == torch.float32 and dl.cell_order is None
+    assert dl.edge_lists.stride() == (1, 2)          # the reference's transposed view of its [E,2] array (data.py:437-438)
     assert torch.equal(dl.features[:, 0].cpu(), torch.from_numpy(g["features"][:, 0]))
     assert (dl.features.cpu() - torch.from_numpy(g["features"])).abs().max().item() <= 1e-6
     assert (dl.edge_features.cpu() - torch.from_numpy(g["edge_features"])).abs().max().item() <= 1e-6
@@ -985,6 +987,33 @@ def test_npz_ingest_matches_reference_loader_and_feeds_inference():
         want = oracle_static().inference_layer(Config(x=torch.from_numpy(g["features"]), edge_attr=torch.from_numpy(g["edge_features"]),
                                                       edge_index=torch.from_numpy(g["edge_lists"])))
     assert (logits.cpu() - want).abs().max().item() <= TOL_LOGIT * max(1.0, want.abs().max().item())
+    # default: the loader relabels the cells (no _3dt.npz here -> breadth-first order of the adjacency).  Every tensor moves with its cell, the
+    # graph is the same graph, and per-cell results restored to file order are the reference's
+    from dgnn_amd.processing.reorder import restore_cell_order
+    clf2 = reconbench_pretrained()
+    d2 = dataLoader(clf2, verbosity=0)
+    d2.run(dict(path=root, filename="0", category="", id="", scan_conf="", gtfile="gt/0", ioufile=""))
+    co = d2.cell_order
+    assert co is not None and co.kind == "bfs"
+    order = co.order.cpu().long()
+    n = order.numel()
+    assert torch.equal(torch.sort(order).values, torch.arange(n)) and torch.equal(co.rank.cpu().long()[order], torch.arange(n))
+    assert torch.equal(d2.features.cpu(), dl.features.cpu()[order]) and torch.equal(d2.gt.cpu(), dl.gt.cpu()[order])
+    assert torch.equal(d2.infinite.cpu(), dl.infinite.cpu()[order])
+    ei_old, ei_new = dl.edge_lists.cpu(), d2.edge_lists.cpu()
+    assert torch.equal(ei_new[0], torch.arange(n).repeat_interleave(4)) and d2.edge_lists.stride() == (1, 2)
+    assert torch.equal(order[ei_new[1]].view(n, 4), ei_old[1].view(-1, 4)[order])          # same neighbours, slot for slot
+    assert torch.equal(d2.edge_features.cpu().view(n, 4, -1), dl.edge_features.cpu().view(-1, 4, 20)[order])
+    data2 = Config(x=d2.features, edge_attr=d2.edge_features, edge_index=d2.edge_lists, infinite=d2.infinite, y=d2.gt)   # as run.py:prepareSample builds it
+    logits2 = net.inference_layer(data2)
+    back = restore_cell_order(logits2, data2)          # finds the order through the loader's tensors (an unmodified prepareSample)
+    assert (back - logits).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())   # same sums in another order
+    assert (back.cpu() - want).abs().max().item() <= TOL_LOGIT * max(1.0, want.abs().max().item())
+    assert torch.equal(restore_cell_order(d2.infinite, d2).cpu(), torch.from_numpy(g["infinite"]))
+    clf2.paths = Config(out=str(tmp_path))
+    d2.exportScore(logits2.cpu())
+    saved = np.load(os.path.join(str(tmp_path), "prediction", "0.npz"))
+    assert np.array_equal(saved["logits"], back.cpu().numpy()) and int(saved["number_of_cells"]) == n
 
 
 def test_integration_md_ctypes_stub_runs_and_matches_the_oracle():
