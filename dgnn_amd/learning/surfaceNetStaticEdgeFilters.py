@@ -275,6 +275,9 @@ class SurfaceNet(nn.Module):
         xe = _dev_f32(data_all.edge_attr, dev)
         xe = xe[:, 1:] if self.clf.regularization.edge_type else xe
         edge_index = data_all.edge_index.to(dev)
+        one = self._infer_one_call(x, xe, edge_index, plan)
+        if one is not None:
+            return one
         if plan is None:
             # whole scene as processing/data.py delivers it: 4 adjacency rows per cell (verified on the device, any
             # other layout falls through to the generic builder)
@@ -283,6 +286,48 @@ class SurfaceNet(nn.Module):
             return self._eval_layers(x, x.size(0), xe, [plan] * self.num_layers, sorted_attr=True, decode=True)   # last launch writes the logits
         x = self._eval_layers(x, x.size(0), xe, [plan] * self.num_layers, sorted_attr=True)
         return self._eval_decoder(x)
+
+    def _infer_one_call(self, x, xe, edge_index, plan):
+        """The whole eval forward -- plan (unless the caller's or a cached one exists), every conv layer, the decoder -- as ONE library call
+        (dgnn_static_infer_fwd issues the launches `_eval_layers` issues, in its order: bit-identical).  Returns the logits, or None when this
+        configuration runs layer by layer: other storage / widths / filters, a per-layer profiling hook, rows the fused kernels do not take."""
+        from ..graph import register_plan
+        if not (ops.INFER_ONE_CALL and ops.FUSED_ENABLED and ops.EDGE_GATHER_IN_KERNEL) or ops.LAYER_HOOK is not None:
+            return None
+        if self.storage_dtype != torch.float32 or x.dtype != torch.float32 or xe.dtype != torch.float32 or xe.dim() != 2 or xe.size(1) != 20 \
+                or xe.stride(0) != 20 or xe.data_ptr() % 16 or edge_index.dtype != torch.int64 or x.size(0) * max(x.stride(0), 128) >= ops.FUSED_MAX_ELEMS:
+            return None
+        dec = self.decoder if self.clf.model.decoder else ()
+        if len(dec) not in (0, 4) or (len(dec) == 4 and not (isinstance(dec[0], nn.Linear) and isinstance(dec[3], nn.Linear)
+                                                              and (dec[1] is None or isinstance(dec[1], BatchNorm)))):
+            return None
+        layers, prepared, last = [], [], self.num_layers - 1
+        with_dec = len(dec) == 4 and self.fuses_decoder(last)
+        for i, layer in enumerate(self.convs):
+            conv = layer[0]
+            le = conv.lin_e
+            if not (isinstance(le, Linear) and le.in_features == 20 and le.bias is not None) or not isinstance(layer[2], nn.ReLU) \
+                    or not (layer[1] is None or isinstance(layer[1], BatchNorm)):
+                return None
+            scale, shift = self._fold(layer[1], conv.lin_j.out_features, x.device)
+            layers.append((le.weight, le.bias, conv.lin_j.weight, conv.lin_j.bias, conv.lin_i.weight, scale, shift))
+            prepared.append(self._prepared(i, with_dec and i == last))
+        decoder = None
+        if len(dec) == 4:
+            s1, h1 = self._fold(dec[1], dec[0].out_features, x.device)
+            decoder = (dec[0].weight, dec[0].bias, s1, h1, dec[3].weight, dec[3].bias)
+        n = x.size(0)
+        if plan is None:
+            held = getattr(edge_index, "_dgnn_plans", None)       # a resident scene: the plan of an earlier call (plan_for's cache)
+            if held:
+                plan = plan_for(edge_index, n, n, hint=ops.PLAN_HINT_REFERENCE)
+        parts = None if plan is None else (plan.rowptr, plan.src, plan.eid)
+        out = ops.static_infer_fwd(x, xe, edge_index, parts, layers, decoder, prepared)
+        if out is None:
+            return None
+        if plan is None:
+            register_plan(edge_index, GraphPlan(edge_index, n, n, hint=ops.PLAN_HINT_REFERENCE, parts=out[1]))
+        return out[0]
 
     def _fusable_rows(self, x, i):
         """the fused launches take packed 20-column fp32 edge rows and 16-byte aligned feature rows; other inputs run layer and decoder apart"""

@@ -523,6 +523,52 @@ def sage_layer_fused_decoder_fwd(rowptr, src, n_dst, x_src, edge_attr, We, be, W
     return out
 
 
+# whole-scene inference as ONE library call (dgnn_static_infer_fwd: plan + every conv layer + decoder); DGNN_INFER_ONE_CALL=0 keeps the per-layer calls
+INFER_ONE_CALL = __import__("os").environ.get("DGNN_INFER_ONE_CALL", "1") != "0"
+
+
+@on_device_of
+def static_infer_fwd(x, edge_attr, edge_index, plan_parts, layers, decoder, prepared=None, hint=PLAN_HINT_REFERENCE, gemm_mode=None):
+    """-> (logits | last activations, plan parts) or None when a shape is outside the fused kernels (nothing launched).
+    `plan_parts` = (rowptr, src, eid) of an existing plan, or None: the plan is built inside the call from `edge_index` (int64 [2,E], any strides)
+    and its arrays are returned.  `layers`: per conv layer (We, be, Wj, bj, Wi, scale | None, shift | None); `decoder` = (W0, b0, scale1 | None,
+    shift1 | None, W3, b3) or None; `prepared`: per-layer dgnn_sage_layer_prepare buffers (the last one made with the decoder) or None."""
+    import ctypes as C
+    _req(x, "x", dim=2)
+    _req(edge_attr, "edge_attr", dim=2)
+    n, dev, L = x.size(0), x.device, len(layers)
+    widths = [x.size(1)] + [l[2].size(0) for l in layers]
+    w_arr = (C.c_int32 * (L + 1))(*widths)
+    E = edge_index.size(1) if edge_index is not None else plan_parts[1].numel()
+    build = plan_parts is None
+    if build:
+        rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        src = torch.empty(max(E, 1), dtype=torch.int32, device=dev)[:E]
+        eid = torch.empty(max(E, 1), dtype=torch.int32, device=dev)[:E]
+        scratch = torch.empty(int(lib().dgnn_plan_scratch_elems(E, n)), dtype=torch.int32, device=dev)
+        plan_parts = (rowptr, src, eid)
+    else:
+        rowptr, src, eid = plan_parts
+        scratch = None
+    n_out = decoder[4].size(0) if decoder is not None else widths[-1]
+    logits = torch.empty((n, n_out), dtype=torch.float32, device=dev)
+    work = torch.empty(int(lib().dgnn_static_infer_workspace_bytes(n, L, w_arr)), dtype=torch.uint8, device=dev)   # (the caching allocator hands out 512-byte aligned blocks)
+
+    def col(i):
+        return (C.c_void_p * L)(*[(l[i].data_ptr() if l[i] is not None else None) for l in layers])
+    prep = (C.c_void_p * L)(*[(p.data_ptr() if p is not None else None) for p in prepared]) if prepared is not None else None
+    d = decoder if decoder is not None else (None,) * 6
+    rc = lib().dgnn_static_infer_fwd(
+        ptr(edge_index) if build else None, edge_index.stride(0) if build else 0, edge_index.stride(1) if build else 0, E, hint, ptr(rowptr), ptr(src),
+        ptr(eid), ptr(scratch), n, ptr(x), _ld(x), ptr(edge_attr), _ld(edge_attr), edge_attr.size(1), L, w_arr, col(0), col(1), col(2), col(3), col(4),
+        col(5), col(6), prep, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), d[0].size(0) if d[0] is not None else 0, ptr(d[4]), ptr(d[5]),
+        d[4].size(0) if d[4] is not None else 0, GEMM_MODE if gemm_mode is None else gemm_mode, ptr(work), ptr(logits), stream_ptr())
+    if rc == DGNN_E_UNSUPPORTED:
+        return None
+    check(rc, "dgnn_static_infer_fwd", poll=build)
+    return logits, plan_parts
+
+
 def decoder_fused_supported(k: int, hidden: int, n_out: int) -> bool:
     return k == 128 and hidden == 64 and n_out in (1, 2)
 

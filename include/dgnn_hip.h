@@ -322,6 +322,31 @@ int dgnn_sage_layer_fused_decoder_fwd_p(const int32_t* rowptr, const int32_t* sr
                                         float* logits, const void* prepared, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Whole-scene inference, ONE call (SurfaceNet.inference_layer, learning/surfaceNetStaticEdgeFilters.py:323-355: every conv -> norm -> relu
+ * over the whole graph, then the decoder :350-351).
+ *   plan     edge_index != NULL: the destination-sorted plan of the scene is built first (dgnn_plan_build with `plan_hint`) INTO the caller's
+ *            rowptr [n+1] / src [E] / eid [E] / plan_scratch [dgnn_plan_scratch_elems(E, n)] -- they stay valid for later calls on the same
+ *            graph; edge_index == NULL: rowptr / src / eid ARE the plan (eid NULL = edge_attr already in plan order).  edge_attr rows follow
+ *            edge_index and are gathered through eid inside the layer launches.
+ *   layers   n_layers fused conv layers (dgnn_sage_layer_fused_fwd[_p]; BatchNorm(eval) folded into scale[l] / shift[l], NULL = none; ReLU)
+ *   decoder  Linear(widths[L] -> c_hidden) - BatchNorm(eval, scale1 / shift1) - ReLU - Linear(-> n_logits) inside the last layer's launch
+ *            (dgnn_sage_layer_fused_decoder_fwd[_p]) or as dgnn_decoder_fused_fwd behind it; W0 == NULL: no decoder, `logits` receives the
+ *            last layer's rows [n, widths[L]]
+ * Per-layer arguments are HOST arrays [n_layers] of device pointers (widths [n_layers + 1]); prepared (may be NULL, entries may be NULL):
+ * dgnn_sage_layer_prepare buffers, the last one made WITH the decoder.  Issues exactly the launches of the per-layer entry points, in their
+ * order: bit-identical results; nothing allocates or synchronises.  Shapes outside the fused kernels (see dgnn_sage_layer_fused_fwd):
+ * DGNN_E_UNSUPPORTED before anything is launched.  workspace: dgnn_static_infer_workspace_bytes(n, n_layers, widths) bytes, 16-byte aligned.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t dgnn_static_infer_workspace_bytes(int64_t n, int n_layers, const int32_t* widths);
+int dgnn_static_infer_fwd(const int64_t* edge_index, int64_t stride_row, int64_t stride_col, int64_t E, int plan_hint, int32_t* rowptr,
+                          int32_t* src, int32_t* eid, int32_t* plan_scratch, int64_t n, const float* x, int64_t ldx, const float* edge_attr,
+                          int64_t lde, int f_e, int n_layers, const int32_t* widths, const float* const* We, const float* const* be,
+                          const float* const* Wj, const float* const* bj, const float* const* Wi, const float* const* scale,
+                          const float* const* shift, const void* const* prepared, const float* W0, const float* b0, const float* scale1,
+                          const float* shift1, int c_hidden, const float* W3, const float* b3, int n_logits, int gemm_mode, void* workspace,
+                          float* logits, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Training-mode conv layer, one call each way (SurfaceNet.forward :214-219 and its autograd, learning/runModel.py:279):
  *   forward : a = aggregate(x)  ->  z = a.Wj^T + x[:n_dst].Wi^T + bj  ->  BatchNorm1d with batch statistics (running buffers
  *             updated when given)  ->  y = relu(.)       rowptr == NULL: a plain Linear + BatchNorm (+ReLU) block, z = x.Wj^T + bj

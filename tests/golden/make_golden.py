@@ -667,8 +667,22 @@ def round3():
     trainer_fixture(ref, host, sd)
 
 
+def round4():
+    """Round 4 (ingest-time cell order): the geometry of the real scene that `static_f4_ignatius_full.npz` holds the features / adjacency / logits of
+    -- `vertices` and `tetrahedra` of data/Ignatius/gt/99_3dt.npz and the per-cell `infinite` flags of 99_labels.npz (data files of the reference,
+    stored as they are: fp64 vertices, int32 indices) -- so that the loader's Morton order runs on a scene in CGAL's own cell order."""
+    base = os.path.join(REF, "data/Ignatius/gt/99")
+    m = np.load(base + "_3dt.npz")
+    inf = np.load(base + "_labels.npz")["infinite"]
+    assert len(m["tetrahedra"]) == int((inf == 0).sum())
+    np.savez_compressed(os.path.join(HERE, "ignatius_3dt.npz"), vertices=m["vertices"], tetrahedra=m["tetrahedra"], infinite=inf)
+    print("round4 ignatius_3dt", m["vertices"].shape, m["tetrahedra"].shape, inf.shape, int(inf.sum()), "infinite cells")
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["ingest"]:      # only the 8f-3 fixture (independent seed)
+    if sys.argv[1:] == ["round4"]:
+        round4()
+    elif sys.argv[1:] == ["ingest"]:      # only the 8f-3 fixture (independent seed)
         ingest_fixture(np.random.default_rng(5))
     elif sys.argv[1:] == ["round3"]:    # only the fixtures added in round 3 (8f-2 trainer, 8f-4 interface; reference host code under stubs)
         round3()
@@ -685,3 +699,4 @@ if __name__ == "__main__":
         ignatius_full(_ref, _sd)
         layer_batch_fixture(_ref, _sd)
         round3()
+        round4()

@@ -1,0 +1,183 @@
+"""Whole-scene inference as ONE library call (dgnn_static_infer_fwd, csrc/infer.hip): the call issues the launches the
+per-layer entry points issue, so its logits must be BIT-IDENTICAL to the layer-by-layer path -- which the other suites hold to the oracle and
+to the reference's golden logits -- on every graph shape, plan source and arithmetic mode; plus the oracle directly on one scene."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from dgnn_amd.config import Config
+from helpers import gold, oracle_static
+from test_gpu_parity import DEV, TOL_LOGIT, hip_static
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(points, seed=0, layout="transposed"):
+    from dgnn_amd.synthetic import delaunay_tet_graph
+    adj, _, _ = delaunay_tet_graph(points, seed=seed)
+    n = adj.shape[0] // 4
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 29, generator=g)
+    ea = torch.randn(4 * n, 20, generator=g)
+    if layout == "transposed":      # the reference's view of its [E,2] array (processing/data.py:437-438)
+        ei = torch.from_numpy(adj.astype(np.int64)).to(DEV).t()
+    else:
+        ei = torch.from_numpy(np.ascontiguousarray(adj.T.astype(np.int64))).to(DEV)
+    return n, x, ea, ei
+
+
+def _both_paths(net, data, plan=None, fresh=True):
+    from dgnn_amd import ops
+    from dgnn_amd.graph import clear_plan_cache
+    assert ops.INFER_ONE_CALL
+    if fresh:
+        clear_plan_cache(data.edge_index)
+    one = net.inference_layer(data, plan=plan)
+    ops.INFER_ONE_CALL = False
+    try:
+        if fresh:
+            clear_plan_cache(data.edge_index)
+        ref = net.inference_layer(data, plan=plan)
+    finally:
+        ops.INFER_ONE_CALL = True
+    return one, ref
+
+
+@pytest.mark.parametrize("points,layout", [(5, "transposed"), (9, "contiguous"), (40, "transposed"), (600, "transposed"), (600, "contiguous"), (9000, "transposed")])
+def test_one_call_equals_the_per_layer_path(points, layout):
+    n, x, ea, ei = _scene(points, seed=points, layout=layout)
+    net = hip_static()
+    data = Config(x=x.to(DEV), edge_attr=ea.to(DEV), edge_index=ei)
+    one, ref = _both_paths(net, data)
+    assert one.shape == (n, 2) and torch.equal(one, ref)
+    # the plan the call built hangs off edge_index like plan_for's: the next call reuses it (and is the same again)
+    held = getattr(ei, "_dgnn_plans", None)
+    assert held and len(held) == 1
+    again, _ = _both_paths(net, data, fresh=False)
+    assert torch.equal(again, ref)
+    plan = next(iter(held.values()))
+    want = np.argsort(ei[1].cpu().numpy(), kind="stable")
+    assert np.array_equal(plan.eid.cpu().numpy(), want) and np.array_equal(plan.src.cpu().numpy(), ei[0].cpu().numpy()[want])
+
+
+def test_one_call_vs_oracle_and_with_a_given_plan():
+    from dgnn_amd import ops
+    from dgnn_amd.graph import GraphPlan
+    n, x, ea, ei = _scene(1500, seed=3)
+    net = hip_static()
+    data = Config(x=x.to(DEV), edge_attr=ea.to(DEV), edge_index=ei)
+    one = net.inference_layer(data)
+    with torch.no_grad():
+        want = oracle_static().inference_layer(Config(x=x, edge_attr=ea, edge_index=ei.cpu()))
+    assert (one.cpu() - want).abs().max().item() <= TOL_LOGIT
+    for hint in (ops.PLAN_HINT_REFERENCE, ops.PLAN_HINT_GENERIC):
+        got, ref = _both_paths(net, data, plan=GraphPlan(ei, n, n, hint=hint))
+        assert torch.equal(got, ref) and torch.equal(got, one)
+
+
+def test_one_call_on_a_ragged_graph_builds_the_generic_plan():
+    """not the reference layout: in-degrees 0 .. dozens, duplicate edges, self loops -> the in-call plan falls through to the generic builder"""
+    rng = np.random.default_rng(5)
+    n, E = 3000, 14000
+    ei = torch.from_numpy(np.stack([rng.integers(0, n, E), rng.integers(0, n // 2, E)]).astype(np.int64)).to(DEV)
+    g = torch.Generator().manual_seed(1)
+    data = Config(x=torch.randn(n, 29, generator=g).to(DEV), edge_attr=torch.randn(E, 20, generator=g).to(DEV), edge_index=ei)
+    net = hip_static()
+    one, ref = _both_paths(net, data)
+    assert torch.equal(one, ref)
+    with torch.no_grad():
+        want = oracle_static().inference_layer(Config(x=data.x.cpu(), edge_attr=data.edge_attr.cpu(), edge_index=ei.cpu()))
+    assert (one.cpu() - want).abs().max().item() <= TOL_LOGIT * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16x3f", "f16x2d"])
+def test_one_call_in_the_other_arithmetic_modes(mode):
+    from dgnn_amd import ops
+    n, x, ea, ei = _scene(700, seed=8)
+    net = hip_static()
+    data = Config(x=x.to(DEV), edge_attr=ea.to(DEV), edge_index=ei)
+    old = ops.GEMM_MODE
+    ops.GEMM_MODE = ops.GEMM_MODE_NAMES[mode]
+    try:
+        one, ref = _both_paths(net, data)
+    finally:
+        ops.GEMM_MODE = old
+    assert torch.equal(one, ref)
+
+
+def test_one_call_follows_the_weights_and_other_widths():
+    """an optimizer step / load_state_dict between calls must show (folds and prepared parameters are cached against the tensors' versions);
+    widths whose last layer cannot carry the decoder run layer + decoder apart inside the call; unsupported widths fall back to the per-layer path"""
+    n, x, ea, ei = _scene(500, seed=2)
+    data = Config(x=x.to(DEV), edge_attr=ea.to(DEV), edge_index=ei)
+    net = hip_static()
+    a = net.inference_layer(data)
+    with torch.no_grad():
+        net.convs[2][0].lin_j.weight.mul_(1.5)
+        net.decoder[1].module.running_var.mul_(2.0)
+    b, ref = _both_paths(net, data)
+    assert torch.equal(b, ref) and not torch.equal(a, b)
+    for convs in ((64, 64, 128, 128), (64, 64, 64, 128), (64, 128, 256, 128)):       # the last: 128 -> 256 has no fused kernel -> per-layer path
+        sd = oracle_static(convs=convs, load=False, seed=4).state_dict()
+        net2 = hip_static(convs=convs, sd=sd)
+        one, ref = _both_paths(net2, data)
+        assert torch.equal(one, ref)
+        with torch.no_grad():
+            want = oracle_static(convs=convs, load=False, seed=4).inference_layer(Config(x=x, edge_attr=ea, edge_index=ei.cpu()))
+        assert (one.cpu() - want).abs().max().item() <= TOL_LOGIT * max(1.0, want.abs().max().item())
+
+
+def test_static_infer_c_abi_plain_call():
+    """the entry point as a C caller uses it: no prepared buffers, a caller-owned plan with eid == NULL (edge rows already in plan order), BatchNorm folded
+    by the caller -- against the oracle"""
+    from dgnn_amd import ops
+    from dgnn_amd._lib import check, lib, ptr
+    n, x, ea, ei = _scene(800, seed=6, layout="contiguous")
+    onet = oracle_static()
+    with torch.no_grad():
+        want = onet.inference_layer(Config(x=x, edge_attr=ea, edge_index=ei.cpu()))
+    sd = {k: v.to(DEV) for k, v in onet.state_dict().items()}
+    rowptr, src, eid = ops.plan_build(ei, n, by=1)
+    ea_sorted = ea.to(DEV)[eid.long()].contiguous()
+    xd = x.to(DEV)[:, 1:].contiguous()
+    L = 4
+    fold = lambda p: ops.bn_fold(sd[p + ".weight"], sd[p + ".bias"], sd[p + ".running_mean"], sd[p + ".running_var"], 1e-5)
+    folds = [fold("convs.%d.norm.module" % i) for i in range(L)]
+    s1, h1 = fold("decoder.1.module")
+    arr = lambda ts: (C.c_void_p * L)(*[t.data_ptr() for t in ts])
+    widths = (C.c_int32 * (L + 1))(28, 64, 128, 128, 128)
+    logits = torch.empty((n, 2), dtype=torch.float32, device=DEV)
+    work = torch.empty(int(lib().dgnn_static_infer_workspace_bytes(n, L, widths)), dtype=torch.uint8, device=DEV)
+    keep = [[sd["convs.%d.conv.%s" % (i, k)] for i in range(L)] for k in ("lin_e.weight", "lin_e.bias", "lin_j.weight", "lin_j.bias", "lin_i.weight")]
+    rc = lib().dgnn_static_infer_fwd(None, 0, 0, 4 * n, 0, ptr(rowptr), ptr(src), None, None, n, ptr(xd), 28, ptr(ea_sorted), 20, 20, L, widths, arr(keep[0]), arr(keep[1]),
+                                     arr(keep[2]), arr(keep[3]), arr(keep[4]), arr([f[0] for f in folds]), arr([f[1] for f in folds]), None,
+                                     ptr(sd["decoder.0.weight"]), ptr(sd["decoder.0.bias"]), ptr(s1), ptr(h1), 64, ptr(sd["decoder.3.weight"]), ptr(sd["decoder.3.bias"]), 2,
+                                     ops.GEMM_F16X2, ptr(work), ptr(logits), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    check(rc, "dgnn_static_infer_fwd")
+    assert (logits.cpu() - want).abs().max().item() <= TOL_LOGIT
+    # a width the fused kernels do not have: refused before anything is launched
+    bad = (C.c_int32 * (L + 1))(28, 64, 128, 256, 128)
+    logits.fill_(7.0)
+    rc = lib().dgnn_static_infer_fwd(None, 0, 0, 4 * n, 0, ptr(rowptr), ptr(src), None, None, n, ptr(xd), 28, ptr(ea_sorted), 20, 20, L, bad, arr(keep[0]), arr(keep[1]),
+                                     arr(keep[2]), arr(keep[3]), arr(keep[4]), arr([f[0] for f in folds]), arr([f[1] for f in folds]), None,
+                                     ptr(sd["decoder.0.weight"]), ptr(sd["decoder.0.bias"]), ptr(s1), ptr(h1), 64, ptr(sd["decoder.3.weight"]), ptr(sd["decoder.3.bias"]), 2,
+                                     ops.GEMM_F16X2, ptr(work), ptr(logits), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == ops.DGNN_E_UNSUPPORTED
+    torch.cuda.synchronize()
+    assert (logits == 7.0).all()
+
+
+def test_ignatius_full_scene_one_call_vs_reference_logits():
+    from test_gpu_scale import logit_check
+    g = gold("static_f4_ignatius_full.npz")
+    n = g["x"].shape[0]
+    fg = np.random.default_rng(int(g["fgeom_seed"])).standard_normal((4 * n, 4)).astype(np.float32)
+    ea = torch.from_numpy(np.concatenate([fg, g["edge_attr16"]], axis=1)).to(DEV)
+    pairs = np.stack([np.repeat(np.arange(n, dtype=np.int64), 4), g["adj_dst"].astype(np.int64)], 1)
+    data = Config(x=torch.from_numpy(g["x"]).to(DEV), edge_attr=ea, edge_index=torch.from_numpy(pairs).to(DEV).t())
+    net = hip_static()
+    one, ref = _both_paths(net, data)
+    assert torch.equal(one, ref)
+    logit_check(one.cpu().numpy(), g["logits"], g["logits64"])

@@ -196,10 +196,13 @@ def test_reordered_scene_gives_the_same_logits_and_a_local_graph(kind):
     assert d_old > n / 6 and d_new < (n / 40 if kind == "morton" else n / 16), (d_old, d_new)
 
 
-def test_ignatius_full_scene_reordered_vs_reference_logits():
-    """the whole real scene (CGAL order) through the adjacency-only order: logits restored to file order against the REFERENCE's"""
+@pytest.mark.parametrize("kind", ["morton", "bfs"])
+def test_ignatius_full_scene_reordered_vs_reference_logits(kind):
+    """the whole real scene (67 017 cells in CGAL's order: median |src - dst| 753 rows, a fifth of the edges further than 16k rows) through the
+    loader's orders -- Morton from the scene's own `_3dt` geometry (tests/golden/ignatius_3dt.npz), breadth-first from the adjacency alone --:
+    logits restored to file order against the REFERENCE's, and what the order does to the neighbour distances"""
     from dgnn_amd import ops
-    from dgnn_amd.processing.reorder import reorder_edges, scene_order
+    from dgnn_amd.processing.reorder import centroids_from_3dt, reorder_edges, scene_order
     from test_gpu_scale import logit_check
     g = gold("static_f4_ignatius_full.npz")
     n = g["x"].shape[0]
@@ -208,16 +211,36 @@ def test_ignatius_full_scene_reordered_vs_reference_logits():
     pairs = np.stack([np.repeat(np.arange(n, dtype=np.int64), 4), g["adj_dst"].astype(np.int64)], 1)
     ei = torch.from_numpy(pairs).to(DEV).t()
     x = torch.from_numpy(np.ascontiguousarray(g["x"])).to(DEV)
-    co = scene_order(ei, n)
-    assert co.kind == "bfs"
+    cent = None
+    if kind == "morton":
+        m = gold("ignatius_3dt.npz")
+        cent = centroids_from_3dt(torch.from_numpy(m["vertices"]), torch.from_numpy(m["tetrahedra"]), torch.from_numpy(m["infinite"]), ei)
+        fin = m["infinite"] == 0                       # numpy restatement on the real geometry (fp32 like the kernel)
+        want = np.zeros((n, 3), np.float32)
+        p = m["vertices"].astype(np.float32)[m["tetrahedra"]]
+        want[fin] = np.float32(0.25) * (((p[:, 0] + p[:, 1]) + p[:, 2]) + p[:, 3])
+        dst4 = g["adj_dst"].astype(np.int64).reshape(n, 4)
+        for i in np.nonzero(~fin)[0]:
+            nb = [d for d in dst4[i] if fin[d]]
+            if nb:
+                want[i] = want[nb[0]]
+        assert np.array_equal(cent.cpu().numpy(), want)
+    co = scene_order(ei, n, centroids=cent, kind=kind)
+    assert co.kind == kind
     ei2, rows = reorder_edges(ei, co.order, co.rank)
     net = hip_static()
     got = net.inference_layer(Config(x=ops.gather_rows(x, co.order), edge_attr=ops.gather_rows(ea, rows), edge_index=ei2))
     err = logit_check(co.to_file(got).cpu().numpy(), g["logits"], g["logits64"])
-    d_old = (ei[0] - ei[1]).abs().float().median().item()
-    d_new = (ei2[0] - ei2[1]).abs().float().median().item()
-    print("Ignatius reordered (bfs): max|dlogit| %.3e; median |src-dst| %d -> %d rows" % (err, d_old, d_new))
-    assert d_new < d_old / 4
+    d_old = (ei[0] - ei[1]).abs().float()
+    d_new = (ei2[0] - ei2[1]).abs().float()
+    far = lambda d: (d > 16384).float().mean().item()
+    print("Ignatius reordered (%s): max|dlogit| %.3e; |src-dst| median %d -> %d rows, mean %.0f -> %.0f, further than 16k rows %.3f -> %.3f"
+          % (kind, err, d_old.median().item(), d_new.median().item(), d_old.mean().item(), d_new.mean().item(), far(d_old), far(d_new)))
+    assert far(d_old) > 0.15                                           # CGAL's order: a heavy tail of far neighbours
+    if kind == "morton":
+        assert d_new.median().item() <= 32 and d_new.mean().item() < d_old.mean().item() / 5 and far(d_new) < 0.03
+    else:                                                              # breadth-first: every neighbour within a couple of shells, no tail at all
+        assert d_new.max().item() < n / 4 and d_new.mean().item() < d_old.mean().item() / 2 and far(d_new) == 0.0
 
 
 def test_generate_takes_a_reordered_scene(tmp_path):
