@@ -249,6 +249,10 @@ def main():
     ap.add_argument("--widths", type=str, default=None, help="conv widths, e.g. 64,128,256,512 (random-init weights); default: kf96 checkpoint")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="bf16: bf16 activation storage, single-product bf16 MFMA, fp32 accumulate")
     ap.add_argument("--cpu-points", type=int, default=30000, help="sample size of the single-thread CPU leg")
+    ap.add_argument("--cell-order", choices=["loader", "generator"], default="loader",
+                    help="loader (default): the scene goes through the package's ingest-time cell order first, as every scene read by dgnn_amd.processing.data does; "
+                         "generator: cells as generated (the headline of rounds 1-3, nested as `generator_order` otherwise)")
+    ap.add_argument("--small-points", type=int, default=10000, help="points of the reconbench-size scenes of the `small_scenes` side measurement (10000 -> ~66k tets)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle legs (and with them the logit check)")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the per-layer replays (the roofline is then reported for the largest layer shape)")
     ap.add_argument("--cached-plan", action="store_true", help="reuse the graph plan across steps (reported, not the metric)")
@@ -327,11 +331,23 @@ def main():
     scene_cpu = None
     transport = None
     if world == 1:
-        adj, _, x, ea = make_scene(args.points, 0)
+        adj, cent, x, ea = make_scene(args.points, 0)
         n_total = n_local = adj.shape[0] // 4
         ei_cpu = torch.from_numpy(adj.T.astype(np.int64))
         scene_cpu = (x, ea, ei_cpu)
-        data = Config(x=x.to(dev), edge_attr=ea.to(dev), edge_index=ei_cpu.to(dev))
+        data_gen = Config(x=x.to(dev), edge_attr=ea.to(dev), edge_index=ei_cpu.to(dev))      # the generator's own cell order
+        cell_order = None
+        if args.cell_order == "loader":
+            # the scene as dgnn_amd.processing.data.dataLoader hands it to the model: cells relabelled once at ingest (Morton order of the cell
+            # centroids, csrc/reorder.hip -- the reference's loader keeps CGAL's insertion order, processing/data.py:434-438); per-cell results
+            # return to file order through the kept permutation (the check below compares in FILE order)
+            from dgnn_amd.processing.reorder import reorder_edges, scene_order
+            cell_order = scene_order(data_gen.edge_index, n_total, centroids=torch.from_numpy(cent).to(dev), kind="morton")
+            ei_o, rows_o = reorder_edges(data_gen.edge_index, cell_order.order, cell_order.rank)
+            data = Config(x=ops.gather_rows(data_gen.x, cell_order.order), edge_attr=ops.gather_rows(data_gen.edge_attr, rows_o), edge_index=ei_o)
+            del rows_o
+        else:
+            data = data_gen
         cached = {}
 
         def step():
@@ -341,7 +357,9 @@ def main():
                 if args.cached_plan:
                     cached["p"] = plan
             return net.inference_layer(data, plan=plan)
-        workload = "synthetic Delaunay tet graph, %d points -> N=%d tets, E=%d, whole-graph inference_layer" % (args.points, n_total, 4 * n_total)
+        workload = "synthetic Delaunay tet graph, %d points -> N=%d tets, E=%d, whole-graph inference_layer; cells in %s" % (
+            args.points, n_total, 4 * n_total, "the order the package's loader leaves them in (ingest-time Morton order of the cell centroids, "
+            "dgnn_amd/processing/reorder.py; `generator_order` = the same scene as generated)" if cell_order is not None else "the generator's order")
     else:
         import torch.distributed as dist
         from dgnn_amd.partition import HaloExchange, PartitionedScene
@@ -533,9 +551,20 @@ def main():
             settle(step)
             dt_x, ps_x = timed_steps(step, args.steps, sync, world, dev)
             extras["exact_f32"] = {"gemm": "fp32 matrix cores (v_mfma_f32_32x32x2_f32), bit-faithful fmaf chains: --gemm-mode f32", "ms_per_step": round(dt_x / args.steps * 1e3, 4),
-                                   "ms_per_step_median": round(float(np.median(ps_x)), 4), "value": round(n_total * args.steps / dt_x, 1), "_logits": step().float().cpu()}
+                                   "ms_per_step_median": round(float(np.median(ps_x)), 4), "value": round(n_total * args.steps / dt_x, 1), "_logits": (cell_order.to_file(step()) if cell_order is not None else step()).float().cpu()}
         finally:
             ops.GEMM_MODE = old_mode
+        # (1b) the scene in the generator's own cell order (the headline of rounds 1-3)
+        value_gen = value
+        if cell_order is not None:
+            def step_g():
+                return net.inference_layer(data_gen, plan=GraphPlan(data_gen.edge_index, n_local, n_local, hint=ops.PLAN_HINT_REFERENCE))
+            settle(step_g)
+            dt_g, ps_g = timed_steps(step_g, args.steps, sync, world, dev)
+            value_gen = n_total * args.steps / dt_g
+            extras["generator_order"] = {"what": "same scene, cells as scipy.spatial.Delaunay numbered them (median |src - dst| = 6 rows; the `value` of rounds 1-3)",
+                                         "ms_per_step": round(dt_g / args.steps * 1e3, 4), "ms_per_step_median": round(float(np.median(ps_g)), 4),
+                                         "value": round(value_gen, 1)}
         # (2) the same graph with its cells numbered at random -- the gather locality of a CGAL-ordered real scene
         if n_total <= 3_000_000:
             adj_r, x_r, ea_r = relabelled_scene(adj, x, ea)
@@ -548,7 +577,91 @@ def main():
             extras["random_cell_order"] = {"what": "same graph, cells renumbered by a seeded random permutation (no gather locality; the generator's own order has median |src - dst| = 6 rows)",
                                            "ms_per_step": round(dt_r / args.steps * 1e3, 4), "ms_per_step_median": round(float(np.median(ps_r)), 4),
                                            "value": round(n_total * args.steps / dt_r, 1)}
-            del data_r, x_r, ea_r, adj_r
+            # (3) that scene through the INGEST-TIME cell order of dgnn_amd.processing (what dataLoader.run does to a real scene, reference seam
+            # processing/data.py:434-438): Morton order of the cell centroids (a scene with <scene>_3dt.npz), breadth-first order of the adjacency (none)
+            from dgnn_amd.processing.reorder import reorder_edges, scene_order
+            perm_r = np.random.default_rng(7).permutation(n_total)      # relabelled_scene's permutation: new id of old cell
+            inv_r = np.empty(n_total, np.int64)
+            inv_r[perm_r] = np.arange(n_total)
+            cent_r = torch.from_numpy(np.ascontiguousarray(cent[inv_r])).to(dev)
+            extras["real_order"] = {"what": "the random_cell_order scene after the loader's ingest-time relabelling (dgnn_amd/processing/reorder.py); logits go back to file "
+                                            "order through the kept permutation", "generator_order_value": round(value_gen, 1)}
+            for kind in ("morton", "bfs"):
+                def ingest():
+                    co_ = scene_order(data_r.edge_index, n_total, centroids=cent_r if kind == "morton" else None, kind=kind)
+                    ei_, rows_ = reorder_edges(data_r.edge_index, co_.order, co_.rank)
+                    return co_, Config(x=ops.gather_rows(data_r.x, co_.order), edge_attr=ops.gather_rows(data_r.edge_attr, rows_), edge_index=ei_)
+                ingest()
+                torch.cuda.synchronize()
+                t_i = time.perf_counter()
+                co_k, data_k = ingest()
+                torch.cuda.synchronize()
+                t_i = time.perf_counter() - t_i
+
+                def step_k():
+                    return net.inference_layer(data_k, plan=GraphPlan(data_k.edge_index, n_local, n_local, hint=ops.PLAN_HINT_REFERENCE))
+                settle(step_k)
+                dt_k, ps_k = timed_steps(step_k, args.steps, sync, world, dev)
+                back = co_k.to_file(step_k())
+                same = float((back - step_r()).abs().max())            # same graph, sums in another order
+                d_k = (data_k.edge_index[0] - data_k.edge_index[1]).abs().float()
+                extras["real_order"][kind] = {"ms_per_step": round(dt_k / args.steps * 1e3, 4), "ms_per_step_median": round(float(np.median(ps_k)), 4),
+                                              "value": round(n_total * args.steps / dt_k, 1), "vs_generator_order": round(n_total * args.steps / dt_k / value_gen, 4),
+                                              "ingest_reorder_ms": round(t_i * 1e3, 2), "median_src_dst_rows": int(d_k.median().item()),
+                                              "max_abs_dlogit_vs_unordered": same}
+                del data_k, co_k
+            del data_r, x_r, ea_r, adj_r, cent_r
+        # (4) reconbench-size scenes (BASELINE config 2: run.py:170-191 classifies one ~66k-cell scene after the other): 25 scenes back to back, each
+        # ONE library call (plan + layers + decoder, dgnn_static_infer_fwd) on a scene whose plan has never been built, and the same 25 as one
+        # block-diagonal batch
+        from dgnn_amd.graph import clear_plan_cache
+        small = []
+        for sd_ in range(5):
+            adj_s, _, x_s, ea_s = make_scene(args.small_points, 100 + sd_)
+            small.append(Config(x=x_s.to(dev), edge_attr=ea_s.to(dev), edge_index=torch.from_numpy(adj_s.astype(np.int64)).to(dev).t()))
+        scenes = [small[i % 5] for i in range(25)]
+        n_small = sum(d_.x.size(0) for d_ in scenes)
+
+        def small_pass():
+            for d_ in scenes:
+                clear_plan_cache(d_.edge_index)
+                net.inference_layer(d_)
+
+        def small_timed(fn, reps=8):
+            fn()
+            fn()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(reps):
+                t0_ = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0_)
+            return float(np.median(ts))
+        t_one = small_timed(small_pass)
+        ops.INFER_ONE_CALL = False
+        try:
+            t_layers = small_timed(small_pass)
+        finally:
+            ops.INFER_ONE_CALL = True
+        off, xs, eas, eis = 0, [], [], []
+        for d_ in scenes:
+            xs.append(d_.x); eas.append(d_.edge_attr); eis.append(d_.edge_index.t().contiguous() + off)
+            off += d_.x.size(0)
+        batch = Config(x=torch.cat(xs), edge_attr=torch.cat(eas), edge_index=torch.cat(eis).t())
+
+        def batch_pass():
+            clear_plan_cache(batch.edge_index)
+            return net.inference_layer(batch)
+        t_batch = small_timed(batch_pass)
+        lg_b = batch_pass()
+        lg_0 = net.inference_layer(scenes[0])
+        extras["small_scenes"] = {"what": "25 scenes of %d tets (%d points each), plan built inside every call" % (scenes[0].x.size(0), args.small_points),
+                                  "one_call_ms_per_scene": round(t_one / 25 * 1e3, 4), "one_call_value": round(n_small / t_one, 1),
+                                  "per_layer_calls_ms_per_scene": round(t_layers / 25 * 1e3, 4), "per_layer_calls_value": round(n_small / t_layers, 1),
+                                  "block_diagonal_batch_ms": round(t_batch * 1e3, 4), "block_diagonal_batch_value": round(n_small / t_batch, 1),
+                                  "batch_equals_scene_bitwise": bool(torch.equal(lg_b[:lg_0.size(0)], lg_0))}
+        del small, scenes, batch, xs, eas, eis
     other = None
     if world > 1 and not args.no_extras:
         # the other scaling mode, same steps / warm-up, so that a SCALE record can be read either way (metric: "1M-tet graph at 1/2/4/8" = strong)
@@ -592,7 +705,8 @@ def main():
         if big:
             got = net.inference_layer(Config(x=x_c.to(dev), edge_attr=ea_c.to(dev), edge_index=ei_c.to(dev))).float().cpu()
         else:
-            got = step().float().cpu()
+            got = step()
+            got = (cell_order.to_file(got) if cell_order is not None else got).float().cpu()      # logits back in file order
         check = {"reference": "CPU oracle, same graph and weights (%d tets)" % n_full}
         check.update(logits_check(got, ref, bf16, ops.BF16_MODE == ops.BF16_COMPENSATED))
         failed = not check["ok"]

@@ -236,12 +236,13 @@ class PartitionedScene:
         self._xe_stripped = None
 
     @staticmethod
-    def build_synthetic(points: int, seed: int, rank: int, world: int, device, keep_global: bool = False) -> "PartitionedScene":
+    def build_synthetic(points: int, seed: int, rank: int, world: int, device, keep_global: bool = False, loader_order: bool = True) -> "PartitionedScene":
         """The seeded Delaunay scene of bench.py cut into `world` parts.  Rank 0 runs the tetrahedralisation and the
         coordinate bisection ONCE and broadcasts the adjacency column and the owner map (two int32 arrays) when a process
         group exists -- every rank repeating scipy.spatial.Delaunay on the whole scene costs minutes at 10M tets; without
         a process group (tests, world == 1) the rank builds them itself.  Each rank then derives its own index structures
         and materialises only the feature rows it needs (hashed N(0,1) values, identical across ranks for shared rows).
+        `loader_order`: the generated scene is first relabelled the way the package's loader relabels every scene it reads (Morton order).
         `keep_global`: the whole scene's adjacency column (int32 [4N]) stays attached as `scene.global_dst` (bench.py's check at N > 1 runs
         the same scene as one graph on rank 0)."""
         import torch.distributed as dist
@@ -249,6 +250,11 @@ class PartitionedScene:
         shared = world > 1 and dist.is_available() and dist.is_initialized()
         if not shared or rank == 0:
             adj, cent, _ = delaunay_tet_graph(points, seed)
+            if loader_order:
+                # cells numbered as the package's loader leaves a scene (ingest-time Morton order, processing/reorder.py): owned cells keep ascending
+                # global ids inside a part, so every part inherits the locality
+                from .synthetic import loader_cell_order
+                adj, cent, _ = loader_cell_order(adj, cent)
             part = rcb_partition(cent, world)
             dst = np.ascontiguousarray(adj[:, 1], dtype=np.int32)
             del adj, cent

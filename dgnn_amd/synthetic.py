@@ -81,6 +81,35 @@ def check_four_regular(adj: np.ndarray) -> bool:
     return bool(np.array_equal(fwd, rev))
 
 
+def loader_cell_order(adj: np.ndarray, cent: np.ndarray):
+    """What dgnn_amd.processing.data.dataLoader does to a scene at ingest (processing/reorder.py, Morton order of the cell centroids), restated
+    with numpy for scene GENERATORS that run on the host before any GPU work (PartitionedScene.build_synthetic cuts the scene on rank 0's host):
+    -> (adjacencies relabelled, reference layout kept, centroids in the new order, order = old id of new cell).  Same keys as
+    csrc/reorder.hip (16 bits per axis over the bounding box, stable sort)."""
+    n = adj.shape[0] // 4
+    c = np.asarray(cent, np.float32)
+    lo, hi = c.min(axis=0), c.max(axis=0)
+    ext = (hi - lo).astype(np.float32)
+    inv = np.where(ext > 0, np.float32(65535.0) / np.where(ext > 0, ext, 1), np.float32(0)).astype(np.float32)
+    q = np.clip(((c - lo).astype(np.float32) * inv).astype(np.float32), 0, 65535).astype(np.uint64)
+    key = np.zeros(n, np.uint64)
+    for a in range(3):
+        v = q[:, a]
+        v = (v | (v << np.uint64(16))) & np.uint64(0x0000FF0000FF)
+        v = (v | (v << np.uint64(8))) & np.uint64(0x00F00F00F00F)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x0C30C30C30C3)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x249249249249)
+        key |= v << np.uint64(a)
+    order = np.argsort(key, kind="stable")
+    rank = np.empty(n, np.int64)
+    rank[order] = np.arange(n)
+    rows = (order[:, None] * 4 + np.arange(4)[None]).reshape(-1)
+    adj2 = np.empty_like(adj)
+    adj2[:, 0] = np.repeat(np.arange(n, dtype=adj.dtype), 4)
+    adj2[:, 1] = rank[adj[rows, 1].astype(np.int64)].astype(adj.dtype)
+    return adj2, np.ascontiguousarray(c[order]), order
+
+
 def hashed_normal(rows, ncols: int, seed: int = 0, device="cpu"):
     """Deterministic N(0,1) float32 tensor [len(rows), ncols] where entry (i, c) depends only on
     (rows[i], c, seed): splitmix64 hash -> Box-Muller, evaluated with torch integer ops on `device`.
