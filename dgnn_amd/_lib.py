@@ -111,7 +111,7 @@ SIGNATURES = {
                                                   vp, vp, i32, vp, vp, vp]),
     "dgnn_static_infer_workspace_bytes": (i64, [i64, i32, vp]),
     "dgnn_static_infer_fwd": (i32, [vp, i64, i64, i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32,
-                                    vp, vp, i32, i32, vp, vp, vp]),
+                                    vp, vp, i32, i32, i32, vp, vp, vp]),
     "dgnn_edge_chain_fwd": (i32, [vp, i64, i32, vp, i64, vp, i64, i64, vp, i32, vp, i64, vp, vp]),
     "dgnn_edge_chain_fwd_bf16": (i32, [vp, i64, i32, vp, i64, vp, i64, i64, vp, i32, vp, i64, vp, vp]),
     "dgnn_edge_chain_bwd": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i64, vp]),

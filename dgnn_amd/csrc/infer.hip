@@ -39,8 +39,8 @@ extern "C" int dgnn_static_infer_fwd(const int64_t* edge_index, int64_t stride_r
                                      int f_e, int n_layers, const int32_t* widths, const float* const* We, const float* const* be,
                                      const float* const* Wj, const float* const* bj, const float* const* Wi, const float* const* scale,
                                      const float* const* shift, const void* const* prepared, const float* W0, const float* b0, const float* scale1,
-                                     const float* shift1, int c_hidden, const float* W3, const float* b3, int n_logits, int gemm_mode, void* workspace,
-                                     float* logits, void* stream) {
+                                     const float* shift1, int c_hidden, const float* W3, const float* b3, int n_logits, int fuse_decoder, int gemm_mode,
+                                     void* workspace, float* logits, void* stream) {
     DGNN_REQUIRE(n >= 0 && E >= 0 && n_layers >= 1 && n_layers <= 16 && widths && We && be && Wj && bj && Wi && scale && shift, DGNN_E_INVALID,
                  "static_infer_fwd: bad sizes / null table");
     if (n == 0) return DGNN_OK;
@@ -80,14 +80,14 @@ extern "C" int dgnn_static_infer_fwd(const int64_t* edge_index, int64_t stride_r
         if (last && dec2) {
             // the last layer's launch carries the decoder (only logits are written); shapes / layouts it does not take run layer and decoder apart
             int rc = DGNN_E_UNSUPPORTED;
-            if (gemm_mode == DGNN_GEMM_F16X2 && n_logits == 2) {
+            if (fuse_decoder && gemm_mode == DGNN_GEMM_F16X2 && n_logits == 2) {
                 rc = prep ? dgnn_sage_layer_fused_decoder_fwd_p(rowptr, src, eid, n, h, nullptr, ldh, ci, edge_attr, lde, f_e, We[l], be[l], Wj[l], bj[l], Wi[l],
                                                                 scale[l], shift[l], 1, co, W0, b0, scale1, shift1, c_hidden, W3, b3, n_logits, logits, prep, stream)
                           : dgnn_sage_layer_fused_decoder_fwd(rowptr, src, eid, n, h, nullptr, ldh, ci, edge_attr, lde, f_e, We[l], be[l], Wj[l], bj[l], Wi[l],
                                                               scale[l], shift[l], 1, co, W0, b0, scale1, shift1, c_hidden, W3, b3, n_logits, logits, stream);
             }
             if (rc != DGNN_E_UNSUPPORTED) return rc;
-            prep = nullptr;     // (a decoder-carrying prepared block is not a plain layer's)
+            if (fuse_decoder) prep = nullptr;     // (a decoder-carrying prepared block is not a plain layer's)
         }
         float* out = (last && !dec2) ? logits : ws.act[l & 1];
         int rc = DGNN_E_UNSUPPORTED;

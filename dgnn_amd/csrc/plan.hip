@@ -13,6 +13,8 @@
 //           eid[k], other[k] = edge_index[other_row][eid[k]].
 #include <stdarg.h>
 
+#include <stdlib.h>
+
 #include "common.h"
 #include <mutex>
 
@@ -594,11 +596,20 @@ extern "C" int dgnn_plan_build(const int64_t* edge_index, int64_t stride_row, in
     }
     if (standby) {
         // The persistent kernel's grid barriers need every block resident at once: the grid is capped by what THIS device can hold
-        // (occupancy x its real CU count -- a CPX/SPX partition or another gfx9 part has fewer than 256), and the launch is a
-        // cooperative one, which the runtime refuses instead of hanging when the grid cannot be co-resident.
+        // (occupancy x its real CU count -- a CPX/SPX partition or another gfx9 part has fewer than 256), so every block becomes resident as soon
+        // as the kernels ahead of it drain.  DGNN_PLAN_COOPERATIVE=1 additionally launches it as a cooperative kernel (the runtime then refuses
+        // a grid that cannot be co-resident instead of hanging) -- off by default: on this stack a process that has issued cooperative launches
+        // slows the kernel launches of every OTHER process on the GPU to half speed for as long as it lives (measured: the training leg of
+        // bench.py, a child process, 0.92 -> 1.85 ms per step).
         const int64_t want = dgnn_cdiv(E > n_key ? E : n_key, (int64_t)SCAN_THREADS * 8);
         const int cap = plan_fallback_resident_blocks();
         const int grid = (int)(want < 1 ? 1 : (want < cap ? want : cap));
+        static const bool cooperative = [] { const char* e = getenv("DGNN_PLAN_COOPERATIVE"); return e && e[0] == '1'; }();
+        if (!cooperative) {
+            hipLaunchKernelGGL(k_plan_fallback, dim3(grid), dim3(SCAN_THREADS), 0, stream, key, oth, sc, E, n_key, n_other, rowptr, other, eid, deg, tmp,
+                               sums, nb, big_count, big_list, need, need + 2, aflag);
+            return dgnn_check_launch("plan_build");
+        }
         int64_t sc_ = sc, E_ = E, nk_ = n_key, no_ = n_other;
         int nb_ = nb;
         int32_t* gsync = need + 2;

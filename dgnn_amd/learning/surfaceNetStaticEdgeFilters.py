@@ -322,7 +322,7 @@ class SurfaceNet(nn.Module):
             if held:
                 plan = plan_for(edge_index, n, n, hint=ops.PLAN_HINT_REFERENCE)
         parts = None if plan is None else (plan.rowptr, plan.src, plan.eid)
-        out = ops.static_infer_fwd(x, xe, edge_index, parts, layers, decoder, prepared)
+        out = ops.static_infer_fwd(x, xe, edge_index, parts, layers, decoder, prepared, fuse_decoder=with_dec)
         if out is None:
             return None
         if plan is None:

@@ -528,11 +528,12 @@ INFER_ONE_CALL = __import__("os").environ.get("DGNN_INFER_ONE_CALL", "1") != "0"
 
 
 @on_device_of
-def static_infer_fwd(x, edge_attr, edge_index, plan_parts, layers, decoder, prepared=None, hint=PLAN_HINT_REFERENCE, gemm_mode=None):
+def static_infer_fwd(x, edge_attr, edge_index, plan_parts, layers, decoder, prepared=None, hint=PLAN_HINT_REFERENCE, gemm_mode=None, fuse_decoder=True):
     """-> (logits | last activations, plan parts) or None when a shape is outside the fused kernels (nothing launched).
     `plan_parts` = (rowptr, src, eid) of an existing plan, or None: the plan is built inside the call from `edge_index` (int64 [2,E], any strides)
     and its arrays are returned.  `layers`: per conv layer (We, be, Wj, bj, Wi, scale | None, shift | None); `decoder` = (W0, b0, scale1 | None,
-    shift1 | None, W3, b3) or None; `prepared`: per-layer dgnn_sage_layer_prepare buffers (the last one made with the decoder) or None."""
+    shift1 | None, W3, b3) or None; `prepared`: per-layer dgnn_sage_layer_prepare buffers or None; `fuse_decoder`: the last layer's launch carries the
+    decoder (prepared[-1] is then the block made WITH the decoder), else layer and decoder run apart."""
     import ctypes as C
     _req(x, "x", dim=2)
     _req(edge_attr, "edge_attr", dim=2)
@@ -562,7 +563,7 @@ def static_infer_fwd(x, edge_attr, edge_index, plan_parts, layers, decoder, prep
         ptr(edge_index) if build else None, edge_index.stride(0) if build else 0, edge_index.stride(1) if build else 0, E, hint, ptr(rowptr), ptr(src),
         ptr(eid), ptr(scratch), n, ptr(x), _ld(x), ptr(edge_attr), _ld(edge_attr), edge_attr.size(1), L, w_arr, col(0), col(1), col(2), col(3), col(4),
         col(5), col(6), prep, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), d[0].size(0) if d[0] is not None else 0, ptr(d[4]), ptr(d[5]),
-        d[4].size(0) if d[4] is not None else 0, GEMM_MODE if gemm_mode is None else gemm_mode, ptr(work), ptr(logits), stream_ptr())
+        d[4].size(0) if d[4] is not None else 0, int(bool(fuse_decoder)), GEMM_MODE if gemm_mode is None else gemm_mode, ptr(work), ptr(logits), stream_ptr())
     if rc == DGNN_E_UNSUPPORTED:
         return None
     check(rc, "dgnn_static_infer_fwd", poll=build)

@@ -329,9 +329,10 @@ int dgnn_sage_layer_fused_decoder_fwd_p(const int32_t* rowptr, const int32_t* sr
  *            graph; edge_index == NULL: rowptr / src / eid ARE the plan (eid NULL = edge_attr already in plan order).  edge_attr rows follow
  *            edge_index and are gathered through eid inside the layer launches.
  *   layers   n_layers fused conv layers (dgnn_sage_layer_fused_fwd[_p]; BatchNorm(eval) folded into scale[l] / shift[l], NULL = none; ReLU)
- *   decoder  Linear(widths[L] -> c_hidden) - BatchNorm(eval, scale1 / shift1) - ReLU - Linear(-> n_logits) inside the last layer's launch
- *            (dgnn_sage_layer_fused_decoder_fwd[_p]) or as dgnn_decoder_fused_fwd behind it; W0 == NULL: no decoder, `logits` receives the
- *            last layer's rows [n, widths[L]]
+ *   decoder  Linear(widths[L] -> c_hidden) - BatchNorm(eval, scale1 / shift1) - ReLU - Linear(-> n_logits): fuse_decoder != 0 -- inside the last
+ *            layer's launch where its shape allows (dgnn_sage_layer_fused_decoder_fwd[_p]; prepared[L-1], if given, must then have been made
+ *            WITH the decoder); otherwise dgnn_decoder_fused_fwd behind a plain last layer (prepared[L-1] a plain layer's).  W0 == NULL: no
+ *            decoder, `logits` receives the last layer's rows [n, widths[L]]
  * Per-layer arguments are HOST arrays [n_layers] of device pointers (widths [n_layers + 1]); prepared (may be NULL, entries may be NULL):
  * dgnn_sage_layer_prepare buffers, the last one made WITH the decoder.  Issues exactly the launches of the per-layer entry points, in their
  * order: bit-identical results; nothing allocates or synchronises.  Shapes outside the fused kernels (see dgnn_sage_layer_fused_fwd):
@@ -343,8 +344,8 @@ int dgnn_static_infer_fwd(const int64_t* edge_index, int64_t stride_row, int64_t
                           int64_t lde, int f_e, int n_layers, const int32_t* widths, const float* const* We, const float* const* be,
                           const float* const* Wj, const float* const* bj, const float* const* Wi, const float* const* scale,
                           const float* const* shift, const void* const* prepared, const float* W0, const float* b0, const float* scale1,
-                          const float* shift1, int c_hidden, const float* W3, const float* b3, int n_logits, int gemm_mode, void* workspace,
-                          float* logits, void* stream);
+                          const float* shift1, int c_hidden, const float* W3, const float* b3, int n_logits, int fuse_decoder, int gemm_mode,
+                          void* workspace, float* logits, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Training-mode conv layer, one call each way (SurfaceNet.forward :214-219 and its autograd, learning/runModel.py:279):

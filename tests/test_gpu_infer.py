@@ -154,7 +154,7 @@ def test_static_infer_c_abi_plain_call():
     rc = lib().dgnn_static_infer_fwd(None, 0, 0, 4 * n, 0, ptr(rowptr), ptr(src), None, None, n, ptr(xd), 28, ptr(ea_sorted), 20, 20, L, widths, arr(keep[0]), arr(keep[1]),
                                      arr(keep[2]), arr(keep[3]), arr(keep[4]), arr([f[0] for f in folds]), arr([f[1] for f in folds]), None,
                                      ptr(sd["decoder.0.weight"]), ptr(sd["decoder.0.bias"]), ptr(s1), ptr(h1), 64, ptr(sd["decoder.3.weight"]), ptr(sd["decoder.3.bias"]), 2,
-                                     ops.GEMM_F16X2, ptr(work), ptr(logits), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                     1, ops.GEMM_F16X2, ptr(work), ptr(logits), C.c_void_p(torch.cuda.current_stream().cuda_stream))
     check(rc, "dgnn_static_infer_fwd")
     assert (logits.cpu() - want).abs().max().item() <= TOL_LOGIT
     # a width the fused kernels do not have: refused before anything is launched
@@ -163,7 +163,7 @@ def test_static_infer_c_abi_plain_call():
     rc = lib().dgnn_static_infer_fwd(None, 0, 0, 4 * n, 0, ptr(rowptr), ptr(src), None, None, n, ptr(xd), 28, ptr(ea_sorted), 20, 20, L, bad, arr(keep[0]), arr(keep[1]),
                                      arr(keep[2]), arr(keep[3]), arr(keep[4]), arr([f[0] for f in folds]), arr([f[1] for f in folds]), None,
                                      ptr(sd["decoder.0.weight"]), ptr(sd["decoder.0.bias"]), ptr(s1), ptr(h1), 64, ptr(sd["decoder.3.weight"]), ptr(sd["decoder.3.bias"]), 2,
-                                     ops.GEMM_F16X2, ptr(work), ptr(logits), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                     1, ops.GEMM_F16X2, ptr(work), ptr(logits), C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == ops.DGNN_E_UNSUPPORTED
     torch.cuda.synchronize()
     assert (logits == 7.0).all()

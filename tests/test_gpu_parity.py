@@ -628,9 +628,11 @@ def test_partitioned_scene_world1_matches_inference_layer():
     from dgnn_amd.partition import PartitionedScene
     from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal
     net = hip_static()
+    from dgnn_amd.synthetic import loader_cell_order
     scene = PartitionedScene.build_synthetic(1500, 3, 0, 1, DEV)
     logits = scene.inference_layer(net)
-    adj, _, _ = delaunay_tet_graph(1500, 3)
+    adj, cent, _ = delaunay_tet_graph(1500, 3)
+    adj = loader_cell_order(adj, cent)[0]          # build_synthetic numbers the cells the way the package's loader leaves a scene (ingest-time Morton order)
     n = adj.shape[0] // 4
     data = Config(x=hashed_normal(np.arange(n), 29, seed=1, device=DEV), edge_attr=hashed_normal(np.arange(4 * n), 20, seed=2, device=DEV),
                   edge_index=torch.from_numpy(adj.T.astype(np.int64)).to(DEV))
@@ -669,7 +671,9 @@ def test_partitioned_scene_two_processes_overlapped_exchange(world, tmp_path):
     from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal
     s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
     mp.spawn(_two_rank_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    adj, _, _ = delaunay_tet_graph(6000, 5)
+    from dgnn_amd.synthetic import loader_cell_order
+    adj, cent, _ = delaunay_tet_graph(6000, 5)
+    adj = loader_cell_order(adj, cent)[0]          # (build_synthetic's cell numbering: the loader's ingest-time order)
     n = adj.shape[0] // 4
     data = Config(x=hashed_normal(np.arange(n), 29, seed=1, device=DEV), edge_attr=hashed_normal(np.arange(4 * n), 20, seed=2, device=DEV),
                   edge_index=torch.from_numpy(adj.T.astype(np.int64)).to(DEV))
