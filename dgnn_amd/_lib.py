@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdgnn_hip.so")
+# DGNN_LIB_PATH: another build of the same library (kernel variants for A/B measurements, tools/build_variant.sh) -- never a fallback
+LIB_PATH = os.environ.get("DGNN_LIB_PATH") or os.path.join(_HERE, "libdgnn_hip.so")
 
 i64, i32, f32, vp = C.c_int64, C.c_int, C.c_float, C.c_void_p
 
@@ -88,6 +89,8 @@ SIGNATURES = {
     "dgnn_cast_f32_to_bf16": (i32, [vp, i64, i64, i32, i32, vp, i64, vp]),
     "dgnn_cast_bf16_to_f32": (i32, [vp, i64, i64, i32, vp, i64, vp]),
     "dgnn_sage_layer_fused_fwd_bf16": (i32, [vp, vp, vp, i64, vp, i32, vp, i64, i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i64, i32, vp]),
+    "dgnn_sage_layer_fused_decoder_fwd_bf16": (i32, [vp, vp, vp, i64, vp, vp, i64, i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i32,
+                                                     vp, vp, i32, vp, i32, vp]),
     "dgnn_decoder_fused_fwd_bf16": (i32, [vp, i64, i64, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, i64, i32, vp]),
     "dgnn_sage_aggregate_fwd_bf16": (i32, [vp, vp, vp, i64, vp, i64, i32, vp, i64, i32, vp, vp, vp, i64, vp, i64, vp, i64, vp]),
     "dgnn_sage_aggregate_bwd_bf16": (i32, [vp, vp, vp, i64, vp, vp, i64, i32, vp, i64, i32, vp, vp, vp, i64, vp, i64, vp, i64,

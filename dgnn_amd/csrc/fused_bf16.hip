@@ -40,7 +40,22 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // XF: the layer's INPUT rows are fp32 (the first layer reads the caller's fp32 feature matrix in place -- no cast pass, and
 // real standardised features reach 174 sigma, where a bf16 rounding of the input alone costs 0.3 absolute): gathered rows enter
 // the fp32 products as they are, the own row goes to the matrix cores as a (hi, lo) pair (PR) or rounded once (PR = 0).
-template <int CIN_PAD, int COUT, int NW = 4, int PR = 0, int XF = 0>
+// Eight-wave form (D16): 16-byte slot of channel block jb (8 channels) of part p (0 = mean hi, 1 = mean lo, 2 = own row) inside an A-tile row.
+// The dense phase reads the tile with ds_read_b128, which the LDS serves in four NON-contiguous 16-lane groups ({0-3, 12-15, 20-27}, ...:
+// MI355X_MICROARCH.md, LDS): a group mixes rows jcol of k-group tq with other rows of k-group tq + 1, so with the k-groups of a k-step in
+// neighbouring slots -- the round-2/3 layout [part][k-step][k-group] -- two lanes of every group met on one bank: 25 conflict cycles per tet,
+// 29 % of the launch's LDS cycles (profiles/r03g_bf16.md).  Here the two k-groups a lane group mixes (tq, tq ^ 1) sit 16 slots (= 256 B, one
+// bank row) apart, so the 16 lanes of a group fall on 16 different slots; the writers (8-lane groups of ds_write_b128, banks modulo 128 B) still
+// store contiguous 128-byte runs.  k-group kg of k-step S holds channel block jb = 8 * (kg & 1) + 4 * (kg >> 1) + S (weights are loaded to match).
+__host__ __device__ constexpr int d16_slot(int p, int jb) { return (p == 0 ? 0 : (p == 1 ? 8 : 32)) + 16 * (jb >> 3) + (jb & 7); }
+__host__ __device__ constexpr int d16_block(int S, int kg) { return 8 * (kg & 1) + 4 * (kg >> 1) + S; }
+
+struct DecB {      // the decoder behind the last conv layer (DEC instantiation); all NULL otherwise
+    const float *W0, *b0, *scale1, *shift1, *W3, *b3;
+    float* logits;
+};
+
+template <int CIN_PAD, int COUT, int NW = 4, int PR = 0, int XF = 0, bool DEC = false>
 struct CfgB {
     static constexpr int XPARTS = (PR && XF) ? 2 : 1;     // own-row parts in the A-tile
     static constexpr int APARTS = PR ? 2 : 1;             // mean parts
@@ -52,7 +67,7 @@ struct CfgB {
     static constexpr int NSLICE = COUT / (D16 ? 16 : 32);
     static constexpr int RG = NW / NSLICE;
     static constexpr int TILE = 32 * RG;
-    static constexpr int ROWB = K * 2 + 16;               // A-tile row: K bf16 + 16 B pad (odd number of 16-B slots)
+    static constexpr int ROWB = D16 ? 57 * 16 : K * 2 + 16;   // A-tile row: K bf16 + 16 B pad (odd number of 16-B slots); D16: 57 slots, see d16_slot
     static constexpr int A_BYTES = TILE * ROWB;
     static constexpr int TPW = TILE / NW;                 // tets per wave (8 or 16)
     static constexpr int RB = TPW / 4;                    // 16-edge row blocks per wave
@@ -61,9 +76,15 @@ struct CfgB {
     static constexpr int EA_BYTES = NQ * FE * 4;
     static constexpr int EA_FULL = EA_BYTES / 1024, EA_TAIL = (EA_BYTES % 1024) / 256;
     static constexpr int BP_BYTES = (PR ? 2 : 1) * NB * 768;   // [part][cb][g<3][j<16] x 16 B filter operand
-    static constexpr int SMEM_BYTES = 2 * A_BYTES + NW * EA_BYTES + BP_BYTES;
+    // DEC: W0 fragments (hi, lo: 2 x 16 KB), the finished tile as decoder operand fragments (2 buffers x (hi, lo) x 8 KB), constants
+    // (A1 | B1 | W3[2] | b3 | bj | scale | shift), partial logits (2 buffers x 4 hidden blocks x 32 tets x 2)
+    static constexpr int W0_BYTES = DEC ? 2 * 16384 : 0, Y_BYTES = DEC ? 2 * 2 * 8192 : 0, C_FLOATS = DEC ? (64 + 64 + 128 + 4 + 3 * 128) : 0,
+                         L_FLOATS = DEC ? 2 * 4 * 32 * 2 : 0;
+    static constexpr int SMEM_BYTES = 2 * A_BYTES + NW * EA_BYTES + BP_BYTES + W0_BYTES + Y_BYTES + 4 * (C_FLOATS + L_FLOATS);
     static constexpr int NS = CIN_PAD / (D16 ? 32 : 16);  // k-steps (of 16, D16: of 32) per operand part (full K per wave)
     static_assert(RG >= 1 && NQ <= 64 && EA_BYTES % 256 == 0 && !(XF && NW == 8), "wave roles");
+    static_assert(!D16 || (PR == 1 && XF == 0 && CIN_PAD == 128 && COUT == 128), "the eight-wave form is the compensated 128 -> 128 layer");
+    static_assert(!DEC || D16, "the decoder rides in the eight-wave form only");
 };
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
@@ -93,14 +114,14 @@ __device__ __forceinline__ void ld_bf(uint32_t (&v)[NB / 2], const uint16_t* p) 
     }
 }
 
-template <int CIN_PAD, int COUT, int NW, int OCC, int PR, int XF>
+template <int CIN_PAD, int COUT, int NW, int OCC, int PR, int XF, bool DEC = false>
 __global__ void __launch_bounds__(64 * NW, OCC)
 k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid, int64_t n_dst,
                   const void* __restrict__ x_, const void* __restrict__ xdst_, int64_t ldx, int c_in, const float* __restrict__ ea,
                   int64_t lde, const float* __restrict__ We, const float* __restrict__ be, const float* __restrict__ Wj,
                   const float* __restrict__ bj, const float* __restrict__ Wi, const float* __restrict__ scale,
-                  const float* __restrict__ shift, int relu, uint16_t* __restrict__ out, int64_t ldo, int64_t ntiles) {
-    using C = CfgB<CIN_PAD, COUT, NW, PR, XF>;
+                  const float* __restrict__ shift, int relu, uint16_t* __restrict__ out, int64_t ldo, int64_t ntiles, DecB dec) {
+    using C = CfgB<CIN_PAD, COUT, NW, PR, XF, DEC>;
     constexpr int ROWB = C::ROWB, TILE = C::TILE, TPW = C::TPW, RB = C::RB, NB = C::NB, NS = C::NS, NH = NB / 2;
     constexpr int NX = XF ? NB : NH;                                 // dwords per lane and row: NB floats or NB/2 bf16 pairs
     constexpr int XOFF = C::APARTS * CIN_PAD * 2;                    // byte offset of the own-row part(s) in an A-tile row
@@ -130,6 +151,11 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     char* const abuf = smemb;                                        // [2][A_BYTES]
     char* const eabuf = smemb + 2 * C::A_BYTES;                      // [NW][EA_BYTES] fp32 attribute strips
     char* const bpbuf = eabuf + NW * C::EA_BYTES;                    // filter operand (bf16)
+    char* const w0buf = bpbuf + C::BP_BYTES;                         // DEC: W0 fragments [part][hidden block][k-step][k-group][16 rows] x 16 B
+    char* const ybuf = w0buf + C::W0_BYTES;                          // DEC: [2][part][k-step][k-group][32 tets] x 16 B
+    float* const cbuf = reinterpret_cast<float*>(ybuf + C::Y_BYTES); // DEC: A1[64] | B1[64] | W3[2][64] | b3[2] pad 2 | bj[128] | scale[128] | shift[128]
+    float* const lbuf = cbuf + C::C_FLOATS;                          // DEC: [2][4 hidden blocks][32 tets][2]
+    (void)w0buf; (void)ybuf; (void)cbuf; (void)lbuf;
 
     const int lane = lane_id(), w = wave_id_uniform();
     const int h = lane >> 5, l31 = lane & 31;
@@ -174,7 +200,7 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         uint32_t ph[4], pl[4], qh[4], ql[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const int k = (D16 ? 32 : 16) * S + 8 * kg + 2 * d;
+            const int k = (D16 ? 8 * d16_block(S, kg) : 16 * S + 8 * kg) + 2 * d;
             const int64_t o0 = (int64_t)col * c_in + (k < c_in ? k : 0), o1 = (int64_t)col * c_in + (k + 1 < c_in ? k + 1 : 0);
             split2(k < c_in ? Wj[o0] : 0.f, k + 1 < c_in ? Wj[o1] : 0.f, ph[d], pl[d]);
             split2(k < c_in ? Wi[o0] : 0.f, k + 1 < c_in ? Wi[o1] : 0.f, qh[d], ql[d]);
@@ -190,6 +216,32 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     const float sc = scale ? scale[col] : 1.f;
     const float sh = scale ? shift[col] : 0.f;
     const bool has_scale = scale != nullptr;
+    if constexpr (DEC) {
+        // decoder operand A = W0 (64 x 128) as (hi, lo) bf16 fragments: entry (hidden row i, 8-channel block kb) -> k-step kb / 4, k-group kb % 4
+        for (int e = threadIdx.x; e < 64 * 16; e += blockDim.x) {
+            const int i = e >> 4, kb = e & 15;
+            const float* wr = dec.W0 + (int64_t)i * 128 + 8 * kb;
+            uint32_t ph[4], pl[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) split2(wr[2 * d], wr[2 * d + 1], ph[d], pl[d]);
+            char* dst = w0buf + ((((i >> 4) * 4 + (kb >> 2)) * 4 + (kb & 3)) * 16 + (i & 15)) * 16;
+            *reinterpret_cast<uint4*>(dst) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+            *reinterpret_cast<uint4*>(dst + 16384) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+        }
+        for (int e = threadIdx.x; e < 64; e += blockDim.x) {
+            const float a1 = dec.scale1 ? dec.scale1[e] : 1.f;
+            cbuf[e] = a1;
+            cbuf[64 + e] = __fmaf_rn(dec.b0[e], a1, dec.scale1 ? dec.shift1[e] : 0.f);     // relu((z + b0) * scale1 + shift1) = relu(z * A1 + B1)
+            cbuf[128 + e] = dec.W3[e];
+            cbuf[192 + e] = dec.W3[64 + e];
+        }
+        if (threadIdx.x < 2) cbuf[256 + threadIdx.x] = dec.b3[threadIdx.x];
+        for (int e = threadIdx.x; e < 128; e += blockDim.x) {
+            cbuf[260 + e] = bj ? bj[e] : 0.f;
+            cbuf[388 + e] = scale ? scale[e] : 1.f;
+            cbuf[516 + e] = scale ? shift[e] : 0.f;
+        }
+    }
     __syncthreads();
 
     // ---- filter-phase role
@@ -270,6 +322,16 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         else *reinterpret_cast<uint32_t*>(d) = v[0];
     };
     auto put_seg = [&](int buf, int row, const uint32_t (&av)[NH], const uint32_t (&al)[NH], const uint32_t (&xv)[NX]) {
+        if constexpr (C::D16) {     // conflict-free slots for the dense phase's ds_read_b128 lane groups (d16_slot)
+            char* rowp = abuf + buf * C::A_BYTES + row * ROWB;
+            put16(rowp + (16 * (jcol >> 3) + (jcol & 7)) * 16, av);
+            put16(rowp + (8 + 16 * (jcol >> 3) + (jcol & 7)) * 16, al);
+            uint32_t t[NH];
+#pragma unroll
+            for (int q = 0; q < NH; ++q) t[q] = xv[q];
+            put16(rowp + (32 + 16 * (jcol >> 3) + (jcol & 7)) * 16, t);
+            return;
+        }
         char* dst = abuf + buf * C::A_BYTES + row * ROWB + c0 * 2;
         put16(dst, av);
         if (PR) put16(dst + CIN_PAD * 2, al);
@@ -284,6 +346,50 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
 #pragma unroll
             for (int q = 0; q < NH; ++q) t[q] = xv[q];
             put16(dst + XOFF, t);
+        }
+    };
+
+    // ---- DEC: the decoder on a finished tile (reference :180-187 applied at :350-351), one tile behind the layer: tile t's finished rows are parked
+    // in LDS as (hi, lo) bf16 operand fragments by the dense phase of iteration t, multiplied with W0 after the tile barrier of iteration t + 1
+    // (wave w: hidden block w & 3, tet block w >> 2; Linear - BatchNorm - ReLU - the 64 -> 2 Linear's partial sums over the wave's 16 hidden
+    // units), and the four partial sums of a tet are added in a fixed order and stored after the barrier of iteration t + 2.  No barrier of its own.
+    auto decoder_stage = [&](int64_t itd) {
+        if constexpr (DEC) {
+            const int hb = w & 3, tb = w >> 2;
+            const char* W = w0buf + ((hb * 4 * 4 + tq) * 16 + jcol) * 16;
+            const char* Y = ybuf + (itd & 1) * 16384 + ((tq * 32) + tb * 16 + jcol) * 16;
+            f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int S = 0; S < 4; ++S) {
+                const bf16x8 wh = *reinterpret_cast<const bf16x8*>(W + S * 1024), wl = *reinterpret_cast<const bf16x8*>(W + S * 1024 + 16384);
+                const bf16x8 yh = *reinterpret_cast<const bf16x8*>(Y + S * 2048), yl = *reinterpret_cast<const bf16x8*>(Y + S * 2048 + 8192);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, yh, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, yl, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, yh, d, 0, 0, 0);
+            }
+            // d[r] = (W0 . y) of hidden unit hb * 16 + 4 * tq + r, tet tb * 16 + jcol
+            const int i0h = hb * 16 + 4 * tq;
+            const f32x4_t a1 = *reinterpret_cast<const f32x4_t*>(cbuf + i0h), b1 = *reinterpret_cast<const f32x4_t*>(cbuf + 64 + i0h);
+            const f32x4_t w30 = *reinterpret_cast<const f32x4_t*>(cbuf + 128 + i0h), w31 = *reinterpret_cast<const f32x4_t*>(cbuf + 192 + i0h);
+            float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float hv = fmaxf(__fmaf_rn(d[r], a1[r], b1[r]), 0.f);
+                p0 = __fmaf_rn(hv, w30[r], p0);
+                p1 = __fmaf_rn(hv, w31[r], p1);
+            }
+            // the four k-group lanes of a tet (l, l ^ 16, l ^ 32, l ^ 48): pairwise sums, the same value in all four
+            p0 = cross_row_sum(p0);
+            p1 = cross_row_sum(p1);
+            if (tq == 0) *reinterpret_cast<float2*>(lbuf + (((itd & 1) * 4 + hb) * 32 + tb * 16 + jcol) * 2) = make_float2(p0, p1);
+        }
+    };
+    auto logits_stage = [&](int64_t itf) {       // wave 0: lane -> (tet lane >> 1, logit lane & 1)
+        if constexpr (DEC) {
+            const float* L = lbuf + (itf & 1) * 256 + lane;
+            const float v = ((L[0] + L[64]) + L[128]) + L[192] + cbuf[256 + (lane & 1)];
+            const int64_t row = tile_of(itf) * TILE + (lane >> 1);
+            if (row < n_dst) dec.logits[row * 2 + (lane & 1)] = v;
         }
     };
 
@@ -394,6 +500,10 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         asm volatile("" : "+v"(vbeg2), "+v"(vsrc1), "+v"(vbeg1), "+v"(veid1));
         issue_loads(it + 1);
         tile_barrier();  // A-tile `it` complete
+        if constexpr (DEC) {
+            if (it >= 1) decoder_stage(it - 1);
+            if (it >= 2 && w == 0) logits_stage(it - 2);
+        }
 
         // ================================================================ C: dense part on bf16 operands, full K per wave
         const int64_t tile = tile_of(it);
@@ -433,30 +543,66 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                 if (full || row0 + rr < n_dst) *reinterpret_cast<uint32_t*>(o + (int64_t)rr * ldo) = pk;
             }
         } else {
-            // sixteen columns per wave: two 16-row blocks of v_mfma_f32_16x16x32_bf16, lane (row jcol, k-group tq)
+            // sixteen columns per wave: two 16-row blocks of v_mfma_f32_16x16x32_bf16, lane (row jcol, k-group tq); k-step S of the lane's
+            // k-group = channel block d16_block(S, tq), parked at slot base + 16 * (tq & 1) + 4 * (tq >> 1) + S of the row (d16_slot)
             f32x4_t acc2[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m) acc2[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            const char* A = abuf + (it & 1) * C::A_BYTES + (rg * 32 + jcol) * ROWB + tq * 16;
+            const char* A = abuf + (it & 1) * C::A_BYTES + (rg * 32 + jcol) * ROWB + (16 * (tq & 1) + 4 * (tq >> 1)) * 16;
 #pragma unroll
             for (int S = 0; S < NS; ++S) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const char* Am = A + m * 16 * ROWB + S * 64;
+                    const char* Am = A + m * 16 * ROWB + S * 16;
                     const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Am);
-                    const bf16x8 xi = *reinterpret_cast<const bf16x8*>(Am + XOFF);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(Am + 8 * 16);
+                    const bf16x8 xi = *reinterpret_cast<const bf16x8*>(Am + 32 * 16);
                     f32x4_t c = acc2[m];
-                    if (PR) {
-                        const bf16x8 al = *reinterpret_cast<const bf16x8*>(Am + CIN_PAD * 2);
+                    if constexpr (DEC) {
+                        // transposed product (weights as the A operand): the lane ends with ONE tet (jcol + 16 m) and 4 consecutive output
+                        // columns cs * 16 + 4 tq + r -- the shape the decoder's operand fragments are cut from; same products, same order
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wjh[S], al, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wjl[S], ah, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wil[S], xi, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wjh[S], ah, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wih[S], xi, c, 0, 0, 0);
+                    } else {
                         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wjh[S], c, 0, 0, 0);
                         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wjl[S], c, 0, 0, 0);
                         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xi, wil[S], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wjh[S], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xi, wih[S], c, 0, 0, 0);
                     }
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wjh[S], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xi, wih[S], c, 0, 0, 0);
                     acc2[m] = c;
                 }
             }
+            if constexpr (DEC) {
+                // bias / BatchNorm(eval) / ReLU of columns cs * 16 + 4 tq + r, then the 8 consecutive columns a lane pair (tq, tq ^ 1) holds become
+                // one decoder operand fragment: both lanes collect all 8 values (v_permlane16_swap), the even lane writes their bf16 hi parts, the odd lane the lo parts (y = hi + lo to 16 bits; y itself is never rounded
+                // to bf16 -- the rounding next to the logits that the two-launch form pays)
+                const int cb4 = cs * 16 + 4 * tq;
+                const f32x4_t bbv = *reinterpret_cast<const f32x4_t*>(cbuf + 260 + cb4), scv = *reinterpret_cast<const f32x4_t*>(cbuf + 388 + cb4),
+                              shv = *reinterpret_cast<const f32x4_t*>(cbuf + 516 + cb4);
+                char* Yw = ybuf + (it & 1) * 16384 + (tq & 1) * 8192 + ((((cs >> 1) * 4 + (cs & 1) * 2 + (tq >> 1)) * 32) + jcol) * 16;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    float v8[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc2[m][r] + bbv[r];
+                        if (has_scale) v = __fmaf_rn(v, scv[r], shv[r]);
+                        if (relu) v = fmaxf(v, 0.f);
+                        const float pv = partner16(v);      // lane l ^ 16's value, no LDS
+                        v8[r] = (tq & 1) ? pv : v;
+                        v8[4 + r] = (tq & 1) ? v : pv;
+                    }
+                    uint32_t ph[4], pl[4];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) split2(v8[2 * d], v8[2 * d + 1], ph[d], pl[d]);
+                    const bool lo_part = (tq & 1) != 0;
+                    *reinterpret_cast<uint4*>(Yw + m * 256) = make_uint4(lo_part ? pl[0] : ph[0], lo_part ? pl[1] : ph[1], lo_part ? pl[2] : ph[2], lo_part ? pl[3] : ph[3]);
+                }
+            } else {
             // C/D layout: column jcol, rows 4*tq + r of the block; (col, col^1) pair up as above
             uint16_t* o = out + (tile * TILE + rg * 32) * ldo + (col & ~1);
 #pragma unroll
@@ -471,26 +617,37 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                     const int rr = m * 16 + 4 * tq + r + odd;
                     if (full || tile * TILE + rg * 32 + rr < n_dst) *reinterpret_cast<uint32_t*>(o + (int64_t)rr * ldo) = pk;
                 }
+            }
+        }
+    }
+    if constexpr (DEC) {
+        // drain: the last tile's decoder, the last two tiles' logits
+        if (my_n >= 1) {
+            tile_barrier();
+            decoder_stage(my_n - 1);
+            if (my_n >= 2 && w == 0) logits_stage(my_n - 2);
+            tile_barrier();
+            if (w == 0) logits_stage(my_n - 1);
         }
     }
 }
 
-template <int CIN_PAD, int COUT, int OCC, int PR, int NW = 4, int XF = 0>
+template <int CIN_PAD, int COUT, int OCC, int PR, int NW = 4, int XF = 0, bool DEC = false>
 int launch_b(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const void* x, const void* xdst, int64_t ldx,
              int c_in, const float* ea, int64_t lde, const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
-             const float* scale, const float* shift, int relu, uint16_t* out, int64_t ldo, hipStream_t stream) {
-    using C = CfgB<CIN_PAD, COUT, NW, PR, XF>;
+             const float* scale, const float* shift, int relu, uint16_t* out, int64_t ldo, hipStream_t stream, DecB dec = DecB{}) {
+    using C = CfgB<CIN_PAD, COUT, NW, PR, XF, DEC>;
     const int64_t ntiles = dgnn_cdiv(n_dst, C::TILE);
     const size_t smem = C::SMEM_BYTES;
     static bool attr_set[DGNN_MAX_DEVICES] = {};
-    dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_bf16<CIN_PAD, COUT, NW, OCC, PR, XF>), smem, attr_set);
+    dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_bf16<CIN_PAD, COUT, NW, OCC, PR, XF, DEC>), smem, attr_set);
     const int per_cu = (int)(160 * 1024 / smem) < OCC ? (int)(160 * 1024 / smem) : OCC;
     const int wg_max = DGNN_NUM_CU * (per_cu < 1 ? 1 : per_cu);
     int grid = (int)(ntiles < wg_max ? ntiles : wg_max);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((k_sage_fused_bf16<CIN_PAD, COUT, NW, OCC, PR, XF>), dim3(grid), dim3(64 * NW), smem, stream, rowptr, src, eid, n_dst, x, xdst,
-                       ldx, c_in, ea, lde, We, be, Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles);
-    return dgnn_check_launch("sage_layer_fused_fwd_bf16");
+    hipLaunchKernelGGL((k_sage_fused_bf16<CIN_PAD, COUT, NW, OCC, PR, XF, DEC>), dim3(grid), dim3(64 * NW), smem, stream, rowptr, src, eid, n_dst, x, xdst,
+                       ldx, c_in, ea, lde, We, be, Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles, dec);
+    return dgnn_check_launch(DEC ? "sage_layer_fused_decoder_fwd_bf16" : "sage_layer_fused_fwd_bf16");
 }
 
 // out[r, c] = bf16(in[r, c]) for c < cols, 0 for cols <= c < cols_pad (row stride ld_out >= cols_pad)
@@ -698,6 +855,29 @@ extern "C" int dgnn_sage_layer_fused_fwd_bf16(const int32_t* rowptr, const int32
                                            out, ldo, stream);
     GOB(128, 128, 2);
 #undef GOB
+}
+
+// The LAST conv layer in bf16 storage with the decoder inside its launch (compensated arithmetic): the finished tile never leaves the compute unit
+// and is never rounded to bf16 -- it reaches the decoder's matrix products as (hi, lo) pairs -- and only fp32 logits are written.
+extern "C" int dgnn_sage_layer_fused_decoder_fwd_bf16(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const uint16_t* x_src,
+                                                      const uint16_t* x_dst, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e,
+                                                      const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
+                                                      const float* scale, const float* shift, int relu, int c_out, const float* W0, const float* b0,
+                                                      const float* scale1, const float* shift1, int c_hidden, const float* W3, const float* b3,
+                                                      int n_logits, float* logits, int mode, void* stream_) {
+    DGNN_REQUIRE(n_dst >= 0 && c_in > 0 && c_out > 0, DGNN_E_INVALID, "sage_layer_fused_decoder_fwd_bf16: bad sizes");
+    if (n_dst == 0) return DGNN_OK;
+    DGNN_REQUIRE(rowptr && src && x_src && edge_attr && We && be && Wj && Wi && W0 && b0 && W3 && b3 && logits, DGNN_E_INVALID,
+                 "sage_layer_fused_decoder_fwd_bf16: null pointer");
+    DGNN_REQUIRE((scale == nullptr) == (shift == nullptr) && (scale1 == nullptr) == (shift1 == nullptr), DGNN_E_INVALID,
+                 "sage_layer_fused_decoder_fwd_bf16: scale/shift must come together");
+    if (x_dst == nullptr) x_dst = x_src;
+    const bool ok = mode == DGNN_BF16_COMPENSATED && c_out == 128 && c_in > 64 && c_in <= 128 && c_in % 8 == 0 && f_e == FE && lde == FE && c_hidden == 64 &&
+                    n_logits == 2 && ((uintptr_t)edge_attr % 16) == 0 && ldx % 8 == 0 && (((uintptr_t)x_src | (uintptr_t)x_dst) % 16) == 0 &&
+                    ((uintptr_t)logits % 8) == 0 && n_dst * ldx < ((int64_t)1 << 31);
+    if (!ok) return DGNN_E_UNSUPPORTED;     // the caller runs dgnn_sage_layer_fused_fwd_bf16 and dgnn_decoder_fused_fwd_bf16
+    return launch_b<128, 128, 1, 1, 8, 0, true>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, shift, relu, nullptr, 0,
+                                                (hipStream_t)stream_, DecB{W0, b0, scale1, shift1, W3, b3, logits});
 }
 
 extern "C" int dgnn_decoder_fused_fwd_bf16(const uint16_t* y, int64_t ldy, int64_t M, int k, const float* W0, const float* b0, const float* scale,

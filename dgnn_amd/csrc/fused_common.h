@@ -127,11 +127,46 @@ __device__ __forceinline__ uint32_t wave_umax(uint32_t m) {
 }
 // maximum over the four lanes l, l^16, l^32, l^48 (the k-groups of one row of a 16x16x32 A operand), left in all four:
 // v_permlane16_swap / v_permlane32_swap exchange whole 16- / 32-lane rows between two registers without going through LDS
+// The swap instructions on two copies of ONE value: (a, b) = {own value, value of lane l ^ 16 (l ^ 32)} -- which of the two is which depends on the
+// lane's row.  Both copies and both results pass through empty asm statements: with plain copies LLVM's machine copy propagation treated the two
+// results as the same register and compiled `r[0] + r[1]` of the bf16 decoder stage as `r[0] + r[0]` (round 4, ROCm 7.2; found by the parity test).
+__device__ __forceinline__ void swap16_pair(uint32_t v, uint32_t& a, uint32_t& b) {
+    uint32_t c = v;
+    asm volatile("" : "+v"(v), "+v"(c));
+    const auto r = __builtin_amdgcn_permlane16_swap(v, c, false, false);
+    a = r[0];
+    b = r[1];
+    asm volatile("" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap32_pair(uint32_t v, uint32_t& a, uint32_t& b) {
+    uint32_t c = v;
+    asm volatile("" : "+v"(v), "+v"(c));
+    const auto r = __builtin_amdgcn_permlane32_swap(v, c, false, false);
+    a = r[0];
+    b = r[1];
+    asm volatile("" : "+v"(a), "+v"(b));
+}
 __device__ __forceinline__ uint32_t cross_row_umax(uint32_t m) {
-    const auto r = __builtin_amdgcn_permlane16_swap(m, m, false, false);
-    m = umax(r[0], r[1]);
-    const auto q = __builtin_amdgcn_permlane32_swap(m, m, false, false);
-    return umax(q[0], q[1]);
+    uint32_t a, b;
+    swap16_pair(m, a, b);
+    m = umax(a, b);
+    swap32_pair(m, a, b);
+    return umax(a, b);
+}
+// sum over the four lanes l, l ^ 16, l ^ 32, l ^ 48, the same value (bit for bit) in all four: (own + partner16) + (the other pair's sum)
+__device__ __forceinline__ float cross_row_sum(float v) {
+    uint32_t a, b;
+    swap16_pair(__builtin_bit_cast(uint32_t, v), a, b);
+    const float s = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+    swap32_pair(__builtin_bit_cast(uint32_t, s), a, b);
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+// value of lane l ^ 16
+__device__ __forceinline__ float partner16(float v) {
+    uint32_t a, b;
+    const uint32_t vb = __builtin_bit_cast(uint32_t, v);
+    swap16_pair(vb, a, b);
+    return __builtin_bit_cast(float, a ^ b ^ vb);     // {a, b} = {own, partner}
 }
 __device__ __forceinline__ f16x8 pack8h(const uint32_t (&d)[4]) {
     return __builtin_bit_cast(f16x8, f32x4{__builtin_bit_cast(float, d[0]), __builtin_bit_cast(float, d[1]),

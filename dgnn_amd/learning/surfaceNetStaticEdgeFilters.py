@@ -331,7 +331,7 @@ class SurfaceNet(nn.Module):
 
     def _fusable_rows(self, x, i):
         """the fused launches take packed 20-column fp32 edge rows and 16-byte aligned feature rows; other inputs run layer and decoder apart"""
-        return x.dtype == torch.float32 and not self.clf.regularization.edge_type
+        return (x.dtype == torch.float32 or self.storage_dtype == torch.bfloat16) and not self.clf.regularization.edge_type
 
     def _fold(self, norm, c, device):
         """BatchNorm(eval) as a per-channel (scale, shift) pair, cached until one of its tensors is written to
@@ -375,9 +375,10 @@ class SurfaceNet(nn.Module):
         return buf
 
     def fuses_decoder(self, i):
-        """True when layer i's launch also carries the decoder (the last conv layer of the shipped widths, fp32 storage: the finished tile goes
-        through Linear-BN-ReLU-Linear in the same kernel and only the logits are written, reference :180-187 applied at :350-351)"""
-        if i != self.num_layers - 1 or self.storage_dtype != torch.float32 or not self.clf.model.decoder or len(self.decoder) != 4:
+        """True when layer i's launch also carries the decoder (the last conv layer of the shipped widths, fp32 storage or -- round 4 -- bf16 storage in
+        the compensated arithmetic: the finished tile goes through Linear-BN-ReLU-Linear in the same kernel and only the logits are written, reference
+        :180-187 applied at :350-351)"""
+        if i != self.num_layers - 1 or not self.clf.model.decoder or len(self.decoder) != 4:
             return False
         conv, dec = self.convs[i][0], self.decoder
         le = conv.lin_e
@@ -385,8 +386,9 @@ class SurfaceNet(nn.Module):
             return False
         if not isinstance(self.convs[i][2], nn.ReLU) or (dec[1] is not None and not isinstance(dec[1], BatchNorm)):
             return False
-        return ops.fused_layer_decoder_supported(conv.lin_j.in_features, conv.lin_j.out_features, le.in_features, dec[0].out_features,
-                                                 dec[3].out_features) and dec[0].in_features == conv.lin_j.out_features
+        sup = ops.fused_layer_decoder_supported_bf16 if self.storage_dtype == torch.bfloat16 else ops.fused_layer_decoder_supported
+        return sup(conv.lin_j.in_features, conv.lin_j.out_features, le.in_features, dec[0].out_features,
+                   dec[3].out_features) and dec[0].in_features == conv.lin_j.out_features
 
     def _eval_layers(self, x, n_dst0, xe, plans, sorted_attr, only=None, out=None, rows=None, decode=False):
         """Eval-mode conv stack: per layer one fused launch when the widths allow it, else the
@@ -413,10 +415,16 @@ class SurfaceNet(nn.Module):
         conv = layer[0]
         if decode:
             le_ = conv.lin_e
-            fusable = (x.dtype == torch.float32 and isinstance(le_, Linear) and le_.in_features == 20
-                       and ops.fused_layer_supported(x.size(1), conv.lin_j.out_features, 20, x)
-                       and ops.fused_layer_decoder_supported(x.size(1), conv.lin_j.out_features, 20, self.decoder[0].out_features,
-                                                             self.decoder[3].out_features, x))
+            if self.storage_dtype == torch.bfloat16:
+                fusable = (isinstance(le_, Linear) and le_.in_features == 20
+                           and ops.fused_layer_supported_bf16(conv.lin_j.in_features, conv.lin_j.out_features, 20, x)
+                           and ops.fused_layer_decoder_supported_bf16(conv.lin_j.in_features, conv.lin_j.out_features, 20, self.decoder[0].out_features,
+                                                                      self.decoder[3].out_features, x))
+            else:
+                fusable = (x.dtype == torch.float32 and isinstance(le_, Linear) and le_.in_features == 20
+                           and ops.fused_layer_supported(x.size(1), conv.lin_j.out_features, 20, x)
+                           and ops.fused_layer_decoder_supported(x.size(1), conv.lin_j.out_features, 20, self.decoder[0].out_features,
+                                                                 self.decoder[3].out_features, x))
             if not fusable:     # this input cannot take the one-launch form (alignment, strides ...): layer and decoder apart, same interface
                 lg = self._eval_decoder(self._eval_layer(i, x, xe, plan, sorted_attr, None, rows, False))
                 if out is None:
@@ -443,6 +451,12 @@ class SurfaceNet(nn.Module):
                 ea, eid = (plan.sorted_edge_attr(xe) if sorted_attr else xe), None
                 if ea.stride(0) != 20 or ea.data_ptr() % 16:
                     ea = ea.contiguous()
+            if decode:      # (`fusable` above: the launch carries the decoder and writes fp32 logits)
+                dec = self.decoder
+                s1, h1 = self._fold(dec[1] if isinstance(dec[1], BatchNorm) else None, dec[0].out_features, x.device)
+                return ops.sage_layer_fused_decoder_fwd_bf16(rowptr, plan.src, n, x, c_in, ea, le.weight, le.bias, conv.lin_j.weight, conv.lin_j.bias,
+                                                             conv.lin_i.weight, scale, shift, True, dec[0].weight, dec[0].bias, s1, h1, dec[3].weight,
+                                                             dec[3].bias, out=out_v, eid=eid, x_dst=x_dst if b else None)
             return ops.sage_layer_fused_fwd_bf16(rowptr, plan.src, n, x, c_in, ea, le.weight, le.bias, conv.lin_j.weight, conv.lin_j.bias,
                                                  conv.lin_i.weight, scale, shift, True, out=out_v, eid=eid, x_dst=x_dst if b else None)
         if simple and le.in_features == 20 and ops.fused_layer_supported(x.size(1), conv.lin_j.out_features, 20, x):

@@ -650,6 +650,34 @@ def sage_layer_fused_fwd_bf16(rowptr, src, n_dst, x_src, c_in, edge_attr, We, be
     return out
 
 
+def fused_layer_decoder_supported_bf16(c_in: int, c_out: int, f_e: int, hidden: int, n_out: int, x=None) -> bool:
+    """the last bf16-storage layer's launch can carry the decoder: shipped shape, compensated arithmetic, bf16 rows 16-byte aligned"""
+    ok = (FUSE_DECODER and FUSED_ENABLED and BF16_MODE == BF16_COMPENSATED and 64 < c_in <= 128 and c_in % 8 == 0 and c_out == 128 and f_e == 20
+          and hidden == 64 and n_out == 2)
+    if ok and x is not None:
+        ok = x.dtype == torch.bfloat16 and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
+    return ok
+
+
+@on_device_of
+def sage_layer_fused_decoder_fwd_bf16(rowptr, src, n_dst, x_src, c_in, edge_attr, We, be, Wj, bj, Wi, scale, shift, relu, W0, b0, scale1, shift1, W3, b3,
+                                      out=None, eid=None, x_dst=None):
+    """Last conv layer (bf16 storage) + decoder, one launch -> fp32 logits [n_dst, 2]; the layer's output is never rounded to bf16."""
+    _req(x_src, "x_src", BF16, dim=2)
+    _same(x_dst, x_src, "x_dst")
+    if out is None:
+        out = torch.empty((n_dst, 2), dtype=torch.float32, device=x_src.device)
+    else:
+        _req(out, "out", dim=2)
+        if out.size(0) < n_dst or out.size(1) != 2 or out.stride(0) != 2:
+            raise ValueError("out must be a contiguous [>= n_dst, 2] buffer")
+    check(lib().dgnn_sage_layer_fused_decoder_fwd_bf16(
+        ptr(rowptr), ptr(src), ptr(eid), n_dst, ptr(x_src), ptr(x_dst), _ld(x_src), c_in, ptr(edge_attr), _ld(edge_attr), We.size(1), ptr(We), ptr(be),
+        ptr(Wj), ptr(bj), ptr(Wi), ptr(scale), ptr(shift), int(bool(relu)), Wj.size(0), ptr(W0.contiguous()), ptr(b0), ptr(scale1), ptr(shift1), W0.size(0),
+        ptr(W3.contiguous()), ptr(b3), W3.size(0), ptr(out), BF16_MODE, stream_ptr()), "dgnn_sage_layer_fused_decoder_fwd_bf16")
+    return out
+
+
 @on_device_of
 def decoder_fused_fwd_bf16(y, W0, b0, scale, shift, W3, b3):
     _req(y, "y", BF16, dim=2)

@@ -303,17 +303,18 @@ class PartitionedScene:
         last = net.num_layers - 1
         # the last layer's launches carry the decoder when the model can do that (as the whole-graph inference_layer does: same kernel, so a
         # partitioned scene stays bit-identical to the whole graph); they then write logits [n_own, 2] instead of rows
-        fuse = bool(getattr(net, "fuses_decoder", lambda i: False)(last)) and x.dtype == torch.float32 and not net.clf.regularization.edge_type
+        fuse = bool(getattr(net, "fuses_decoder", lambda i: False)(last)) and net._fusable_rows(x, last)
 
         def layer_fn(i, h, out, b, e):
             net._eval_layers(h, self.n_own, xe, [plan] * net.num_layers, False, only=i, out=out, rows=(b, e), decode=fuse and i == last)
 
-        def alloc(r, c):
-            return torch.empty((r, c), dtype=getattr(net, "storage_dtype", torch.float32), device=self.device)
-
         widths = list(net.clf.model.convs)
         if fuse:
             widths[last] = 2
+
+        def alloc(r, c):      # activations in the model's storage type; the decoder-carrying last launch writes fp32 logits
+            logits = fuse and c == 2 and r == self.n_own
+            return torch.empty((r, c), dtype=torch.float32 if logits else getattr(net, "storage_dtype", torch.float32), device=self.device)
         return run_partitioned_layers(self.lp, x, net.num_layers, layer_fn, (lambda lg: lg) if fuse else net._eval_decoder, self.exchange, alloc,
                                       widths=widths)
 

@@ -543,6 +543,19 @@ int dgnn_sage_layer_fused_fwd_bf16(const int32_t* rowptr, const int32_t* src, co
                                    const float* scale, const float* shift, int relu, int c_out, uint16_t* out, int64_t ldo, int mode,
                                    void* stream);
 /* dgnn_decoder_fused_fwd on bf16 rows (16-byte aligned, ldy % 8 == 0); logits stay fp32 */
+/* The LAST conv layer in bf16 storage with the decoder inside its launch (round 4; SurfaceNet.inference_layer :343-351 in the bf16 storage path):
+ * dgnn_sage_layer_fused_fwd_bf16 followed by dgnn_decoder_fused_fwd_bf16 without the bf16 round trip of the layer's output -- the finished tile
+ * reaches the decoder's matrix products as (hi, lo) bf16 pairs (16 significant bits; it is NEVER rounded to bf16: the storage rounding next to
+ * the logits is gone) and only fp32 logits [n_dst, 2] are written.  Arguments as the two entry points.  Covers the shipped shape in the
+ * compensated arithmetic: 64 < c_in <= 128 (c_in % 8 == 0), c_out = 128, f_e = 20 packed rows, decoder 128 -> 64 -> 2, bf16 rows 16-byte aligned
+ * (ldx % 8 == 0), mode = DGNN_BF16_COMPENSATED; anything else: DGNN_E_UNSUPPORTED, nothing launched.  A tet's logits depend on its own inputs only
+ * (destination sub-ranges give bit-identical results). */
+int dgnn_sage_layer_fused_decoder_fwd_bf16(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const uint16_t* x_src,
+                                           const uint16_t* x_dst, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e,
+                                           const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
+                                           const float* scale, const float* shift, int relu, int c_out, const float* W0, const float* b0,
+                                           const float* scale1, const float* shift1, int c_hidden, const float* W3, const float* b3, int n_logits,
+                                           float* logits, int mode, void* stream);
 int dgnn_decoder_fused_fwd_bf16(const uint16_t* y, int64_t ldy, int64_t M, int k, const float* W0, const float* b0, const float* scale,
                                 const float* shift, int hidden, const float* W3, const float* b3, int n_out, float* out, int64_t ldo,
                                 int mode, void* stream);

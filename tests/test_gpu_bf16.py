@@ -167,6 +167,86 @@ def test_fused_layer_bf16_irregular_degrees_and_tail():
     assert rel_err(out.float(), ref) < 1.5e-2
 
 
+@pytest.mark.parametrize("points,c_in", [(5, 128), (40, 128), (700, 128), (700, 96), (5000, 128)])
+def test_last_bf16_layer_with_the_decoder_inside(points, c_in):
+    """dgnn_sage_layer_fused_decoder_fwd_bf16 (round 4): the last conv layer of the bf16 storage path with Linear-BN-ReLU-Linear inside its launch
+    (reference :180-187 applied at :350-351).  The layer's output is never rounded to bf16, so the logits must follow the fp64 evaluation of
+    layer + decoder on the bf16 INPUT rows as the kernel sees them to the 2^-15 of the (hi, lo) operand pairs -- several times closer than the
+    two-launch form, which stores the rows as bf16 in between; graphs smaller than a tile / not a multiple of one; destination sub-ranges bit-identical."""
+    from dgnn_amd import ops
+    from dgnn_amd.synthetic import delaunay_tet_graph
+    from oracle.pyg_semantics import propagate_mean
+    if ops.BF16_MODE != ops.BF16_COMPENSATED:
+        pytest.skip("the one-launch form exists for the compensated arithmetic")
+    adj, _, _ = delaunay_tet_graph(points, seed=points)
+    n = adj.shape[0] // 4
+    ei = torch.from_numpy(adj.T.astype(np.int64))
+    g = torch.Generator().manual_seed(points + c_in)
+    x = torch.relu(torch.randn(n, c_in, generator=g))           # post-ReLU activations, as the layer sees them
+    x[::53] *= 20
+    ea = torch.randn(4 * n, 20, generator=g)
+    We, be = torch.randn(c_in, 20, generator=g) * 0.3, torch.randn(c_in, generator=g)
+    Wj, Wi, bj = torch.randn(128, c_in, generator=g) * 0.1, torch.randn(128, c_in, generator=g) * 0.1, torch.randn(128, generator=g)
+    scale, shift = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g)
+    W0, b0 = torch.randn(64, 128, generator=g) * 0.15, torch.randn(64, generator=g)
+    s1, h1 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    W3, b3 = torch.randn(2, 64, generator=g) * 0.3, torch.randn(2, generator=g)
+    r = lambda t: t.to(BF).double()
+    d = lambda t: t.double()
+    a = propagate_mean(r(x), n, ei, d(ea) @ d(We).t() + d(be))
+    y = torch.relu((a @ d(Wj).t() + r(x) @ d(Wi).t() + d(bj)) * d(scale) + d(shift))
+    hid = torch.relu((y @ d(W0).t() + d(b0)) * d(s1) + d(h1))
+    ref = hid @ d(W3).t() + d(b3)
+    mag = (hid.abs() @ d(W3).abs().t()) + (y.abs() @ d(W0).abs().t() * d(s1).abs()) @ d(W3).abs().t()     # sum of |terms| behind a logit
+    rowptr, src, eid = ops.plan_build(ei.to(DEV), n, 1, n_other=n)
+    xb = ops.cast_to_bf16(x.to(DEV))
+    dv = lambda *ts: [t.to(DEV) for t in ts]
+    layer = dv(We, be, Wj, bj, Wi, scale, shift)
+    deco = dv(W0, b0, s1, h1, W3, b3)
+    assert ops.fused_layer_decoder_supported_bf16(c_in, 128, 20, 64, 2, xb)
+    one = ops.sage_layer_fused_decoder_fwd_bf16(rowptr, src, n, xb, c_in, ea.to(DEV), *layer, True, *deco, eid=eid)
+    assert one.dtype == torch.float32 and one.shape == (n, 2)
+    two = ops.decoder_fused_fwd_bf16(ops.sage_layer_fused_fwd_bf16(rowptr, src, n, xb, c_in, ea.to(DEV), *layer, True, eid=eid), *deco)
+    e1, e2 = (one.cpu().double() - ref).abs(), (two.cpu().double() - ref).abs()
+    bound = 2.0 ** -13 * mag + 1e-4
+    assert bool((e1 <= bound).all()), float((e1 / bound).max())
+    if n >= 1000:
+        assert e1.pow(2).mean().sqrt() < 0.2 * e2.pow(2).mean().sqrt(), (float(e1.max()), float(e2.max()))     # the bf16 round trip of the rows is what the two launches pay
+    assert torch.equal(one, ops.sage_layer_fused_decoder_fwd_bf16(rowptr, src, n, xb, c_in, ea.to(DEV), *layer, True, *deco, eid=eid))     # run to run
+    # rows already in plan order (eid = None), and destination sub-ranges (interior / boundary launches of a partitioned scene): the same bits
+    assert torch.equal(one, ops.sage_layer_fused_decoder_fwd_bf16(rowptr, src, n, xb, c_in, ops.gather_rows(ea.to(DEV), eid), *layer, True, *deco))
+    if n > 40:
+        out = torch.full((n, 2), float("nan"), device=DEV)
+        for b, e in ((0, 37), (37, n - 5), (n - 5, n)):
+            ops.sage_layer_fused_decoder_fwd_bf16(rowptr[b:e + 1], src, e - b, xb, c_in, ea.to(DEV), *layer, True, *deco, out=out[b:e], eid=eid, x_dst=xb[b:e])
+        assert torch.equal(out, one)
+
+
+def test_last_bf16_layer_with_the_decoder_inside_irregular_degrees():
+    """in-degrees 0 .. many (the per-lane generic path inside the launch) and a ragged destination count"""
+    from dgnn_amd import ops
+    g = torch.Generator().manual_seed(11)
+    n_src, n_dst, E, c_in = 1500, 1003, 5200, 128
+    ei = torch.stack([torch.randint(0, n_src, (E,), generator=g), torch.randint(0, n_dst + 30, (E,), generator=g).clamp_max(n_dst - 1)])
+    x = torch.relu(torch.randn(n_src, c_in, generator=g))
+    ea = torch.randn(E, 20, generator=g)
+    We, be = torch.randn(c_in, 20, generator=g) * 0.3, torch.randn(c_in, generator=g)
+    Wj, Wi, bj = torch.randn(128, c_in, generator=g) * 0.1, torch.randn(128, c_in, generator=g) * 0.1, torch.randn(128, generator=g)
+    W0, b0 = torch.randn(64, 128, generator=g) * 0.15, torch.randn(64, generator=g)
+    W3, b3 = torch.randn(2, 64, generator=g) * 0.3, torch.randn(2, generator=g)
+    rowptr, src, eid = ops.plan_build(ei.to(DEV), n_dst, 1, n_other=n_src)
+    xb = ops.cast_to_bf16(x.to(DEV))
+    dv = lambda *ts: [t.to(DEV) if t is not None else None for t in ts]
+    layer, deco = dv(We, be, Wj, bj, Wi, None, None), dv(W0, b0, None, None, W3, b3)
+    one = ops.sage_layer_fused_decoder_fwd_bf16(rowptr, src, n_dst, xb, c_in, ea.to(DEV), *layer, True, *deco, eid=eid)
+    rows = ops.sage_layer_fused_fwd_bf16(rowptr, src, n_dst, xb, c_in, ea.to(DEV), *layer, True, eid=eid)
+    two = ops.decoder_fused_fwd_bf16(rows, *deco)
+    # the two-launch form sees the rows rounded to bf16: one relative 2^-9 per row element through 128 -> 64 -> 2
+    y = rows.float().cpu().double()
+    mag = ((y.abs() @ W0.double().abs().t()) @ W3.double().abs().t())
+    assert bool(((one.cpu().double() - two.cpu().double()).abs() <= EPS * mag + 1e-3).all())
+
+
 def test_generic_bf16_ops_vs_fp64_on_rounded_inputs():
     """aggregate (fused filter / given phi) fwd + bwd, GEMM fwd, weight gradient, BatchNorm train fwd/bwd, relu, column sums"""
     from dgnn_amd import ops

@@ -528,7 +528,9 @@ def test_library_adam_takes_over_a_torch_adam_state_mid_run():
     with torch.no_grad():
         for a, b in zip(pa, pb):
             a.copy_(b)
-    oa.load_state_dict(ob.state_dict())         # ... and now takes over torch's state: step tensors, torch's moment buffers
+    import copy
+    oa.load_state_dict(copy.deepcopy(ob.state_dict()))     # ... and now takes over torch's state as a checkpoint holds it: `step` tensors, torch's moment layout
+    # (a deep copy, as torch.save / torch.load make one: Optimizer.load_state_dict itself keeps the tensors it is handed)
     assert all(isinstance(oa.state[p]["step"], int) and oa.state[p]["step"] == 3 for p in pa)
     for _ in range(4):
         grads()
