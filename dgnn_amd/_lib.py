@@ -87,6 +87,7 @@ SIGNATURES = {
     "dgnn_khop_blocks_regular_wait": (i32, [vp, i32, vp]),
     "dgnn_decoder_fused_fwd": (i32, [vp, i64, i64, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, i64, vp]),
     "dgnn_cast_f32_to_bf16": (i32, [vp, i64, i64, i32, i32, vp, i64, vp]),
+    "dgnn_rows_unsigned_to_bf16": (i32, [vp, i64, i64, i32, vp, i64, vp]),
     "dgnn_cast_bf16_to_f32": (i32, [vp, i64, i64, i32, vp, i64, vp]),
     "dgnn_sage_layer_fused_fwd_bf16": (i32, [vp, vp, vp, i64, vp, i32, vp, i64, i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i64, i32, vp]),
     "dgnn_sage_layer_fused_decoder_fwd_bf16": (i32, [vp, vp, vp, i64, vp, vp, i64, i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i32,

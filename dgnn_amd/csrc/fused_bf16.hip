@@ -47,7 +47,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // 29 % of the launch's LDS cycles (profiles/r03g_bf16.md).  Here the two k-groups a lane group mixes (tq, tq ^ 1) sit 16 slots (= 256 B, one
 // bank row) apart, so the 16 lanes of a group fall on 16 different slots; the writers (8-lane groups of ds_write_b128, banks modulo 128 B) still
 // store contiguous 128-byte runs.  k-group kg of k-step S holds channel block jb = 8 * (kg & 1) + 4 * (kg >> 1) + S (weights are loaded to match).
-__host__ __device__ constexpr int d16_slot(int p, int jb) { return (p == 0 ? 0 : (p == 1 ? 8 : 32)) + 16 * (jb >> 3) + (jb & 7); }
+__host__ __device__ constexpr int d16_slot(int p, int jb) { return (p & 1) * 8 + (p >> 1) * 32 + 16 * (jb >> 3) + (jb & 7); }   // p = 3: the own row's lo part (UB rows)
 __host__ __device__ constexpr int d16_block(int S, int kg) { return 8 * (kg & 1) + 4 * (kg >> 1) + S; }
 
 struct DecB {      // the decoder behind the last conv layer (DEC instantiation); all NULL otherwise
@@ -55,9 +55,15 @@ struct DecB {      // the decoder behind the last conv layer (DEC instantiation)
     float* logits;
 };
 
-template <int CIN_PAD, int COUT, int NW = 4, int PR = 0, int XF = 0, bool DEC = false>
+// UB (round 4): rows of a layer that ends in a ReLU are never negative, so their sign bit carries nothing: UNSIGNED rows keep the fp32 bits
+// [30:15] -- bf16's 8 exponent bits and EIGHT explicit mantissa bits (9 significant bits) in the same two bytes; the rounding that storage costs
+// halves (2^-10 of the value instead of 2^-9).  Measured on the 1M-tet metric graph with all three stored layers unsigned: max |dlogit| 5.9e-2 ->
+// 2.1e-2, rms 4.1e-3 -> 2.1e-3 -- SURVEY 8c's flat 5e-2 then holds for every logit.  UB bit 0: the INPUT rows are unsigned (gathered rows
+// decode with one more shift; the own row enters the matrix cores as a (hi, lo) bf16 pair like an fp32 row), bit 1: the OUTPUT rows are.
+template <int CIN_PAD, int COUT, int NW = 4, int PR = 0, int XF = 0, bool DEC = false, int UB = 0>
 struct CfgB {
-    static constexpr int XPARTS = (PR && XF) ? 2 : 1;     // own-row parts in the A-tile
+    static constexpr bool UBI = (UB & 1) != 0, UBO = (UB & 2) != 0;
+    static constexpr int XPARTS = (PR && (XF || UBI)) ? 2 : 1;     // own-row parts in the A-tile
     static constexpr int APARTS = PR ? 2 : 1;             // mean parts
     static constexpr int K = (APARTS + XPARTS) * CIN_PAD; // A-tile row: [a_hi | a_lo | x_hi | x_lo] ... [a | x_i]
     // NW == 4: four waves, each a 32-column slice of v_mfma_f32_32x32x16_bf16 blocks.  NW == 8: eight waves, each a 16-column slice
@@ -67,7 +73,7 @@ struct CfgB {
     static constexpr int NSLICE = COUT / (D16 ? 16 : 32);
     static constexpr int RG = NW / NSLICE;
     static constexpr int TILE = 32 * RG;
-    static constexpr int ROWB = D16 ? 57 * 16 : K * 2 + 16;   // A-tile row: K bf16 + 16 B pad (odd number of 16-B slots); D16: 57 slots, see d16_slot
+    static constexpr int ROWB = D16 ? (UBI ? 65 : 57) * 16 : K * 2 + 16;   // A-tile row: K bf16 + 16 B pad (odd number of 16-B slots); D16: see d16_slot
     static constexpr int A_BYTES = TILE * ROWB;
     static constexpr int TPW = TILE / NW;                 // tets per wave (8 or 16)
     static constexpr int RB = TPW / 4;                    // 16-edge row blocks per wave
@@ -85,6 +91,8 @@ struct CfgB {
     static_assert(RG >= 1 && NQ <= 64 && EA_BYTES % 256 == 0 && !(XF && NW == 8), "wave roles");
     static_assert(!D16 || (PR == 1 && XF == 0 && CIN_PAD == 128 && COUT == 128), "the eight-wave form is the compensated 128 -> 128 layer");
     static_assert(!DEC || D16, "the decoder rides in the eight-wave form only");
+    static_assert(UB == 0 || PR == 1, "unsigned rows belong to the compensated arithmetic");
+    static_assert(!(XF && UBI) && !(DEC && UBO), "fp32 input rows are not unsigned rows; the decoder-carrying launch stores logits");
 };
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
@@ -94,6 +102,14 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
 __device__ __forceinline__ float bf16_round(float v) { return bf_lo(pack_bf16(v, 0.f)); }
+// unsigned rows (UB): value = bits << 15; two values per dword, round to nearest even on bit 15 of the fp32 pattern (the sign is cleared: -0 -> +0)
+__device__ __forceinline__ float ub_lo(uint32_t u) { return __builtin_bit_cast(float, (u & 0xFFFFu) << 15); }
+__device__ __forceinline__ float ub_hi(uint32_t u) { return __builtin_bit_cast(float, (u >> 1) & 0x7FFF8000u); }
+__device__ __forceinline__ uint32_t ub_enc(float v) {
+    const uint32_t b = __builtin_bit_cast(uint32_t, v) & 0x7FFFFFFFu;
+    return (b + 0x3FFFu + ((b >> 15) & 1u)) >> 15;
+}
+__device__ __forceinline__ uint32_t pack_ub(float a, float b) { return ub_enc(a) | (ub_enc(b) << 16); }
 // (x0, x1) -> packed hi pair and packed lo pair: x = hi + lo + O(2^-17 |x|), both parts bf16
 __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
     hi = pack_bf16(x0, x1);
@@ -114,14 +130,15 @@ __device__ __forceinline__ void ld_bf(uint32_t (&v)[NB / 2], const uint16_t* p) 
     }
 }
 
-template <int CIN_PAD, int COUT, int NW, int OCC, int PR, int XF, bool DEC = false>
+template <int CIN_PAD, int COUT, int NW, int OCC, int PR, int XF, bool DEC = false, int UB = 0>
 __global__ void __launch_bounds__(64 * NW, OCC)
 k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid, int64_t n_dst,
                   const void* __restrict__ x_, const void* __restrict__ xdst_, int64_t ldx, int c_in, const float* __restrict__ ea,
                   int64_t lde, const float* __restrict__ We, const float* __restrict__ be, const float* __restrict__ Wj,
                   const float* __restrict__ bj, const float* __restrict__ Wi, const float* __restrict__ scale,
                   const float* __restrict__ shift, int relu, uint16_t* __restrict__ out, int64_t ldo, int64_t ntiles, DecB dec) {
-    using C = CfgB<CIN_PAD, COUT, NW, PR, XF, DEC>;
+    using C = CfgB<CIN_PAD, COUT, NW, PR, XF, DEC, UB>;
+    constexpr bool UBI = C::UBI, UBO = C::UBO;
     constexpr int ROWB = C::ROWB, TILE = C::TILE, TPW = C::TPW, RB = C::RB, NB = C::NB, NS = C::NS, NH = NB / 2;
     constexpr int NX = XF ? NB : NH;                                 // dwords per lane and row: NB floats or NB/2 bf16 pairs
     constexpr int XOFF = C::APARTS * CIN_PAD * 2;                    // byte offset of the own-row part(s) in an A-tile row
@@ -144,6 +161,7 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     };
     auto chan = [&](const uint32_t (&v)[NX], int cb) -> float {    // channel cb of a fragment as fp32
         if constexpr (XF) return __builtin_bit_cast(float, v[cb]);
+        else if constexpr (UBI) return (cb & 1) ? ub_hi(v[cb >> 1]) : ub_lo(v[cb >> 1]);
         else return (cb & 1) ? bf_hi(v[cb >> 1]) : bf_lo(v[cb >> 1]);
     };
     (void)x; (void)xdst; (void)xf; (void)xdstf;
@@ -322,31 +340,31 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
         else *reinterpret_cast<uint32_t*>(d) = v[0];
     };
     auto put_seg = [&](int buf, int row, const uint32_t (&av)[NH], const uint32_t (&al)[NH], const uint32_t (&xv)[NX]) {
-        if constexpr (C::D16) {     // conflict-free slots for the dense phase's ds_read_b128 lane groups (d16_slot)
-            char* rowp = abuf + buf * C::A_BYTES + row * ROWB;
-            put16(rowp + (16 * (jcol >> 3) + (jcol & 7)) * 16, av);
-            put16(rowp + (8 + 16 * (jcol >> 3) + (jcol & 7)) * 16, al);
-            uint32_t t[NH];
+        // own row as the matrix cores take it: bf16 rows are copied as they are; fp32 rows (XF) and unsigned rows (UB) become a (hi, lo) bf16 pair
+        uint32_t xh[NH], xl[NH];
+        if constexpr (XF) {
 #pragma unroll
-            for (int q = 0; q < NH; ++q) t[q] = xv[q];
-            put16(rowp + (32 + 16 * (jcol >> 3) + (jcol & 7)) * 16, t);
+            for (int q = 0; q < NH; ++q) split2(__builtin_bit_cast(float, xv[2 * q]), __builtin_bit_cast(float, xv[2 * q + 1]), xh[q], xl[q]);
+        } else if constexpr (UBI) {
+#pragma unroll
+            for (int q = 0; q < NH; ++q) split2(ub_lo(xv[q]), ub_hi(xv[q]), xh[q], xl[q]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NH; ++q) { xh[q] = xv[q]; xl[q] = 0u; }
+        }
+        if constexpr (C::D16) {     // conflict-free slots for the dense phase's ds_read_b128 lane groups (d16_slot)
+            char* rowp = abuf + buf * C::A_BYTES + row * ROWB + (16 * (jcol >> 3) + (jcol & 7)) * 16;
+            put16(rowp, av);
+            put16(rowp + 8 * 16, al);
+            put16(rowp + 32 * 16, xh);
+            if constexpr (C::XPARTS == 2) put16(rowp + 40 * 16, xl);
             return;
         }
         char* dst = abuf + buf * C::A_BYTES + row * ROWB + c0 * 2;
         put16(dst, av);
         if (PR) put16(dst + CIN_PAD * 2, al);
-        if constexpr (XF) {
-            uint32_t xh[NH], xl[NH];
-#pragma unroll
-            for (int q = 0; q < NH; ++q) split2(__builtin_bit_cast(float, xv[2 * q]), __builtin_bit_cast(float, xv[2 * q + 1]), xh[q], xl[q]);
-            put16(dst + XOFF, xh);
-            if (PR) put16(dst + XOFF + CIN_PAD * 2, xl);
-        } else {
-            uint32_t t[NH];
-#pragma unroll
-            for (int q = 0; q < NH; ++q) t[q] = xv[q];
-            put16(dst + XOFF, t);
-        }
+        put16(dst + XOFF, xh);
+        if constexpr (C::XPARTS == 2) put16(dst + XOFF + CIN_PAD * 2, xl);
     };
 
     // ---- DEC: the decoder on a finished tile (reference :180-187 applied at :350-351), one tile behind the layer: tile t's finished rows are parked
@@ -522,7 +540,7 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                     const bf16x8 al = *reinterpret_cast<const bf16x8*>(A + CIN_PAD * 2 + S * 32);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wjh[S], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wjl[S], acc, 0, 0, 0);
-                    if (XF) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(A + XOFF + CIN_PAD * 2 + S * 32), wih[S], acc, 0, 0, 0);
+                    if constexpr (C::XPARTS == 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(A + XOFF + CIN_PAD * 2 + S * 32), wih[S], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xi, wil[S], acc, 0, 0, 0);
                 }
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wjh[S], acc, 0, 0, 0);
@@ -538,7 +556,7 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                 if (has_scale) { v0 = __fmaf_rn(v0, sc, sh); v1 = __fmaf_rn(v1, sc, sh); }
                 if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
                 const float n0 = __shfl_xor(v0, 1), n1 = __shfl_xor(v1, 1);
-                const uint32_t pk = odd ? pack_bf16(n1, v1) : pack_bf16(v0, n0);
+                const uint32_t pk = UBO ? (odd ? pack_ub(n1, v1) : pack_ub(v0, n0)) : (odd ? pack_bf16(n1, v1) : pack_bf16(v0, n0));
                 const int rr = (r & 3) + 8 * (r >> 2) + odd;
                 if (full || row0 + rr < n_dst) *reinterpret_cast<uint32_t*>(o + (int64_t)rr * ldo) = pk;
             }
@@ -558,6 +576,11 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                     const bf16x8 al = *reinterpret_cast<const bf16x8*>(Am + 8 * 16);
                     const bf16x8 xi = *reinterpret_cast<const bf16x8*>(Am + 32 * 16);
                     f32x4_t c = acc2[m];
+                    if constexpr (C::XPARTS == 2) {      // unsigned input rows: the own row's lo part (its ninth significant bit)
+                        const bf16x8 xl = *reinterpret_cast<const bf16x8*>(Am + 40 * 16);
+                        if constexpr (DEC) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wih[S], xl, c, 0, 0, 0);
+                        else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, wih[S], c, 0, 0, 0);
+                    }
                     if constexpr (DEC) {
                         // transposed product (weights as the A operand): the lane ends with ONE tet (jcol + 16 m) and 4 consecutive output
                         // columns cs * 16 + 4 tq + r -- the shape the decoder's operand fragments are cut from; same products, same order
@@ -613,7 +636,7 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
                     if (has_scale) { v0 = __fmaf_rn(v0, sc, sh); v1 = __fmaf_rn(v1, sc, sh); }
                     if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
                     const float n0 = __shfl_xor(v0, 1), n1 = __shfl_xor(v1, 1);
-                    const uint32_t pk = odd ? pack_bf16(n1, v1) : pack_bf16(v0, n0);
+                    const uint32_t pk = UBO ? (odd ? pack_ub(n1, v1) : pack_ub(v0, n0)) : (odd ? pack_bf16(n1, v1) : pack_bf16(v0, n0));
                     const int rr = m * 16 + 4 * tq + r + odd;
                     if (full || tile * TILE + rg * 32 + rr < n_dst) *reinterpret_cast<uint32_t*>(o + (int64_t)rr * ldo) = pk;
                 }
@@ -632,20 +655,20 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     }
 }
 
-template <int CIN_PAD, int COUT, int OCC, int PR, int NW = 4, int XF = 0, bool DEC = false>
+template <int CIN_PAD, int COUT, int OCC, int PR, int NW = 4, int XF = 0, bool DEC = false, int UB = 0>
 int launch_b(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const void* x, const void* xdst, int64_t ldx,
              int c_in, const float* ea, int64_t lde, const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
              const float* scale, const float* shift, int relu, uint16_t* out, int64_t ldo, hipStream_t stream, DecB dec = DecB{}) {
-    using C = CfgB<CIN_PAD, COUT, NW, PR, XF, DEC>;
+    using C = CfgB<CIN_PAD, COUT, NW, PR, XF, DEC, UB>;
     const int64_t ntiles = dgnn_cdiv(n_dst, C::TILE);
     const size_t smem = C::SMEM_BYTES;
     static bool attr_set[DGNN_MAX_DEVICES] = {};
-    dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_bf16<CIN_PAD, COUT, NW, OCC, PR, XF, DEC>), smem, attr_set);
+    dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_bf16<CIN_PAD, COUT, NW, OCC, PR, XF, DEC, UB>), smem, attr_set);
     const int per_cu = (int)(160 * 1024 / smem) < OCC ? (int)(160 * 1024 / smem) : OCC;
     const int wg_max = DGNN_NUM_CU * (per_cu < 1 ? 1 : per_cu);
     int grid = (int)(ntiles < wg_max ? ntiles : wg_max);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((k_sage_fused_bf16<CIN_PAD, COUT, NW, OCC, PR, XF, DEC>), dim3(grid), dim3(64 * NW), smem, stream, rowptr, src, eid, n_dst, x, xdst,
+    hipLaunchKernelGGL((k_sage_fused_bf16<CIN_PAD, COUT, NW, OCC, PR, XF, DEC, UB>), dim3(grid), dim3(64 * NW), smem, stream, rowptr, src, eid, n_dst, x, xdst,
                        ldx, c_in, ea, lde, We, be, Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles, dec);
     return dgnn_check_launch(DEC ? "sage_layer_fused_decoder_fwd_bf16" : "sage_layer_fused_fwd_bf16");
 }
@@ -659,6 +682,17 @@ __global__ void k_cast_f32_bf16(const float* __restrict__ in, int64_t ld_in, int
         const int c = (int)(t - r * (cols_pad / 2)) * 2;
         const float a = c < cols ? in[r * ld_in + c] : 0.f, b = c + 1 < cols ? in[r * ld_in + c + 1] : 0.f;
         *reinterpret_cast<uint32_t*>(out + r * ld_out + c) = pack_bf16(a, b);
+    }
+}
+
+// unsigned rows (value = bits << 15) -> plain bf16 (round to nearest even): for consumers outside the fused layers
+__global__ void k_rows_unsigned_bf16(const uint16_t* __restrict__ in, int64_t ld_in, int64_t n, int cols, uint16_t* __restrict__ out, int64_t ld_out) {
+    const int64_t total = n * (cols / 2);
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / (cols / 2);
+        const int c = (int)(t - r * (cols / 2)) * 2;
+        const uint32_t u = *reinterpret_cast<const uint32_t*>(in + r * ld_in + c);
+        *reinterpret_cast<uint32_t*>(out + r * ld_out + c) = pack_bf16(ub_lo(u), ub_hi(u));
     }
 }
 
@@ -795,6 +829,14 @@ extern "C" int dgnn_cast_f32_to_bf16(const float* in, int64_t ld_in, int64_t n, 
     return dgnn_check_launch("cast_f32_to_bf16");
 }
 
+extern "C" int dgnn_rows_unsigned_to_bf16(const uint16_t* in, int64_t ld_in, int64_t n, int cols, uint16_t* out, int64_t ld_out, void* stream) {
+    DGNN_REQUIRE(n >= 0 && cols >= 0 && cols % 2 == 0 && ld_in % 2 == 0 && ld_out % 2 == 0, DGNN_E_INVALID, "rows_unsigned_to_bf16: bad sizes (even widths / strides)");
+    if (n == 0 || cols == 0) return DGNN_OK;
+    DGNN_REQUIRE(in && out && (((uintptr_t)in | (uintptr_t)out) % 4) == 0, DGNN_E_INVALID, "rows_unsigned_to_bf16: null / unaligned pointer");
+    hipLaunchKernelGGL(k_rows_unsigned_bf16, dim3(dgnn_grid_cap(dgnn_cdiv(n * (cols / 2), 256))), dim3(256), 0, (hipStream_t)stream, in, ld_in, n, cols, out, ld_out);
+    return dgnn_check_launch("rows_unsigned_to_bf16");
+}
+
 extern "C" int dgnn_cast_bf16_to_f32(const uint16_t* in, int64_t ld_in, int64_t n, int cols, float* out, int64_t ld_out, void* stream) {
     DGNN_REQUIRE(n >= 0 && cols >= 0, DGNN_E_INVALID, "cast_bf16_to_f32: bad sizes");
     if (n == 0 || cols == 0) return DGNN_OK;
@@ -829,9 +871,20 @@ extern "C" int dgnn_sage_layer_fused_fwd_bf16(const int32_t* rowptr, const int32
     DGNN_REQUIRE(!x_f32 || (cin_pad == 32 && (((uintptr_t)x_src | (uintptr_t)x_dst) % 4) == 0), DGNN_E_UNSUPPORTED,
                  "sage_layer_fused_fwd_bf16: fp32 input rows are supported for c_in <= 32 (the first layer)");
     DGNN_REQUIRE(ldo % 2 == 0 && ((uintptr_t)out % 4) == 0, DGNN_E_UNSUPPORTED, "sage_layer_fused_fwd_bf16: out rows must be 4-byte aligned");
+    const bool ub_in = (mode & DGNN_BF16_ROWS_IN_UNSIGNED) != 0, ub_out = (mode & DGNN_BF16_ROWS_OUT_UNSIGNED) != 0;
+    mode &= ~(DGNN_BF16_ROWS_IN_UNSIGNED | DGNN_BF16_ROWS_OUT_UNSIGNED);
     DGNN_REQUIRE(mode == DGNN_BF16_SINGLE || mode == DGNN_BF16_COMPENSATED, DGNN_E_INVALID, "sage_layer_fused_fwd_bf16: bad mode %d", mode);
+    // unsigned rows: compensated arithmetic; the output format needs the ReLU (values >= 0); a layer either keeps the format (in and out) or, reading
+    // fp32 rows, starts it
+    DGNN_REQUIRE(!(ub_in || ub_out) || mode == DGNN_BF16_COMPENSATED, DGNN_E_UNSUPPORTED, "sage_layer_fused_fwd_bf16: unsigned rows need the compensated mode");
+    DGNN_REQUIRE(!ub_out || relu, DGNN_E_INVALID, "sage_layer_fused_fwd_bf16: unsigned output rows need relu (values >= 0)");
+    DGNN_REQUIRE(x_f32 ? !ub_in : ub_in == ub_out, DGNN_E_UNSUPPORTED, "sage_layer_fused_fwd_bf16: a layer on bf16 rows keeps the row format (in == out)");
+    const bool ub = ub_out;
 #define GOB(CP, CO, OCC)                                                                                                                  \
     do {                                                                                                                                  \
+        if (ub)                                                                                                                           \
+            return launch_b<CP, CO, OCC, 1, 4, 0, false, 3>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, \
+                                                            scale, shift, relu, out, ldo, stream);                                        \
         if (mode == DGNN_BF16_COMPENSATED)                                                                                                \
             return launch_b<CP, CO, OCC, 1>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale,  \
                                             shift, relu, out, ldo, stream);                                                               \
@@ -840,16 +893,20 @@ extern "C" int dgnn_sage_layer_fused_fwd_bf16(const int32_t* rowptr, const int32
     } while (0)
     if (x_f32) {
         const bool pr = mode == DGNN_BF16_COMPENSATED;
-#define GOX(CO, PRV) return launch_b<32, CO, 2, PRV, 4, 1>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, \
-                                                          scale, shift, relu, out, ldo, stream)
-        if (c_out == 64) { if (pr) GOX(64, 1); else GOX(64, 0); }
-        if (pr) GOX(128, 1); else GOX(128, 0);
+#define GOX(CO, PRV, UBV) return launch_b<32, CO, 2, PRV, 4, 1, false, UBV>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, \
+                                                                          scale, shift, relu, out, ldo, stream)
+        if (c_out == 64) { if (ub) GOX(64, 1, 2); if (pr) GOX(64, 1, 0); else GOX(64, 0, 0); }
+        if (ub) GOX(128, 1, 2);
+        if (pr) GOX(128, 1, 0); else GOX(128, 0, 0);
 #undef GOX
     }
     if (cin_pad == 32) { if (c_out == 64) GOB(32, 64, 2); else GOB(32, 128, 2); }
     if (cin_pad == 64) { if (c_out == 64) GOB(64, 64, 2); else GOB(64, 128, 2); }
     if (c_out == 64) GOB(128, 64, 2);
     // 128 -> 128: the compensated form keeps four weight parts resident -> eight-wave workgroups with 16-column slices
+    if (ub)
+        return launch_b<128, 128, 1, 1, 8, 0, false, 3>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, shift, relu,
+                                                        out, ldo, stream);
     if (mode == DGNN_BF16_COMPENSATED)
         return launch_b<128, 128, 1, 1, 8>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, shift, relu,
                                            out, ldo, stream);
@@ -872,10 +929,15 @@ extern "C" int dgnn_sage_layer_fused_decoder_fwd_bf16(const int32_t* rowptr, con
     DGNN_REQUIRE((scale == nullptr) == (shift == nullptr) && (scale1 == nullptr) == (shift1 == nullptr), DGNN_E_INVALID,
                  "sage_layer_fused_decoder_fwd_bf16: scale/shift must come together");
     if (x_dst == nullptr) x_dst = x_src;
+    const bool ub_in = (mode & DGNN_BF16_ROWS_IN_UNSIGNED) != 0;
+    mode &= ~DGNN_BF16_ROWS_IN_UNSIGNED;
     const bool ok = mode == DGNN_BF16_COMPENSATED && c_out == 128 && c_in > 64 && c_in <= 128 && c_in % 8 == 0 && f_e == FE && lde == FE && c_hidden == 64 &&
                     n_logits == 2 && ((uintptr_t)edge_attr % 16) == 0 && ldx % 8 == 0 && (((uintptr_t)x_src | (uintptr_t)x_dst) % 16) == 0 &&
                     ((uintptr_t)logits % 8) == 0 && n_dst * ldx < ((int64_t)1 << 31);
     if (!ok) return DGNN_E_UNSUPPORTED;     // the caller runs dgnn_sage_layer_fused_fwd_bf16 and dgnn_decoder_fused_fwd_bf16
+    if (ub_in)
+        return launch_b<128, 128, 1, 1, 8, 0, true, 1>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, shift, relu, nullptr,
+                                                       0, (hipStream_t)stream_, DecB{W0, b0, scale1, shift1, W3, b3, logits});
     return launch_b<128, 128, 1, 1, 8, 0, true>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, shift, relu, nullptr, 0,
                                                 (hipStream_t)stream_, DecB{W0, b0, scale1, shift1, W3, b3, logits});
 }

@@ -150,6 +150,22 @@ class SurfaceNet(nn.Module):
         self.storage_dtype = dtype
         return self
 
+    def activation_dtype(self, i, input_dtype=torch.float32):
+        """dtype of the rows conv layer i leaves in HBM in eval mode: the storage type -- or, in bf16 storage (compensated arithmetic), ops.UROWS
+        (torch.int16: UNSIGNED rows, half of bf16's storage rounding in the same bytes, ops.py) while the chain of fused layers that starts on the
+        caller's fp32 feature rows is unbroken.  Callers that allocate a layer's output themselves (the partitioned forward) ask here."""
+        if self.storage_dtype != torch.bfloat16:
+            return self.storage_dtype
+        if not (ops.BF16_UNSIGNED_ROWS and ops.BF16_MODE == ops.BF16_COMPENSATED and ops.FUSED_ENABLED) or input_dtype != torch.float32:
+            return torch.bfloat16
+        for j in range(i + 1):
+            conv = self.convs[j][0]
+            le = conv.lin_e
+            fused = isinstance(le, Linear) and le.in_features == 20 and ops.fused_layer_supported_bf16(conv.lin_j.in_features, conv.lin_j.out_features, 20)
+            if not fused or (j == 0 and conv.lin_j.in_features > 32) or not isinstance(self.convs[j][2], nn.ReLU):
+                return torch.bfloat16
+        return ops.UROWS
+
     def dominant_kernel_name(self, shape):
         return "k_sage_fused_bf16<%d,%d>" % (32 if shape[0] <= 32 else (64 if shape[0] <= 64 else 128), shape[1])
 
@@ -440,11 +456,16 @@ class SurfaceNet(nn.Module):
         x_dst = x[b:e]
         out_v = out if (out is None or rows is None) else out[b:e]
         simple = isinstance(le, Linear) and le.in_features in (2, 20)
-        if x.dtype == torch.bfloat16 or (self.storage_dtype == torch.bfloat16 and simple and le.in_features == 20
-                                         and ops.fused_layer_supported_bf16(conv.lin_j.in_features, conv.lin_j.out_features, 20, x)):
+        if x.dtype in (torch.bfloat16, ops.UROWS) or (self.storage_dtype == torch.bfloat16 and simple and le.in_features == 20
+                                                      and ops.fused_layer_supported_bf16(conv.lin_j.in_features, conv.lin_j.out_features, 20, x)):
             c_in = conv.lin_j.in_features    # the logical width: bf16 rows may carry zero padding columns
             if not (simple and le.in_features == 20 and ops.fused_layer_supported_bf16(c_in, conv.lin_j.out_features, 20, x)):
                 return self._eval_layer_bf16_unfused(conv, scale, shift, x, xe, plan, sorted_attr, out_v, rows)
+            # row format of the output (ops.UROWS): a fused layer on fp32 feature rows starts the unsigned format, one on 16-bit rows keeps its input's;
+            # a caller-supplied buffer names the format by its dtype
+            uns = (ops.BF16_UNSIGNED_ROWS and ops.BF16_MODE == ops.BF16_COMPENSATED and x.dtype != torch.bfloat16) if out_v is None else out_v.dtype == ops.UROWS
+            if x.dtype != torch.float32 and uns != (x.dtype == ops.UROWS):
+                raise ops.DgnnError("bf16 storage: layer %d reads %s rows but is asked to write %s rows" % (i, x.dtype, out_v.dtype))
             if sorted_attr and ops.EDGE_GATHER_IN_KERNEL and xe.stride(0) == 20 and xe.data_ptr() % 16 == 0:
                 ea, eid = xe, plan.eid
             else:
@@ -458,7 +479,8 @@ class SurfaceNet(nn.Module):
                                                              conv.lin_i.weight, scale, shift, True, dec[0].weight, dec[0].bias, s1, h1, dec[3].weight,
                                                              dec[3].bias, out=out_v, eid=eid, x_dst=x_dst if b else None)
             return ops.sage_layer_fused_fwd_bf16(rowptr, plan.src, n, x, c_in, ea, le.weight, le.bias, conv.lin_j.weight, conv.lin_j.bias,
-                                                 conv.lin_i.weight, scale, shift, True, out=out_v, eid=eid, x_dst=x_dst if b else None)
+                                                 conv.lin_i.weight, scale, shift, True, out=out_v, eid=eid, x_dst=x_dst if b else None,
+                                                 rows_out_unsigned=uns)
         if simple and le.in_features == 20 and ops.fused_layer_supported(x.size(1), conv.lin_j.out_features, 20, x):
             # sorted_attr: xe is in the caller's edge order.  Either the kernel gathers each row by eid (no staging
             # copy of the edge features), or the rows are staged into plan order once and reused by all layers.
@@ -518,6 +540,8 @@ class SurfaceNet(nn.Module):
             raise NotImplementedError("destination sub-ranges in bf16 storage need a fused-kernel width")
         le = conv.lin_e
         c_in = conv.lin_j.in_features
+        if x.dtype == ops.UROWS:      # unsigned rows of a fused layer: the generic kernels take plain bf16
+            x = ops.rows_unsigned_to_bf16(x)
         xs = x[:, :c_in] if x.size(1) != c_in else x
         if isinstance(le, Linear) and le.in_features in (2, 20):
             ea = plan.sorted_edge_attr(xe) if sorted_attr else xe
@@ -529,6 +553,8 @@ class SurfaceNet(nn.Module):
 
     def _eval_decoder(self, x):
         dec = self.decoder
+        if x.dtype == ops.UROWS:          # (a last layer that did not carry the decoder left unsigned rows)
+            x = ops.rows_unsigned_to_bf16(x)
         if not self.clf.model.decoder or len(dec) == 0:
             return x.float() if x.dtype == torch.bfloat16 else x
         if len(dec) == 1:

@@ -87,10 +87,10 @@ def plan_build(edge_index: torch.Tensor, n_key: int, by: int, hint: int = PLAN_H
 @on_device_of
 def gather_rows(src: torch.Tensor, idx: torch.Tensor, cols: int = None) -> torch.Tensor:
     """out = src[idx, :cols] (cols None: all columns); only the requested columns are read"""
-    if src.dtype == torch.bfloat16:   # rows of bf16 pairs move as fp32 words (bit copies)
+    if src.dtype in (torch.bfloat16, torch.int16):   # rows of 16-bit pairs (bf16, or unsigned rows in their int16 container) move as fp32 words (bit copies)
         if not src.is_contiguous() or src.size(1) % 2 or (cols is not None and cols % 2):
-            raise ValueError("bf16 gather_rows needs contiguous rows of even width")
-        return gather_rows(src.view(torch.float32), idx, None if cols is None else cols // 2).view(torch.bfloat16)
+            raise ValueError("16-bit gather_rows needs contiguous rows of even width")
+        return gather_rows(src.view(torch.float32), idx, None if cols is None else cols // 2).view(src.dtype)
     _req(src, "src", dim=2)
     _req(idx, "idx", torch.int32, 1)
     cols = src.size(1) if cols is None else int(cols)
@@ -104,9 +104,9 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor, cols: int = None) -> torch
 
 @on_device_of
 def scatter_rows_(out: torch.Tensor, idx: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
-    if src.dtype == torch.bfloat16:   # bit copies of bf16 pairs as fp32 words
-        if not (src.is_contiguous() and out.is_contiguous()) or src.size(1) % 2 or out.dtype != torch.bfloat16:
-            raise ValueError("bf16 scatter_rows_ needs contiguous bf16 rows of even width")
+    if src.dtype in (torch.bfloat16, torch.int16):   # bit copies of 16-bit pairs as fp32 words
+        if not (src.is_contiguous() and out.is_contiguous()) or src.size(1) % 2 or out.dtype != src.dtype:
+            raise ValueError("16-bit scatter_rows_ needs contiguous rows of even width and one row format")
         scatter_rows_(out.view(torch.float32), idx, src.view(torch.float32))
         return out
     _req(src, "src", dim=2)
@@ -587,6 +587,13 @@ def decoder_fused_fwd(y, W0, b0, scale, shift, W3, b3):
 
 # ---- bf16 storage path (BASELINE config 3) ----------------------------------------------------------------------------------
 BF16 = torch.bfloat16
+# UNSIGNED rows (round 4; include/dgnn_hip.h DGNN_BF16_ROWS_*_UNSIGNED): rows written behind a ReLU keep the fp32 bits [30:15] -- 8 exponent + 8 mantissa
+# bits, no sign -- in their 16 bits: half the storage rounding of bf16 in the same bytes.  Such rows travel in torch.int16 tensors (the dtype IS the
+# format: it survives slicing, cat and the halo exchange), written and read by the fused bf16-storage layers only; rows_unsigned_to_bf16 converts for
+# every other consumer.  DGNN_BF16_UNSIGNED_ROWS=0: plain bf16 rows everywhere (rounds 2-3).
+UROWS = torch.int16
+BF16_UNSIGNED_ROWS = __import__("os").environ.get("DGNN_BF16_UNSIGNED_ROWS", "1") != "0"
+BF16_ROWS_IN_UNSIGNED, BF16_ROWS_OUT_UNSIGNED = 16, 32
 BF16_SINGLE, BF16_COMPENSATED = 0, 1
 # how the fused bf16-storage kernels feed the matrix cores: "single" = every operand rounded to bf16 once; "compensated"
 # (default) = only the stored activations are bf16, the fp32 mean / attributes / parameters go in as (hi, lo) bf16 pairs
@@ -606,7 +613,18 @@ def cast_to_bf16(x: torch.Tensor, cols_pad: int = None) -> torch.Tensor:
 
 
 @on_device_of
+def rows_unsigned_to_bf16(x: torch.Tensor) -> torch.Tensor:
+    """unsigned rows (int16 container) -> plain bf16 rows, round to nearest even"""
+    _req(x, "x", UROWS, dim=2)
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    check(lib().dgnn_rows_unsigned_to_bf16(ptr(x), _ld(x), x.size(0), x.size(1), ptr(out), x.size(1), stream_ptr()), "dgnn_rows_unsigned_to_bf16")
+    return out
+
+
+@on_device_of
 def cast_to_f32(x: torch.Tensor) -> torch.Tensor:
+    if x.dtype == UROWS:
+        x = rows_unsigned_to_bf16(x)
     _req(x, "x", BF16, dim=2)
     out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     check(lib().dgnn_cast_bf16_to_f32(ptr(x), _ld(x), x.size(0), x.size(1), ptr(out), x.size(1), stream_ptr()), "dgnn_cast_bf16_to_f32")
@@ -629,23 +647,24 @@ def fused_layer_supported_bf16(c_in: int, c_out: int, f_e: int, x: torch.Tensor 
 
 @on_device_of
 def sage_layer_fused_fwd_bf16(rowptr, src, n_dst, x_src, c_in, edge_attr, We, be, Wj, bj, Wi, scale, shift, relu, out=None, eid=None,
-                              x_dst=None):
+                              x_dst=None, rows_out_unsigned=False):
     """bf16-storage twin of sage_layer_fused_fwd.  `x_src` bf16 [n_src, ld >= c_in] (padding columns allowed: `c_in` is the
     logical width = Wj.shape[1]) -- or, for the first layer (c_in <= 32), the caller's fp32 rows read in place; returns bf16
     [n_dst, c_out]."""
-    _req(x_src, "x_src", ACT, dim=2)
+    _req(x_src, "x_src", ACT + (UROWS,), dim=2)
     _same(x_dst, x_src, "x_dst")
     c_out = Wj.size(0)
     if out is None:
-        out = torch.empty((n_dst, c_out), dtype=BF16, device=x_src.device)
+        out = torch.empty((n_dst, c_out), dtype=UROWS if rows_out_unsigned else BF16, device=x_src.device)
     else:
-        _req(out, "out", BF16, dim=2)
+        _req(out, "out", (BF16, UROWS), dim=2)      # the buffer's dtype names the row format it receives
         if out.size(0) < n_dst or out.size(1) != c_out or out.stride(0) != c_out:
             raise ValueError("out must be a contiguous [>= n_dst, c_out] buffer")
+    fmt = (BF16_ROWS_IN_UNSIGNED if x_src.dtype == UROWS else 0) | (BF16_ROWS_OUT_UNSIGNED if out.dtype == UROWS else 0)
     check(lib().dgnn_sage_layer_fused_fwd_bf16(
         ptr(rowptr), ptr(src), ptr(eid), n_dst, ptr(x_src), int(x_src.dtype == torch.float32), ptr(x_dst), _ld(x_src), c_in, ptr(edge_attr),
         _ld(edge_attr), We.size(1),
-        ptr(We), ptr(be), ptr(Wj), ptr(bj), ptr(Wi), ptr(scale), ptr(shift), int(bool(relu)), c_out, ptr(out), c_out, BF16_MODE, stream_ptr()),
+        ptr(We), ptr(be), ptr(Wj), ptr(bj), ptr(Wi), ptr(scale), ptr(shift), int(bool(relu)), c_out, ptr(out), c_out, BF16_MODE | fmt, stream_ptr()),
         "dgnn_sage_layer_fused_fwd_bf16")
     return out
 
@@ -655,7 +674,7 @@ def fused_layer_decoder_supported_bf16(c_in: int, c_out: int, f_e: int, hidden: 
     ok = (FUSE_DECODER and FUSED_ENABLED and BF16_MODE == BF16_COMPENSATED and 64 < c_in <= 128 and c_in % 8 == 0 and c_out == 128 and f_e == 20
           and hidden == 64 and n_out == 2)
     if ok and x is not None:
-        ok = x.dtype == torch.bfloat16 and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
+        ok = x.dtype in (torch.bfloat16, UROWS) and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
     return ok
 
 
@@ -663,7 +682,7 @@ def fused_layer_decoder_supported_bf16(c_in: int, c_out: int, f_e: int, hidden: 
 def sage_layer_fused_decoder_fwd_bf16(rowptr, src, n_dst, x_src, c_in, edge_attr, We, be, Wj, bj, Wi, scale, shift, relu, W0, b0, scale1, shift1, W3, b3,
                                       out=None, eid=None, x_dst=None):
     """Last conv layer (bf16 storage) + decoder, one launch -> fp32 logits [n_dst, 2]; the layer's output is never rounded to bf16."""
-    _req(x_src, "x_src", BF16, dim=2)
+    _req(x_src, "x_src", (BF16, UROWS), dim=2)
     _same(x_dst, x_src, "x_dst")
     if out is None:
         out = torch.empty((n_dst, 2), dtype=torch.float32, device=x_src.device)
@@ -674,7 +693,8 @@ def sage_layer_fused_decoder_fwd_bf16(rowptr, src, n_dst, x_src, c_in, edge_attr
     check(lib().dgnn_sage_layer_fused_decoder_fwd_bf16(
         ptr(rowptr), ptr(src), ptr(eid), n_dst, ptr(x_src), ptr(x_dst), _ld(x_src), c_in, ptr(edge_attr), _ld(edge_attr), We.size(1), ptr(We), ptr(be),
         ptr(Wj), ptr(bj), ptr(Wi), ptr(scale), ptr(shift), int(bool(relu)), Wj.size(0), ptr(W0.contiguous()), ptr(b0), ptr(scale1), ptr(shift1), W0.size(0),
-        ptr(W3.contiguous()), ptr(b3), W3.size(0), ptr(out), BF16_MODE, stream_ptr()), "dgnn_sage_layer_fused_decoder_fwd_bf16")
+        ptr(W3.contiguous()), ptr(b3), W3.size(0), ptr(out), BF16_MODE | (BF16_ROWS_IN_UNSIGNED if x_src.dtype == UROWS else 0), stream_ptr()),
+        "dgnn_sage_layer_fused_decoder_fwd_bf16")
     return out
 
 

@@ -169,6 +169,8 @@ class HaloExchange:
         """h_full [n_own + n_halo, C] with the rows to send valid: begins filling the halo rows in place."""
         if not self.active:
             return
+        if h_full.dtype == torch.int16:      # unsigned 16-bit rows (dgnn_amd.ops.UROWS): the collective moves them as bf16 bit patterns
+            h_full = h_full.view(torch.bfloat16)
         send = self.pack(h_full, self.send_idx32) if self.pack is not None else h_full.index_select(0, self.send_idx)
         if self.stream is None:
             self._post(h_full, send)
@@ -312,9 +314,15 @@ class PartitionedScene:
         if fuse:
             widths[last] = 2
 
-        def alloc(r, c):      # activations in the model's storage type; the decoder-carrying last launch writes fp32 logits
-            logits = fuse and c == 2 and r == self.n_own
-            return torch.empty((r, c), dtype=torch.float32 if logits else getattr(net, "storage_dtype", torch.float32), device=self.device)
+        act = getattr(net, "activation_dtype", None)
+        n_alloc = [0]
+
+        def alloc(r, c):      # layer i's rows in the format the model stores them in; the decoder-carrying last launch writes fp32 logits
+            i = n_alloc[0]
+            n_alloc[0] += 1
+            logits = fuse and i == last
+            dt = torch.float32 if logits else (act(i, x.dtype) if act is not None else getattr(net, "storage_dtype", torch.float32))
+            return torch.empty((r, c), dtype=dt, device=self.device)
         return run_partitioned_layers(self.lp, x, net.num_layers, layer_fn, (lambda lg: lg) if fuse else net._eval_decoder, self.exchange, alloc,
                                       widths=widths)
 

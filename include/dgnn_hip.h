@@ -530,6 +530,15 @@ int dgnn_decoder_fused_fwd(const float* y, int64_t ldy, int64_t M, int k, const 
 #define DGNN_BF16_SINGLE 0      /* every operand rounded to bf16 once, one MFMA per product */
 #define DGNN_BF16_COMPENSATED 1 /* only what is STORED is bf16: the fp32 mean, attributes and parameters enter the matrix cores as
                                    (hi, lo) bf16 pairs (16 bits; filter 3 products, a.Wj 3, x_i.Wi 2) -- the default */
+/* Row-format flags OR-ed into `mode` of dgnn_sage_layer_fused_fwd_bf16 / dgnn_sage_layer_fused_decoder_fwd_bf16 (round 4, compensated arithmetic only):
+ * UNSIGNED rows.  A row written behind a ReLU has no negative entries, so its 16 bits can hold the fp32 bits [30:15] -- bf16's 8 exponent bits and
+ * EIGHT explicit mantissa bits (9 significant bits; value = bits << 15) -- instead of sign + 7: same bytes, half the storage rounding (2^-10 of a
+ * value).  _OUT: this launch writes such rows (needs relu != 0); _IN: x_src / x_dst are such rows.  A layer on 16-bit rows keeps the format (IN and OUT
+ * together); the first layer, reading fp32 rows, may start it (OUT only); the decoder-carrying launch takes IN.  With the three stored layers of the
+ * shipped model unsigned: max |dlogit| on the 1M-tet graph 5.9e-2 -> 2.1e-2.  dgnn_rows_unsigned_to_bf16 converts to plain bf16. */
+#define DGNN_BF16_ROWS_IN_UNSIGNED 16
+#define DGNN_BF16_ROWS_OUT_UNSIGNED 32
+int dgnn_rows_unsigned_to_bf16(const uint16_t* in, int64_t ld_in, int64_t n, int cols, uint16_t* out, int64_t ld_out, void* stream);
 /* out[r, 0:cols] = bf16(in[r, 0:cols]), out[r, cols:cols_pad] = 0   (cols_pad even, ld_out >= cols_pad, ld_out even) */
 int dgnn_cast_f32_to_bf16(const float* in, int64_t ld_in, int64_t n, int cols, int cols_pad, uint16_t* out, int64_t ld_out, void* stream);
 int dgnn_cast_bf16_to_f32(const uint16_t* in, int64_t ld_in, int64_t n, int cols, float* out, int64_t ld_out, void* stream);

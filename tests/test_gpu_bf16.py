@@ -1,6 +1,13 @@
 """bf16 STORAGE path (BASELINE config 3): activations / edge embeddings bf16 in HBM, products on the bf16
 matrix cores, fp32 accumulation, fp32 parameters.
 
+Round 4: in the default (compensated) arithmetic the last layer's launch carries the decoder (its rows are never stored) and the rows of the other
+layers are stored UNSIGNED (post-ReLU rows have no sign: 9 significant bits in the same 16, ops.UROWS).  On the 1M-tet metric graph SURVEY 8c's
+flat bound then holds for EVERY logit: max |dlogit| 2.1e-2 <= 5e-2 (rms 2.1e-3, arg-max agreement 99.97 %) -- asserted by
+test_inference_layer_bf16_metric_graph_and_ignatius; the whole Ignatius scene (logits up to +-167: 5e-2 absolute would be 3e-4 relative, below what
+any 16-bit row can carry) is held to the relative form below.  With DGNN_BF16_UNSIGNED_ROWS=0 / DGNN_FUSE_DECODER=0 (the round-3 path) and in the
+single-product mode the two-level statement applies:
+
 Stated tolerance on logits against the fp32 reference (SURVEY 8c asks for 5e-2 abs and >= 99.9 % arg-max agreement):
   * |dlogit| <= 5e-2 * max(1, |logit| / 8) for at least 99.99 % of the logits, and <= 1e-1 * max(1, |logit| / 8) for every one
     -- measured on the 1M-tet metric graph (2 M logits) in the default compensated mode: rms 5.7e-3, 99.9th percentile 2.6e-2,
@@ -247,6 +254,79 @@ def test_last_bf16_layer_with_the_decoder_inside_irregular_degrees():
     assert bool(((one.cpu().double() - two.cpu().double()).abs() <= EPS * mag + 1e-3).all())
 
 
+def _ub_decode(t):
+    """unsigned rows (int16 container) -> float64 values: bits << 15"""
+    b = (t.cpu().to(torch.int32) & 0xFFFF) << 15
+    return b.view(torch.float32).double()
+
+
+def _ub_round(t):
+    """fp32 >= 0 -> the value its unsigned 16-bit row keeps (round to nearest even on bit 15)"""
+    b = t.contiguous().view(torch.int32)
+    b = ((b + 0x3FFF + ((b >> 15) & 1)) >> 15) << 15
+    return b.view(torch.float32)
+
+
+@pytest.mark.parametrize("c_in,c_out", [(28, 64), (64, 128), (128, 128), (64, 64), (96, 128)])
+def test_unsigned_rows_fused_layer_vs_fp64(c_in, c_out):
+    """UNSIGNED 16-bit rows (ops.UROWS, round 4): a layer on fp32 feature rows starts the format, a layer on unsigned rows keeps it.  Against fp64 on
+    the inputs as the kernel sees them: the stored result is off by at most HALF of bf16's spacing (2^-10 of the value) + the (hi, lo) operand terms."""
+    from dgnn_amd import ops
+    from dgnn_amd.synthetic import delaunay_tet_graph
+    from oracle.pyg_semantics import propagate_mean
+    if ops.BF16_MODE != ops.BF16_COMPENSATED:
+        pytest.skip("unsigned rows belong to the compensated arithmetic")
+    adj, _, _ = delaunay_tet_graph(900, seed=c_in)
+    n = adj.shape[0] // 4
+    ei = torch.from_numpy(adj.T.astype(np.int64))
+    g = torch.Generator().manual_seed(c_in * 7 + c_out)
+    first = c_in <= 32
+    x = torch.randn(n, c_in, generator=g) if first else torch.relu(torch.randn(n, c_in, generator=g))
+    x[::53] *= 30
+    ea = torch.randn(4 * n, 20, generator=g)
+    We, be = torch.randn(c_in, 20, generator=g) * 0.3, torch.randn(c_in, generator=g)
+    Wj, Wi, bj = torch.randn(c_out, c_in, generator=g) * 0.1, torch.randn(c_out, c_in, generator=g) * 0.1, torch.randn(c_out, generator=g)
+    scale, shift = torch.rand(c_out, generator=g) + 0.5, torch.randn(c_out, generator=g)
+    d = lambda t: t.double()
+    rowptr, src, eid = ops.plan_build(ei.to(DEV), n, 1, n_other=n)
+    if first:
+        xin, xd = x.to(DEV), x.double()                                    # fp32 rows, read in place
+    else:
+        xr = _ub_round(x)
+        xin = ((xr.view(torch.int32) >> 15).to(torch.int16)).to(DEV)       # the rows as a previous layer stores them
+        xd = xr.double()
+        assert torch.equal(_ub_decode(xin), xd)
+        assert torch.equal(ops.rows_unsigned_to_bf16(xin).cpu(), xr.to(BF))  # converter: round to nearest even to plain bf16
+    a = propagate_mean(xd, n, ei, d(ea) @ d(We).t() + d(be))
+    ref = torch.relu((a @ d(Wj).t() + xd @ d(Wi).t() + d(bj)) * d(scale) + d(shift))
+    mag = (a.abs() @ d(Wj).abs().t() + xd.abs() @ d(Wi).abs().t()) * d(scale).abs()
+    dv = lambda *ts: [t.to(DEV) for t in ts]
+    out = ops.sage_layer_fused_fwd_bf16(rowptr, src, n, xin, c_in, ea.to(DEV), *dv(We, be, Wj, bj, Wi, scale, shift), True, eid=eid, rows_out_unsigned=True)
+    assert out.dtype == ops.UROWS and out.shape == (n, c_out)
+    err = (_ub_decode(out) - ref).abs()
+    bound = 0.5 * EPS * ref.abs() + 2.0 ** -14 * mag + 1e-3
+    assert bool((err <= bound).all()), float((err / bound).max())
+    # the same layer writing plain bf16 rows (fp32 input only: a layer on 16-bit rows keeps its input's format) is twice as far out at the worst row
+    if first:
+        plain = ops.sage_layer_fused_fwd_bf16(rowptr, src, n, xin, c_in, ea.to(DEV), *dv(We, be, Wj, bj, Wi, scale, shift), True, eid=eid)
+        assert plain.dtype == BF
+        e_plain = (plain.cpu().double() - ref).abs()
+        assert err.pow(2).mean().sqrt() < 0.7 * e_plain.pow(2).mean().sqrt()
+    else:
+        with pytest.raises(Exception):
+            ops.sage_layer_fused_fwd_bf16(rowptr, src, n, xin, c_in, ea.to(DEV), *dv(We, be, Wj, bj, Wi, scale, shift), True, eid=eid, rows_out_unsigned=False)
+    if c_in > 64 and c_out == 128:      # ... and into the decoder-carrying launch
+        W0, b0 = torch.randn(64, 128, generator=g) * 0.15, torch.randn(64, generator=g)
+        W3, b3 = torch.randn(2, 64, generator=g) * 0.3, torch.randn(2, generator=g)
+        hid = torch.relu(ref @ d(W0).t() + d(b0))
+        lref = hid @ d(W3).t() + d(b3)
+        lmag = (hid.abs() @ d(W3).abs().t()) + (ref.abs() @ d(W0).abs().t()) @ d(W3).abs().t()
+        lg = ops.sage_layer_fused_decoder_fwd_bf16(rowptr, src, n, xin, c_in, ea.to(DEV), *dv(We, be, Wj, bj, Wi, scale, shift), True,
+                                                   *dv(W0, b0), None, None, *dv(W3, b3), eid=eid)
+        e = (lg.cpu().double() - lref).abs()
+        assert bool((e <= 2.0 ** -13 * lmag + 1e-4).all()), float((e / (2.0 ** -13 * lmag + 1e-4)).max())
+
+
 def test_generic_bf16_ops_vs_fp64_on_rounded_inputs():
     """aggregate (fused filter / given phi) fwd + bwd, GEMM fwd, weight gradient, BatchNorm train fwd/bwd, relu, column sums"""
     from dgnn_amd import ops
@@ -371,6 +451,15 @@ def test_inference_layer_bf16_metric_graph_and_ignatius():
     got = _bf16_inference(net, Config(x=s["x"].to(DEV), edge_attr=s["ea"].to(DEV), edge_index=s["ei"].to(DEV)))
     err, agree = bf_check(got, ref, "1M")
     print("bf16 1M graph: max|dlogit| %.3e, arg-max agreement %.5f" % (err, agree))
+    from dgnn_amd import ops
+    if ops.BF16_MODE == ops.BF16_COMPENSATED and ops.BF16_UNSIGNED_ROWS and ops.FUSE_DECODER:
+        # SURVEY 8c as written: <= 5e-2 absolute for EVERY one of the 2 M logits, >= 99.9 % arg-max agreement (measured 2.1e-2 / 99.97 %)
+        assert err <= 5e-2 and agree >= 0.999, (err, agree)
+        net.set_storage_dtype(BF)
+        try:
+            assert net.activation_dtype(0) == ops.UROWS and net.activation_dtype(2) == ops.UROWS and net.fuses_decoder(3)
+        finally:
+            net.set_storage_dtype(torch.float32)
     g = gold("static_f4_ignatius_full.npz")
     n = g["x"].shape[0]
     fg = np.random.default_rng(int(g["fgeom_seed"])).standard_normal((4 * n, 4)).astype(np.float32)
