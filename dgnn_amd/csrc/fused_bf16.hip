@@ -63,7 +63,14 @@ struct DecB {      // the decoder behind the last conv layer (DEC instantiation)
 template <int CIN_PAD, int COUT, int NW = 4, int PR = 0, int XF = 0, bool DEC = false, int UB = 0>
 struct CfgB {
     static constexpr bool UBI = (UB & 1) != 0, UBO = (UB & 2) != 0;
-    static constexpr int XPARTS = (PR && (XF || UBI)) ? 2 : 1;     // own-row parts in the A-tile
+#ifndef DGNN_UB_OWN_PAIR
+#define DGNN_UB_OWN_PAIR 0
+#endif
+    // own-row parts in the A-tile.  An unsigned own row (UBI) goes to the matrix cores rounded to bf16 (one part): its ninth bit would cost a (hi, lo)
+    // split per tet and a sixth product per k-step for 2^-10 of ONE of the layer's two terms -- measured on the 1M-tet graph (CPU model of the
+    // storage roundings): max |dlogit| 2.1e-2 -> 2.8e-2 without it, rms 2.1e-3 -> 2.6e-3; the gathered rows keep all nine bits
+    // (DGNN_UB_OWN_PAIR=1 builds the pair form)
+    static constexpr int XPARTS = (PR && (XF || (UBI && DGNN_UB_OWN_PAIR))) ? 2 : 1;
     static constexpr int APARTS = PR ? 2 : 1;             // mean parts
     static constexpr int K = (APARTS + XPARTS) * CIN_PAD; // A-tile row: [a_hi | a_lo | x_hi | x_lo] ... [a | x_i]
     // NW == 4: four waves, each a 32-column slice of v_mfma_f32_32x32x16_bf16 blocks.  NW == 8: eight waves, each a 16-column slice
@@ -73,7 +80,7 @@ struct CfgB {
     static constexpr int NSLICE = COUT / (D16 ? 16 : 32);
     static constexpr int RG = NW / NSLICE;
     static constexpr int TILE = 32 * RG;
-    static constexpr int ROWB = D16 ? (UBI ? 65 : 57) * 16 : K * 2 + 16;   // A-tile row: K bf16 + 16 B pad (odd number of 16-B slots); D16: see d16_slot
+    static constexpr int ROWB = D16 ? (XPARTS == 2 ? 65 : 57) * 16 : K * 2 + 16;   // A-tile row: K bf16 + 16 B pad (odd number of 16-B slots); D16: see d16_slot
     static constexpr int A_BYTES = TILE * ROWB;
     static constexpr int TPW = TILE / NW;                 // tets per wave (8 or 16)
     static constexpr int RB = TPW / 4;                    // 16-edge row blocks per wave
@@ -103,8 +110,15 @@ __device__ __forceinline__ float bf_lo(uint32_t u) { return __builtin_bit_cast(f
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
 __device__ __forceinline__ float bf16_round(float v) { return bf_lo(pack_bf16(v, 0.f)); }
 // unsigned rows (UB): value = bits << 15; two values per dword, round to nearest even on bit 15 of the fp32 pattern (the sign is cleared: -0 -> +0)
+// (one instruction each, like the bf16 decodes: the low half's shift leaves the neighbour's last bit in the sign position, which the |.| source
+// modifier of the consuming instruction drops for free; the high half is a sub-dword (SDWA WORD_1) shift)
+#ifdef DGNN_UB_MASK_DECODE
 __device__ __forceinline__ float ub_lo(uint32_t u) { return __builtin_bit_cast(float, (u & 0xFFFFu) << 15); }
 __device__ __forceinline__ float ub_hi(uint32_t u) { return __builtin_bit_cast(float, (u >> 1) & 0x7FFF8000u); }
+#else
+__device__ __forceinline__ float ub_lo(uint32_t u) { return __builtin_fabsf(__builtin_bit_cast(float, u << 15)); }
+__device__ __forceinline__ float ub_hi(uint32_t u) { return __builtin_bit_cast(float, (u >> 16) << 15); }
+#endif
 __device__ __forceinline__ uint32_t ub_enc(float v) {
     const uint32_t b = __builtin_bit_cast(uint32_t, v) & 0x7FFFFFFFu;
     return (b + 0x3FFFu + ((b >> 15) & 1u)) >> 15;
@@ -347,7 +361,10 @@ k_sage_fused_bf16(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
             for (int q = 0; q < NH; ++q) split2(__builtin_bit_cast(float, xv[2 * q]), __builtin_bit_cast(float, xv[2 * q + 1]), xh[q], xl[q]);
         } else if constexpr (UBI) {
 #pragma unroll
-            for (int q = 0; q < NH; ++q) split2(ub_lo(xv[q]), ub_hi(xv[q]), xh[q], xl[q]);
+            for (int q = 0; q < NH; ++q) {
+                if constexpr (C::XPARTS == 2) split2(ub_lo(xv[q]), ub_hi(xv[q]), xh[q], xl[q]);
+                else { xh[q] = pack_bf16(ub_lo(xv[q]), ub_hi(xv[q])); xl[q] = 0u; }
+            }
         } else {
 #pragma unroll
             for (int q = 0; q < NH; ++q) { xh[q] = xv[q]; xl[q] = 0u; }

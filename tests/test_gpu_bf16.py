@@ -304,7 +304,10 @@ def test_unsigned_rows_fused_layer_vs_fp64(c_in, c_out):
     out = ops.sage_layer_fused_fwd_bf16(rowptr, src, n, xin, c_in, ea.to(DEV), *dv(We, be, Wj, bj, Wi, scale, shift), True, eid=eid, rows_out_unsigned=True)
     assert out.dtype == ops.UROWS and out.shape == (n, c_out)
     err = (_ub_decode(out) - ref).abs()
-    bound = 0.5 * EPS * ref.abs() + 2.0 ** -14 * mag + 1e-3
+    # an unsigned OWN row enters the matrix cores rounded to bf16 (its ninth bit is not worth a sixth product per k-step: csrc/fused_bf16.hip XPARTS);
+    # the gathered rows keep all nine bits
+    own = torch.zeros_like(ref) if first else 0.5 * EPS * (xd.abs() @ d(Wi).abs().t()) * d(scale).abs()
+    bound = 0.5 * EPS * ref.abs() + 2.0 ** -14 * mag + own + 1e-3
     assert bool((err <= bound).all()), float((err / bound).max())
     # the same layer writing plain bf16 rows (fp32 input only: a layer on 16-bit rows keeps its input's format) is twice as far out at the worst row
     if first:
@@ -324,7 +327,8 @@ def test_unsigned_rows_fused_layer_vs_fp64(c_in, c_out):
         lg = ops.sage_layer_fused_decoder_fwd_bf16(rowptr, src, n, xin, c_in, ea.to(DEV), *dv(We, be, Wj, bj, Wi, scale, shift), True,
                                                    *dv(W0, b0), None, None, *dv(W3, b3), eid=eid)
         e = (lg.cpu().double() - lref).abs()
-        assert bool((e <= 2.0 ** -13 * lmag + 1e-4).all()), float((e / (2.0 ** -13 * lmag + 1e-4)).max())
+        lb = 2.0 ** -13 * lmag + (own @ d(W0).abs().t()) @ d(W3).abs().t() + 1e-4
+        assert bool((e <= lb).all()), float((e / lb).max())
 
 
 def test_generic_bf16_ops_vs_fp64_on_rounded_inputs():

@@ -39,7 +39,8 @@ def worker(lib, dtype, points):
     plan = GraphPlan(data.edge_index, n, n, hint=ops.PLAN_HINT_REFERENCE)
     h = net._input_rows(data.x)
     if dtype == "bf16":
-        h = ops.cast_to_bf16(h)
+        h = net._storage_input(h)            # (the first fused layer reads the fp32 rows in place)
+    f32 = lambda t: t if t.dtype == torch.float32 else ops.cast_to_f32(t)     # bf16 / unsigned 16-bit rows -> values
     fns, outs = [], []
     for i in range(4):
         fn = lambda h=h, i=i: net._eval_layers(h, n, data.edge_attr, [plan] * 4, True, only=i)
@@ -52,8 +53,8 @@ def worker(lib, dtype, points):
     full = lambda: net.inference_layer(data, plan=GraphPlan(data.edge_index, n, n, hint=ops.PLAN_HINT_REFERENCE))
     fns.append(full)
     torch.cuda.synchronize()
-    chk = [float(o.double().abs().sum()) for o in outs] + [float(logits.double().abs().sum())]
-    sample = [o[::997].float().cpu().numpy().tolist() for o in (outs[3], logits)]
+    chk = [float(f32(o).double().abs().sum()) for o in outs] + [float(logits.double().abs().sum())]
+    sample = [f32(o)[::997].float().cpu().numpy().tolist() for o in (outs[3], logits)]
     print(json.dumps({"ready": True, "checksums": chk}), flush=True)
     for line in sys.stdin:
         cmd = line.strip()
