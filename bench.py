@@ -11,8 +11,8 @@ One step = one pass of the hot path over the graph, inputs resident in HBM in th
 (x [N,29] fp32, edge_attr [4N,20] fp32, edge_index [2,4N] int64).  The step INCLUDES building the
 graph plan (stable destination sort), because the reference takes a raw edge_index on every call.
 N>1: the scene is partitioned spatially, one part per rank, with an RCCL halo exchange of boundary-tet
-features before conv layers 1..3.  `--scaling weak` (default): gpus x `--points` points, ~1M tets per GPU;
-`--scaling strong`: the `--points` scene itself (the 1M-tet metric graph) cut N ways.  Rank 0 prints ONE JSON line.
+features before conv layers 1..3.  `--scaling strong` (default since round 4: the metric's "1M-tet graph at 1/2/4/8"): the `--points` scene
+itself cut N ways; `--scaling weak`: gpus x `--points` points, ~1M tets per GPU (nested under `other_scaling`).  Rank 0 prints ONE JSON line.
 
 Secondary lines: `--widths 64,128,256,512`, `--widths 128,256,512,1024` (random-init weights,
 torch.manual_seed(0)), `--points 1485000` (10M tets), `--dtype bf16` (bf16 storage + single-product bf16 MFMA).
@@ -243,9 +243,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=150000, help="Delaunay points (150000 -> 1 010 078 tets; 1485000 -> 10M tets)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N>1: weak = gpus x --points points (fixed work per GPU), strong = the --points scene cut N ways; the other one is measured too "
-                         "and nested under `other_scaling`")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="N>1: strong (default: the metric reads \"1M-tet graph at 1/2/4/8 MI355X\") = the --points scene cut N ways, weak = gpus x --points "
+                         "points (fixed work per GPU); the other one is measured too and nested under `other_scaling`")
     ap.add_argument("--widths", type=str, default=None, help="conv widths, e.g. 64,128,256,512 (random-init weights); default: kf96 checkpoint")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="bf16: bf16 activation storage, single-product bf16 MFMA, fp32 accumulate")
     ap.add_argument("--cpu-points", type=int, default=30000, help="sample size of the single-thread CPU leg")
@@ -364,7 +364,7 @@ def main():
         import torch.distributed as dist
         from dgnn_amd.partition import HaloExchange, PartitionedScene
         gloo = dist.new_group(backend="gloo")     # host-side traffic of the bench itself (flags, the gathered logits of the check)
-        transport = "RCCL" if backend == "nccl" else "host-staged %s (validation run, not a benchmark)" % backend
+        transport = "RCCL" if backend == "nccl" else "host-staged %s (validation run, not a benchmark)" % backend    # (refined below once the scene exists)
         host_staged = [False]
 
         def build_scene(mode):
@@ -375,6 +375,9 @@ def main():
             return sc, total_points
         scene, total_points = build_scene(args.scaling)
         n_total, n_local = scene.n_total, scene.n_own
+        if backend == "nccl":
+            transport = ("RCCL, one send / recv group per layer issued by the library on its side stream (dgnn_halo_exchange_start / _wait)"
+                         if getattr(scene.exchange, "_native", None) is not None else "RCCL through torch.distributed.batch_isend_irecv")
 
         def step():
             return scene.inference_layer(net)

@@ -116,6 +116,16 @@ SIGNATURES = {
     "dgnn_static_infer_workspace_bytes": (i64, [i64, i32, vp]),
     "dgnn_static_infer_fwd": (i32, [vp, i64, i64, i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32,
                                     vp, vp, i32, i32, i32, vp, vp, vp]),
+    "dgnn_rccl_available": (i32, []),
+    "dgnn_comm_unique_id": (i32, [vp]),
+    "dgnn_comm_create": (i32, [vp, i32, i32, vp]),
+    "dgnn_comm_destroy": (i32, [vp]),
+    "dgnn_halo_plan_create": (i32, [i32, i32, i64, vp, vp, vp, vp]),
+    "dgnn_halo_plan_destroy": (i32, [vp]),
+    "dgnn_halo_send_rows": (i64, [vp]),
+    "dgnn_halo_recv_rows": (i64, [vp]),
+    "dgnn_halo_exchange_start": (i32, [vp, vp, vp, i64, i32, i32, vp, vp]),
+    "dgnn_halo_exchange_wait": (i32, [vp, vp]),
     "dgnn_edge_chain_fwd": (i32, [vp, i64, i32, vp, i64, vp, i64, i64, vp, i32, vp, i64, vp, vp]),
     "dgnn_edge_chain_fwd_bf16": (i32, [vp, i64, i32, vp, i64, vp, i64, i64, vp, i32, vp, i64, vp, vp]),
     "dgnn_edge_chain_bwd": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i64, vp]),

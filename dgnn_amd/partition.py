@@ -143,6 +143,62 @@ class HaloExchange:
         self.active = (sum(lp.send_counts) + sum(lp.recv_counts)) > 0
         self.stream = torch.cuda.Stream(device=self.device) if (self.device.type == "cuda" and self.active) else None
         self._pending = None
+        # The exchange as LIBRARY calls (csrc/halo.hip: pack kernel + one RCCL send / recv group on the library's side stream, an event handed
+        # back) instead of torch.distributed ops issued one by one from Python -- under the RCCL backend, unless DGNN_NATIVE_HALO=0.  The
+        # communicator is the library's own: rank 0's unique id travels over the process group, every rank of the group joins (also ranks without
+        # a halo: communicator creation is collective).  Anything that goes wrong here leaves the torch.distributed transport in place.
+        self._native = None
+        self._native_bufs = {}
+        import os
+        if self.device.type == "cuda" and not self.via_host and os.environ.get("DGNN_NATIVE_HALO", "1") != "0":
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl" and (self.active or dist.get_world_size(group) > 1):
+                try:
+                    self._init_native(group)
+                except Exception as e:  # noqa: BLE001
+                    import sys
+                    sys.stderr.write("dgnn_amd: library halo exchange unavailable (%s); torch.distributed transport is used\n" % e)
+                    self._native = None
+
+    def _init_native(self, group):
+        import ctypes as C
+        import torch.distributed as dist
+        from ._lib import check, lib
+        L = lib()
+        if not L.dgnn_rccl_available():
+            raise RuntimeError("no RCCL library could be opened")
+        lp = self.lp
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        with torch.cuda.device(self.device):
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                buf = (C.c_ubyte * 128)()
+                check(L.dgnn_comm_unique_id(buf), "dgnn_comm_unique_id")
+                uid = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
+            if world > 1:
+                t = uid.to(self.device)
+                dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                uid = t.cpu()
+            idb = (C.c_ubyte * 128)(*uid.tolist())
+            comm = C.c_void_p()
+            check(L.dgnn_comm_create(idb, rank, world, C.byref(comm)), "dgnn_comm_create")
+            plan = C.c_void_p()
+            sc = (C.c_int64 * world)(*[int(v) for v in lp.send_counts])
+            rc = (C.c_int64 * world)(*[int(v) for v in lp.recv_counts])
+            check(L.dgnn_halo_plan_create(rank, world, lp.n_own, C.c_void_p(self.send_idx32.data_ptr()) if self.send_idx32.numel() else None, sc, rc,
+                                          C.byref(plan)), "dgnn_halo_plan_create")
+        self._native = (L, comm, plan)
+
+    def __del__(self):
+        nat = getattr(self, "_native", None)
+        if nat is not None:
+            try:
+                L, comm, plan = nat
+                L.dgnn_halo_plan_destroy(plan)
+                L.dgnn_comm_destroy(comm)
+            except Exception:  # noqa: BLE001 -- interpreter teardown
+                pass
+            self._native = None
 
     def _post(self, h_full, send):
         import torch.distributed as dist
@@ -169,6 +225,18 @@ class HaloExchange:
         """h_full [n_own + n_halo, C] with the rows to send valid: begins filling the halo rows in place."""
         if not self.active:
             return
+        if self._native is not None:
+            from ._lib import check, ptr, stream_ptr
+            L, comm, plan = self._native
+            esz, c = h_full.element_size(), h_full.size(1)
+            key = (c, esz)
+            buf = self._native_bufs.get(key)
+            if buf is None:      # one packed-rows buffer per row shape, reused by every exchange (the next pack is ordered behind the previous wait)
+                buf = self._native_bufs[key] = torch.empty(max(1, int(sum(self.lp.send_counts)) * c * esz), dtype=torch.uint8, device=self.device)
+            with torch.cuda.device(self.device):
+                check(L.dgnn_halo_exchange_start(plan, comm, ptr(h_full), h_full.stride(0), c, esz, ptr(buf), stream_ptr()), "dgnn_halo_exchange_start")
+            self._pending = "native"
+            return
         if h_full.dtype == torch.int16:      # unsigned 16-bit rows (dgnn_amd.ops.UROWS): the collective moves them as bf16 bit patterns
             h_full = h_full.view(torch.bfloat16)
         send = self.pack(h_full, self.send_idx32) if self.pack is not None else h_full.index_select(0, self.send_idx)
@@ -184,7 +252,13 @@ class HaloExchange:
         self._pending = True
 
     def wait(self) -> None:
-        if self._pending:
+        if self._pending == "native":
+            from ._lib import check, stream_ptr
+            L, _, plan = self._native
+            with torch.cuda.device(self.device):
+                check(L.dgnn_halo_exchange_wait(plan, stream_ptr()), "dgnn_halo_exchange_wait")
+            self._pending = None
+        elif self._pending:
             torch.cuda.current_stream(self.device).wait_stream(self.stream)
             self._pending = None
 

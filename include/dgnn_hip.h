@@ -699,6 +699,35 @@ int dgnn_cell_order_bfs(const int64_t* edge_index, int64_t stride_row, int64_t s
 int dgnn_reorder_edges_ref(const int64_t* edge_index, int64_t stride_row, int64_t stride_col, int64_t n, const int32_t* order,
                            const int32_t* rank, int64_t* pairs_out, int32_t* edge_rows_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Partitioned scene: per-layer halo exchange over RCCL (what replaces the reference's k-hop recomputation for scenes that do not
+ * fit one pass, learning/surfaceNetStaticEdgeFilters.py:232-275 / run.py:221-223).  A rank's activation buffer is [n_own + n_halo, C]: owned
+ * rows first, then the halo rows grouped by owner rank.  Before conv layer l >= 1:
+ *   dgnn_halo_exchange_start  packs x[send_idx] on `stream`, then -- on the plan's own side stream, ordered behind the pack by an event -- ONE
+ *                             group of ncclRecv (straight into the buffer's tail) and ncclSend (every GPU pair of an MI355X node has a direct xGMI
+ *                             link: single-hop neighbour exchange, no ring)
+ *   dgnn_halo_exchange_wait   makes `stream` wait for the received rows
+ * Launches queued on `stream` between the two (the interior cells) overlap the transfer.  Rows are `elem_bytes` (2 or 4) x C bytes, whole 4-byte
+ * words; send_buf: dgnn_halo_send_rows(plan) * C * elem_bytes bytes, caller-owned, reusable after the wait.  send_idx (device int32, caller-owned,
+ * must outlive the plan): local ids of the owned rows to send, grouped by destination rank; send_counts / recv_counts: host arrays [world].
+ * `comm`: an ncclComm_t -- the caller's, or one made by dgnn_comm_create from the 128-byte id of dgnn_comm_unique_id (rank 0 asks, the host
+ * broadcasts it over its own channel, every rank creates on its current device).  RCCL is resolved at run time (DGNN_RCCL_LIB, an already
+ * loaded librccl, the loader's path): dgnn_rccl_available() == 0 and DGNN_E_UNSUPPORTED from these entry points where there is none.
+ * Nothing allocates device memory or synchronises the host; a rank may be its own peer (RCCL allows self send / recv inside a group).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dgnn_halo_plan dgnn_halo_plan;
+int dgnn_rccl_available(void);
+int dgnn_comm_unique_id(void* id128);
+int dgnn_comm_create(const void* id128, int rank, int world, void** comm_out);
+int dgnn_comm_destroy(void* comm);
+int dgnn_halo_plan_create(int rank, int world, int64_t n_own, const int32_t* send_idx, const int64_t* send_counts, const int64_t* recv_counts,
+                          dgnn_halo_plan** out);
+int dgnn_halo_plan_destroy(dgnn_halo_plan* plan);
+int64_t dgnn_halo_send_rows(const dgnn_halo_plan* plan);
+int64_t dgnn_halo_recv_rows(const dgnn_halo_plan* plan);
+int dgnn_halo_exchange_start(dgnn_halo_plan* plan, void* comm, void* x, int64_t ld, int C, int elem_bytes, void* send_buf, void* stream);
+int dgnn_halo_exchange_wait(dgnn_halo_plan* plan, void* stream);
+
 /* elementwise helpers used by the Updated variant (F.relu at surfaceNetUpdatedEdgeFilters.py:239-241
  * and the scatter of phi rows into the zero [E_all,C] buffer at :236-237) */
 int dgnn_relu(const float* x, int64_t n, float* y, void* stream);

@@ -43,16 +43,54 @@ def _rccl_worker(rank, port, out_dir):
     lp = LocalPart(rank=0, world=1, n_total=n_own, own_gid=np.arange(n_own), n_interior=n_own - n_halo, halo_gid=send_idx.copy(),
                    edge_index=np.zeros((2, 0), np.int64), edge_gid=np.zeros(0, np.int64), send_idx=send_idx,
                    send_counts=[n_halo], recv_counts=[n_halo])
-    ex = HaloExchange(lp, DEV, pack=ops.gather_rows)
-    assert ex.active and ex.stream is not None and not ex.via_host
-    for it in range(3):
-        h = torch.full((n_own + n_halo, c), float("nan"), device=DEV)
-        h[:n_own] = torch.randn(n_own, c, device=DEV)
-        ex.start(h)
-        busy = ops.relu(h[:n_own])            # "interior" work on the compute stream while the rows travel
-        ex.wait()
-        assert torch.equal(h[n_own:], h[torch.from_numpy(send_idx).to(DEV)]), it
-        assert torch.equal(busy, torch.relu(h[:n_own]))
+    for native in (True, False):
+        # native: the exchange as LIBRARY calls (dgnn_halo_plan_create / dgnn_halo_exchange_start / _wait, csrc/halo.hip: pack kernel + one RCCL
+        # group on the library's side stream, its own communicator made from a unique id); else the torch.distributed transport of rounds 1-3
+        os.environ["DGNN_NATIVE_HALO"] = "1" if native else "0"
+        ex = HaloExchange(lp, DEV, pack=ops.gather_rows)
+        assert ex.active and ex.stream is not None and not ex.via_host and (ex._native is not None) == native
+        for it in range(3):
+            h = torch.full((n_own + n_halo, c), float("nan"), device=DEV)
+            h[:n_own] = torch.randn(n_own, c, device=DEV)
+            ex.start(h)
+            busy = ops.relu(h[:n_own])            # "interior" work on the compute stream while the rows travel
+            ex.wait()
+            assert torch.equal(h[n_own:], h[torch.from_numpy(send_idx).to(DEV)]), it
+            assert torch.equal(busy, torch.relu(h[:n_own]))
+        # 16-bit rows (bf16 storage, and the unsigned rows' int16 container) and another width through the same plan
+        for dt, cc in ((torch.bfloat16, 64), (torch.int16, 128)):
+            h = torch.zeros((n_own + n_halo, cc), dtype=dt, device=DEV)
+            h[:n_own] = (torch.randn(n_own, cc, device=DEV) * 100).to(dt)
+            ex.start(h)
+            ex.wait()
+            assert torch.equal(h[n_own:], h[torch.from_numpy(send_idx).to(DEV)]), dt
+        del ex
+    # the C ABI directly, with a row stride wider than the row (rows then travel one by one inside the group)
+    if True:
+        import ctypes as C
+        from dgnn_amd._lib import check, lib, ptr
+        L = lib()
+        assert L.dgnn_rccl_available()
+        uid = (C.c_ubyte * 128)()
+        check(L.dgnn_comm_unique_id(uid), "uid")
+        comm, plan = C.c_void_p(), C.c_void_p()
+        check(L.dgnn_comm_create(uid, 0, 1, C.byref(comm)), "comm")
+        idx32 = torch.from_numpy(send_idx.astype(np.int32)).to(DEV)
+        one = (C.c_int64 * 1)(n_halo)
+        check(L.dgnn_halo_plan_create(0, 1, n_own, ptr(idx32), one, one, C.byref(plan)), "plan")
+        assert L.dgnn_halo_send_rows(plan) == n_halo and L.dgnn_halo_recv_rows(plan) == n_halo
+        wide = torch.zeros((n_own + n_halo, 40), device=DEV)
+        wide[:n_own] = torch.randn(n_own, 40, device=DEV)
+        view = wide[:, :28]                           # rows of 28 floats, stride 40
+        keep = wide[n_own:, 28:].clone()
+        sbuf = torch.empty(n_halo * 28 * 4, dtype=torch.uint8, device=DEV)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(L.dgnn_halo_exchange_start(plan, comm, ptr(view), 40, 28, 4, ptr(sbuf), st), "start")
+        check(L.dgnn_halo_exchange_wait(plan, st), "wait")
+        torch.cuda.synchronize()
+        assert torch.equal(wide[n_own:, :28], wide[torch.from_numpy(send_idx).to(DEV), :28]) and torch.equal(wide[n_own:, 28:], keep)
+        check(L.dgnn_halo_plan_destroy(plan), "plan destroy")
+        check(L.dgnn_comm_destroy(comm), "comm destroy")
     torch.cuda.synchronize()
     open(os.path.join(out_dir, "ok"), "w").write("rccl ok")
     dist.destroy_process_group()

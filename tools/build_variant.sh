@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../dgnn_amd/csrc"
 name=$1; shift
 out=../variants/$name.so
 mkdir -p ../variants build_$name
-for f in plan aggregate gemm norm sampler mesh ingest reorder infer adam train chain loss; do
+for f in plan aggregate gemm norm sampler mesh ingest reorder infer halo adam train chain loss; do
   [ build/$f.o -nt $f.hip ] || make -s build/$f.o
   cp build/$f.o build_$name/$f.o
 done
