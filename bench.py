@@ -792,6 +792,8 @@ def main():
             out["training_step"] = training_leg(["--updated", "--dtype", "bf16"] if bf16 else [])
             if not bf16 and not args.no_extras:
                 out["training_step_updated_bf16"] = training_leg(["--updated", "--dtype", "bf16"])   # BASELINE config 3's model and storage type
+                # the widths and batch size the reference trains ModelNet10 with (configs/modelnet.yaml:44,56: [128,256,512,1024], batch 1024)
+                out["training_step_modelnet_widths"] = training_leg(["--widths", "128,256,512,1024", "--batch", "1024", "--steps", "100", "--warmup", "100"])
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

@@ -33,6 +33,8 @@ ap.add_argument("--updated", action="store_true", help="surfaceNetUpdatedEdgeFil
 ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="bf16: activations / phi stored in bf16, bf16 MFMA, fp32 accumulate and master weights")
 ap.add_argument("--points", type=int, default=150000)
 ap.add_argument("--batch", type=int, default=2048)
+ap.add_argument("--widths", type=str, default=None, help="conv widths, e.g. 128,256,512,1024 (configs/modelnet.yaml:56; batch 1024 there) or 64,128,256,512 "
+                                                          "(eth / aerial / terrestrial); default: the shipped checkpoint's 64,128,128,128")
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--warmup", type=int, default=300, help="untimed steps; the GPU needs ~0.5 s of this load before its step time settles (measured: 2.4 -> 1.5 ms over the first ~300 steps of a process)")
 ap.add_argument("--prefetch", choices=["none", "stream", "thread"], default="stream",
@@ -66,7 +68,8 @@ x[:, 0] = x[:, 0].abs() + 0.05
 ea = hashed_normal(np.arange(4 * n), 20, seed=2 + 10 * rank, device=dev)
 occ = torch.sigmoid(2 * x[:, 3:4] + x[:, 7:8])
 all_ = Config(x=x, y=torch.cat([occ, 1 - occ], 1), edge_attr=ea)
-clf = reconbench_pretrained(device=dev)
+widths = [int(v) for v in args.widths.split(",")] if args.widths else [64, 128, 128, 128]
+clf = reconbench_pretrained(device=dev, convs=tuple(widths))
 clf.temp.current_epoch = 0
 clf.training.metrics = Metrics()
 torch.manual_seed(0)
@@ -74,7 +77,7 @@ if args.updated:
     import torch.nn.functional as F
     from dgnn_amd.learning.surfaceNetUpdatedEdgeFilters import SurfaceNet as UpdatedNet
     from dgnn_amd.partition import allreduce_gradients
-    uclf = Config.wrap(dict(training=dict(model_params=[64, 128, 128, 128], model_name="sage+", loss="kl"),
+    uclf = Config.wrap(dict(training=dict(model_params=list(widths), model_name="sage+", loss="kl"),
                             features=dict(normalization_feature=1, keep_normalization_feature=0), temp=dict(device=dev)))
     net = UpdatedNet(28, uclf).to(dev).train()
 
@@ -158,32 +161,51 @@ def replay_roofline():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / it
 
-    w = [28, 64, 128, 128, 128]
+    w = [28] + list(widths)
+    if args.updated:
+        # Updated variant: the longest launches are the given-phi aggregate backward (k_agg_bwd_g) of the outer blocks: reads x, da and the edge
+        # embeddings phi [E, C] once, writes dx and dphi [E, C]
+        e, e_id, size = adjs[1]
+        c = w[1]
+        plan = plan_for(e, size[0], size[1])
+        tp = plan.transposed
+        dt_ = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+        esz = 2 if args.dtype == "bf16" else 4
+        xx, da = torch.randn(size[0], c, device=dev).to(dt_), torch.randn(size[1], c, device=dev).to(dt_)
+        phi = torch.randn(e.size(1), c, device=dev).to(dt_)
+        t_b = timed(lambda: ops.aggregate_bwd(tp[0], tp[1], tp[2], size[0], plan.rowptr, xx, da, phi=phi))
+        bytes_b = ((2 * size[0] + size[1]) * c + 2 * e.size(1) * c) * esz + e.size(1) * 8
+        return {"bound": "hbm", "kernel": "k_agg_bwd_g (given-phi aggregate backward of the %d-channel layer, lane-group form: reads x, da, phi [E, C]; writes dx, dphi [E, C]; "
+                                           "the longest launches of the step are its instances)" % c, "achieved": round(bytes_b / t_b / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(bytes_b / t_b / 1e6 / 8000.0, 4), "traffic": None, "algorithmic_bytes_per_launch": bytes_b, "avg_launch_ms": round(t_b, 4),
+                "timing": "the launch replayed 10x at the last block's shapes, HIP events on the launching stream"}
     gemms, flops, ms = [], 0.0, 0.0
     for i, (e, e_id, size) in enumerate(adjs):
         n_src, n_dst = size
         gemms.append((n_dst, w[i], w[i], w[i + 1]))                      # z = a.Wj^T + x_dst.Wi^T
         gemms += [(n_dst, w[i + 1], 0, w[i])] * (2 if i > 0 else 1)      # da = dz.Wj (+ dx_dst += dz.Wi)
-    gemms += [(batch, 128, 0, 64), (batch, 64, 0, 2), (batch, 2, 0, 64), (batch, 64, 0, 128)]   # decoder forward / backward
+    hd = w[-1] // 2
+    gemms += [(batch, w[-1], 0, hd), (batch, hd, 0, 2), (batch, 2, 0, hd), (batch, hd, 0, w[-1])]   # decoder forward / backward
     for M, k1, k2, no in gemms:
         A1, W1 = torch.randn(M, k1, device=dev), torch.randn(no, k1, device=dev)
         A2, W2 = (torch.randn(M, k2, device=dev), torch.randn(no, k2, device=dev)) if k2 else (None, None)
         out = torch.empty(M, no, device=dev)
         ms += timed(lambda: ops.linear_fwd(A1, W1, A2, W2, out=out))
         flops += 2.0 * M * (k1 + k2) * no
-    e, e_id, size = adjs[1]                     # 64-channel layer: the largest launch that also writes dx
+    e, e_id, size = adjs[1]                     # second conv layer (64 channels at the shipped widths): the largest launch that also writes dx
+    c1 = w[1]
     plan = plan_for(e, size[0], size[1])
     tp, rows = plan.transposed, plan.transposed_edge_rows
-    x, da = torch.randn(size[0], 64, device=dev), torch.randn(size[1], 64, device=dev)
-    We, be = torch.randn(64, 20, device=dev), torch.randn(64, device=dev)
+    x, da = torch.randn(size[0], c1, device=dev), torch.randn(size[1], c1, device=dev)
+    We, be = torch.randn(c1, 20, device=dev), torch.randn(c1, device=dev)
     t_b = timed(lambda: ops.aggregate_bwd(tp[0], tp[1], rows if rows is not None else tp[2], size[0], plan.rowptr, x, da, all_.edge_attr if rows is not None
                                           else all_.edge_attr[e_id], We, be))
-    bytes_b = size[0] * 64 * 4 * 2 + e.size(1) * 88 + size[1] * 64 * 4 + size[0] * 4
+    bytes_b = size[0] * c1 * 4 * 2 + e.size(1) * 88 + size[1] * c1 * 4 + size[0] * 4
     peak = 2500.0 / 6
     # primary object: the HBM-bound gather / scatter kernel with the longest single launch; the GEMMs (largest share of the
     # step's GPU time, but 15 small launches: M <= 70k rows, K <= 256) are reported next to it
-    return {"bound": "hbm", "kernel": "k_agg_bwd_c<1,20> (aggregate backward of the 64-channel layer, chunked form: gathers da rows, recomputes the filter, "
-                                       "writes dx, dWe, dbe; the longest launches of the step are its instances)", "achieved": round(bytes_b / t_b / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+    return {"bound": "hbm", "kernel": "k_agg_bwd_c<1,20> (aggregate backward of the %d-channel layer, chunked form: gathers da rows, recomputes the filter, "
+                                       "writes dx, dWe, dbe; the longest launches of the step are its instances)" % c1, "achieved": round(bytes_b / t_b / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
             "frac": round(bytes_b / t_b / 1e6 / 8000.0, 4), "traffic": None, "algorithmic_bytes_per_launch": bytes_b, "avg_launch_ms": round(t_b, 4),
             "timing": "each launch replayed 10x at the last block's shapes, HIP events on the launching stream",
             "gemm": {"bound": "mfma", "kernel": "k_linear_fwd_x3 (%d launches per step: conv / decoder GEMMs forward, input gradients backward)" % len(gemms),
@@ -200,7 +222,7 @@ if world > 1:
     dist.all_gather(sums, cs, group=dist.new_group(backend="gloo"))
     replicas = {"param_abs_sum_per_rank": [float(v) for v in sums], "equal": all(float(v) == float(sums[0]) for v in sums)}
 roof = None
-if rank == 0 and not args.no_roofline and not args.updated and args.dtype == "f32":
+if rank == 0 and not args.no_roofline and (args.updated or args.dtype == "f32"):
     roof = replay_roofline()
 if rank == 0:
     print(json.dumps({"metric": "training step (block builder + fwd + bwd + %sAdam), %d x MI355X" % ("gradient all-reduce + " if world > 1 else "", world),
