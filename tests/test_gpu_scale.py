@@ -347,7 +347,7 @@ def test_training_step_at_bench_scale_matches_the_oracle(convs, points, batch):
 
 
 @pytest.mark.parametrize("dtype,params,points,batch", [(torch.float32, (64, 128, 128, 128), 30000, 2048), (torch.bfloat16, (64, 128, 128, 128), 30000, 2048),
-                                                       (torch.bfloat16, (64, 128, 256, 512), 10000, 1024)])
+                                                       (torch.bfloat16, (64, 128, 256, 512), 10000, 1024), (torch.float32, (64, 128, 256, 512), 10000, 1024)])
 def test_updated_training_step_at_scale_matches_the_oracle(dtype, params, points, batch):
     """Updated variant ("sage": the reference's "sage+" head cannot be differentiated -- F.relu followed by an in-place nn.ReLU, :245-246 --
     so gradients are compared on the plain model as in the golden test) on a 2048-target 4-hop block of a 200k-tet scene (~90k cells per block; the oracle materialises the
@@ -396,9 +396,17 @@ def test_updated_training_step_at_scale_matches_the_oracle(dtype, params, points
     else:   # bf16 storage: SURVEY 8c's two-level tolerance on the logits, bf16 resolution on the gradients
         assert (err <= 5e-2 * scale).float().mean().item() >= 0.9999 and err.max().item() <= 1e-1 * scale
         rel, floor = 6e-2, 6e-3
+    wide = tuple(params) != (64, 128, 128, 128)
     for k, p in net.named_parameters():
-        e = (p.grad.double().cpu() - ograds[k]).abs().max().item()
-        assert e <= rel * ograds[k].abs().max().item() + floor * gmax, (k, e, ograds[k].abs().max().item(), gmax)
+        d = (p.grad.double().cpu() - ograds[k])
+        e = d.abs().max().item()
+        if wide and dtype == torch.bfloat16:
+            # [64,128,256,512], random init: every stored dy / dphi is rounded to bf16 on its way down four layers of 256-512 channels; measured
+            # (tools history, round 4) rms error / rms gradient 0.4 % at the last conv layer, 4 % / 7 % / 8 % at layers 2 / 1 / 0, largest single
+            # entry 17 % of the tensor's largest -- the fp32-storage build of the same step sits at 1e-6.  Bounds: 1.5x what was measured.
+            assert d.pow(2).mean().sqrt().item() <= 0.13 * ograds[k].pow(2).mean().sqrt().item() and e <= 0.26 * ograds[k].abs().max().item(), (k, e, ograds[k].abs().max().item())
+        else:
+            assert e <= rel * ograds[k].abs().max().item() + floor * gmax, (k, e, ograds[k].abs().max().item(), gmax)
 
 
 @pytest.mark.parametrize("k1,k2,n_out", [(128, 128, 128), (64, 0, 2), (128, 0, 64), (70, 33, 37), (256, 256, 512), (28, 28, 64)])
