@@ -104,6 +104,9 @@ class Metrics:
         return self.reg_sum / e if e else 0.0
 
 
+TRAIN_DIRECT = __import__("os").environ.get("DGNN_TRAIN_DIRECT", "1") != "0"
+
+
 def make_adam(params, lr):
     """the reference's optimizer (:290 torch.optim.Adam(model.parameters(), lr)); fp32 parameters on a GPU are stepped by one library launch
     (dgnn_amd.optim.Adam: same rule and state), anything else -- and DGNN_TORCH_ADAM=1 -- by torch's own"""
@@ -204,6 +207,9 @@ class Trainer:
         process group of size > 1 uses that group, a single process changes nothing."""
         if not self._all_training():
             self.model.train()
+        direct = self._train_direct(data_train, optimizer, clf, group)
+        if direct is not None:
+            return direct
         logits_cell = self.model(data_train)
         n_sup = data_train.batch_adjs[self.model.num_layers - 1].size[1] if hasattr(data_train.batch_adjs[0], "size") \
             else data_train.batch_adjs[self.model.num_layers - 1][2][1]
@@ -217,6 +223,46 @@ class Trainer:
         allreduce_gradients(self.model, group)   # no-op without a process group / with one rank
         optimizer.step()
         return loss.detach()
+
+    def _train_direct(self, data_train, optimizer, clf, group):
+        """The step without the autograd engine (DGNN_TRAIN_DIRECT=0 keeps the autograd path): the Static model's whole-model library calls, the
+        fused kl loss and its gradient issued directly (SurfaceNet.train_step_direct) -- the step is bound by the host's issue rate, and the engine's
+        bookkeeping, the loss Function and zero_grad were a fifth of it.  Same kernels in the same order: same numbers as the autograd path
+        (tests/test_gpu_train.py).  None = this configuration takes the autograd path (other losses / models, an active edge regulariser)."""
+        model = self.model
+        step = getattr(model, "train_step_direct", None)
+        if step is None or not TRAIN_DIRECT or clf.training.loss != "kl" or not FUSED_KL_LOSS or not clf.regularization.cell_type \
+                or clf.regularization.cell_norm not in Fn.ops.CELL_NORMS:
+            return None
+        if clf.regularization.edge_epoch is not None and clf.temp.current_epoch >= clf.regularization.edge_epoch:
+            return None
+        x_all, y_all = data_train.all.x, data_train.all.y
+        if not (x_all.is_cuda and y_all.is_cuda and x_all.dtype == torch.float32 and y_all.dtype == torch.float32):
+            return None
+        n_sup = data_train.batch_adjs[model.num_layers - 1].size[1] if hasattr(data_train.batch_adjs[0], "size") \
+            else data_train.batch_adjs[model.num_layers - 1][2][1]
+        ids = data_train.batch_n_id[:n_sup].to(x_all.device)
+        data_train.batch_x = x_all[ids]                # (the reference leaves these on the data object, :273-274)
+        data_train.batch_gt = y_all[ids]
+        metrics, norm = clf.training.metrics, Fn.ops.CELL_NORMS[clf.regularization.cell_norm]
+        one = self.__dict__.get("_one")
+        if one is None or one.device != x_all.device:
+            one = self._one = torch.ones((), dtype=torch.float32, device=x_all.device)
+
+        def loss_fn(logits):
+            if logits.dim() != 2 or logits.size(1) != 2 or logits.size(0) != n_sup:
+                raise RuntimeError("train: the model returned %s logits for %d targets" % (tuple(logits.shape), n_sup))
+            vol = data_train.batch_x[:, 0]
+            loss, sums = Fn.ops.kl_cell_loss_fwd(logits, data_train.batch_gt, vol, norm)
+            metrics.addPacked(sums, n_sup)
+            return loss, Fn.ops.kl_cell_loss_bwd(logits, data_train.batch_gt, vol, norm, sums, one)
+        loss = step(data_train, loss_fn)
+        if loss is None:
+            return None
+        from ..partition import allreduce_gradients
+        allreduce_gradients(model, group)
+        optimizer.step()
+        return loss
 
     def train_test(self, data, clf, group=None):
         """Epoch loop of the reference (:285-405): Adam, lr * 0.1^(epoch // adjust_lr_every), one `train` per sampled batch,

@@ -246,6 +246,18 @@ class SurfaceNet(nn.Module):
         """Training-mode forward through ONE library call (and one in the backward) when every layer qualifies for the composite
         entry points: fp32 rows, lin_e a Linear over <= 32 attributes, BatchNorm in training mode after every conv and inside the
         decoder.  Returns the logits, or None (the per-layer path then runs)."""
+        built = self._train_spec(x, data, dev)
+        if built is None:
+            return None
+        spec, tail = built
+        h = Fn.static_train_model(x, spec)
+        if tail is not None:
+            h = Fn.linear2(h, tail.weight, bias=tail.bias, out_f32=True)
+        return h
+
+    def _train_spec(self, x, data, dev):
+        """-> (per-layer spec for Fn.static_train_model / ops.static_train_fwd, the decoder's output Linear when it does NOT ride in the call | None),
+        or None when a layer does not qualify (see _train_whole_model)"""
         from .. import ops
         if not (ops.TRAIN_COMPOSITE and ops.TRAIN_WHOLE_MODEL) or x.dtype != torch.float32 or self.num_layers + 2 > 8:
             return None
@@ -268,6 +280,7 @@ class SurfaceNet(nn.Module):
             spec.append(dict(plan=plan, edge_attr=ea, scene_rows=in_place and conv.lin_e is not None, lin_e=conv.lin_e, lin_j=conv.lin_j, lin_i=conv.lin_i,
                              bn=norm.module))
             n_src = size[1]
+        tail = None
         if len(dec) == 4:
             if not dec[1].module.training or dec[1].module.momentum is None:
                 return None
@@ -275,11 +288,48 @@ class SurfaceNet(nn.Module):
             if ops.TRAIN_DECODER_OUTPUT_IN_CALL and isinstance(dec[3], torch.nn.Linear) and dec[3].bias is not None:
                 # the decoder's output Linear rides in the same two library calls (a layer without BatchNorm / ReLU)
                 spec.append(dict(plan=None, n_rows=n_src, edge_attr=None, scene_rows=False, lin_e=None, lin_j=dec[3], lin_i=None, bn=None))
-                return Fn.static_train_model(x, spec)
-        h = Fn.static_train_model(x, spec)
-        if len(dec) == 4:
-            h = Fn.linear2(h, dec[3].weight, bias=dec[3].bias, out_f32=True)
-        return h
+            else:
+                tail = dec[3]
+        return spec, tail
+
+    def train_step_direct(self, data, loss_fn):
+        """Forward, loss and backward of ONE training step without the autograd engine (round 4; reference learning/runModel.py:266-279: forward,
+        calcLossAndOA, loss.backward()): the whole-model library calls each way (dgnn_static_train_fwd / _bwd) are issued directly around
+        `loss_fn(logits) -> (loss, dlogits)`, the parameters' .grad are SET to the fresh gradients (what zero_grad + backward leave).  Same kernels,
+        same order as the autograd node (functional._StaticTrainModel): same numbers.  Returns the detached loss, or None when the model does not
+        take the whole-model calls with logits out of the call (the caller then runs the autograd path)."""
+        from .. import ops
+        dev = self._device()
+        x_all = data.all.x
+        n_id = data.batch_n_id.to(x_all.device)
+        x = _dev_f32(x_all[n_id, 1:] if self.clf.regularization.cell_type else x_all[n_id, :], dev)
+        if self.storage_dtype != torch.float32:
+            return None
+        built = self._train_spec(x, data, dev)
+        if built is None or built[1] is not None or len(built[0]) <= self.num_layers:
+            return None
+        spec = built[0]
+        layers = []
+        for sp in spec:
+            le, lj, li, bn, plan = sp["lin_e"], sp["lin_j"], sp["lin_i"], sp["bn"], sp["plan"]
+            layers.append(dict(plan_parts=plan.part_ptrs(bool(sp["scene_rows"])) if plan is not None else None,
+                               n_dst=plan.n_dst if plan is not None else sp["n_rows"], n_src=plan.n_src if plan is not None else sp["n_rows"],
+                               edge_attr=sp["edge_attr"] if le is not None else None, We=le.weight if le is not None else None,
+                               be=le.bias if le is not None else None, Wj=lj.weight, bj=lj.bias, Wi=li.weight if li is not None else None,
+                               gamma=bn.weight if bn is not None else None, beta=bn.bias if bn is not None else None, bn=bn))
+        with torch.no_grad():
+            logits, buf, meta = ops.static_train_fwd(x, layers)
+            loss, dlogits = loss_fn(logits)
+            for l, sp in zip(layers, spec):
+                if sp["plan"] is not None:
+                    l["t_parts"] = sp["plan"].transposed_ptrs(bool(sp["scene_rows"]))
+            grads = ops.static_train_bwd(x, layers, buf, meta, dlogits)
+        for l, g in zip(layers, grads):
+            for name, gr in zip(("We", "be", "Wj", "bj", "Wi", "gamma", "beta"), g):
+                p_ = l[name]
+                if p_ is not None and p_.requires_grad:
+                    p_.grad = gr
+        return loss.detach()
 
     # ---- INFERENCE, whole graph (reference :323-355; the benchmarked path) ---------------------
     @torch.no_grad()

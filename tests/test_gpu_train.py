@@ -605,6 +605,50 @@ def test_library_adam_and_block_builder_follow_their_tensors_device():
         Adam([torch.nn.Parameter(torch.ones(3, device="cuda:0")), torch.nn.Parameter(torch.ones(3, device=d1))])
 
 
+def test_direct_training_step_equals_the_autograd_step():
+    """Trainer.train without the autograd engine (round 4: SurfaceNet.train_step_direct issues the whole-model calls, the fused loss and its gradient
+    directly) against the autograd path (DGNN_TRAIN_DIRECT=0) on the same blocks: loss, every parameter after three Adam steps, BatchNorm buffers,
+    metrics -- bit for bit (same kernels in the same order); the gradients of the last step too."""
+    import dgnn_amd.learning.runModel as RM
+    from dgnn_amd.learning.runModel import Metrics, Trainer
+    from dgnn_amd.sampler import NeighborSampler
+    from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal
+    adj, _, _ = delaunay_tet_graph(4000, seed=13)
+    n = adj.shape[0] // 4
+    ei = torch.from_numpy(adj.T.astype(np.int64)).to(DEV)
+    x = hashed_normal(np.arange(n), 29, seed=1, device=DEV)
+    x[:, 0] = x[:, 0].abs() + 0.05
+    ea = hashed_normal(np.arange(4 * n), 20, seed=2, device=DEV)
+    occ = torch.sigmoid(2 * x[:, 3:4] + x[:, 7:8])
+    all_ = Config(x=x, y=torch.cat([occ, 1 - occ], 1), edge_attr=ea)
+    out = {}
+    for direct in (True, False):
+        RM.TRAIN_DIRECT = direct
+        try:
+            clf = make_clf()
+            clf.temp.device = DEV
+            clf.temp.current_epoch = 0
+            clf.training.metrics = Metrics()
+            net = hip_static(train=True)
+            tr = Trainer(net)
+            opt = RM.make_adam(net.parameters(), 0.005)
+            loader = NeighborSampler(ei, sizes=[-1] * 4, node_idx=torch.arange(0, 3 * 256, device=DEV), num_nodes=n, batch_size=256)
+            losses = []
+            for bs, n_id, adjs in loader:
+                d = Config(all=all_, batch_n_id=n_id, batch_adjs=adjs)
+                losses.append(tr.train(d, opt, clf).item())
+                assert d.batch_x.shape == (256, 29) and d.batch_gt.shape == (256, 2)       # left on the data object as the reference does (:273-274)
+            out[direct] = (losses, {k: v.detach().clone() for k, v in net.state_dict().items()}, {k: p.grad.clone() for k, p in net.named_parameters()},
+                           (clf.training.metrics.getCellLoss(), clf.training.metrics.getOA(), clf.training.metrics.samples_sum))
+        finally:
+            RM.TRAIN_DIRECT = True
+    assert out[True][0] == out[False][0] and out[True][3] == out[False][3]
+    for k in out[False][1]:
+        assert torch.equal(out[True][1][k], out[False][1][k]), k
+    for k in out[False][2]:
+        assert torch.equal(out[True][2][k], out[False][2][k]), k
+
+
 def test_aux_stream_backward_gives_identical_gradients():
     """dgnn_train_set_aux_stream(1): weight gradients on the library's second stream beside the dx chain -- same numbers"""
     from dgnn_amd._lib import lib
