@@ -58,6 +58,8 @@ SIGNATURES = {
     "dgnn_bn_batch_stats_fold": (i32, [vp, i64, i64, i32, vp, vp, vp, vp, f32, vp, vp, f32, vp, vp, vp, vp]),
     "dgnn_scale_shift_act": (i32, [vp, i64, vp, vp, i32, i64, i32, vp, i64, vp]),
     "dgnn_bn_relu_bwd": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, vp, f32, i32, i32, i64, i32, vp, i64, vp, vp, vp, vp]),
+    "dgnn_bn_relu_bwd_sums": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, f32, i32, i64, i32, vp, vp, vp]),
+    "dgnn_bn_relu_bwd_apply": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, vp, f32, i32, i64, i32, vp, C.c_double, vp, i64, vp]),
     "dgnn_colsum": (i32, [vp, i64, i64, i32, vp, i32, vp, vp]),
     "dgnn_sage_aggregate_bwd_scratch_elems": (i64, [i64, i32, i32]),
     "dgnn_sage_aggregate_bwd": (i32, [vp, vp, vp, i64, vp, vp, i64, i32, vp, i64, i32, vp, vp, vp, i64, vp, i64, vp, i64,

@@ -233,9 +233,8 @@ __global__ void k_bn_relu_bwd_apply(const T* __restrict__ x, int64_t ldx, const 
                                     const T* __restrict__ dy, int64_t lddy, const float* __restrict__ gamma,
                                     const float* __restrict__ mean, const float* __restrict__ var, float eps, int train,
                                     int relu, int64_t M, int c, const float* __restrict__ sum_g,
-                                    const float* __restrict__ sum_gx, T* __restrict__ dx, int64_t lddx) {
-    const int64_t total = M * c;
-    const float invM = 1.0f / (float)M;
+                                    const float* __restrict__ sum_gx, T* __restrict__ dx, int64_t lddx, float invM) {
+    const int64_t total = M * c;      // invM = 1 / (rows the sums were taken over): M here, the whole scene's rows when the batch spans several ranks
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = t / c;
         const int col = (int)(t - r * c);
@@ -328,8 +327,21 @@ static int bn_relu_bwd_t(const T* x, int64_t ldx, const T* y, int64_t ldy, const
     launch_colreduce<1, T>(nblk, stream, x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, rpb, P);
     hipLaunchKernelGGL(k_sum_finalize, dim3((c + 15) / 16), dim3(FIN_THREADS), 0, stream, P, nblk, c, sums, sums + c, 0, dbeta, dgamma);
     hipLaunchKernelGGL((k_bn_relu_bwd_apply<T>), dim3(dgnn_grid_cap(dgnn_cdiv(M * c, 256))), dim3(256), 0, stream, x, ldx, y, ldy, dy, lddy,
-                       gamma, mean, var, eps, train, relu, M, c, sums, sums + c, dx, lddx);
+                       gamma, mean, var, eps, train, relu, M, c, sums, sums + c, dx, lddx, 1.0f / (float)M);
     return dgnn_check_launch("bn_relu_bwd");
+}
+
+// The two halves of bn_relu_bwd_t for batch statistics that span several ranks (a scene cut across GPUs, dgnn_amd/partition.py): the local sums
+// [sum g | sum g * x_hat] (g = dy behind the ReLU mask) -- which the host all-reduces --, then dx from sums over `count` rows.
+static int bn_relu_bwd_sums_f32(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* dy, int64_t lddy, const float* mean, const float* var,
+                                float eps, int relu, int64_t M, int c, float* sums, float* scratch, hipStream_t stream) {
+    DGNN_REQUIRE(M > 0 && c > 0 && x && dy && mean && var && sums && scratch && (!relu || y), DGNN_E_INVALID, "bn_relu_bwd_sums: bad args");
+    const int nblk = red_blocks(M);
+    const int64_t rpb = dgnn_cdiv(M, nblk);
+    double* P = as_f64(scratch);
+    launch_colreduce<1, float>(nblk, stream, x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, rpb, P);
+    hipLaunchKernelGGL(k_sum_finalize, dim3((c + 15) / 16), dim3(FIN_THREADS), 0, stream, P, nblk, c, sums, sums + c, 0, (float*)nullptr, (float*)nullptr);
+    return dgnn_check_launch("bn_relu_bwd_sums");
 }
 
 template <typename T>
@@ -384,6 +396,20 @@ extern "C" int dgnn_bn_relu_bwd(const float* x, int64_t ldx, const float* y, int
                                 void* stream) {
     return bn_relu_bwd_t<float>(x, ldx, y, ldy, dy, lddy, gamma, mean, var, eps, train, relu, M, c, dx, lddx, dgamma, dbeta, scratch,
                                 (hipStream_t)stream);
+}
+extern "C" int dgnn_bn_relu_bwd_sums(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* dy, int64_t lddy, const float* mean,
+                                     const float* var, float eps, int relu, int64_t M, int c, float* sums, float* scratch, void* stream) {
+    return bn_relu_bwd_sums_f32(x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, sums, scratch, (hipStream_t)stream);
+}
+extern "C" int dgnn_bn_relu_bwd_apply(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* dy, int64_t lddy, const float* gamma,
+                                      const float* mean, const float* var, float eps, int relu, int64_t M, int c, const float* sums, double count,
+                                      float* dx, int64_t lddx, void* stream) {
+    DGNN_REQUIRE(M >= 0 && c > 0 && count >= 1.0, DGNN_E_INVALID, "bn_relu_bwd_apply: bad sizes");
+    if (M == 0) return DGNN_OK;
+    DGNN_REQUIRE(x && dy && mean && var && sums && dx && (!relu || y), DGNN_E_INVALID, "bn_relu_bwd_apply: null pointer");
+    hipLaunchKernelGGL((k_bn_relu_bwd_apply<float>), dim3(dgnn_grid_cap(dgnn_cdiv(M * c, 256))), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, dy, lddy,
+                       gamma, mean, var, eps, 1, relu, M, c, sums, sums + c, dx, lddx, (float)(1.0 / count));
+    return dgnn_check_launch("bn_relu_bwd_apply");
 }
 extern "C" int dgnn_bn_relu_bwd_bf16(const uint16_t* x, int64_t ldx, const uint16_t* y, int64_t ldy, const uint16_t* dy, int64_t lddy,
                                      const float* gamma, const float* mean, const float* var, float eps, int train, int relu,

@@ -335,6 +335,50 @@ def kl_cell_loss(logits, gt, vol, cell_norm=None):
     return _KLCellLoss.apply(logits, gt, vol, ops.CELL_NORMS.get(cell_norm, 0))
 
 
+class _SceneBatchNormRelu(torch.autograd.Function):
+    """BatchNorm1d (training mode) + ReLU over a scene that is cut across ranks (dgnn_amd/partition.py; SURVEY 8e: one [2 C] all-reduce per layer each
+    way): per-row work in the library's kernels -- local column statistics (dgnn_bn_batch_stats), scale / shift + ReLU (dgnn_scale_shift_act), the
+    backward's column sums and apply (dgnn_bn_relu_bwd_sums / _apply) --, the [C]-vectors in between on the host side of the collective in fp64."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, reduce, relu):
+        n_loc, c = x.shape
+        m_l, v_l = ops.bn_batch_stats(x)                                  # local mean / biased variance
+        m64 = m_l.double()
+        st = torch.cat([m64 * n_loc, (v_l.double() + m64 * m64) * n_loc, torch.full((1,), float(n_loc), dtype=torch.float64, device=x.device)])
+        st = reduce(st)
+        n = float(st[2 * c].item())
+        mean64 = st[:c] / n
+        var64 = (st[c:2 * c] / n - mean64 * mean64).clamp_min(0.0)
+        mean, var = mean64.float(), var64.float()
+        if bn.track_running_stats and bn.running_mean is not None:
+            with torch.no_grad():
+                bn.num_batches_tracked.add_(1)
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                bn.running_mean.mul_(1 - mom).add_((mom * mean64).to(bn.running_mean.dtype))
+                bn.running_var.mul_(1 - mom).add_((mom * var64 * (n / max(n - 1.0, 1.0))).to(bn.running_var.dtype))
+        scale, shift = ops.bn_fold(gamma, beta, mean, var, bn.eps)
+        y = ops.scale_shift_act(x, scale, shift, relu)
+        ctx.save_for_backward(x, y, gamma, mean, var)
+        ctx.cfg = (reduce, bool(relu), float(bn.eps), n)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, mean, var = ctx.saved_tensors
+        reduce, relu, eps, n = ctx.cfg
+        dy = dy.contiguous()
+        loc = ops.bn_relu_bwd_sums(x, y, dy, mean, var, eps, relu)          # this rank's (sum g, sum g * x_hat) = its dbeta / dgamma terms
+        glob = reduce(loc.double().reshape(-1).clone()).float().reshape(2, -1)
+        dx = ops.bn_relu_bwd_apply(x, y, dy, gamma, mean, var, eps, relu, glob, n)
+        return dx, loc[1].clone(), loc[0].clone(), None, None, None
+
+
+def scene_batch_norm_relu(x, bn: torch.nn.BatchNorm1d, reduce, relu: bool = True):
+    """`reduce(t)`: all-reduce (sum) of a 1-D fp64 tensor over the ranks that share the scene"""
+    return _SceneBatchNormRelu.apply(x, bn.weight, bn.bias, bn, reduce, relu)
+
+
 def aggregate(x_src, plan, edge_attr=None, We=None, be=None, phi=None):
     if We is not None:
         return _Aggregate.apply(x_src, edge_attr, We, be, plan)

@@ -392,6 +392,29 @@ def bn_relu_bwd(x, y, dy, gamma, mean, var, eps, train, relu):
     return dx, dgamma, dbeta
 
 
+@on_device_of
+def bn_relu_bwd_sums(x, y, dy, mean, var, eps, relu):
+    """local [2, c] = (sum g, sum g * x_hat), g = dy behind the ReLU mask of y -- the half of bn_relu_bwd a partitioned scene all-reduces"""
+    _req(x, "x", dim=2)
+    M, c = x.shape
+    sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
+    scratch = _f32(lib().dgnn_colstats_scratch_elems(M, c), x.device)
+    check(lib().dgnn_bn_relu_bwd_sums(ptr(x), _ld(x), ptr(y), _ld(y) if y is not None else 0, ptr(dy), _ld(dy), ptr(mean), ptr(var), float(eps),
+                                      int(bool(relu)), M, c, ptr(sums), ptr(scratch), stream_ptr()), "dgnn_bn_relu_bwd_sums")
+    return sums
+
+
+@on_device_of
+def bn_relu_bwd_apply(x, y, dy, gamma, mean, var, eps, relu, sums, count):
+    """dx of y = relu(bn(x)) from sums [2, c] taken over `count` rows (all ranks' rows of a partitioned scene)"""
+    _req(x, "x", dim=2)
+    M, c = x.shape
+    dx = torch.empty((M, c), dtype=torch.float32, device=x.device)
+    check(lib().dgnn_bn_relu_bwd_apply(ptr(x), _ld(x), ptr(y), _ld(y) if y is not None else 0, ptr(dy), _ld(dy), ptr(gamma), ptr(mean), ptr(var), float(eps),
+                                       int(bool(relu)), M, c, ptr(sums.contiguous()), float(count), ptr(dx), c, stream_ptr()), "dgnn_bn_relu_bwd_apply")
+    return dx
+
+
 # ---- fused inference layer ----------------------------------------------------------------------
 def fused_layer_supported(c_in: int, c_out: int, f_e: int, x: torch.Tensor = None) -> bool:
     """Mirrors the shape dispatch of dgnn_sage_layer_fused_fwd (csrc/fused.hip): c_in <= 64 -> c_out in {64,128};

@@ -401,6 +401,18 @@ class PartitionedScene:
                                       widths=widths)
 
 
+def _partitioned_scene_train_forward(self, net, group=None):
+    """Train-mode forward of `net` (the Static SurfaceNet) over this rank's part of the scene -> logits [n_own, out] of the owned cells with a
+    backward (halo gradients return to their owners, BatchNorm statistics span the scene): see partitioned_train_forward."""
+    x = self.x_local[:, 1:] if net.clf.regularization.cell_type else self.x_local
+    return partitioned_train_forward(self.lp, x.contiguous() if x.stride(1) != 1 else x, self.edge_attr, self.edge_index, [blk[0] for blk in net.convs],
+                                     [getattr(blk[1], "module", None) if len(blk) > 1 else None for blk in net.convs],
+                                     net.decoder if net.clf.model.decoder else None, self.exchange, group)
+
+
+PartitionedScene.train_forward = _partitioned_scene_train_forward
+
+
 def _needs_host_staging(t: torch.Tensor, group) -> bool:
     import torch.distributed as dist
     return t.is_cuda and dist.get_backend(group) != "nccl"
@@ -469,3 +481,179 @@ def broadcast_parameters(model: torch.nn.Module, group=None, src: int = 0) -> No
             n = t.numel()
             t.copy_(flat[off:off + n].view_as(t).to(t.dtype))
             off += n
+
+
+# ---- backward of a partitioned single scene (SURVEY 8e "Backward mirrors it"; round 4) ------------------------------------------------------
+# Training ONE scene that is cut across ranks (the reference trains on sampled blocks of a resident scene, learning/runModel.py:264-282; a scene that does
+# not fit one GPU has no reference counterpart -- this is the partitioned forward's mirror image):
+#   * the halo exchange gets a backward: the gradient of the halo rows goes back to their owners and is ADDED to the gradient of the rows they sent;
+#   * BatchNorm in training mode takes its batch statistics over the WHOLE scene: one [2 C] all-reduce (sum, sum of squares) forward, one [2 C]
+#     all-reduce (sum dy, sum dy * x_hat) backward per layer; the running buffers are updated with the global statistics on every rank;
+#   * every rank's parameter gradients are partial sums over its owned cells: ONE flat all-reduce (SUM) at the end of the backward.
+# Both pieces are autograd Functions, so the conv layers in between can be the HIP model's (functional.py) or, in the CPU tests, the oracle's modules.
+
+
+def _rows_reverse_exchange(lp: LocalPart, g_halo: torch.Tensor, group, via_host: bool):
+    """sends the gradient rows of the halo (grouped by owner) back to their owners; returns [n_send, C]: the gradient contributions for the rows this
+    rank sent, in send_idx order"""
+    import torch.distributed as dist
+    dev = g_halo.device
+    if via_host:
+        g_halo = g_halo.cpu()
+    back = torch.empty((int(sum(lp.send_counts)), g_halo.size(1)), dtype=g_halo.dtype, device=g_halo.device)
+    ops_, so, ro = [], 0, 0
+    for peer in range(lp.world):
+        ns, nr = lp.send_counts[peer], lp.recv_counts[peer]
+        if ns:
+            ops_.append(dist.P2POp(dist.irecv, back[so:so + ns], peer, group=group))
+        if nr:
+            ops_.append(dist.P2POp(dist.isend, g_halo[ro:ro + nr].contiguous(), peer, group=group))
+        so += ns
+        ro += nr
+    if ops_:
+        for req in dist.batch_isend_irecv(ops_):
+            req.wait()
+    return back.to(dev) if via_host else back
+
+
+class _HaloRows(torch.autograd.Function):
+    """h_own [n_own, C] -> [n_own + n_halo, C] with the peers' rows behind the owned ones; backward: halo gradients return to their owners"""
+
+    @staticmethod
+    def forward(ctx, h_own, exchange):
+        lp = exchange.lp
+        full = torch.empty((lp.n_own + lp.n_halo, h_own.size(1)), dtype=h_own.dtype, device=h_own.device)
+        full[:lp.n_own] = h_own
+        exchange(full)
+        ctx.exchange = exchange
+        return full
+
+    @staticmethod
+    def backward(ctx, g_full):
+        ex = ctx.exchange
+        lp = ex.lp
+        g_own = g_full[:lp.n_own].clone()
+        if ex.active:
+            back = _rows_reverse_exchange(lp, g_full[lp.n_own:], ex.group, ex.via_host)
+            g_own.index_add_(0, ex.send_idx, back)       # a row sent to several peers collects every peer's contribution
+        return g_own, None
+
+
+def halo_rows(h_own: torch.Tensor, exchange: HaloExchange) -> torch.Tensor:
+    """differentiable halo exchange (see _HaloRows)"""
+    return _HaloRows.apply(h_own, exchange)
+
+
+class _SceneBatchNorm(torch.autograd.Function):
+    """BatchNorm1d in training mode over a scene that is cut across ranks: statistics over ALL ranks' rows (biased variance for the normalisation,
+    unbiased for the running buffer, as torch.nn.BatchNorm1d), fp64 sums"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, group, via_host):
+        import torch.distributed as dist
+        c = x.size(1)
+        xs = x.double()
+        st = torch.cat([xs.sum(0), (xs * xs).sum(0), torch.full((1,), float(x.size(0)), dtype=torch.float64, device=x.device)])
+        st = _all_reduce_sum(st, group, via_host)
+        n = st[2 * c].item()
+        mean = st[:c] / n
+        var = (st[c:2 * c] / n - mean * mean).clamp_min(0.0)
+        invstd = torch.rsqrt(var + bn.eps)
+        xhat = (xs - mean) * invstd
+        if bn.track_running_stats and bn.running_mean is not None:
+            with torch.no_grad():
+                bn.num_batches_tracked.add_(1)
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                bn.running_mean.mul_(1 - mom).add_((mom * mean).to(bn.running_mean.dtype))
+                bn.running_var.mul_(1 - mom).add_((mom * var * (n / max(n - 1.0, 1.0))).to(bn.running_var.dtype))
+        ctx.save_for_backward(xhat, gamma, invstd)
+        ctx.cfg = (group, via_host, n)
+        return (xhat * gamma.double() + beta.double()).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xhat, gamma, invstd = ctx.saved_tensors
+        group, via_host, n = ctx.cfg
+        c = xhat.size(1)
+        dyd = dy.double()
+        loc = torch.cat([dyd.sum(0), (dyd * xhat).sum(0)])
+        glob = _all_reduce_sum(loc.clone(), group, via_host)
+        dx = (gamma.double() * invstd) * (dyd - glob[:c] / n - xhat * (glob[c:] / n))
+        # parameter gradients stay LOCAL partial sums: the flat all-reduce at the end of the step adds them up like every other parameter's
+        return dx.to(dy.dtype), loc[c:].to(gamma.dtype), loc[:c].to(gamma.dtype), None, None, None
+
+
+def _all_reduce_sum(t: torch.Tensor, group, via_host: bool) -> torch.Tensor:
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return t
+    if via_host and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        return h.to(t.device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def scene_batch_norm(x: torch.Tensor, bn: torch.nn.BatchNorm1d, group=None, via_host: bool = False) -> torch.Tensor:
+    """training-mode BatchNorm1d with scene-wide statistics (see _SceneBatchNorm); eval mode is the module itself (no communication)"""
+    if not bn.training:
+        return torch.nn.functional.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
+    return _SceneBatchNorm.apply(x, bn.weight, bn.bias, bn, group, via_host)
+
+
+def partitioned_train_forward(lp: LocalPart, x_local: torch.Tensor, edge_attr_local: torch.Tensor, edge_index_local: torch.Tensor, convs, norms,
+                              decoder, exchange: HaloExchange, group=None):
+    """Train-mode forward of the Static model over a partitioned scene -> logits [n_own, out] of the owned cells, differentiable end to end
+    (reference SurfaceNet.forward :196-227 with the whole scene as one block, cut across ranks).
+    convs[i]((h_full, h_own), edge_attr, edge_index) is layer i's conv (the HIP model's SAGEConv or the oracle's), norms[i] its BatchNorm1d (or None),
+    decoder = the model's decoder Sequential (Linear, norm wrapper | None, ReLU, Linear) or a single Linear.  Layer 0 reads the rank's input rows (its
+    halo input features are part of x_local); every later layer exchanges its input's halo first."""
+    via_host = bool(exchange.via_host)
+    on_gpu = x_local.is_cuda
+
+    def bn_relu(z, bn):
+        # GPU: the library's kernels around the collective (functional._SceneBatchNormRelu, BatchNorm + ReLU in one pass each way); CPU (tests): torch ops
+        if on_gpu and bn is not None and bn.training and z.dtype == torch.float32:
+            from . import functional as Fn
+            return Fn.scene_batch_norm_relu(z, bn, lambda t: _all_reduce_sum(t, group, via_host), True)
+        return torch.relu(scene_batch_norm(z, bn, group, via_host) if bn is not None else z)
+
+    h_full = x_local
+    for i, conv in enumerate(convs):
+        if i > 0:
+            h_full = halo_rows(h_own, exchange)
+        h_own = bn_relu(conv((h_full, h_full[:lp.n_own]), edge_attr_local, edge_index_local), norms[i])
+    if decoder is None:
+        return h_own
+    mods = list(decoder) if isinstance(decoder, torch.nn.Sequential) else [decoder]
+    h, k = h_own, 0
+    while k < len(mods):
+        m = mods[k]
+        bn = getattr(m, "module", m)
+        if isinstance(bn, torch.nn.BatchNorm1d):
+            if k + 1 < len(mods) and isinstance(mods[k + 1], torch.nn.ReLU):      # the decoder's norm -> ReLU pair
+                h = bn_relu(h, bn)
+                k += 1
+            else:
+                h = scene_batch_norm(h, bn, group, via_host)
+        elif isinstance(m, torch.nn.ReLU):
+            h = torch.relu(h)
+        elif m is not None:
+            if on_gpu:
+                from . import functional as Fn
+                h = Fn.linear2(h, m.weight, bias=m.bias)
+            else:
+                h = torch.nn.functional.linear(h, m.weight, m.bias)
+        k += 1
+    return h
+
+
+def partitioned_kl_loss(logits: torch.Tensor, gt: torch.Tensor, vol: torch.Tensor, group=None, via_host: bool = False) -> torch.Tensor:
+    """the Trainer's volume-weighted KL cell loss (learning/runModel.py:171-209, cell_norm None) of a partitioned scene: sum over ALL ranks' cells of
+    w * kl / sum of w; every rank returns the scene's loss, its backward yields this rank's share of the gradient"""
+    cell = torch.nn.functional.kl_div(torch.nn.functional.log_softmax(logits, dim=-1), gt[:, :2], reduction="none").sum(1) * vol
+    w_all = _all_reduce_sum(vol.double().sum().reshape(1).clone(), group, via_host)[0].to(cell.dtype)
+    mine = cell.sum() / w_all
+    total = _all_reduce_sum(mine.detach().double().reshape(1).clone(), group, via_host)[0].to(cell.dtype)
+    return mine + (total - mine.detach())       # value: the scene's loss; gradient: this rank's term

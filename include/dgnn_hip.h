@@ -203,6 +203,14 @@ int dgnn_bn_relu_bwd(const float* x, int64_t ldx, const float* y, int64_t ldy, c
                      int64_t M, int c, float* dx, int64_t lddx, float* dgamma, float* dbeta, float* scratch,
                      void* stream);
 /* out[c] (+)= sum over rows (bias gradients) */
+/* dgnn_bn_relu_bwd in two halves, for batch statistics that span several ranks (a scene cut across GPUs; SURVEY 8e: the [2 C] all-reduce per layer):
+ * _sums: sums[0..c) = sum g, sums[c..2c) = sum g * x_hat over the M local rows (g = dy behind the ReLU mask; also this rank's dbeta / dgamma terms);
+ * _apply: dx from sums taken over `count` rows (all ranks').  fp32 rows; scratch as dgnn_bn_relu_bwd. */
+int dgnn_bn_relu_bwd_sums(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* dy, int64_t lddy, const float* mean,
+                          const float* var, float eps, int relu, int64_t M, int c, float* sums, float* scratch, void* stream);
+int dgnn_bn_relu_bwd_apply(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* dy, int64_t lddy, const float* gamma,
+                           const float* mean, const float* var, float eps, int relu, int64_t M, int c, const float* sums, double count,
+                           float* dx, int64_t lddx, void* stream);
 int dgnn_colsum(const float* x, int64_t ldx, int64_t M, int c, float* out, int accumulate, float* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -128,3 +128,70 @@ def test_config4_10m_tets_eight_parts_equal_the_whole_graph():
     for r in range(world):
         logits[own[r]] = hs[r] if fuse else net._eval_decoder(hs[r][:lps[r].n_own])
     assert torch.equal(logits, full)
+
+
+# ---- backward of a partitioned single scene with the HIP model (round 4; SURVEY 8e "Backward mirrors it") -------------------------------------------
+def _ptrain_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dgnn_amd.partition import PartitionedScene, allreduce_gradients, build_local_part, partitioned_kl_loss, rcb_partition
+    from test_gpu_parity import DEV, hip_static
+    from test_partition_cpu import _scene
+    adj, cent, x, ea = _scene(900, 6)
+    x[:, 0] = x[:, 0].abs() + 0.05
+    occ = torch.sigmoid(2 * x[:, 3:4] + x[:, 7:8])
+    y = torch.cat([occ, 1 - occ], 1)
+    lp = build_local_part(adj.T.astype(np.int64), rcb_partition(cent, world), rank, world)
+    rows = torch.from_numpy(np.concatenate([lp.own_gid, lp.halo_gid]))
+    own = torch.from_numpy(lp.own_gid)
+    net = hip_static(train=True)
+    scene = PartitionedScene(lp, x[rows], ea[torch.from_numpy(lp.edge_gid)], DEV)
+    assert scene.exchange.via_host              # both ranks share the box's one GPU: rows and sums are staged through host memory under gloo
+    logits = scene.train_forward(net)
+    loss = partitioned_kl_loss(logits, y[own].to(DEV), x[own, 0].to(DEV), via_host=True)
+    loss.backward()
+    allreduce_gradients(net, average=False)
+    torch.save(dict(gid=own, logits=logits.detach().cpu(), loss=loss.detach().cpu(), grads={k: p.grad.cpu() for k, p in net.named_parameters()},
+                    buffers={k: b.cpu() for k, b in net.named_buffers()}), os.path.join(out_dir, "t%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_partitioned_backward_hip_model_two_processes(tmp_path):
+    """a scene cut across two processes, HIP model in training mode: halo gradients return to their owners (reverse exchange), BatchNorm statistics and
+    their backward sums span both parts ([2 C] all-reduces around dgnn_bn_batch_stats / dgnn_bn_relu_bwd_sums / _apply), parameter gradients are summed --
+    logits, loss, every parameter gradient and the running buffers against the fp64 oracle's single-process whole-graph step"""
+    import socket
+    import torch.multiprocessing as mp
+    import torch.nn.functional as F
+    from helpers import oracle_static
+    from test_partition_cpu import _scene
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    mp.spawn(_ptrain_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    adj, cent, x, ea = _scene(900, 6)
+    n = adj.shape[0] // 4
+    x, ea = x.double(), ea.double()
+    x[:, 0] = x[:, 0].abs() + 0.05
+    occ = torch.sigmoid(2 * x[:, 3:4] + x[:, 7:8])
+    y = torch.cat([occ, 1 - occ], 1)
+    ei = torch.from_numpy(adj.T.astype(np.int64))
+    onet = oracle_static(train=True, dtype=torch.float64)
+    ologits = onet(Config(all=Config(x=x, edge_attr=ea), batch_n_id=torch.arange(n), batch_adjs=[(ei, torch.arange(4 * n), (n, n))] * 4))
+    w = x[:, 0]
+    oloss = (F.kl_div(F.log_softmax(ologits, dim=-1), y, reduction="none").sum(1) * w).sum() / w.sum()
+    oloss.backward()
+    outs = [torch.load(os.path.join(str(tmp_path), "t%d.pt" % r)) for r in range(2)]
+    got = torch.full((n, 2), float("nan"), dtype=torch.float64)
+    for o in outs:
+        got[o["gid"]] = o["logits"].double()
+    assert (got - ologits.detach()).abs().max().item() <= 2e-4 * max(1.0, ologits.abs().max().item())
+    ograds = {k: p.grad for k, p in onet.named_parameters()}
+    gmax = max(g.abs().max().item() for g in ograds.values())
+    for o in outs:
+        assert abs(o["loss"].item() - oloss.item()) <= 2e-5 * abs(oloss.item()) + 1e-9
+        for k, g in o["grads"].items():
+            err = (g.double() - ograds[k]).abs().max().item()
+            assert err <= 5e-4 * ograds[k].abs().max().item() + 5e-6 * gmax, (k, err)
+        for k, b in dict(onet.named_buffers()).items():
+            assert (o["buffers"][k].double() - b.double()).abs().max().item() <= 1e-5 * max(b.double().abs().max().item(), 1e-30) + 1e-12, k

@@ -152,3 +152,75 @@ def test_dp_gradient_allreduce(tmp_path):
             a += p.grad / world
     for a, b in zip(acc, g0):
         assert torch.allclose(a, b, atol=1e-7)
+
+
+# ---- backward of a partitioned single scene (round 4; SURVEY 8e "Backward mirrors it") ----------------------------------------------------------
+def _whole_graph_train_step(dtype=torch.float64):
+    """the reference's train-mode forward on the WHOLE scene as one block per layer (SurfaceNet.forward :196-227), the Trainer's kl loss over every
+    cell, backward: logits, loss, gradients, BatchNorm buffers of a single process"""
+    adj, cent, x, ea = _scene()
+    n = adj.shape[0] // 4
+    ei = torch.from_numpy(adj.T.astype(np.int64))
+    net = oracle_static(train=True, dtype=dtype)
+    x, ea = x.to(dtype), ea.to(dtype)
+    x[:, 0] = x[:, 0].abs() + 0.05
+    occ = torch.sigmoid(2 * x[:, 3:4] + x[:, 7:8])
+    y = torch.cat([occ, 1 - occ], 1)
+    whole = [(ei, torch.arange(4 * n), (n, n))] * net.num_layers
+    logits = net(Config(all=Config(x=x, edge_attr=ea), batch_n_id=torch.arange(n), batch_adjs=whole))
+    import torch.nn.functional as F
+    w = x[:, 0]
+    loss = (F.kl_div(F.log_softmax(logits, dim=-1), y, reduction="none").sum(1) * w).sum() / w.sum()
+    loss.backward()
+    return net, logits.detach(), loss.detach(), x, ea, y, adj, cent
+
+
+def _train_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from dgnn_amd.partition import allreduce_gradients, partitioned_kl_loss, partitioned_train_forward
+    adj, cent, x, ea = _scene()
+    dtype = torch.float64
+    x, ea = x.to(dtype), ea.to(dtype)
+    x[:, 0] = x[:, 0].abs() + 0.05
+    occ = torch.sigmoid(2 * x[:, 3:4] + x[:, 7:8])
+    y = torch.cat([occ, 1 - occ], 1)
+    ei = adj.T.astype(np.int64)
+    lp = build_local_part(ei, rcb_partition(cent, world), rank, world)
+    rows = torch.from_numpy(np.concatenate([lp.own_gid, lp.halo_gid]))
+    own = torch.from_numpy(lp.own_gid)
+    net = oracle_static(train=True, dtype=dtype)
+    exchange = HaloExchange(lp, "cpu")
+    logits = partitioned_train_forward(lp, x[rows][:, 1:], ea[torch.from_numpy(lp.edge_gid)], torch.from_numpy(lp.edge_index),
+                                       [blk[0] for blk in net.convs], [blk[1].module for blk in net.convs], net.decoder, exchange)
+    loss = partitioned_kl_loss(logits, y[own], x[own, 0])
+    loss.backward()
+    allreduce_gradients(net, average=False)        # partial sums over the owned cells -> the scene's gradient on every rank
+    torch.save(dict(gid=own, logits=logits.detach(), loss=loss.detach(), grads={k: p.grad.clone() for k, p in net.named_parameters()},
+                    buffers={k: b.clone() for k, b in net.named_buffers()}), os.path.join(out_dir, "t%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partitioned_backward_matches_the_whole_graph_backward(world, tmp_path):
+    """halo rows' gradients return to their owners, BatchNorm(train) statistics and their backward sums span every rank, parameter gradients are summed:
+    logits, loss, EVERY parameter gradient and the BatchNorm running buffers of `world` processes equal the single-process whole-graph step (fp64)"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_train_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    net, logits, loss, *_ = _whole_graph_train_step()
+    outs = [torch.load(os.path.join(str(tmp_path), "t%d.pt" % r)) for r in range(world)]
+    got = torch.full_like(logits, float("nan"))
+    for o in outs:
+        got[o["gid"]] = o["logits"]
+    assert (got - logits).abs().max().item() <= 1e-10 * max(1.0, logits.abs().max().item())
+    ref_g = {k: p.grad for k, p in net.named_parameters()}
+    gmax = max(g.abs().max().item() for g in ref_g.values())
+    for o in outs:
+        assert abs(o["loss"].item() - loss.item()) <= 1e-12 * max(1.0, abs(loss.item()))
+        for k, g in o["grads"].items():
+            assert (g - ref_g[k]).abs().max().item() <= 1e-7 * gmax, k        # (fp64; the scene-wide variance is E[x^2] - mean^2 of all-reduced sums, torch's is two-pass)
+        for k, b in dict(net.named_buffers()).items():
+            assert (o["buffers"][k].double() - b.double()).abs().max().item() <= 1e-7 * max(1.0, b.double().abs().max().item()), k
