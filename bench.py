@@ -10,8 +10,10 @@ ReLU] + decoder -> logits [N,2]), shipped kf96 weights.
 One step = one pass of the hot path over the graph, inputs resident in HBM in the reference's layout
 (x [N,29] fp32, edge_attr [4N,20] fp32, edge_index [2,4N] int64).  The step INCLUDES building the
 graph plan (stable destination sort), because the reference takes a raw edge_index on every call.
-N>1: the scene is partitioned spatially, one part per rank, with an RCCL halo exchange of boundary-tet
-features before conv layers 1..3.  `--scaling strong` (default since round 4: the metric's "1M-tet graph at 1/2/4/8"): the `--points` scene
+N>1: the scene is partitioned spatially, one part per rank; every part keeps the rings of cells 1..4 hops outside it resident and recomputes each
+layer on the rings later layers still read (`--halo recompute`, default: no collective in the data path, one library call per step; a ring of a
+1/8 part of the 1M-tet scene is 3.7 % of its cells) -- or, `--halo exchange`, keeps one ring and exchanges its rows over RCCL before conv layers
+1..3 (the form the partitioned backward uses).  `--scaling strong` (default since round 4: the metric's "1M-tet graph at 1/2/4/8"): the `--points` scene
 itself cut N ways; `--scaling weak`: gpus x `--points` points, ~1M tets per GPU (nested under `other_scaling`).  Rank 0 prints ONE JSON line.
 
 Secondary lines: `--widths 64,128,256,512`, `--widths 128,256,512,1024` (random-init weights,
@@ -243,6 +245,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=150000, help="Delaunay points (150000 -> 1 010 078 tets; 1485000 -> 10M tets)")
+    ap.add_argument("--halo", choices=["recompute", "exchange"], default="recompute",
+                    help="N>1: recompute (default) = every part keeps L rings of halo cells and recomputes each layer on the rings later layers read, no collective "
+                         "in the data path; exchange = one ring, rows exchanged between the layers over RCCL (the form the partitioned backward uses)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
                     help="N>1: strong (default: the metric reads \"1M-tet graph at 1/2/4/8 MI355X\") = the --points scene cut N ways, weak = gpus x --points "
                          "points (fixed work per GPU); the other one is measured too and nested under `other_scaling`")
@@ -369,19 +374,22 @@ def main():
 
         def build_scene(mode):
             total_points = args.points * world if mode == "weak" else args.points
-            sc = PartitionedScene.build_synthetic(total_points, 0, rank, world, dev, keep_global=True)
+            sc = PartitionedScene.build_synthetic(total_points, 0, rank, world, dev, keep_global=True, halo=args.halo, hops=net.num_layers)
             if host_staged[0]:
                 sc.exchange = HaloExchange(sc.lp, dev, pack=ops.gather_rows, group=gloo, via_host=True)
             return sc, total_points
         scene, total_points = build_scene(args.scaling)
         n_total, n_local = scene.n_total, scene.n_own
-        if backend == "nccl":
+        rings = args.halo == "recompute"
+        if rings:
+            transport = "none in the data path"
+        elif backend == "nccl":
             transport = ("RCCL, one send / recv group per layer issued by the library on its side stream (dgnn_halo_exchange_start / _wait)"
                          if getattr(scene.exchange, "_native", None) is not None else "RCCL through torch.distributed.batch_isend_irecv")
 
         def step():
             return scene.inference_layer(net)
-        if backend == "nccl":
+        if backend == "nccl" and not rings:
             # Safety net: if the device-to-device exchange cannot run on this node (P2P/IPC disabled ...), every rank sees the
             # error in its first step; all ranks then agree to stage the halo rows through host memory over gloo, and the
             # JSON line says so.  Compute is unchanged.
@@ -398,8 +406,15 @@ def main():
                 host_staged[0] = True
                 scene.exchange = HaloExchange(scene.lp, dev, pack=ops.gather_rows, group=gloo, via_host=True)
                 transport = "host-staged gloo (RCCL point-to-point failed on this node)"
-        workload = "synthetic Delaunay scene, %d points -> N=%d tets, %d-way spatial partition (%s scaling) + %s halo exchange overlapped with interior cells" % (
-            total_points, n_total, world, args.scaling, transport)
+        if rings:
+            workload = ("synthetic Delaunay scene, %d points -> N=%d tets, %d-way spatial partition (%s scaling); every part keeps %d rings of halo cells resident and "
+                        "recomputes each layer on the rings later layers read (this rank: %d owned cells + rings %s): no collective in the data path, one "
+                        "library call per step (dgnn_static_infer_rings_fwd)%s" % (
+                            total_points, n_total, world, args.scaling, net.num_layers, n_local, scene.lp.ring_counts,
+                            "" if backend == "nccl" else "; validation run under %s (ranks may share a device), not a benchmark" % backend))
+        else:
+            workload = "synthetic Delaunay scene, %d points -> N=%d tets, %d-way spatial partition (%s scaling) + %s halo exchange overlapped with interior cells" % (
+                total_points, n_total, world, args.scaling, transport)
 
     settle(step)
     # ---- per-kernel breakdown (outside the timed region): replay each layer between events ----
@@ -444,8 +459,18 @@ def main():
             return ev
         layer_events.setdefault((c_in, c_out, bool(plain)), []).append((tok, ev, n_dst))
         return None
-    ops.LAYER_HOOK = hook
+    # N = 1: the events sit inside the timed steps.  N > 1: a shard of the scene is small enough for the per-launch events (and the per-layer calls they
+    # need: the product's step there is ONE library call) to show in the step time, so the timed region runs the product's step as it is and the same
+    # number of instrumented steps follows it for the roofline object.
+    events_in_timed = world == 1
+    if events_in_timed:
+        ops.LAYER_HOOK = hook
     dt, per_step = timed_steps(step, args.steps, sync, world, dev)
+    if not events_in_timed:
+        ops.LAYER_HOOK = hook
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
     ops.LAYER_HOOK = None
     ms_per_step = dt / args.steps * 1e3
     value = n_total * args.steps / dt
@@ -512,7 +537,8 @@ def main():
                  "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                  "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": st["algo"], "algorithmic_bytes_per_tet": st["per_tet"],
                  "avg_launch_ms": round(st["ms"], 4), "share_of_step": round(st["total_ms"] / args.steps / ms_per_step, 4),
-                 "timing": "HIP events around each launch inside the timed steps (%d launches)" % st["n_events"], "pmc": pmc or None}
+                 "timing": ("HIP events around each launch inside the timed steps (%d launches)" if events_in_timed else
+                            "HIP events around each launch in K instrumented steps right behind the timed region (%d launches)") % st["n_events"], "pmc": pmc or None}
             if not plain:
                 r["algorithmic_bytes_note"] = ("SURVEY 8d rows this launch executes: last conv layer %d B/tet + decoder %d B/tet (the contract figure; the launch itself moves "
                                                "%d B/tet less: the layer's output never leaves the compute unit)" % (layer_bytes(c_in, c_out, elem), elem * c_out + 8, 2 * elem * c_out))

@@ -118,6 +118,10 @@ SIGNATURES = {
     "dgnn_static_infer_workspace_bytes": (i64, [i64, i32, vp]),
     "dgnn_static_infer_fwd": (i32, [vp, i64, i64, i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32,
                                     vp, vp, i32, i32, i32, vp, vp, vp]),
+    "dgnn_static_infer_rings_fwd": (i32, [vp, i64, i64, i64, i32, vp, vp, vp, vp, i32, i64, vp, vp, i64, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                          vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp]),
+    "dgnn_static_infer_partitioned_fwd": (i32, [vp, i64, i64, i64, i32, vp, vp, vp, vp, i32, i64, i64, i64, vp, i64, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp,
+                                                vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "dgnn_rccl_available": (i32, []),
     "dgnn_comm_unique_id": (i32, [vp]),
     "dgnn_comm_create": (i32, [vp, i32, i32, vp]),

@@ -353,15 +353,13 @@ class SurfaceNet(nn.Module):
         x = self._eval_layers(x, x.size(0), xe, [plan] * self.num_layers, sorted_attr=True)
         return self._eval_decoder(x)
 
-    def _infer_one_call(self, x, xe, edge_index, plan):
-        """The whole eval forward -- plan (unless the caller's or a cached one exists), every conv layer, the decoder -- as ONE library call
-        (dgnn_static_infer_fwd issues the launches `_eval_layers` issues, in its order: bit-identical).  Returns the logits, or None when this
-        configuration runs layer by layer: other storage / widths / filters, a per-layer profiling hook, rows the fused kernels do not take."""
-        from ..graph import register_plan
+    def _one_call_tables(self, x, xe):
+        """What dgnn_static_infer_fwd / dgnn_static_infer_partitioned_fwd take for this model: (layers, decoder, prepared, with_dec) -- or None when
+        this configuration runs layer by layer: other storage / widths / filters, a per-layer profiling hook, rows the fused kernels do not take."""
         if not (ops.INFER_ONE_CALL and ops.FUSED_ENABLED and ops.EDGE_GATHER_IN_KERNEL) or ops.LAYER_HOOK is not None:
             return None
         if self.storage_dtype != torch.float32 or x.dtype != torch.float32 or xe.dtype != torch.float32 or xe.dim() != 2 or xe.size(1) != 20 \
-                or xe.stride(0) != 20 or xe.data_ptr() % 16 or edge_index.dtype != torch.int64 or x.size(0) * max(x.stride(0), 128) >= ops.FUSED_MAX_ELEMS:
+                or xe.stride(0) != 20 or xe.data_ptr() % 16 or x.size(0) * max(x.stride(0), 128) >= ops.FUSED_MAX_ELEMS:
             return None
         dec = self.decoder if self.clf.model.decoder else ()
         if len(dec) not in (0, 4) or (len(dec) == 4 and not (isinstance(dec[0], nn.Linear) and isinstance(dec[3], nn.Linear)
@@ -382,6 +380,19 @@ class SurfaceNet(nn.Module):
         if len(dec) == 4:
             s1, h1 = self._fold(dec[1], dec[0].out_features, x.device)
             decoder = (dec[0].weight, dec[0].bias, s1, h1, dec[3].weight, dec[3].bias)
+        return layers, decoder, prepared, with_dec
+
+    def _infer_one_call(self, x, xe, edge_index, plan):
+        """The whole eval forward -- plan (unless the caller's or a cached one exists), every conv layer, the decoder -- as ONE library call
+        (dgnn_static_infer_fwd issues the launches `_eval_layers` issues, in its order: bit-identical).  Returns the logits, or None when this
+        configuration runs layer by layer (`_one_call_tables`)."""
+        from ..graph import register_plan
+        if edge_index.dtype != torch.int64:
+            return None
+        tabs = self._one_call_tables(x, xe)
+        if tabs is None:
+            return None
+        layers, decoder, prepared, with_dec = tabs
         n = x.size(0)
         if plan is None:
             held = getattr(edge_index, "_dgnn_plans", None)       # a resident scene: the plan of an earlier call (plan_for's cache)
@@ -513,8 +524,10 @@ class SurfaceNet(nn.Module):
                 return self._eval_layer_bf16_unfused(conv, scale, shift, x, xe, plan, sorted_attr, out_v, rows)
             # row format of the output (ops.UROWS): a fused layer on fp32 feature rows starts the unsigned format, one on 16-bit rows keeps its input's;
             # a caller-supplied buffer names the format by its dtype
-            uns = (ops.BF16_UNSIGNED_ROWS and ops.BF16_MODE == ops.BF16_COMPENSATED and x.dtype != torch.bfloat16) if out_v is None else out_v.dtype == ops.UROWS
-            if x.dtype != torch.float32 and uns != (x.dtype == ops.UROWS):
+            # (the decoder-carrying launch writes fp32 logits: no row format to agree on)
+            uns = (ops.BF16_UNSIGNED_ROWS and ops.BF16_MODE == ops.BF16_COMPENSATED and x.dtype != torch.bfloat16) if (out_v is None or decode) \
+                else out_v.dtype == ops.UROWS
+            if not decode and x.dtype != torch.float32 and uns != (x.dtype == ops.UROWS):
                 raise ops.DgnnError("bf16 storage: layer %d reads %s rows but is asked to write %s rows" % (i, x.dtype, out_v.dtype))
             if sorted_attr and ops.EDGE_GATHER_IN_KERNEL and xe.stride(0) == 20 and xe.data_ptr() % 16 == 0:
                 ea, eid = xe, plan.eid

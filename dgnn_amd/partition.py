@@ -72,6 +72,8 @@ class LocalPart:
     send_idx: np.ndarray         # int64 [n_send] local ids of owned rows to send, grouped by destination rank
     send_counts: List[int]       # rows sent to each rank
     recv_counts: List[int]       # rows received from each rank (== sizes of the halo groups)
+    # ring form (build_ring_part): halo_gid = the cells 1, 2, ... hops from the owned set, ring after ring; nothing is sent or received
+    ring_counts: Optional[List[int]] = None
 
     @property
     def n_own(self):
@@ -115,6 +117,43 @@ def build_local_part(edge_index: np.ndarray, part: np.ndarray, rank: int, world:
     assert (e_loc >= 0).all()
     return LocalPart(rank, world, n, own_gid, n_interior, halo_gid, e_loc, e_sel.astype(np.int64), send_idx, send_counts,
                      recv_counts)
+
+
+def build_ring_part(edge_index: np.ndarray, part: np.ndarray, rank: int, world: int, hops: int) -> LocalPart:
+    """The part of `rank` with `hops` rings of halo cells and NO exchange: ring k = the cells k hops (along in-edges) from the owned set.  A stack of
+    `hops` conv layers computes layer l for the owned cells and rings 1 .. hops-1-l (LocalPart.ring_dst) -- the reference's k-hop recomputation
+    (learning/surfaceNetStaticEdgeFilters.py:232-275) applied to a whole part: every rank is independent of the others during a forward.
+    Local ids: owned cells (ascending global id: the scene's locality order carries over), ring 1, ring 2, ... (each ascending); `edge_index` holds
+    the in-edges of the owned cells and of rings 1 .. hops-1 (the cells some layer computes), grouped by local destination."""
+    src, dst = np.asarray(edge_index[0], np.int64), np.asarray(edge_index[1], np.int64)
+    n = part.shape[0]
+    have = part == rank
+    own_gid = np.nonzero(have)[0].astype(np.int64)
+    have = have.copy()
+    rings = []
+    for _ in range(hops):
+        new = np.unique(src[have[dst] & ~have[src]])
+        rings.append(new.astype(np.int64))
+        have[new] = True
+    halo_gid = np.concatenate(rings) if rings else np.zeros(0, np.int64)
+    loc = np.full(n, -1, dtype=np.int64)
+    loc[own_gid] = np.arange(own_gid.shape[0])
+    loc[halo_gid] = own_gid.shape[0] + np.arange(halo_gid.shape[0])
+    n_computed = own_gid.shape[0] + sum(r.shape[0] for r in rings[:-1])       # the outermost ring is only read
+    ld = loc[dst]
+    e_sel = np.nonzero((ld >= 0) & (ld < n_computed))[0]
+    e_sel = e_sel[np.argsort(ld[e_sel], kind="stable")]
+    e_loc = np.stack([loc[src[e_sel]], ld[e_sel]])
+    assert (e_loc >= 0).all()
+    zeros = [0] * world
+    return LocalPart(rank, world, n, own_gid, int(own_gid.shape[0]), halo_gid, e_loc, e_sel.astype(np.int64), np.zeros(0, np.int64), zeros, list(zeros),
+                     ring_counts=[int(r.shape[0]) for r in rings])
+
+
+def ring_dst(lp: LocalPart, num_layers: int) -> List[int]:
+    """destinations of layer l of a `num_layers`-deep stack on a ring part: owned cells + rings 1 .. num_layers-1-l"""
+    assert lp.ring_counts is not None and len(lp.ring_counts) >= num_layers, "the part was built with fewer rings than the model has conv layers"
+    return [lp.n_own + sum(lp.ring_counts[:num_layers - 1 - l]) for l in range(num_layers)]
 
 
 class HaloExchange:
@@ -268,6 +307,21 @@ class HaloExchange:
         return h_full
 
 
+class LoopbackExchange(HaloExchange):
+    """Timing stand-in for a single-process measurement of one rank's launch chain (tools/bench_partition_rank.py): the packed rows are copied
+    into the head of the halo tail on the side stream instead of travelling to a peer.  Not a transport: the halo rows are not the peers' rows."""
+
+    def __init__(self, lp: LocalPart, device, pack: Optional[Callable] = None):
+        super().__init__(lp, device, pack=pack, group=None, via_host=False)
+        self._native = None
+
+    def _post(self, h_full, send):
+        tail = h_full[self.n_own:]
+        k = min(send.size(0), tail.size(0))
+        if k:
+            tail[:k].copy_(send[:k])
+
+
 def run_partitioned_layers(lp: LocalPart, x_local: torch.Tensor, num_layers: int, layer_fn: Callable, decoder_fn: Callable,
                            exchange: HaloExchange, alloc: Callable, widths) -> torch.Tensor:
     """x_local [n_own + n_halo, F] (halo input rows included).  `layer_fn(i, h, out, b, e)` computes layer i for the owned
@@ -312,7 +366,8 @@ class PartitionedScene:
         self._xe_stripped = None
 
     @staticmethod
-    def build_synthetic(points: int, seed: int, rank: int, world: int, device, keep_global: bool = False, loader_order: bool = True) -> "PartitionedScene":
+    def build_synthetic(points: int, seed: int, rank: int, world: int, device, keep_global: bool = False, loader_order: bool = True,
+                        halo: str = "exchange", hops: int = 4) -> "PartitionedScene":
         """The seeded Delaunay scene of bench.py cut into `world` parts.  Rank 0 runs the tetrahedralisation and the
         coordinate bisection ONCE and broadcasts the adjacency column and the owner map (two int32 arrays) when a process
         group exists -- every rank repeating scipy.spatial.Delaunay on the whole scene costs minutes at 10M tets; without
@@ -350,7 +405,9 @@ class PartitionedScene:
         ei = np.empty((2, 4 * n), dtype=np.int64)
         ei[0] = np.repeat(np.arange(n, dtype=np.int64), 4)   # the reference layout: row 4t+r = (t, r-th neighbour)
         ei[1] = dst
-        lp = build_local_part(ei, part, rank, world)
+        # halo "recompute": `hops` rings of halo cells resident, every layer recomputed on the rings later layers read, no exchange (build_ring_part);
+        # "exchange": one ring, its rows exchanged between the layers (RCCL) -- the form the partitioned BACKWARD uses
+        lp = build_ring_part(ei, part, rank, world, hops) if halo == "recompute" else build_local_part(ei, part, rank, world)
         del ei
         rows = np.concatenate([lp.own_gid, lp.halo_gid])
         x_local = hashed_normal(rows, 29, seed=1, device=device)
@@ -363,9 +420,6 @@ class PartitionedScene:
     def inference_layer(self, net, rebuild_plan: bool = True) -> torch.Tensor:
         """Partitioned equivalent of SurfaceNet.inference_layer: logits [n_own, 2] of the owned tets."""
         n_src = self.n_own + self.n_halo
-        if self.plan is None or rebuild_plan:
-            self.plan = self._GraphPlan(self.edge_index, n_src, self.n_own, hint=1)  # local list is grouped by destination
-        plan = self.plan
         x = self.x_local[:, 1:] if net.clf.regularization.cell_type else self.x_local
         x = net._storage_input(x) if hasattr(net, "_storage_input") else x
         if net.clf.regularization.edge_type:
@@ -376,6 +430,14 @@ class PartitionedScene:
         else:
             xe = self.edge_attr
 
+        if self.lp.ring_counts is not None:
+            return self._infer_rings(net, x, xe, n_src, rebuild_plan)
+        one = self._infer_one_call(net, x, xe, n_src, rebuild_plan)
+        if one is not None:
+            return one
+        if self.plan is None or rebuild_plan:
+            self.plan = self._GraphPlan(self.edge_index, n_src, self.n_own, hint=1)  # local list is grouped by destination
+        plan = self.plan
         last = net.num_layers - 1
         # the last layer's launches carry the decoder when the model can do that (as the whole-graph inference_layer does: same kernel, so a
         # partitioned scene stays bit-identical to the whole graph); they then write logits [n_own, 2] instead of rows
@@ -399,6 +461,107 @@ class PartitionedScene:
             return torch.empty((r, c), dtype=dt, device=self.device)
         return run_partitioned_layers(self.lp, x, net.num_layers, layer_fn, (lambda lg: lg) if fuse else net._eval_decoder, self.exchange, alloc,
                                       widths=widths)
+
+
+def _partitioned_scene_infer_one_call(self, net, x, xe, n_src, rebuild_plan):
+    """The step as ONE library call (dgnn_static_infer_partitioned_fwd: plan, layer 0, [interior | wait | boundary] + exchange start per later layer,
+    decoder-carrying last launches) when the model's configuration has that form and the exchange is the library's own (RCCL; or there is none to
+    do: a single-rank part).  A strong-scaling shard is otherwise host-bound: 0.58 ms of interpreter time per step in front of 0.2 ms of GPU work
+    at 1/8 of the 1M-tet scene (tools/bench_partition_rank.py).  None: the per-layer chain below runs (any other transport, bf16 storage, hooks)."""
+    from . import ops
+    self.used_one_call = False
+    if not getattr(self, "one_call", True) or getattr(net, "_one_call_tables", None) is None:
+        return None
+    ex = self.exchange
+    if type(ex) is not HaloExchange or (ex.active and ex._native is None) or ex._pending:
+        return None
+    tabs = net._one_call_tables(x, xe)
+    if tabs is None:
+        return None
+    layers, decoder, prepared, with_dec = tabs
+    if with_dec and not net._fusable_rows(x, net.num_layers - 1):      # (the per-layer chain runs layer and decoder apart there: stay identical to it)
+        return None
+    halo = comm = sbuf = None
+    if ex.active:
+        _, comm, halo = ex._native
+        maxw = max(int(l[2].size(0)) for l in layers)
+        nbytes = max(1, int(sum(self.lp.send_counts)) * maxw * 4)
+        sbuf = getattr(self, "_one_call_sbuf", None)
+        if sbuf is None or sbuf.numel() < nbytes:
+            sbuf = self._one_call_sbuf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+    build = self.plan is None or rebuild_plan
+    parts = None if build else (self.plan.rowptr, self.plan.src, self.plan.eid)
+    out = ops.static_infer_partitioned_fwd(x, xe, self.edge_index, parts, self.n_own, self.lp.n_interior, layers, decoder, prepared, halo=halo, comm=comm,
+                                           send_buf=sbuf, fuse_decoder=with_dec)
+    if out is None:
+        return None
+    if build:
+        self.plan = self._GraphPlan(self.edge_index, n_src, self.n_own, hint=1, parts=out[1])
+    self.used_one_call = True
+    return out[0]
+
+
+PartitionedScene._infer_one_call = _partitioned_scene_infer_one_call
+
+
+def _partitioned_scene_infer_rings(self, net, x, xe, n_src, rebuild_plan):
+    """Forward of a ring part (build_ring_part): layer l over the owned cells and the rings that later layers still read; no exchange.  One library call
+    (dgnn_static_infer_rings_fwd) where the model's configuration has that form, else the per-layer entry points over the same destination prefixes."""
+    from . import ops
+    lp, L = self.lp, net.num_layers
+    nd = ring_dst(lp, L)
+    self.used_one_call = False
+    build = self.plan is None or rebuild_plan
+    last = L - 1
+    fuse = bool(getattr(net, "fuses_decoder", lambda i: False)(last)) and net._fusable_rows(x, last)
+    tabs = net._one_call_tables(x, xe) if (getattr(self, "one_call", True) and getattr(net, "_one_call_tables", None) is not None) else None
+    if tabs is not None and (not tabs[3] or fuse):
+        layers, decoder, prepared, with_dec = tabs
+        parts = None if build else (self.plan.rowptr, self.plan.src, self.plan.eid)
+        out = ops.static_infer_rings_fwd(x, xe, self.edge_index, parts, nd, layers, decoder, prepared, fuse_decoder=with_dec)
+        if out is not None:
+            if build:
+                self.plan = self._GraphPlan(self.edge_index, n_src, nd[0], hint=1, parts=out[1])
+            self.used_one_call = True
+            return out[0]
+    if build:
+        self.plan = self._GraphPlan(self.edge_index, n_src, nd[0], hint=1)
+    plan = self.plan
+    act = getattr(net, "activation_dtype", None)
+    h = x
+    for i in range(L):
+        dec = fuse and i == last
+        dt = torch.float32 if dec else (act(i, x.dtype) if act is not None else getattr(net, "storage_dtype", torch.float32))
+        out = torch.empty((nd[i], 2 if dec else net.clf.model.convs[i]), dtype=dt, device=self.device)
+        h = net._eval_layers(h, nd[i], xe, [plan] * L, False, only=i, out=out, rows=(0, nd[i]), decode=dec)
+    return h if fuse else net._eval_decoder(h[:self.n_own])
+
+
+PartitionedScene._infer_rings = _partitioned_scene_infer_rings
+
+
+def build_self_halo_part(edge_index: np.ndarray, n: int, remote: np.ndarray) -> LocalPart:
+    """A single-rank part that is ITS OWN PEER (RCCL allows self send / recv inside a group): the cells `remote` are ALSO held as halo rows -- every
+    edge leaving one of them reads the halo copy, which the exchange fills from the owned row.  Its partitioned forward must equal the whole
+    scene's bit for bit, so the full RCCL path (plan of the local graph, interior / boundary launches, the library's exchange, decoder) can be
+    validated on one GPU (tests/test_gpu_infer.py) and timed (tools/bench_partition_rank.py)."""
+    src, dst = np.asarray(edge_index[0], np.int64), np.asarray(edge_index[1], np.int64)
+    remote = np.unique(np.asarray(remote, np.int64))
+    is_remote = np.zeros(n, dtype=bool)
+    is_remote[remote] = True
+    cut = is_remote[src]
+    boundary = is_remote.copy()
+    boundary[dst[cut]] = True
+    own_gid = np.concatenate([np.nonzero(~boundary)[0], np.nonzero(boundary)[0]]).astype(np.int64)
+    loc = np.empty(n, dtype=np.int64)
+    loc[own_gid] = np.arange(n)
+    slot = np.full(n, -1, dtype=np.int64)
+    slot[remote] = n + np.arange(remote.shape[0])
+    e_sel = np.argsort(loc[dst], kind="stable")
+    e_src = np.where(cut[e_sel], slot[src[e_sel]], loc[src[e_sel]])
+    k = int(remote.shape[0])
+    return LocalPart(0, 1, n, own_gid, int(np.count_nonzero(~boundary)), remote.copy(), np.stack([e_src, loc[dst[e_sel]]]), e_sel.astype(np.int64),
+                     loc[remote], [k], [k])
 
 
 def _partitioned_scene_train_forward(self, net, group=None):

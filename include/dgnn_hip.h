@@ -356,6 +356,26 @@ int dgnn_static_infer_fwd(const int64_t* edge_index, int64_t stride_row, int64_t
                           void* workspace, float* logits, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * One rank's part of a scene cut across GPUs, ONE call per step and NO data-path exchange.  Behind its owned cells the part holds the
+ * rings of cells 1 .. L hops away (L = n_layers; their input rows are static and resident), and layer l is computed for the owned cells and the
+ * rings up to L-1-l hops out -- the reference's own k-hop recomputation (learning/surfaceNetStaticEdgeFilters.py:232-275, one sampled batch at a
+ * time) applied to a whole part.  Local cell order: owned cells, ring 1, ring 2, ...; the local edge list holds the in-edges of every cell that some
+ * layer computes (owned + rings 1 .. L-1), sources < n_loc.
+ *   n_dst [n_layers]  destinations of layer l = the first n_dst[l] local cells (non-increasing; n_dst[L-1] = the owned cells = rows of `logits`);
+ *                     the plan (built when edge_index != NULL) covers n_dst[0] destinations, n_loc = all local cells incl. the outermost ring
+ *   attr_in_plan_order != 0: edge_attr rows are grouped by destination already (a part's local list is): read in place, not through eid
+ * Everything else as dgnn_static_infer_fwd (which is this call with every n_dst[l] = n).  A cell's result does not depend on which other cells
+ * share its launch: the union of the ranks' logits is bit-identical to the whole scene's.  workspace: dgnn_static_infer_workspace_bytes(n_dst[0], ...).
+ * ---------------------------------------------------------------------------------------------- */
+int dgnn_static_infer_rings_fwd(const int64_t* edge_index, int64_t stride_row, int64_t stride_col, int64_t E, int plan_hint, int32_t* rowptr,
+                                int32_t* src, int32_t* eid, int32_t* plan_scratch, int attr_in_plan_order, int64_t n_loc, const int64_t* n_dst,
+                                const float* x, int64_t ldx, const float* edge_attr, int64_t lde, int f_e, int n_layers, const int32_t* widths,
+                                const float* const* We, const float* const* be, const float* const* Wj, const float* const* bj,
+                                const float* const* Wi, const float* const* scale, const float* const* shift, const void* const* prepared,
+                                const float* W0, const float* b0, const float* scale1, const float* shift1, int c_hidden, const float* W3,
+                                const float* b3, int n_logits, int fuse_decoder, int gemm_mode, void* workspace, float* logits, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Training-mode conv layer, one call each way (SurfaceNet.forward :214-219 and its autograd, learning/runModel.py:279):
  *   forward : a = aggregate(x)  ->  z = a.Wj^T + x[:n_dst].Wi^T + bj  ->  BatchNorm1d with batch statistics (running buffers
  *             updated when given)  ->  y = relu(.)       rowptr == NULL: a plain Linear + BatchNorm (+ReLU) block, z = x.Wj^T + bj
@@ -735,6 +755,31 @@ int64_t dgnn_halo_send_rows(const dgnn_halo_plan* plan);
 int64_t dgnn_halo_recv_rows(const dgnn_halo_plan* plan);
 int dgnn_halo_exchange_start(dgnn_halo_plan* plan, void* comm, void* x, int64_t ld, int C, int elem_bytes, void* send_buf, void* stream);
 int dgnn_halo_exchange_wait(dgnn_halo_plan* plan, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * One rank's part of a scene cut across GPUs, ONE call per step (what replaces the reference's k-hop recomputation at
+ * learning/surfaceNetStaticEdgeFilters.py:232-275 for a scene larger than -- or, strong scaling, spread over more than -- one GPU).
+ * dgnn_static_infer_fwd for the LOCAL bipartite graph of a part: n_own owned cells (the first n_interior of them neither read a halo row nor are
+ * sent to a peer) + n_halo halo rows behind them; x [n_own + n_halo, widths[0]] with the halo's input rows resident; the local edge list has
+ * destinations < n_own and sources < n_own + n_halo.  Launch chain (dgnn_amd/partition.py run_partitioned_layers, now inside the library):
+ *   plan of the local graph (edge_index != NULL; n_key = n_own, n_other = n_own + n_halo) -> layer 0 over the owned cells ->
+ *   per layer l >= 1: interior cells [0, n_interior) | dgnn_halo_exchange_wait | boundary cells [n_interior, n_own)
+ *   behind every layer but the last: dgnn_halo_exchange_start on its output rows [n_own + n_halo, widths[l+1]] (fp32, packed)
+ *   last layer: both launches carry the decoder where dgnn_static_infer_fwd's would; logits [n_own, n_logits]
+ * attr_in_plan_order != 0: edge_attr rows are already grouped by destination (a part's local list is): the layers read them in place, eid is
+ * only written by the plan build.  halo == NULL (n_halo must be 0): a single-rank part, no exchange.  send_buf: dgnn_halo_send_rows(halo) *
+ * max(widths[1..L-1]) * 4 bytes.  workspace: dgnn_static_infer_workspace_bytes(n_own + n_halo, n_layers, widths).  Same kernels, ranges and
+ * order as the per-layer calls: the union of the ranks' logits is bit-identical to dgnn_static_infer_fwd on the whole scene.
+ * Nothing allocates or synchronises; DGNN_E_UNSUPPORTED before anything is launched for shapes outside the fused kernels.
+ * ---------------------------------------------------------------------------------------------- */
+int dgnn_static_infer_partitioned_fwd(const int64_t* edge_index, int64_t stride_row, int64_t stride_col, int64_t E, int plan_hint, int32_t* rowptr,
+                                      int32_t* src, int32_t* eid, int32_t* plan_scratch, int attr_in_plan_order, int64_t n_own, int64_t n_interior,
+                                      int64_t n_halo, const float* x, int64_t ldx, const float* edge_attr, int64_t lde, int f_e, int n_layers,
+                                      const int32_t* widths, const float* const* We, const float* const* be, const float* const* Wj,
+                                      const float* const* bj, const float* const* Wi, const float* const* scale, const float* const* shift,
+                                      const void* const* prepared, const float* W0, const float* b0, const float* scale1, const float* shift1,
+                                      int c_hidden, const float* W3, const float* b3, int n_logits, int fuse_decoder, int gemm_mode,
+                                      dgnn_halo_plan* halo, void* comm, void* send_buf, void* workspace, float* logits, void* stream);
 
 /* elementwise helpers used by the Updated variant (F.relu at surfaceNetUpdatedEdgeFilters.py:239-241
  * and the scatter of phi rows into the zero [E_all,C] buffer at :236-237) */

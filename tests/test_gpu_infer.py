@@ -2,6 +2,7 @@
 per-layer entry points issue, so its logits must be BIT-IDENTICAL to the layer-by-layer path -- which the other suites hold to the oracle and
 to the reference's golden logits -- on every graph shape, plan source and arithmetic mode; plus the oracle directly on one scene."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -181,3 +182,100 @@ def test_ignatius_full_scene_one_call_vs_reference_logits():
     one, ref = _both_paths(net, data)
     assert torch.equal(one, ref)
     logit_check(one.cpu().numpy(), g["logits"], g["logits64"])
+
+
+# ---- one rank's part of a partitioned scene in one call, the library's RCCL exchange inside it -----------------------------------------------------
+def _self_halo_worker(rank, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    from dgnn_amd.partition import HaloExchange, PartitionedScene, build_self_halo_part
+    from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal
+    net = hip_static()
+    for points, frac in ((3000, 0.04), (700, 0.5), (2000, 0.0)):
+        adj, cent, _ = delaunay_tet_graph(points, seed=points)
+        n = adj.shape[0] // 4
+        ei = adj.T.astype(np.int64)
+        x = hashed_normal(np.arange(n), 29, seed=1, device=DEV)
+        ea = hashed_normal(np.arange(4 * n), 20, seed=2, device=DEV)
+        full = net.inference_layer(Config(x=x, edge_attr=ea, edge_index=torch.from_numpy(ei).to(DEV)))
+        # cells in a slab of the scene are ALSO held as halo rows, filled by the library's exchange from the rank's own rows (its own peer)
+        lo = np.quantile(cent[:, 0], 0.5 - frac / 2)
+        hi = np.quantile(cent[:, 0], 0.5 + frac / 2)
+        remote = np.nonzero((cent[:, 0] >= lo) & (cent[:, 0] < hi))[0] if frac else np.zeros(0, np.int64)
+        lp = build_self_halo_part(ei, n, remote)
+        assert lp.n_halo == remote.shape[0] and (frac == 0 or 0 < lp.n_interior < lp.n_own)
+        rows = np.concatenate([lp.own_gid, lp.halo_gid])
+        scene = PartitionedScene(lp, x[torch.from_numpy(rows).to(DEV)], ea[torch.from_numpy(lp.edge_gid).to(DEV)], DEV)
+        # the halo's INPUT rows are resident (layer 0 needs no exchange); every later layer's halo rows arrive through RCCL
+        assert type(scene.exchange) is HaloExchange and (scene.exchange._native is not None) == (frac > 0)
+        gid = torch.from_numpy(lp.own_gid).to(DEV)
+        for one_call in (True, False, True):
+            scene.one_call = one_call
+            for rebuild in (True, False):
+                logits = scene.inference_layer(net, rebuild_plan=rebuild)
+                assert scene.used_one_call == one_call
+                got = torch.empty_like(full)
+                got[gid] = logits
+                assert torch.equal(got, full), (points, frac, one_call, rebuild)
+    torch.cuda.synchronize()
+    open(os.path.join(out_dir, "ok"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+def test_partitioned_one_call_with_rccl_self_exchange_equals_whole_scene(tmp_path):
+    """dgnn_static_infer_partitioned_fwd on a part that is its own peer: plan of the local graph, interior / boundary launches, the library's RCCL exchange
+    between the layers, decoder-carrying last launches -- bit-identical to the whole scene, and to the per-layer chain it replaces."""
+    import socket
+    import torch.multiprocessing as mp
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    mp.spawn(_self_halo_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), "ok"))
+
+
+# ---- ring parts: a scene cut across ranks with NO exchange (every rank recomputes the rings of halo cells later layers read) -------------------------
+@pytest.mark.parametrize("world,storage", [(2, "f32"), (8, "f32"), (3, "bf16")])
+def test_ring_parts_union_equals_whole_scene(world, storage):
+    """dgnn_static_infer_rings_fwd / the per-layer chain over the same destination prefixes: rank after rank on the one GPU (the ranks are independent:
+    this IS the multi-GPU computation), union of the logits == the whole scene's, bit for bit."""
+    from dgnn_amd.partition import PartitionedScene, build_ring_part, rcb_partition, ring_dst
+    from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal, loader_cell_order
+    adj, cent, _ = delaunay_tet_graph(5000, seed=11)
+    adj, cent, _ = loader_cell_order(adj, cent)
+    n = adj.shape[0] // 4
+    ei = adj.T.astype(np.int64)
+    x = hashed_normal(np.arange(n), 29, seed=1, device=DEV)
+    ea = hashed_normal(np.arange(4 * n), 20, seed=2, device=DEV)
+    net = hip_static()
+    if storage == "bf16":
+        net.set_storage_dtype(torch.bfloat16)
+    full = net.inference_layer(Config(x=x, edge_attr=ea, edge_index=torch.from_numpy(ei).to(DEV)))
+    part = rcb_partition(cent, world)
+    for one_call in ((True, False) if storage == "f32" else (False,)):
+        got = torch.full_like(full, float("nan"))
+        for rank in range(world):
+            lp = build_ring_part(ei, part, rank, world, net.num_layers)
+            assert 0 < lp.n_halo and ring_dst(lp, 4)[3] == lp.n_own
+            rows = np.concatenate([lp.own_gid, lp.halo_gid])
+            scene = PartitionedScene(lp, x[torch.from_numpy(rows).to(DEV)], ea[torch.from_numpy(lp.edge_gid).to(DEV)], DEV)
+            scene.one_call = one_call
+            for rebuild in (True, False):
+                logits = scene.inference_layer(net, rebuild_plan=rebuild)
+                assert scene.used_one_call == one_call and logits.shape == (lp.n_own, 2)
+            got[torch.from_numpy(lp.own_gid).to(DEV)] = logits
+        assert torch.equal(got, full), (world, storage, one_call)
+
+
+def test_static_infer_rings_c_abi_rejects_growing_destination_counts():
+    from dgnn_amd import ops
+    from dgnn_amd._lib import lib, ptr
+    L = 4
+    widths = (C.c_int32 * (L + 1))(28, 64, 128, 128, 128)
+    nd = (C.c_int64 * L)(10, 12, 8, 8)
+    t = torch.zeros(64, device=DEV)
+    arr = (C.c_void_p * L)(*[t.data_ptr()] * L)
+    i32 = torch.zeros(64, dtype=torch.int32, device=DEV)
+    rc = lib().dgnn_static_infer_rings_fwd(None, 0, 0, 40, 1, ptr(i32), ptr(i32), None, None, 1, 16, nd, ptr(t), 28, ptr(t), 20, 20, L, widths, arr, arr, arr, arr, arr,
+                                           arr, arr, None, None, None, None, None, 0, None, None, 0, 0, ops.GEMM_F16X2, ptr(t), ptr(t), None)
+    assert rc == -1      # DGNN_E_INVALID (include/dgnn_hip.h)

@@ -35,12 +35,13 @@ def torchrun(script, args, nproc=2, timeout=900):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("scaling", ["strong", "weak"])
-def test_bench_py_two_ranks_as_the_driver_launches_it(scaling):
+@pytest.mark.parametrize("scaling,halo", [("strong", "recompute"), ("weak", "recompute"), ("strong", "exchange")])
+def test_bench_py_two_ranks_as_the_driver_launches_it(scaling, halo):
     """bench.py --gpus 2: ONE JSON line from rank 0, the contract's keys, and a `check` at N > 1: the logits of both ranks' cells, gathered on rank 0,
     are bit-identical to the same scene run as one whole graph by a single rank and agree with the CPU oracle; the other scaling mode is nested
     with its own check."""
-    d = torchrun("bench.py", ["--gpus", "2", "--scaling", scaling, "--steps", "2", "--warmup", "1", "--no-train", "--points", "30000"])
+    d = torchrun("bench.py", ["--gpus", "2", "--scaling", scaling, "--steps", "2", "--warmup", "1", "--no-train", "--points", "30000"] +
+                 (["--halo", halo] if halo != "recompute" else []))       # (recompute = rings of halo cells, no exchange: the default)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "check", "other_scaling"):
         assert k in d, k
@@ -53,7 +54,9 @@ def test_bench_py_two_ranks_as_the_driver_launches_it(scaling):
     assert c["vs_cpu_oracle"]["ok"] and c["vs_cpu_oracle"]["max_abs_err"] <= 1e-4
     o = d["other_scaling"]
     assert o["scaling"] == ("weak" if scaling == "strong" else "strong") and o["check"]["ok"] and o["check"]["bit_identical_to_single_rank"]
-    assert "host-staged gloo" in d["config"]["workload"]          # says what it was: a validation run, not a benchmark
+    # says what it was: a validation run, not a benchmark
+    assert ("host-staged gloo" if halo == "exchange" else "validation run under gloo") in d["config"]["workload"]
+    assert ("no collective in the data path" in d["config"]["workload"]) == (halo == "recompute")
     assert 0.2 < d["config"]["tets_per_gpu"] / (n_main / 2) < 1.8
 
 

@@ -60,6 +60,56 @@ def test_rcb_and_local_part_structure():
                 so += ns
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_ring_part_structure_and_oracle_forward_without_exchange(world):
+    """build_ring_part: L rings of halo cells, layer l over the owned cells + rings 1 .. L-1-l, no exchange at all.  Structure, and the CPU oracle's
+    layers run over those destination prefixes: the union of the ranks' logits equals the whole scene's."""
+    from dgnn_amd.partition import build_ring_part, ring_dst
+    adj, cent, x, ea = _scene()
+    n = adj.shape[0] // 4
+    ei = adj.T.astype(np.int64)
+    part = rcb_partition(cent, world)
+    torch.set_num_threads(1)
+    net = oracle_static()
+    L = net.num_layers
+    with torch.no_grad():
+        ref = net.inference_layer(Config(x=x, edge_attr=ea, edge_index=torch.from_numpy(ei))).numpy()
+    got = np.full_like(ref, np.nan)
+    for rank in range(world):
+        lp = build_ring_part(ei, part, rank, world, L)
+        nd = ring_dst(lp, L)
+        assert lp.n_interior == lp.n_own and sum(lp.send_counts) == 0 and sum(lp.recv_counts) == 0 and len(lp.ring_counts) == L
+        assert np.array_equal(lp.own_gid, np.nonzero(part == rank)[0]) and sum(lp.ring_counts) == lp.n_halo
+        assert nd[L - 1] == lp.n_own and nd[0] == lp.n_own + sum(lp.ring_counts[:L - 1]) and all(a >= b for a, b in zip(nd, nd[1:]))
+        gl = np.concatenate([lp.own_gid, lp.halo_gid])
+        assert len(np.unique(gl)) == len(gl)
+        # the in-edges of every computed cell, 4 each, grouped by destination in global edge order; sources of layer l's destinations lie inside
+        # what layer l-1 computed (the input rows for layer 0)
+        assert lp.edge_index.shape[1] == 4 * nd[0] and np.array_equal(lp.edge_index[1], np.repeat(np.arange(nd[0]), 4))
+        assert np.all(np.diff(lp.edge_gid.reshape(-1, 4), axis=1) > 0)
+        assert np.array_equal(gl[lp.edge_index[0]], ei[0][lp.edge_gid]) and np.array_equal(gl[lp.edge_index[1]], ei[1][lp.edge_gid])
+        reach = [lp.n_own + lp.n_halo] + nd
+        for l in range(L):
+            assert lp.edge_index[0][:4 * nd[l]].max() < reach[l]
+        # ring k is exactly k hops out
+        off = lp.n_own
+        dist_k = np.full(n, -1); dist_k[lp.own_gid] = 0
+        for k in range(1, L + 1):
+            nb = np.unique(ei[0][(dist_k[ei[1]] == k - 1) & (dist_k[ei[0]] < 0)])
+            dist_k[nb] = k
+            assert np.array_equal(nb, gl[off:off + lp.ring_counts[k - 1]])
+            off += lp.ring_counts[k - 1]
+        h = x[torch.from_numpy(gl)][:, 1:]
+        ea_local = ea[torch.from_numpy(lp.edge_gid)]
+        e_loc = torch.from_numpy(lp.edge_index)
+        with torch.no_grad():
+            for i in range(L):
+                blk = net.convs[i]
+                h = blk[2](blk[1](blk[0]((h, h[:nd[i]]), ea_local[:4 * nd[i]], e_loc[:, :4 * nd[i]])))
+            got[lp.own_gid] = net.decoder(h).numpy()
+    assert not np.isnan(got).any() and np.abs(got - ref).max() <= 1e-5
+
+
 def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
