@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) k_colreduce(const T* __restrict__ x, int6
     }
 }
 
-// Rows of a power-of-two number of channels (fp32: 4..256, bf16: 8..256) with 16-byte aligned rows: every thread walks V = 16 / sizeof(T)
+// Rows of a power-of-two number of channels (fp32: 4..256, bf16: 8..512) or a multiple of that window (round 4: 512, 1024, ...) with 16-byte aligned rows: every thread walks V = 16 / sizeof(T)
 // columns with 16-byte loads (256 threads = c/V column groups x 256 V / c row lanes).  The scalar kernel above keeps one element load per
 // row in flight per lane and ran the training step's 15 column reductions at 1.4-2.7 TB/s.  Same partials layout; sums are fp64, so the
 // different association order is invisible after the rounding to fp32 except at exact ties.
@@ -76,66 +76,76 @@ __global__ void __launch_bounds__(256) k_colreduce4(const T* __restrict__ x, int
                                                     const float* __restrict__ var, float eps, int relu, int64_t M, int c,
                                                     int64_t rows_per_block, double* __restrict__ partials) {
     constexpr int V = RowPiece<T>::V;
-    __shared__ double red[2][256 * V];   // [quantity][row lane][column], nrl * c = 256 V
-    const int ng = c / V, nrl = 256 / ng;
-    const int tg = threadIdx.x % ng, ty = threadIdx.x / ng, col = V * tg;
+    constexpr int CW = 64 * V;            // widest column window: 64 column groups x 4 row lanes (fp32: 256 columns, bf16: 512)
+    __shared__ double red[2][256 * V];   // [quantity][row lane][column of the window], nrl * cw = 256 V
+    // rows wider than the window (the reference's training widths 512 / 1024): one window = a 1 KB piece of the row per blockIdx.y
+    const int cw = c < CW ? c : CW;
+    const int ng = cw / V, nrl = 256 / ng;
+    const int tg = threadIdx.x % ng, ty = threadIdx.x / ng;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = min(M, r0 + rows_per_block);
-    double s0[V], s1[V];
-    float mu[V], is[V];
+    {
+        const int cb = blockIdx.y * cw;      // one window per blockIdx.y: a [1024 x 1024] matrix (the last layers of a small batch) still fills the chip
+        const int col = cb + V * tg;
+        double s0[V], s1[V];
+        float mu[V], is[V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-        s0[j] = s1[j] = 0.0;
-        mu[j] = 0.f;
-        is[j] = 1.f;
-        if (MODE == 1) {
-            mu[j] = mean[col + j];
-            is[j] = 1.0f / sqrtf(var[col + j] + eps);
-        }
-    }
-    for (int64_t r = r0 + ty; r < r1; r += nrl) {
-        RowPiece<T> xv;
-        xv.load(x + r * ldx + col);
-        if (MODE == 0) {
-#pragma unroll
-            for (int j = 0; j < V; ++j) {
-                const float v = xv.get(j);
-                s0[j] += v;
-                s1[j] += (double)v * v;
+        for (int j = 0; j < V; ++j) {
+            s0[j] = s1[j] = 0.0;
+            mu[j] = 0.f;
+            is[j] = 1.f;
+            if (MODE == 1) {
+                mu[j] = mean[col + j];
+                is[j] = 1.0f / sqrtf(var[col + j] + eps);
             }
-        } else if (MODE == 1) {
-            RowPiece<T> gv, yv;
-            gv.load(dy + r * lddy + col);
-            if (relu) yv.load(y + r * ldy + col);
-#pragma unroll
-            for (int j = 0; j < V; ++j) {
-                float g = gv.get(j);
-                if (relu && !(yv.get(j) > 0.f)) g = 0.f;
-                const float xh = (xv.get(j) - mu[j]) * is[j];
-                s0[j] += g;
-                s1[j] += (double)g * xh;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < V; ++j) s0[j] += xv.get(j);
         }
-    }
+        for (int64_t r = r0 + ty; r < r1; r += nrl) {
+            RowPiece<T> xv;
+            xv.load(x + r * ldx + col);
+            if (MODE == 0) {
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-        red[0][ty * c + col + j] = s0[j];
-        red[1][ty * c + col + j] = s1[j];
-    }
-    __syncthreads();
-    for (int o = threadIdx.x; o < 2 * c; o += 256) {
-        const int q = o / c, cc = o - q * c;
-        double t = 0.0;
-        for (int k = 0; k < nrl; ++k) t += red[q][k * c + cc];
-        partials[((int64_t)blockIdx.x * 2 + q) * c + cc] = t;
+                for (int j = 0; j < V; ++j) {
+                    const float v = xv.get(j);
+                    s0[j] += v;
+                    s1[j] += (double)v * v;
+                }
+            } else if (MODE == 1) {
+                RowPiece<T> gv, yv;
+                gv.load(dy + r * lddy + col);
+                if (relu) yv.load(y + r * ldy + col);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    float g = gv.get(j);
+                    if (relu && !(yv.get(j) > 0.f)) g = 0.f;
+                    const float xh = (xv.get(j) - mu[j]) * is[j];
+                    s0[j] += g;
+                    s1[j] += (double)g * xh;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < V; ++j) s0[j] += xv.get(j);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            red[0][ty * cw + V * tg + j] = s0[j];
+            red[1][ty * cw + V * tg + j] = s1[j];
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o < 2 * cw; o += 256) {
+            const int q = o / cw, cc = o - q * cw;
+            double t = 0.0;
+            for (int k = 0; k < nrl; ++k) t += red[q][k * cw + cc];
+            partials[((int64_t)blockIdx.x * 2 + q) * c + cb + cc] = t;
+        }
     }
 }
 
 template <typename T>
-inline bool colreduce4_ok(int c) { return c >= (int)(16 / sizeof(T)) && c <= 256 && (c & (c - 1)) == 0; }
+inline bool colreduce4_ok(int c) {
+    constexpr int V = 16 / sizeof(T);
+    return c >= V && ((c <= 64 * V && (c & (c - 1)) == 0) || c % (64 * V) == 0);
+}
 
 // Deterministic two-level finalisers: 1024 threads = 16 columns x 64 slices; slice s sums partial blocks s, s+64, ... in
 // ascending order, then the 64 slice sums are added in slice order.  (A single thread per column walking all ~1000 partial
@@ -284,7 +294,7 @@ static void launch_colreduce(int nblk, hipStream_t stream, const T* x, int64_t l
     constexpr int V = 16 / sizeof(T);
     auto al = [](const void* p, int64_t ld) { return p == nullptr || ((((uintptr_t)p) & 15) == 0 && ld % V == 0); };
     if (colreduce4_ok<T>(c) && al(x, ldx) && al(y, ldy) && al(dy, lddy)) {
-        hipLaunchKernelGGL((k_colreduce4<MODE, T>), dim3(nblk), dim3(256), 0, stream, x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, rpb, P);
+        hipLaunchKernelGGL((k_colreduce4<MODE, T>), dim3(nblk, c > 64 * V ? c / (64 * V) : 1), dim3(256), 0, stream, x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, rpb, P);
         return;
     }
     hipLaunchKernelGGL((k_colreduce<MODE, T>), dim3(nblk), dim3(256), 0, stream, x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, rpb, P);
