@@ -354,13 +354,24 @@ class SurfaceNet(nn.Module):
         return self._eval_decoder(x)
 
     def _one_call_tables(self, x, xe):
-        """What dgnn_static_infer_fwd / dgnn_static_infer_partitioned_fwd take for this model: (layers, decoder, prepared, with_dec) -- or None when
-        this configuration runs layer by layer: other storage / widths / filters, a per-layer profiling hook, rows the fused kernels do not take."""
+        """What dgnn_static_infer_fwd / dgnn_static_infer_rings_fwd / dgnn_static_infer_partitioned_fwd take for this model: (layers, decoder, prepared,
+        with_dec, cache) -- or None when this configuration runs layer by layer: other storage / widths / filters, a per-layer profiling hook, rows the
+        fused kernels do not take.  `cache`: a dict the ops wrappers keep their argument tables (ctypes arrays of the tensors' addresses) in.
+        Walking the module tree (nn.Module.__getattr__, Sequential.__getitem__: ~180 lookups) was 70 % of a 0.14 ms call on a reconbench-size scene,
+        so the tables are kept until one of the tensors they were made from is written to or moved: the (address, version) pairs of the parameters
+        and BatchNorm buffers -- read through the modules found on the first call -- are the key (load_state_dict, optimizer steps, .to(), train-mode
+        running statistics all change it).  Replacing a sub-MODULE of a built model is not seen: call `invalidate_caches()` after such surgery."""
         if not (ops.INFER_ONE_CALL and ops.FUSED_ENABLED and ops.EDGE_GATHER_IN_KERNEL) or ops.LAYER_HOOK is not None:
             return None
         if self.storage_dtype != torch.float32 or x.dtype != torch.float32 or xe.dtype != torch.float32 or xe.dim() != 2 or xe.size(1) != 20 \
                 or xe.stride(0) != 20 or xe.data_ptr() % 16 or x.size(0) * max(x.stride(0), 128) >= ops.FUSED_MAX_ELEMS:
             return None
+        hit = self.__dict__.get("_oc_tables")
+        if hit is not None:
+            mods, key, tabs = hit
+            if key == (self._oc_key(mods), ops.GEMM_MODE, ops.PREPARED_PARAMS, ops.FUSE_DECODER, x.device):
+                return tabs
+        mods = []            # every module a tensor of the tables comes from
         dec = self.decoder if self.clf.model.decoder else ()
         if len(dec) not in (0, 4) or (len(dec) == 4 and not (isinstance(dec[0], nn.Linear) and isinstance(dec[3], nn.Linear)
                                                               and (dec[1] is None or isinstance(dec[1], BatchNorm)))):
@@ -376,11 +387,34 @@ class SurfaceNet(nn.Module):
             scale, shift = self._fold(layer[1], conv.lin_j.out_features, x.device)
             layers.append((le.weight, le.bias, conv.lin_j.weight, conv.lin_j.bias, conv.lin_i.weight, scale, shift))
             prepared.append(self._prepared(i, with_dec and i == last))
+            mods += [le, conv.lin_j, conv.lin_i] + ([layer[1].module] if layer[1] is not None else [])
         decoder = None
         if len(dec) == 4:
             s1, h1 = self._fold(dec[1], dec[0].out_features, x.device)
             decoder = (dec[0].weight, dec[0].bias, s1, h1, dec[3].weight, dec[3].bias)
-        return layers, decoder, prepared, with_dec
+            mods += [dec[0], dec[3]] + ([dec[1].module] if dec[1] is not None else [])
+        tabs = (layers, decoder, prepared, with_dec, {})
+        self.__dict__["_oc_tables"] = (mods, (self._oc_key(mods), ops.GEMM_MODE, ops.PREPARED_PARAMS, ops.FUSE_DECODER, x.device), tabs)
+        return tabs
+
+    @staticmethod
+    def _oc_key(mods):
+        key = []
+        for m in mods:
+            for t in m._parameters.values():
+                if t is not None:
+                    key.append(t.data_ptr())
+                    key.append(t._version)
+            for t in m._buffers.values():
+                if t is not None:
+                    key.append(t.data_ptr())
+                    key.append(t._version)
+        return key
+
+    def invalidate_caches(self):
+        """Forget everything derived from the parameters (folded BatchNorm, prepared layer blocks, the one-call tables): after replacing a sub-module."""
+        for k in ("_oc_tables", "_fold_cache", "_prep_cache"):
+            self.__dict__.pop(k, None)
 
     def _infer_one_call(self, x, xe, edge_index, plan):
         """The whole eval forward -- plan (unless the caller's or a cached one exists), every conv layer, the decoder -- as ONE library call
@@ -392,14 +426,14 @@ class SurfaceNet(nn.Module):
         tabs = self._one_call_tables(x, xe)
         if tabs is None:
             return None
-        layers, decoder, prepared, with_dec = tabs
+        layers, decoder, prepared, with_dec, cache = tabs
         n = x.size(0)
         if plan is None:
             held = getattr(edge_index, "_dgnn_plans", None)       # a resident scene: the plan of an earlier call (plan_for's cache)
             if held:
                 plan = plan_for(edge_index, n, n, hint=ops.PLAN_HINT_REFERENCE)
         parts = None if plan is None else (plan.rowptr, plan.src, plan.eid)
-        out = ops.static_infer_fwd(x, xe, edge_index, parts, layers, decoder, prepared, fuse_decoder=with_dec)
+        out = ops.static_infer_fwd(x, xe, edge_index, parts, layers, decoder, prepared, fuse_decoder=with_dec, cache=cache)
         if out is None:
             return None
         if plan is None:

@@ -550,19 +550,38 @@ def sage_layer_fused_decoder_fwd(rowptr, src, n_dst, x_src, edge_attr, We, be, W
 INFER_ONE_CALL = __import__("os").environ.get("DGNN_INFER_ONE_CALL", "1") != "0"
 
 
+def _infer_tables(x_width, layers, decoder, prepared, cache):
+    """ctypes argument tables of the one-call entry points: (L, widths, 7 per-layer pointer arrays, prepared, the decoder's 8 scalars / addresses,
+    n_out); kept in `cache` (the model's, valid as long as the tensors are: SurfaceNet._one_call_tables) when one is given."""
+    import ctypes as C
+    if cache is not None:
+        hit = cache.get(x_width)
+        if hit is not None:
+            return hit
+    L = len(layers)
+    widths = [x_width] + [l[2].size(0) for l in layers]
+    w_arr = (C.c_int32 * (L + 1))(*widths)
+    cols = tuple((C.c_void_p * L)(*[(l[i].data_ptr() if l[i] is not None else None) for l in layers]) for i in range(7))
+    prep = (C.c_void_p * L)(*[(p.data_ptr() if p is not None else None) for p in prepared]) if prepared is not None else None
+    d = decoder if decoder is not None else (None,) * 6
+    dec = (ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), d[0].size(0) if d[0] is not None else 0, ptr(d[4]), ptr(d[5]), d[4].size(0) if d[4] is not None else 0)
+    out = (L, w_arr, cols, prep, dec, decoder[4].size(0) if decoder is not None else widths[-1])
+    if cache is not None:
+        cache[x_width] = out
+    return out
+
+
 @on_device_of
-def static_infer_fwd(x, edge_attr, edge_index, plan_parts, layers, decoder, prepared=None, hint=PLAN_HINT_REFERENCE, gemm_mode=None, fuse_decoder=True):
+def static_infer_fwd(x, edge_attr, edge_index, plan_parts, layers, decoder, prepared=None, hint=PLAN_HINT_REFERENCE, gemm_mode=None, fuse_decoder=True, cache=None):
     """-> (logits | last activations, plan parts) or None when a shape is outside the fused kernels (nothing launched).
     `plan_parts` = (rowptr, src, eid) of an existing plan, or None: the plan is built inside the call from `edge_index` (int64 [2,E], any strides)
     and its arrays are returned.  `layers`: per conv layer (We, be, Wj, bj, Wi, scale | None, shift | None); `decoder` = (W0, b0, scale1 | None,
     shift1 | None, W3, b3) or None; `prepared`: per-layer dgnn_sage_layer_prepare buffers or None; `fuse_decoder`: the last layer's launch carries the
-    decoder (prepared[-1] is then the block made WITH the decoder), else layer and decoder run apart."""
-    import ctypes as C
+    decoder (prepared[-1] is then the block made WITH the decoder), else layer and decoder run apart.  `cache`: see _infer_tables."""
     _req(x, "x", dim=2)
     _req(edge_attr, "edge_attr", dim=2)
-    n, dev, L = x.size(0), x.device, len(layers)
-    widths = [x.size(1)] + [l[2].size(0) for l in layers]
-    w_arr = (C.c_int32 * (L + 1))(*widths)
+    n, dev = x.size(0), x.device
+    L, w_arr, cols, prep, dec, n_out = _infer_tables(x.size(1), layers, decoder, prepared, cache)
     E = edge_index.size(1) if edge_index is not None else plan_parts[1].numel()
     build = plan_parts is None
     if build:
@@ -574,19 +593,12 @@ def static_infer_fwd(x, edge_attr, edge_index, plan_parts, layers, decoder, prep
     else:
         rowptr, src, eid = plan_parts
         scratch = None
-    n_out = decoder[4].size(0) if decoder is not None else widths[-1]
     logits = torch.empty((n, n_out), dtype=torch.float32, device=dev)
     work = torch.empty(int(lib().dgnn_static_infer_workspace_bytes(n, L, w_arr)), dtype=torch.uint8, device=dev)   # (the caching allocator hands out 512-byte aligned blocks)
-
-    def col(i):
-        return (C.c_void_p * L)(*[(l[i].data_ptr() if l[i] is not None else None) for l in layers])
-    prep = (C.c_void_p * L)(*[(p.data_ptr() if p is not None else None) for p in prepared]) if prepared is not None else None
-    d = decoder if decoder is not None else (None,) * 6
     rc = lib().dgnn_static_infer_fwd(
         ptr(edge_index) if build else None, edge_index.stride(0) if build else 0, edge_index.stride(1) if build else 0, E, hint, ptr(rowptr), ptr(src),
-        ptr(eid), ptr(scratch), n, ptr(x), _ld(x), ptr(edge_attr), _ld(edge_attr), edge_attr.size(1), L, w_arr, col(0), col(1), col(2), col(3), col(4),
-        col(5), col(6), prep, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), d[0].size(0) if d[0] is not None else 0, ptr(d[4]), ptr(d[5]),
-        d[4].size(0) if d[4] is not None else 0, int(bool(fuse_decoder)), GEMM_MODE if gemm_mode is None else gemm_mode, ptr(work), ptr(logits), stream_ptr())
+        ptr(eid), ptr(scratch), n, ptr(x), _ld(x), ptr(edge_attr), _ld(edge_attr), edge_attr.size(1), L, w_arr, *cols, prep, *dec, int(bool(fuse_decoder)),
+        GEMM_MODE if gemm_mode is None else gemm_mode, ptr(work), ptr(logits), stream_ptr())
     if rc == DGNN_E_UNSUPPORTED:
         return None
     check(rc, "dgnn_static_infer_fwd", poll=build)
@@ -595,17 +607,16 @@ def static_infer_fwd(x, edge_attr, edge_index, plan_parts, layers, decoder, prep
 
 @on_device_of
 def static_infer_rings_fwd(x, edge_attr, edge_index, plan_parts, n_dst, layers, decoder, prepared=None, hint=PLAN_HINT_GROUPED, gemm_mode=None, fuse_decoder=True,
-                           attr_in_plan_order=True):
+                           attr_in_plan_order=True, cache=None):
     """One rank's part of a partitioned scene, rings of halo cells recomputed instead of exchanged (dgnn_static_infer_rings_fwd; arguments as
     static_infer_fwd): x [n_loc, F] local rows (owned cells, ring 1, ring 2, ...), `edge_index` the local list (in-edges of the first n_dst[0] cells),
     n_dst[l] = destinations of layer l.  -> (logits [n_dst[-1], n_logits], plan parts) or None (nothing launched)."""
     import ctypes as C
     _req(x, "x", dim=2)
     _req(edge_attr, "edge_attr", dim=2)
-    n_loc, dev, L = x.size(0), x.device, len(layers)
+    n_loc, dev = x.size(0), x.device
+    L, w_arr, cols, prep, dec, n_out = _infer_tables(x.size(1), layers, decoder, prepared, cache)
     assert len(n_dst) == L
-    widths = [x.size(1)] + [l[2].size(0) for l in layers]
-    w_arr = (C.c_int32 * (L + 1))(*widths)
     nd_arr = (C.c_int64 * L)(*[int(v) for v in n_dst])
     E = edge_index.size(1) if edge_index is not None else plan_parts[1].numel()
     build = plan_parts is None
@@ -618,20 +629,12 @@ def static_infer_rings_fwd(x, edge_attr, edge_index, plan_parts, n_dst, layers, 
     else:
         rowptr, src, eid = plan_parts
         scratch = None
-    n_out = decoder[4].size(0) if decoder is not None else widths[-1]
     logits = torch.empty((n_dst[-1], n_out), dtype=torch.float32, device=dev)
     work = torch.empty(int(lib().dgnn_static_infer_workspace_bytes(n_dst[0], L, w_arr)), dtype=torch.uint8, device=dev)
-
-    def col(i):
-        return (C.c_void_p * L)(*[(l[i].data_ptr() if l[i] is not None else None) for l in layers])
-    prep = (C.c_void_p * L)(*[(p.data_ptr() if p is not None else None) for p in prepared]) if prepared is not None else None
-    d = decoder if decoder is not None else (None,) * 6
     rc = lib().dgnn_static_infer_rings_fwd(
         ptr(edge_index) if build else None, edge_index.stride(0) if build else 0, edge_index.stride(1) if build else 0, E, hint, ptr(rowptr), ptr(src),
         ptr(eid), ptr(scratch), int(bool(attr_in_plan_order)), n_loc, nd_arr, ptr(x), _ld(x), ptr(edge_attr), _ld(edge_attr), edge_attr.size(1),
-        L, w_arr, col(0), col(1), col(2), col(3), col(4), col(5), col(6), prep, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]),
-        d[0].size(0) if d[0] is not None else 0, ptr(d[4]), ptr(d[5]), d[4].size(0) if d[4] is not None else 0, int(bool(fuse_decoder)),
-        GEMM_MODE if gemm_mode is None else gemm_mode, ptr(work), ptr(logits), stream_ptr())
+        L, w_arr, *cols, prep, *dec, int(bool(fuse_decoder)), GEMM_MODE if gemm_mode is None else gemm_mode, ptr(work), ptr(logits), stream_ptr())
     if rc == DGNN_E_UNSUPPORTED:
         return None
     check(rc, "dgnn_static_infer_rings_fwd", poll=build)
@@ -640,17 +643,15 @@ def static_infer_rings_fwd(x, edge_attr, edge_index, plan_parts, n_dst, layers, 
 
 @on_device_of
 def static_infer_partitioned_fwd(x, edge_attr, edge_index, plan_parts, n_own, n_interior, layers, decoder, prepared=None, halo=None, comm=None, send_buf=None,
-                                 hint=PLAN_HINT_GROUPED, gemm_mode=None, fuse_decoder=True, attr_in_plan_order=True):
+                                 hint=PLAN_HINT_GROUPED, gemm_mode=None, fuse_decoder=True, attr_in_plan_order=True, cache=None):
     """One rank's part of a partitioned scene in one library call (dgnn_static_infer_partitioned_fwd; arguments as static_infer_fwd): x [n_own + n_halo, F]
     local rows, `edge_index` the local list (destinations < n_own), `halo` / `comm` the library's halo plan and communicator (None: a single-rank
     part), `send_buf` a uint8 buffer of n_send * max hidden width * 4 bytes.  -> (logits [n_own, n_logits], plan parts) or None (nothing launched)."""
-    import ctypes as C
     _req(x, "x", dim=2)
     _req(edge_attr, "edge_attr", dim=2)
-    n_loc, dev, L = x.size(0), x.device, len(layers)
+    n_loc, dev = x.size(0), x.device
     n_halo = n_loc - n_own
-    widths = [x.size(1)] + [l[2].size(0) for l in layers]
-    w_arr = (C.c_int32 * (L + 1))(*widths)
+    L, w_arr, cols, prep, dec, n_out = _infer_tables(x.size(1), layers, decoder, prepared, cache)
     E = edge_index.size(1) if edge_index is not None else plan_parts[1].numel()
     build = plan_parts is None
     if build:
@@ -662,20 +663,13 @@ def static_infer_partitioned_fwd(x, edge_attr, edge_index, plan_parts, n_own, n_
     else:
         rowptr, src, eid = plan_parts
         scratch = None
-    n_out = decoder[4].size(0) if decoder is not None else widths[-1]
     logits = torch.empty((n_own, n_out), dtype=torch.float32, device=dev)
     work = torch.empty(int(lib().dgnn_static_infer_workspace_bytes(n_loc, L, w_arr)), dtype=torch.uint8, device=dev)
-
-    def col(i):
-        return (C.c_void_p * L)(*[(l[i].data_ptr() if l[i] is not None else None) for l in layers])
-    prep = (C.c_void_p * L)(*[(p.data_ptr() if p is not None else None) for p in prepared]) if prepared is not None else None
-    d = decoder if decoder is not None else (None,) * 6
     rc = lib().dgnn_static_infer_partitioned_fwd(
         ptr(edge_index) if build else None, edge_index.stride(0) if build else 0, edge_index.stride(1) if build else 0, E, hint, ptr(rowptr), ptr(src),
         ptr(eid), ptr(scratch), int(bool(attr_in_plan_order)), n_own, n_interior, n_halo, ptr(x), _ld(x), ptr(edge_attr), _ld(edge_attr), edge_attr.size(1),
-        L, w_arr, col(0), col(1), col(2), col(3), col(4), col(5), col(6), prep, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]),
-        d[0].size(0) if d[0] is not None else 0, ptr(d[4]), ptr(d[5]), d[4].size(0) if d[4] is not None else 0, int(bool(fuse_decoder)),
-        GEMM_MODE if gemm_mode is None else gemm_mode, halo, comm, ptr(send_buf), ptr(work), ptr(logits), stream_ptr())
+        L, w_arr, *cols, prep, *dec, int(bool(fuse_decoder)), GEMM_MODE if gemm_mode is None else gemm_mode, halo, comm, ptr(send_buf), ptr(work), ptr(logits),
+        stream_ptr())
     if rc == DGNN_E_UNSUPPORTED:
         return None
     check(rc, "dgnn_static_infer_partitioned_fwd", poll=build)

@@ -478,7 +478,7 @@ def _partitioned_scene_infer_one_call(self, net, x, xe, n_src, rebuild_plan):
     tabs = net._one_call_tables(x, xe)
     if tabs is None:
         return None
-    layers, decoder, prepared, with_dec = tabs
+    layers, decoder, prepared, with_dec, cache = tabs
     if with_dec and not net._fusable_rows(x, net.num_layers - 1):      # (the per-layer chain runs layer and decoder apart there: stay identical to it)
         return None
     halo = comm = sbuf = None
@@ -492,7 +492,7 @@ def _partitioned_scene_infer_one_call(self, net, x, xe, n_src, rebuild_plan):
     build = self.plan is None or rebuild_plan
     parts = None if build else (self.plan.rowptr, self.plan.src, self.plan.eid)
     out = ops.static_infer_partitioned_fwd(x, xe, self.edge_index, parts, self.n_own, self.lp.n_interior, layers, decoder, prepared, halo=halo, comm=comm,
-                                           send_buf=sbuf, fuse_decoder=with_dec)
+                                           send_buf=sbuf, fuse_decoder=with_dec, cache=cache)
     if out is None:
         return None
     if build:
@@ -516,9 +516,9 @@ def _partitioned_scene_infer_rings(self, net, x, xe, n_src, rebuild_plan):
     fuse = bool(getattr(net, "fuses_decoder", lambda i: False)(last)) and net._fusable_rows(x, last)
     tabs = net._one_call_tables(x, xe) if (getattr(self, "one_call", True) and getattr(net, "_one_call_tables", None) is not None) else None
     if tabs is not None and (not tabs[3] or fuse):
-        layers, decoder, prepared, with_dec = tabs
+        layers, decoder, prepared, with_dec, cache = tabs
         parts = None if build else (self.plan.rowptr, self.plan.src, self.plan.eid)
-        out = ops.static_infer_rings_fwd(x, xe, self.edge_index, parts, nd, layers, decoder, prepared, fuse_decoder=with_dec)
+        out = ops.static_infer_rings_fwd(x, xe, self.edge_index, parts, nd, layers, decoder, prepared, fuse_decoder=with_dec, cache=cache)
         if out is not None:
             if build:
                 self.plan = self._GraphPlan(self.edge_index, n_src, nd[0], hint=1, parts=out[1])
