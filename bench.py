@@ -691,6 +691,40 @@ def main():
                                   "block_diagonal_batch_ms": round(t_batch * 1e3, 4), "block_diagonal_batch_value": round(n_small / t_batch, 1),
                                   "batch_equals_scene_bitwise": bool(torch.equal(lg_b[:lg_0.size(0)], lg_0))}
         del small, scenes, batch, xs, eas, eis
+        # (5) the metric's other GPU counts, one rank at a time on THIS GPU: the step of a rank's part of a W-way cut of this very scene (ring parts,
+        # dgnn_amd/partition.py: the ranks do not talk during a step -- no collective in the data path -- so a rank's step time here is its step time
+        # there; the W-GPU job additionally pays the timing harness's barrier).  First and last rank of every cut; logits checked against the whole
+        # scene's.  `bench.py --gpus W` runs exactly these parts, one per GPU.
+        if n_total <= 3_000_000 and cell_order is not None:
+            from dgnn_amd.partition import PartitionedScene, build_ring_part, rcb_partition
+            ei_np = data.edge_index.cpu().numpy()
+            cent_o = cent[cell_order.order.cpu().numpy()]
+            whole = step()
+            parts_out = {}
+            for W in (2, 4, 8):
+                part = rcb_partition(cent_o, W)
+                ms_w, same_w, own_w, ring_w = [], True, [], []
+                for r_ in (0, W - 1):
+                    lp = build_ring_part(ei_np, part, r_, W, net.num_layers)
+                    rows_ = torch.from_numpy(np.concatenate([lp.own_gid, lp.halo_gid])).to(dev)
+                    sc_ = PartitionedScene(lp, data.x[rows_], data.edge_attr[torch.from_numpy(lp.edge_gid).to(dev)], dev)
+                    fn_ = lambda sc_=sc_: sc_.inference_layer(net)
+                    settle(fn_)
+                    k_p = max(args.steps, 100)        # (a shard's step is 0.2-0.8 ms: enough of them to be past the clock ramp that follows the host-side part building)
+                    for _ in range(20):
+                        fn_()
+                    dt_p, _ = timed_steps(fn_, k_p, sync, world, dev)
+                    ms_w.append(round(dt_p / k_p * 1e3, 4))
+                    same_w = same_w and bool(torch.equal(fn_(), whole[torch.from_numpy(lp.own_gid).to(dev)]))
+                    own_w.append(lp.n_own)
+                    ring_w.append(lp.ring_counts)
+                    del sc_, rows_, lp
+                parts_out[str(W)] = {"ms_per_step_rank_first_last": ms_w, "owned_cells": own_w, "rings": ring_w, "bit_identical_to_whole_scene": same_w,
+                                     "value_if_every_rank_takes_the_slower": round(n_total / max(ms_w) * 1e3, 1),
+                                     "vs_this_gpu": round(n_total / max(ms_w) * 1e3 / value, 3)}
+            extras["strong_scaling_parts"] = {"what": "ring parts of the W-way cut of this scene, each timed alone on this GPU (the ranks are independent during a step: no "
+                                                      "collective in the data path); `bench.py --gpus W` runs them one per GPU", "steps_per_part": max(args.steps, 100), "parts": parts_out}
+            del ei_np, cent_o, whole
     other = None
     if world > 1 and not args.no_extras:
         # the other scaling mode, same steps / warm-up, so that a SCALE record can be read either way (metric: "1M-tet graph at 1/2/4/8" = strong)
