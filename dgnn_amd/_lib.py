@@ -120,6 +120,8 @@ SIGNATURES = {
                                     vp, vp, i32, i32, i32, vp, vp, vp]),
     "dgnn_static_infer_rings_fwd": (i32, [vp, i64, i64, i64, i32, vp, vp, vp, vp, i32, i64, vp, vp, i64, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                           vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp]),
+    "dgnn_static_infer_rings_fwd_bf16": (i32, [vp, i64, i64, i64, i32, vp, vp, vp, vp, i32, i64, vp, vp, i64, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp,
+                                               vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp]),
     "dgnn_static_infer_partitioned_fwd": (i32, [vp, i64, i64, i64, i32, vp, vp, vp, vp, i32, i64, i64, i64, vp, i64, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp,
                                                 vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "dgnn_rccl_available": (i32, []),

@@ -144,6 +144,69 @@ extern "C" int dgnn_static_infer_rings_fwd(const int64_t* edge_index, int64_t st
                        n_logits, fuse_decoder, gemm_mode, workspace, logits, stream);
 }
 
+// ---- bf16 STORAGE (BASELINE config 3), whole scene or ring part, one call ------------------------------------------------------------------------------
+// The chain SurfaceNet.inference_layer runs in bf16 storage when every layer has the fused form: layer 0 reads the caller's fp32 rows in place and
+// starts the 16-bit rows (UNSIGNED when `mode` carries DGNN_BF16_ROWS_OUT_UNSIGNED: 9 significant bits behind the ReLU), the middle layers keep the
+// format, the last layer's launch carries the decoder and writes fp32 logits.  Configurations outside that form: DGNN_E_UNSUPPORTED, nothing launched
+// (the Python mirror then issues its per-layer chain).
+extern "C" int dgnn_static_infer_rings_fwd_bf16(const int64_t* edge_index, int64_t stride_row, int64_t stride_col, int64_t E, int plan_hint, int32_t* rowptr,
+                                                int32_t* src, int32_t* eid, int32_t* plan_scratch, int attr_in_plan_order, int64_t n_loc, const int64_t* n_dst,
+                                                const float* x, int64_t ldx, const float* edge_attr, int64_t lde, int f_e, int n_layers, const int32_t* widths,
+                                                const float* const* We, const float* const* be, const float* const* Wj, const float* const* bj,
+                                                const float* const* Wi, const float* const* scale, const float* const* shift, const float* W0, const float* b0,
+                                                const float* scale1, const float* shift1, int c_hidden, const float* W3, const float* b3, int n_logits, int mode,
+                                                void* workspace, float* logits, void* stream) {
+    const char* who = "static_infer_rings_fwd_bf16";
+    DGNN_REQUIRE(n_loc >= 0 && E >= 0 && n_layers >= 2 && n_layers <= 16 && widths && We && be && Wj && bj && Wi && scale && shift && n_dst, DGNN_E_INVALID,
+                 "%s: bad sizes / null table", who);
+    for (int l = 0; l < n_layers; ++l)
+        DGNN_REQUIRE(n_dst[l] >= 0 && n_dst[l] <= (l ? n_dst[l - 1] : n_loc), DGNN_E_INVALID, "%s: destination counts must not grow from layer to layer", who);
+    if (n_dst[n_layers - 1] == 0) return DGNN_OK;
+    DGNN_REQUIRE(x && edge_attr && workspace && logits && ((uintptr_t)workspace % 16) == 0, DGNN_E_INVALID, "%s: null / unaligned pointer", who);
+    const bool build = edge_index != nullptr;
+    DGNN_REQUIRE(rowptr && src && (!build || (eid && plan_scratch)) && (attr_in_plan_order || eid), DGNN_E_INVALID, "%s: plan arrays missing", who);
+    const bool uns = (mode & DGNN_BF16_ROWS_OUT_UNSIGNED) != 0;
+    const int base = mode & ~(DGNN_BF16_ROWS_IN_UNSIGNED | DGNN_BF16_ROWS_OUT_UNSIGNED);
+    bool ok = W0 && b0 && W3 && b3 && base == DGNN_BF16_COMPENSATED && f_e == 20 && lde == 20 && ((uintptr_t)edge_attr % 16) == 0 && widths[0] <= 32 &&
+              widths[0] % 2 == 0 && ((uintptr_t)x % 4) == 0 && widths[n_layers] == 128 && widths[n_layers - 1] > 64 && c_hidden == 64 && n_logits == 2;
+    int maxw = 0;
+    for (int l = 0; l < n_layers && ok; ++l) {
+        const int ci = widths[l], co = widths[l + 1];
+        const int nb = ci <= 32 ? 2 : (ci <= 64 ? 4 : 8);
+        ok = ci > 0 && ci <= 128 && ci % nb == 0 && (co == 64 || co == 128) && We[l] && be[l] && Wj[l] && Wi[l] && ((scale[l] == nullptr) == (shift[l] == nullptr));
+        maxw = co > maxw ? co : maxw;
+    }
+    ok = ok && n_loc * (int64_t)(ldx > maxw ? ldx : maxw) < ((int64_t)1 << 31);
+    if (!ok) {
+        dgnn_set_error("%s: a layer shape / operand layout / arithmetic mode outside the fully fused bf16-storage chain", who);
+        return DGNN_E_UNSUPPORTED;
+    }
+    const Workspace ws = carve(workspace, n_dst[0], n_layers, widths);      // (sized for 4-byte rows: the 2-byte rows use half of each buffer)
+    if (build) {
+        DGNN_REQUIRE(E < INT32_MAX && n_loc < INT32_MAX, DGNN_E_UNSUPPORTED, "%s: E and n must fit int32", who);
+        const int rc = dgnn_plan_build(edge_index, stride_row, stride_col, E, n_dst[0], n_loc, 1, plan_hint, rowptr, src, eid, plan_scratch, stream);
+        if (rc != DGNN_OK) return rc;
+    }
+    const int32_t* e_ = attr_in_plan_order ? nullptr : eid;
+    const void* h = x;
+    int64_t ldh = ldx;
+    for (int l = 0; l < n_layers; ++l) {
+        const int ci = widths[l], co = widths[l + 1];
+        const int fmt = uns ? ((l ? DGNN_BF16_ROWS_IN_UNSIGNED : 0) | DGNN_BF16_ROWS_OUT_UNSIGNED) : 0;
+        if (l == n_layers - 1)
+            return dgnn_sage_layer_fused_decoder_fwd_bf16(rowptr, src, e_, n_dst[l], static_cast<const uint16_t*>(h), nullptr, ldh, ci, edge_attr, lde, f_e, We[l],
+                                                          be[l], Wj[l], bj[l], Wi[l], scale[l], shift[l], 1, co, W0, b0, scale1, shift1, c_hidden, W3, b3, n_logits,
+                                                          logits, base | (uns ? DGNN_BF16_ROWS_IN_UNSIGNED : 0), stream);
+        uint16_t* out = reinterpret_cast<uint16_t*>(ws.act[l & 1]);
+        const int rc = dgnn_sage_layer_fused_fwd_bf16(rowptr, src, e_, n_dst[l], h, l == 0, nullptr, ldh, ci, edge_attr, lde, f_e, We[l], be[l], Wj[l], bj[l], Wi[l],
+                                                      scale[l], shift[l], 1, co, out, co, base | fmt, stream);
+        if (rc != DGNN_OK) return rc;
+        h = out;
+        ldh = co;
+    }
+    return DGNN_OK;
+}
+
 // ---- one rank's part of a scene cut across GPUs, ONE call per step (dgnn_amd/partition.py run_partitioned_layers) -------------------------
 // The launch chain PartitionedScene.inference_layer issued from Python -- plan of the local bipartite graph, layer 0 over the owned cells, then per
 // later layer [interior cells | wait for the halo | boundary cells] with the exchange of the layer's output rows started right behind it -- was

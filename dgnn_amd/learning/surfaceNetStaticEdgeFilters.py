@@ -363,13 +363,17 @@ class SurfaceNet(nn.Module):
         running statistics all change it).  Replacing a sub-MODULE of a built model is not seen: call `invalidate_caches()` after such surgery."""
         if not (ops.INFER_ONE_CALL and ops.FUSED_ENABLED and ops.EDGE_GATHER_IN_KERNEL) or ops.LAYER_HOOK is not None:
             return None
-        if self.storage_dtype != torch.float32 or x.dtype != torch.float32 or xe.dtype != torch.float32 or xe.dim() != 2 or xe.size(1) != 20 \
+        bf16 = self.storage_dtype == torch.bfloat16      # (the fully fused bf16-storage chain: dgnn_static_infer_rings_fwd_bf16)
+        if (self.storage_dtype != torch.float32 and not bf16) or x.dtype != torch.float32 or xe.dtype != torch.float32 or xe.dim() != 2 or xe.size(1) != 20 \
                 or xe.stride(0) != 20 or xe.data_ptr() % 16 or x.size(0) * max(x.stride(0), 128) >= ops.FUSED_MAX_ELEMS:
             return None
+        if bf16 and (ops.BF16_MODE != ops.BF16_COMPENSATED or self.num_layers < 2):
+            return None
+        flags = (ops.GEMM_MODE, ops.PREPARED_PARAMS, ops.FUSE_DECODER, bf16, x.device)
         hit = self.__dict__.get("_oc_tables")
         if hit is not None:
             mods, key, tabs = hit
-            if key == (self._oc_key(mods), ops.GEMM_MODE, ops.PREPARED_PARAMS, ops.FUSE_DECODER, x.device):
+            if key == (self._oc_key(mods), flags):
                 return tabs
         mods = []            # every module a tensor of the tables comes from
         dec = self.decoder if self.clf.model.decoder else ()
@@ -384,17 +388,21 @@ class SurfaceNet(nn.Module):
             if not (isinstance(le, Linear) and le.in_features == 20 and le.bias is not None) or not isinstance(layer[2], nn.ReLU) \
                     or not (layer[1] is None or isinstance(layer[1], BatchNorm)):
                 return None
+            if bf16 and not ops.fused_layer_supported_bf16(conv.lin_j.in_features, conv.lin_j.out_features, 20, x if i == 0 else None):
+                return None
             scale, shift = self._fold(layer[1], conv.lin_j.out_features, x.device)
             layers.append((le.weight, le.bias, conv.lin_j.weight, conv.lin_j.bias, conv.lin_i.weight, scale, shift))
-            prepared.append(self._prepared(i, with_dec and i == last))
+            prepared.append(None if bf16 else self._prepared(i, with_dec and i == last))
             mods += [le, conv.lin_j, conv.lin_i] + ([layer[1].module] if layer[1] is not None else [])
         decoder = None
         if len(dec) == 4:
             s1, h1 = self._fold(dec[1], dec[0].out_features, x.device)
             decoder = (dec[0].weight, dec[0].bias, s1, h1, dec[3].weight, dec[3].bias)
             mods += [dec[0], dec[3]] + ([dec[1].module] if dec[1] is not None else [])
-        tabs = (layers, decoder, prepared, with_dec, {})
-        self.__dict__["_oc_tables"] = (mods, (self._oc_key(mods), ops.GEMM_MODE, ops.PREPARED_PARAMS, ops.FUSE_DECODER, x.device), tabs)
+        if bf16 and not with_dec:          # (the bf16 chain has no decoder-apart form)
+            return None
+        tabs = (layers, decoder, None if bf16 else prepared, with_dec, {})
+        self.__dict__["_oc_tables"] = (mods, (self._oc_key(mods), flags), tabs)
         return tabs
 
     @staticmethod
@@ -433,7 +441,11 @@ class SurfaceNet(nn.Module):
             if held:
                 plan = plan_for(edge_index, n, n, hint=ops.PLAN_HINT_REFERENCE)
         parts = None if plan is None else (plan.rowptr, plan.src, plan.eid)
-        out = ops.static_infer_fwd(x, xe, edge_index, parts, layers, decoder, prepared, fuse_decoder=with_dec, cache=cache)
+        if self.storage_dtype == torch.bfloat16:
+            out = ops.static_infer_rings_fwd_bf16(x, xe, edge_index, parts, [n] * self.num_layers, layers, decoder, hint=ops.PLAN_HINT_REFERENCE,
+                                                  attr_in_plan_order=False, cache=cache)
+        else:
+            out = ops.static_infer_fwd(x, xe, edge_index, parts, layers, decoder, prepared, fuse_decoder=with_dec, cache=cache)
         if out is None:
             return None
         if plan is None:

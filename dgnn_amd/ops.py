@@ -642,6 +642,41 @@ def static_infer_rings_fwd(x, edge_attr, edge_index, plan_parts, n_dst, layers, 
 
 
 @on_device_of
+def static_infer_rings_fwd_bf16(x, edge_attr, edge_index, plan_parts, n_dst, layers, decoder, hint=PLAN_HINT_GROUPED, attr_in_plan_order=True, cache=None):
+    """static_infer_rings_fwd in bf16 STORAGE (dgnn_static_infer_rings_fwd_bf16): fp32 input rows read in place by the first layer, 16-bit rows (unsigned
+    with BF16_UNSIGNED_ROWS) between the layers, the decoder inside the last launch.  A whole scene is n_dst = [n] * L.  None: nothing launched."""
+    import ctypes as C
+    _req(x, "x", dim=2)
+    _req(edge_attr, "edge_attr", dim=2)
+    n_loc, dev = x.size(0), x.device
+    L, w_arr, cols, _, dec, n_out = _infer_tables(x.size(1), layers, decoder, None, cache)
+    assert len(n_dst) == L and decoder is not None
+    nd_arr = (C.c_int64 * L)(*[int(v) for v in n_dst])
+    E = edge_index.size(1) if edge_index is not None else plan_parts[1].numel()
+    build = plan_parts is None
+    if build:
+        rowptr = torch.empty(n_dst[0] + 1, dtype=torch.int32, device=dev)
+        src = torch.empty(max(E, 1), dtype=torch.int32, device=dev)[:E]
+        eid = torch.empty(max(E, 1), dtype=torch.int32, device=dev)[:E]
+        scratch = torch.empty(int(lib().dgnn_plan_scratch_elems(E, n_dst[0])), dtype=torch.int32, device=dev)
+        plan_parts = (rowptr, src, eid)
+    else:
+        rowptr, src, eid = plan_parts
+        scratch = None
+    logits = torch.empty((n_dst[-1], n_out), dtype=torch.float32, device=dev)
+    work = torch.empty(int(lib().dgnn_static_infer_workspace_bytes(n_dst[0], L, w_arr)), dtype=torch.uint8, device=dev)
+    mode = BF16_MODE | (BF16_ROWS_OUT_UNSIGNED if BF16_UNSIGNED_ROWS else 0)
+    rc = lib().dgnn_static_infer_rings_fwd_bf16(
+        ptr(edge_index) if build else None, edge_index.stride(0) if build else 0, edge_index.stride(1) if build else 0, E, hint, ptr(rowptr), ptr(src),
+        ptr(eid), ptr(scratch), int(bool(attr_in_plan_order)), n_loc, nd_arr, ptr(x), _ld(x), ptr(edge_attr), _ld(edge_attr), edge_attr.size(1),
+        L, w_arr, *cols, *dec, mode, ptr(work), ptr(logits), stream_ptr())
+    if rc == DGNN_E_UNSUPPORTED:
+        return None
+    check(rc, "dgnn_static_infer_rings_fwd_bf16", poll=build)
+    return logits, plan_parts
+
+
+@on_device_of
 def static_infer_partitioned_fwd(x, edge_attr, edge_index, plan_parts, n_own, n_interior, layers, decoder, prepared=None, halo=None, comm=None, send_buf=None,
                                  hint=PLAN_HINT_GROUPED, gemm_mode=None, fuse_decoder=True, attr_in_plan_order=True, cache=None):
     """One rank's part of a partitioned scene in one library call (dgnn_static_infer_partitioned_fwd; arguments as static_infer_fwd): x [n_own + n_halo, F]

@@ -475,7 +475,7 @@ def _partitioned_scene_infer_one_call(self, net, x, xe, n_src, rebuild_plan):
     ex = self.exchange
     if type(ex) is not HaloExchange or (ex.active and ex._native is None) or ex._pending:
         return None
-    tabs = net._one_call_tables(x, xe)
+    tabs = net._one_call_tables(x, xe) if net.storage_dtype == torch.float32 else None
     if tabs is None:
         return None
     layers, decoder, prepared, with_dec, cache = tabs
@@ -518,7 +518,10 @@ def _partitioned_scene_infer_rings(self, net, x, xe, n_src, rebuild_plan):
     if tabs is not None and (not tabs[3] or fuse):
         layers, decoder, prepared, with_dec, cache = tabs
         parts = None if build else (self.plan.rowptr, self.plan.src, self.plan.eid)
-        out = ops.static_infer_rings_fwd(x, xe, self.edge_index, parts, nd, layers, decoder, prepared, fuse_decoder=with_dec, cache=cache)
+        if net.storage_dtype == torch.bfloat16:
+            out = ops.static_infer_rings_fwd_bf16(x, xe, self.edge_index, parts, nd, layers, decoder, cache=cache)
+        else:
+            out = ops.static_infer_rings_fwd(x, xe, self.edge_index, parts, nd, layers, decoder, prepared, fuse_decoder=with_dec, cache=cache)
         if out is not None:
             if build:
                 self.plan = self._GraphPlan(self.edge_index, n_src, nd[0], hint=1, parts=out[1])

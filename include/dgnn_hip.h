@@ -375,6 +375,19 @@ int dgnn_static_infer_rings_fwd(const int64_t* edge_index, int64_t stride_row, i
                                 const float* W0, const float* b0, const float* scale1, const float* shift1, int c_hidden, const float* W3,
                                 const float* b3, int n_logits, int fuse_decoder, int gemm_mode, void* workspace, float* logits, void* stream);
 
+/* The same in bf16 STORAGE (BASELINE config 3; whole scene: every n_dst[l] = n_loc): layer 0 reads the caller's fp32 rows in place (widths[0] <= 32) and
+ * starts the 16-bit rows -- unsigned when `mode` carries DGNN_BF16_ROWS_OUT_UNSIGNED --, the middle layers keep the format, the last layer's launch
+ * carries the decoder (dgnn_sage_layer_fused_decoder_fwd_bf16) and writes fp32 logits.  mode = DGNN_BF16_COMPENSATED [| DGNN_BF16_ROWS_OUT_UNSIGNED];
+ * the decoder is required (128 -> 64 -> 2 behind a 128-wide last layer).  Anything else: DGNN_E_UNSUPPORTED, nothing launched.  Bit-identical to the
+ * per-layer bf16 entry points.  workspace as dgnn_static_infer_rings_fwd. */
+int dgnn_static_infer_rings_fwd_bf16(const int64_t* edge_index, int64_t stride_row, int64_t stride_col, int64_t E, int plan_hint, int32_t* rowptr,
+                                     int32_t* src, int32_t* eid, int32_t* plan_scratch, int attr_in_plan_order, int64_t n_loc, const int64_t* n_dst,
+                                     const float* x, int64_t ldx, const float* edge_attr, int64_t lde, int f_e, int n_layers, const int32_t* widths,
+                                     const float* const* We, const float* const* be, const float* const* Wj, const float* const* bj,
+                                     const float* const* Wi, const float* const* scale, const float* const* shift, const float* W0, const float* b0,
+                                     const float* scale1, const float* shift1, int c_hidden, const float* W3, const float* b3, int n_logits, int mode,
+                                     void* workspace, float* logits, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Training-mode conv layer, one call each way (SurfaceNet.forward :214-219 and its autograd, learning/runModel.py:279):
  *   forward : a = aggregate(x)  ->  z = a.Wj^T + x[:n_dst].Wi^T + bj  ->  BatchNorm1d with batch statistics (running buffers

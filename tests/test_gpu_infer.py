@@ -252,7 +252,7 @@ def test_ring_parts_union_equals_whole_scene(world, storage):
         net.set_storage_dtype(torch.bfloat16)
     full = net.inference_layer(Config(x=x, edge_attr=ea, edge_index=torch.from_numpy(ei).to(DEV)))
     part = rcb_partition(cent, world)
-    for one_call in ((True, False) if storage == "f32" else (False,)):
+    for one_call in (True, False):
         got = torch.full_like(full, float("nan"))
         for rank in range(world):
             lp = build_ring_part(ei, part, rank, world, net.num_layers)
@@ -279,3 +279,34 @@ def test_static_infer_rings_c_abi_rejects_growing_destination_counts():
     rc = lib().dgnn_static_infer_rings_fwd(None, 0, 0, 40, 1, ptr(i32), ptr(i32), None, None, 1, 16, nd, ptr(t), 28, ptr(t), 20, 20, L, widths, arr, arr, arr, arr, arr,
                                            arr, arr, None, None, None, None, None, 0, None, None, 0, 0, ops.GEMM_F16X2, ptr(t), ptr(t), None)
     assert rc == -1      # DGNN_E_INVALID (include/dgnn_hip.h)
+
+
+@pytest.mark.parametrize("points,unsigned", [(7, True), (600, True), (9000, True), (9000, False)])
+def test_one_call_bf16_storage_equals_the_per_layer_path(points, unsigned):
+    """dgnn_static_infer_rings_fwd_bf16 on a whole scene: the chain of the per-layer bf16 entry points (fp32 input rows read in place, 16-bit rows between
+    the layers -- unsigned or plain bf16 --, decoder in the last launch), bit for bit; other bf16 arithmetic: the call declines, same logits."""
+    from dgnn_amd import ops
+    n, x, ea, ei = _scene(points, seed=points + 1)
+    net = hip_static()
+    net.set_storage_dtype(torch.bfloat16)
+    data = Config(x=x.to(DEV), edge_attr=ea.to(DEV), edge_index=ei)
+    old = ops.BF16_UNSIGNED_ROWS
+    ops.BF16_UNSIGNED_ROWS = unsigned
+    try:
+        assert net._one_call_tables(data.x[:, 1:], data.edge_attr) is not None
+        one, ref = _both_paths(net, data)
+        assert one.shape == (n, 2) and one.dtype == torch.float32 and torch.equal(one, ref)
+        mode = ops.BF16_MODE
+        ops.BF16_MODE = ops.BF16_SINGLE
+        try:
+            assert net._one_call_tables(data.x[:, 1:], data.edge_attr) is None
+            a, b = _both_paths(net, data)
+            assert torch.equal(a, b)
+        finally:
+            ops.BF16_MODE = mode
+    finally:
+        ops.BF16_UNSIGNED_ROWS = old
+    # fp32 storage again on the same model object: the cached tables follow the storage type
+    net.set_storage_dtype(torch.float32)
+    one32, ref32 = _both_paths(net, data)
+    assert torch.equal(one32, ref32) and (one32 - one).abs().max().item() < 0.2
