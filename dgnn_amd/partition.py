@@ -191,7 +191,9 @@ class HaloExchange:
         import os
         if self.device.type == "cuda" and not self.via_host and os.environ.get("DGNN_NATIVE_HALO", "1") != "0":
             import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl" and (self.active or dist.get_world_size(group) > 1):
+            # (ring parts -- build_ring_part -- never exchange: no communicator is made for them, on any rank)
+            if dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl" and lp.ring_counts is None \
+                    and (self.active or dist.get_world_size(group) > 1):
                 try:
                     self._init_native(group)
                 except Exception as e:  # noqa: BLE001
