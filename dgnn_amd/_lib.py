@@ -86,6 +86,8 @@ SIGNATURES = {
     "dgnn_khop_reset": (i32, [vp, i64, vp, vp]),
     "dgnn_khop_blocks_regular": (i32, [vp, vp, vp, i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dgnn_khop_blocks_regular_start": (vp, [vp, vp, vp, i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dgnn_khop_blocks_regular_start_rows": (vp, [vp, vp, vp, i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                                 i32, vp, vp, vp, vp, vp, vp]),
     "dgnn_khop_blocks_regular_wait": (i32, [vp, i32, vp]),
     "dgnn_decoder_fused_fwd": (i32, [vp, i64, i64, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, i64, vp]),
     "dgnn_cast_f32_to_bf16": (i32, [vp, i64, i64, i32, i32, vp, i64, vp]),

@@ -382,14 +382,32 @@ template <typename T>
 std::vector<T> copy_n(const T* p, int n) {
     return p ? std::vector<T>(p, p + n) : std::vector<T>();
 }
+// rows of a block gathered by the builder itself (round 4): out[i, 0:cols] = src[idx[i] * ld + 0:cols] for the block's node ids
+// (which = 0: all nodes of the outermost block) or its targets (which = 1) -- the head-of-step x_all[n_id, 1:], x_all[ids], y_all[ids] of the
+// training loop (learning/surfaceNetStaticEdgeFilters.py:206, learning/runModel.py:273-274), 30 us of torch indexing kernels on the step's own
+// stream, now behind the block on the builder's stream a step ahead
+struct KhopRows {
+    int n = 0;
+    const float* src[4];
+    int64_t ld[4];
+    int cols[4], which[4];
+    float* out[4];
+};
+__global__ void k_gather_rows_i64(const float* __restrict__ src, int64_t ld, const int64_t* __restrict__ idx, int64_t n, int cols, float* __restrict__ out) {
+    const int64_t total = n * cols;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / cols;
+        const int c = (int)(t - r * cols);
+        out[t] = src[idx[r] * ld + c];
+    }
+}
 }  // namespace
 
-extern "C" void* dgnn_khop_blocks_regular_start(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int deg, const int64_t* batch,
-                                                int64_t n_batch, int hops, int32_t* pos, int32_t* first, int64_t* const* ei, int64_t* const* e_id,
-                                                int32_t* const* src32, int32_t* const* e_id32, int32_t* const* off, int64_t* const* n_id_out,
-                                                const int64_t* cap_t, const int64_t* cap_e, int32_t* scratch, int32_t* n_new_dev,
-                                                int32_t* const* t_rowptr, int32_t* const* t_dst, int32_t* const* t_eid, int32_t* const* t_rows,
-                                                const int64_t* cap_all, int32_t* plan_scratch, void* stream) {
+static void* khop_start(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int deg, const int64_t* batch, int64_t n_batch, int hops, int32_t* pos,
+                        int32_t* first, int64_t* const* ei, int64_t* const* e_id, int32_t* const* src32, int32_t* const* e_id32, int32_t* const* off,
+                        int64_t* const* n_id_out, const int64_t* cap_t, const int64_t* cap_e, int32_t* scratch, int32_t* n_new_dev, int32_t* const* t_rowptr,
+                        int32_t* const* t_dst, int32_t* const* t_eid, int32_t* const* t_rows, const int64_t* cap_all, int32_t* plan_scratch, KhopRows rows,
+                        void* stream) {
     if (hops < 1 || hops > 16 || !ei || !e_id || !src32 || !e_id32 || !off || !n_id_out || !cap_t || !cap_e) {
         dgnn_set_error("khop_blocks_regular_start: bad args");
         return nullptr;
@@ -414,9 +432,59 @@ extern "C" void* dgnn_khop_blocks_regular_start(const int32_t* rowptr, const int
                                          want_t ? j->t_rowptr.data() : nullptr, want_t ? j->t_dst.data() : nullptr, want_t ? j->t_eid.data() : nullptr,
                                          want_t ? j->t_rows.data() : nullptr, want_t ? j->cap_all.data() : nullptr, plan_scratch, j->counts.data(),
                                          stream);
-        if (j->rc != DGNN_OK) j->err = dgnn_last_error_string();   // the error text is per thread: carry it over
+        if (j->rc != DGNN_OK) {
+            j->err = dgnn_last_error_string();   // the error text is per thread: carry it over
+            return;
+        }
+        for (int i = 0; i < rows.n; ++i) {       // the block's feature / label rows, behind the block on the builder's stream
+            const int64_t n = rows.which[i] ? n_batch : j->counts[hops];
+            const int64_t* idx = rows.which[i] ? batch : j->n_id_out[hops - 1];
+            if (n <= 0) continue;
+            hipLaunchKernelGGL(k_gather_rows_i64, dim3(dgnn_grid_cap(dgnn_cdiv(n * rows.cols[i], 256))), dim3(256), 0, (hipStream_t)stream, rows.src[i], rows.ld[i],
+                               idx, n, rows.cols[i], rows.out[i]);
+        }
+        if (rows.n) {
+            j->rc = dgnn_check_launch("khop_blocks_regular_start_rows");
+            if (j->rc != DGNN_OK) j->err = dgnn_last_error_string();
+        }
     });
     return j;
+}
+
+extern "C" void* dgnn_khop_blocks_regular_start(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int deg, const int64_t* batch,
+                                                int64_t n_batch, int hops, int32_t* pos, int32_t* first, int64_t* const* ei, int64_t* const* e_id,
+                                                int32_t* const* src32, int32_t* const* e_id32, int32_t* const* off, int64_t* const* n_id_out,
+                                                const int64_t* cap_t, const int64_t* cap_e, int32_t* scratch, int32_t* n_new_dev,
+                                                int32_t* const* t_rowptr, int32_t* const* t_dst, int32_t* const* t_eid, int32_t* const* t_rows,
+                                                const int64_t* cap_all, int32_t* plan_scratch, void* stream) {
+    return khop_start(rowptr, src, eid, deg, batch, n_batch, hops, pos, first, ei, e_id, src32, e_id32, off, n_id_out, cap_t, cap_e, scratch, n_new_dev, t_rowptr,
+                      t_dst, t_eid, t_rows, cap_all, plan_scratch, KhopRows(), stream);
+}
+
+// ... and up to 4 row gathers behind the block: r_src[i] (fp32, already offset to its first column), row stride r_ld[i], r_cols[i] columns, r_which[i]
+// 0 = all nodes of the outermost block (n_id_out[hops-1][:counts[hops]]) / 1 = the batch's targets, r_out[i] [capacity, r_cols[i]] packed rows
+extern "C" void* dgnn_khop_blocks_regular_start_rows(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int deg, const int64_t* batch,
+                                                     int64_t n_batch, int hops, int32_t* pos, int32_t* first, int64_t* const* ei, int64_t* const* e_id,
+                                                     int32_t* const* src32, int32_t* const* e_id32, int32_t* const* off, int64_t* const* n_id_out,
+                                                     const int64_t* cap_t, const int64_t* cap_e, int32_t* scratch, int32_t* n_new_dev,
+                                                     int32_t* const* t_rowptr, int32_t* const* t_dst, int32_t* const* t_eid, int32_t* const* t_rows,
+                                                     const int64_t* cap_all, int32_t* plan_scratch, int n_rows, const float* const* r_src, const int64_t* r_ld,
+                                                     const int32_t* r_cols, const int32_t* r_which, float* const* r_out, void* stream) {
+    KhopRows rows;
+    if (n_rows < 0 || n_rows > 4 || (n_rows && !(r_src && r_ld && r_cols && r_which && r_out))) {
+        dgnn_set_error("khop_blocks_regular_start_rows: at most 4 row gathers, all arrays given");
+        return nullptr;
+    }
+    rows.n = n_rows;
+    for (int i = 0; i < n_rows; ++i) {
+        if (!r_src[i] || !r_out[i] || r_cols[i] <= 0 || r_ld[i] < r_cols[i]) {
+            dgnn_set_error("khop_blocks_regular_start_rows: bad row gather %d", i);
+            return nullptr;
+        }
+        rows.src[i] = r_src[i], rows.ld[i] = r_ld[i], rows.cols[i] = r_cols[i], rows.which[i] = r_which[i], rows.out[i] = r_out[i];
+    }
+    return khop_start(rowptr, src, eid, deg, batch, n_batch, hops, pos, first, ei, e_id, src32, e_id32, off, n_id_out, cap_t, cap_e, scratch, n_new_dev, t_rowptr,
+                      t_dst, t_eid, t_rows, cap_all, plan_scratch, rows, stream);
 }
 
 extern "C" int dgnn_khop_blocks_regular_wait(void* job, int hops, int64_t* counts_out) {

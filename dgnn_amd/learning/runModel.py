@@ -213,9 +213,7 @@ class Trainer:
         logits_cell = self.model(data_train)
         n_sup = data_train.batch_adjs[self.model.num_layers - 1].size[1] if hasattr(data_train.batch_adjs[0], "size") \
             else data_train.batch_adjs[self.model.num_layers - 1][2][1]
-        ids = data_train.batch_n_id[:n_sup].to(data_train.all.x.device)
-        data_train.batch_x = data_train.all.x[ids]
-        data_train.batch_gt = data_train.all.y[ids]
+        data_train.batch_x, data_train.batch_gt = self._batch_rows(data_train, n_sup)
         loss = self.calcLossAndOA(logits_cell, None, data_train, clf, clf.training.metrics)
         optimizer.zero_grad()
         loss.backward()
@@ -223,6 +221,41 @@ class Trainer:
         allreduce_gradients(self.model, group)   # no-op without a process group / with one rank
         optimizer.step()
         return loss.detach()
+
+    @staticmethod
+    def _batch_rows(data_train, n_sup):
+        """all.x[ids], all.y[ids] for the batch's targets (reference :273-274): from the block's builder when the loader gathered them behind the block
+        (attach_block_rows), else indexed here"""
+        from ..sampler import block_rows
+        x_all, y_all, n_id = data_train.all.x, data_train.all.y, data_train.batch_n_id
+        bx = block_rows(n_id, x_all, 0, x_all.size(1), "batch") if x_all.dim() == 2 else None
+        by = block_rows(n_id, y_all, 0, y_all.size(1), "batch") if y_all.dim() == 2 else None
+        if bx is not None and by is not None and bx.size(0) == n_sup and by.size(0) == n_sup:
+            return bx, by
+        ids = n_id[:n_sup].to(x_all.device)
+        return x_all[ids], y_all[ids]
+
+    @staticmethod
+    def attach_block_rows(loader, data_all, model):
+        """Tells a dgnn_amd NeighborSampler to gather, behind every block and on its own stream, the rows a training step indexes at its head: the
+        model's input rows x[n_id, 1:] (or x[n_id]) and the targets' x / y rows.  Any other loader: nothing happens, the step indexes as before."""
+        attach = getattr(loader, "attach_rows", None)
+        x_all, y_all = getattr(data_all, "x", None), getattr(data_all, "y", None)
+        if attach is None or not isinstance(x_all, torch.Tensor) or x_all.dim() != 2:
+            return
+        clf = getattr(model, "clf", None)
+        drop = False
+        if clf is not None:
+            reg, feat = getattr(clf, "regularization", None), getattr(clf, "features", None)
+            if type(model).__module__.endswith("UpdatedEdgeFilters"):
+                drop = bool(feat is not None and feat.normalization_feature and not feat.keep_normalization_feature)
+            else:
+                drop = bool(reg is not None and reg.cell_type)
+        col0 = 1 if drop else 0
+        specs = [(x_all, col0, x_all.size(1) - col0, "all"), (x_all, 0, x_all.size(1), "batch")]
+        if isinstance(y_all, torch.Tensor) and y_all.dim() == 2:
+            specs.append((y_all, 0, y_all.size(1), "batch"))
+        attach(specs)
 
     def _train_direct(self, data_train, optimizer, clf, group):
         """The step without the autograd engine (DGNN_TRAIN_DIRECT=0 keeps the autograd path): the Static model's whole-model library calls, the
@@ -241,9 +274,7 @@ class Trainer:
             return None
         n_sup = data_train.batch_adjs[model.num_layers - 1].size[1] if hasattr(data_train.batch_adjs[0], "size") \
             else data_train.batch_adjs[model.num_layers - 1][2][1]
-        ids = data_train.batch_n_id[:n_sup].to(x_all.device)
-        data_train.batch_x = x_all[ids]                # (the reference leaves these on the data object, :273-274)
-        data_train.batch_gt = y_all[ids]
+        data_train.batch_x, data_train.batch_gt = self._batch_rows(data_train, n_sup)     # (the reference leaves these on the data object, :273-274)
         metrics, norm = clf.training.metrics, Fn.ops.CELL_NORMS[clf.regularization.cell_norm]
         one = self.__dict__.get("_one")
         if one is None or one.device != x_all.device:
@@ -292,6 +323,7 @@ class Trainer:
         clf.training.metrics = Metrics()
         iterations = 0
         row = {}
+        self.attach_block_rows(data.train.batches, data.train.all, self.model)
         for current_epoch in range(1, clf.training.epochs + 1):
             clf.temp.current_epoch = current_epoch
             adjust_learning_rate(optimizer, clf)

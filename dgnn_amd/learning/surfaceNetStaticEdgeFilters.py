@@ -36,6 +36,16 @@ class BatchNorm(nn.Module):
         return Fn.batch_norm_act(x, self.module, relu)
 
 
+def _block_x(x_all, n_id, col0, dev):
+    """x_all[n_id, col0:] as fp32 rows on `dev` (reference :206) -- the rows the block's builder already gathered on its own stream when the loader was
+    told to (sampler.NeighborSampler.attach_rows), else indexed here"""
+    from ..sampler import block_rows
+    x = block_rows(n_id, x_all, col0, x_all.size(1) - col0, "all") if x_all.dim() == 2 else None
+    if x is None:
+        x = x_all[n_id, col0:] if col0 else x_all[n_id, :]
+    return _dev_f32(x, dev)
+
+
 def _dev_f32(t: torch.Tensor, device) -> torch.Tensor:
     """H2D copy as the reference's ``.to(self.clf.temp.device)`` does; keeps views of resident data."""
     if t.device != torch.device(device) or t.dtype != torch.float32:
@@ -215,7 +225,7 @@ class SurfaceNet(nn.Module):
         dev = self._device()
         x_all = data.all.x
         n_id = data.batch_n_id.to(x_all.device)
-        x = _dev_f32(x_all[n_id, 1:] if self.clf.regularization.cell_type else x_all[n_id, :], dev)
+        x = _block_x(x_all, n_id, 1 if self.clf.regularization.cell_type else 0, dev)
         if self.storage_dtype == torch.bfloat16:
             x = Fn.to_bf16(x)
         whole = self._train_whole_model(x, data, dev)
@@ -302,7 +312,7 @@ class SurfaceNet(nn.Module):
         dev = self._device()
         x_all = data.all.x
         n_id = data.batch_n_id.to(x_all.device)
-        x = _dev_f32(x_all[n_id, 1:] if self.clf.regularization.cell_type else x_all[n_id, :], dev)
+        x = _block_x(x_all, n_id, 1 if self.clf.regularization.cell_type else 0, dev)
         if self.storage_dtype != torch.float32:
             return None
         built = self._train_spec(x, data, dev)

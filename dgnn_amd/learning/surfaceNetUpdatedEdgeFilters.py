@@ -115,10 +115,12 @@ class SurfaceNet(nn.Module):
         f = self.clf.features
         x_all = data_all.x
         n_id = data_all.n_id.to(x_all.device)
-        if f.normalization_feature and not f.keep_normalization_feature:
-            x = _dev_f32(x_all[n_id, 1:], dev)
-        else:
-            x = _dev_f32(x_all[n_id, :], dev)
+        from ..sampler import block_rows
+        col0 = 1 if (f.normalization_feature and not f.keep_normalization_feature) else 0
+        x = block_rows(n_id, x_all, col0, x_all.size(1) - col0, "all") if x_all.dim() == 2 else None     # gathered by the block's builder (attach_rows)?
+        if x is None:
+            x = x_all[n_id, 1:] if col0 else x_all[n_id, :]
+        x = _dev_f32(x, dev)
         if self.storage_dtype == torch.bfloat16:
             x = Fn.to_bf16(x)
         edge_attr = _dev_f32(data_all.edge_attr, dev)

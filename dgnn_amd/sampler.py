@@ -69,6 +69,7 @@ class NeighborSampler:
         # been drawn.  A training loop consumes a block before it asks for the next; anything that keeps blocks (list(loader)) must not
         # set it.
         self._ring = [None] * 3 if reuse_buffers else None
+        self._rows = []
         self._escaped = None
         self._pos = torch.full((n,), -1, dtype=torch.int32, device=self.device)
         self._first = torch.full((n,), _I32_MAX, dtype=torch.int32, device=self.device)
@@ -77,6 +78,21 @@ class NeighborSampler:
         # two host round trips per hop (reading the count back) is not needed
         rp = self.plan.rowptr
         self._regular = bool(((rp[1:] - rp[:-1]) == 4).all().item()) if n > 0 else False
+
+    def attach_rows(self, specs):
+        """Rows the builder gathers behind every block, on its own stream (prefetching iteration with reuse_buffers over a 4-regular graph; other
+        modes ignore it): `specs` = up to 4 tuples (src, col0, cols, which) -- src a resident fp32 [N, C] tensor with unit column stride, the columns
+        [col0, col0 + cols) of its rows at the block's node ids (which = "all": n_id) or at the batch's targets (which = "batch": n_id[:batch_size]).
+        What the reference's training loop indexes at the head of every step (x_all[n_id, 1:], x_all[ids], y_all[ids]; learning/
+        surfaceNetStaticEdgeFilters.py:206, learning/runModel.py:273-274).  Consumers ask `block_rows(n_id, src, col0, cols, which)`."""
+        ok = []
+        for src, col0, cols, which in specs:
+            if isinstance(src, torch.Tensor) and src.is_cuda and src.device == self.device and src.dtype == torch.float32 and src.dim() == 2 \
+                    and src.stride(1) == 1 and 0 <= col0 and col0 + cols <= src.size(1) and cols > 0 and which in ("all", "batch"):
+                ok.append((src, int(col0), int(cols), which))
+        self._rows = ok[:4]
+        if self._ring is not None:
+            self._ring = [None] * 3        # buffer sets are sized with their row outputs
 
     def _arange_full(self, n):
         """the shared 0, 1, 2, ... buffer, at least n long"""
@@ -291,6 +307,15 @@ class NeighborSampler:
             t_arrs = [arr(b[k]) for k in ("t_rowptr", "t_dst", "t_eid", "t_rows")]
         b["args_tail"] = (arr(b["ei"]), arr(b["e_id"]), arr(b["src32"]), arr(b["e_id32"]), arr(b["off"]), arr(b["n_out"]), caps(cap_t), caps(cap_e),
                           ptr(scratch[:-1]), ptr(scratch[-1:]), *t_arrs, caps(cap_all) if want_t else None, ptr(plan_scratch))
+        if self._rows:     # row gathers behind the block (attach_rows): outputs sized by the outermost block's bound / the batch
+            cap_nodes = min(cap_t[-1] + cap_e[-1], self.num_nodes)
+            outs = [torch.empty((cap_nodes if which == "all" else nb, cols), dtype=torch.float32, device=dev) for _, _, cols, which in self._rows]
+            k = len(outs)
+            b["rows_out"] = outs
+            b["rows_spec"] = list(self._rows)
+            b["rows_args"] = (k, (C.c_void_p * k)(*[src.data_ptr() + 4 * col0 for src, col0, _, _ in self._rows]),
+                              (C.c_int64 * k)(*[src.stride(0) for src, _, _, _ in self._rows]), (C.c_int32 * k)(*[cols for _, _, cols, _ in self._rows]),
+                              (C.c_int32 * k)(*[int(which == "batch") for _, _, _, which in self._rows]), (C.c_void_p * k)(*[o.data_ptr() for o in outs]))
         return b
 
     def _start_regular(self, n_id: torch.Tensor, background: bool, b=None, stream=None):
@@ -305,11 +330,18 @@ class NeighborSampler:
         b["counts"] = counts = (C.c_int64 * (b["hops"] + 1))()
         L = lib()
         args = (ptr(p.rowptr), ptr(p.src), ptr(p.eid), 4, ptr(n_id), nb, b["hops"], ptr(self._pos), ptr(self._first)) + b["args_tail"]
-        if background:
+        if background and b.get("rows_args") is not None:
+            b["job"] = L.dgnn_khop_blocks_regular_start_rows(*args, *b["rows_args"], stream if stream is not None else stream_ptr())
+            if not b["job"]:
+                check(-1, "dgnn_khop_blocks_regular_start_rows")
+            b["rows_live"] = True
+        elif background:
+            b["rows_live"] = False
             b["job"] = L.dgnn_khop_blocks_regular_start(*args, stream if stream is not None else stream_ptr())
             if not b["job"]:
                 check(-1, "dgnn_khop_blocks_regular_start")
         else:
+            b["rows_live"] = False
             check(L.dgnn_khop_blocks_regular(*args, counts, stream_ptr()), "dgnn_khop_blocks_regular", poll=True)
         return b
 
@@ -337,7 +369,12 @@ class NeighborSampler:
             if self._escaped is not None:
                 self._escaped += [b[k][h] for k in ("ei", "e_id", "off", "src32", "e_id32", "n_out")] + [self._iota]
         adjs = adjs[0] if len(adjs) == 1 else adjs[::-1]
-        return b["nb"], b["n_out"][-1][:int(counts[hops])], adjs
+        n_id = b["n_out"][-1][:int(counts[hops])]
+        if b.get("rows_live"):     # the rows the builder gathered behind this block ride on its n_id (block_rows)
+            n_all = int(counts[hops])
+            n_id._dgnn_rows = {(src.data_ptr(), col0, cols, which): out[:(n_all if which == "all" else b["nb"])]
+                               for (src, col0, cols, which), out in zip(b["rows_spec"], b["rows_out"])}
+        return b["nb"], n_id, adjs
 
     def _sample_regular(self, n_id: torch.Tensor):
         return self._finish_regular(self._start_regular(n_id, background=False))
@@ -381,3 +418,13 @@ class NeighborSampler:
         check(L.dgnn_khop_reset(ptr(n_id), n_id.numel(), ptr(self._pos), st), "dgnn_khop_reset")
         adjs = adjs[0] if len(adjs) == 1 else adjs[::-1]
         return batch_size, n_id, adjs
+
+
+
+def block_rows(n_id, src, col0, cols, which="all"):
+    """The rows src[ids, col0:col0 + cols] of a block (ids = n_id, or its targets for which = "batch") when the block's builder gathered them
+    (NeighborSampler.attach_rows), else None -- the caller then indexes `src` itself."""
+    d = getattr(n_id, "_dgnn_rows", None)
+    if not d or not isinstance(src, torch.Tensor):
+        return None
+    return d.get((src.data_ptr(), int(col0), int(cols), which))

@@ -685,6 +685,17 @@ void* dgnn_khop_blocks_regular_start(const int32_t* rowptr, const int32_t* src, 
                                      const int64_t* cap_t, const int64_t* cap_e, int32_t* scratch, int32_t* n_new_dev, int32_t* const* t_rowptr,
                                      int32_t* const* t_dst, int32_t* const* t_eid, int32_t* const* t_rows, const int64_t* cap_all,
                                      int32_t* plan_scratch, void* stream);
+/* ... and up to 4 row gathers behind the block, on the builder's stream (the head-of-step x_all[n_id, 1:] / x_all[ids] / y_all[ids] of the reference's
+ * training loop, learning/surfaceNetStaticEdgeFilters.py:206 and learning/runModel.py:273-274): r_out[i][k, 0:r_cols[i]] = r_src[i][id_k * r_ld[i] + 0:r_cols[i]]
+ * for id_k = the nodes of the outermost block (r_which[i] = 0; n_id_out[hops-1][:counts[hops]]) or the batch's targets (r_which[i] = 1).  r_src[i] is
+ * fp32 and already points at the first wanted column; r_out[i] holds capacity x r_cols[i] packed rows.  Valid after dgnn_khop_blocks_regular_wait. */
+void* dgnn_khop_blocks_regular_start_rows(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int deg, const int64_t* batch,
+                                          int64_t n_batch, int hops, int32_t* pos, int32_t* first, int64_t* const* ei, int64_t* const* e_id,
+                                          int32_t* const* src32, int32_t* const* e_id32, int32_t* const* off, int64_t* const* n_id_out,
+                                          const int64_t* cap_t, const int64_t* cap_e, int32_t* scratch, int32_t* n_new_dev,
+                                          int32_t* const* t_rowptr, int32_t* const* t_dst, int32_t* const* t_eid, int32_t* const* t_rows,
+                                          const int64_t* cap_all, int32_t* plan_scratch, int n_rows, const float* const* r_src, const int64_t* r_ld,
+                                          const int32_t* r_cols, const int32_t* r_which, float* const* r_out, void* stream);
 int dgnn_khop_blocks_regular_wait(void* job, int hops, int64_t* counts_out);
 
 /* ------------------------------------------------------------------------------------------------

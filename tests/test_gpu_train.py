@@ -649,6 +649,68 @@ def test_direct_training_step_equals_the_autograd_step():
         assert torch.equal(out[True][2][k], out[False][2][k]), k
 
 
+@pytest.mark.parametrize("model", ["static", "updated"])
+def test_block_builder_gathers_the_step_rows_and_the_run_is_the_same(model):
+    """NeighborSampler.attach_rows (Trainer.attach_block_rows): x[n_id, 1:], x[ids], y[ids] come out of the block builder -- equal to indexing, for every
+    block of a buffer-ring loader and after a second attach; a training run with and without them ends bit-identical (same rows, same kernels)."""
+    import dgnn_amd.learning.runModel as RM
+    from dgnn_amd.learning.runModel import Metrics, Trainer
+    from dgnn_amd.sampler import NeighborSampler, block_rows
+    from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal
+    adj, _, _ = delaunay_tet_graph(4000, seed=17)
+    n = adj.shape[0] // 4
+    ei = torch.from_numpy(adj.T.astype(np.int64)).to(DEV)
+    x = hashed_normal(np.arange(n), 29, seed=1, device=DEV)
+    x[:, 0] = x[:, 0].abs() + 0.05
+    ea = hashed_normal(np.arange(4 * n), 20, seed=2, device=DEV)
+    occ = torch.sigmoid(2 * x[:, 3:4] + x[:, 7:8])
+    all_ = Config(x=x, y=torch.cat([occ, 1 - occ], 1), edge_attr=ea)
+    out = {}
+    for attach in (True, False):
+        clf = make_clf()
+        clf.temp.device = DEV
+        clf.temp.current_epoch = 0
+        clf.training.metrics = Metrics()
+        if model == "updated":
+            from dgnn_amd.learning.surfaceNetUpdatedEdgeFilters import SurfaceNet as Updated
+            ucfg = Config.wrap(dict(training=dict(model_params=[64, 128, 128, 128], model_name="sage+", loss="kl"),
+                                    features=dict(normalization_feature=1, keep_normalization_feature=0), temp=dict(device=DEV)))
+            torch.manual_seed(3)
+            net = Updated(28, ucfg).to(DEV).train()
+        else:
+            net = hip_static(train=True)
+        tr = Trainer(net)
+        opt = RM.make_adam(net.parameters(), 0.005)
+        loader = NeighborSampler(ei, sizes=[-1] * 4, node_idx=torch.arange(0, 5 * 200 + 37, device=DEV), num_nodes=n, batch_size=200, reuse_buffers=True)
+        if attach:
+            tr.attach_block_rows(loader, all_, net)
+            tr.attach_block_rows(loader, all_, net)      # (a second time: buffer sets are rebuilt)
+        losses = []
+        for bs, n_id, adjs in loader:
+            for (src, c0, nc, which) in ((x, 1, 28, "all"), (x, 0, 29, "batch"), (all_.y, 0, 2, "batch")):
+                got = block_rows(n_id, src, c0, nc, which)
+                assert (got is not None) == attach
+                if attach:
+                    ids = n_id if which == "all" else n_id[:bs]
+                    assert torch.equal(got, src[ids, c0:c0 + nc]), (which, c0)
+            d = Config(all=all_, batch_n_id=n_id, batch_adjs=adjs)
+            if model == "updated":
+                logits = net(Config(x=x, edge_attr=ea, n_id=n_id, adjs=adjs))
+                loss = (logits * torch.arange(logits.numel(), device=DEV).view_as(logits).float().cos()).sum()
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                losses.append(loss.item())
+            else:
+                losses.append(tr.train(d, opt, clf).item())
+                assert d.batch_x.shape == (bs, 29) and d.batch_gt.shape == (bs, 2)
+        assert len(losses) == 6
+        out[attach] = (losses, {k: v.detach().clone() for k, v in net.state_dict().items()})
+    assert out[True][0] == out[False][0]
+    for k in out[False][1]:
+        assert torch.equal(out[True][1][k], out[False][1][k]), k
+
+
 def test_aux_stream_backward_gives_identical_gradients():
     """dgnn_train_set_aux_stream(1): weight gradients on the library's second stream beside the dx chain -- same numbers"""
     from dgnn_amd._lib import lib

@@ -84,14 +84,16 @@ if args.updated:
     class _Tr:   # the reference's loss (runModel.py:171-211) on the Updated model's (x, edge_attr, n_id, adjs) batch layout
         def train(self, data, opt, clf, group=None):
             opt.zero_grad()
-            ids = data.batch_n_id[:data.batch_adjs[-1][2][1]]
             logits = net(Config(x=data.all.x, edge_attr=data.all.edge_attr, n_id=data.batch_n_id, adjs=data.batch_adjs)).float()
             from dgnn_amd import functional as Fn
-            loss, _ = Fn.kl_cell_loss(logits, data.all.y[ids], data.all.x[ids, 0])   # the Trainer's fused loss (runModel.py:171-209)
+            bx, by = Trainer._batch_rows(data, data.batch_adjs[-1][2][1])            # x[ids], y[ids]: from the block builder when it gathered them
+            loss, _ = Fn.kl_cell_loss(logits, by, bx[:, 0])   # the Trainer's fused loss (runModel.py:171-209)
             loss.backward()
             allreduce_gradients(net, group)
             opt.step()
             return loss
+
+        attach_block_rows = staticmethod(Trainer.attach_block_rows)
     tr = _Tr()
 else:
     net = SurfaceNet(clf).to(dev).train()
@@ -113,6 +115,8 @@ need = batch * (steps + args.warmup)
 idx = torch.cat([torch.randperm(n, generator=g)[:per] for _ in range(need // per + 1)])[:need]
 loader = NeighborSampler(ei, sizes=[-1] * 4, node_idx=idx.to(dev), num_nodes=n, batch_size=batch,
                          prefetch={"none": False, "stream": True, "thread": "thread"}[args.prefetch], reuse_buffers=not args.fresh_blocks)
+if os.environ.get("DGNN_BLOCK_ROWS", "1") != "0":
+    tr.attach_block_rows(loader, all_, net)      # x[n_id, 1:], x[ids], y[ids] gathered by the block builder behind every block (as Trainer.train_test does)
 it = iter(loader)
 block = 0
 for _ in range(args.warmup):
