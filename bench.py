@@ -245,6 +245,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=150000, help="Delaunay points (150000 -> 1 010 078 tets; 1485000 -> 10M tets)")
+    ap.add_argument("--events-every", type=int, default=4,
+                    help="N=1: every k-th timed step carries the per-launch HIP events of the roofline object (the events and the per-layer calls they need cost "
+                         "the step 1-2 %%); 1 = every step")
     ap.add_argument("--halo", choices=["recompute", "exchange"], default="recompute",
                     help="N>1: recompute (default) = every part keeps L rings of halo cells and recomputes each layer on the rings later layers read, no collective "
                          "in the data path; exchange = one ring, rows exchanged between the layers over RCCL (the form the partitioned backward uses)")
@@ -462,16 +465,31 @@ def main():
     # N = 1: the events sit inside the timed steps.  N > 1: a shard of the scene is small enough for the per-launch events (and the per-layer calls they
     # need: the product's step there is ONE library call) to show in the step time, so the timed region runs the product's step as it is and the same
     # number of instrumented steps follows it for the roofline object.
+    # The events cost the step 1-2 % (eight markers in the queue and the per-layer calls they need -- the product's step is ONE library call): every
+    # `--events-every`-th timed step carries them (default 4: 5 of the 20 default steps), the others run the step exactly as a user's call does.
     events_in_timed = world == 1
-    if events_in_timed:
+    inst = {"i": 0, "n": 0}
+    every = max(1, args.events_every)
+
+    def step_timed():
+        on = inst["i"] % every == 0
+        inst["i"] += 1
+        if not on:
+            return step()
+        inst["n"] += 1
         ops.LAYER_HOOK = hook
-    dt, per_step = timed_steps(step, args.steps, sync, world, dev)
+        try:
+            return step()
+        finally:
+            ops.LAYER_HOOK = None
+    dt, per_step = timed_steps(step_timed if events_in_timed else step, args.steps, sync, world, dev)
     if not events_in_timed:
         ops.LAYER_HOOK = hook
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
     ops.LAYER_HOOK = None
+    n_inst = inst["n"] if events_in_timed else args.steps      # steps that carried events
     ms_per_step = dt / args.steps * 1e3
     value = n_total * args.steps / dt
 
@@ -482,13 +500,13 @@ def main():
         rows = sum(r for _, _, r in evs)
         # launches of this kind per step (a partitioned layer is two launches, interior + boundary cells: `rows` adds them up so that bytes and
         # time cover the same cells)
-        n_l = max(1, round(rows / (n_local * args.steps)))
-        ms = tot / (n_l * args.steps)
+        n_l = max(1, round(rows / (n_local * n_inst)))
+        ms = tot / (n_l * n_inst)
         c_in, c_out, plain = key
         # SURVEY 8d per-unit figure of what this launch executes: the layer's row, plus the decoder's row (elem * C + 8) when it rides along
         per_tet = layer_bytes(c_in, c_out, elem) + (0 if plain else elem * c_out + 8)
-        algo = int(per_tet * rows / (n_l * args.steps))
-        return {"total_ms": tot, "launches_per_step": n_l, "ms": ms, "algo": algo, "per_tet": per_tet, "rows_per_launch": rows / (n_l * args.steps), "n_events": len(evs)}
+        algo = int(per_tet * rows / (n_l * n_inst))
+        return {"total_ms": tot, "launches_per_step": n_l, "ms": ms, "algo": algo, "per_tet": per_tet, "rows_per_launch": rows / (n_l * n_inst), "n_events": len(evs)}
 
     roof = None
     if layer_events:
@@ -536,8 +554,8 @@ def main():
             r = {"bound": "hbm", "kernel": "%s (%d launch%s per step)" % (kname, st["launches_per_step"], "" if st["launches_per_step"] == 1 else "es"),
                  "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                  "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": st["algo"], "algorithmic_bytes_per_tet": st["per_tet"],
-                 "avg_launch_ms": round(st["ms"], 4), "share_of_step": round(st["total_ms"] / args.steps / ms_per_step, 4),
-                 "timing": ("HIP events around each launch inside the timed steps (%d launches)" if events_in_timed else
+                 "avg_launch_ms": round(st["ms"], 4), "share_of_step": round(st["total_ms"] / n_inst / ms_per_step, 4),
+                 "timing": (("HIP events around each launch inside the timed steps, every %d-th step (%%d launches)" % every) if events_in_timed else
                             "HIP events around each launch in K instrumented steps right behind the timed region (%d launches)") % st["n_events"], "pmc": pmc or None}
             if not plain:
                 r["algorithmic_bytes_note"] = ("SURVEY 8d rows this launch executes: last conv layer %d B/tet + decoder %d B/tet (the contract figure; the launch itself moves "
