@@ -92,7 +92,7 @@ class NeighborSampler:
                 ok.append((src, int(col0), int(cols), which))
         self._rows = ok[:4]
         if self._ring is not None:
-            self._ring = [None] * 3        # buffer sets are sized with their row outputs
+            self._ring = [None] * 3        # buffer sets are sized with their row outputs (call this BEFORE iterating, not from inside the loop)
 
     def _arange_full(self, n):
         """the shared 0, 1, 2, ... buffer, at least n long"""
@@ -374,6 +374,8 @@ class NeighborSampler:
             n_all = int(counts[hops])
             n_id._dgnn_rows = {(src.data_ptr(), col0, cols, which): out[:(n_all if which == "all" else b["nb"])]
                                for (src, col0, cols, which), out in zip(b["rows_spec"], b["rows_out"])}
+            if self._escaped is not None:      # fresh buffers (no reuse ring): the consumer's stream must be recorded on them like on the block's arrays
+                self._escaped += list(b["rows_out"])
         return b["nb"], n_id, adjs
 
     def _sample_regular(self, n_id: torch.Tensor):
