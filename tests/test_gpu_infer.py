@@ -235,6 +235,31 @@ def test_partitioned_one_call_with_rccl_self_exchange_equals_whole_scene(tmp_pat
 
 
 # ---- ring parts: a scene cut across ranks with NO exchange (every rank recomputes the rings of halo cells later layers read) -------------------------
+def test_ring_parts_of_a_tiny_scene_cover_it_and_agree():
+    """more ranks than a scene has room for: rings swallow the whole scene, a rank may own a handful of cells or none -- the union still equals the whole"""
+    from dgnn_amd.partition import PartitionedScene, build_ring_part, rcb_partition
+    from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal
+    adj, cent, _ = delaunay_tet_graph(9, seed=2)
+    n = adj.shape[0] // 4
+    ei = adj.T.astype(np.int64)
+    x = hashed_normal(np.arange(n), 29, seed=1, device=DEV)
+    ea = hashed_normal(np.arange(4 * n), 20, seed=2, device=DEV)
+    net = hip_static()
+    full = net.inference_layer(Config(x=x, edge_attr=ea, edge_index=torch.from_numpy(ei).to(DEV)))
+    world = 16
+    part = rcb_partition(cent, world)
+    part[part == 3] = 4                     # rank 3 owns nothing
+    got = torch.full_like(full, float("nan"))
+    for rank in range(world):
+        lp = build_ring_part(ei, part, rank, world, net.num_layers)
+        rows = np.concatenate([lp.own_gid, lp.halo_gid])
+        scene = PartitionedScene(lp, x[torch.from_numpy(rows).to(DEV)], ea[torch.from_numpy(lp.edge_gid).to(DEV)], DEV)
+        logits = scene.inference_layer(net)
+        assert logits.shape == (lp.n_own, 2) and (rank != 3 or lp.n_own == 0)
+        got[torch.from_numpy(lp.own_gid).to(DEV)] = logits
+    assert torch.equal(got, full)
+
+
 @pytest.mark.parametrize("world,storage", [(2, "f32"), (8, "f32"), (3, "bf16")])
 def test_ring_parts_union_equals_whole_scene(world, storage):
     """dgnn_static_infer_rings_fwd / the per-layer chain over the same destination prefixes: rank after rank on the one GPU (the ranks are independent:
