@@ -28,8 +28,13 @@ def worker(lib, dtype, points):
     from dgnn_amd.learning.surfaceNetStaticEdgeFilters import SurfaceNet
     import bench
     dev = "cuda:0"
-    adj, _, x, ea = bench.make_scene(points, 0)
+    adj, cent, x, ea = bench.make_scene(points, 0)
     n = adj.shape[0] // 4
+    if os.environ.get("DGNN_VARIANTS_ORDER", "loader") == "loader":      # the scene as the package's loader leaves it (ingest-time Morton order), as bench.py
+        from dgnn_amd.synthetic import loader_cell_order
+        adj, cent, order = loader_cell_order(adj, cent)
+        x = x[torch.from_numpy(order)]
+        ea = ea.view(n, 4, -1)[torch.from_numpy(order)].reshape(4 * n, -1)
     net = SurfaceNet(reconbench_pretrained(device=dev))
     net.load_state_dict(bench.load_weights())
     net = net.to(dev).eval()
