@@ -335,3 +335,20 @@ def test_one_call_bf16_storage_equals_the_per_layer_path(points, unsigned):
     net.set_storage_dtype(torch.float32)
     one32, ref32 = _both_paths(net, data)
     assert torch.equal(one32, ref32) and (one32 - one).abs().max().item() < 0.2
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_inference_layer_on_an_empty_and_a_single_cell_scene(storage):
+    """no cells -> logits [0, 2]; one cell whose four neighbour slots point at itself (the smallest reference-layout scene) -> finite logits equal to the
+    per-layer path's; one call and per-layer chain alike"""
+    net = hip_static()
+    if storage == "bf16":
+        net.set_storage_dtype(torch.bfloat16)
+    empty = Config(x=torch.zeros(0, 29, device=DEV), edge_attr=torch.zeros(0, 20, device=DEV), edge_index=torch.zeros(2, 0, dtype=torch.int64, device=DEV))
+    one, ref = _both_paths(net, empty)
+    assert one.shape == (0, 2) and ref.shape == (0, 2)
+    g = torch.Generator().manual_seed(1)
+    single = Config(x=torch.randn(1, 29, generator=g).to(DEV), edge_attr=torch.randn(4, 20, generator=g).to(DEV),
+                    edge_index=torch.zeros(2, 4, dtype=torch.int64, device=DEV))
+    one, ref = _both_paths(net, single)
+    assert one.shape == (1, 2) and torch.isfinite(one).all() and torch.equal(one, ref)
