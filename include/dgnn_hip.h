@@ -364,8 +364,9 @@ int dgnn_static_infer_fwd(const int64_t* edge_index, int64_t stride_row, int64_t
  *   n_dst [n_layers]  destinations of layer l = the first n_dst[l] local cells (non-increasing; n_dst[L-1] = the owned cells = rows of `logits`);
  *                     the plan (built when edge_index != NULL) covers n_dst[0] destinations, n_loc = all local cells incl. the outermost ring
  *   attr_in_plan_order != 0: edge_attr rows are grouped by destination already (a part's local list is): read in place, not through eid
- * Everything else as dgnn_static_infer_fwd (which is this call with every n_dst[l] = n).  A cell's result does not depend on which other cells
- * share its launch: the union of the ranks' logits is bit-identical to the whole scene's.  workspace: dgnn_static_infer_workspace_bytes(n_dst[0], ...).
+ * Everything else as dgnn_static_infer_fwd (which is this call with every n_dst[l] = n).  On a reference-layout scene (4 in-edges per cell) a cell's
+ * result does not depend on which other cells share its launch: the union of the ranks' logits is bit-identical to the whole scene's (a ragged graph:
+ * equal to fp32 rounding).  workspace: dgnn_static_infer_workspace_bytes(n_dst[0], ...).
  * ---------------------------------------------------------------------------------------------- */
 int dgnn_static_infer_rings_fwd(const int64_t* edge_index, int64_t stride_row, int64_t stride_col, int64_t E, int plan_hint, int32_t* rowptr,
                                 int32_t* src, int32_t* eid, int32_t* plan_scratch, int attr_in_plan_order, int64_t n_loc, const int64_t* n_dst,
