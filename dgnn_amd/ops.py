@@ -64,6 +64,7 @@ def _f32_work(n, device):
 
 # ---- plan ---------------------------------------------------------------------------------------
 PLAN_HINT_AUTO, PLAN_HINT_GROUPED, PLAN_HINT_REFERENCE, PLAN_HINT_GENERIC = 0, 1, 2, 3
+PLAN_HINT_GROUPED_TRUSTED = 4     # GROUPED without the device-side check / standby builder: for lists this package laid out itself (partition.build_ring_part)
 
 
 @on_device_of

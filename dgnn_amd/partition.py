@@ -146,8 +146,10 @@ def build_ring_part(edge_index: np.ndarray, part: np.ndarray, rank: int, world: 
     e_loc = np.stack([loc[src[e_sel]], ld[e_sel]])
     assert (e_loc >= 0).all()
     zeros = [0] * world
-    return LocalPart(rank, world, n, own_gid, int(own_gid.shape[0]), halo_gid, e_loc, e_sel.astype(np.int64), np.zeros(0, np.int64), zeros, list(zeros),
-                     ring_counts=[int(r.shape[0]) for r in rings])
+    lp = LocalPart(rank, world, n, own_gid, int(own_gid.shape[0]), halo_gid, e_loc, e_sel.astype(np.int64), np.zeros(0, np.int64), zeros, list(zeros),
+                   ring_counts=[int(r.shape[0]) for r in rings])
+    lp.trusted_grouped = bool(e_loc.shape[1] == 0 or (np.all(np.diff(e_loc[1]) >= 0) and e_loc[1, -1] < n_computed and e_loc.min() >= 0))   # by construction; checked once, here
+    return lp
 
 
 def ring_dst(lp: LocalPart, num_layers: int) -> List[int]:
@@ -307,6 +309,9 @@ class HaloExchange:
         self.start(h_full)
         self.wait()
         return h_full
+
+
+RING_TRUSTED_PLAN = __import__("os").environ.get("DGNN_RING_TRUSTED_PLAN", "1") != "0"     # 0: a ring part's plan goes through the verified GROUPED builder
 
 
 class LoopbackExchange(HaloExchange):
@@ -520,10 +525,12 @@ def _partitioned_scene_infer_rings(self, net, x, xe, n_src, rebuild_plan):
     if tabs is not None and (not tabs[3] or fuse):
         layers, decoder, prepared, with_dec, cache = tabs
         parts = None if build else (self.plan.rowptr, self.plan.src, self.plan.eid)
+        # (the local list was laid out grouped by destination by build_ring_part: its plan is ONE launch, nothing to verify -- lp.trusted_grouped)
+        hint = ops.PLAN_HINT_GROUPED_TRUSTED if (getattr(lp, "trusted_grouped", False) and RING_TRUSTED_PLAN) else ops.PLAN_HINT_GROUPED
         if net.storage_dtype == torch.bfloat16:
-            out = ops.static_infer_rings_fwd_bf16(x, xe, self.edge_index, parts, nd, layers, decoder, cache=cache)
+            out = ops.static_infer_rings_fwd_bf16(x, xe, self.edge_index, parts, nd, layers, decoder, hint=hint, cache=cache)
         else:
-            out = ops.static_infer_rings_fwd(x, xe, self.edge_index, parts, nd, layers, decoder, prepared, fuse_decoder=with_dec, cache=cache)
+            out = ops.static_infer_rings_fwd(x, xe, self.edge_index, parts, nd, layers, decoder, prepared, hint=hint, fuse_decoder=with_dec, cache=cache)
         if out is not None:
             if build:
                 self.plan = self._GraphPlan(self.edge_index, n_src, nd[0], hint=1, parts=out[1])

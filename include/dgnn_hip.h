@@ -81,6 +81,9 @@ int dgnn_poll_async_error(void);
 #define DGNN_PLAN_HINT_GROUPED 1
 #define DGNN_PLAN_HINT_REFERENCE 2
 #define DGNN_PLAN_HINT_GENERIC 3 /* attempt neither: straight to the generic kernels */
+#define DGNN_PLAN_HINT_GROUPED_TRUSTED 4 /* GROUPED without the device-side check and without the generic builder standing by: ONE launch.  For lists
+                                           * the caller laid out itself (a ring part); a list that is not ascending in range gives a wrong plan (never an
+                                           * out-of-bounds write) */
 int64_t dgnn_plan_scratch_elems(int64_t E, int64_t n_key);
 int dgnn_plan_build(const int64_t* edge_index, int64_t stride_row, int64_t stride_col, int64_t E, int64_t n_key,
                     int64_t n_other, int by, int hint, int32_t* rowptr, int32_t* other, int32_t* eid, int32_t* scratch,

@@ -1201,3 +1201,27 @@ def test_linear_fwd_x2h_vs_fp64(k1, k2, n_out):
         finally:
             ops.X2HP = old_hp
         assert torch.equal(outs[0], outs[1]) and (outs[0].cpu().double() - ref).abs().max().item() > 0      # (and it is the fp16 two-part arithmetic, not fp64)
+
+
+def test_plan_grouped_trusted_hint_is_the_grouped_plan_in_one_launch():
+    """DGNN_PLAN_HINT_GROUPED_TRUSTED (ring parts: the list was laid out grouped by destination by this package): the same plan as the verified GROUPED builder,
+    with rows without edges at the start / middle / end; a list that breaks the promise gives some plan inside its arrays (no fault), an empty list works"""
+    from dgnn_amd import ops
+    rng = np.random.default_rng(3)
+    n_dst, n_src = 4000, 6000
+    deg = rng.integers(0, 7, n_dst)
+    deg[:5] = 0; deg[2000:2010] = 0; deg[-7:] = 0
+    dst = np.repeat(np.arange(n_dst), deg)
+    ei = torch.from_numpy(np.stack([rng.integers(0, n_src, dst.shape[0]), dst])).to(DEV)
+    want = ops.plan_build(ei, n_dst, by=1, hint=ops.PLAN_HINT_GROUPED, n_other=n_src)
+    got = ops.plan_build(ei, n_dst, by=1, hint=ops.PLAN_HINT_GROUPED_TRUSTED, n_other=n_src)
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    bad = ei.clone()
+    bad[1] = bad[1].flip(0)                                # descending keys: the promise is broken
+    bad[1, 17] = n_dst + 12345                             # ... and one key out of range
+    rp, oth, eid = ops.plan_build(bad, n_dst, by=1, hint=ops.PLAN_HINT_GROUPED_TRUSTED, n_other=n_src)
+    torch.cuda.synchronize()
+    assert rp.numel() == n_dst + 1 and int(rp.max()) <= bad.size(1) and int(oth.max()) < n_src
+    rp0, _, _ = ops.plan_build(torch.zeros(2, 0, dtype=torch.int64, device=DEV), 5, by=1, hint=ops.PLAN_HINT_GROUPED_TRUSTED)
+    assert torch.equal(rp0.cpu(), torch.zeros(6, dtype=torch.int32))
