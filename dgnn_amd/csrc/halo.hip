@@ -78,6 +78,16 @@ __global__ void k_halo_pack(const uint32_t* __restrict__ in, int64_t ld, const i
     }
 }
 
+// rows of `cols` 4-byte words: out[r * ld + c] = in[r * cols + c]  (packed staging -> the strided tail of the activation buffer)
+__global__ void k_halo_unpack(const uint32_t* __restrict__ in, int64_t n, int cols, uint32_t* __restrict__ out, int64_t ld) {
+    const int64_t total = n * cols;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / cols;
+        const int c = (int)(t - r * cols);
+        out[r * ld + c] = in[t];
+    }
+}
+
 }  // namespace
 
 struct dgnn_halo_plan {
@@ -88,6 +98,11 @@ struct dgnn_halo_plan {
     hipStream_t side;
     hipEvent_t packed, done;
     bool pending;
+    // receive staging for a STRIDED buffer (ld != C): one packed message per peer lands here and k_halo_unpack spreads it, so that what goes over the
+    // wire -- ONE message of rows * C * elem_bytes per peer and direction -- never depends on either side's row stride (a rank that
+    // received row by row because ITS ld != C needed a peer that sent row by row, i.e. the same ld everywhere).  Owned by the plan, grown on demand.
+    void* stage;
+    size_t stage_bytes;
 };
 
 extern "C" int dgnn_rccl_available(void) { return rccl().handle != nullptr; }
@@ -144,6 +159,8 @@ extern "C" int dgnn_halo_plan_create(int rank, int world, int64_t n_own, const i
     p->pending = false;
     p->side = nullptr;
     p->packed = p->done = nullptr;
+    p->stage = nullptr;
+    p->stage_bytes = 0;
     ok = ok && (p->n_send == 0 || send_idx != nullptr);
     ok = ok && hipGetDevice(&p->device) == hipSuccess && hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) == hipSuccess &&
          hipEventCreateWithFlags(&p->packed, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&p->done, hipEventDisableTiming) == hipSuccess;
@@ -168,6 +185,7 @@ extern "C" int dgnn_halo_plan_destroy(dgnn_halo_plan* p) {
     (void)hipStreamDestroy(p->side);
     (void)hipEventDestroy(p->packed);
     (void)hipEventDestroy(p->done);
+    if (p->stage) (void)hipFree(p->stage);
     delete[] p->send_off;
     delete[] p->recv_off;
     delete p;
@@ -197,28 +215,36 @@ extern "C" int dgnn_halo_exchange_start(dgnn_halo_plan* p, void* comm, void* x, 
     // the side stream starts once the packed rows -- and everything before them on the caller's stream, i.e. the buffer itself -- are ready
     if (hipEventRecord(p->packed, stream) != hipSuccess || hipStreamWaitEvent(p->side, p->packed, 0) != hipSuccess) return dgnn_check_launch("halo_exchange_start");
     ncclComm_t c = static_cast<ncclComm_t>(comm);
+    char* tail = static_cast<char*>(x) + p->n_own * ld_bytes;
+    char* land = tail;                 // where the packed halo rows land: the tail itself when it is packed (ld == C), else the plan's staging area
+    if (ld != C && p->n_recv) {
+        const size_t need = (size_t)(p->n_recv * row_bytes);
+        if (need > p->stage_bytes) {       // (first use / a wider layer: the one allocation this library makes, inside the opaque plan)
+            (void)hipStreamSynchronize(p->side);
+            if (p->stage) (void)hipFree(p->stage);
+            p->stage = nullptr;
+            p->stage_bytes = 0;
+            if (hipMalloc(&p->stage, need) != hipSuccess) { (void)hipGetLastError(); dgnn_set_error("halo_exchange_start: no memory for %zu bytes of receive staging", need); return DGNN_E_LAUNCH; }
+            p->stage_bytes = need;
+        }
+        land = static_cast<char*>(p->stage);
+    }
     ncclResult_t rc = r.GroupStart();
     if (rc != ncclSuccess) return rccl_fail("halo_exchange_start (group start)", rc);
-    char* tail = static_cast<char*>(x) + p->n_own * ld_bytes;
     for (int peer = 0; peer < p->world && rc == ncclSuccess; ++peer) {
         const int64_t nr = p->recv_off[peer + 1] - p->recv_off[peer], ns = p->send_off[peer + 1] - p->send_off[peer];
-        // halo rows of one owner land contiguously in the tail: with ld == C one transfer, otherwise row by row inside the same group
-        if (nr) {
-            if (ld == C) rc = r.Recv(tail + p->recv_off[peer] * ld_bytes, (size_t)(nr * row_bytes), ncclInt8, peer, c, p->side);
-            else
-                for (int64_t i = 0; i < nr && rc == ncclSuccess; ++i)
-                    rc = r.Recv(tail + (p->recv_off[peer] + i) * ld_bytes, (size_t)row_bytes, ncclInt8, peer, c, p->side);
-        }
-        if (ns && rc == ncclSuccess) {
-            if (ld == C) rc = r.Send(static_cast<char*>(send_buf) + p->send_off[peer] * row_bytes, (size_t)(ns * row_bytes), ncclInt8, peer, c, p->side);
-            else
-                for (int64_t i = 0; i < ns && rc == ncclSuccess; ++i)
-                    rc = r.Send(static_cast<char*>(send_buf) + (p->send_off[peer] + i) * row_bytes, (size_t)row_bytes, ncclInt8, peer, c, p->side);
-        }
+        // ONE message per peer and direction, whatever the row strides on either side
+        if (nr) rc = r.Recv(land + p->recv_off[peer] * row_bytes, (size_t)(nr * row_bytes), ncclInt8, peer, c, p->side);
+        if (ns && rc == ncclSuccess) rc = r.Send(static_cast<char*>(send_buf) + p->send_off[peer] * row_bytes, (size_t)(ns * row_bytes), ncclInt8, peer, c, p->side);
     }
     const ncclResult_t rc2 = r.GroupEnd();
     if (rc != ncclSuccess) return rccl_fail("halo_exchange_start (send / recv)", rc);
     if (rc2 != ncclSuccess) return rccl_fail("halo_exchange_start (group end)", rc2);
+    if (land != tail) {
+        const int cols = (int)(row_bytes / 4);
+        hipLaunchKernelGGL(k_halo_unpack, dim3(dgnn_grid_cap(dgnn_cdiv(p->n_recv * cols, 256))), dim3(256), 0, p->side, reinterpret_cast<const uint32_t*>(land), p->n_recv, cols,
+                           reinterpret_cast<uint32_t*>(tail), ld_bytes / 4);
+    }
     if (hipEventRecord(p->done, p->side) != hipSuccess) return dgnn_check_launch("halo_exchange_start");
     p->pending = true;
     return DGNN_OK;

@@ -343,9 +343,14 @@ class _SceneBatchNormRelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, bn, reduce, relu):
         n_loc, c = x.shape
-        m_l, v_l = ops.bn_batch_stats(x)                                  # local mean / biased variance
-        m64 = m_l.double()
-        st = torch.cat([m64 * n_loc, (v_l.double() + m64 * m64) * n_loc, torch.full((1,), float(n_loc), dtype=torch.float64, device=x.device)])
+        if n_loc == 0:
+            # a rank that owns no rows of this scene (rcb_partition of a tiny scene) contributes zero sums and STILL enters both
+            # all-reduces -- the row kernels require M > 0 and raising before the collective left the other ranks waiting in it
+            st = torch.zeros(2 * c + 1, dtype=torch.float64, device=x.device)
+        else:
+            m_l, v_l = ops.bn_batch_stats(x)                              # local mean / biased variance
+            m64 = m_l.double()
+            st = torch.cat([m64 * n_loc, (v_l.double() + m64 * m64) * n_loc, torch.full((1,), float(n_loc), dtype=torch.float64, device=x.device)])
         st = reduce(st)
         n = float(st[2 * c].item())
         mean64 = st[:c] / n
@@ -357,8 +362,11 @@ class _SceneBatchNormRelu(torch.autograd.Function):
                 mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
                 bn.running_mean.mul_(1 - mom).add_((mom * mean64).to(bn.running_mean.dtype))
                 bn.running_var.mul_(1 - mom).add_((mom * var64 * (n / max(n - 1.0, 1.0))).to(bn.running_var.dtype))
-        scale, shift = ops.bn_fold(gamma, beta, mean, var, bn.eps)
-        y = ops.scale_shift_act(x, scale, shift, relu)
+        if n_loc == 0:
+            y = torch.empty_like(x)
+        else:
+            scale, shift = ops.bn_fold(gamma, beta, mean, var, bn.eps)
+            y = ops.scale_shift_act(x, scale, shift, relu)
         ctx.save_for_backward(x, y, gamma, mean, var)
         ctx.cfg = (reduce, bool(relu), float(bn.eps), n)
         return y
@@ -368,9 +376,10 @@ class _SceneBatchNormRelu(torch.autograd.Function):
         x, y, gamma, mean, var = ctx.saved_tensors
         reduce, relu, eps, n = ctx.cfg
         dy = dy.contiguous()
-        loc = ops.bn_relu_bwd_sums(x, y, dy, mean, var, eps, relu)          # this rank's (sum g, sum g * x_hat) = its dbeta / dgamma terms
+        empty = x.size(0) == 0                                              # (see forward: zero sums, both collectives entered, nothing to apply)
+        loc = torch.zeros((2, x.size(1)), dtype=torch.float32, device=x.device) if empty else ops.bn_relu_bwd_sums(x, y, dy, mean, var, eps, relu)   # this rank's (sum g, sum g * x_hat) = its dbeta / dgamma terms
         glob = reduce(loc.double().reshape(-1).clone()).float().reshape(2, -1)
-        dx = ops.bn_relu_bwd_apply(x, y, dy, gamma, mean, var, eps, relu, glob, n)
+        dx = torch.empty_like(x) if empty else ops.bn_relu_bwd_apply(x, y, dy, gamma, mean, var, eps, relu, glob, n)
         return dx, loc[1].clone(), loc[0].clone(), None, None, None
 
 

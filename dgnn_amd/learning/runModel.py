@@ -267,13 +267,15 @@ class Trainer:
         if step is None or not TRAIN_DIRECT or clf.training.loss != "kl" or not FUSED_KL_LOSS or not clf.regularization.cell_type \
                 or clf.regularization.cell_norm not in Fn.ops.CELL_NORMS:
             return None
-        if clf.regularization.edge_epoch is not None and clf.temp.current_epoch >= clf.regularization.edge_epoch:
-            return None
+        if clf.regularization.edge_epoch is not None and (clf.temp.current_epoch >= clf.regularization.edge_epoch or clf.graph.additional_num_hops != 1):
+            return None        # (the second clause: `_with_regularization` prints and exits for such a config BEFORE edge_epoch is reached -- reference :250-253)
         x_all, y_all = data_train.all.x, data_train.all.y
         if not (x_all.is_cuda and y_all.is_cuda and x_all.dtype == torch.float32 and y_all.dtype == torch.float32):
             return None
         n_sup = data_train.batch_adjs[model.num_layers - 1].size[1] if hasattr(data_train.batch_adjs[0], "size") \
             else data_train.batch_adjs[model.num_layers - 1][2][1]
+        if n_sup == 0:
+            return None        # (the fused kl loss is guarded by logits.size(0) > 0 on the autograd path; an empty batch takes that path)
         data_train.batch_x, data_train.batch_gt = self._batch_rows(data_train, n_sup)     # (the reference leaves these on the data object, :273-274)
         metrics, norm = clf.training.metrics, Fn.ops.CELL_NORMS[clf.regularization.cell_norm]
         one = self.__dict__.get("_one")

@@ -334,11 +334,16 @@ class SurfaceNet(nn.Module):
                 if sp["plan"] is not None:
                     l["t_parts"] = sp["plan"].transposed_ptrs(bool(sp["scene_rows"]))
             grads = ops.static_train_bwd(x, layers, buf, meta, dlogits)
+        written = set()
         for l, g in zip(layers, grads):
             for name, gr in zip(("We", "be", "Wj", "bj", "Wi", "gamma", "beta"), g):
                 p_ = l[name]
                 if p_ is not None and p_.requires_grad:
                     p_.grad = gr
+                    written.add(id(p_))
+        for p_ in self.parameters():          # what zero_grad + backward leave: a trainable parameter this step did not reach has NO gradient
+            if p_.requires_grad and p_.grad is not None and id(p_) not in written:       # (a stale one from an earlier autograd step would be applied by Adam)
+                p_.grad = None
         return loss.detach()
 
     # ---- INFERENCE, whole graph (reference :323-355; the benchmarked path) ---------------------

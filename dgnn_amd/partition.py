@@ -204,32 +204,56 @@ class HaloExchange:
                     self._native = None
 
     def _init_native(self, group):
+        """Creates the library's communicator + halo plan.  COLLECTIVE over `group`, and every decision on the way is AGREED ON by all ranks
+        (a rank that failed locally -- no RCCL to open, no unique id on rank 0 -- used to fall back alone while its peers blocked in the
+        broadcast / ncclCommInitRank, or later mixed the two transports): (1) all-reduce(MIN) of "RCCL opens here" and, from rank 0, "the unique id
+        exists"; only if every rank says yes does anyone enter the broadcast and `dgnn_comm_create`; (2) all-reduce(MIN) of the local outcome of
+        communicator + plan creation; on a zero every rank destroys what it made and raises, so the whole group stays on torch.distributed."""
         import ctypes as C
         import torch.distributed as dist
         from ._lib import check, lib
         L = lib()
-        if not L.dgnn_rccl_available():
-            raise RuntimeError("no RCCL library could be opened")
         lp = self.lp
         rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+        def agree(flag: bool) -> bool:
+            if world == 1:
+                return bool(flag)
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            return bool(t.item())
+
         with torch.cuda.device(self.device):
+            ok = bool(L.dgnn_rccl_available())
             uid = torch.zeros(128, dtype=torch.uint8)
-            if rank == 0:
+            if ok and rank == 0:
                 buf = (C.c_ubyte * 128)()
-                check(L.dgnn_comm_unique_id(buf), "dgnn_comm_unique_id")
-                uid = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
+                ok = L.dgnn_comm_unique_id(buf) == 0
+                if ok:
+                    uid = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
+            if not agree(ok):
+                raise RuntimeError("RCCL (or rank 0's unique id) is unavailable on at least one rank of the group")
             if world > 1:
                 t = uid.to(self.device)
                 dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
                 uid = t.cpu()
             idb = (C.c_ubyte * 128)(*uid.tolist())
-            comm = C.c_void_p()
-            check(L.dgnn_comm_create(idb, rank, world, C.byref(comm)), "dgnn_comm_create")
-            plan = C.c_void_p()
-            sc = (C.c_int64 * world)(*[int(v) for v in lp.send_counts])
-            rc = (C.c_int64 * world)(*[int(v) for v in lp.recv_counts])
-            check(L.dgnn_halo_plan_create(rank, world, lp.n_own, C.c_void_p(self.send_idx32.data_ptr()) if self.send_idx32.numel() else None, sc, rc,
-                                          C.byref(plan)), "dgnn_halo_plan_create")
+            comm, plan = C.c_void_p(), C.c_void_p()
+            err = None
+            try:
+                check(L.dgnn_comm_create(idb, rank, world, C.byref(comm)), "dgnn_comm_create")
+                sc = (C.c_int64 * world)(*[int(v) for v in lp.send_counts])
+                rc = (C.c_int64 * world)(*[int(v) for v in lp.recv_counts])
+                check(L.dgnn_halo_plan_create(rank, world, lp.n_own, C.c_void_p(self.send_idx32.data_ptr()) if self.send_idx32.numel() else None, sc, rc,
+                                              C.byref(plan)), "dgnn_halo_plan_create")
+            except Exception as e:  # noqa: BLE001 -- reported after the agreement below
+                err = e
+            if not agree(err is None):
+                if plan:
+                    L.dgnn_halo_plan_destroy(plan)
+                if comm:
+                    L.dgnn_comm_destroy(comm)
+                raise RuntimeError("communicator / halo plan creation failed on at least one rank%s" % ("" if err is None else " (here: %s)" % err))
         self._native = (L, comm, plan)
 
     def __del__(self):
@@ -518,6 +542,17 @@ def _partitioned_scene_infer_rings(self, net, x, xe, n_src, rebuild_plan):
     lp, L = self.lp, net.num_layers
     nd = ring_dst(lp, L)
     self.used_one_call = False
+    # A part built with MORE rings than the model has conv layers (build_synthetic's default hops=4 under a 3-layer net) also lists the in-edges of
+    # rings this stack never computes.  The local list is grouped by ascending destination, so the edges of the cells layer 0 computes are a PREFIX
+    # of it: the plan (n_key = nd[0]) is built over that prefix only -- surplus edges would otherwise be clamped into the last row by the trusted
+    # builder.
+    ei = self.edge_index
+    if len(lp.ring_counts) > L:
+        n_e = int(np.searchsorted(lp.edge_index[1], nd[0], side="left"))
+        ei, xe = ei[:, :n_e], xe[:n_e]
+        self._ring_ei = ei         # (a plan holds its edge list weakly)
+    if self.plan is not None and (self.plan.n_dst != nd[0] or self.plan.E != ei.size(1)):
+        self.plan = None           # (another model depth was run on this part before)
     build = self.plan is None or rebuild_plan
     last = L - 1
     fuse = bool(getattr(net, "fuses_decoder", lambda i: False)(last)) and net._fusable_rows(x, last)
@@ -528,16 +563,16 @@ def _partitioned_scene_infer_rings(self, net, x, xe, n_src, rebuild_plan):
         # (the local list was laid out grouped by destination by build_ring_part: its plan is ONE launch, nothing to verify -- lp.trusted_grouped)
         hint = ops.PLAN_HINT_GROUPED_TRUSTED if (getattr(lp, "trusted_grouped", False) and RING_TRUSTED_PLAN) else ops.PLAN_HINT_GROUPED
         if net.storage_dtype == torch.bfloat16:
-            out = ops.static_infer_rings_fwd_bf16(x, xe, self.edge_index, parts, nd, layers, decoder, hint=hint, cache=cache)
+            out = ops.static_infer_rings_fwd_bf16(x, xe, ei, parts, nd, layers, decoder, hint=hint, cache=cache)
         else:
-            out = ops.static_infer_rings_fwd(x, xe, self.edge_index, parts, nd, layers, decoder, prepared, hint=hint, fuse_decoder=with_dec, cache=cache)
+            out = ops.static_infer_rings_fwd(x, xe, ei, parts, nd, layers, decoder, prepared, hint=hint, fuse_decoder=with_dec, cache=cache)
         if out is not None:
             if build:
-                self.plan = self._GraphPlan(self.edge_index, n_src, nd[0], hint=1, parts=out[1])
+                self.plan = self._GraphPlan(ei, n_src, nd[0], hint=1, parts=out[1])
             self.used_one_call = True
             return out[0]
     if build:
-        self.plan = self._GraphPlan(self.edge_index, n_src, nd[0], hint=1)
+        self.plan = self._GraphPlan(ei, n_src, nd[0], hint=1)
     plan = self.plan
     act = getattr(net, "activation_dtype", None)
     h = x

@@ -143,6 +143,7 @@ class dataLoader:
         kind = str(getattr(self.clf.temp, "cell_order", None) or os.environ.get("DGNN_CELL_ORDER", "auto")).lower()
         if kind not in ("none", "0", "false", "off"):
             self._reorder_cells(base, kind)
+        reorder.register_scene_order(self, self.cell_order)     # by path + gtfile: survives every copy of the loader's tensors (reorder.find_cell_order)
 
     def _reorder_cells(self, base, kind):
         """relabels the scene (module docstring); every per-cell / per-edge tensor of the loader moves with its cell"""

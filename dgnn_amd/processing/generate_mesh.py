@@ -118,6 +118,7 @@ def generate(data, prediction, clf):
     infinite = torch.as_tensor(data.infinite)
     # a scene the loader relabelled (processing/reorder.py): `_3dt.npz` knows the cells in FILE order -- logits and the infinite flags go back to it
     from .reorder import restore_cell_order
+    # (found on the object, on the loader's tagged tensors, or -- when those were copied -- in the registry of loaded scenes by path + gtfile)
     pred_dev, prediction = restore_cell_order(pred_dev, data), restore_cell_order(prediction, data)
     infinite = restore_cell_order(infinite, data)
     mfile = os.path.join(data.path, data.gtfile + "_3dt.npz")

@@ -111,14 +111,59 @@ def scene_order(edge_index: torch.Tensor, n: int, infinite=None, mfile: str = No
     return CellOrder(*cell_order_bfs(edge_index, n), "bfs")
 
 
+# The permutation of every scene the loader has relabelled in this process, by the scene's files (`path`, `gtfile`): the per-tensor RANK_TAG does not
+# survive `.to()`, `.clone()`, `.cpu()`, `torch.cat`, indexing or pickling, the data object's `path` / `gtfile` strings (run.py:212-213) do.  An entry
+# is replaced when the same scene is loaded again and set to None when it is loaded WITHOUT relabelling (so that a stale order is never applied).
+_SCENE_ORDERS = {}
+
+
+def _scene_key(data):
+    get = (lambda k: data.get(k)) if isinstance(data, dict) else (lambda k: getattr(data, k, None))
+    path, gt = get("path"), get("gtfile")
+    if path is None or gt is None:
+        return None
+    import os
+    return os.path.normpath(os.path.join(str(path), str(gt)))
+
+
+def register_scene_order(data, co) -> None:
+    """called by `dataLoader.run` for every scene it loads (co = None: loaded in file order)"""
+    key = _scene_key(data)
+    if key is not None:
+        _SCENE_ORDERS[key] = co
+
+
+def find_cell_order(data):
+    """-> (CellOrder | None, known): the order `data`'s rows are in.  Looked up (1) on the object itself (`cell_order`: the loader, or a dataset
+    object that carries the field), (2) on the loader's tagged per-cell tensors (an unmodified run.py:prepareSample hands those on), (3) in the
+    registry of scenes this process has loaded, by the object's `path` + `gtfile`.  `known` is False when none of the three says anything."""
+    said = False
+    if (isinstance(data, dict) and "cell_order" in data) or (not isinstance(data, dict) and hasattr(data, "cell_order")):
+        co = data["cell_order"] if isinstance(data, dict) else data.cell_order
+        if co is not None:
+            return co, True
+        said = hasattr(data, "run")         # the loader itself: None = its current scene is in file order
+        if said:
+            return None, True
+    for name in ("infinite", "x", "features", "y", "gt"):
+        v = getattr(data, name, None) if not isinstance(data, dict) else data.get(name)
+        co = getattr(v, RANK_TAG, None) if v is not None else None
+        if co is not None:
+            return co, True
+    key = _scene_key(data)
+    if key is not None and key in _SCENE_ORDERS:
+        return _SCENE_ORDERS[key], True
+    return None, said
+
+
 def restore_cell_order(t: torch.Tensor, data) -> torch.Tensor:
-    """Per-cell tensor `t` (rows in the order of `data`) back in FILE order; `data` is the loader, a dataset object carrying `cell_order`, or
-    one built by an unmodified `run.py:prepareSample` (the loader tags its per-cell tensors).  Unchanged when the scene was not reordered."""
-    co = getattr(data, "cell_order", None)
+    """Per-cell tensor `t` (rows in the order of `data`) back in FILE order; `data` is the loader, a dataset object carrying `cell_order`, one built by
+    an unmodified `run.py:prepareSample` (tagged tensors), or any object with the `path` / `gtfile` of a scene this process's loader has loaded
+    (the registry: survives `.to()` / `.clone()` / `torch.cat` / pickling of the tensors) -- see `find_cell_order`.  Unchanged when the scene was
+    not relabelled.  A permutation whose length is not `t`'s row count raises (a mixed-up scene) instead of scrambling the result."""
+    co, _ = find_cell_order(data)
     if co is None:
-        for name in ("infinite", "x", "features", "y", "gt"):
-            v = getattr(data, name, None) if not isinstance(data, dict) else data.get(name)
-            co = getattr(v, RANK_TAG, None) if v is not None else None
-            if co is not None:
-                break
-    return t if co is None else co.to_file(t)
+        return t
+    if co.rank.numel() != t.size(0):
+        raise RuntimeError("restore_cell_order: the scene's permutation has %d cells, the tensor %d rows" % (co.rank.numel(), t.size(0)))
+    return co.to_file(t)

@@ -292,6 +292,47 @@ def test_ring_parts_union_equals_whole_scene(world, storage):
         assert torch.equal(got, full), (world, storage, one_call)
 
 
+@pytest.mark.parametrize("extra,storage", [(1, "f32"), (2, "f32"), (1, "bf16")])
+def test_ring_parts_built_with_more_rings_than_the_model_has_layers(extra, storage):
+    """a part built with hops > num_layers (PartitionedScene.build_synthetic's default is 4 under any model) lists in-edges of rings the stack
+    never computes; the plan must be built over the prefix of edges whose destinations layer 0 computes (trusted AND verified builder, one call and
+    per-layer chain) -- union of the logits == the whole scene's, bit for bit."""
+    import dgnn_amd.partition as P
+    from dgnn_amd.partition import PartitionedScene, build_ring_part, rcb_partition, ring_dst
+    from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal, loader_cell_order
+    adj, cent, _ = delaunay_tet_graph(4000, seed=13)
+    adj, cent, _ = loader_cell_order(adj, cent)
+    n = adj.shape[0] // 4
+    ei = adj.T.astype(np.int64)
+    x = hashed_normal(np.arange(n), 29, seed=3, device=DEV)
+    ea = hashed_normal(np.arange(4 * n), 20, seed=4, device=DEV)
+    net = hip_static()
+    if storage == "bf16":
+        net.set_storage_dtype(torch.bfloat16)
+    full = net.inference_layer(Config(x=x, edge_attr=ea, edge_index=torch.from_numpy(ei).to(DEV)))
+    world = 3
+    part = rcb_partition(cent, world)
+    old = P.RING_TRUSTED_PLAN
+    try:
+        for trusted in (True, False):
+            P.RING_TRUSTED_PLAN = trusted
+            for one_call in (True, False):
+                got = torch.full_like(full, float("nan"))
+                for rank in range(world):
+                    lp = build_ring_part(ei, part, rank, world, net.num_layers + extra)
+                    assert len(lp.ring_counts) == net.num_layers + extra and ring_dst(lp, net.num_layers)[-1] == lp.n_own
+                    assert lp.edge_index.shape[1] > int(np.searchsorted(lp.edge_index[1], ring_dst(lp, net.num_layers)[0]))   # surplus edges exist
+                    rows = np.concatenate([lp.own_gid, lp.halo_gid])
+                    scene = PartitionedScene(lp, x[torch.from_numpy(rows).to(DEV)], ea[torch.from_numpy(lp.edge_gid).to(DEV)], DEV)
+                    scene.one_call = one_call
+                    for rebuild in (True, False):
+                        logits = scene.inference_layer(net, rebuild_plan=rebuild)
+                    got[torch.from_numpy(lp.own_gid).to(DEV)] = logits
+                assert torch.equal(got, full), (extra, storage, trusted, one_call)
+    finally:
+        P.RING_TRUSTED_PLAN = old
+
+
 def test_static_infer_rings_c_abi_rejects_growing_destination_counts():
     from dgnn_amd import ops
     from dgnn_amd._lib import lib, ptr

@@ -264,3 +264,19 @@ def test_generate_takes_a_reordered_scene(tmp_path):
                  Config(path=str(tmp_path), gtfile="gt/0", filename="0", id="", category="", infinite=inf_rows)):
         mesh, _ = generate(data, pred_rows, clf)
         assert np.array_equal(np.asarray(mesh.faces), g["faces"]) and np.array_equal(np.asarray(mesh.vertices), g["vertices_out"])
+    # (c) ADVICE r4: every tensor was COPIED (.clone() / .cpu() / cat drop the tag) -- the order is found by the scene's path + gtfile in the
+    # registry the loader fills; a permutation of another length raises instead of scrambling the mesh
+    from dgnn_amd.processing import reorder as R
+    key_obj = Config(path=str(tmp_path), gtfile="gt/0")
+    R.register_scene_order(key_obj, co)
+    try:
+        data = Config(path=str(tmp_path), gtfile="gt/0", filename="0", id="", category="", infinite=inf_rows.clone().cpu())
+        assert getattr(data.infinite, RANK_TAG, None) is None
+        mesh, _ = generate(data, pred_rows.clone(), clf)
+        assert np.array_equal(np.asarray(mesh.faces), g["faces"]) and np.array_equal(np.asarray(mesh.vertices), g["vertices_out"])
+        with pytest.raises(RuntimeError, match="permutation"):
+            R.restore_cell_order(pred_rows[:-1], data)
+        R.register_scene_order(key_obj, None)         # the same scene loaded again WITHOUT relabelling: the stale order is gone
+        assert R.find_cell_order(data) == (None, True)
+    finally:
+        R._SCENE_ORDERS.clear()
