@@ -130,6 +130,7 @@ SIGNATURES = {
     "dgnn_comm_unique_id": (i32, [vp]),
     "dgnn_comm_create": (i32, [vp, i32, i32, vp]),
     "dgnn_comm_destroy": (i32, [vp]),
+    "dgnn_comm_count": (i32, [vp]),
     "dgnn_halo_plan_create": (i32, [i32, i32, i64, vp, vp, vp, vp]),
     "dgnn_halo_plan_destroy": (i32, [vp]),
     "dgnn_halo_send_rows": (i64, [vp]),

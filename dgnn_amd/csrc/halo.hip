@@ -28,6 +28,7 @@ struct Rccl {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -52,7 +53,7 @@ Rccl& rccl() {
 #define SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, name))
         SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
         SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
-        SYM(GetErrorString, "ncclGetErrorString");
+        SYM(GetErrorString, "ncclGetErrorString"); SYM(CommCount, "ncclCommCount");
 #undef SYM
         if (!(r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv)) {
             r.why = "librccl.so lacks a point-to-point entry point";
@@ -135,6 +136,15 @@ extern "C" int dgnn_comm_destroy(void* comm) {
     DGNN_REQUIRE(r.handle, DGNN_E_UNSUPPORTED, "comm_destroy: RCCL unavailable");
     const ncclResult_t rc = r.CommDestroy(static_cast<ncclComm_t>(comm));
     return rc == ncclSuccess ? DGNN_OK : rccl_fail("comm_destroy", rc);
+}
+
+extern "C" int dgnn_comm_count(void* comm) {
+    DGNN_REQUIRE(comm, DGNN_E_INVALID, "comm_count: null communicator");
+    Rccl& r = rccl();
+    DGNN_REQUIRE(r.handle && r.CommCount, DGNN_E_UNSUPPORTED, "comm_count: RCCL unavailable");
+    int n = 0;
+    const ncclResult_t rc = r.CommCount(static_cast<ncclComm_t>(comm), &n);
+    return rc == ncclSuccess ? n : rccl_fail("comm_count", rc);
 }
 
 extern "C" int dgnn_halo_plan_create(int rank, int world, int64_t n_own, const int32_t* send_idx, const int64_t* send_counts, const int64_t* recv_counts,

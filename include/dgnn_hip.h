@@ -769,13 +769,18 @@ int dgnn_reorder_edges_ref(const int64_t* edge_index, int64_t stride_row, int64_
  * `comm`: an ncclComm_t -- the caller's, or one made by dgnn_comm_create from the 128-byte id of dgnn_comm_unique_id (rank 0 asks, the host
  * broadcasts it over its own channel, every rank creates on its current device).  RCCL is resolved at run time (DGNN_RCCL_LIB, an already
  * loaded librccl, the loader's path): dgnn_rccl_available() == 0 and DGNN_E_UNSUPPORTED from these entry points where there is none.
- * Nothing allocates device memory or synchronises the host; a rank may be its own peer (RCCL allows self send / recv inside a group).
+ * What goes over a link is ONE message of rows * C * elem_bytes per peer and direction, whatever either side's row stride: with ld == C it lands in
+ * the tail directly and nothing allocates or synchronises the host; with ld != C it lands in a receive staging area owned by the plan (allocated on
+ * first use, grown on demand, freed by dgnn_halo_plan_destroy) and is spread into the strided tail by a copy kernel on the side stream.
+ * A rank may be its own peer (RCCL allows self send / recv inside a group).  dgnn_comm_count: ncclCommCount of `comm` (the number of ranks the
+ * communicator spans: what a benchmark line reports as the RCCL world size), negative error code on failure.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct dgnn_halo_plan dgnn_halo_plan;
 int dgnn_rccl_available(void);
 int dgnn_comm_unique_id(void* id128);
 int dgnn_comm_create(const void* id128, int rank, int world, void** comm_out);
 int dgnn_comm_destroy(void* comm);
+int dgnn_comm_count(void* comm);
 int dgnn_halo_plan_create(int rank, int world, int64_t n_own, const int32_t* send_idx, const int64_t* send_counts, const int64_t* recv_counts,
                           dgnn_halo_plan** out);
 int dgnn_halo_plan_destroy(dgnn_halo_plan* plan);

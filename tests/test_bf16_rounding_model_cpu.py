@@ -71,6 +71,87 @@ def test_storage_format_ordering_on_a_small_scene():
     assert rows[3][1] < 5e-2 and rows[3][3] > 0.999, rows[3]
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 2 and sys.argv[2] == "train"):
     for name, mx, rms, agree in table(int(sys.argv[1]) if len(sys.argv) > 1 else 150000):
         print("%-52s max %.3e  rms %.3e  arg-max agreement %.5f" % (name, mx, rms, agree))
+
+
+# ---- training twin (tests/bf16_training_model.py): the Updated variant's step with the bf16 roundings of the HIP path injected ---------------------------
+def _updated_block(points, batch, params, seed=1):
+    """a sampled 4-hop block of a small Delaunay scene for the Updated model (CPU sampler restated in oracle/pyg_semantics.py), random-init weights"""
+    from dgnn_amd.config import Config
+    from dgnn_amd.synthetic import delaunay_tet_graph
+    from oracle.pyg_semantics import neighbor_sampler_full
+    from oracle.updated_edge_filters import SurfaceNet as ONet
+    adj, _, _ = delaunay_tet_graph(points, seed)
+    n = adj.shape[0] // 4
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 29, generator=g)
+    ea = torch.randn(4 * n, 20, generator=g)
+    idx = torch.randperm(n, generator=g)[:batch].numpy()
+    n_id, adjs = neighbor_sampler_full(adj.T.astype(np.int64), n, idx, len(params))
+    adjs = [(torch.from_numpy(a), torch.from_numpy(e), s) for a, e, s in adjs]
+    G = torch.randn(batch, params[-1], generator=g)
+    clf = Config.wrap(dict(training=dict(model_params=list(params), model_name="sage", loss="kl"),
+                           features=dict(normalization_feature=1, keep_normalization_feature=0), temp=dict(device="cpu")))
+    torch.manual_seed(5)
+    net = ONet(28, clf)
+    return net, x, ea, torch.from_numpy(n_id), adjs, G, clf
+
+
+def test_training_model_without_rounding_is_the_oracle():
+    """every rounding site off: the explicit forward / backward of tests/bf16_training_model.py == the oracle's autograd step in fp64 (this pins the model)"""
+    from bf16_training_model import error_table, updated_step
+    from dgnn_amd.config import Config
+    params = (16, 24, 32, 8)
+    net, x, ea, n_id, adjs, G, _ = _updated_block(400, 24, params)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)      # the oracle's torch.zeros([E_all, C]) (reference :236)
+    try:
+        onet = net.double()
+        ologits = onet(Config(x=x.double(), edge_attr=ea.double(), n_id=n_id, adjs=adjs))
+        (ologits * G.double()).sum().backward()
+    finally:
+        torch.set_default_dtype(old)
+    logits, grads = updated_step(net.state_dict(), params, 28, x, ea, n_id, adjs, G, sites=())
+    assert (logits - ologits.detach()).abs().max().item() <= 1e-12 * max(1.0, ologits.abs().max().item())
+    ref = {k: p.grad for k, p in onet.named_parameters()}
+    assert set(ref) == set(grads)
+    for k, (mx, rms) in error_table(ref, grads).items():
+        assert mx <= 1e-11, (k, mx)
+
+
+def training_price_table(points, batch, params, threads=8):
+    """[(sites switched on, {param: (max err / max, rms err / rms)})]: the un-rounded step against the model with all sites, and with one family of
+    sites left in fp32 at a time -- which stored tensor the gradient error of bf16 storage comes from."""
+    from bf16_training_model import ALL_SITES, error_table, updated_step
+    torch.set_num_threads(threads)
+    net, x, ea, n_id, adjs, G, _ = _updated_block(points, batch, params)
+    sd = net.state_dict()
+    _, ref = updated_step(sd, params, 28, x, ea, n_id, adjs, G, sites=())
+    rows = []
+    for name, sites in (("all sites (the HIP path)", ALL_SITES), ("weights kept fp32 in the products", ALL_SITES - {"w"}), ("dy / da / dx kept fp32", ALL_SITES - {"dy"}),
+                        ("dphi / d_ea kept fp32", ALL_SITES - {"dphi"}), ("dy and dphi kept fp32 (forward storage only)", ALL_SITES - {"dy", "dphi"}),
+                        ("forward tensors kept fp32 (backward storage only)", frozenset({"dy", "dphi"}))):
+        _, got = updated_step(sd, params, 28, x, ea, n_id, adjs, G, sites=sites)
+        rows.append((name, error_table(ref, got)))
+    return rows
+
+
+def test_training_model_rounding_sites_add_up_on_a_small_block():
+    """the model with all sites differs from the un-rounded step at bf16 level (a few 1e-3 .. 1e-1 of a gradient tensor), and leaving a family of
+    sites in fp32 never makes the worst layer WORSE by more than noise -- the table BASELINE.md section 4 quotes is made by this function"""
+    rows = training_price_table(600, 32, (32, 48, 64, 16), threads=min(os.cpu_count() or 8, 8))
+    worst = {name: max(v[1] for v in tab.values()) for name, tab in rows}
+    full = worst["all sites (the HIP path)"]
+    assert 1e-4 < full < 0.5, worst
+    assert worst["dy and dphi kept fp32 (forward storage only)"] <= full * 1.2 and worst["forward tensors kept fp32 (backward storage only)"] <= full * 1.2, worst
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "train":
+    # python tests/test_bf16_rounding_model_cpu.py 10000 train [w0,w1,w2,w3] [batch]: the price table of the training step (rms error / rms gradient per conv layer)
+    params = tuple(int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "128,256,512,1024").split(","))
+    for name, tab in training_price_table(int(sys.argv[1]), int(sys.argv[4]) if len(sys.argv) > 4 else 1024, params):
+        print(name)
+        for l in range(len(params)):
+            print("   layer %d: " % l + "  ".join("%s rms %.2e max %.2e" % (k.split(".", 2)[2], tab[k][1], tab[k][0]) for k in sorted(tab) if k.startswith("convs.%d." % l)))

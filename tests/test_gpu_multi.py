@@ -58,6 +58,14 @@ def test_bench_py_two_ranks_as_the_driver_launches_it(scaling, halo):
     assert ("host-staged gloo" if halo == "exchange" else "validation run under gloo") in d["config"]["workload"]
     assert ("no collective in the data path" in d["config"]["workload"]) == (halo == "recompute")
     assert 0.2 < d["config"]["tets_per_gpu"] / (n_main / 2) < 1.8
+    # round 5: north_star's exchange form rides in every ring-parts line (here host-staged: the ranks share one GPU under gloo)
+    assert ("halo_exchange" in d) == (halo == "recompute")
+    if halo == "recompute":
+        h = d["halo_exchange"]
+        for k in ("ms_per_step", "value", "transport", "rccl_world", "check", "n_tets", "halo_rows_this_rank"):
+            assert k in h, k
+        assert h["n_tets"] == n_main and h["check"]["ok"] and h["check"]["bit_identical_to_single_rank"] and h["rccl_world"] is None and "host-staged" in h["transport"]
+        assert h["halo_rows_this_rank"] > 0 and abs(h["value"] - n_main / h["ms_per_step"] * 1e3) <= 1e-3 * h["value"]
 
 
 @pytest.mark.parametrize("extra", [["--updated"], ["--updated", "--dtype", "bf16"], []])

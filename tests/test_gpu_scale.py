@@ -348,13 +348,21 @@ def test_training_step_at_bench_scale_matches_the_oracle(convs, points, batch):
 
 
 @pytest.mark.parametrize("dtype,params,points,batch", [(torch.float32, (64, 128, 128, 128), 30000, 2048), (torch.bfloat16, (64, 128, 128, 128), 30000, 2048),
-                                                       (torch.bfloat16, (64, 128, 256, 512), 10000, 1024), (torch.float32, (64, 128, 256, 512), 10000, 1024)])
+                                                       (torch.bfloat16, (64, 128, 256, 512), 10000, 1024), (torch.float32, (64, 128, 256, 512), 10000, 1024),
+                                                       (torch.bfloat16, (128, 256, 512, 1024), 10000, 1024), (torch.float32, (128, 256, 512, 1024), 10000, 1024)])
 def test_updated_training_step_at_scale_matches_the_oracle(dtype, params, points, batch):
     """Updated variant ("sage": the reference's "sage+" head cannot be differentiated -- F.relu followed by an in-place nn.ReLU, :245-246 --
-    so gradients are compared on the plain model as in the golden test) on a 2048-target 4-hop block of a 200k-tet scene (~90k cells per block; the oracle materialises the
-    reference's whole-scene [E_all, C] edge tensors, which bounds the scene size here): composite conv calls + sparse edge chaining
-    against the CPU oracle in fp64 -- logits and every parameter gradient; bf16 storage at the tolerance of SURVEY 8c.
-    Round 4: bf16 storage also at the widths the reference trains large scenes with ([64,128,256,512]: configs/eth.yaml:56, aerial.yaml:57), batch 1024."""
+    so gradients are compared on the plain model as in the golden test) on a 4-hop block of a Delaunay scene (the oracle materialises the
+    reference's whole-scene [E_all, C] edge tensors, which bounds the scene size here): composite conv calls + sparse edge chaining against the CPU
+    oracle in fp64 -- logits and every parameter gradient.
+    Widths: the shipped ones, [64,128,256,512] (configs/eth.yaml:56, aerial.yaml:57) and -- round 5, BASELINE config 3 at its own workload --
+    [128,256,512,1024] at batch 1024 (configs/modelnet.yaml:44,56).
+    bf16 STORAGE (round 5): the gradients are held to the STORAGE-ROUNDING MODEL of tests/bf16_training_model.py -- the fp64 step
+    with a round-to-bf16 at exactly the tensors the HIP path stores or feeds to the bf16 matrix cores -- within 1e-3 of each tensor's largest entry
+    (two correct fp32-accumulating implementations of that model differ by 2-3.5e-4: python tests/test_bf16_rounding_model_cpu.py, `arith=`), and
+    the logits to it within two bf16 steps.  The model's own distance from the un-rounded oracle is the price of the format, printed here and
+    tabulated in BASELINE.md section 4 (it is set by ReLU-mask flips of near-zero pre-activations: ANY 2^-9 perturbation of the forward pass moves
+    the early layers' gradients by 3-8 % rms; keeping dy / dphi in fp32 would not change it); the logits keep SURVEY 8c's tolerance against the oracle."""
     from dgnn_amd.learning import surfaceNetUpdatedEdgeFilters as U
     from dgnn_amd.sampler import NeighborSampler
     from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal
@@ -378,12 +386,14 @@ def test_updated_training_step_at_scale_matches_the_oracle(dtype, params, points
     net = net.to(DEV).set_storage_dtype(dtype)
     logits = net(Config(x=x, edge_attr=ea, n_id=n_id, adjs=adjs))
     (logits * G).sum().backward()
+    cadjs = [(a.cpu(), e.cpu(), s) for a, e, s in adjs]
+    torch.set_num_threads(min(os.cpu_count() or 8, 32))
     old = torch.get_default_dtype()
     torch.set_default_dtype(torch.float64)   # the oracle's torch.zeros([E_all, C]) (reference :236) must be fp64 too
     try:
         onet = ONet(28, oclf)
         onet.load_state_dict({k: v.double() for k, v in sd.items()})
-        ologits = onet(Config(x=x.double().cpu(), edge_attr=ea.double().cpu(), n_id=n_id.cpu(), adjs=[(a.cpu(), e.cpu(), s) for a, e, s in adjs]))
+        ologits = onet(Config(x=x.double().cpu(), edge_attr=ea.double().cpu(), n_id=n_id.cpu(), adjs=cadjs))
         (ologits * G.double().cpu()).sum().backward()
     finally:
         torch.set_default_dtype(old)
@@ -391,23 +401,57 @@ def test_updated_training_step_at_scale_matches_the_oracle(dtype, params, points
     err = (logits.detach().double().cpu() - ologits.detach()).abs()
     ograds = {k: p.grad for k, p in onet.named_parameters()}
     gmax = max(g.abs().max().item() for g in ograds.values())
+    hgrads = {k: p.grad for k, p in net.named_parameters()}
     if dtype == torch.float32:
         assert err.max().item() <= 2e-4 * scale
-        rel, floor = 5e-4, 5e-6
-    else:   # bf16 storage: SURVEY 8c's two-level tolerance on the logits, bf16 resolution on the gradients
-        assert (err <= 5e-2 * scale).float().mean().item() >= 0.9999 and err.max().item() <= 1e-1 * scale
-        rel, floor = 6e-2, 6e-3
-    wide = tuple(params) != (64, 128, 128, 128)
-    for k, p in net.named_parameters():
-        d = (p.grad.double().cpu() - ograds[k])
-        e = d.abs().max().item()
-        if wide and dtype == torch.bfloat16:
-            # [64,128,256,512], random init: every stored dy / dphi is rounded to bf16 on its way down four layers of 256-512 channels; measured
-            # (tools history, round 4) rms error / rms gradient 0.4 % at the last conv layer, 4 % / 7 % / 8 % at layers 2 / 1 / 0, largest single
-            # entry 17 % of the tensor's largest -- the fp32-storage build of the same step sits at 1e-6.  Bounds: 1.5x what was measured.
-            assert d.pow(2).mean().sqrt().item() <= 0.13 * ograds[k].pow(2).mean().sqrt().item() and e <= 0.26 * ograds[k].abs().max().item(), (k, e, ograds[k].abs().max().item())
-        else:
-            assert e <= rel * ograds[k].abs().max().item() + floor * gmax, (k, e, ograds[k].abs().max().item(), gmax)
+        for k, g in hgrads.items():
+            e = (g.double().cpu() - ograds[k]).abs().max().item()
+            assert e <= 5e-4 * ograds[k].abs().max().item() + 5e-6 * gmax, (k, e, ograds[k].abs().max().item(), gmax)
+        return
+    # bf16 storage.  Logits against the oracle: SURVEY 8c's two-level tolerance
+    assert (err <= 5e-2 * scale).float().mean().item() >= 0.9999 and err.max().item() <= 1e-1 * scale
+    from bf16_training_model import error_table, updated_step
+    mlogits, mgrads = updated_step(sd, params, 28, x.cpu(), ea.cpu(), n_id.cpu(), cadjs, G.cpu())
+    assert set(mgrads) == set(hgrads)
+    # logits against the model: the same bf16 values except where the fp32 accumulation order tips a rounding (a step of the top binade is 2^-8 of it)
+    dl = (logits.detach().double().cpu() - mlogits).abs()
+    top = mlogits.abs().max().item()
+    assert (dl == 0).double().mean().item() >= 0.995 and dl.max().item() <= 2.0 ** -7 * top, ((dl == 0).double().mean().item(), dl.max().item(), top)
+    vs_model = error_table(mgrads, hgrads)
+    price = error_table(ograds, mgrads)             # the format's price: model vs the un-rounded oracle
+    vs_oracle = error_table(ograds, hgrads)
+    rows = []
+    for l in range(len(params)):
+        ks = [k for k in sorted(mgrads) if k.startswith("convs.%d." % l)]
+        rows.append(dict(layer=l, hip_vs_model_max=max(vs_model[k][0] for k in ks), hip_vs_model_rms=max(vs_model[k][1] for k in ks),
+                         model_vs_oracle_max=max(price[k][0] for k in ks), model_vs_oracle_rms=max(price[k][1] for k in ks),
+                         hip_vs_oracle_max=max(vs_oracle[k][0] for k in ks), hip_vs_oracle_rms=max(vs_oracle[k][1] for k in ks)))
+    print("bf16 training, widths %s, batch %d, block of %d cells: per conv layer (worst parameter tensor)" % (list(params), batch, n_id.numel()))
+    for r in rows:
+        print("   layer %(layer)d: HIP vs rounding model max %(hip_vs_model_max).2e rms %(hip_vs_model_rms).2e | price (model vs fp64 oracle) max %(model_vs_oracle_max).2e rms "
+              "%(model_vs_oracle_rms).2e | HIP vs oracle max %(hip_vs_oracle_max).2e rms %(hip_vs_oracle_rms).2e" % r)
+    try:      # scratch copy for BASELINE.md's table
+        import json
+        os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "bf16_training_price_%s.json" % "_".join(map(str, params))), "w") as f:
+            json.dump(dict(widths=list(params), batch=batch, block_cells=int(n_id.numel()), layers=rows), f)
+    except OSError:
+        pass
+    # The bound.  Two CORRECT fp32-accumulating implementations of the model do not agree to fp32 rounding: where an accumulation order tips the
+    # rounding of one stored bf16 value, and that value sits next to a ReLU threshold further down, one mask entry flips and with it one row's
+    # contribution to the gradients below it -- sparse, row-shaped differences.  The model evaluated in fp32 against itself in fp64 (tests/
+    # bf16_training_model.py `arith=`; python tests/test_bf16_rounding_model_cpu.py) shows what that amounts to: 2-5e-4 of a tensor's largest entry at
+    # the shipped widths and [64,128,256,512], and at [128,256,512,1024] anything from 5e-4 to isolated entries at 2e-2 with an rms of 4e-3,
+    # depending on the block -- while ONE mis-placed rounding site (a site of the model switched off) is dense: rms 3-7 % on the layers below it.
+    # Hence: rms <= 1e-3 of the tensor's rms (measured here: <= 5.2e-4), 99.9 % of a tensor's entries within 1e-3 of its largest (fp32 class),
+    # every entry within 2e-2 (a flipped mask entry's row).
+    mmax = max(g.abs().max().item() for g in mgrads.values())
+    for k, (mx, rms) in vs_model.items():
+        ref_k = mgrads[k]
+        d = (hgrads[k].double().cpu() - ref_k).abs()
+        top_k = ref_k.abs().max().item()
+        inside = (d <= 1e-3 * top_k + 1e-6 * mmax).double().mean().item()
+        assert rms <= 1e-3 and inside >= 0.999 and d.max().item() <= 2e-2 * top_k + 1e-6 * mmax, (k, mx, rms, inside)
 
 
 @pytest.mark.parametrize("k1,k2,n_out", [(128, 128, 128), (64, 0, 2), (128, 0, 64), (70, 33, 37), (256, 256, 512), (28, 28, 64)])

@@ -65,7 +65,8 @@ def _rccl_worker(rank, port, out_dir):
             ex.wait()
             assert torch.equal(h[n_own:], h[torch.from_numpy(send_idx).to(DEV)]), dt
         del ex
-    # the C ABI directly, with a row stride wider than the row (rows then travel one by one inside the group)
+    # the C ABI directly, with a row stride wider than the row (round 5: one packed message per peer lands in the plan's staging area and is spread
+    # into the strided tail by a copy kernel -- what travels never depends on a side's row stride)
     if True:
         import ctypes as C
         from dgnn_amd._lib import check, lib, ptr
@@ -75,6 +76,7 @@ def _rccl_worker(rank, port, out_dir):
         check(L.dgnn_comm_unique_id(uid), "uid")
         comm, plan = C.c_void_p(), C.c_void_p()
         check(L.dgnn_comm_create(uid, 0, 1, C.byref(comm)), "comm")
+        assert L.dgnn_comm_count(comm) == 1 and L.dgnn_comm_count(None) < 0
         idx32 = torch.from_numpy(send_idx.astype(np.int32)).to(DEV)
         one = (C.c_int64 * 1)(n_halo)
         check(L.dgnn_halo_plan_create(0, 1, n_own, ptr(idx32), one, one, C.byref(plan)), "plan")
