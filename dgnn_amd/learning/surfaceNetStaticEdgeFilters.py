@@ -649,6 +649,13 @@ class SurfaceNet(nn.Module):
                                              x_dst=x_dst[s0:s1], prepared=self._prepared(i, False))
                 x = out_v
             return x
+        if simple and le.in_features == 20 and out is None and rows is None and self.wide_layer_split_rows(x.size(1), conv.lin_j.out_features):
+            y = self._eval_layer_wide(i, conv, scale, shift, x, xe, plan, sorted_attr)
+            if y is not None:
+                return y
+        if isinstance(x, ops.SplitRows):       # a layer the wide kernels do not take behind one they did: back to fp32 rows
+            x = x.float()
+            x_dst = x[b:e]
         if simple:
             ea = plan.sorted_edge_attr(xe) if sorted_attr else xe
             a = ops.aggregate_fwd(rowptr, plan.src, None, n, x, ea, le.weight, le.bias)
@@ -657,6 +664,50 @@ class SurfaceNet(nn.Module):
                 raise NotImplementedError("destination sub-ranges need a Linear edge filter")
             a = Fn.aggregate(x, plan, **conv._filter_args(xe))
         return ops.linear_fwd(a, conv.lin_j.weight, x_dst, conv.lin_i.weight, conv.lin_j.bias, scale, shift, True, out=out_v)
+
+    # ---- wide conv layers on split rows (round 5; csrc/wide.hip) -------------------------------------------------------------------------------
+    def wide_layer_split_rows(self, c_in, c_out):
+        """True when the eval-mode conv layer c_in -> c_out runs on dgnn_sage_aggregate_sr + dgnn_linear_sr (fp32 storage, default arithmetic, the widths
+        of the reference's real configs: configs/eth.yaml:56, aerial.yaml:57, modelnet.yaml:56)"""
+        return self.storage_dtype == torch.float32 and ops.wide_layer_supported(int(c_in), int(c_out), 20)
+
+    def _wide_prepared(self, key, tensors, make):
+        """what the wide kernels derive from the weights (split weight rows, the filter operand), cached until one of `tensors` is written to"""
+        k = tuple((t.data_ptr(), t._version) for t in tensors)
+        cache = self.__dict__.setdefault("_prep_cache", {})
+        hit = cache.get(("wide",) + tuple(key))
+        if hit is not None and hit[0] == k:
+            return hit[1]
+        val = make()
+        cache[("wide",) + tuple(key)] = (k, val)
+        return val
+
+    def _eval_layer_wide(self, i, conv, scale, shift, x, xe, plan, sorted_attr):
+        """conv + BatchNorm(eval) + ReLU of a wide layer: the mean aggregate and the own rows as SPLIT ROWS (ops.SplitRows), the dense product straight on
+        them, the output again split rows -- what the next wide layer and the decoder read.  None: the library declined the layout."""
+        le = conv.lin_e
+        if sorted_attr and ops.EDGE_GATHER_IN_KERNEL and xe.stride(0) == 20 and xe.data_ptr() % 16 == 0:
+            ea, eid = xe, plan.eid
+        else:
+            ea, eid = (plan.sorted_edge_attr(xe) if sorted_attr else xe), None
+            if ea.stride(0) != 20 or ea.data_ptr() % 16:
+                ea = ea.contiguous()
+        prep = self._wide_prepared((i, "filter"), (le.weight, le.bias), lambda: ops.sr_prepare_filter(le.weight, le.bias))
+        Wp = self._wide_prepared((i, "dense"), (conv.lin_j.weight, conv.lin_i.weight), lambda: ops.pack_rows(conv.lin_j.weight, conv.lin_i.weight, per_row=True))
+        if prep is None:
+            return None
+        n = plan.n_dst
+        if isinstance(x, ops.SplitRows):
+            a = ops.aggregate_sr(plan.rowptr, plan.src, eid, n, x, ea, le.weight, le.bias, prep)
+            xi = x[:n]
+        else:
+            if x.stride(0) % 4 or x.data_ptr() % 16:
+                x = x.contiguous()
+            got = ops.aggregate_sr(plan.rowptr, plan.src, eid, n, x, ea, le.weight, le.bias, prep, own_rows=True)
+            a, xi = got if got is not None else (None, None)
+        if a is None:
+            return None
+        return ops.linear_sr(a, Wp, xi, conv.lin_j.bias, scale, shift, relu=True)
 
     def _eval_layer_bf16_unfused(self, conv, scale, shift, x, xe, plan, sorted_attr, out_v, rows):
         """bf16 storage, widths the fused bf16 kernel does not cover: the generic bf16 aggregate + bf16-MFMA GEMM pair."""
@@ -677,6 +728,16 @@ class SurfaceNet(nn.Module):
 
     def _eval_decoder(self, x):
         dec = self.decoder
+        if isinstance(x, ops.SplitRows):
+            # behind a wide layer: Linear(h3 -> h3/2) + BN + ReLU straight on the split rows (fp32 rows out), then the small output Linear
+            if self.clf.model.decoder and len(dec) == 4 and isinstance(dec[0], nn.Linear) and dec[0].out_features % 256 == 0 and isinstance(dec[2], nn.ReLU) \
+                    and (dec[1] is None or isinstance(dec[1], BatchNorm)):
+                scale, shift = self._fold(dec[1] if isinstance(dec[1], BatchNorm) else None, dec[0].out_features, x.device)
+                Wp = self._wide_prepared(("dec0",), (dec[0].weight,), lambda: ops.pack_rows(dec[0].weight, per_row=True))
+                h = ops.linear_sr(x, Wp, None, dec[0].bias, scale, shift, relu=True, out_f32=True)
+                if h is not None:
+                    return ops.linear_fwd(h, dec[3].weight, bias=dec[3].bias)
+            x = x.float()
         if x.dtype == ops.UROWS:          # (a last layer that did not carry the decoder left unsigned rows)
             x = ops.rows_unsigned_to_bf16(x)
         if not self.clf.model.decoder or len(dec) == 0:

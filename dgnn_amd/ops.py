@@ -416,6 +416,136 @@ def bn_relu_bwd_apply(x, y, dy, gamma, mean, var, eps, relu, sums, count):
     return dx
 
 
+# ---- wide conv layers on split rows (csrc/wide.hip) ---------------------------------------------
+# DGNN_WIDE_SR=0: the layers wider than the fused kernels keep the fp32 aggregate + x2h / x3 GEMM pair of rounds 2-4
+WIDE_SR = __import__("os").environ.get("DGNN_WIDE_SR", "1") != "0"
+
+
+class SplitRows:
+    """A wide activation [n, C] as the wide kernels store it (include/dgnn_hip.h "SPLIT ROWS"): `data` uint8 [n, C * 4] -- per 32 channels a 128-byte chunk
+    [hi x 32 | lo x 32] fp16 of x * s in the chunk's position order -- and `scales` fp32 [n, ceil(C / 256)], one power of two per row and 256 channels.
+    Produced by aggregate_sr / linear_sr / pack_rows; `.float()` gives the fp32 rows back (22 significand bits per value)."""
+
+    def __init__(self, data, scales, channels):
+        self.data, self.scales, self.channels = data, scales, int(channels)
+
+    size = lambda self, d=None: (self.data.size(0), self.channels) if d is None else (self.data.size(0), self.channels)[d]
+    shape = property(lambda self: (self.data.size(0), self.channels))
+    device = property(lambda self: self.data.device)
+    dtype = "split_rows"
+    is_cuda = property(lambda self: self.data.is_cuda)
+
+    def __getitem__(self, sl):
+        """row ranges only (a prefix / sub-range of the rows): views of both tensors"""
+        if not isinstance(sl, slice) or sl.step not in (None, 1):
+            raise TypeError("SplitRows supports contiguous row ranges only")
+        return SplitRows(self.data[sl], self.scales[sl], self.channels)
+
+    def float(self):
+        return unpack_rows(self)
+
+
+def sr_groups(c):
+    return (int(c) + 255) // 256
+
+
+@on_device_of
+def pack_rows(A1, A2=None, per_row=False):
+    """fp32 rows [n, k1] (| [n, k2]) -> SplitRows of [A1 | A2] (widths multiples of 32); per_row: ONE scale per row (weights) instead of one per 256 channels"""
+    _req(A1, "A1", dim=2)
+    n, k1 = A1.shape
+    k2 = 0
+    if A2 is not None:
+        _req(A2, "A2", dim=2)
+        k2 = A2.size(1)
+    C_ = k1 + k2
+    if k1 % 32 or k2 % 32:
+        raise ValueError("split rows need widths that are multiples of 32")
+    ng = 1 if per_row else max(1, (C_ // 32 + 7) // 8)
+    data = torch.empty((n, C_ * 4), dtype=torch.uint8, device=A1.device)
+    scales = torch.empty((n, ng), dtype=torch.float32, device=A1.device)
+    check(lib().dgnn_sr_pack(ptr(A1), _ld(A1), k1, ptr(A2), _ld(A2) if A2 is not None else 0, k2, n, 0 if per_row else 8, ptr(data), C_ * 4, ptr(scales), ng,
+                             stream_ptr()), "dgnn_sr_pack")
+    return SplitRows(data, scales, C_)
+
+
+@on_device_of
+def unpack_rows(sr: "SplitRows") -> torch.Tensor:
+    n, C_ = sr.size()
+    out = torch.empty((n, C_), dtype=torch.float32, device=sr.device)
+    ng = sr.scales.size(1)
+    gch = 8 if ng == sr_groups(C_) and not (ng == 1 and C_ > 256) else 0
+    check(lib().dgnn_sr_unpack(ptr(sr.data), sr.data.stride(0), ptr(sr.scales), ng, gch, C_, n, ptr(out), C_, stream_ptr()), "dgnn_sr_unpack")
+    return out
+
+
+def wide_layer_supported(c_in: int, c_out: int, f_e: int) -> bool:
+    """dgnn_sage_aggregate_sr + dgnn_linear_sr take this conv layer (default arithmetic only)"""
+    return WIDE_SR and GEMM_MODE == GEMM_F16X2 and f_e == 20 and c_in in (128, 256, 512) and c_out % 256 == 0 and c_out > 0
+
+
+@on_device_of
+def sr_prepare_filter(We, be):
+    c = We.size(0)
+    nb = int(lib().dgnn_sr_filter_prepared_bytes(c))
+    if nb <= 0 or We.size(1) != 20:
+        return None
+    buf = torch.empty(nb, dtype=torch.uint8, device=We.device)
+    check(lib().dgnn_sr_prepare_filter(ptr(We.contiguous()), ptr(be.contiguous()), c, ptr(buf), stream_ptr()), "dgnn_sr_prepare_filter")
+    return buf
+
+
+@on_device_of
+def aggregate_sr(rowptr, src, eid, n_dst, x, edge_attr, We, be, prep, own_rows=False):
+    """-> a (SplitRows [n_dst, C]) [, x[:n_dst] as SplitRows when `own_rows` and x is an fp32 tensor] or None when the library declines the layout"""
+    sr_in = isinstance(x, SplitRows)
+    c = x.size(1)
+    dev = x.device
+    ng = sr_groups(c)
+    a = SplitRows(torch.empty((n_dst, c * 4), dtype=torch.uint8, device=dev), torch.empty((n_dst, ng), dtype=torch.float32, device=dev), c)
+    xo = None
+    if own_rows and not sr_in:
+        xo = SplitRows(torch.empty((n_dst, c * 4), dtype=torch.uint8, device=dev), torch.empty((n_dst, ng), dtype=torch.float32, device=dev), c)
+    if sr_in:
+        xp, ldx, xs = ptr(x.data), x.data.stride(0), ptr(x.scales)
+    else:
+        _req(x, "x", dim=2)
+        xp, ldx, xs = ptr(x), _ld(x), None
+    rc = lib().dgnn_sage_aggregate_sr(ptr(rowptr), ptr(src), ptr(eid), n_dst, xp, int(sr_in), ldx, xs, c, ptr(edge_attr), _ld(edge_attr), ptr(We.contiguous()),
+                                      ptr(be.contiguous()), ptr(prep), ptr(a.data), ptr(a.scales), ptr(xo.data) if xo is not None else None,
+                                      ptr(xo.scales) if xo is not None else None, stream_ptr())
+    if rc == DGNN_E_UNSUPPORTED:
+        return None
+    check(rc, "dgnn_sage_aggregate_sr")
+    return (a, xo) if own_rows else a
+
+
+@on_device_of
+def linear_sr(A1, Wp, A2=None, bias=None, scale=None, shift=None, relu=False, out_f32=False, rows=None):
+    """act(([A1 | A2] . W^T + bias) * scale + shift): A1 / A2 SplitRows, Wp = pack_rows(W1, W2, per_row=True) -> SplitRows, or an fp32 tensor with out_f32;
+    `rows`: only the first `rows` rows of the operands.  None when the library declines the shape."""
+    M = A1.size(0) if rows is None else int(rows)
+    n_out = Wp.size(0)
+    dev = A1.device
+    c1, c2 = A1.channels, (A2.channels if A2 is not None else 0)
+    if Wp.channels != c1 + c2:
+        raise ValueError("packed weights have %d input channels, operands %d" % (Wp.channels, c1 + c2))
+    if out_f32:
+        o32 = torch.empty((M, n_out), dtype=torch.float32, device=dev)
+        osr = None
+    else:
+        o32 = None
+        osr = SplitRows(torch.empty((M, n_out * 4), dtype=torch.uint8, device=dev), torch.empty((M, sr_groups(n_out)), dtype=torch.float32, device=dev), n_out)
+    rc = lib().dgnn_linear_sr(ptr(A1.data), A1.data.stride(0), ptr(A1.scales), c1, ptr(A2.data) if A2 is not None else None,
+                              A2.data.stride(0) if A2 is not None else 0, ptr(A2.scales) if A2 is not None else None, c2, ptr(Wp.data), ptr(Wp.scales),
+                              ptr(bias), ptr(scale), ptr(shift), int(bool(relu)), M, n_out, ptr(osr.data) if osr is not None else None,
+                              n_out * 4 if osr is not None else 0, ptr(osr.scales) if osr is not None else None, ptr(o32), n_out, stream_ptr())
+    if rc == DGNN_E_UNSUPPORTED:
+        return None
+    check(rc, "dgnn_linear_sr")
+    return o32 if out_f32 else osr
+
+
 # ---- fused inference layer ----------------------------------------------------------------------
 def fused_layer_supported(c_in: int, c_out: int, f_e: int, x: torch.Tensor = None) -> bool:
     """Mirrors the shape dispatch of dgnn_sage_layer_fused_fwd (csrc/fused.hip): c_in <= 64 -> c_out in {64,128};

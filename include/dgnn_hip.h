@@ -814,6 +814,45 @@ int dgnn_static_infer_partitioned_fwd(const int64_t* edge_index, int64_t stride_
                                       int c_hidden, const float* W3, const float* b3, int n_logits, int fuse_decoder, int gemm_mode,
                                       dgnn_halo_plan* halo, void* comm, void* send_buf, void* workspace, float* logits, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Wide conv layers on SPLIT ROWS (round 5; csrc/wide.hip).  SAGEConv.forward (learning/surfaceNetStaticEdgeFilters.py:66-96) at the widths the
+ * reference's real configs use (configs/eth.yaml:56, aerial.yaml:57: [64,128,256,512]; configs/modelnet.yaml:56: [128,256,512,1024]): layers
+ * with C_in in {128, 256, 512} and C_out a multiple of 256 -- outside dgnn_sage_layer_fused_fwd's shapes -- as
+ *     dgnn_sage_aggregate_sr   a = mean_j x_j * lin_e(edge_attr_j)                       (:75-80, :89-96)
+ *     dgnn_linear_sr           act(([a | x_i] . [Wj | Wi]^T + bj) * scale + shift)       (:81-86 + BatchNorm(eval) + ReLU; also the decoder's first Linear)
+ * with every wide activation stored in HBM as SPLIT ROWS: a row of C channels (C % 32 == 0) is C / 32 chunks of 128 bytes; chunk q holds, for its 32
+ * positions p, hi[p] (fp16, bytes 2p) and lo[p] (fp16, bytes 64 + 2p) of x * s for channel 32 q + PI(p), PI(p) = (p & 3) | (p >> 4) << 2 |
+ * ((p >> 2) & 3) << 3, hi = RN16(x s), lo = RN16(x s - hi) (22 significand bits in 4 bytes); s is a power of two per row and GROUP of 256 channels
+ * (`scales` [rows][ceil(C / 256)] fp32) that puts the group's largest magnitude into [2^14, 2^15); a group below 2^-112 is stored as zeros with
+ * s = 2^127.  dgnn_sr_row_bytes(C) = C / 32 * 128.  The format is what the fp16 two-part matrix products consume (3 products per fp32 product,
+ * fp32 accumulation: fp32-class results, tests/test_gpu_wide.py), written by the kernel that PRODUCES the activation: no row-scale pass, no
+ * split instructions and no fp32 staging in the consumer.  dgnn_sr_pack / dgnn_sr_unpack convert from / to fp32 rows (weights at prepare time,
+ * boundaries, tests).  All pointers 16-byte aligned; nothing allocates or synchronises.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t dgnn_sr_row_bytes(int C);
+/* fp32 rows [rows][k1 (+ k2)] (k1, k2 multiples of 32) -> split rows dst [rows][dst_row_bytes] + scales [rows][ng]; gch = chunks per scale group:
+ * 8 for activations (ng = ceil(chunks / 8)), 0 = ONE group per row (ng = 1): the weights of dgnn_linear_sr are [Wj | Wi] packed with gch = 0 */
+int dgnn_sr_pack(const float* A1, int64_t ld1, int k1, const float* A2, int64_t ld2, int k2, int64_t rows, int gch, void* dst,
+                 int64_t dst_row_bytes, float* scales, int ng, void* stream);
+int dgnn_sr_unpack(const void* src, int64_t row_bytes, const float* scales, int ng, int gch, int C, int64_t rows, float* out, int64_t ldo,
+                   void* stream);
+/* the filter operand [We^T ; be] of dgnn_sage_aggregate_sr, prepared once per set of weights (C in {128, 256, 512}; 0 bytes = unsupported width) */
+int64_t dgnn_sr_filter_prepared_bytes(int C);
+int dgnn_sr_prepare_filter(const float* We, const float* be, int C, void* buf, void* stream);
+/* a_out / a_scales: split rows of a [n_dst][C].  x: the source rows, split rows (x_is_sr != 0, xs their scales) or fp32 rows (row stride ldx floats);
+ * with fp32 rows and x_out != NULL the destinations' own rows x[:n_dst] are also written as split rows (x_out, x_scales).  edge_attr: fp32 packed
+ * [E][20] rows, gathered by eid (NULL: plan order).  Any in-degree (4-regular groups take the matrix-core path).  DGNN_E_UNSUPPORTED before anything
+ * is launched for other widths / layouts. */
+int dgnn_sage_aggregate_sr(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const void* x, int x_is_sr, int64_t ldx,
+                           const float* xs, int C, const float* edge_attr, int64_t lde, const float* We, const float* be, const void* prep, void* a_out,
+                           float* a_scales, void* x_out, float* x_scales, void* stream);
+/* A1 (C1 channels) and A2 (C2 channels; NULL / 0: one operand) split rows with their scales; Wp / sw = dgnn_sr_pack([W1 | W2] fp32 [n_out][C1 + C2],
+ * gch = 0); n_out a multiple of 256.  Output: split rows (out_sr, out_row_bytes, out_scales [M][n_out / 256]) or -- out_sr == NULL -- fp32 rows
+ * out_f32 [M][n_out] with row stride ldo.  DGNN_E_UNSUPPORTED for other shapes. */
+int dgnn_linear_sr(const void* A1, int64_t row_bytes1, const float* scales1, int C1, const void* A2, int64_t row_bytes2, const float* scales2, int C2,
+                   const void* Wp, const float* sw, const float* bias, const float* scale, const float* shift, int relu, int64_t M, int n_out, void* out_sr,
+                   int64_t out_row_bytes, float* out_scales, float* out_f32, int64_t ldo, void* stream);
+
 /* elementwise helpers used by the Updated variant (F.relu at surfaceNetUpdatedEdgeFilters.py:239-241
  * and the scatter of phi rows into the zero [E_all,C] buffer at :236-237) */
 int dgnn_relu(const float* x, int64_t n, float* y, void* stream);
