@@ -137,7 +137,7 @@ SIGNATURES = {
     "dgnn_sr_filter_prepared_bytes": (i64, [i32]),
     "dgnn_sr_prepare_filter": (i32, [vp, vp, i32, vp, vp]),
     "dgnn_sage_aggregate_sr": (i32, [vp, vp, vp, i64, vp, i32, i64, vp, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
-    "dgnn_linear_sr": (i32, [vp, i64, vp, i32, vp, i64, vp, i32, vp, vp, vp, vp, vp, i32, i64, i32, vp, i64, vp, vp, i64, vp]),
+    "dgnn_linear_sr": (i32, [vp, i64, vp, i32, vp, i64, vp, i32, vp, vp, vp, vp, vp, i32, i64, i32, vp, i64, vp, vp, i64, vp, vp, i32, vp, vp]),
     "dgnn_halo_plan_create": (i32, [i32, i32, i64, vp, vp, vp, vp]),
     "dgnn_halo_plan_destroy": (i32, [vp]),
     "dgnn_halo_send_rows": (i64, [vp]),

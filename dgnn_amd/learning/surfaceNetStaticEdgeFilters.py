@@ -734,6 +734,10 @@ class SurfaceNet(nn.Module):
                     and (dec[1] is None or isinstance(dec[1], BatchNorm)):
                 scale, shift = self._fold(dec[1] if isinstance(dec[1], BatchNorm) else None, dec[0].out_features, x.device)
                 Wp = self._wide_prepared(("dec0",), (dec[0].weight,), lambda: ops.pack_rows(dec[0].weight, per_row=True))
+                if isinstance(dec[3], nn.Linear) and dec[3].out_features in (1, 2):      # the output Linear rides in the same launch: only logits leave it
+                    lg = ops.linear_sr(x, Wp, None, dec[0].bias, scale, shift, relu=True, proj=(dec[3].weight, dec[3].bias))
+                    if lg is not None:
+                        return lg
                 h = ops.linear_sr(x, Wp, None, dec[0].bias, scale, shift, relu=True, out_f32=True)
                 if h is not None:
                     return ops.linear_fwd(h, dec[3].weight, bias=dec[3].bias)

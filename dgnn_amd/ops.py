@@ -521,8 +521,9 @@ def aggregate_sr(rowptr, src, eid, n_dst, x, edge_attr, We, be, prep, own_rows=F
 
 
 @on_device_of
-def linear_sr(A1, Wp, A2=None, bias=None, scale=None, shift=None, relu=False, out_f32=False, rows=None):
-    """act(([A1 | A2] . W^T + bias) * scale + shift): A1 / A2 SplitRows, Wp = pack_rows(W1, W2, per_row=True) -> SplitRows, or an fp32 tensor with out_f32;
+def linear_sr(A1, Wp, A2=None, bias=None, scale=None, shift=None, relu=False, out_f32=False, rows=None, proj=None):
+    """act(([A1 | A2] . W^T + bias) * scale + shift): A1 / A2 SplitRows, Wp = pack_rows(W1, W2, per_row=True) -> SplitRows; with out_f32 an fp32 tensor;
+    with proj = (W3 [n_proj, n_out], b3 | None) the logits act(...) . W3^T + b3 [M, n_proj] (the decoder's output Linear inside the launch).
     `rows`: only the first `rows` rows of the operands.  None when the library declines the shape."""
     M = A1.size(0) if rows is None else int(rows)
     n_out = Wp.size(0)
@@ -530,20 +531,28 @@ def linear_sr(A1, Wp, A2=None, bias=None, scale=None, shift=None, relu=False, ou
     c1, c2 = A1.channels, (A2.channels if A2 is not None else 0)
     if Wp.channels != c1 + c2:
         raise ValueError("packed weights have %d input channels, operands %d" % (Wp.channels, c1 + c2))
-    if out_f32:
+    o32 = osr = lg = W3 = b3 = None
+    n_proj = 0
+    if proj is not None:
+        W3, b3 = proj
+        W3 = _req(W3, "W3", dim=2).contiguous()
+        n_proj = W3.size(0)
+        if W3.size(1) != n_out or n_proj not in (1, 2):
+            return None
+        lg = (torch.zeros if n_out > 256 else torch.empty)((M, n_proj), dtype=torch.float32, device=dev)     # (column tiles add into zeroed logits)
+    elif out_f32:
         o32 = torch.empty((M, n_out), dtype=torch.float32, device=dev)
-        osr = None
     else:
-        o32 = None
         osr = SplitRows(torch.empty((M, n_out * 4), dtype=torch.uint8, device=dev), torch.empty((M, sr_groups(n_out)), dtype=torch.float32, device=dev), n_out)
     rc = lib().dgnn_linear_sr(ptr(A1.data), A1.data.stride(0), ptr(A1.scales), c1, ptr(A2.data) if A2 is not None else None,
                               A2.data.stride(0) if A2 is not None else 0, ptr(A2.scales) if A2 is not None else None, c2, ptr(Wp.data), ptr(Wp.scales),
                               ptr(bias), ptr(scale), ptr(shift), int(bool(relu)), M, n_out, ptr(osr.data) if osr is not None else None,
-                              n_out * 4 if osr is not None else 0, ptr(osr.scales) if osr is not None else None, ptr(o32), n_out, stream_ptr())
+                              n_out * 4 if osr is not None else 0, ptr(osr.scales) if osr is not None else None, ptr(o32), n_out, ptr(W3), ptr(b3), n_proj, ptr(lg),
+                              stream_ptr())
     if rc == DGNN_E_UNSUPPORTED:
         return None
     check(rc, "dgnn_linear_sr")
-    return o32 if out_f32 else osr
+    return lg if proj is not None else (o32 if out_f32 else osr)
 
 
 # ---- fused inference layer ----------------------------------------------------------------------

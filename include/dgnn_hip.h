@@ -847,11 +847,14 @@ int dgnn_sage_aggregate_sr(const int32_t* rowptr, const int32_t* src, const int3
                            const float* xs, int C, const float* edge_attr, int64_t lde, const float* We, const float* be, const void* prep, void* a_out,
                            float* a_scales, void* x_out, float* x_scales, void* stream);
 /* A1 (C1 channels) and A2 (C2 channels; NULL / 0: one operand) split rows with their scales; Wp / sw = dgnn_sr_pack([W1 | W2] fp32 [n_out][C1 + C2],
- * gch = 0); n_out a multiple of 256.  Output: split rows (out_sr, out_row_bytes, out_scales [M][n_out / 256]) or -- out_sr == NULL -- fp32 rows
- * out_f32 [M][n_out] with row stride ldo.  DGNN_E_UNSUPPORTED for other shapes. */
+ * gch = 0); n_out a multiple of 256.  Exactly ONE output: split rows (out_sr, out_row_bytes, out_scales [M][n_out / 256]); fp32 rows out_f32
+ * [M][n_out] with row stride ldo; or logits [M][n_proj] = act(...) . W3^T + b3 (W3 fp32 [n_proj][n_out], n_proj 1 or 2: the decoder's output
+ * Linear applied to the finished hidden rows inside the launch, reference :180-187; n_out > 256: logits must be ZERO on entry, the column tiles
+ * add into them -- two addends per logit at n_out = 512, an order-independent sum; n_out > 512 is declined).  DGNN_E_UNSUPPORTED for other shapes. */
 int dgnn_linear_sr(const void* A1, int64_t row_bytes1, const float* scales1, int C1, const void* A2, int64_t row_bytes2, const float* scales2, int C2,
                    const void* Wp, const float* sw, const float* bias, const float* scale, const float* shift, int relu, int64_t M, int n_out, void* out_sr,
-                   int64_t out_row_bytes, float* out_scales, float* out_f32, int64_t ldo, void* stream);
+                   int64_t out_row_bytes, float* out_scales, float* out_f32, int64_t ldo, const float* W3, const float* b3, int n_proj, float* logits,
+                   void* stream);
 
 /* elementwise helpers used by the Updated variant (F.relu at surfaceNetUpdatedEdgeFilters.py:239-241
  * and the scatter of phi rows into the zero [E_all,C] buffer at :236-237) */

@@ -117,6 +117,18 @@ def test_linear_sr_vs_fp64(c1, c2, n_out, M):
         k = M - 131
         part = ops.linear_sr(a1, Wp, a2, bias.to(DEV), scale.to(DEV), shift.to(DEV), relu=relu, out_f32=True, rows=k)
         assert torch.equal(part, o32[:k])
+        # the decoder's output Linear inside the launch (reference :180-187): logits = act(...) . W3^T + b3, the hidden rows never stored
+        for n_proj in (2, 1):
+            W3 = torch.randn(n_proj, n_out, generator=g) / n_out ** 0.5
+            b3 = torch.randn(n_proj, generator=g)
+            lg = ops.linear_sr(a1, Wp, a2, bias.to(DEV), scale.to(DEV), shift.to(DEV), relu=relu, proj=(W3.to(DEV), b3.to(DEV)))
+            if n_out > 512:
+                assert lg is None          # more than two column tiles would make the atomic sum order-dependent: declined
+                continue
+            want = o32.double().cpu() @ W3.double().t() + b3.double()
+            wmag = o32.double().cpu().abs() @ W3.double().abs().t() + b3.double().abs()
+            assert lg.shape == (M, n_proj) and ((lg.double().cpu() - want).abs() <= 2e-6 * wmag + 1e-30).all()
+            assert torch.equal(lg, ops.linear_sr(a1, Wp, a2, bias.to(DEV), scale.to(DEV), shift.to(DEV), relu=relu, proj=(W3.to(DEV), b3.to(DEV))))
 
 
 def _graph(n, seed, ragged):
@@ -205,7 +217,7 @@ def test_wide_widths_whole_model_vs_oracle_and_the_fp32_row_path(convs):
         got = net.inference_layer(data)
     finally:
         ops.linear_sr = real
-    assert len(calls) == (3 if convs[0] == 64 else 4)          # the wide conv layers + the decoder's hidden layer
+    assert len(calls) == (3 if convs[0] == 64 else 4)          # the wide conv layers + the decoder (hidden layer and output Linear in one launch)
     with torch.no_grad():
         want = onet.inference_layer(Config(x=x.cpu(), edge_attr=ea.cpu(), edge_index=ei.cpu()))
     err = (got.cpu() - want).abs()
