@@ -443,15 +443,15 @@ def test_updated_training_step_at_scale_matches_the_oracle(dtype, params, points
     # bf16_training_model.py `arith=`; python tests/test_bf16_rounding_model_cpu.py) shows what that amounts to: 2-5e-4 of a tensor's largest entry at
     # the shipped widths and [64,128,256,512], and at [128,256,512,1024] anything from 5e-4 to isolated entries at 2e-2 with an rms of 4e-3,
     # depending on the block -- while ONE mis-placed rounding site (a site of the model switched off) is dense: rms 3-7 % on the layers below it.
-    # Hence: rms <= 1e-3 of the tensor's rms (measured here: <= 5.2e-4), 99.9 % of a tensor's entries within 1e-3 of its largest (fp32 class),
+    # Hence: rms <= 1e-3 of the tensor's rms (measured here: <= 5.2e-4), all but 0.1 % of a tensor's entries (two of a bias vector) within 1e-3 of its largest (fp32 class),
     # every entry within 2e-2 (a flipped mask entry's row).
     mmax = max(g.abs().max().item() for g in mgrads.values())
     for k, (mx, rms) in vs_model.items():
         ref_k = mgrads[k]
         d = (hgrads[k].double().cpu() - ref_k).abs()
         top_k = ref_k.abs().max().item()
-        inside = (d <= 1e-3 * top_k + 1e-6 * mmax).double().mean().item()
-        assert rms <= 1e-3 and inside >= 0.999 and d.max().item() <= 2e-2 * top_k + 1e-6 * mmax, (k, mx, rms, inside)
+        outside = int((d > 1e-3 * top_k + 1e-6 * mmax).sum().item())       # entries beyond fp32 class: at most 0.1 % of the tensor (two for a bias vector)
+        assert rms <= 1e-3 and outside <= max(2, d.numel() // 1000) and d.max().item() <= 2e-2 * top_k + 1e-6 * mmax, (k, mx, rms, outside, d.numel())
 
 
 @pytest.mark.parametrize("k1,k2,n_out", [(128, 128, 128), (64, 0, 2), (128, 0, 64), (70, 33, 37), (256, 256, 512), (28, 28, 64)])
