@@ -1128,6 +1128,11 @@ int launch2(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64
 
 }  // namespace
 
+int dgnn_ws_enabled();      // fused_ws.hip
+int dgnn_sage_layer_fused_ws_try(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src, const float* x_dst, int64_t ldx,
+                                 int c_in, const float* edge_attr, int64_t lde, const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
+                                 const float* scale, const float* shift, int relu, int c_out, float* out, int64_t ldo, hipStream_t stream);
+
 // Returns DGNN_E_UNSUPPORTED when the shape does not fit this variant (the caller then uses fused.hip MODE 1).
 int dgnn_sage_layer_fused_mfma_try(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src,
                                    const float* x_dst, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, const float* We, const float* be,
@@ -1136,6 +1141,13 @@ int dgnn_sage_layer_fused_mfma_try(const int32_t* rowptr, const int32_t* src, co
     const int cin_pad = c_in <= 32 ? 32 : (c_in <= 64 ? 64 : 128);
     const int nb = cin_pad / 16;
     if (c_in % nb != 0 || (c_out != 64 && c_out != 128) || (cin_pad == 128 && c_out != 128)) return DGNN_E_UNSUPPORTED;
+    if (c_in == 128 && c_out == 128 && f16_parts == 2 && prep_mode != 1 && dgnn_ws_enabled()) {
+        // round 5: the plain 128 -> 128 layer in the default arithmetic runs wave-specialised (fused_ws.hip); it derives what it needs from the weights
+        // itself (a prepared buffer is not read)
+        const int rc = dgnn_sage_layer_fused_ws_try(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, shift, relu, c_out, out,
+                                                    ldo, stream);
+        if (rc != DGNN_E_UNSUPPORTED) return rc;
+    }
     const int xvec = ((((uintptr_t)x_src | (uintptr_t)x_dst) % 16) == 0 && ldx % 4 == 0) ? 1 : 0;
     if (nb >= 4 && !xvec && prep_mode != 1) return DGNN_E_UNSUPPORTED;
     if (f16_parts && prep_mode != 1 && (ldo % 4 != 0 || ((uintptr_t)out % 16) != 0)) f16_parts = 0;  // the fp16 forms store 16-byte pieces of the output rows

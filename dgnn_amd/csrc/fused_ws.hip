@@ -1,0 +1,406 @@
+// Wave-specialised fused conv layer, 128 -> 128 (round 5; VERDICT r4 item 3, DESIGN 10 "next" of round 4).
+//
+// Reference: SAGEConv.forward + BatchNorm(eval) + ReLU, learning/surfaceNetStaticEdgeFilters.py:66-96, :345-346 -- the shipped model's layers 2 and 3.
+// k_sage_fused_mfma<128,128> runs eight wavefronts that ALL walk the same two phases (filter / mean, barrier, dense product): 44-48 % of its wave cycles
+// are parked, the matrix pipe is 26 % busy, and at 229-250 VGPRs two wavefronts per SIMD is all it admits (docs/history_r1-r4.md 5a, 5b).  The probe
+// tools/probe_producer.py says what the split buys: the producer side ALONE (gathers, filter product, mean, row split -- k_agg_sr<8, false> with its HBM
+// stores off) runs 1M cells in 0.31-0.34 ms at 4 resp. 2 wavefronts per SIMD: it is bound by its reads, not by latency, once nothing else shares its
+// wavefronts.  So here a 1024-thread workgroup (16 wavefronts, 4 per SIMD, <= 128 VGPRs each) is
+//   8 PRODUCERS  one group of 4 cells each per 32-cell tile: index chain two tiles ahead, 4 neighbour rows + own row as 16-byte loads, filter product on
+//                v_mfma_f32_16x16x32_f16 (per-edge power-of-two scales, 3 products), in-lane 4-term mean, the [a | x_i] row scaled by one power of two,
+//                split (hi, lo) and parked in an LDS ring slot (1 KB per cell, XOR-swizzled 16-byte pieces, conflict-free for both sides);
+//   8 CONSUMERS  16 output channels each, their [Wj | Wi] rows resident as fp16 (hi, lo) fragments (64 VGPRs): D[channel][cell] on v_mfma_f32_16x16x32_f16
+//                with the weights as the A operand, 48 products per tile; epilogue per lane = one cell x 4 consecutive channels: inverse scales,
+//                bias / BatchNorm / ReLU, one 16-byte non-temporal store;
+//   consumers work on tile t-1 while producers build tile t; ONE s_barrier per tile hands the ring slot over.  No K split, no partial-sum exchange,
+//   no resident weights in the gathering wavefronts.
+// Arithmetic: the fp16 two-part form (fused_common.h): scaling groups per cell row [a | x_i], per edge, per [We | be], per consumer (its 16 weight rows).
+// A cell's result depends on its own inputs only: destination sub-ranges, ring parts and differently tiled runs agree bit for bit.  Groups of any
+// in-degree other than 4 take a per-lane fp32 path (never on Delaunay scenes).
+#include <stdlib.h>
+
+#include "common.h"
+#include "fused_common.h"
+
+namespace {
+using namespace fused;
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#define H8(v) __builtin_bit_cast(f16x8, v)
+
+constexpr int WS_C = 128;                    // channels in and out
+constexpr int WS_TILE = 32;                  // cells per tile
+constexpr int WS_NP = 8;                     // producer wavefronts (the other 8 of the 16 are consumers)
+constexpr int WS_ROWB = 1024;                // ring bytes per cell: [hi of a | hi of x | lo of a | lo of x], 128 fp16 each
+constexpr int WS_SLOT = WS_TILE * WS_ROWB;   // 32 KB
+constexpr int WS_BP = 8 * 2 * 48 * 16;       // filter operand [cb < 8][hi | lo][48] x 16 B
+// RING slots of the hand-off: 2 = one s_barrier per tile (producers on tile t, consumers on t - 1, everybody meets once per tile);
+// 4 = no barrier in the loop: per-slot LDS counters -- `ready` (+1 per producer that has parked its rows), `done` (+1 per consumer that has read them) --
+// let every wavefront run at its own pace, a producer only waits for a slot four tiles back to be drained (the barrier form ties all 16 wavefronts
+// to the slowest gather of every tile)
+template <int RING> struct WsL {
+    static constexpr int OFF_BP = RING * WS_SLOT;
+    static constexpr int OFF_ROWF = OFF_BP + WS_BP;                 // [RING][32] inverse row scales
+    static constexpr int OFF_CST = OFF_ROWF + RING * WS_TILE * 4;   // bias | scale | shift [128]
+    static constexpr int OFF_SC = OFF_CST + 3 * WS_C * 4;           // max |We|, |be|; then ready[RING], done[RING]
+    static constexpr int SMEM = OFF_SC + 16 + 2 * RING * 4 + 16;
+};
+
+__device__ __forceinline__ void st_nt16(float* p, f32x4_t v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(p)); }
+__device__ __forceinline__ uint32_t bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+template <int RING>
+__global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid,
+                                                        int64_t n_dst, const float* __restrict__ x, const float* __restrict__ xdst, int64_t ldx,
+                                                        const float* __restrict__ ea, int64_t lde, const float* __restrict__ We, const float* __restrict__ be,
+                                                        const float* __restrict__ Wj, const float* __restrict__ bj, const float* __restrict__ Wi,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift, int relu, float* __restrict__ out,
+                                                        int64_t ldo, int64_t ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char ws_smem[];
+    typedef WsL<RING> L;
+    constexpr bool FLAGS = RING > 2;
+    char* const ring = ws_smem;
+    char* const bpbuf = ws_smem + L::OFF_BP;
+    float* const rowf = reinterpret_cast<float*>(ws_smem + L::OFF_ROWF);
+    float* const cst = reinterpret_cast<float*>(ws_smem + L::OFF_CST);
+    uint32_t* const scbuf = reinterpret_cast<uint32_t*>(ws_smem + L::OFF_SC);
+    volatile uint32_t* const ready = reinterpret_cast<volatile uint32_t*>(ws_smem + L::OFF_SC + 16);
+    volatile uint32_t* const done = ready + RING;
+    // wait until *ctr >= target (LDS word, wave-uniform): a short sleep between polls keeps the LDS and the issue slots for the working wavefronts
+    auto wait_for = [&](volatile uint32_t* ctr, uint32_t target) {
+        while ((int32_t)(__builtin_amdgcn_readfirstlane((int)*ctr) - (int)target) < 0) __builtin_amdgcn_s_sleep(2);
+    };
+    const int lane = lane_id(), w = wave_id_uniform();
+    const int jcol = lane & 15, tq = lane >> 4;
+
+    // tiles of this workgroup: XCD b % 8 walks one contiguous eighth of the cells (gathered neighbour rows stay in that XCD's L2)
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot_ = blockIdx.x >> 3, wg_per_xcd = (nwg + 7 - xcd) >> 3;
+    const int64_t per = (ntiles + 7) / 8, t_lo = xcd * per, t_hi = min(ntiles, t_lo + per);
+    int64_t my_n = 0;
+    if (t_lo + slot_ < t_hi) my_n = (t_hi - t_lo - slot_ + wg_per_xcd - 1) / wg_per_xcd;
+    auto tile_of = [&](int64_t it) { return t_lo + slot_ + it * wg_per_xcd; };
+
+    // ---- prologue: power-of-two scale of [We | be], the split filter operand in LDS, the epilogue's per-channel constants
+    if (threadIdx.x == 0) scbuf[0] = 0u;
+    if (threadIdx.x < 2 * RING) ready[threadIdx.x] = 0u;
+    __syncthreads();
+    {
+        uint32_t me = 0u;
+        for (int e = threadIdx.x; e < WS_C * FE; e += blockDim.x) me = umax(me, absbits(We[e]));
+        for (int e = threadIdx.x; e < WS_C; e += blockDim.x) me = umax(me, absbits(be[e]));
+        me = wave_umax(me);
+        if (lane == 0) atomicMax(&scbuf[0], me);
+    }
+    for (int c = threadIdx.x; c < WS_C; c += blockDim.x) {
+        cst[c] = bj ? bj[c] : 0.f;
+        cst[WS_C + c] = scale ? scale[c] : 1.f;
+        cst[2 * WS_C + c] = scale ? shift[c] : 0.f;
+    }
+    __syncthreads();
+    float sWe, inv_sWe;
+    pow2_scales(scbuf[0], sWe, inv_sWe);
+    // entry (cb, part, g, j): channel c = 8 j + cb, k = 8 g .. 8 g + 7 (g < 3: attributes 0..19, the bias at k = 20, zeros)
+    for (int e = threadIdx.x; e < 8 * 48; e += blockDim.x) {
+        const int cb = e / 48, gj = e - cb * 48, g = gj >> 4, j = gj & 15;
+        const int c = 8 * j + cb;
+        uint32_t ph[4], pl[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            float v[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = 8 * g + 2 * d + u;
+                v[u] = k < FE ? We[(int64_t)c * FE + k] : (k == FE ? be[c] : 0.f);
+            }
+            split2h(v[0] * sWe, v[1] * sWe, ph[d], pl[d]);
+        }
+        uint4* dst = reinterpret_cast<uint4*>(bpbuf + ((cb * 2) * 48 + gj) * 16);
+        dst[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+        dst[48] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+    }
+
+    if (w >= WS_NP) {
+        // =================================================================== CONSUMER: channels [16 cw, 16 cw + 16)
+        const int cw = w - WS_NP;
+        // resident weights: lane (m = jcol: channel 16 cw + m, g = tq) holds K index 32 s + 8 g + i of k-step s: s < 4 -> Wj (the mean half), else Wi
+        const int col = 16 * cw + jcol;
+        uint32_t mw = 0u;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float* wr = (s < 4 ? Wj : Wi) + (int64_t)col * WS_C + 32 * (s & 3) + 8 * tq;
+            const f32x4_t r0 = *reinterpret_cast<const f32x4_t*>(wr), r1 = *reinterpret_cast<const f32x4_t*>(wr + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mw = umax(mw, umax(absbits(r0[i]), absbits(r1[i])));
+        }
+        float sW, inv_sW;
+        pow2_scales(wave_umax(mw), sW, inv_sW);     // one scale per consumer (its 16 weight rows)
+        f16x8 wh[8], wl[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float* wr = (s < 4 ? Wj : Wi) + (int64_t)col * WS_C + 32 * (s & 3) + 8 * tq;
+            const f32x4_t r0 = *reinterpret_cast<const f32x4_t*>(wr), r1 = *reinterpret_cast<const f32x4_t*>(wr + 4);
+            uint32_t ph[4], pl[4];
+            split2h(r0[0] * sW, r0[1] * sW, ph[0], pl[0]);
+            split2h(r0[2] * sW, r0[3] * sW, ph[1], pl[1]);
+            split2h(r1[0] * sW, r1[1] * sW, ph[2], pl[2]);
+            split2h(r1[2] * sW, r1[3] * sW, ph[3], pl[3]);
+            wh[s] = pack8h(ph);
+            wl[s] = pack8h(pl);
+        }
+        __syncthreads();   // (the producers' prologue barrier)
+        const int c0 = 16 * cw + 4 * tq;          // this lane's 4 consecutive output channels
+        const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(cst + c0), sc = *reinterpret_cast<const f32x4_t*>(cst + WS_C + c0),
+                      sh = *reinterpret_cast<const f32x4_t*>(cst + 2 * WS_C + c0);
+        for (int64_t it = FLAGS ? 1 : 0; it <= my_n; ++it) {
+            if (it >= 1) {
+                const int sl = (int)((it - 1) % RING);
+                if constexpr (FLAGS) wait_for(ready + sl, (uint32_t)(WS_NP * ((it - 1) / RING + 1)));
+                const char* tb = ring + sl * WS_SLOT;
+                f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    f16x8 xh[2], xl[2];
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const char* rp = tb + (16 * b + jcol) * WS_ROWB;
+                        xh[b] = H8(*reinterpret_cast<const uint4*>(rp + (((4 * s + tq) ^ jcol) << 4)));
+                        xl[b] = H8(*reinterpret_cast<const uint4*>(rp + (((32 + 4 * s + tq) ^ jcol) << 4)));
+                    }
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s], xh[b], acc[b], 0, 0, 0);     // small terms first
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], xl[b], acc[b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], xh[b], acc[b], 0, 0, 0);
+                }
+                float invr[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) invr[b] = rowf[sl * WS_TILE + 16 * b + jcol] * inv_sW;
+                if constexpr (FLAGS) {
+                    // every read of the slot has returned: hand it back
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) atomicAdd(const_cast<uint32_t*>(done + sl), 1u);
+                }
+                const int64_t cell0 = tile_of(it - 1) * WS_TILE;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int T = 16 * b + jcol;
+                    const int64_t cell = cell0 + T;
+                    f32x4_t v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float t_ = __fmaf_rn(acc[b][i], invr[b], bb[i]);
+                        t_ = __fmaf_rn(t_, sc[i], sh[i]);
+                        v[i] = relu ? fmaxf(t_, 0.f) : t_;
+                    }
+                    if (cell < n_dst) st_nt16(out + cell * ldo + c0, v);
+                }
+            }
+            if constexpr (!FLAGS) tile_barrier();
+        }
+        return;
+    }
+
+    // ======================================================================= PRODUCER: group p of 4 cells of every tile
+    __syncthreads();   // filter operand and constants in place
+    const int p = w;
+    const int P0 = 8 * jcol;                       // the lane's 8 channels
+    auto load_rp = [&](int64_t it, int& vb) {
+        if (it < my_n) {
+            const int64_t i0 = tile_of(it) * WS_TILE + 4 * p;
+            const int nv = (int)max((int64_t)0, min((int64_t)4, n_dst - i0));
+            vb = nv > 0 ? rowptr[i0 + (lane < nv ? lane : nv)] : 0;
+        }
+    };
+    auto load_idx = [&](int64_t it, int vb, bool& reg, int& vsrc, int& veid) {
+        reg = false;
+        if (it < my_n) {
+            const int64_t i0 = tile_of(it) * WS_TILE + 4 * p;
+            const int nv = (int)max((int64_t)0, min((int64_t)4, n_dst - i0));
+            if (nv > 0) {
+                const int b0 = __builtin_amdgcn_readfirstlane(vb);
+                reg = __all(vb == b0 + 4 * (lane < nv ? lane : nv)) != 0;
+                if (reg) {
+                    const int k_me = b0 + (lane < 4 * nv ? lane : 4 * nv - 1);
+                    vsrc = src[k_me];
+                    veid = eid ? eid[k_me] : k_me;
+                }
+            }
+        }
+    };
+    int vb1 = 0, vb2 = 0, vsrc1 = 0, veid1 = 0;
+    bool reg1 = false;
+    load_rp(0, vb1);
+    load_rp(1, vb2);
+    load_idx(0, vb1, reg1, vsrc1, veid1);
+
+    for (int64_t it = 0; it < my_n + (FLAGS ? 0 : 1); ++it) {
+        if (it < my_n) {
+            const int64_t i0 = tile_of(it) * WS_TILE + 4 * p;
+            const int sl = (int)(it % RING);
+            const int nv = (int)max((int64_t)0, min((int64_t)4, n_dst - i0));
+            const bool regular = reg1;
+            const int vsrc = vsrc1, veid = veid1;
+            vb1 = vb2;
+            load_idx(it + 1, vb1, reg1, vsrc1, veid1);
+            load_rp(it + 2, vb2);
+            if (nv > 0) {
+                const int tl = tq < nv ? tq : nv - 1;      // a short group at the end of the graph: clamped (duplicated) cells
+                const int64_t cell = i0 + tl;
+                float aout[8], xv[8];
+                {
+                    const float* rp = xdst + cell * ldx + P0;
+                    const f32x4_t a4 = *reinterpret_cast<const f32x4_t*>(rp), b4 = *reinterpret_cast<const f32x4_t*>(rp + 4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        xv[i] = a4[i];
+                        xv[4 + i] = b4[i];
+                    }
+                }
+                if (regular) {
+                    const float* er = ea + (int64_t)__shfl(veid, jcol) * lde;
+                    const f32x4_t q0 = *reinterpret_cast<const f32x4_t*>(er + 8 * (tq < 2 ? tq : 2));
+                    const f32x4_t q1 = *reinterpret_cast<const f32x4_t*>(er + 8 * (tq < 1 ? tq : 1) + 4);
+                    f32x4_t ra[4], rb_[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float* rp = x + (int64_t)__shfl(vsrc, tl * 4 + r) * ldx + P0;
+                        ra[r] = *reinterpret_cast<const f32x4_t*>(rp);
+                        rb_[r] = *reinterpret_cast<const f32x4_t*>(rp + 4);
+                    }
+                    float av[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        av[i] = tq < 3 ? q0[i] : 0.f;
+                        av[4 + i] = tq < 2 ? q1[i] : 0.f;
+                    }
+                    if (tq == 2) av[4] = 1.0f;
+                    float mf = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; i += 2) mf = fmaxf(fmaxf(mf, fabsf(av[i])), fabsf(av[i + 1]));
+                    float sA, inv_sA;
+                    pow2_scales(cross_row_umax(bits(mf)), sA, inv_sA);      // one scale per EDGE (a row of the operand)
+                    uint32_t ph[4], pl[4];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) split2h(av[2 * d] * sA, av[2 * d + 1] * sA, ph[d], pl[d]);
+                    float inv_e[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) inv_e[r] = __shfl(inv_sA, 4 * tq + r);
+                    const f16x8 ah = pack8h(ph), al = pack8h(pl);
+#pragma unroll
+                    for (int c4 = 0; c4 < 8; c4 += 2) {
+                        f16x8 bh[2], bl[2];
+                        f32x4_t d[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const char* bp = bpbuf + (((c4 + u) * 2) * 48 + (tq < 3 ? tq : 0) * 16 + jcol) * 16;   // k-group 3 re-reads group 0: its A operand is zero
+                            bh[u] = H8(*reinterpret_cast<const uint4*>(bp));
+                            bl[u] = H8(*reinterpret_cast<const uint4*>(bp + 768));
+                            d[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                        }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) d[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[u], d[u], 0, 0, 0);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) d[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[u], d[u], 0, 0, 0);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) d[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[u], d[u], 0, 0, 0);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int c8 = c4 + u;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) d[u][r] *= inv_e[r];     // exact: powers of two
+                            float a = __fmul_rn((c8 < 4 ? ra[0][c8 & 3] : rb_[0][c8 & 3]), d[u][0]);
+#pragma unroll
+                            for (int r = 1; r < 4; ++r) a = __fmaf_rn((c8 < 4 ? ra[r][c8 & 3] : rb_[r][c8 & 3]), d[u][r], a);
+                            aout[c8] = a * (0.25f * inv_sWe);
+                        }
+                    }
+                } else {
+                    // generic path (a group with any in-degree other than 4): plain fp32 per lane, one edge at a time (never on Delaunay scenes)
+#pragma unroll
+                    for (int cb = 0; cb < 8; ++cb) aout[cb] = 0.f;
+                    if (tq < nv) {
+                        const int b = rowptr[cell], e_end = rowptr[cell + 1];
+                        for (int k = b; k < e_end; ++k) {
+                            const int s_ = src[k];
+                            const float* ar = ea + (int64_t)(eid ? eid[k] : k) * lde;
+#pragma unroll 1
+                            for (int cb = 0; cb < 8; ++cb) {
+                                const int c = P0 + cb;
+                                float pf = be[c];
+                                for (int f = 0; f < FE; ++f) pf = __fmaf_rn(We[(int64_t)c * FE + f], ar[f], pf);
+                                aout[cb] = __fadd_rn(aout[cb], __fmul_rn(x[(int64_t)s_ * ldx + c], pf));
+                            }
+                        }
+                        const float cnt = (float)max(e_end - b, 1);
+#pragma unroll
+                        for (int cb = 0; cb < 8; ++cb) aout[cb] = __fdiv_rn(aout[cb], cnt);
+                    }
+                }
+                // the [mean | own] row: one power-of-two scale (its 16 lanes), split, parked in the ring slot of this tile
+                float ma = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    ma = fmaxf(fmaxf(ma, fabsf(aout[i])), fabsf(aout[i + 1]));
+                    ma = fmaxf(fmaxf(ma, fabsf(xv[i])), fabsf(xv[i + 1]));
+                }
+                float s_, inv_;
+                pow2_scales(row16_umax(bits(ma)), s_, inv_);
+                const int T = 4 * p + tq;
+                if constexpr (FLAGS) wait_for(done + sl, (uint32_t)(8 * (it / RING)));      // the slot's previous tile has been read by all 8 consumers
+                if (jcol == 0) rowf[sl * WS_TILE + T] = inv_;
+                uint32_t ah_[4], al_[4], xh_[4], xl_[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    split2h(aout[2 * d] * s_, aout[2 * d + 1] * s_, ah_[d], al_[d]);
+                    split2h(xv[2 * d] * s_, xv[2 * d + 1] * s_, xh_[d], xl_[d]);
+                }
+                char* rowp = ring + sl * WS_SLOT + T * WS_ROWB;
+                const int key = T & 15;
+                *reinterpret_cast<uint4*>(rowp + ((jcol ^ key) << 4)) = make_uint4(ah_[0], ah_[1], ah_[2], ah_[3]);
+                *reinterpret_cast<uint4*>(rowp + (((16 + jcol) ^ key) << 4)) = make_uint4(xh_[0], xh_[1], xh_[2], xh_[3]);
+                *reinterpret_cast<uint4*>(rowp + (((32 + jcol) ^ key) << 4)) = make_uint4(al_[0], al_[1], al_[2], al_[3]);
+                *reinterpret_cast<uint4*>(rowp + (((48 + jcol) ^ key) << 4)) = make_uint4(xl_[0], xl_[1], xl_[2], xl_[3]);
+            }
+            if constexpr (FLAGS) {
+                // this producer's rows of the tile are parked (LDS operations of a wavefront complete in order; a group past the end of the graph parks nothing)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) atomicAdd(const_cast<uint32_t*>(ready + sl), 1u);
+            }
+        }
+        if constexpr (!FLAGS) tile_barrier();
+    }
+}
+
+}  // namespace
+
+// 1 = the wave-specialised kernel takes the plain 128 -> 128 layer in the default arithmetic (DGNN_WS=0: k_sage_fused_mfma<128,128> as in rounds 2-4)
+int dgnn_ws_enabled() {
+    static const int v = getenv("DGNN_WS") ? atoi(getenv("DGNN_WS")) : 1;
+    return v;
+}
+
+// same contract as dgnn_sage_layer_fused_mfma_try for c_in == c_out == 128; DGNN_E_UNSUPPORTED: the caller keeps the two-phase kernel
+int dgnn_sage_layer_fused_ws_try(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src, const float* x_dst, int64_t ldx,
+                                 int c_in, const float* edge_attr, int64_t lde, const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
+                                 const float* scale, const float* shift, int relu, int c_out, float* out, int64_t ldo, hipStream_t stream) {
+    if (c_in != WS_C || c_out != WS_C || lde != FE || ldx % 4 != 0 || ldo % 4 != 0 ||
+        ((((uintptr_t)x_src | (uintptr_t)x_dst | (uintptr_t)edge_attr | (uintptr_t)out | (uintptr_t)Wj | (uintptr_t)Wi) % 16) != 0))
+        return DGNN_E_UNSUPPORTED;
+    const int64_t ntiles = dgnn_cdiv(n_dst, WS_TILE);
+    int grid = (int)(ntiles < DGNN_NUM_CU ? ntiles : DGNN_NUM_CU);
+    if (grid < 1) grid = 1;
+    static const int ring = getenv("DGNN_WS_RING") ? atoi(getenv("DGNN_WS_RING")) : 4;
+    if (ring == 2) {
+        static bool attr_a[DGNN_MAX_DEVICES] = {};
+        dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_ws<2>), WsL<2>::SMEM, attr_a);
+        hipLaunchKernelGGL(k_sage_fused_ws<2>, dim3(grid), dim3(1024), WsL<2>::SMEM, stream, rowptr, src, eid, n_dst, x_src, x_dst, ldx, edge_attr, lde, We, be, Wj, bj,
+                           Wi, scale, shift, relu, out, ldo, ntiles);
+    } else {
+        static bool attr_b[DGNN_MAX_DEVICES] = {};
+        dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_ws<4>), WsL<4>::SMEM, attr_b);
+        hipLaunchKernelGGL(k_sage_fused_ws<4>, dim3(grid), dim3(1024), WsL<4>::SMEM, stream, rowptr, src, eid, n_dst, x_src, x_dst, ldx, edge_attr, lde, We, be, Wj, bj,
+                           Wi, scale, shift, relu, out, ldo, ntiles);
+    }
+    return dgnn_check_launch("sage_layer_fused_fwd(wave-specialised)");
+}

@@ -184,7 +184,8 @@ __global__ void __launch_bounds__(512, 2) k_agg_sr(const int32_t* __restrict__ r
                                                    const float* __restrict__ ea, int64_t lde, const float* __restrict__ We, const float* __restrict__ be,
                                                    const char* __restrict__ prep, int pass, char* __restrict__ ao, int64_t arb, float* __restrict__ as, int nga,
                                                    char* __restrict__ xo, float* __restrict__ xos, int nt_) {
-    const bool nt = nt_ != 0;
+    const bool nt = (nt_ & 1) != 0;
+    const bool no_store = (nt_ & 2) != 0;       // DGNN_SR_NT=2 / 3: timing probe of the producer side alone (tools/probe_producer.py); never set by the product
     constexpr int NSB = NB / 8;                                        // sub-blocks of 8 positions per lane
     extern __shared__ __attribute__((aligned(16))) char agg_smem[];
     char* const bpbuf = agg_smem;                                      // [cb][part][48] x 16 B
@@ -389,7 +390,7 @@ __global__ void __launch_bounds__(512, 2) k_agg_sr(const int32_t* __restrict__ r
             const uint32_t m = row16_umax(b_of(mx));
             float s_store, s_mul;
             sr_scale(m, s_store, s_mul);
-            if (tq < nv) {
+            if (tq < nv && !(no_store && s_mul != 12345.f)) {
                 if (jcol == 0) oscale[pass] = s_store;
 #pragma unroll
                 for (int sb = 0; sb < NSB; ++sb) {
