@@ -131,6 +131,7 @@ SIGNATURES = {
     "dgnn_comm_create": (i32, [vp, i32, i32, vp]),
     "dgnn_comm_destroy": (i32, [vp]),
     "dgnn_comm_count": (i32, [vp]),
+    "dgnn_wave_specialised_enabled": (i32, []),
     "dgnn_sr_row_bytes": (i64, [i32]),
     "dgnn_sr_pack": (i32, [vp, i64, i32, vp, i64, i32, i64, i32, vp, i64, vp, i32, vp]),
     "dgnn_sr_unpack": (i32, [vp, i64, vp, i32, i32, i32, i64, vp, i64, vp]),

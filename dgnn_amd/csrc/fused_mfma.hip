@@ -1131,7 +1131,9 @@ int launch2(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64
 int dgnn_ws_enabled();      // fused_ws.hip
 int dgnn_sage_layer_fused_ws_try(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src, const float* x_dst, int64_t ldx,
                                  int c_in, const float* edge_attr, int64_t lde, const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
-                                 const float* scale, const float* shift, int relu, int c_out, float* out, int64_t ldo, hipStream_t stream);
+                                 const float* scale, const float* shift, int relu, int c_out, float* out, int64_t ldo, hipStream_t stream, const float* W0 = nullptr,
+                                 const float* b0 = nullptr, const float* scale1 = nullptr, const float* shift1 = nullptr, const float* W3 = nullptr,
+                                 const float* b3 = nullptr, float* logits = nullptr);
 
 // Returns DGNN_E_UNSUPPORTED when the shape does not fit this variant (the caller then uses fused.hip MODE 1).
 int dgnn_sage_layer_fused_mfma_try(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src,
@@ -1197,6 +1199,11 @@ int fused_decoder_impl(const int32_t* rowptr, const int32_t* src, const int32_t*
              ((uintptr_t)logits % 8) == 0 && n_dst * ldx < ((int64_t)1 << 31);
     if (prep_mode != 0) ok = ok && prep != nullptr && ((uintptr_t)prep % 16) == 0;
     if (!ok) return DGNN_E_UNSUPPORTED;
+    if (prep_mode != 1 && c_in == 128 && dgnn_ws_enabled()) {      // round 5: the wave-specialised kernel carries the decoder too (fused_ws.hip)
+        const int rc = dgnn_sage_layer_fused_ws_try(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, shift, relu, c_out, nullptr,
+                                                    0, stream, W0, b0, scale1, shift1, W3, b3, logits);
+        if (rc != DGNN_E_UNSUPPORTED) return rc;
+    }
     DecArgs dec{W0, b0, scale1, shift1, W3, b3, logits, prep, prep_mode};
     return launch2<128, 128, 2, 2, true>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, shift, relu, nullptr, 0, 1,
                                          stream, dec);

@@ -42,23 +42,46 @@ template <int RING> struct WsL {
     static constexpr int OFF_BP = RING * WS_SLOT;
     static constexpr int OFF_ROWF = OFF_BP + WS_BP;                 // [RING][32] inverse row scales
     static constexpr int OFF_CST = OFF_ROWF + RING * WS_TILE * 4;   // bias | scale | shift [128]
-    static constexpr int OFF_SC = OFF_CST + 3 * WS_C * 4;           // max |We|, |be|; then ready[RING], done[RING]
-    static constexpr int SMEM = OFF_SC + 16 + 2 * RING * 4 + 16;
+    static constexpr int OFF_SC = OFF_CST + 3 * WS_C * 4;           // max |We|, |be|; then ready[RING], done[RING], hcnt, hfree, lcnt
+    static constexpr int OFF_DC = OFF_SC + 16 + 2 * RING * 4 + 16 + 16;   // decoder constants: A1 | B1 [64], W3 [2][64], b3 [2] (+2 pad)
+    static constexpr int OFF_PLOG = OFF_DC + (64 + 64 + 128 + 4) * 4;     // partial logits [2 tiles][8 consumers][32 cells][2]
+    static constexpr int OFF_HPART = (OFF_PLOG + 2 * 8 * 32 * 8 + 255) & ~255;   // partial hidden rows [8 consumers][32 cells][64] fp32, 16-byte pieces XOR-swizzled by cell
+    static constexpr int SMEM = OFF_SC + 16 + 2 * RING * 4 + 16 + 16;
+    static constexpr int SMEM_DEC = OFF_HPART + 8 * 32 * 64 * 4;
 };
+
+// the decoder behind the last conv layer (reference learning/surfaceNetStaticEdgeFilters.py:180-187, applied at :350-351): Linear(128 -> 64) - BatchNorm(eval) -
+// ReLU - Linear(64 -> 2).  In the DEC instantiation the consumers do not store the layer's rows: a lane's 4 finished channels of one cell ARE the B operand
+// of v_mfma_f32_16x16x16_f16 (K = the consumer's 16 channels), so every consumer multiplies its slice by its 64 x 16 block of W0 (resident: 16 VGPRs) in
+// the fp16 two-part form with one power-of-two scale per cell and slice, parks the fp32 partial hidden rows in LDS, and once all eight have (a counter)
+// adds them up in a fixed order for its 8 hidden units, applies BatchNorm / ReLU and W3, and leaves partial logits; consumer 0 adds those eight in a
+// fixed order and stores 8 bytes per cell.  Every sum has one order and touches one cell's values only (sub-ranges and ring parts give the same bits).
+struct WsDec {
+    const float* W0;      // [64, 128]
+    const float* b0;      // [64]
+    const float* scale1;  // [64] folded BatchNorm of the decoder, or NULL
+    const float* shift1;
+    const float* W3;      // [2, 64]
+    const float* b3;      // [2]
+    float* logits;        // [n_dst, 2]
+};
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+
 
 __device__ __forceinline__ void st_nt16(float* p, f32x4_t v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(p)); }
 __device__ __forceinline__ uint32_t bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 
-template <int RING>
+template <int RING, bool FLAGS, bool DEC>
 __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid,
                                                         int64_t n_dst, const float* __restrict__ x, const float* __restrict__ xdst, int64_t ldx,
                                                         const float* __restrict__ ea, int64_t lde, const float* __restrict__ We, const float* __restrict__ be,
                                                         const float* __restrict__ Wj, const float* __restrict__ bj, const float* __restrict__ Wi,
                                                         const float* __restrict__ scale, const float* __restrict__ shift, int relu, float* __restrict__ out,
-                                                        int64_t ldo, int64_t ntiles) {
+                                                        int64_t ldo, int64_t ntiles, int knobs, WsDec dec) {
+    static_assert(!DEC || FLAGS, "the decoder stage hands over by counters");
     extern __shared__ __attribute__((aligned(16))) char ws_smem[];
+    const bool nt_store = (knobs & 1) != 0;
     typedef WsL<RING> L;
-    constexpr bool FLAGS = RING > 2;
     char* const ring = ws_smem;
     char* const bpbuf = ws_smem + L::OFF_BP;
     float* const rowf = reinterpret_cast<float*>(ws_smem + L::OFF_ROWF);
@@ -66,9 +89,20 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
     uint32_t* const scbuf = reinterpret_cast<uint32_t*>(ws_smem + L::OFF_SC);
     volatile uint32_t* const ready = reinterpret_cast<volatile uint32_t*>(ws_smem + L::OFF_SC + 16);
     volatile uint32_t* const done = ready + RING;
+    volatile uint32_t* const hcnt = done + RING;          // DEC: +1 per consumer whose partial hidden rows of a tile are parked
+    volatile uint32_t* const hfree = hcnt + 1;            //      +1 per consumer that has read them
+    volatile uint32_t* const lcnt = hcnt + 2;             //      +1 per consumer whose partial logits of a tile are parked
+    float* const dcst = reinterpret_cast<float*>(ws_smem + L::OFF_DC);
+    float* const plog = reinterpret_cast<float*>(ws_smem + L::OFF_PLOG);
+    char* const hpart = ws_smem + L::OFF_HPART;
     // wait until *ctr >= target (LDS word, wave-uniform): a short sleep between polls keeps the LDS and the issue slots for the working wavefronts
+    // The compiler barriers matter: the poll is a volatile load, which orders nothing against the ORDINARY LDS loads behind it -- without the second one
+    // the compiler hoisted the consumer's read of a tile's row scales above the poll (a stale scale for one producer's four cells, once in thousands of
+    // tiles: caught by tests/test_gpu_parity.py::test_fused_layers_row_level_on_larger_graph) -- nor the ordinary stores in front of it.
     auto wait_for = [&](volatile uint32_t* ctr, uint32_t target) {
+        asm volatile("" ::: "memory");
         while ((int32_t)(__builtin_amdgcn_readfirstlane((int)*ctr) - (int)target) < 0) __builtin_amdgcn_s_sleep(2);
+        asm volatile("" ::: "memory");
     };
     const int lane = lane_id(), w = wave_id_uniform();
     const int jcol = lane & 15, tq = lane >> 4;
@@ -82,7 +116,17 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
 
     // ---- prologue: power-of-two scale of [We | be], the split filter operand in LDS, the epilogue's per-channel constants
     if (threadIdx.x == 0) scbuf[0] = 0u;
-    if (threadIdx.x < 2 * RING) ready[threadIdx.x] = 0u;
+    if (threadIdx.x < 2 * RING + 4) ready[threadIdx.x] = 0u;
+    if constexpr (DEC) {
+        for (int n_ = threadIdx.x; n_ < 64; n_ += blockDim.x) {
+            const float s1 = dec.scale1 ? dec.scale1[n_] : 1.f, h1 = dec.scale1 ? dec.shift1[n_] : 0.f;
+            dcst[n_] = s1;                                   // h = relu(sum * A1 + B1)
+            dcst[64 + n_] = __fmaf_rn(dec.b0[n_], s1, h1);
+            dcst[128 + n_] = dec.W3[n_];
+            dcst[192 + n_] = dec.W3[64 + n_];
+        }
+        if (threadIdx.x < 2) dcst[256 + threadIdx.x] = dec.b3[threadIdx.x];
+    }
     __syncthreads();
     {
         uint32_t me = 0u;
@@ -147,24 +191,50 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
             wh[s] = pack8h(ph);
             wl[s] = pack8h(pl);
         }
+        // DEC: W0[:, 16 cw .. 16 cw + 15] as A-operand fragments of v_mfma_f32_16x16x16_f16: lane (m = jcol, kg = tq) holds hidden unit 16 hb + m, channels
+        // 16 cw + 4 kg .. + 3; one power-of-two scale per consumer
+        f16x4_t w0h[4], w0l[4];
+        float inv_sW0 = 1.f;
+        if constexpr (DEC) {
+            uint32_t m0 = 0u;
+            f32x4_t raw[4];
+#pragma unroll
+            for (int hb = 0; hb < 4; ++hb) {
+                raw[hb] = *reinterpret_cast<const f32x4_t*>(dec.W0 + (int64_t)(16 * hb + jcol) * WS_C + 16 * cw + 4 * tq);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m0 = umax(m0, absbits(raw[hb][i]));
+            }
+            float sW0;
+            pow2_scales(wave_umax(m0), sW0, inv_sW0);
+#pragma unroll
+            for (int hb = 0; hb < 4; ++hb) {
+                uint32_t ph[2], pl[2];
+                split2h(raw[hb][0] * sW0, raw[hb][1] * sW0, ph[0], pl[0]);
+                split2h(raw[hb][2] * sW0, raw[hb][3] * sW0, ph[1], pl[1]);
+                w0h[hb] = __builtin_bit_cast(f16x4_t, make_uint2(ph[0], ph[1]));
+                w0l[hb] = __builtin_bit_cast(f16x4_t, make_uint2(pl[0], pl[1]));
+            }
+        }
         __syncthreads();   // (the producers' prologue barrier)
         const int c0 = 16 * cw + 4 * tq;          // this lane's 4 consecutive output channels
-        const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(cst + c0), sc = *reinterpret_cast<const f32x4_t*>(cst + WS_C + c0),
-                      sh = *reinterpret_cast<const f32x4_t*>(cst + 2 * WS_C + c0);
         for (int64_t it = FLAGS ? 1 : 0; it <= my_n; ++it) {
             if (it >= 1) {
                 const int sl = (int)((it - 1) % RING);
                 if constexpr (FLAGS) wait_for(ready + sl, (uint32_t)(WS_NP * ((it - 1) / RING + 1)));
                 const char* tb = ring + sl * WS_SLOT;
                 f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                // (the swizzle key passes through an empty asm every tile: left alone, the compiler keeps all 32 loop-invariant read addresses in registers
+                // -- 19 spilled in the decoder-carrying instantiation -- instead of two integer instructions per read)
+                int key = jcol;
+                asm volatile("" : "+v"(key));
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
                     f16x8 xh[2], xl[2];
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
                         const char* rp = tb + (16 * b + jcol) * WS_ROWB;
-                        xh[b] = H8(*reinterpret_cast<const uint4*>(rp + (((4 * s + tq) ^ jcol) << 4)));
-                        xl[b] = H8(*reinterpret_cast<const uint4*>(rp + (((32 + 4 * s + tq) ^ jcol) << 4)));
+                        xh[b] = H8(*reinterpret_cast<const uint4*>(rp + (((4 * s + tq) ^ key) << 4)));
+                        xl[b] = H8(*reinterpret_cast<const uint4*>(rp + (((32 + 4 * s + tq) ^ key) << 4)));
                     }
 #pragma unroll
                     for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s], xh[b], acc[b], 0, 0, 0);     // small terms first
@@ -182,18 +252,107 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                     if (lane == 0) atomicAdd(const_cast<uint32_t*>(done + sl), 1u);
                 }
                 const int64_t cell0 = tile_of(it - 1) * WS_TILE;
+                // (the per-channel constants are re-read from LDS every tile: 12 registers the decoder stage needs)
+                const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(cst + c0), sc = *reinterpret_cast<const f32x4_t*>(cst + WS_C + c0),
+                              sh = *reinterpret_cast<const f32x4_t*>(cst + 2 * WS_C + c0);
+                f32x4_t yv[2];
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    const int T = 16 * b + jcol;
-                    const int64_t cell = cell0 + T;
-                    f32x4_t v;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         float t_ = __fmaf_rn(acc[b][i], invr[b], bb[i]);
                         t_ = __fmaf_rn(t_, sc[i], sh[i]);
-                        v[i] = relu ? fmaxf(t_, 0.f) : t_;
+                        yv[b][i] = relu ? fmaxf(t_, 0.f) : t_;
                     }
-                    if (cell < n_dst) st_nt16(out + cell * ldo + c0, v);
+                }
+                if constexpr (!DEC) {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const int64_t cell = cell0 + 16 * b + jcol;
+                        if (cell < n_dst) {
+                            if (nt_store) st_nt16(out + cell * ldo + c0, yv[b]);
+                            else *reinterpret_cast<f32x4_t*>(out + cell * ldo + c0) = yv[b];
+                        }
+                    }
+                } else {
+                    const uint32_t tix = (uint32_t)(it - 1);             // tile counter of this workgroup
+                    // (1) partial hidden rows over this consumer's 16 channels: one scale per cell and slice (the cell's 4 lanes are 16 apart); parked
+                    // block by block -- the previous tile's partials have been read by everybody
+                    wait_for(hfree, 8u * tix);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const float my = fmaxf(fmaxf(fabsf(yv[b][0]), fabsf(yv[b][1])), fmaxf(fabsf(yv[b][2]), fabsf(yv[b][3])));
+                        float sY, inv_sY;
+                        pow2_scales(cross_row_umax(bits(my)), sY, inv_sY);
+                        uint32_t ph[2], pl[2];
+                        split2h(yv[b][0] * sY, yv[b][1] * sY, ph[0], pl[0]);
+                        split2h(yv[b][2] * sY, yv[b][3] * sY, ph[1], pl[1]);
+                        const f16x4_t yh = __builtin_bit_cast(f16x4_t, make_uint2(ph[0], ph[1])), yl = __builtin_bit_cast(f16x4_t, make_uint2(pl[0], pl[1]));
+                        const float inv = inv_sY * inv_sW0;
+                        const int T = 16 * b + key;
+                        char* rp = hpart + ((cw * WS_TILE + T) << 8);        // 64 hidden units = 16 pieces of 16 B, piece (4 hb + kg) at slot piece ^ (T & 15)
+#pragma unroll
+                        for (int hb = 0; hb < 4; ++hb) {
+                            f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+                            d = __builtin_amdgcn_mfma_f32_16x16x16f16(w0l[hb], yh, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_16x16x16f16(w0h[hb], yl, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_16x16x16f16(w0h[hb], yh, d, 0, 0, 0);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) d[i] *= inv;
+                            *reinterpret_cast<f32x4_t*>(rp + (((4 * hb + tq) ^ key) << 4)) = d;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) atomicAdd(const_cast<uint32_t*>(hcnt), 1u);
+                    // (2) hidden units [8 cw, 8 cw + 8) of all 32 cells: lane (cell n = lane & 31, rh = lane >> 5) takes units 8 cw + 4 rh .. + 3
+                    wait_for(hcnt, 8u * (tix + 1));
+                    int n_ = lane & 31;
+                    asm volatile("" : "+v"(n_));                            // (addresses recomputed per tile, see `key`)
+                    const int rh = lane >> 5;
+                    f32x4_t hs = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(hpart + ((q * WS_TILE + n_) << 8) + (((2 * cw + rh) ^ (n_ & 15)) << 4));
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) hs[i] += v[i];           // consumers 0 .. 7 in order
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) atomicAdd(const_cast<uint32_t*>(hfree), 1u);
+                    const int u0 = 8 * cw + 4 * rh;
+                    float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float hv = fmaxf(__fmaf_rn(hs[i], dcst[u0 + i], dcst[64 + u0 + i]), 0.f);
+                        l0 = __fmaf_rn(hv, dcst[128 + u0 + i], l0);
+                        l1 = __fmaf_rn(hv, dcst[192 + u0 + i], l1);
+                    }
+                    uint32_t oa, ob;
+                    swap32_pair(bits(l0), oa, ob);
+                    const float o0 = __builtin_bit_cast(float, oa ^ ob ^ bits(l0));
+                    swap32_pair(bits(l1), oa, ob);
+                    const float o1 = __builtin_bit_cast(float, oa ^ ob ^ bits(l1));
+                    float* pl_ = plog + (((tix & 1) * 8 + cw) * WS_TILE + n_) * 2;
+                    if (rh == 0) {
+                        pl_[0] = l0 + o0;                                    // units 4 rh = 0's first
+                        pl_[1] = l1 + o1;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) atomicAdd(const_cast<uint32_t*>(lcnt), 1u);
+                    // (3) consumer 0 adds the eight partial logits of a cell in one order and stores them
+                    if (cw == 0) {
+                        wait_for(lcnt, 8u * (tix + 1));
+                        if (lane < WS_TILE) {
+                            float s0 = dcst[256], s1 = dcst[257];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const float* pq = plog + (((tix & 1) * 8 + q) * WS_TILE + lane) * 2;
+                                s0 += pq[0];
+                                s1 += pq[1];
+                            }
+                            const int64_t cell = cell0 + lane;
+                            if (cell < n_dst) *reinterpret_cast<float2*>(dec.logits + cell * 2) = make_float2(s0, s1);
+                        }
+                    }
                 }
             }
             if constexpr (!FLAGS) tile_barrier();
@@ -361,9 +520,14 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                 *reinterpret_cast<uint4*>(rowp + (((16 + jcol) ^ key) << 4)) = make_uint4(xh_[0], xh_[1], xh_[2], xh_[3]);
                 *reinterpret_cast<uint4*>(rowp + (((32 + jcol) ^ key) << 4)) = make_uint4(al_[0], al_[1], al_[2], al_[3]);
                 *reinterpret_cast<uint4*>(rowp + (((48 + jcol) ^ key) << 4)) = make_uint4(xl_[0], xl_[1], xl_[2], xl_[3]);
+            } else if constexpr (FLAGS) {
+                // a group past the end of the graph parks nothing, but its count must not land in `ready` while the slot's PREVIOUS tile is still being
+                // produced: the consumers would take seven real producers plus this one for eight and read a late producer's rows before they are written
+                // (seen on the workgroup that owns the last, partial tile of a scene: tools/det_ws_real.py)
+                wait_for(done + sl, (uint32_t)(8 * (it / RING)));
             }
             if constexpr (FLAGS) {
-                // this producer's rows of the tile are parked (LDS operations of a wavefront complete in order; a group past the end of the graph parks nothing)
+                // this producer's rows of the tile are parked (LDS operations of a wavefront complete in order)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) atomicAdd(const_cast<uint32_t*>(ready + sl), 1u);
             }
@@ -380,27 +544,39 @@ int dgnn_ws_enabled() {
     return v;
 }
 
-// same contract as dgnn_sage_layer_fused_mfma_try for c_in == c_out == 128; DGNN_E_UNSUPPORTED: the caller keeps the two-phase kernel
+// C ABI (include/dgnn_hip.h): which kernel dgnn_sage_layer_fused_fwd / _decoder_fwd launch for a 128 -> 128 layer in DGNN_GEMM_F16X2
+extern "C" int dgnn_wave_specialised_enabled(void) { return dgnn_ws_enabled() != 0 ? 1 : 0; }
+
+// same contract as dgnn_sage_layer_fused_mfma_try for c_in == c_out == 128; with W0 != NULL the launch carries the decoder 128 -> 64 -> 2 and writes
+// logits [n_dst, 2] instead of rows (`out` unused).  DGNN_E_UNSUPPORTED: the caller keeps the two-phase kernel
 int dgnn_sage_layer_fused_ws_try(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src, const float* x_dst, int64_t ldx,
                                  int c_in, const float* edge_attr, int64_t lde, const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
-                                 const float* scale, const float* shift, int relu, int c_out, float* out, int64_t ldo, hipStream_t stream) {
-    if (c_in != WS_C || c_out != WS_C || lde != FE || ldx % 4 != 0 || ldo % 4 != 0 ||
-        ((((uintptr_t)x_src | (uintptr_t)x_dst | (uintptr_t)edge_attr | (uintptr_t)out | (uintptr_t)Wj | (uintptr_t)Wi) % 16) != 0))
+                                 const float* scale, const float* shift, int relu, int c_out, float* out, int64_t ldo, hipStream_t stream, const float* W0,
+                                 const float* b0, const float* scale1, const float* shift1, const float* W3, const float* b3, float* logits) {
+    const bool dec = W0 != nullptr;
+    if (c_in != WS_C || c_out != WS_C || lde != FE || ldx % 4 != 0 || (!dec && ldo % 4 != 0) ||
+        ((((uintptr_t)x_src | (uintptr_t)x_dst | (uintptr_t)edge_attr | (uintptr_t)(dec ? nullptr : out) | (uintptr_t)Wj | (uintptr_t)Wi | (uintptr_t)W0) % 16) != 0) ||
+        (dec && ((uintptr_t)logits % 8) != 0))
         return DGNN_E_UNSUPPORTED;
     const int64_t ntiles = dgnn_cdiv(n_dst, WS_TILE);
     int grid = (int)(ntiles < DGNN_NUM_CU ? ntiles : DGNN_NUM_CU);
     if (grid < 1) grid = 1;
-    static const int ring = getenv("DGNN_WS_RING") ? atoi(getenv("DGNN_WS_RING")) : 4;
-    if (ring == 2) {
-        static bool attr_a[DGNN_MAX_DEVICES] = {};
-        dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_ws<2>), WsL<2>::SMEM, attr_a);
-        hipLaunchKernelGGL(k_sage_fused_ws<2>, dim3(grid), dim3(1024), WsL<2>::SMEM, stream, rowptr, src, eid, n_dst, x_src, x_dst, ldx, edge_attr, lde, We, be, Wj, bj,
-                           Wi, scale, shift, relu, out, ldo, ntiles);
-    } else {
-        static bool attr_b[DGNN_MAX_DEVICES] = {};
-        dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_ws<4>), WsL<4>::SMEM, attr_b);
-        hipLaunchKernelGGL(k_sage_fused_ws<4>, dim3(grid), dim3(1024), WsL<4>::SMEM, stream, rowptr, src, eid, n_dst, x_src, x_dst, ldx, edge_attr, lde, We, be, Wj, bj,
-                           Wi, scale, shift, relu, out, ldo, ntiles);
-    }
-    return dgnn_check_launch("sage_layer_fused_fwd(wave-specialised)");
+    static const int ring = getenv("DGNN_WS_RING") ? atoi(getenv("DGNN_WS_RING")) : 22;          // 2 = one barrier per tile; 22 / 3 / 4 = counters, 2 / 3 / 4 slots (measured: equal)
+    static const int knobs = getenv("DGNN_WS_NT") ? atoi(getenv("DGNN_WS_NT")) : 1;
+    const WsDec d{W0, b0, scale1, shift1, W3, b3, logits};
+#define DGNN_WS_GO(R_, F_, D_)                                                                                                                              \
+    do {                                                                                                                                                    \
+        static bool attr_[DGNN_MAX_DEVICES] = {};                                                                                                           \
+        const size_t sm_ = D_ ? WsL<R_>::SMEM_DEC : WsL<R_>::SMEM;                                                                                          \
+        dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_ws<R_, F_, D_>), sm_, attr_);                                                    \
+        hipLaunchKernelGGL((k_sage_fused_ws<R_, F_, D_>), dim3(grid), dim3(1024), sm_, stream, rowptr, src, eid, n_dst, x_src, x_dst, ldx, edge_attr, lde, We, be, \
+                           Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles, knobs, d);                                                                     \
+    } while (0)
+    if (dec) DGNN_WS_GO(2, true, true);
+    else if (ring == 2) DGNN_WS_GO(2, false, false);
+    else if (ring == 3) DGNN_WS_GO(3, true, false);
+    else if (ring == 4) DGNN_WS_GO(4, true, false);
+    else DGNN_WS_GO(2, true, false);
+#undef DGNN_WS_GO
+    return dgnn_check_launch(dec ? "sage_layer_fused_decoder_fwd(wave-specialised)" : "sage_layer_fused_fwd(wave-specialised)");
 }

@@ -292,6 +292,11 @@ int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* src, const i
                               const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
                               const float* scale, const float* shift, int relu, int c_out, float* out, int64_t ldo,
                               int gemm_mode, void* stream);
+/* 1: the 128 -> 128 layers in DGNN_GEMM_F16X2 (plain and decoder-carrying) run as the WAVE-SPECIALISED kernel (csrc/fused_ws.hip: workgroups of 8
+ * producer wavefronts -- gather, filter MLP, mean, row split -- and 8 consumer wavefronts -- the dense product against register-resident weights, the
+ * epilogue, the decoder -- around a ring of 32-tet tiles in LDS; same arithmetic form and error level as the two-phase kernel, not the same bits);
+ * 0: the two-phase kernel of rounds 2-4 (environment DGNN_WS=0, read once per process).  What a benchmark line names its dominant kernel by. */
+int dgnn_wave_specialised_enabled(void);
 
 /* The LAST conv layer + BatchNorm(eval) + ReLU of SurfaceNet.inference_layer (learning/surfaceNetStaticEdgeFilters.py:343-347) together with the
  * decoder Linear(c_out -> c_hidden) - BatchNorm(eval, folded into scale1 / shift1, NULL = none) - ReLU - Linear(c_hidden -> n_logits)

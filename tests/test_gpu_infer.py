@@ -184,6 +184,34 @@ def test_ignatius_full_scene_one_call_vs_reference_logits():
     logit_check(one.cpu().numpy(), g["logits"], g["logits64"])
 
 
+def test_ignatius_layers_repeat_bit_for_bit_with_cold_caches():
+    """Run-to-run determinism of the wave-specialised 128 -> 128 launches (plain and decoder-carrying) where it once failed: the Ignatius scene has
+    67017 cells = 2094 tiles of 32 + 9, so one workgroup owns a last tile in which five of the eight producer groups are empty; those groups' `ready`
+    counts used to land before the slot's previous tile was fully produced, and with cold caches (a 1 GiB sweep between launches: gathers of some quads
+    take microseconds) the consumers read a late quad's rows too early -- one launch in five, always tile 2030.  (tools/det_ws_real.py locates it.)"""
+    from dgnn_amd.graph import GraphPlan
+    g = gold("static_f4_ignatius_full.npz")
+    n = g["x"].shape[0]
+    assert n % 32 == 9
+    fg = np.random.default_rng(int(g["fgeom_seed"])).standard_normal((4 * n, 4)).astype(np.float32)
+    ea = torch.from_numpy(np.concatenate([fg, g["edge_attr16"]], axis=1)).to(DEV)
+    pairs = np.stack([np.repeat(np.arange(n, dtype=np.int64), 4), g["adj_dst"].astype(np.int64)], 1)
+    ei = torch.from_numpy(pairs).to(DEV).t().contiguous()
+    net = hip_static()
+    plan = GraphPlan(ei, n, n)
+    acts = [torch.from_numpy(g["x"]).to(DEV)[:, 1:].contiguous()]
+    for i in range(3):
+        acts.append(net._eval_layers(acts[-1], n, ea, [plan] * 4, True, only=i).clone())
+    junk = torch.empty(1 << 28, device=DEV)
+    for i, decode in ((2, False), (3, False), (3, True)):
+        first = net._eval_layers(acts[i], n, ea, [plan] * 4, True, only=i, decode=decode).clone()
+        for rep in range(60):
+            junk.add_(1.0)
+            o = net._eval_layers(acts[i], n, ea, [plan] * 4, True, only=i, decode=decode)
+            bad = (o != first).any(1).nonzero().flatten()
+            assert bad.numel() == 0, (i, decode, rep, bad[:8].tolist())
+
+
 # ---- one rank's part of a partitioned scene in one call, the library's RCCL exchange inside it -----------------------------------------------------
 def _self_halo_worker(rank, port, out_dir):
     import torch.distributed as dist
