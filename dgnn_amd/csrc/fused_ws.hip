@@ -42,20 +42,27 @@ template <int RING> struct WsL {
     static constexpr int OFF_BP = RING * WS_SLOT;
     static constexpr int OFF_ROWF = OFF_BP + WS_BP;                 // [RING][32] inverse row scales
     static constexpr int OFF_CST = OFF_ROWF + RING * WS_TILE * 4;   // bias | scale | shift [128]
-    static constexpr int OFF_SC = OFF_CST + 3 * WS_C * 4;           // max |We|, |be|; then ready[RING], done[RING], hcnt, hfree, lcnt
+    static constexpr int OFF_SC = OFF_CST + 3 * WS_C * 4;           // max |We|, |be|; then ready[RING], done[RING], ycnt[2], yfree[2], lcnt[2]
     static constexpr int OFF_DC = OFF_SC + 16 + 2 * RING * 4 + 16 + 16;   // decoder constants: A1 | B1 [64], W3 [2][64], b3 [2] (+2 pad)
-    static constexpr int OFF_PLOG = OFF_DC + (64 + 64 + 128 + 4) * 4;     // partial logits [2 tiles][8 consumers][32 cells][2]
-    static constexpr int OFF_HPART = (OFF_PLOG + 2 * 8 * 32 * 8 + 255) & ~255;   // partial hidden rows [8 consumers][32 cells][64] fp32, 16-byte pieces XOR-swizzled by cell
+    static constexpr int OFF_PLOG = OFF_DC + (64 + 64 + 128 + 4) * 4;     // partial logits [2 tiles][4 hidden blocks][32 cells][2]
+    static constexpr int OFF_YS = OFF_PLOG + 2 * 4 * 32 * 8;              // inverse scales of the parked rows [2 tiles][8 slices][32 cells]
+    static constexpr int OFF_W0 = (OFF_YS + 2 * 8 * 32 * 4 + 255) & ~255; // W0 as A-operand fragments [4 hidden blocks][8 slices][64 lanes] x 16 B (hi x 4 | lo x 4)
+    static constexpr int OFF_YT = OFF_W0 + 4 * 8 * 64 * 16;               // the layer's finished tile as B-operand fragments [2 tiles][8 slices][2 blocks][64 lanes] x 16 B
     static constexpr int SMEM = OFF_SC + 16 + 2 * RING * 4 + 16 + 16;
-    static constexpr int SMEM_DEC = OFF_HPART + 8 * 32 * 64 * 4;
+    static constexpr int SMEM_DEC = OFF_YT + 2 * 8 * 2 * 64 * 16;
 };
 
 // the decoder behind the last conv layer (reference learning/surfaceNetStaticEdgeFilters.py:180-187, applied at :350-351): Linear(128 -> 64) - BatchNorm(eval) -
-// ReLU - Linear(64 -> 2).  In the DEC instantiation the consumers do not store the layer's rows: a lane's 4 finished channels of one cell ARE the B operand
-// of v_mfma_f32_16x16x16_f16 (K = the consumer's 16 channels), so every consumer multiplies its slice by its 64 x 16 block of W0 (resident: 16 VGPRs) in
-// the fp16 two-part form with one power-of-two scale per cell and slice, parks the fp32 partial hidden rows in LDS, and once all eight have (a counter)
-// adds them up in a fixed order for its 8 hidden units, applies BatchNorm / ReLU and W3, and leaves partial logits; consumer 0 adds those eight in a
-// fixed order and stores 8 bytes per cell.  Every sum has one order and touches one cell's values only (sub-ranges and ring parts give the same bits).
+// ReLU - Linear(64 -> 2).  In the DEC instantiation the consumers do not store the layer's rows.  Three stages, each one tile behind the one before it, so
+// that no wavefront ever waits for data another one has only just produced (the first form of this kernel exchanged fp32 partial hidden rows of the SAME
+// tile -- three lock-step meetings of the eight consumers per tile, 1.1 us of a tile's 4.4):
+//   A(t)    consumer s: its 16 finished channels of the 32 cells, one power-of-two scale per cell and slice, split (hi, lo) -- a lane's 4 channels of one
+//           cell ARE a B-operand fragment of v_mfma_f32_16x16x16_f16 -- parked in LDS (16 bytes per lane and row block, linear);
+//   B(t-1)  consumer (hb, b): hidden units 16 hb .. + 15 of cells 16 b .. + 15 = 8 slices x 3 products against W0's fragments (LDS, laid out once per
+//           workgroup), every slice scaled back and added in slice order; BatchNorm / ReLU / W3 over the lane's 4 units, the 4 lanes of a cell added in
+//           one order: partial logits per cell and hidden block;
+//   C(t-2)  consumer 0 adds the four partial logits of a cell in one order and stores 8 bytes per cell.
+// Every sum has one order and touches one cell's values only (sub-ranges and ring parts give the same bits).
 struct WsDec {
     const float* W0;      // [64, 128]
     const float* b0;      // [64]
@@ -70,6 +77,8 @@ typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void st_nt16(float* p, f32x4_t v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(p)); }
 __device__ __forceinline__ uint32_t bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+__device__ unsigned long long ws_dbg[8];     // TIMING PROBE (knobs 512): [producer wait, producer total, consumer wait, consumer total] in s_memtime ticks
 
 template <int RING, bool FLAGS, bool DEC>
 __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid,
@@ -89,19 +98,32 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
     uint32_t* const scbuf = reinterpret_cast<uint32_t*>(ws_smem + L::OFF_SC);
     volatile uint32_t* const ready = reinterpret_cast<volatile uint32_t*>(ws_smem + L::OFF_SC + 16);
     volatile uint32_t* const done = ready + RING;
-    volatile uint32_t* const hcnt = done + RING;          // DEC: +1 per consumer whose partial hidden rows of a tile are parked
-    volatile uint32_t* const hfree = hcnt + 1;            //      +1 per consumer that has read them
-    volatile uint32_t* const lcnt = hcnt + 2;             //      +1 per consumer whose partial logits of a tile are parked
+    // DEC: one counter per buffer (tile parity), like ready / done per ring slot.  A single running counter is NOT enough: a fast consumer's count for the
+    // next tile can stand in for a slow consumer's count of this one wherever nothing else holds the fast one back (the first tiles, the drain)
+    volatile uint32_t* const ycnt = done + RING;          // [2] +1 per consumer whose 16 channels of a finished tile are parked (stage A)
+    volatile uint32_t* const yfree = ycnt + 2;            // [2] +1 per consumer that has read a parked tile (stage B)
+    volatile uint32_t* const lcnt = ycnt + 4;             // [2] +1 per consumer whose partial logits of a tile are parked (stage B)
     float* const dcst = reinterpret_cast<float*>(ws_smem + L::OFF_DC);
     float* const plog = reinterpret_cast<float*>(ws_smem + L::OFF_PLOG);
-    char* const hpart = ws_smem + L::OFF_HPART;
+    float* const ysc = reinterpret_cast<float*>(ws_smem + L::OFF_YS);
+    char* const w0buf = ws_smem + L::OFF_W0;
+    char* const ytile = ws_smem + L::OFF_YT;
     // wait until *ctr >= target (LDS word, wave-uniform): a short sleep between polls keeps the LDS and the issue slots for the working wavefronts
     // The compiler barriers matter: the poll is a volatile load, which orders nothing against the ORDINARY LDS loads behind it -- without the second one
     // the compiler hoisted the consumer's read of a tile's row scales above the poll (a stale scale for one producer's four cells, once in thousands of
     // tiles: caught by tests/test_gpu_parity.py::test_fused_layers_row_level_on_larger_graph) -- nor the ordinary stores in front of it.
+    typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
+    const bool timing = (knobs & 512) != 0;
+    unsigned long long t_wait = 0ull, t_main = 0ull;
+    const unsigned long long t_begin = timing ? __builtin_amdgcn_s_memtime() : 0ull;
     auto wait_for = [&](volatile uint32_t* ctr, uint32_t target) {
         asm volatile("" ::: "memory");
-        while ((int32_t)(__builtin_amdgcn_readfirstlane((int)*ctr) - (int)target) < 0) __builtin_amdgcn_s_sleep(2);
+        const unsigned long long t0_ = timing ? __builtin_amdgcn_s_memtime() : 0ull;
+        // (the poll through an LDS-space pointer = ds_read_b32: the generic pointer compiled to a flat load, whose s_waitcnt vmcnt(0) also drained the
+        // wavefront's gathers in flight)
+        lds_vu32* c3 = (lds_vu32*)ctr;
+        while ((int32_t)(__builtin_amdgcn_readfirstlane((int)*c3) - (int)target) < 0) __builtin_amdgcn_s_sleep(1);
+        if (timing) t_wait += __builtin_amdgcn_s_memtime() - t0_;
         asm volatile("" ::: "memory");
     };
     const int lane = lane_id(), w = wave_id_uniform();
@@ -116,7 +138,7 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
 
     // ---- prologue: power-of-two scale of [We | be], the split filter operand in LDS, the epilogue's per-channel constants
     if (threadIdx.x == 0) scbuf[0] = 0u;
-    if (threadIdx.x < 2 * RING + 4) ready[threadIdx.x] = 0u;
+    if (threadIdx.x < 2 * RING + 8) ready[threadIdx.x] = 0u;
     if constexpr (DEC) {
         for (int n_ = threadIdx.x; n_ < 64; n_ += blockDim.x) {
             const float s1 = dec.scale1 ? dec.scale1[n_] : 1.f, h1 = dec.scale1 ? dec.shift1[n_] : 0.f;
@@ -163,6 +185,49 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
         dst[48] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
     }
 
+    // DEC, stage B of tile t (a PRODUCER wavefront's job, see above): hidden units 16 hb .. + 15 of cells 16 b .. + 15 -- lane (cell n = jcol, tq) ends up with
+    // units 16 hb + 4 tq .. + 3
+    auto stage_b = [&](uint32_t t, int hb, int b) {
+        wait_for(ycnt + (t & 1), 8u * (t / 2 + 1));
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                            // (addresses recomputed per tile, see `key` below)
+        const char* yt = ytile + ((t & 1) << 14) + ((b * 64 + ln) << 4);
+        const char* wp = w0buf + ((hb * 512 + ln) << 4);
+        const float* sp = ysc + (t & 1) * 8 * WS_TILE + 16 * b + (ln & 15);
+        f32x4_t hs = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const uint4 wa = *reinterpret_cast<const uint4*>(wp + (s << 10)), ya = *reinterpret_cast<const uint4*>(yt + (s << 11));
+            const float inv = sp[s * WS_TILE];
+            const f16x4_t w0h = __builtin_bit_cast(f16x4_t, make_uint2(wa.x, wa.y)), w0l = __builtin_bit_cast(f16x4_t, make_uint2(wa.z, wa.w));
+            const f16x4_t yh = __builtin_bit_cast(f16x4_t, make_uint2(ya.x, ya.y)), yl = __builtin_bit_cast(f16x4_t, make_uint2(ya.z, ya.w));
+            f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+            d = __builtin_amdgcn_mfma_f32_16x16x16f16(w0l, yh, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x16f16(w0h, yl, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x16f16(w0h, yh, d, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hs[i] += d[i] * inv;     // slices 0 .. 7 in order (the scale is a power of two: exact)
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) atomicAdd(const_cast<uint32_t*>(yfree + (t & 1)), 1u);
+        const int u0 = 16 * hb + 4 * (ln >> 4);
+        float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float hv = fmaxf(__fmaf_rn(hs[i], dcst[u0 + i], dcst[64 + u0 + i]), 0.f);
+            l0 = __fmaf_rn(hv, dcst[128 + u0 + i], l0);
+            l1 = __fmaf_rn(hv, dcst[192 + u0 + i], l1);
+        }
+        // the cell's 4 lanes (16 apart): (q0 + q1) + (q2 + q3) in every one of them
+        l0 += __shfl_xor(l0, 16);
+        l1 += __shfl_xor(l1, 16);
+        l0 += __shfl_xor(l0, 32);
+        l1 += __shfl_xor(l1, 32);
+        if (ln < 16) *reinterpret_cast<float2*>(plog + (((t & 1) * 4 + hb) * WS_TILE + 16 * b + ln) * 2) = make_float2(l0, l1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) atomicAdd(const_cast<uint32_t*>(lcnt + (t & 1)), 1u);
+    };
+
     if (w >= WS_NP) {
         // =================================================================== CONSUMER: channels [16 cw, 16 cw + 16)
         const int cw = w - WS_NP;
@@ -191,9 +256,8 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
             wh[s] = pack8h(ph);
             wl[s] = pack8h(pl);
         }
-        // DEC: W0[:, 16 cw .. 16 cw + 15] as A-operand fragments of v_mfma_f32_16x16x16_f16: lane (m = jcol, kg = tq) holds hidden unit 16 hb + m, channels
-        // 16 cw + 4 kg .. + 3; one power-of-two scale per consumer
-        f16x4_t w0h[4], w0l[4];
+        // DEC: W0[:, 16 cw .. 16 cw + 15] (slice cw) as A-operand fragments of v_mfma_f32_16x16x16_f16, for everybody: lane (m = jcol, kg = tq) of hidden block hb
+        // holds hidden unit 16 hb + m, channels 16 cw + 4 kg .. + 3; one power-of-two scale per slice
         float inv_sW0 = 1.f;
         if constexpr (DEC) {
             uint32_t m0 = 0u;
@@ -211,37 +275,69 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                 uint32_t ph[2], pl[2];
                 split2h(raw[hb][0] * sW0, raw[hb][1] * sW0, ph[0], pl[0]);
                 split2h(raw[hb][2] * sW0, raw[hb][3] * sW0, ph[1], pl[1]);
-                w0h[hb] = __builtin_bit_cast(f16x4_t, make_uint2(ph[0], ph[1]));
-                w0l[hb] = __builtin_bit_cast(f16x4_t, make_uint2(pl[0], pl[1]));
+                *reinterpret_cast<uint4*>(w0buf + (((hb * 8 + cw) * 64 + lane) << 4)) = make_uint4(ph[0], ph[1], pl[0], pl[1]);
             }
         }
         __syncthreads();   // (the producers' prologue barrier)
+        if (knobs & 64) __builtin_amdgcn_s_setprio(1);
+        if (knobs & 256) __builtin_amdgcn_s_setprio(3);
         const int c0 = 16 * cw + 4 * tq;          // this lane's 4 consecutive output channels
-        for (int64_t it = FLAGS ? 1 : 0; it <= my_n; ++it) {
-            if (it >= 1) {
+        const int64_t n_it = my_n + (DEC ? 2 : 0);       // DEC: stage B runs one tile behind the product, stage C two
+        for (int64_t it = FLAGS ? 1 : 0; it <= n_it; ++it) {
+            if constexpr (DEC) {
+                // C(it - 3): consumer 0 adds the four partial logits of a cell in one order and stores them.  (First in the iteration: the others' B(it - 1)
+                // -- next iteration -- reuses this buffer, and they get there only behind this wavefront's A(it - 1) below.)
+                if (cw == 0 && it >= 3) {
+                    const uint32_t t = (uint32_t)(it - 3);
+                    wait_for(lcnt + (t & 1), 8u * (t / 2 + 1));
+                    if (lane < WS_TILE) {
+                        float s0 = dcst[256], s1 = dcst[257];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float* pq = plog + (((t & 1) * 4 + q) * WS_TILE + lane) * 2;
+                            s0 += pq[0];
+                            s1 += pq[1];
+                        }
+                        const int64_t cell = tile_of(t) * WS_TILE + lane;
+                        if (cell < n_dst) *reinterpret_cast<float2*>(dec.logits + cell * 2) = make_float2(s0, s1);
+                    }
+                }
+            }
+            if (it >= 1 && it <= my_n) {
                 const int sl = (int)((it - 1) % RING);
                 if constexpr (FLAGS) wait_for(ready + sl, (uint32_t)(WS_NP * ((it - 1) / RING + 1)));
+                const unsigned long long tm0_ = timing ? __builtin_amdgcn_s_memtime() : 0ull;
                 const char* tb = ring + sl * WS_SLOT;
                 f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
                 // (the swizzle key passes through an empty asm every tile: left alone, the compiler keeps all 32 loop-invariant read addresses in registers
                 // -- 19 spilled in the decoder-carrying instantiation -- instead of two integer instructions per read)
                 int key = jcol;
                 asm volatile("" : "+v"(key));
-#pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    f16x8 xh[2], xl[2];
+                // ring reads one whole k-step ahead of the products (two register sets).  The scheduling barrier pins that order: left alone, the compiler
+                // sinks every read to just in front of its first use and waits for it on the spot -- sixteen exposed LDS round trips per tile.  (Two steps
+                // ahead = three sets: over the 128-register budget, spills inside the loop, twice the time.)
+                f16x8 xh[2][2], xl[2][2];
+                auto ld_step = [&](int s, int set) {
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
                         const char* rp = tb + (16 * b + jcol) * WS_ROWB;
-                        xh[b] = H8(*reinterpret_cast<const uint4*>(rp + (((4 * s + tq) ^ key) << 4)));
-                        xl[b] = H8(*reinterpret_cast<const uint4*>(rp + (((32 + 4 * s + tq) ^ key) << 4)));
+                        xh[set][b] = H8(*reinterpret_cast<const uint4*>(rp + (((4 * s + tq) ^ key) << 4)));
+                        xl[set][b] = H8(*reinterpret_cast<const uint4*>(rp + (((32 + 4 * s + tq) ^ key) << 4)));
                     }
+                };
+                ld_step(0, 0);
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s], xh[b], acc[b], 0, 0, 0);     // small terms first
+                for (int s = 0; s < 8; ++s) {
+                    const int set = s & 1;
+                    if (s + 1 < 8) ld_step(s + 1, set ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], xl[b], acc[b], 0, 0, 0);
+                    for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s], xh[set][b], acc[b], 0, 0, 0);     // small terms first
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], xh[b], acc[b], 0, 0, 0);
+                    for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], xl[set][b], acc[b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], xh[set][b], acc[b], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 float invr[2];
 #pragma unroll
@@ -251,7 +347,7 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (lane == 0) atomicAdd(const_cast<uint32_t*>(done + sl), 1u);
                 }
-                const int64_t cell0 = tile_of(it - 1) * WS_TILE;
+                if (timing) t_main += __builtin_amdgcn_s_memtime() - tm0_;
                 // (the per-channel constants are re-read from LDS every tile: 12 registers the decoder stage needs)
                 const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(cst + c0), sc = *reinterpret_cast<const f32x4_t*>(cst + WS_C + c0),
                               sh = *reinterpret_cast<const f32x4_t*>(cst + 2 * WS_C + c0);
@@ -266,6 +362,7 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                     }
                 }
                 if constexpr (!DEC) {
+                    const int64_t cell0 = tile_of(it - 1) * WS_TILE;
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
                         const int64_t cell = cell0 + 16 * b + jcol;
@@ -275,10 +372,12 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                         }
                     }
                 } else {
-                    const uint32_t tix = (uint32_t)(it - 1);             // tile counter of this workgroup
-                    // (1) partial hidden rows over this consumer's 16 channels: one scale per cell and slice (the cell's 4 lanes are 16 apart); parked
-                    // block by block -- the previous tile's partials have been read by everybody
-                    wait_for(hfree, 8u * tix);
+                    // A(it - 1): this consumer's 16 channels of the tile, one scale per cell and slice (the cell's 4 lanes are 16 apart), parked as B-operand
+                    // fragments; the buffer's previous tile (two back) has been read by everybody
+                    const uint32_t t = (uint32_t)(it - 1);
+                    wait_for(yfree + (t & 1), 8u * (t / 2));
+                    char* yt = ytile + ((t & 1) << 14) + ((cw * 128 + lane) << 4);
+                    float* ys = ysc + ((t & 1) * 8 + cw) * WS_TILE + jcol;
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
                         const float my = fmaxf(fmaxf(fabsf(yv[b][0]), fabsf(yv[b][1])), fmaxf(fabsf(yv[b][2]), fabsf(yv[b][3])));
@@ -287,81 +386,26 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                         uint32_t ph[2], pl[2];
                         split2h(yv[b][0] * sY, yv[b][1] * sY, ph[0], pl[0]);
                         split2h(yv[b][2] * sY, yv[b][3] * sY, ph[1], pl[1]);
-                        const f16x4_t yh = __builtin_bit_cast(f16x4_t, make_uint2(ph[0], ph[1])), yl = __builtin_bit_cast(f16x4_t, make_uint2(pl[0], pl[1]));
-                        const float inv = inv_sY * inv_sW0;
-                        const int T = 16 * b + key;
-                        char* rp = hpart + ((cw * WS_TILE + T) << 8);        // 64 hidden units = 16 pieces of 16 B, piece (4 hb + kg) at slot piece ^ (T & 15)
-#pragma unroll
-                        for (int hb = 0; hb < 4; ++hb) {
-                            f32x4_t d = {0.f, 0.f, 0.f, 0.f};
-                            d = __builtin_amdgcn_mfma_f32_16x16x16f16(w0l[hb], yh, d, 0, 0, 0);
-                            d = __builtin_amdgcn_mfma_f32_16x16x16f16(w0h[hb], yl, d, 0, 0, 0);
-                            d = __builtin_amdgcn_mfma_f32_16x16x16f16(w0h[hb], yh, d, 0, 0, 0);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) d[i] *= inv;
-                            *reinterpret_cast<f32x4_t*>(rp + (((4 * hb + tq) ^ key) << 4)) = d;
-                        }
+                        *reinterpret_cast<uint4*>(yt + (b << 10)) = make_uint4(ph[0], ph[1], pl[0], pl[1]);
+                        if (tq == 0) ys[16 * b] = inv_sY * inv_sW0;
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (lane == 0) atomicAdd(const_cast<uint32_t*>(hcnt), 1u);
-                    // (2) hidden units [8 cw, 8 cw + 8) of all 32 cells: lane (cell n = lane & 31, rh = lane >> 5) takes units 8 cw + 4 rh .. + 3
-                    wait_for(hcnt, 8u * (tix + 1));
-                    int n_ = lane & 31;
-                    asm volatile("" : "+v"(n_));                            // (addresses recomputed per tile, see `key`)
-                    const int rh = lane >> 5;
-                    f32x4_t hs = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(hpart + ((q * WS_TILE + n_) << 8) + (((2 * cw + rh) ^ (n_ & 15)) << 4));
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) hs[i] += v[i];           // consumers 0 .. 7 in order
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (lane == 0) atomicAdd(const_cast<uint32_t*>(hfree), 1u);
-                    const int u0 = 8 * cw + 4 * rh;
-                    float l0 = 0.f, l1 = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float hv = fmaxf(__fmaf_rn(hs[i], dcst[u0 + i], dcst[64 + u0 + i]), 0.f);
-                        l0 = __fmaf_rn(hv, dcst[128 + u0 + i], l0);
-                        l1 = __fmaf_rn(hv, dcst[192 + u0 + i], l1);
-                    }
-                    uint32_t oa, ob;
-                    swap32_pair(bits(l0), oa, ob);
-                    const float o0 = __builtin_bit_cast(float, oa ^ ob ^ bits(l0));
-                    swap32_pair(bits(l1), oa, ob);
-                    const float o1 = __builtin_bit_cast(float, oa ^ ob ^ bits(l1));
-                    float* pl_ = plog + (((tix & 1) * 8 + cw) * WS_TILE + n_) * 2;
-                    if (rh == 0) {
-                        pl_[0] = l0 + o0;                                    // units 4 rh = 0's first
-                        pl_[1] = l1 + o1;
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (lane == 0) atomicAdd(const_cast<uint32_t*>(lcnt), 1u);
-                    // (3) consumer 0 adds the eight partial logits of a cell in one order and stores them
-                    if (cw == 0) {
-                        wait_for(lcnt, 8u * (tix + 1));
-                        if (lane < WS_TILE) {
-                            float s0 = dcst[256], s1 = dcst[257];
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) {
-                                const float* pq = plog + (((tix & 1) * 8 + q) * WS_TILE + lane) * 2;
-                                s0 += pq[0];
-                                s1 += pq[1];
-                            }
-                            const int64_t cell = cell0 + lane;
-                            if (cell < n_dst) *reinterpret_cast<float2*>(dec.logits + cell * 2) = make_float2(s0, s1);
-                        }
-                    }
+                    if (lane == 0) atomicAdd(const_cast<uint32_t*>(ycnt + (t & 1)), 1u);
                 }
             }
             if constexpr (!FLAGS) tile_barrier();
+        }
+        if (timing && lane == 0) {
+            atomicAdd(&ws_dbg[2], t_wait);
+            atomicAdd(&ws_dbg[4], t_main);
+            atomicAdd(&ws_dbg[3], __builtin_amdgcn_s_memtime() - t_begin);
         }
         return;
     }
 
     // ======================================================================= PRODUCER: group p of 4 cells of every tile
     __syncthreads();   // filter operand and constants in place
+    if (knobs & 128) __builtin_amdgcn_s_setprio(1);
     const int p = w;
     const int P0 = 8 * jcol;                       // the lane's 8 channels
     auto load_rp = [&](int64_t it, int& vb) {
@@ -393,40 +437,54 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
     load_rp(1, vb2);
     load_idx(0, vb1, reg1, vsrc1, veid1);
 
-    for (int64_t it = 0; it < my_n + (FLAGS ? 0 : 1); ++it) {
+    // DEC: this wavefront also runs stage B of tile it - 2 (hidden block p & 3 of row block p >> 2) -- BETWEEN issuing its gathers for tile `it` and using
+    // them: the job fills the gather latency, and its data (the consumers' stage A of tile it - 2) is complete about when the slot the producer is going to
+    // write is handed back anyway.  Two more iterations drain the last two tiles.
+    for (int64_t it = 0; it < my_n + (FLAGS ? (DEC ? 2 : 0) : 1); ++it) {
+        int nv = 0, sl = 0, tl = 0;
+        bool regular = false;
+        f32x4_t xa4, xb4, q0, q1, ra[4], rb_[4];        // the gathered rows (in flight across stage B); read only on the path that loaded them
+        int64_t cell = 0;
         if (it < my_n) {
             const int64_t i0 = tile_of(it) * WS_TILE + 4 * p;
-            const int sl = (int)(it % RING);
-            const int nv = (int)max((int64_t)0, min((int64_t)4, n_dst - i0));
-            const bool regular = reg1;
+            sl = (int)(it % RING);
+            nv = (int)max((int64_t)0, min((int64_t)4, n_dst - i0));
+            regular = reg1;
             const int vsrc = vsrc1, veid = veid1;
             vb1 = vb2;
             load_idx(it + 1, vb1, reg1, vsrc1, veid1);
             load_rp(it + 2, vb2);
             if (nv > 0) {
-                const int tl = tq < nv ? tq : nv - 1;      // a short group at the end of the graph: clamped (duplicated) cells
-                const int64_t cell = i0 + tl;
-                float aout[8], xv[8];
-                {
-                    const float* rp = xdst + cell * ldx + P0;
-                    const f32x4_t a4 = *reinterpret_cast<const f32x4_t*>(rp), b4 = *reinterpret_cast<const f32x4_t*>(rp + 4);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        xv[i] = a4[i];
-                        xv[4 + i] = b4[i];
-                    }
-                }
+                tl = tq < nv ? tq : nv - 1;      // a short group at the end of the graph: clamped (duplicated) cells
+                cell = i0 + tl;
+                const float* rp0 = xdst + cell * ldx + P0;
+                xa4 = *reinterpret_cast<const f32x4_t*>(rp0);
+                xb4 = *reinterpret_cast<const f32x4_t*>(rp0 + 4);
                 if (regular) {
                     const float* er = ea + (int64_t)__shfl(veid, jcol) * lde;
-                    const f32x4_t q0 = *reinterpret_cast<const f32x4_t*>(er + 8 * (tq < 2 ? tq : 2));
-                    const f32x4_t q1 = *reinterpret_cast<const f32x4_t*>(er + 8 * (tq < 1 ? tq : 1) + 4);
-                    f32x4_t ra[4], rb_[4];
+                    q0 = *reinterpret_cast<const f32x4_t*>(er + 8 * (tq < 2 ? tq : 2));
+                    q1 = *reinterpret_cast<const f32x4_t*>(er + 8 * (tq < 1 ? tq : 1) + 4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float* rp = x + (int64_t)__shfl(vsrc, tl * 4 + r) * ldx + P0;
                         ra[r] = *reinterpret_cast<const f32x4_t*>(rp);
                         rb_[r] = *reinterpret_cast<const f32x4_t*>(rp + 4);
                     }
+                }
+            }
+        }
+        if constexpr (DEC) {
+            if (it >= 2) stage_b((uint32_t)(it - 2), p & 3, p >> 2);
+        }
+        if (it < my_n) {
+            if (nv > 0) {
+                float aout[8], xv[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xv[i] = xa4[i];
+                    xv[4 + i] = xb4[i];
+                }
+                if (regular) {
                     float av[8];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -534,9 +592,23 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
         }
         if constexpr (!FLAGS) tile_barrier();
     }
+    if (timing && lane == 0) {
+        atomicAdd(&ws_dbg[0], t_wait);
+        atomicAdd(&ws_dbg[1], __builtin_amdgcn_s_memtime() - t_begin);
+    }
 }
 
 }  // namespace
+
+extern "C" int dgnn_ws_debug_read(unsigned long long* out8, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out8, HIP_SYMBOL(ws_dbg), sizeof(unsigned long long) * 8);
+    if (reset) {
+        unsigned long long z[8] = {};
+        hipMemcpyToSymbol(HIP_SYMBOL(ws_dbg), z, sizeof(z));
+    }
+    return 0;
+}
 
 // 1 = the wave-specialised kernel takes the plain 128 -> 128 layer in the default arithmetic (DGNN_WS=0: k_sage_fused_mfma<128,128> as in rounds 2-4)
 int dgnn_ws_enabled() {
