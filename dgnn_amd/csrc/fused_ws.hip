@@ -12,8 +12,15 @@
 //   8 CONSUMERS  16 output channels each, their [Wj | Wi] rows resident as fp16 (hi, lo) fragments (64 VGPRs): D[channel][cell] on v_mfma_f32_16x16x32_f16
 //                with the weights as the A operand, 48 products per tile; epilogue per lane = one cell x 4 consecutive channels: inverse scales,
 //                bias / BatchNorm / ReLU, one 16-byte non-temporal store;
-//   consumers work on tile t-1 while producers build tile t; ONE s_barrier per tile hands the ring slot over.  No K split, no partial-sum exchange,
-//   no resident weights in the gathering wavefronts.
+//   The ring slots are handed over by LDS counters, no barrier in the loop: `ready[slot]` +1 per producer that has parked its rows of a tile, `done[slot]` +1
+//   per consumer that has read them; every wavefront runs at its own pace, a producer only waits when the slot it is about to write (two tiles back) has
+//   not been drained.  EVERY adder waits for the slot first, the producer groups past the end of the graph included -- a count that lands early can stand
+//   in for a late wavefront's (that race, and the same one in the decoder's counters, are pinned by tests/test_gpu_infer.py::
+//   test_ignatius_layers_repeat_bit_for_bit_with_cold_caches and tests/test_gpu_parity.py::test_last_layer_and_decoder_in_one_launch).  No K split, no
+//   partial-sum exchange, no resident weights in the gathering wavefronts.
+// Where the time goes (a build with s_memtime around the polls, profiles/r05_ws_phases.md): the producers bound the plain launch (they wait 8-12 % of their
+// time, the consumers 35-45 %); a consumer's 48 products take ~2 us of a 3.3 us tile because the two consumers of a SIMD start together and share its
+// matrix pipe with two producers.
 // Arithmetic: the fp16 two-part form (fused_common.h): scaling groups per cell row [a | x_i], per edge, per [We | be], per consumer (its 16 weight rows).
 // A cell's result depends on its own inputs only: destination sub-ranges, ring parts and differently tiled runs agree bit for bit.  Groups of any
 // in-degree other than 4 take a per-lane fp32 path (never on Delaunay scenes).
@@ -34,10 +41,9 @@ constexpr int WS_NP = 8;                     // producer wavefronts (the other 8
 constexpr int WS_ROWB = 1024;                // ring bytes per cell: [hi of a | hi of x | lo of a | lo of x], 128 fp16 each
 constexpr int WS_SLOT = WS_TILE * WS_ROWB;   // 32 KB
 constexpr int WS_BP = 8 * 2 * 48 * 16;       // filter operand [cb < 8][hi | lo][48] x 16 B
-// RING slots of the hand-off: 2 = one s_barrier per tile (producers on tile t, consumers on t - 1, everybody meets once per tile);
-// 4 = no barrier in the loop: per-slot LDS counters -- `ready` (+1 per producer that has parked its rows), `done` (+1 per consumer that has read them) --
-// let every wavefront run at its own pace, a producer only waits for a slot four tiles back to be drained (the barrier form ties all 16 wavefronts
-// to the slowest gather of every tile)
+// RING slots of the hand-off.  FLAGS = false (RING 2 only): one s_barrier per tile instead of the counters (producers on tile t, consumers on t - 1, everybody
+// meets once per tile: ties all 16 wavefronts to the slowest gather of every tile; DGNN_WS_RING=2, kept as the simple form to test against).
+// FLAGS = true: the counters; 2, 3 or 4 slots measure the same (DGNN_WS_RING=22 / 3 / 4), the decoder-carrying launch has LDS for 2.
 template <int RING> struct WsL {
     static constexpr int OFF_BP = RING * WS_SLOT;
     static constexpr int OFF_ROWF = OFF_BP + WS_BP;                 // [RING][32] inverse row scales
@@ -58,9 +64,11 @@ template <int RING> struct WsL {
 // tile -- three lock-step meetings of the eight consumers per tile, 1.1 us of a tile's 4.4):
 //   A(t)    consumer s: its 16 finished channels of the 32 cells, one power-of-two scale per cell and slice, split (hi, lo) -- a lane's 4 channels of one
 //           cell ARE a B-operand fragment of v_mfma_f32_16x16x16_f16 -- parked in LDS (16 bytes per lane and row block, linear);
-//   B(t-1)  consumer (hb, b): hidden units 16 hb .. + 15 of cells 16 b .. + 15 = 8 slices x 3 products against W0's fragments (LDS, laid out once per
+//   B(t-1)  job (hb, b) of 8: hidden units 16 hb .. + 15 of cells 16 b .. + 15 = 8 slices x 3 products against W0's fragments (LDS, laid out once per
 //           workgroup), every slice scaled back and added in slice order; BatchNorm / ReLU / W3 over the lane's 4 units, the 4 lanes of a cell added in
-//           one order: partial logits per cell and hidden block;
+//           one order: partial logits per cell and hidden block.  A tile's 8 jobs go to the 8 wavefronts of ONE role: the consumers on three tiles of
+//           four, the producers -- between issuing a tile's gathers and using them -- on the fourth (measured: producers always 0.54 ms, half 0.507,
+//           three of four 0.493, consumers always 0.525 on one box; the producers are the busier role but have the gather latency to fill);
 //   C(t-2)  consumer 0 adds the four partial logits of a cell in one order and stores 8 bytes per cell.
 // Every sum has one order and touches one cell's values only (sub-ranges and ring parts give the same bits).
 struct WsDec {
@@ -77,8 +85,6 @@ typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void st_nt16(float* p, f32x4_t v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(p)); }
 __device__ __forceinline__ uint32_t bits(float f) { return __builtin_bit_cast(uint32_t, f); }
-
-__device__ unsigned long long ws_dbg[8];     // TIMING PROBE (knobs 512): [producer wait, producer total, consumer wait, consumer total] in s_memtime ticks
 
 template <int RING, bool FLAGS, bool DEC>
 __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid,
@@ -113,17 +119,20 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
     // the compiler hoisted the consumer's read of a tile's row scales above the poll (a stale scale for one producer's four cells, once in thousands of
     // tiles: caught by tests/test_gpu_parity.py::test_fused_layers_row_level_on_larger_graph) -- nor the ordinary stores in front of it.
     typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
-    const bool timing = (knobs & 512) != 0;
-    unsigned long long t_wait = 0ull, t_main = 0ull;
-    const unsigned long long t_begin = timing ? __builtin_amdgcn_s_memtime() : 0ull;
     auto wait_for = [&](volatile uint32_t* ctr, uint32_t target) {
         asm volatile("" ::: "memory");
-        const unsigned long long t0_ = timing ? __builtin_amdgcn_s_memtime() : 0ull;
         // (the poll through an LDS-space pointer = ds_read_b32: the generic pointer compiled to a flat load, whose s_waitcnt vmcnt(0) also drained the
         // wavefront's gathers in flight)
+#ifdef WS_EXP_FLAT_POLL
+        while ((int32_t)(__builtin_amdgcn_readfirstlane((int)*ctr) - (int)target) < 0) __builtin_amdgcn_s_sleep(2);
+#else
         lds_vu32* c3 = (lds_vu32*)ctr;
+#ifdef WS_EXP_SLEEP2
+        while ((int32_t)(__builtin_amdgcn_readfirstlane((int)*c3) - (int)target) < 0) __builtin_amdgcn_s_sleep(2);
+#else
         while ((int32_t)(__builtin_amdgcn_readfirstlane((int)*c3) - (int)target) < 0) __builtin_amdgcn_s_sleep(1);
-        if (timing) t_wait += __builtin_amdgcn_s_memtime() - t0_;
+#endif
+#endif
         asm volatile("" ::: "memory");
     };
     const int lane = lane_id(), w = wave_id_uniform();
@@ -228,6 +237,11 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
         if (lane == 0) atomicAdd(const_cast<uint32_t*>(lcnt + (t & 1)), 1u);
     };
 
+    // who runs stage B of tile t: every wavefront of one role takes one of the tile's 8 jobs.  (knobs bits 4-5: 0 = producers always, 1 = consumers on even
+    // tiles, 2 = consumers on three tiles of four, 3 = consumers always)
+    const int bsel = (knobs >> 4) & 3;
+    auto b_on_consumers = [&](uint32_t t) { return bsel == 0 ? false : bsel == 1 ? (t & 1) == 0 : bsel == 2 ? (t & 3) != 3 : true; };
+
     if (w >= WS_NP) {
         // =================================================================== CONSUMER: channels [16 cw, 16 cw + 16)
         const int cw = w - WS_NP;
@@ -279,8 +293,6 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
             }
         }
         __syncthreads();   // (the producers' prologue barrier)
-        if (knobs & 64) __builtin_amdgcn_s_setprio(1);
-        if (knobs & 256) __builtin_amdgcn_s_setprio(3);
         const int c0 = 16 * cw + 4 * tq;          // this lane's 4 consecutive output channels
         const int64_t n_it = my_n + (DEC ? 2 : 0);       // DEC: stage B runs one tile behind the product, stage C two
         for (int64_t it = FLAGS ? 1 : 0; it <= n_it; ++it) {
@@ -306,7 +318,6 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
             if (it >= 1 && it <= my_n) {
                 const int sl = (int)((it - 1) % RING);
                 if constexpr (FLAGS) wait_for(ready + sl, (uint32_t)(WS_NP * ((it - 1) / RING + 1)));
-                const unsigned long long tm0_ = timing ? __builtin_amdgcn_s_memtime() : 0ull;
                 const char* tb = ring + sl * WS_SLOT;
                 f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
                 // (the swizzle key passes through an empty asm every tile: left alone, the compiler keeps all 32 loop-invariant read addresses in registers
@@ -330,14 +341,18 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                 for (int s = 0; s < 8; ++s) {
                     const int set = s & 1;
                     if (s + 1 < 8) ld_step(s + 1, set ^ 1);
+#ifndef WS_EXP_NO_SCHED
                     __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
                     for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s], xh[set][b], acc[b], 0, 0, 0);     // small terms first
 #pragma unroll
                     for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], xl[set][b], acc[b], 0, 0, 0);
 #pragma unroll
                     for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], xh[set][b], acc[b], 0, 0, 0);
+#ifndef WS_EXP_NO_SCHED
                     __builtin_amdgcn_sched_barrier(0);
+#endif
                 }
                 float invr[2];
 #pragma unroll
@@ -347,7 +362,6 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (lane == 0) atomicAdd(const_cast<uint32_t*>(done + sl), 1u);
                 }
-                if (timing) t_main += __builtin_amdgcn_s_memtime() - tm0_;
                 // (the per-channel constants are re-read from LDS every tile: 12 registers the decoder stage needs)
                 const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(cst + c0), sc = *reinterpret_cast<const f32x4_t*>(cst + WS_C + c0),
                               sh = *reinterpret_cast<const f32x4_t*>(cst + 2 * WS_C + c0);
@@ -393,19 +407,16 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                     if (lane == 0) atomicAdd(const_cast<uint32_t*>(ycnt + (t & 1)), 1u);
                 }
             }
+            if constexpr (DEC) {
+                if (it >= 2 && it <= my_n + 1 && b_on_consumers((uint32_t)(it - 2))) stage_b((uint32_t)(it - 2), cw & 3, cw >> 2);
+            }
             if constexpr (!FLAGS) tile_barrier();
-        }
-        if (timing && lane == 0) {
-            atomicAdd(&ws_dbg[2], t_wait);
-            atomicAdd(&ws_dbg[4], t_main);
-            atomicAdd(&ws_dbg[3], __builtin_amdgcn_s_memtime() - t_begin);
         }
         return;
     }
 
     // ======================================================================= PRODUCER: group p of 4 cells of every tile
     __syncthreads();   // filter operand and constants in place
-    if (knobs & 128) __builtin_amdgcn_s_setprio(1);
     const int p = w;
     const int P0 = 8 * jcol;                       // the lane's 8 channels
     auto load_rp = [&](int64_t it, int& vb) {
@@ -441,43 +452,51 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
     // them: the job fills the gather latency, and its data (the consumers' stage A of tile it - 2) is complete about when the slot the producer is going to
     // write is handed back anyway.  Two more iterations drain the last two tiles.
     for (int64_t it = 0; it < my_n + (FLAGS ? (DEC ? 2 : 0) : 1); ++it) {
-        int nv = 0, sl = 0, tl = 0;
+        int nv = 0, sl = 0, tl = 0, vsrc = 0, veid = 0;
         bool regular = false;
-        f32x4_t xa4, xb4, q0, q1, ra[4], rb_[4];        // the gathered rows (in flight across stage B); read only on the path that loaded them
+        f32x4_t xa4, xb4, q0, q1, ra[4], rb_[4];        // the gathered rows (DEC: in flight across stage B); read only on the path that loaded them
         int64_t cell = 0;
+        auto own_row = [&]() {
+            const float* rp0 = xdst + cell * ldx + P0;
+            xa4 = *reinterpret_cast<const f32x4_t*>(rp0);
+            xb4 = *reinterpret_cast<const f32x4_t*>(rp0 + 4);
+        };
+        auto neighbour_rows = [&]() {
+            const float* er = ea + (int64_t)__shfl(veid, jcol) * lde;
+            q0 = *reinterpret_cast<const f32x4_t*>(er + 8 * (tq < 2 ? tq : 2));
+            q1 = *reinterpret_cast<const f32x4_t*>(er + 8 * (tq < 1 ? tq : 1) + 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* rp = x + (int64_t)__shfl(vsrc, tl * 4 + r) * ldx + P0;
+                ra[r] = *reinterpret_cast<const f32x4_t*>(rp);
+                rb_[r] = *reinterpret_cast<const f32x4_t*>(rp + 4);
+            }
+        };
         if (it < my_n) {
             const int64_t i0 = tile_of(it) * WS_TILE + 4 * p;
             sl = (int)(it % RING);
             nv = (int)max((int64_t)0, min((int64_t)4, n_dst - i0));
             regular = reg1;
-            const int vsrc = vsrc1, veid = veid1;
+            vsrc = vsrc1;
+            veid = veid1;
             vb1 = vb2;
             load_idx(it + 1, vb1, reg1, vsrc1, veid1);
             load_rp(it + 2, vb2);
-            if (nv > 0) {
-                tl = tq < nv ? tq : nv - 1;      // a short group at the end of the graph: clamped (duplicated) cells
-                cell = i0 + tl;
-                const float* rp0 = xdst + cell * ldx + P0;
-                xa4 = *reinterpret_cast<const f32x4_t*>(rp0);
-                xb4 = *reinterpret_cast<const f32x4_t*>(rp0 + 4);
-                if (regular) {
-                    const float* er = ea + (int64_t)__shfl(veid, jcol) * lde;
-                    q0 = *reinterpret_cast<const f32x4_t*>(er + 8 * (tq < 2 ? tq : 2));
-                    q1 = *reinterpret_cast<const f32x4_t*>(er + 8 * (tq < 1 ? tq : 1) + 4);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float* rp = x + (int64_t)__shfl(vsrc, tl * 4 + r) * ldx + P0;
-                        ra[r] = *reinterpret_cast<const f32x4_t*>(rp);
-                        rb_[r] = *reinterpret_cast<const f32x4_t*>(rp + 4);
-                    }
-                }
-            }
+            tl = tq < nv ? tq : nv - 1;      // a short group at the end of the graph: clamped (duplicated) cells
+            cell = i0 + tl;
         }
         if constexpr (DEC) {
-            if (it >= 2) stage_b((uint32_t)(it - 2), p & 3, p >> 2);
+            // (the gathers leave ahead of stage B only in this instantiation: in the plain one the loads and their use stay in ONE basic block -- split, the
+            // plain launch lost 9 %: 0.412 -> 0.450 ms)
+            if (it < my_n && nv > 0) {
+                own_row();
+                if (regular) neighbour_rows();
+            }
+            if (it >= 2 && !b_on_consumers((uint32_t)(it - 2))) stage_b((uint32_t)(it - 2), p & 3, p >> 2);
         }
         if (it < my_n) {
             if (nv > 0) {
+                if constexpr (!DEC) own_row();
                 float aout[8], xv[8];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -485,6 +504,7 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                     xv[4 + i] = xb4[i];
                 }
                 if (regular) {
+                    if constexpr (!DEC) neighbour_rows();
                     float av[8];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -592,23 +612,9 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
         }
         if constexpr (!FLAGS) tile_barrier();
     }
-    if (timing && lane == 0) {
-        atomicAdd(&ws_dbg[0], t_wait);
-        atomicAdd(&ws_dbg[1], __builtin_amdgcn_s_memtime() - t_begin);
-    }
 }
 
 }  // namespace
-
-extern "C" int dgnn_ws_debug_read(unsigned long long* out8, int reset) {
-    hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out8, HIP_SYMBOL(ws_dbg), sizeof(unsigned long long) * 8);
-    if (reset) {
-        unsigned long long z[8] = {};
-        hipMemcpyToSymbol(HIP_SYMBOL(ws_dbg), z, sizeof(z));
-    }
-    return 0;
-}
 
 // 1 = the wave-specialised kernel takes the plain 128 -> 128 layer in the default arithmetic (DGNN_WS=0: k_sage_fused_mfma<128,128> as in rounds 2-4)
 int dgnn_ws_enabled() {
@@ -634,7 +640,7 @@ int dgnn_sage_layer_fused_ws_try(const int32_t* rowptr, const int32_t* src, cons
     int grid = (int)(ntiles < DGNN_NUM_CU ? ntiles : DGNN_NUM_CU);
     if (grid < 1) grid = 1;
     static const int ring = getenv("DGNN_WS_RING") ? atoi(getenv("DGNN_WS_RING")) : 22;          // 2 = one barrier per tile; 22 / 3 / 4 = counters, 2 / 3 / 4 slots (measured: equal)
-    static const int knobs = getenv("DGNN_WS_NT") ? atoi(getenv("DGNN_WS_NT")) : 1;
+    static const int knobs = getenv("DGNN_WS_NT") ? atoi(getenv("DGNN_WS_NT")) : 33;   // 1: non-temporal row stores; bits 4-5: who runs the decoder's stage B (2 = consumers on 3 tiles of 4)
     const WsDec d{W0, b0, scale1, shift1, W3, b3, logits};
 #define DGNN_WS_GO(R_, F_, D_)                                                                                                                              \
     do {                                                                                                                                                    \
