@@ -123,16 +123,8 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
         asm volatile("" ::: "memory");
         // (the poll through an LDS-space pointer = ds_read_b32: the generic pointer compiled to a flat load, whose s_waitcnt vmcnt(0) also drained the
         // wavefront's gathers in flight)
-#ifdef WS_EXP_FLAT_POLL
-        while ((int32_t)(__builtin_amdgcn_readfirstlane((int)*ctr) - (int)target) < 0) __builtin_amdgcn_s_sleep(2);
-#else
         lds_vu32* c3 = (lds_vu32*)ctr;
-#ifdef WS_EXP_SLEEP2
-        while ((int32_t)(__builtin_amdgcn_readfirstlane((int)*c3) - (int)target) < 0) __builtin_amdgcn_s_sleep(2);
-#else
         while ((int32_t)(__builtin_amdgcn_readfirstlane((int)*c3) - (int)target) < 0) __builtin_amdgcn_s_sleep(1);
-#endif
-#endif
         asm volatile("" ::: "memory");
     };
     const int lane = lane_id(), w = wave_id_uniform();
@@ -341,18 +333,14 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                 for (int s = 0; s < 8; ++s) {
                     const int set = s & 1;
                     if (s + 1 < 8) ld_step(s + 1, set ^ 1);
-#ifndef WS_EXP_NO_SCHED
                     __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
                     for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s], xh[set][b], acc[b], 0, 0, 0);     // small terms first
 #pragma unroll
                     for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], xl[set][b], acc[b], 0, 0, 0);
 #pragma unroll
                     for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], xh[set][b], acc[b], 0, 0, 0);
-#ifndef WS_EXP_NO_SCHED
                     __builtin_amdgcn_sched_barrier(0);
-#endif
                 }
                 float invr[2];
 #pragma unroll
