@@ -338,6 +338,14 @@ def main():
         # the timed steps were the first to hold all layers' outputs at once); the W warm-up steps the contract asks for follow as given.
         for _ in range(2):
             step_fn()
+        # ... and the buffers of the per-layer calls an INSTRUMENTED timed step makes (ops.LAYER_HOOK set: the whole-scene call steps aside): left
+        # untouched, the first instrumented step of the timed region paid the first touches (10M tets: mean 37 ms over a 13.7 ms median)
+        ops.LAYER_HOOK = lambda tok, c_in, c_out, n_dst, plain=True: None
+        try:
+            for _ in range(2):
+                step_fn()
+        finally:
+            ops.LAYER_HOOK = None
         torch.cuda.synchronize()
         for _ in range(args.warmup):
             step_fn()

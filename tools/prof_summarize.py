@@ -80,7 +80,7 @@ def get(i, col, dom=None):
 
 def dec_stats():
     """the same counters for the instantiation of the 128 -> 128 layer that also carries the decoder (template argument DEC = true), fp32 only"""
-    dom = "k_sage_fused_mfma<128, 128, 8, 2, 2, 2, t"
+    dom = "k_sage_fused_ws<2, true, true>" if "k_sage_fused_ws" in DOM else "k_sage_fused_mfma<128, 128, 8, 2, 2, 2, t"
     f, wr, du = get(3, "FETCH_SIZE", dom), get(4, "WRITE_SIZE", dom), get(3, "dur_us", dom)
     if not (f and wr is not None and du):
         return None
@@ -93,7 +93,7 @@ def dec_stats():
     if ks:
         rr = d_stats[d_stats["Name"].str.contains(dom, regex=False)]
         tr = float(rr.iloc[0]["AverageNs"]) / 1e3 if len(rr) else None
-    return {"kernel": dom + "rue>", "traffic_bytes_per_launch": (2 * f + wr) * 1024, "fetch_kib": f, "write_kib": wr, "avg_launch_us_profiled": du,
+    return {"kernel": dom if dom.endswith(">") else dom + "rue>", "traffic_bytes_per_launch": (2 * f + wr) * 1024, "fetch_kib": f, "write_kib": wr, "avg_launch_us_profiled": du,
             "avg_launch_us_kernel_trace": tr, "mfma_busy_frac": round(busy / 1024 / cyc, 4), "valu_busy_frac": round(valu * 2 / 1024 / cyc, 4),
             "tcc_hit_rate": round(hit / (hit + miss), 4), "clock_ghz": round(clk, 3), "wait_any_frac": round(wany / wc, 4)}
 
