@@ -1143,8 +1143,8 @@ int dgnn_sage_layer_fused_mfma_try(const int32_t* rowptr, const int32_t* src, co
     const int cin_pad = c_in <= 32 ? 32 : (c_in <= 64 ? 64 : 128);
     const int nb = cin_pad / 16;
     if (c_in % nb != 0 || (c_out != 64 && c_out != 128) || (cin_pad == 128 && c_out != 128)) return DGNN_E_UNSUPPORTED;
-    if (c_in == 128 && c_out == 128 && f16_parts == 2 && prep_mode != 1 && dgnn_ws_enabled()) {
-        // round 5: the plain 128 -> 128 layer in the default arithmetic runs wave-specialised (fused_ws.hip); it derives what it needs from the weights
+    if ((c_in == 128 || c_in == 64) && c_out == 128 && f16_parts == 2 && prep_mode != 1 && dgnn_ws_enabled()) {
+        // round 5: the plain 128 -> 128 and 64 -> 128 layers in the default arithmetic run wave-specialised (fused_ws.hip); it derives what it needs from the weights
         // itself (a prepared buffer is not read)
         const int rc = dgnn_sage_layer_fused_ws_try(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, shift, relu, c_out, out,
                                                     ldo, stream);

@@ -35,18 +35,26 @@ using namespace fused;
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define H8(v) __builtin_bit_cast(f16x8, v)
 
-constexpr int WS_C = 128;                    // channels in and out
+constexpr int WS_C = 128;                    // channels out (and in: CIN = 128, the shipped model's layers 2 and 3; CIN = 64: its layer 1)
 constexpr int WS_TILE = 32;                  // cells per tile
 constexpr int WS_NP = 8;                     // producer wavefronts (the other 8 of the 16 are consumers)
-constexpr int WS_ROWB = 1024;                // ring bytes per cell: [hi of a | hi of x | lo of a | lo of x], 128 fp16 each
-constexpr int WS_SLOT = WS_TILE * WS_ROWB;   // 32 KB
-constexpr int WS_BP = 8 * 2 * 48 * 16;       // filter operand [cb < 8][hi | lo][48] x 16 B
+// per input width CIN: ring bytes per cell = [hi of a | hi of x | lo of a | lo of x], CIN fp16 each (1 KB / 512 B); a ring slot = 32 cells (32 / 16 KB);
+// the filter operand [cb < CIN / 16][hi | lo][48] x 16 B
+template <int CIN> struct WsC {
+    static constexpr int NCH = CIN / 16;        // channels of a cell's rows per producer lane (8 / 4)
+    static constexpr int NV = NCH / 4;          // ... as 16-byte loads
+    static constexpr int KH = CIN / 32;         // k-steps of the dense product per half (a | x_i)
+    static constexpr int PP = CIN / 8;          // 16-byte pieces per quarter of a ring row
+    static constexpr int ROWB = 8 * CIN;
+    static constexpr int SLOT = WS_TILE * ROWB;
+    static constexpr int BP = NCH * 2 * 48 * 16;
+};
 // RING slots of the hand-off.  FLAGS = false (RING 2 only): one s_barrier per tile instead of the counters (producers on tile t, consumers on t - 1, everybody
 // meets once per tile: ties all 16 wavefronts to the slowest gather of every tile; DGNN_WS_RING=2, kept as the simple form to test against).
 // FLAGS = true: the counters; 2, 3 or 4 slots measure the same (DGNN_WS_RING=22 / 3 / 4), the decoder-carrying launch has LDS for 2.
-template <int RING> struct WsL {
-    static constexpr int OFF_BP = RING * WS_SLOT;
-    static constexpr int OFF_ROWF = OFF_BP + WS_BP;                 // [RING][32] inverse row scales
+template <int CIN, int RING> struct WsL {
+    static constexpr int OFF_BP = RING * WsC<CIN>::SLOT;
+    static constexpr int OFF_ROWF = OFF_BP + WsC<CIN>::BP;          // [RING][32] inverse row scales
     static constexpr int OFF_CST = OFF_ROWF + RING * WS_TILE * 4;   // bias | scale | shift [128]
     static constexpr int OFF_SC = OFF_CST + 3 * WS_C * 4;           // max |We|, |be|; then ready[RING], done[RING], ycnt[2], yfree[2], lcnt[2]
     static constexpr int OFF_DC = OFF_SC + 16 + 2 * RING * 4 + 16 + 16;   // decoder constants: A1 | B1 [64], W3 [2][64], b3 [2] (+2 pad)
@@ -86,7 +94,7 @@ typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_nt16(float* p, f32x4_t v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(p)); }
 __device__ __forceinline__ uint32_t bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 
-template <int RING, bool FLAGS, bool DEC>
+template <int CIN, int RING, bool FLAGS, bool DEC>
 __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid,
                                                         int64_t n_dst, const float* __restrict__ x, const float* __restrict__ xdst, int64_t ldx,
                                                         const float* __restrict__ ea, int64_t lde, const float* __restrict__ We, const float* __restrict__ be,
@@ -94,9 +102,12 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                                                         const float* __restrict__ scale, const float* __restrict__ shift, int relu, float* __restrict__ out,
                                                         int64_t ldo, int64_t ntiles, int knobs, WsDec dec) {
     static_assert(!DEC || FLAGS, "the decoder stage hands over by counters");
+    static_assert(CIN == 128 || (CIN == 64 && !DEC), "input widths of the shipped model's 128-wide layers");
+    typedef WsC<CIN> G;
+    constexpr int NCH = G::NCH, NV = G::NV, KH = G::KH, PP = G::PP;
     extern __shared__ __attribute__((aligned(16))) char ws_smem[];
     const bool nt_store = (knobs & 1) != 0;
-    typedef WsL<RING> L;
+    typedef WsL<CIN, RING> L;
     char* const ring = ws_smem;
     char* const bpbuf = ws_smem + L::OFF_BP;
     float* const rowf = reinterpret_cast<float*>(ws_smem + L::OFF_ROWF);
@@ -153,8 +164,8 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
     __syncthreads();
     {
         uint32_t me = 0u;
-        for (int e = threadIdx.x; e < WS_C * FE; e += blockDim.x) me = umax(me, absbits(We[e]));
-        for (int e = threadIdx.x; e < WS_C; e += blockDim.x) me = umax(me, absbits(be[e]));
+        for (int e = threadIdx.x; e < CIN * FE; e += blockDim.x) me = umax(me, absbits(We[e]));
+        for (int e = threadIdx.x; e < CIN; e += blockDim.x) me = umax(me, absbits(be[e]));
         me = wave_umax(me);
         if (lane == 0) atomicMax(&scbuf[0], me);
     }
@@ -166,10 +177,10 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
     __syncthreads();
     float sWe, inv_sWe;
     pow2_scales(scbuf[0], sWe, inv_sWe);
-    // entry (cb, part, g, j): channel c = 8 j + cb, k = 8 g .. 8 g + 7 (g < 3: attributes 0..19, the bias at k = 20, zeros)
-    for (int e = threadIdx.x; e < 8 * 48; e += blockDim.x) {
+    // entry (cb, part, g, j): channel c = NCH j + cb, k = 8 g .. 8 g + 7 (g < 3: attributes 0..19, the bias at k = 20, zeros)
+    for (int e = threadIdx.x; e < NCH * 48; e += blockDim.x) {
         const int cb = e / 48, gj = e - cb * 48, g = gj >> 4, j = gj & 15;
-        const int c = 8 * j + cb;
+        const int c = NCH * j + cb;
         uint32_t ph[4], pl[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -237,22 +248,22 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
     if (w >= WS_NP) {
         // =================================================================== CONSUMER: channels [16 cw, 16 cw + 16)
         const int cw = w - WS_NP;
-        // resident weights: lane (m = jcol: channel 16 cw + m, g = tq) holds K index 32 s + 8 g + i of k-step s: s < 4 -> Wj (the mean half), else Wi
+        // resident weights: lane (m = jcol: channel 16 cw + m, g = tq) holds K index 32 s + 8 g + i of k-step s: s < KH -> Wj (the mean half), else Wi
         const int col = 16 * cw + jcol;
         uint32_t mw = 0u;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const float* wr = (s < 4 ? Wj : Wi) + (int64_t)col * WS_C + 32 * (s & 3) + 8 * tq;
+        for (int s = 0; s < 2 * KH; ++s) {
+            const float* wr = (s < KH ? Wj : Wi) + (int64_t)col * CIN + 32 * (s % KH) + 8 * tq;
             const f32x4_t r0 = *reinterpret_cast<const f32x4_t*>(wr), r1 = *reinterpret_cast<const f32x4_t*>(wr + 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) mw = umax(mw, umax(absbits(r0[i]), absbits(r1[i])));
         }
         float sW, inv_sW;
         pow2_scales(wave_umax(mw), sW, inv_sW);     // one scale per consumer (its 16 weight rows)
-        f16x8 wh[8], wl[8];
+        f16x8 wh[2 * KH], wl[2 * KH];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const float* wr = (s < 4 ? Wj : Wi) + (int64_t)col * WS_C + 32 * (s & 3) + 8 * tq;
+        for (int s = 0; s < 2 * KH; ++s) {
+            const float* wr = (s < KH ? Wj : Wi) + (int64_t)col * CIN + 32 * (s % KH) + 8 * tq;
             const f32x4_t r0 = *reinterpret_cast<const f32x4_t*>(wr), r1 = *reinterpret_cast<const f32x4_t*>(wr + 4);
             uint32_t ph[4], pl[4];
             split2h(r0[0] * sW, r0[1] * sW, ph[0], pl[0]);
@@ -310,7 +321,7 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
             if (it >= 1 && it <= my_n) {
                 const int sl = (int)((it - 1) % RING);
                 if constexpr (FLAGS) wait_for(ready + sl, (uint32_t)(WS_NP * ((it - 1) / RING + 1)));
-                const char* tb = ring + sl * WS_SLOT;
+                const char* tb = ring + sl * G::SLOT;
                 f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
                 // (the swizzle key passes through an empty asm every tile: left alone, the compiler keeps all 32 loop-invariant read addresses in registers
                 // -- 19 spilled in the decoder-carrying instantiation -- instead of two integer instructions per read)
@@ -323,16 +334,16 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                 auto ld_step = [&](int s, int set) {
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
-                        const char* rp = tb + (16 * b + jcol) * WS_ROWB;
+                        const char* rp = tb + (16 * b + jcol) * G::ROWB;
                         xh[set][b] = H8(*reinterpret_cast<const uint4*>(rp + (((4 * s + tq) ^ key) << 4)));
-                        xl[set][b] = H8(*reinterpret_cast<const uint4*>(rp + (((32 + 4 * s + tq) ^ key) << 4)));
+                        xl[set][b] = H8(*reinterpret_cast<const uint4*>(rp + (((2 * PP + 4 * s + tq) ^ key) << 4)));
                     }
                 };
                 ld_step(0, 0);
 #pragma unroll
-                for (int s = 0; s < 8; ++s) {
+                for (int s = 0; s < 2 * KH; ++s) {
                     const int set = s & 1;
-                    if (s + 1 < 8) ld_step(s + 1, set ^ 1);
+                    if (s + 1 < 2 * KH) ld_step(s + 1, set ^ 1);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s], xh[set][b], acc[b], 0, 0, 0);     // small terms first
@@ -406,7 +417,7 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
     // ======================================================================= PRODUCER: group p of 4 cells of every tile
     __syncthreads();   // filter operand and constants in place
     const int p = w;
-    const int P0 = 8 * jcol;                       // the lane's 8 channels
+    const int P0 = NCH * jcol;                     // the lane's NCH channels
     auto load_rp = [&](int64_t it, int& vb) {
         if (it < my_n) {
             const int64_t i0 = tile_of(it) * WS_TILE + 4 * p;
@@ -442,12 +453,12 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
     for (int64_t it = 0; it < my_n + (FLAGS ? (DEC ? 2 : 0) : 1); ++it) {
         int nv = 0, sl = 0, tl = 0, vsrc = 0, veid = 0;
         bool regular = false;
-        f32x4_t xa4, xb4, q0, q1, ra[4], rb_[4];        // the gathered rows (DEC: in flight across stage B); read only on the path that loaded them
+        f32x4_t xo[NV], q0, q1, rr[4][NV];              // the gathered rows (DEC: in flight across stage B); read only on the path that loaded them
         int64_t cell = 0;
         auto own_row = [&]() {
             const float* rp0 = xdst + cell * ldx + P0;
-            xa4 = *reinterpret_cast<const f32x4_t*>(rp0);
-            xb4 = *reinterpret_cast<const f32x4_t*>(rp0 + 4);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) xo[v] = *reinterpret_cast<const f32x4_t*>(rp0 + 4 * v);
         };
         auto neighbour_rows = [&]() {
             const float* er = ea + (int64_t)__shfl(veid, jcol) * lde;
@@ -456,8 +467,8 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float* rp = x + (int64_t)__shfl(vsrc, tl * 4 + r) * ldx + P0;
-                ra[r] = *reinterpret_cast<const f32x4_t*>(rp);
-                rb_[r] = *reinterpret_cast<const f32x4_t*>(rp + 4);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) rr[r][v] = *reinterpret_cast<const f32x4_t*>(rp + 4 * v);
             }
         };
         if (it < my_n) {
@@ -485,11 +496,11 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
         if (it < my_n) {
             if (nv > 0) {
                 if constexpr (!DEC) own_row();
-                float aout[8], xv[8];
+                float aout[NCH], xv[NCH];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    xv[i] = xa4[i];
-                    xv[4 + i] = xb4[i];
+                for (int v = 0; v < NV; ++v) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) xv[4 * v + i] = xo[v][i];
                 }
                 if (regular) {
                     if constexpr (!DEC) neighbour_rows();
@@ -513,7 +524,7 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                     for (int r = 0; r < 4; ++r) inv_e[r] = __shfl(inv_sA, 4 * tq + r);
                     const f16x8 ah = pack8h(ph), al = pack8h(pl);
 #pragma unroll
-                    for (int c4 = 0; c4 < 8; c4 += 2) {
+                    for (int c4 = 0; c4 < NCH; c4 += 2) {
                         f16x8 bh[2], bl[2];
                         f32x4_t d[2];
 #pragma unroll
@@ -534,23 +545,23 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                             const int c8 = c4 + u;
 #pragma unroll
                             for (int r = 0; r < 4; ++r) d[u][r] *= inv_e[r];     // exact: powers of two
-                            float a = __fmul_rn((c8 < 4 ? ra[0][c8 & 3] : rb_[0][c8 & 3]), d[u][0]);
+                            float a = __fmul_rn(rr[0][c8 >> 2][c8 & 3], d[u][0]);
 #pragma unroll
-                            for (int r = 1; r < 4; ++r) a = __fmaf_rn((c8 < 4 ? ra[r][c8 & 3] : rb_[r][c8 & 3]), d[u][r], a);
+                            for (int r = 1; r < 4; ++r) a = __fmaf_rn(rr[r][c8 >> 2][c8 & 3], d[u][r], a);
                             aout[c8] = a * (0.25f * inv_sWe);
                         }
                     }
                 } else {
                     // generic path (a group with any in-degree other than 4): plain fp32 per lane, one edge at a time (never on Delaunay scenes)
 #pragma unroll
-                    for (int cb = 0; cb < 8; ++cb) aout[cb] = 0.f;
+                    for (int cb = 0; cb < NCH; ++cb) aout[cb] = 0.f;
                     if (tq < nv) {
                         const int b = rowptr[cell], e_end = rowptr[cell + 1];
                         for (int k = b; k < e_end; ++k) {
                             const int s_ = src[k];
                             const float* ar = ea + (int64_t)(eid ? eid[k] : k) * lde;
 #pragma unroll 1
-                            for (int cb = 0; cb < 8; ++cb) {
+                            for (int cb = 0; cb < NCH; ++cb) {
                                 const int c = P0 + cb;
                                 float pf = be[c];
                                 for (int f = 0; f < FE; ++f) pf = __fmaf_rn(We[(int64_t)c * FE + f], ar[f], pf);
@@ -559,13 +570,13 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                         }
                         const float cnt = (float)max(e_end - b, 1);
 #pragma unroll
-                        for (int cb = 0; cb < 8; ++cb) aout[cb] = __fdiv_rn(aout[cb], cnt);
+                        for (int cb = 0; cb < NCH; ++cb) aout[cb] = __fdiv_rn(aout[cb], cnt);
                     }
                 }
                 // the [mean | own] row: one power-of-two scale (its 16 lanes), split, parked in the ring slot of this tile
                 float ma = 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; i += 2) {
+                for (int i = 0; i < NCH; i += 2) {
                     ma = fmaxf(fmaxf(ma, fabsf(aout[i])), fabsf(aout[i + 1]));
                     ma = fmaxf(fmaxf(ma, fabsf(xv[i])), fabsf(xv[i + 1]));
                 }
@@ -574,18 +585,28 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                 const int T = 4 * p + tq;
                 if constexpr (FLAGS) wait_for(done + sl, (uint32_t)(8 * (it / RING)));      // the slot's previous tile has been read by all 8 consumers
                 if (jcol == 0) rowf[sl * WS_TILE + T] = inv_;
-                uint32_t ah_[4], al_[4], xh_[4], xl_[4];
+                uint32_t ah_[NCH / 2], al_[NCH / 2], xh_[NCH / 2], xl_[NCH / 2];
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
+                for (int d = 0; d < NCH / 2; ++d) {
                     split2h(aout[2 * d] * s_, aout[2 * d + 1] * s_, ah_[d], al_[d]);
                     split2h(xv[2 * d] * s_, xv[2 * d + 1] * s_, xh_[d], xl_[d]);
                 }
-                char* rowp = ring + sl * WS_SLOT + T * WS_ROWB;
+                char* rowp = ring + sl * G::SLOT + T * G::ROWB;
                 const int key = T & 15;
-                *reinterpret_cast<uint4*>(rowp + ((jcol ^ key) << 4)) = make_uint4(ah_[0], ah_[1], ah_[2], ah_[3]);
-                *reinterpret_cast<uint4*>(rowp + (((16 + jcol) ^ key) << 4)) = make_uint4(xh_[0], xh_[1], xh_[2], xh_[3]);
-                *reinterpret_cast<uint4*>(rowp + (((32 + jcol) ^ key) << 4)) = make_uint4(al_[0], al_[1], al_[2], al_[3]);
-                *reinterpret_cast<uint4*>(rowp + (((48 + jcol) ^ key) << 4)) = make_uint4(xl_[0], xl_[1], xl_[2], xl_[3]);
+                if constexpr (NCH == 8) {
+                    // the lane's 8 channels = one 16-byte piece of each quarter
+                    *reinterpret_cast<uint4*>(rowp + ((jcol ^ key) << 4)) = make_uint4(ah_[0], ah_[1], ah_[2], ah_[3]);
+                    *reinterpret_cast<uint4*>(rowp + (((PP + jcol) ^ key) << 4)) = make_uint4(xh_[0], xh_[1], xh_[2], xh_[3]);
+                    *reinterpret_cast<uint4*>(rowp + (((2 * PP + jcol) ^ key) << 4)) = make_uint4(al_[0], al_[1], al_[2], al_[3]);
+                    *reinterpret_cast<uint4*>(rowp + (((3 * PP + jcol) ^ key) << 4)) = make_uint4(xl_[0], xl_[1], xl_[2], xl_[3]);
+                } else {
+                    // the lane's 4 channels = half a piece: lanes 2 i, 2 i + 1 fill piece i of each quarter
+                    const int pc = jcol >> 1, half = (jcol & 1) << 3;
+                    *reinterpret_cast<uint2*>(rowp + ((pc ^ key) << 4) + half) = make_uint2(ah_[0], ah_[1]);
+                    *reinterpret_cast<uint2*>(rowp + (((PP + pc) ^ key) << 4) + half) = make_uint2(xh_[0], xh_[1]);
+                    *reinterpret_cast<uint2*>(rowp + (((2 * PP + pc) ^ key) << 4) + half) = make_uint2(al_[0], al_[1]);
+                    *reinterpret_cast<uint2*>(rowp + (((3 * PP + pc) ^ key) << 4) + half) = make_uint2(xl_[0], xl_[1]);
+                }
             } else if constexpr (FLAGS) {
                 // a group past the end of the graph parks nothing, but its count must not land in `ready` while the slot's PREVIOUS tile is still being
                 // produced: the consumers would take seven real producers plus this one for eight and read a late producer's rows before they are written
@@ -620,29 +641,35 @@ int dgnn_sage_layer_fused_ws_try(const int32_t* rowptr, const int32_t* src, cons
                                  const float* scale, const float* shift, int relu, int c_out, float* out, int64_t ldo, hipStream_t stream, const float* W0,
                                  const float* b0, const float* scale1, const float* shift1, const float* W3, const float* b3, float* logits) {
     const bool dec = W0 != nullptr;
-    if (c_in != WS_C || c_out != WS_C || lde != FE || ldx % 4 != 0 || (!dec && ldo % 4 != 0) ||
+    if ((c_in != WS_C && !(c_in == 64 && !dec)) || c_out != WS_C || lde != FE || ldx % 4 != 0 || (!dec && ldo % 4 != 0) ||
         ((((uintptr_t)x_src | (uintptr_t)x_dst | (uintptr_t)edge_attr | (uintptr_t)(dec ? nullptr : out) | (uintptr_t)Wj | (uintptr_t)Wi | (uintptr_t)W0) % 16) != 0) ||
         (dec && ((uintptr_t)logits % 8) != 0))
         return DGNN_E_UNSUPPORTED;
+    static const int ws64 = getenv("DGNN_WS_64") ? atoi(getenv("DGNN_WS_64")) : 1;     // 0: the 64 -> 128 layer stays on the two-phase kernel
+    if (c_in == 64 && !ws64) return DGNN_E_UNSUPPORTED;
     const int64_t ntiles = dgnn_cdiv(n_dst, WS_TILE);
     int grid = (int)(ntiles < DGNN_NUM_CU ? ntiles : DGNN_NUM_CU);
     if (grid < 1) grid = 1;
     static const int ring = getenv("DGNN_WS_RING") ? atoi(getenv("DGNN_WS_RING")) : 22;          // 2 = one barrier per tile; 22 / 3 / 4 = counters, 2 / 3 / 4 slots (measured: equal)
     static const int knobs = getenv("DGNN_WS_NT") ? atoi(getenv("DGNN_WS_NT")) : 33;   // 1: non-temporal row stores; bits 4-5: who runs the decoder's stage B (2 = consumers on 3 tiles of 4)
     const WsDec d{W0, b0, scale1, shift1, W3, b3, logits};
-#define DGNN_WS_GO(R_, F_, D_)                                                                                                                              \
+#define DGNN_WS_GO(C_, R_, F_, D_)                                                                                                                          \
     do {                                                                                                                                                    \
         static bool attr_[DGNN_MAX_DEVICES] = {};                                                                                                           \
-        const size_t sm_ = D_ ? WsL<R_>::SMEM_DEC : WsL<R_>::SMEM;                                                                                          \
-        dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_ws<R_, F_, D_>), sm_, attr_);                                                    \
-        hipLaunchKernelGGL((k_sage_fused_ws<R_, F_, D_>), dim3(grid), dim3(1024), sm_, stream, rowptr, src, eid, n_dst, x_src, x_dst, ldx, edge_attr, lde, We, be, \
-                           Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles, knobs, d);                                                                     \
+        const size_t sm_ = D_ ? WsL<C_, R_>::SMEM_DEC : WsL<C_, R_>::SMEM;                                                                                  \
+        dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_ws<C_, R_, F_, D_>), sm_, attr_);                                                \
+        hipLaunchKernelGGL((k_sage_fused_ws<C_, R_, F_, D_>), dim3(grid), dim3(1024), sm_, stream, rowptr, src, eid, n_dst, x_src, x_dst, ldx, edge_attr, lde, We, \
+                           be, Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles, knobs, d);                                                                 \
     } while (0)
-    if (dec) DGNN_WS_GO(2, true, true);
-    else if (ring == 2) DGNN_WS_GO(2, false, false);
-    else if (ring == 3) DGNN_WS_GO(3, true, false);
-    else if (ring == 4) DGNN_WS_GO(4, true, false);
-    else DGNN_WS_GO(2, true, false);
+    if (c_in == 64) {
+        if (ring == 2) DGNN_WS_GO(64, 2, false, false);
+        else if (ring == 22) DGNN_WS_GO(64, 2, true, false);
+        else DGNN_WS_GO(64, 4, true, false);          // (16 KB slots: four of them by default)
+    } else if (dec) DGNN_WS_GO(128, 2, true, true);
+    else if (ring == 2) DGNN_WS_GO(128, 2, false, false);
+    else if (ring == 3) DGNN_WS_GO(128, 3, true, false);
+    else if (ring == 4) DGNN_WS_GO(128, 4, true, false);
+    else DGNN_WS_GO(128, 2, true, false);
 #undef DGNN_WS_GO
     return dgnn_check_launch(dec ? "sage_layer_fused_decoder_fwd(wave-specialised)" : "sage_layer_fused_fwd(wave-specialised)");
 }

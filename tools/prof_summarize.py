@@ -80,7 +80,7 @@ def get(i, col, dom=None):
 
 def dec_stats():
     """the same counters for the instantiation of the 128 -> 128 layer that also carries the decoder (template argument DEC = true), fp32 only"""
-    dom = "k_sage_fused_ws<2, true, true>" if "k_sage_fused_ws" in DOM else "k_sage_fused_mfma<128, 128, 8, 2, 2, 2, t"
+    dom = "k_sage_fused_ws<128, 2, true, true>" if "k_sage_fused_ws" in DOM else "k_sage_fused_mfma<128, 128, 8, 2, 2, 2, t"
     f, wr, du = get(3, "FETCH_SIZE", dom), get(4, "WRITE_SIZE", dom), get(3, "dur_us", dom)
     if not (f and wr is not None and du):
         return None
