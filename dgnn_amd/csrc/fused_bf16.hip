@@ -863,6 +863,10 @@ extern "C" int dgnn_cast_bf16_to_f32(const uint16_t* in, int64_t ld_in, int64_t 
     return dgnn_check_launch("cast_bf16_to_f32");
 }
 
+int dgnn_sage_layer_fused_ws16_try(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const uint16_t* x_src, const uint16_t* x_dst,
+                                   int64_t ldx, int c_in, const float* edge_attr, int64_t lde, const float* We, const float* be, const float* Wj, const float* bj,
+                                   const float* Wi, const float* scale, const float* shift, int relu, int c_out, uint16_t* out, int64_t ldo, hipStream_t stream);   // fused_ws.hip
+
 extern "C" int dgnn_sage_layer_fused_fwd_bf16(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst,
                                               const void* x_src, int x_f32, const void* x_dst, int64_t ldx, int c_in, const float* edge_attr,
                                               int64_t lde, int f_e, const float* We, const float* be, const float* Wj, const float* bj,
@@ -897,6 +901,12 @@ extern "C" int dgnn_sage_layer_fused_fwd_bf16(const int32_t* rowptr, const int32
     DGNN_REQUIRE(!ub_out || relu, DGNN_E_INVALID, "sage_layer_fused_fwd_bf16: unsigned output rows need relu (values >= 0)");
     DGNN_REQUIRE(x_f32 ? !ub_in : ub_in == ub_out, DGNN_E_UNSUPPORTED, "sage_layer_fused_fwd_bf16: a layer on bf16 rows keeps the row format (in == out)");
     const bool ub = ub_out;
+    if (ub && ub_in && !x_f32 && c_out == 128 && (c_in == 128 || c_in == 64)) {
+        // round 5: the wave-specialised kernel (fused_ws.hip) reads and writes unsigned 16-bit rows too (DGNN_WS=0 / DGNN_WS_16=0: the kernels below)
+        const int rc = dgnn_sage_layer_fused_ws16_try(rowptr, src, eid, n_dst, static_cast<const uint16_t*>(x_src), static_cast<const uint16_t*>(x_dst), ldx, c_in,
+                                                      edge_attr, lde, We, be, Wj, bj, Wi, scale, shift, relu, c_out, out, ldo, stream);
+        if (rc != DGNN_E_UNSUPPORTED) return rc;
+    }
 #define GOB(CP, CO, OCC)                                                                                                                  \
     do {                                                                                                                                  \
         if (ub)                                                                                                                           \

@@ -92,9 +92,18 @@ typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 
 
 __device__ __forceinline__ void st_nt16(float* p, f32x4_t v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(p)); }
+// IO16: the rows in HBM are the UNSIGNED 16-bit rows of the bf16-storage chain (fused_bf16.hip "UB": value = bits << 15 -- 8 exponent and 8 explicit
+// mantissa bits of a value that is never negative, written behind a ReLU; round to nearest even on bit 15 of the fp32 pattern)
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float ub16_lo(uint32_t u) { return __builtin_fabsf(__builtin_bit_cast(float, u << 15)); }
+__device__ __forceinline__ float ub16_hi(uint32_t u) { return __builtin_bit_cast(float, (u >> 16) << 15); }
+__device__ __forceinline__ uint32_t ub16_enc(float v) {
+    const uint32_t b = __builtin_bit_cast(uint32_t, v) & 0x7FFFFFFFu;
+    return (b + 0x3FFFu + ((b >> 15) & 1u)) >> 15;
+}
 __device__ __forceinline__ uint32_t bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 
-template <int CIN, int RING, bool FLAGS, bool DEC>
+template <int CIN, int RING, bool FLAGS, bool DEC, bool IO16 = false>
 __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid,
                                                         int64_t n_dst, const float* __restrict__ x, const float* __restrict__ xdst, int64_t ldx,
                                                         const float* __restrict__ ea, int64_t lde, const float* __restrict__ We, const float* __restrict__ be,
@@ -103,6 +112,11 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                                                         int64_t ldo, int64_t ntiles, int knobs, WsDec dec) {
     static_assert(!DEC || FLAGS, "the decoder stage hands over by counters");
     static_assert(CIN == 128 || (CIN == 64 && !DEC), "input widths of the shipped model's 128-wide layers");
+    static_assert(!IO16 || !DEC, "the decoder-carrying launch of the bf16-storage chain stays with fused_bf16.hip");
+    // IO16: x / xdst / out are uint16_t rows (ldx / ldo in elements of that type)
+    const uint16_t* const x16 = reinterpret_cast<const uint16_t*>(x);
+    const uint16_t* const xdst16 = reinterpret_cast<const uint16_t*>(xdst);
+    uint16_t* const out16 = reinterpret_cast<uint16_t*>(out);
     typedef WsC<CIN> G;
     constexpr int NCH = G::NCH, NV = G::NV, KH = G::KH, PP = G::PP;
     extern __shared__ __attribute__((aligned(16))) char ws_smem[];
@@ -380,8 +394,14 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                     for (int b = 0; b < 2; ++b) {
                         const int64_t cell = cell0 + 16 * b + jcol;
                         if (cell < n_dst) {
-                            if (nt_store) st_nt16(out + cell * ldo + c0, yv[b]);
-                            else *reinterpret_cast<f32x4_t*>(out + cell * ldo + c0) = yv[b];
+                            if constexpr (IO16) {
+                                const u32x2_t pk = {ub16_enc(yv[b][0]) | (ub16_enc(yv[b][1]) << 16), ub16_enc(yv[b][2]) | (ub16_enc(yv[b][3]) << 16)};
+                                if (nt_store) __builtin_nontemporal_store(pk, reinterpret_cast<u32x2_t*>(out16 + cell * ldo + c0));
+                                else *reinterpret_cast<u32x2_t*>(out16 + cell * ldo + c0) = pk;
+                            } else {
+                                if (nt_store) st_nt16(out + cell * ldo + c0, yv[b]);
+                                else *reinterpret_cast<f32x4_t*>(out + cell * ldo + c0) = yv[b];
+                            }
                         }
                     }
                 } else {
@@ -454,11 +474,23 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
         int nv = 0, sl = 0, tl = 0, vsrc = 0, veid = 0;
         bool regular = false;
         f32x4_t xo[NV], q0, q1, rr[4][NV];              // the gathered rows (DEC: in flight across stage B); read only on the path that loaded them
+        uint32_t xo16[NCH / 2], rr16[4][NCH / 2];       // IO16: the same rows as packed pairs of 16-bit values, decoded where they are used
         int64_t cell = 0;
         auto own_row = [&]() {
-            const float* rp0 = xdst + cell * ldx + P0;
+            if constexpr (IO16) {
+                const uint16_t* rp0 = xdst16 + cell * ldx + P0;
+                if constexpr (NCH == 8) {
+                    const uint4 u = *reinterpret_cast<const uint4*>(rp0);
+                    xo16[0] = u.x, xo16[1] = u.y, xo16[2] = u.z, xo16[3] = u.w;
+                } else {
+                    const uint2 u = *reinterpret_cast<const uint2*>(rp0);
+                    xo16[0] = u.x, xo16[1] = u.y;
+                }
+            } else {
+                const float* rp0 = xdst + cell * ldx + P0;
 #pragma unroll
-            for (int v = 0; v < NV; ++v) xo[v] = *reinterpret_cast<const f32x4_t*>(rp0 + 4 * v);
+                for (int v = 0; v < NV; ++v) xo[v] = *reinterpret_cast<const f32x4_t*>(rp0 + 4 * v);
+            }
         };
         auto neighbour_rows = [&]() {
             const float* er = ea + (int64_t)__shfl(veid, jcol) * lde;
@@ -466,9 +498,20 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
             q1 = *reinterpret_cast<const f32x4_t*>(er + 8 * (tq < 1 ? tq : 1) + 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float* rp = x + (int64_t)__shfl(vsrc, tl * 4 + r) * ldx + P0;
+                if constexpr (IO16) {
+                    const uint16_t* rp = x16 + (int64_t)__shfl(vsrc, tl * 4 + r) * ldx + P0;
+                    if constexpr (NCH == 8) {
+                        const uint4 u = *reinterpret_cast<const uint4*>(rp);
+                        rr16[r][0] = u.x, rr16[r][1] = u.y, rr16[r][2] = u.z, rr16[r][3] = u.w;
+                    } else {
+                        const uint2 u = *reinterpret_cast<const uint2*>(rp);
+                        rr16[r][0] = u.x, rr16[r][1] = u.y;
+                    }
+                } else {
+                    const float* rp = x + (int64_t)__shfl(vsrc, tl * 4 + r) * ldx + P0;
 #pragma unroll
-                for (int v = 0; v < NV; ++v) rr[r][v] = *reinterpret_cast<const f32x4_t*>(rp + 4 * v);
+                    for (int v = 0; v < NV; ++v) rr[r][v] = *reinterpret_cast<const f32x4_t*>(rp + 4 * v);
+                }
             }
         };
         if (it < my_n) {
@@ -500,7 +543,10 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) xv[4 * v + i] = xo[v][i];
+                    for (int i = 0; i < 4; ++i) {
+                        if constexpr (IO16) xv[4 * v + i] = (i & 1) ? ub16_hi(xo16[2 * v + (i >> 1)]) : ub16_lo(xo16[2 * v + (i >> 1)]);
+                        else xv[4 * v + i] = xo[v][i];
+                    }
                 }
                 if (regular) {
                     if constexpr (!DEC) neighbour_rows();
@@ -545,9 +591,13 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                             const int c8 = c4 + u;
 #pragma unroll
                             for (int r = 0; r < 4; ++r) d[u][r] *= inv_e[r];     // exact: powers of two
-                            float a = __fmul_rn(rr[0][c8 >> 2][c8 & 3], d[u][0]);
+                            auto nb_ = [&](int r) {
+                                if constexpr (IO16) return (c8 & 1) ? ub16_hi(rr16[r][c8 >> 1]) : ub16_lo(rr16[r][c8 >> 1]);
+                                else return rr[r][c8 >> 2][c8 & 3];
+                            };
+                            float a = __fmul_rn(nb_(0), d[u][0]);
 #pragma unroll
-                            for (int r = 1; r < 4; ++r) a = __fmaf_rn(rr[r][c8 >> 2][c8 & 3], d[u][r], a);
+                            for (int r = 1; r < 4; ++r) a = __fmaf_rn(nb_(r), d[u][r], a);
                             aout[c8] = a * (0.25f * inv_sWe);
                         }
                     }
@@ -565,7 +615,8 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                                 const int c = P0 + cb;
                                 float pf = be[c];
                                 for (int f = 0; f < FE; ++f) pf = __fmaf_rn(We[(int64_t)c * FE + f], ar[f], pf);
-                                aout[cb] = __fadd_rn(aout[cb], __fmul_rn(x[(int64_t)s_ * ldx + c], pf));
+                                const float xs_ = IO16 ? __builtin_bit_cast(float, (uint32_t)x16[(int64_t)s_ * ldx + c] << 15) : x[(int64_t)s_ * ldx + c];
+                                aout[cb] = __fadd_rn(aout[cb], __fmul_rn(xs_, pf));
                             }
                         }
                         const float cnt = (float)max(e_end - b, 1);
@@ -672,4 +723,40 @@ int dgnn_sage_layer_fused_ws_try(const int32_t* rowptr, const int32_t* src, cons
     else DGNN_WS_GO(128, 2, true, false);
 #undef DGNN_WS_GO
     return dgnn_check_launch(dec ? "sage_layer_fused_decoder_fwd(wave-specialised)" : "sage_layer_fused_fwd(wave-specialised)");
+}
+
+// The same kernel on the UNSIGNED 16-bit rows of the bf16-storage chain (DGNN_BF16_COMPENSATED | _ROWS_IN_UNSIGNED | _ROWS_OUT_UNSIGNED, fused_bf16.hip): rows
+// decoded to fp32 where the producers use them (exact), the fp16 two-part arithmetic of the fp32-I/O kernel in between, rows encoded (round to nearest even
+// on bit 15) in the consumers' epilogue.  c_in in {64, 128}, c_out == 128, relu (the format has no sign).  DGNN_E_UNSUPPORTED: the caller keeps its own kernel.
+int dgnn_sage_layer_fused_ws16_try(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const uint16_t* x_src, const uint16_t* x_dst,
+                                   int64_t ldx, int c_in, const float* edge_attr, int64_t lde, const float* We, const float* be, const float* Wj, const float* bj,
+                                   const float* Wi, const float* scale, const float* shift, int relu, int c_out, uint16_t* out, int64_t ldo, hipStream_t stream) {
+    static const int on = getenv("DGNN_WS_16") ? atoi(getenv("DGNN_WS_16")) : 1;
+    const int nch = c_in / 16;
+    if (!on || !dgnn_ws_enabled() || (c_in != 128 && c_in != 64) || c_out != WS_C || !relu || lde != FE || ldx % nch != 0 || ldo % 4 != 0 ||
+        ((((uintptr_t)x_src | (uintptr_t)x_dst) % (2 * nch)) != 0) || ((uintptr_t)out % 8) != 0 ||
+        ((((uintptr_t)edge_attr | (uintptr_t)Wj | (uintptr_t)Wi) % 16) != 0))
+        return DGNN_E_UNSUPPORTED;
+    const int64_t ntiles = dgnn_cdiv(n_dst, WS_TILE);
+    int grid = (int)(ntiles < DGNN_NUM_CU ? ntiles : DGNN_NUM_CU);
+    if (grid < 1) grid = 1;
+    static const int knobs = getenv("DGNN_WS_NT") ? atoi(getenv("DGNN_WS_NT")) : 33;
+    const WsDec d{};
+    const float* xs = reinterpret_cast<const float*>(x_src);
+    const float* xd = reinterpret_cast<const float*>(x_dst);
+    float* o = reinterpret_cast<float*>(out);
+    if (c_in == 64) {
+        static bool attr_[DGNN_MAX_DEVICES] = {};
+        const size_t sm_ = WsL<64, 4>::SMEM;
+        dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_ws<64, 4, true, false, true>), sm_, attr_);
+        hipLaunchKernelGGL((k_sage_fused_ws<64, 4, true, false, true>), dim3(grid), dim3(1024), sm_, stream, rowptr, src, eid, n_dst, xs, xd, ldx, edge_attr, lde, We, be,
+                           Wj, bj, Wi, scale, shift, relu, o, ldo, ntiles, knobs, d);
+    } else {
+        static bool attr_[DGNN_MAX_DEVICES] = {};
+        const size_t sm_ = WsL<128, 2>::SMEM;
+        dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused_ws<128, 2, true, false, true>), sm_, attr_);
+        hipLaunchKernelGGL((k_sage_fused_ws<128, 2, true, false, true>), dim3(grid), dim3(1024), sm_, stream, rowptr, src, eid, n_dst, xs, xd, ldx, edge_attr, lde, We, be,
+                           Wj, bj, Wi, scale, shift, relu, o, ldo, ntiles, knobs, d);
+    }
+    return dgnn_check_launch("sage_layer_fused_fwd_bf16(wave-specialised)");
 }

@@ -295,7 +295,10 @@ int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* src, const i
 /* 1: the 128 -> 128 layers in DGNN_GEMM_F16X2 (plain and decoder-carrying) run as the WAVE-SPECIALISED kernel (csrc/fused_ws.hip: workgroups of 8
  * producer wavefronts -- gather, filter MLP, mean, row split -- and 8 consumer wavefronts -- the dense product against register-resident weights, the
  * epilogue, the decoder -- around a ring of 32-tet tiles in LDS; same arithmetic form and error level as the two-phase kernel, not the same bits);
- * 0: the two-phase kernel of rounds 2-4 (environment DGNN_WS=0, read once per process).  What a benchmark line names its dominant kernel by. */
+ * 0: the two-phase kernel of rounds 2-4 (environment DGNN_WS=0, read once per process).  What a benchmark line names its dominant kernel by.
+ * The same kernel takes the 64 -> 128 layer (DGNN_WS_64=0: not) and, in the bf16-storage chain, the plain 64 -> 128 and 128 -> 128 layers on UNSIGNED
+ * 16-bit rows (dgnn_sage_layer_fused_fwd_bf16 with DGNN_BF16_COMPENSATED | _ROWS_IN_UNSIGNED | _ROWS_OUT_UNSIGNED; DGNN_WS_16=0: not): rows decoded
+ * exactly, the fp16 two-part arithmetic of the fp32-I/O kernel in between (tighter than the compensated bf16 products), rows encoded in the epilogue. */
 int dgnn_wave_specialised_enabled(void);
 
 /* The LAST conv layer + BatchNorm(eval) + ReLU of SurfaceNet.inference_layer (learning/surfaceNetStaticEdgeFilters.py:343-347) together with the
