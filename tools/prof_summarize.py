@@ -80,7 +80,8 @@ def get(i, col, dom=None):
 
 def dec_stats():
     """the same counters for the instantiation of the 128 -> 128 layer that also carries the decoder (template argument DEC = true), fp32 only"""
-    dom = "k_sage_fused_ws<128, 2, true, true>" if "k_sage_fused_ws" in DOM else "k_sage_fused_mfma<128, 128, 8, 2, 2, 2, t"
+    dom = "k_sage_fused_bf16<128, 128" if a.dtype == "bf16" else (
+        "k_sage_fused_ws<128, 2, true, true, false>" if "k_sage_fused_ws" in DOM else "k_sage_fused_mfma<128, 128, 8, 2, 2, 2, t")
     f, wr, du = get(3, "FETCH_SIZE", dom), get(4, "WRITE_SIZE", dom), get(3, "dur_us", dom)
     if not (f and wr is not None and du):
         return None
@@ -93,7 +94,7 @@ def dec_stats():
     if ks:
         rr = d_stats[d_stats["Name"].str.contains(dom, regex=False)]
         tr = float(rr.iloc[0]["AverageNs"]) / 1e3 if len(rr) else None
-    return {"kernel": dom if dom.endswith(">") else dom + "rue>", "traffic_bytes_per_launch": (2 * f + wr) * 1024, "fetch_kib": f, "write_kib": wr, "avg_launch_us_profiled": du,
+    return {"kernel": dom if dom.endswith(">") else (dom + ", ..., DEC = true>" if a.dtype == "bf16" else dom + "rue>"), "traffic_bytes_per_launch": (2 * f + wr) * 1024, "fetch_kib": f, "write_kib": wr, "avg_launch_us_profiled": du,
             "avg_launch_us_kernel_trace": tr, "mfma_busy_frac": round(busy / 1024 / cyc, 4), "valu_busy_frac": round(valu * 2 / 1024 / cyc, 4),
             "tcc_hit_rate": round(hit / (hit + miss), 4), "clock_ghz": round(clk, 3), "wait_any_frac": round(wany / wc, 4)}
 
@@ -122,8 +123,15 @@ if fetch and write:
             % (fetch, write),
             "  = %.3f GB against %.3f GB algorithmic (%d B/tet) -> %.2fx; at %.0f us that is %.2f TB/s through the L2 <-> fabric interface "
             "(Infinity-Cache hits are counted there, MI355X_MICROARCH.md)\n" % (traffic / 1e9, algo / 1e9, per_tet, traffic / algo, dur, traffic / dur / 1e6)]
-    ds = dec_stats() if a.dtype == "f32" else None
-    if ds:
+    ds = dec_stats() if (a.dtype == "f32" or "k_sage_fused_ws" in DOM) else None
+    if ds and a.dtype == "bf16":
+        cb = (bench.layer_bytes(128, 128, 2) + 2 * 128 + 8) * N
+        out += ["## reading (%s: the last layer's launch with the decoder inside, %.0f us per launch under the profiler)\n" % (ds["kernel"], ds["avg_launch_us_profiled"]),
+                "* fabric traffic per launch (2 x FETCH_SIZE %.0f KiB + WRITE_SIZE %.0f KiB) x 1024 = %.3f GB against the contract's %.3f GB (layer row %d + decoder row %d B/tet) -> %.2fx"
+                % (ds["fetch_kib"], ds["write_kib"], ds["traffic_bytes_per_launch"] / 1e9, cb / 1e9, bench.layer_bytes(128, 128, 2), 2 * 128 + 8, ds["traffic_bytes_per_launch"] / cb),
+                "* matrix pipe %.0f %% busy, VALU %.0f %%, %.0f %% of wave cycles parked, L2 hit rate %.0f %%, clock %.2f GHz\n" % (
+                    100 * ds["mfma_busy_frac"], 100 * ds["valu_busy_frac"], 100 * ds["wait_any_frac"], 100 * ds["tcc_hit_rate"], ds["clock_ghz"])]
+    elif ds:
         cb = (bench.layer_bytes(128, 128) + 520) * N
         out += ["## reading (%s: the last layer's launch with the decoder inside, %.0f us per launch under the profiler)\n" % (ds["kernel"], ds["avg_launch_us_profiled"]),
                 "* fabric traffic per launch (2 x FETCH_SIZE %.0f KiB + WRITE_SIZE %.0f KiB) x 1024 = %.3f GB: the layer's 0.52 GB of output and the decoder's 0.52 GB read are gone "
@@ -141,7 +149,7 @@ if fetch and write:
                "write_kib": write, "mfma_busy_frac": round(busy / 1024 / cyc, 4), "valu_busy_frac": round(valu * 2 / 1024 / cyc, 4),
                "tcc_hit_rate": round(hit / (hit + miss), 4), "clock_ghz": round(clk, 3), "avg_launch_us_profiled": dur,
                "avg_launch_us_kernel_trace": trace_ns / 1e3 if trace_ns else None, "wait_any_frac": round(wany / wc, 4),
-               "with_decoder": dec_stats() if a.dtype == "f32" else None, "commit": commit, "csrc_sha": bench.csrc_sha(),
+               "with_decoder": dec_stats() if (a.dtype == "f32" or "k_sage_fused_ws" in DOM) else None, "commit": commit, "csrc_sha": bench.csrc_sha(),
                "source": "profiles/%s.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH doubled per the guide)" % a.name},
               open(os.path.join(ROOT, "profiles", a.name + "_traffic.json"), "w"))
 open(os.path.join(ROOT, "profiles", a.name + ".md"), "w").write("\n".join(out))
