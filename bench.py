@@ -551,14 +551,14 @@ def main():
                 kname = net.dominant_kernel_name(shape)
                 if plain and shape in ((128, 128), (64, 128)) and ops.lib().dgnn_wave_specialised_enabled() == 1 and os.environ.get("DGNN_WS_16", "1") != "0" \
                         and ops.BF16_UNSIGNED_ROWS and ops.BF16_MODE == ops.BF16_COMPENSATED:
-                    kname = "k_sage_fused_ws<%d,%s,counters,plain,16-bit rows>" % (c_in, "2" if c_in == 128 else "4")     # csrc/fused_ws.hip on the unsigned 16-bit rows
+                    kname = "k_sage_fused_ws<%d,%s,counters,plain,16-bit rows>" % (c_in, "2")     # csrc/fused_ws.hip on the unsigned 16-bit rows
             elif fused:
                 kname = {0: "k_sage_fused<%d,%d,0>", 1: "k_sage_fused<%d,%d,1>", 2: "k_sage_fused_mfma<%d,%d>", 3: "k_sage_fused_mfma<%d,%d,dense f16x2>",
                          4: "k_sage_fused_mfma<%d,%d,f16x2>"}[ops.GEMM_MODE] % (32 if c_in <= 32 else (64 if c_in <= 64 else 128), c_out)
                 ws = ops.GEMM_MODE == ops.GEMM_F16X2 and shape in ((128, 128), (64, 128)) and ops.lib().dgnn_wave_specialised_enabled() == 1
                 if ws:
                     # csrc/fused_ws.hip: 8 producer + 8 consumer wavefronts per workgroup, rows handed over in an LDS ring (DGNN_WS=0: the two-phase kernel)
-                    kname = "k_sage_fused_ws<%d,%s,counters,%s>" % (c_in, "2" if c_in == 128 else "4", "plain" if plain else "DEC")
+                    kname = "k_sage_fused_ws<%d,%s,counters,%s>" % (c_in, "2", "plain" if plain else "DEC")
                 if not plain:
                     kname = (kname if ws else kname[:-1] + ",DEC>") + " (last conv layer + decoder in one launch)"
             elif wide_sr:
