@@ -1,6 +1,7 @@
-// Wave-specialised fused conv layer, 128 -> 128 (round 5; VERDICT r4 item 3, DESIGN 10 "next" of round 4).
+// Wave-specialised fused conv layer, C_in in {64, 128} -> 128 (round 5; VERDICT r4 item 3, DESIGN 10 "next" of round 4).
 //
-// Reference: SAGEConv.forward + BatchNorm(eval) + ReLU, learning/surfaceNetStaticEdgeFilters.py:66-96, :345-346 -- the shipped model's layers 2 and 3.
+// Reference: SAGEConv.forward + BatchNorm(eval) + ReLU, learning/surfaceNetStaticEdgeFilters.py:66-96, :345-346 -- the shipped model's layers 1, 2 and 3
+// (the description below is for C_in = 128; 64: half the channels per producer lane, 512-byte ring rows, 4 k-steps).
 // k_sage_fused_mfma<128,128> runs eight wavefronts that ALL walk the same two phases (filter / mean, barrier, dense product): 44-48 % of its wave cycles
 // are parked, the matrix pipe is 26 % busy, and at 229-250 VGPRs two wavefronts per SIMD is all it admits (docs/history_r1-r4.md 5a, 5b).  The probe
 // tools/probe_producer.py says what the split buys: the producer side ALONE (gathers, filter product, mean, row split -- k_agg_sr<8, false> with its HBM
@@ -211,7 +212,7 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
         dst[48] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
     }
 
-    // DEC, stage B of tile t (a PRODUCER wavefront's job, see above): hidden units 16 hb .. + 15 of cells 16 b .. + 15 -- lane (cell n = jcol, tq) ends up with
+    // DEC, stage B of tile t, job (hb, b) (either role runs it, see above): hidden units 16 hb .. + 15 of cells 16 b .. + 15 -- lane (cell n = jcol, tq) ends up with
     // units 16 hb + 4 tq .. + 3
     auto stage_b = [&](uint32_t t, int hb, int b) {
         wait_for(ycnt + (t & 1), 8u * (t / 2 + 1));
@@ -467,9 +468,9 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
     load_rp(1, vb2);
     load_idx(0, vb1, reg1, vsrc1, veid1);
 
-    // DEC: this wavefront also runs stage B of tile it - 2 (hidden block p & 3 of row block p >> 2) -- BETWEEN issuing its gathers for tile `it` and using
-    // them: the job fills the gather latency, and its data (the consumers' stage A of tile it - 2) is complete about when the slot the producer is going to
-    // write is handed back anyway.  Two more iterations drain the last two tiles.
+    // DEC: on the tiles the rule gives to the producers (b_on_consumers) this wavefront also runs stage B of tile it - 2 (hidden block p & 3 of row block
+    // p >> 2) -- BETWEEN issuing its gathers for tile `it` and using them: the job fills the gather latency, and its data (the consumers' stage A of tile
+    // it - 2) is complete about when the slot the producer is going to write is handed back anyway.  Two more iterations drain the last two tiles.
     for (int64_t it = 0; it < my_n + (FLAGS ? (DEC ? 2 : 0) : 1); ++it) {
         int nv = 0, sl = 0, tl = 0, vsrc = 0, veid = 0;
         bool regular = false;
@@ -676,17 +677,17 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
 
 }  // namespace
 
-// 1 = the wave-specialised kernel takes the plain 128 -> 128 layer in the default arithmetic (DGNN_WS=0: k_sage_fused_mfma<128,128> as in rounds 2-4)
+// 1 = the wave-specialised kernel takes the 64 -> 128 / 128 -> 128 layers in the default arithmetic (DGNN_WS=0: k_sage_fused_mfma<.., 128> as in rounds 2-4)
 int dgnn_ws_enabled() {
     static const int v = getenv("DGNN_WS") ? atoi(getenv("DGNN_WS")) : 1;
     return v;
 }
 
-// C ABI (include/dgnn_hip.h): which kernel dgnn_sage_layer_fused_fwd / _decoder_fwd launch for a 128 -> 128 layer in DGNN_GEMM_F16X2
+// C ABI (include/dgnn_hip.h): which kernel dgnn_sage_layer_fused_fwd / _decoder_fwd launch for a 64 -> 128 / 128 -> 128 layer in DGNN_GEMM_F16X2
 extern "C" int dgnn_wave_specialised_enabled(void) { return dgnn_ws_enabled() != 0 ? 1 : 0; }
 
-// same contract as dgnn_sage_layer_fused_mfma_try for c_in == c_out == 128; with W0 != NULL the launch carries the decoder 128 -> 64 -> 2 and writes
-// logits [n_dst, 2] instead of rows (`out` unused).  DGNN_E_UNSUPPORTED: the caller keeps the two-phase kernel
+// same contract as dgnn_sage_layer_fused_mfma_try for c_in in {64, 128}, c_out == 128; with W0 != NULL (c_in == 128) the launch carries the decoder
+// 128 -> 64 -> 2 and writes logits [n_dst, 2] instead of rows (`out` unused).  DGNN_E_UNSUPPORTED: the caller keeps the two-phase kernel
 int dgnn_sage_layer_fused_ws_try(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x_src, const float* x_dst, int64_t ldx,
                                  int c_in, const float* edge_attr, int64_t lde, const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
                                  const float* scale, const float* shift, int relu, int c_out, float* out, int64_t ldo, hipStream_t stream, const float* W0,
@@ -715,7 +716,7 @@ int dgnn_sage_layer_fused_ws_try(const int32_t* rowptr, const int32_t* src, cons
     if (c_in == 64) {
         if (ring == 2) DGNN_WS_GO(64, 2, false, false);
         else if (ring == 22) DGNN_WS_GO(64, 2, true, false);
-        else DGNN_WS_GO(64, 4, true, false);          // (16 KB slots: four of them by default)
+        else DGNN_WS_GO(64, 4, true, false);          // (DGNN_WS_RING=3 / 4: four 16 KB slots)
     } else if (dec) DGNN_WS_GO(128, 2, true, true);
     else if (ring == 2) DGNN_WS_GO(128, 2, false, false);
     else if (ring == 3) DGNN_WS_GO(128, 3, true, false);
