@@ -5,6 +5,8 @@ hand-off protocol and the tiling can get wrong: cell counts that leave 1 / 9 / 3
 workgroups, ragged in-degrees (the per-lane path inside a tile of matrix-core groups), padded row strides, destination sub-ranges, edge rows through `eid`;
 and repeated launches bit for bit.  The whole-model parity suites (tests/test_gpu_parity.py, test_gpu_infer.py, test_gpu_bf16.py) run the same kernels
 through the module interface; tests/test_gpu_infer.py::test_ignatius_layers_repeat_bit_for_bit_with_cold_caches pins the race the hand-off once had."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -12,6 +14,7 @@ import torch
 from test_gpu_parity import DEV
 
 pytestmark = pytest.mark.gpu
+BOUND_SCALE = float(os.environ.get("DGNN_TEST_BOUND_SCALE", "1"))      # (< 1: how much margin the stated bounds have on this box)
 
 
 def _graph(n, seed, ragged):
@@ -67,7 +70,7 @@ def test_ws_layer_vs_fp64(c_in, n, ragged):
     out = ops.sage_layer_fused_fwd(rowptr, src, n, xs, ea.to(DEV), *dv(We, be, Wj, bj, Wi, scale, shift), True, eid=eid)
     err = (out.cpu().double() - ref).abs()
     # 22 significand bits per operand, fp32 accumulation of up to 2 c_in + 84 terms: a few 2^-22 of the terms' magnitude
-    bound = 2.0 ** -19 * mag + 1e-30
+    bound = BOUND_SCALE * 2.0 ** -19 * mag + 1e-30
     assert bool((err <= bound).all()), (float((err / bound).max()), int((err > bound).sum()))
     for _ in range(3):
         assert torch.equal(out, ops.sage_layer_fused_fwd(rowptr, src, n, xs, ea.to(DEV), *dv(We, be, Wj, bj, Wi, scale, shift), True, eid=eid))
@@ -102,7 +105,7 @@ def test_ws_layer_on_unsigned_16_bit_rows_vs_fp64(c_in, n, ragged):
     assert out.dtype == ops.UROWS and out.shape == (n, 128)
     err = (_ub_decode(out) - ref).abs()
     # the stored value is off by at most half of the format's spacing (9 significant bits: 2^-9 of the value; EPS = 2^-8) + the arithmetic's few 2^-22 of the terms
-    bound = 0.5 * EPS * ref.abs() + 2.0 ** -19 * mag + 1e-30
+    bound = 0.5 * EPS * ref.abs() + BOUND_SCALE * 2.0 ** -19 * mag + 1e-30
     assert bool((err <= bound).all()), (float((err / bound).max()), int((err > bound).sum()))
     for _ in range(3):
         assert torch.equal(out, ops.sage_layer_fused_fwd_bf16(rowptr, src, n, xin, c_in, ea.to(DEV), *dv(We, be, Wj, bj, Wi, scale, shift), True, eid=eid,
@@ -132,7 +135,7 @@ def test_ws_last_layer_with_the_decoder_vs_fp64(n, ragged):
     args = dv(We, be, Wj, bj, Wi, scale, shift)
     lg = ops.sage_layer_fused_decoder_fwd(rowptr, src, n, x.to(DEV), ea.to(DEV), *args, True, *dv(W0, b0, s1, h1, W3, b3), eid=eid)
     err = (lg.cpu().double() - lref).abs()
-    bound = 2.0 ** -18 * lmag + 1e-30
+    bound = BOUND_SCALE * 2.0 ** -18 * lmag + 1e-30
     assert bool((err <= bound).all()), (float((err / bound).max()), int((err > bound).sum()))
     for _ in range(5):
         assert torch.equal(lg, ops.sage_layer_fused_decoder_fwd(rowptr, src, n, x.to(DEV), ea.to(DEV), *args, True, *dv(W0, b0, s1, h1, W3, b3), eid=eid))
