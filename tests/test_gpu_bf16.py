@@ -183,8 +183,8 @@ def test_last_bf16_layer_with_the_decoder_inside(points, c_in):
     from dgnn_amd import ops
     from dgnn_amd.synthetic import delaunay_tet_graph
     from oracle.pyg_semantics import propagate_mean
-    if ops.BF16_MODE != ops.BF16_COMPENSATED:
-        pytest.skip("the one-launch form exists for the compensated arithmetic")
+    if ops.BF16_MODE != ops.BF16_COMPENSATED or not ops.FUSE_DECODER:
+        pytest.skip("the one-launch form exists for the compensated arithmetic (DGNN_FUSE_DECODER=0 selects the two-launch form)")
     adj, _, _ = delaunay_tet_graph(points, seed=points)
     n = adj.shape[0] // 4
     ei = torch.from_numpy(adj.T.astype(np.int64))

@@ -656,9 +656,12 @@ def test_block_builder_gathers_the_step_rows_and_the_run_is_the_same(model):
     """NeighborSampler.attach_rows (Trainer.attach_block_rows): x[n_id, 1:], x[ids], y[ids] come out of the block builder -- equal to indexing, for every
     block of a buffer-ring loader and after a second attach; a training run with and without them ends bit-identical (same rows, same kernels)."""
     import dgnn_amd.learning.runModel as RM
+    import dgnn_amd.sampler as SM
     from dgnn_amd.learning.runModel import Metrics, Trainer
     from dgnn_amd.sampler import NeighborSampler, block_rows
     from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal
+    if not SM.ONE_CALL:
+        pytest.skip("the block builder gathers the step's rows in its one-call form (DGNN_KHOP_ONE_CALL=0 selects the hop-by-hop builder)")
     adj, _, _ = delaunay_tet_graph(4000, seed=17)
     n = adj.shape[0] // 4
     ei = torch.from_numpy(adj.T.astype(np.int64)).to(DEV)
