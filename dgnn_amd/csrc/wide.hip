@@ -763,7 +763,12 @@ __global__ void __launch_bounds__(GT, 1) k_gemm_sr2(SrPart p1, SrPart p2, const 
             // stage stg holds W(ch ..) once this wave's share has landed (everything but the 8 most recent operations has: those are cell fragments
             // of the next two chunks and, behind a group boundary, a scale word) and everybody else's has (barrier); the barrier also hands the stage
             // read before this one back to the DMA
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            // At the tail the operations counted on are not issued any more (no stage / no cell fragments past the last chunk): behind the last
+            // CPS chunks fewer than 8 operations follow the stage's DMA, so the wave drains everything there (nch is uniform: a scalar branch).
+            if (ch + CPS >= nch)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             __syncthreads();
             dma_stage(stg + (CPS == 1 ? 2 : 1));
         }

@@ -810,6 +810,9 @@ class SurfaceNet(nn.Module):
                 x = ops.gather_rows(x_all, n_id.to(dev).to(torch.int32))
                 plan = plan_for(edge_index.to(dev), size[0], size[1], hint=ops.PLAN_HINT_GROUPED)
                 ea = ops.gather_rows(xe_all, e_id.to(dev).to(torch.int32))
-                xs.append(self._eval_layers(x, plan.n_dst, ea, [plan] * self.num_layers, True, only=i))  # stays in HBM
+                y = self._eval_layers(x, plan.n_dst, ea, [plan] * self.num_layers, True, only=i)   # stays in HBM
+                # a >= 256-wide layer hands back split rows (ops.SplitRows); this schedule concatenates the batches and gathers the next
+                # layer's inputs by row, so they go back to fp32 rows here (exact: hi + lo is the stored value)
+                xs.append(y.float() if isinstance(y, ops.SplitRows) else y)
             x_all = torch.cat(xs, dim=0)
         return self._eval_decoder(x_all)

@@ -111,10 +111,17 @@ def scene_order(edge_index: torch.Tensor, n: int, infinite=None, mfile: str = No
     return CellOrder(*cell_order_bfs(edge_index, n), "bfs")
 
 
-# The permutation of every scene the loader has relabelled in this process, by the scene's files (`path`, `gtfile`): the per-tensor RANK_TAG does not
+# The permutation of the scenes the loader has relabelled in this process, by the scene's files (`path`, `gtfile`): the per-tensor RANK_TAG does not
 # survive `.to()`, `.clone()`, `.cpu()`, `torch.cat`, indexing or pickling, the data object's `path` / `gtfile` strings (run.py:212-213) do.  An entry
 # is replaced when the same scene is loaded again and set to None when it is loaded WITHOUT relabelling (so that a stale order is never applied).
-_SCENE_ORDERS = {}
+# The strings alone do not say that an object's rows ARE in the relabelled order (one built straight from the npz files, a cached dataset, a second
+# loader with cell_order off carries the same strings): an entry therefore keeps the relabelled `infinite` flags (1 byte per cell, host memory) and is
+# applied only to an object whose own `infinite` equals them -- a positive sign that its rows went through the relabelling loader.  The registry holds
+# the _SCENE_ORDERS_MAX most recently loaded scenes.
+import collections
+
+_SCENE_ORDERS = collections.OrderedDict()
+_SCENE_ORDERS_MAX = 32
 
 
 def _scene_key(data):
@@ -126,17 +133,27 @@ def _scene_key(data):
     return os.path.normpath(os.path.join(str(path), str(gt)))
 
 
+def _flags_u8(v):
+    return torch.as_tensor(v).detach().reshape(-1).to("cpu").ne(0).to(torch.uint8)
+
+
 def register_scene_order(data, co) -> None:
     """called by `dataLoader.run` for every scene it loads (co = None: loaded in file order)"""
     key = _scene_key(data)
-    if key is not None:
-        _SCENE_ORDERS[key] = co
+    if key is None:
+        return
+    inf = getattr(data, "infinite", None) if not isinstance(data, dict) else data.get("infinite")
+    _SCENE_ORDERS.pop(key, None)
+    _SCENE_ORDERS[key] = (co, _flags_u8(inf) if (co is not None and inf is not None) else None)
+    while len(_SCENE_ORDERS) > _SCENE_ORDERS_MAX:
+        _SCENE_ORDERS.popitem(last=False)
 
 
 def find_cell_order(data):
     """-> (CellOrder | None, known): the order `data`'s rows are in.  Looked up (1) on the object itself (`cell_order`: the loader, or a dataset
     object that carries the field), (2) on the loader's tagged per-cell tensors (an unmodified run.py:prepareSample hands those on), (3) in the
-    registry of scenes this process has loaded, by the object's `path` + `gtfile`.  `known` is False when none of the three says anything."""
+    registry of scenes this process has loaded, by the object's `path` + `gtfile` -- applied only when the object's `infinite` flags equal the
+    relabelled scene's (see _SCENE_ORDERS).  `known` is False when none of the three says anything."""
     said = False
     if (isinstance(data, dict) and "cell_order" in data) or (not isinstance(data, dict) and hasattr(data, "cell_order")):
         co = data["cell_order"] if isinstance(data, dict) else data.cell_order
@@ -152,7 +169,15 @@ def find_cell_order(data):
             return co, True
     key = _scene_key(data)
     if key is not None and key in _SCENE_ORDERS:
-        return _SCENE_ORDERS[key], True
+        co, flags = _SCENE_ORDERS[key]
+        if co is None:
+            return None, True
+        inf = getattr(data, "infinite", None) if not isinstance(data, dict) else data.get("infinite")
+        if inf is not None and flags is not None:
+            mine = _flags_u8(inf)
+            if mine.numel() == flags.numel() and torch.equal(mine, flags):
+                return co, True
+        return None, said        # same files, but nothing says these rows were relabelled: left alone
     return None, said
 
 

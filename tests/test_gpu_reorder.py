@@ -267,7 +267,7 @@ def test_generate_takes_a_reordered_scene(tmp_path):
     # (c) ADVICE r4: every tensor was COPIED (.clone() / .cpu() / cat drop the tag) -- the order is found by the scene's path + gtfile in the
     # registry the loader fills; a permutation of another length raises instead of scrambling the mesh
     from dgnn_amd.processing import reorder as R
-    key_obj = Config(path=str(tmp_path), gtfile="gt/0")
+    key_obj = Config(path=str(tmp_path), gtfile="gt/0", infinite=inf_rows.clone())      # what dataLoader.run registers: the loader after relabelling
     R.register_scene_order(key_obj, co)
     try:
         data = Config(path=str(tmp_path), gtfile="gt/0", filename="0", id="", category="", infinite=inf_rows.clone().cpu())
@@ -276,6 +276,18 @@ def test_generate_takes_a_reordered_scene(tmp_path):
         assert np.array_equal(np.asarray(mesh.faces), g["faces"]) and np.array_equal(np.asarray(mesh.vertices), g["vertices_out"])
         with pytest.raises(RuntimeError, match="permutation"):
             R.restore_cell_order(pred_rows[:-1], data)
+        # an object with the same files whose rows are in FILE order (built straight from the npz, a cached dataset, a loader with
+        # cell_order off that did not register) is NOT permuted: its `infinite` flags are not the relabelled scene's
+        in_file_order = Config(path=str(tmp_path), gtfile="gt/0", filename="0", id="", category="", infinite=torch.from_numpy(g["infinite"]).clone())
+        assert R.find_cell_order(in_file_order)[0] is None
+        mesh, _ = generate(in_file_order, torch.from_numpy(g["prediction"]).to(DEV), clf)
+        assert np.array_equal(np.asarray(mesh.faces), g["faces"])
+        # ... nor one that carries no per-cell flags at all; and the registry is bounded
+        assert R.find_cell_order(Config(path=str(tmp_path), gtfile="gt/0"))[0] is None
+        for i in range(R._SCENE_ORDERS_MAX + 5):
+            R.register_scene_order(Config(path=str(tmp_path), gtfile="gt/other%d" % i, infinite=inf_rows), co)
+        assert len(R._SCENE_ORDERS) == R._SCENE_ORDERS_MAX
+        R.register_scene_order(key_obj, co)
         R.register_scene_order(key_obj, None)         # the same scene loaded again WITHOUT relabelling: the stale order is gone
         assert R.find_cell_order(data) == (None, True)
     finally:

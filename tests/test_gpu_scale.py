@@ -450,8 +450,24 @@ def test_updated_training_step_at_scale_matches_the_oracle(dtype, params, points
         ref_k = mgrads[k]
         d = (hgrads[k].double().cpu() - ref_k).abs()
         top_k = ref_k.abs().max().item()
-        outside = int((d > 1e-3 * top_k + 1e-6 * mmax).sum().item())       # entries beyond fp32 class: at most 0.1 % of the tensor (two for a bias vector)
+        far = d > 1e-3 * top_k + 1e-6 * mmax
+        outside = int(far.sum().item())       # entries beyond fp32 class: at most 0.1 % of the tensor (two for a bias vector)
         assert rms <= 1e-3 and outside <= max(2, d.numel() // 1000) and d.max().item() <= 2e-2 * top_k + 1e-6 * mmax, (k, mx, rms, outside, d.numel())
+        # ... and they are SPARSE: a flipped mask entry adds one cell's rank-one term to a weight gradient, spread over the whole matrix -- it never
+        # fills a row or a column of it.  No output channel (row) and no input channel (column) may hold more than max(2, 2 %) of its entries
+        # outside the fp32 class, so a whole wrong row / column (a mis-indexed channel) cannot hide in the 0.1 % allowance.
+        if d.dim() == 2:
+            per_row, per_col = far.sum(dim=1), far.sum(dim=0)
+            assert int(per_row.max().item()) <= max(2, d.size(1) // 50) and int(per_col.max().item()) <= max(2, d.size(0) // 50), \
+                (k, int(per_row.max().item()), int(per_col.max().item()), tuple(d.shape))
+    # A loose guard against the un-rounded fp64 oracle stays: the rounding model is hand-written beside the kernels, so a rounding site
+    # mirrored wrongly in both, or a regression that shows up as a larger format price, must not pass on the model comparison alone.  Tabulated
+    # price: 8.4-9.4 % rms at layer 0, 6.5-6.8 % / 4.5-5.5 % at layers 1 / 2, 0.5-0.6 % at the last conv layer; the bound
+    # is 1.5 x the worst tabulated figure per layer class, for the model AND for the HIP gradients.
+    for r in rows:
+        cap = 0.14 if r["layer"] < len(params) - 1 else 0.012
+        assert r["model_vs_oracle_rms"] <= cap and r["hip_vs_oracle_rms"] <= cap, r
+        assert abs(r["hip_vs_oracle_rms"] - r["model_vs_oracle_rms"]) <= 2e-3, r      # the HIP path pays the model's price, not more
 
 
 @pytest.mark.parametrize("k1,k2,n_out", [(128, 128, 128), (64, 0, 2), (128, 0, 64), (70, 33, 37), (256, 256, 512), (28, 28, 64)])

@@ -230,3 +230,33 @@ def test_wide_widths_whole_model_vs_oracle_and_the_fp32_row_path(convs):
     finally:
         ops.WIDE_SR = old
     assert (base - got).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("convs", [(64, 128, 256, 512)])
+def test_wide_widths_minibatch_schedules_vs_whole_graph(convs):
+    """The two mini-batched inference schedules at the reference's wide widths (configs/eth.yaml:56 validates with per_layer=1 + batch_size:
+    reference inference_layer_batch :279-320 via learning/runModel.py:405; inference_batch_layer :232-275): the wide layers hand back split rows
+    (ops.SplitRows) and both schedules must still run and agree with whole-graph inference_layer within the fp32 tolerance."""
+    from dgnn_amd.sampler import NeighborSampler
+    from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal
+    adj, _, _ = delaunay_tet_graph(900, 6)
+    n = adj.shape[0] // 4
+    x = hashed_normal(np.arange(n), 29, seed=1, device=DEV)
+    ea = hashed_normal(np.arange(4 * n), 20, seed=2, device=DEV)
+    ei = torch.from_numpy(adj.T.astype(np.int64)).to(DEV)
+    onet = oracle_static(convs=convs, load=False, seed=4)
+    for m in onet.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    net = hip_static(convs=convs, sd=onet.state_dict())
+    assert net.wide_layer_split_rows(convs[1], convs[2]) and net.wide_layer_split_rows(convs[2], convs[3])
+    full = net.inference_layer(Config(x=x, edge_attr=ea, edge_index=ei))
+    tol = TOL_LOGIT * max(1.0, full.abs().max().item())
+    one_hop = NeighborSampler(ei, sizes=[-1], num_nodes=n, batch_size=1024, shuffle=False)
+    lb = net.inference_layer_batch(Config(x=x, edge_attr=ea), one_hop)
+    assert lb.shape == full.shape and (lb - full).abs().max().item() <= tol
+    sel = torch.arange(0, n, 7, device=DEV)
+    k_hop = NeighborSampler(ei, sizes=[-1] * 4, node_idx=sel, num_nodes=n, batch_size=256, shuffle=False)
+    bl = net.inference_batch_layer(Config(x=x, edge_attr=ea), k_hop)
+    assert (bl[sel] - full[sel]).abs().max().item() <= tol
