@@ -285,7 +285,7 @@ def headline_of(full, full_path):
             h[k] = pick(t, ("ms_per_step", "targets_per_s", "launches_per_step", "error"))
     cv = full.get("config3_convergence")
     if cv:
-        h["config3_convergence"] = pick(cv, ("ok", "steps", "loss_f32_last", "loss_bf16_last", "max_rel_gap", "band", "error"))
+        h["config3_convergence"] = pick(cv, ("ok", "steps", "loss_f32_first", "loss_f32_last", "loss_bf16_last", "max_rel_gap_early", "max_rel_gap_late", "band", "error"))
     o = full.get("other_scaling")
     if o:
         h["other_scaling"] = {"scaling": o.get("scaling"), "value": o.get("value"), "ms_per_step": o.get("ms_per_step"), "ok": (o.get("check") or {}).get("ok")}
@@ -346,6 +346,25 @@ def drop_scene_builder(h):
         proc.kill()          # the exact child started above
         proc.wait()
     shutil.rmtree(d, ignore_errors=True)
+
+
+def convergence_leg():
+    """tools/config3_convergence.py as a child process: both loss curves, the gaps between them and the stated band"""
+    import subprocess
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    band = {"early": 0.30, "late": 0.08}       # tests/test_gpu_config3.py: BAND_EARLY (steps < 100), BAND_LATE
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "config3_convergence.py")], capture_output=True, text=True, timeout=120)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": "config3_convergence exited %d: %s" % (r.returncode, r.stderr.strip().splitlines()[-1:] or "")}
+        d = json.loads(line[-1])
+        d["band"] = band
+        d["ok"] = bool(d["finite"] and d["max_rel_gap_early"] <= band["early"] and d["max_rel_gap_late"] <= band["late"] and d["loss_bf16_last"] <= 0.05 * d["loss_f32_first"])
+        return d
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
 
 
 def training_leg(extra=()):
@@ -1226,6 +1245,10 @@ def main():
                 # BASELINE config 3 at its own workload: the Updated variant, bf16 storage, ModelNet10's widths and batch size
                 out["training_step_updated_bf16_modelnet_widths"] = training_leg(["--updated", "--dtype", "bf16", "--widths", "128,256,512,1024", "--batch", "1024",
                                                                                   "--steps", "100", "--warmup", "100"])
+            if not bf16 and not args.no_extras:
+                # BASELINE config 3 as a functional check: Updated model, ModelNet10 widths / batch, 300 Adam steps in fp32 storage and in bf16 storage from the
+                # same weights on the same blocks (tools/config3_convergence.py; tests/test_gpu_config3.py asserts the same band)
+                out["config3_convergence"] = convergence_leg()
         line = json.dumps(headline_of(out, write_full(out)))
         if len(line) > 4096:      # never the driver's problem: drop the optional legs, largest first, until the line fits
             h_ = json.loads(line)

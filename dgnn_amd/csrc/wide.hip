@@ -981,7 +981,11 @@ extern "C" int dgnn_sage_aggregate_sr(const int32_t* rowptr, const int32_t* src,
     const int64_t rowb = (int64_t)(C / 32) * SRB;
     const size_t lds = (size_t)NBv * 2 * 48 * 16;
     static const int wg_per_cu = getenv("DGNN_AGG_SR_WGS") ? atoi(getenv("DGNN_AGG_SR_WGS")) : 2;
-    const dim3 grid((unsigned)dgnn_grid_cap(dgnn_cdiv(dgnn_cdiv(n_dst, 4), 8), wg_per_cu < 1 ? 1 : wg_per_cu)), block(512);
+    // (the kernel deals the groups of 4 cells to the XCDs' eighths by blockIdx.x & 7: with fewer than 8 workgroups the eighths without one were
+    // never computed -- a block of fewer than 256 destination cells, round 6 -- so a launch has at least 8, the surplus ones leave at once)
+    int nwg_ = dgnn_grid_cap(dgnn_cdiv(dgnn_cdiv(n_dst, 4), 8), wg_per_cu < 1 ? 1 : wg_per_cu);
+    if (nwg_ < 8) nwg_ = 8;
+    const dim3 grid((unsigned)nwg_), block(512);
     hipStream_t st = (hipStream_t)stream;
     static const int ilv = getenv("DGNN_AGG_SR_ILV") ? atoi(getenv("DGNN_AGG_SR_ILV")) : 2;   // measured: 1 / 2 / 4 interleaved chains within 1 % (the launch is bound by its gathers); 2 keeps four wavefronts per SIMD
 #define DGNN_AGG_SR(NB_, SR_, IL_)                                                                                                                       \

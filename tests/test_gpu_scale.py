@@ -453,13 +453,15 @@ def test_updated_training_step_at_scale_matches_the_oracle(dtype, params, points
         far = d > 1e-3 * top_k + 1e-6 * mmax
         outside = int(far.sum().item())       # entries beyond fp32 class: at most 0.1 % of the tensor (two for a bias vector)
         assert rms <= 1e-3 and outside <= max(2, d.numel() // 1000) and d.max().item() <= 2e-2 * top_k + 1e-6 * mmax, (k, mx, rms, outside, d.numel())
-        # ... and they are SPARSE: a flipped mask entry adds one cell's rank-one term to a weight gradient, spread over the whole matrix -- it never
-        # fills a row or a column of it.  No output channel (row) and no input channel (column) may hold more than max(2, 2 %) of its entries
-        # outside the fp32 class, so a whole wrong row / column (a mis-indexed channel) cannot hide in the 0.1 % allowance.
-        if d.dim() == 2:
+        # ... and they have the SHAPE of a flipped mask entry: a flip at (cell, channel j) changes dz[cell, j] alone, i.e. ROW j of the layer's dWl / dWr
+        # (by delta * a[cell, :] resp. delta * x[cell, :]: part of that row crosses the fp32 class, measured up to 38 of 256 entries) and nothing of any
+        # other row.  So: at most max(2, 1 %) of a weight gradient's rows may hold more than 2 % of their entries outside, and none more than a quarter
+        # -- a mis-indexed channel (a whole wrong row or column) cannot hide in the 0.1 % allowance above.
+        if d.dim() == 2 and d.size(1) >= 16:
             per_row, per_col = far.sum(dim=1), far.sum(dim=0)
-            assert int(per_row.max().item()) <= max(2, d.size(1) // 50) and int(per_col.max().item()) <= max(2, d.size(0) // 50), \
-                (k, int(per_row.max().item()), int(per_col.max().item()), tuple(d.shape))
+            rows_hit = int((per_row > max(2, d.size(1) // 50)).sum().item())
+            assert rows_hit <= max(2, d.size(0) // 100) and int(per_row.max().item()) <= max(4, d.size(1) // 4) and int(per_col.max().item()) <= max(4, d.size(0) // 4), \
+                (k, rows_hit, int(per_row.max().item()), int(per_col.max().item()), tuple(d.shape))
     # A loose guard against the un-rounded fp64 oracle stays: the rounding model is hand-written beside the kernels, so a rounding site
     # mirrored wrongly in both, or a regression that shows up as a larger format price, must not pass on the model comparison alone.  Tabulated
     # price: 8.4-9.4 % rms at layer 0, 6.5-6.8 % / 4.5-5.5 % at layers 1 / 2, 0.5-0.6 % at the last conv layer; the bound
