@@ -165,6 +165,7 @@ SIGNATURES = {
     "dgnn_kl_cell_loss_scratch_doubles": (i64, [i64]),
     "dgnn_kl_cell_loss_fwd": (i32, [vp, i64, vp, i64, vp, i64, i32, i64, vp, vp, vp, vp]),
     "dgnn_kl_cell_loss_bwd": (i32, [vp, i64, vp, i64, vp, i64, i32, i64, vp, vp, vp, i64, vp]),
+    "dgnn_kl_cell_loss_step": (i32, [vp, i64, vp, i64, vp, i64, i32, i64, vp, vp, vp, vp, vp, i64, vp]),
     "dgnn_sage_layer_train_scratch_elems": (i64, [i64, i64, i32, i32, i32]),
     "dgnn_sage_layer_train_fwd": (i32, [vp, vp, vp, i64, vp, i64, i32, vp, i64, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, f32, f32, i32,
                                         vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),

@@ -310,11 +310,17 @@ __device__ __forceinline__ int rl(int v, int l) { return __builtin_amdgcn_readla
 __device__ __forceinline__ float rlf(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 
 constexpr int CH_ROWS = 16;   // rows per chunk at most (row pointers in lanes 0 .. 16)
+static bool no_dx_form() {
+    static const bool on = !(getenv("DGNN_AGG_BWD_NODX") && getenv("DGNN_AGG_BWD_NODX")[0] == '0');
+    return on;
+}
 
 // ADD: dx[row] = (the row's sum) + add[row] for row < n_add -- the `dx[:n_dst] += dz . Wi` of a conv layer's backward without a
 // launch of its own (same rounding as the GEMM epilogue that used to accumulate into dx: fl(sum + addend)).  The chunk's addend rows are
 // parked in the wavefront's part of `red` when the chunk starts (16 independent loads) so that no row waits for its own.
-template <int CPL, int FE, typename T, int SLOTS, bool ADD = false>
+// DX = false (round 6): the first conv layer's backward -- its input is data, only dWe / dbe are wanted -- skips the filter's recomputation (phi is
+// needed for dx alone: 20 of the 40 fused multiply-adds per channel and edge) and the dx bookkeeping.
+template <int CPL, int FE, typename T, int SLOTS, bool ADD = false, bool DX = true>
 __global__ void __launch_bounds__(256) k_agg_bwd_c(const int32_t* __restrict__ t_rowptr, const int32_t* __restrict__ t_dst,
                                                    const int32_t* __restrict__ t_eid, int64_t n_src, const int32_t* __restrict__ rowptr_dst,
                                                    const T* __restrict__ x, int64_t ldx, int c_in, const float* __restrict__ ea, int64_t lde,
@@ -376,6 +382,7 @@ __global__ void __launch_bounds__(256) k_agg_bwd_c(const int32_t* __restrict__ t
                 for (int j = 0; j < CPL; ++j) park[r * CPL + j] = av[r].v[j];
         }
         auto finish_until = [&](int r) {   // rows without out-edges get dx = 0 like the others get their sum
+            if (!DX) return;
             while (cur < r) {
                 if (on && dx) {
                     Vec<CPL, T> o;
@@ -426,8 +433,10 @@ __global__ void __launch_bounds__(256) k_agg_bwd_c(const int32_t* __restrict__ t
 #pragma unroll
                         for (int f = 0; f < NW; ++f) {
                             af[f] = rlf(Av[j], f);
+                            if (DX) {
 #pragma unroll
-                            for (int jj = 0; jj < CPL; ++jj) p[jj] = __fmaf_rn(w[jj][f], af[f], p[jj]);
+                                for (int jj = 0; jj < CPL; ++jj) p[jj] = __fmaf_rn(w[jj][f], af[f], p[jj]);
+                            }
                         }
                     } else if (FE == 0) {
 #pragma unroll
@@ -441,7 +450,7 @@ __global__ void __launch_bounds__(256) k_agg_bwd_c(const int32_t* __restrict__ t
 #pragma unroll
                         for (int jj = 0; jj < CPL; ++jj) {
                             const float dm = __fdiv_rn(gq[j].v[jj], cnt);
-                            acc[jj] = __fadd_rn(acc[jj], __fmul_rn(dm, p[jj]));
+                            if (DX) acc[jj] = __fadd_rn(acc[jj], __fmul_rn(dm, p[jj]));
                             dph.v[jj] = __fmul_rn(dm, xq[j].v[jj]);
                             if (FE > 0) {
                                 gb[jj] += dph.v[jj];
@@ -910,6 +919,10 @@ int agg_bwd_t(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
         hipLaunchKernelGGL((k_agg_bwd_c<CPL, FE == 0 ? 0 : 20, T, (CPL == 2 && sizeof(T) == 4) ? 4 : 8, true>), grid, block, 0, stream, t_rowptr, t_dst, \
                            t_eid, n_src, rowptr_dst, x_src, ldx, c_in, edge_attr, lde, We, be, phi, ldphi, da, ldda, dx_src, lddx, dphi_out, lddphi, \
                            partials, rw, add, ldadd, n_add, dphi_ext);                                                \
+    else if (chunked && FE == 20 && !dx_src && no_dx_form())                                                          \
+        hipLaunchKernelGGL((k_agg_bwd_c<CPL, FE == 20 ? 20 : 1, T, (CPL == 2 && sizeof(T) == 4) ? 4 : 8, false, false>), grid, block, 0, stream, t_rowptr, \
+                           t_dst, t_eid, n_src, rowptr_dst, x_src, ldx, c_in, edge_attr, lde, We, be, phi, ldphi, da, ldda, dx_src, lddx, dphi_out, \
+                           lddphi, partials, rw, (const T*)nullptr, (int64_t)0, (int64_t)0, dphi_ext);                \
     else if (chunked)                                                                                                 \
         hipLaunchKernelGGL((k_agg_bwd_c<CPL, FE, T, (CPL == 2 && sizeof(T) == 4) ? 4 : 8>), grid, block, 0, stream, t_rowptr, t_dst, t_eid, n_src, \
                            rowptr_dst, x_src, ldx, c_in, edge_attr, lde, We, be, phi, ldphi, da, ldda, dx_src, lddx, dphi_out, lddphi, partials, rw, \

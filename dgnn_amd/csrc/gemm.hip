@@ -1703,9 +1703,22 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce_cat(WgradReduceDesc d) {
     wgrad_reduce_cat_phase(d, blockIdx.x, threadIdx.x, redf, redd, 1);
 }
 
-int wgrad_splits(int64_t M) {
+// Row splits of a weight gradient A^T B (A [M, n_a]).  n_a = 0: the upper bound the scratch sizes are computed from.
+// Round 6: the count follows the number of 64-row tiles of the OUTPUT along n_a -- every split writes an [n_a, n_b] partial matrix, and at the
+// reference's training widths 512 splits of a [1024, 2048] gradient were 4 GB of partials written and read back per layer (k_linear_wgrad_x3_cat
+// 165 us + k_reduce_layer 90 us of a 1.18 ms step); a gradient with many tiles fills the chip with far fewer splits.  It depends on (M, n_a) only, so
+// the separate and the merged launches of a layer's gradients still walk the same row splits (bit-identical results).
+int wgrad_splits(int64_t M, int n_a = 0) {
     int64_t s = dgnn_cdiv(M, 4 * RK);  // at least 128 rows per split
-    if (s > WGRAD_SPLITS) s = WGRAD_SPLITS;
+    int64_t cap = WGRAD_SPLITS;
+    if (n_a > 0) {
+        static const bool by_tiles = !(getenv("DGNN_WGRAD_SPLITS_BY_TILES") && getenv("DGNN_WGRAD_SPLITS_BY_TILES")[0] == '0');
+        if (by_tiles) {
+            cap = WGRAD_SPLITS / dgnn_cdiv(n_a, WT);
+            if (cap < 32) cap = 32;
+        }
+    }
+    if (s > cap) s = cap;
     return (int)(s < 1 ? 1 : s);
 }
 
@@ -1731,7 +1744,7 @@ extern "C" int dgnn_linear_fwd(const float* A1, int64_t lda1, int k1, const floa
 
 extern "C" int64_t dgnn_linear_wgrad_scratch_elems(int64_t M, int n_a, int n_b) {
     if (M < 0 || n_a <= 0 || n_b <= 0) return 1;
-    return (int64_t)wgrad_splits(M) * n_a * n_b;
+    return (int64_t)wgrad_splits(M, n_a) * n_a * n_b;
 }
 
 extern "C" int dgnn_linear_wgrad(const float* A, int64_t lda, int n_a, const float* B, int64_t ldb, int n_b, int64_t M,
@@ -1739,7 +1752,7 @@ extern "C" int dgnn_linear_wgrad(const float* A, int64_t lda, int n_a, const flo
     hipStream_t stream = (hipStream_t)stream_;
     DGNN_REQUIRE(M >= 0 && n_a > 0 && n_b > 0, DGNN_E_INVALID, "linear_wgrad: bad sizes");
     DGNN_REQUIRE(dW && partials && (M == 0 || (A && B)), DGNN_E_INVALID, "linear_wgrad: null pointer");
-    const int splits = wgrad_splits(M);
+    const int splits = wgrad_splits(M, n_a);
     const int64_t rps = dgnn_cdiv(dgnn_cdiv(M, splits), RK) * RK;
     dim3 grid((unsigned)dgnn_cdiv(n_a, WT), (unsigned)dgnn_cdiv(n_b, WT), splits);
     hipLaunchKernelGGL(k_linear_wgrad, grid, dim3(256), 0, stream, A, lda, n_a, B, ldb, n_b, M, rps < RK ? RK : rps, partials);
@@ -1788,7 +1801,7 @@ extern "C" int dgnn_linear_wgrad_bf16(const void* A, int a_f32, int64_t lda, int
     hipStream_t stream = (hipStream_t)stream_;
     DGNN_REQUIRE(M >= 0 && n_a > 0 && n_b > 0, DGNN_E_INVALID, "linear_wgrad_bf16: bad sizes");
     DGNN_REQUIRE(dW && partials && (M == 0 || (A && B)), DGNN_E_INVALID, "linear_wgrad_bf16: null pointer");
-    const int splits = wgrad_splits(M);
+    const int splits = wgrad_splits(M, n_a);
     int64_t rps = dgnn_cdiv(dgnn_cdiv(M, splits), RKB) * RKB;
     if (rps < RKB) rps = RKB;
     dim3 grid((unsigned)dgnn_cdiv(n_a, WT), (unsigned)dgnn_cdiv(n_b, WT), splits);
@@ -1932,7 +1945,7 @@ extern "C" int dgnn_linear_wgrad_x3(const float* A, int64_t lda, int n_a, const 
     hipStream_t stream = (hipStream_t)stream_;
     DGNN_REQUIRE(M >= 0 && n_a > 0 && n_b > 0, DGNN_E_INVALID, "linear_wgrad_x3: bad sizes");
     DGNN_REQUIRE(dW && partials && (M == 0 || (A && B)), DGNN_E_INVALID, "linear_wgrad_x3: null pointer");
-    const int splits = wgrad_splits(M);
+    const int splits = wgrad_splits(M, n_a);
     const int64_t rps = dgnn_cdiv(dgnn_cdiv(M, splits), XRK) * XRK;
     dim3 grid((unsigned)dgnn_cdiv(n_a, WT), (unsigned)dgnn_cdiv(n_b, WT), splits);
     hipLaunchKernelGGL(k_linear_wgrad_x3, grid, dim3(256), 0, stream, A, lda, n_a, B, ldb, n_b, M, rps < XRK ? XRK : rps, partials);
@@ -1944,7 +1957,7 @@ extern "C" int dgnn_linear_wgrad_x3(const float* A, int64_t lda, int n_a, const 
 // fp32 partials [splits][n_a][n_b1 + n_b2], then fp64 bias partials [splits][n_a] (8-byte aligned inside the float scratch)
 extern "C" int64_t dgnn_linear_wgrad_cat_scratch_elems(int64_t M, int n_a, int n_b1, int n_b2) {
     if (M < 0 || n_a <= 0 || n_b1 <= 0 || n_b2 < 0) return 4;
-    const int64_t splits = wgrad_splits(M);
+    const int64_t splits = wgrad_splits(M, n_a);
     return splits * n_a * (n_b1 + n_b2) + 2 * splits * n_a + 4;
 }
 
@@ -1954,7 +1967,7 @@ int dgnn_linear_wgrad_x3_cat_deferred(const float* A, int64_t lda, int n_a, cons
     DGNN_REQUIRE(M >= 0 && n_a > 0 && n_b1 > 0 && n_b2 >= 0, DGNN_E_INVALID, "linear_wgrad_x3_cat: bad sizes");
     DGNN_REQUIRE(dW1 && scratch && (M == 0 || (A && B1)) && ((n_b2 == 0) == (B2 == nullptr)) && (n_b2 == 0 || dW2), DGNN_E_INVALID,
                  "linear_wgrad_x3_cat: null pointer");
-    const int splits = wgrad_splits(M);
+    const int splits = wgrad_splits(M, n_a);
     const int64_t rps = dgnn_cdiv(dgnn_cdiv(M, splits), XRK) * XRK;
     const int nby1 = (int)dgnn_cdiv(n_b1, WT), nby2 = (int)dgnn_cdiv(n_b2, WT);
     float* partials = scratch;
@@ -1986,7 +1999,7 @@ int dgnn_linear_wgrad_bf16_cat_deferred(const void* A, int a_f32, int64_t lda, i
     DGNN_REQUIRE(M >= 0 && n_a > 0 && n_b1 > 0 && n_b2 >= 0, DGNN_E_INVALID, "linear_wgrad_bf16_cat: bad sizes");
     DGNN_REQUIRE(dW1 && scratch && (M == 0 || (A && B1)) && ((n_b2 == 0) == (B2 == nullptr)) && (n_b2 == 0 || dW2), DGNN_E_INVALID,
                  "linear_wgrad_bf16_cat: null pointer");
-    const int splits = wgrad_splits(M);
+    const int splits = wgrad_splits(M, n_a);
     int64_t rps = dgnn_cdiv(dgnn_cdiv(M, splits), RKB) * RKB;
     if (rps < RKB) rps = RKB;
     const int nby1 = (int)dgnn_cdiv(n_b1, WT), nby2 = (int)dgnn_cdiv(n_b2, WT);

@@ -147,16 +147,20 @@ inline bool colreduce4_ok(int c) {
     return c >= V && ((c <= 64 * V && (c & (c - 1)) == 0) || c % (64 * V) == 0);
 }
 
-// Deterministic two-level finalisers: 1024 threads = 16 columns x 64 slices; slice s sums partial blocks s, s+64, ... in
-// ascending order, then the 64 slice sums are added in slice order.  (A single thread per column walking all ~1000 partial
+// Deterministic two-level finalisers: 1024 threads = COLS columns x (1024 / COLS) slices; slice s sums partial blocks s, s + slices, ... in
+// ascending order, then the slice sums are added in slice order.  (A single thread per column walking all ~1000 partial
 // blocks was a 80-90 us dependent-load chain -- 30 % of a training step; 16 slices still left a 64-long chain, 10-20 us.)
-constexpr int FIN_SLICES = 64, FIN_THREADS = 16 * FIN_SLICES;
+// COLS = 16 (64 slices): the form of rounds 2-5.  COLS = 4 (256 slices), round 6, for many partial rows: a 64-channel layer's 4 400 partial rows (the
+// GEMM epilogue leaves one per 32 rows of a 140k-cell block) were read by FOUR workgroups, 15 us; with 4 columns per workgroup sixteen read them.
+constexpr int FIN_THREADS = 1024;
+template <int COLS>
 __device__ __forceinline__ bool finalize_pair(const double* __restrict__ partials, int nblk, int c, double& s, double& q) {
-    __shared__ double red[2][FIN_SLICES][17];
-    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4, col = blockIdx.x * 16 + o;
+    constexpr int SLICES = FIN_THREADS / COLS;
+    __shared__ double red[2][SLICES][COLS + 1];
+    const int o = threadIdx.x % COLS, sl = threadIdx.x / COLS, col = blockIdx.x * COLS + o;
     double ps = 0.0, pq = 0.0;
     if (col < c)
-        for (int b = sl; b < nblk; b += FIN_SLICES) {
+        for (int b = sl; b < nblk; b += SLICES) {
             ps += partials[((int64_t)b * 2 + 0) * c + col];
             pq += partials[((int64_t)b * 2 + 1) * c + col];
         }
@@ -166,21 +170,24 @@ __device__ __forceinline__ bool finalize_pair(const double* __restrict__ partial
     if (sl != 0 || col >= c) return false;
     s = 0.0;
     q = 0.0;
-    for (int k = 0; k < FIN_SLICES; ++k) {
+    for (int k = 0; k < SLICES; ++k) {
         s += red[0][k][o];
         q += red[1][k][o];
     }
     return true;
 }
+inline int fin_cols(int nblk) { return nblk >= 512 ? 4 : 16; }
 
+template <int COLS>
 __global__ void __launch_bounds__(FIN_THREADS) k_stats_finalize(const double* __restrict__ partials, int nblk, int64_t M, int c,
                                                         float* __restrict__ mean, float* __restrict__ var,
                                                         float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                        float* __restrict__ scale, float* __restrict__ shift) {
+                                                        float* __restrict__ scale, float* __restrict__ shift, int64_t* __restrict__ nbt) {
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;      // num_batches_tracked of this BatchNorm (was a launch of its own per forward)
     double s, q;
-    if (!finalize_pair(partials, nblk, c, s, q)) return;
-    const int col = blockIdx.x * 16 + (threadIdx.x & 15);
+    if (!finalize_pair<COLS>(partials, nblk, c, s, q)) return;
+    const int col = blockIdx.x * COLS + (threadIdx.x % COLS);
     const double m = s / (double)M;
     double v = q / (double)M - m * m;
     if (v < 0.0) v = 0.0;
@@ -200,16 +207,33 @@ __global__ void __launch_bounds__(FIN_THREADS) k_stats_finalize(const double* __
 }
 
 // sums[0][c] = first quantity, sums[1][c] = second (float), optional accumulate into out0/out1
+template <int COLS>
 __global__ void __launch_bounds__(FIN_THREADS) k_sum_finalize(const double* __restrict__ partials, int nblk, int c, float* __restrict__ out0,
                                                       float* __restrict__ out1, int accumulate, float* __restrict__ copy0,
                                                       float* __restrict__ copy1) {
     double s, q;
-    if (!finalize_pair(partials, nblk, c, s, q)) return;
-    const int col = blockIdx.x * 16 + (threadIdx.x & 15);
+    if (!finalize_pair<COLS>(partials, nblk, c, s, q)) return;
+    const int col = blockIdx.x * COLS + (threadIdx.x % COLS);
     if (out0) out0[col] = accumulate ? out0[col] + (float)s : (float)s;
     if (out1) out1[col] = accumulate ? out1[col] + (float)q : (float)q;
     if (copy0) copy0[col] = (float)s;  // second destination (dbeta / dgamma of the caller) instead of two memcpy launches
     if (copy1) copy1[col] = (float)q;
+}
+
+static void launch_stats_finalize(hipStream_t stream, const double* P, int nblk, int64_t M, int c, float* mean, float* var, float* rmean, float* rvar,
+                                  float momentum, const float* gamma, const float* beta, float eps, float* scale, float* shift, int64_t* nbt) {
+    if (fin_cols(nblk) == 4)
+        hipLaunchKernelGGL(k_stats_finalize<4>, dim3((c + 3) / 4), dim3(FIN_THREADS), 0, stream, P, nblk, M, c, mean, var, rmean, rvar, momentum, gamma, beta, eps,
+                           scale, shift, nbt);
+    else
+        hipLaunchKernelGGL(k_stats_finalize<16>, dim3((c + 15) / 16), dim3(FIN_THREADS), 0, stream, P, nblk, M, c, mean, var, rmean, rvar, momentum, gamma, beta,
+                           eps, scale, shift, nbt);
+}
+static void launch_sum_finalize(hipStream_t stream, const double* P, int nblk, int c, float* out0, float* out1, int accumulate, float* copy0, float* copy1) {
+    if (fin_cols(nblk) == 4)
+        hipLaunchKernelGGL(k_sum_finalize<4>, dim3((c + 3) / 4), dim3(FIN_THREADS), 0, stream, P, nblk, c, out0, out1, accumulate, copy0, copy1);
+    else
+        hipLaunchKernelGGL(k_sum_finalize<16>, dim3((c + 15) / 16), dim3(FIN_THREADS), 0, stream, P, nblk, c, out0, out1, accumulate, copy0, copy1);
 }
 
 __global__ void k_bn_fold(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
@@ -309,8 +333,7 @@ static int bn_batch_stats_t(const T* x, int64_t ldx, int64_t M, int c, float* me
     const int64_t rpb = dgnn_cdiv(M, nblk);
     double* P = as_f64(scratch);
     launch_colreduce<0, T>(nblk, stream, x, ldx, (const T*)nullptr, (int64_t)0, (const T*)nullptr, (int64_t)0, nullptr, nullptr, 0.f, 0, M, c, rpb, P);
-    hipLaunchKernelGGL(k_stats_finalize, dim3((c + 15) / 16), dim3(FIN_THREADS), 0, stream, P, nblk, M, c, mean, var, running_mean,
-                       running_var, momentum, gamma, beta, eps, scale, shift);
+    launch_stats_finalize(stream, P, nblk, M, c, mean, var, running_mean, running_var, momentum, gamma, beta, eps, scale, shift, nullptr);
     return dgnn_check_launch("bn_batch_stats");
 }
 
@@ -335,7 +358,7 @@ static int bn_relu_bwd_t(const T* x, int64_t ldx, const T* y, int64_t ldy, const
     double* P = as_f64(scratch);
     float* sums = reinterpret_cast<float*>(P + (int64_t)nblk * 2 * c);
     launch_colreduce<1, T>(nblk, stream, x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, rpb, P);
-    hipLaunchKernelGGL(k_sum_finalize, dim3((c + 15) / 16), dim3(FIN_THREADS), 0, stream, P, nblk, c, sums, sums + c, 0, dbeta, dgamma);
+    launch_sum_finalize(stream, P, nblk, c, sums, sums + c, 0, dbeta, dgamma);
     hipLaunchKernelGGL((k_bn_relu_bwd_apply<T>), dim3(dgnn_grid_cap(dgnn_cdiv(M * c, 256))), dim3(256), 0, stream, x, ldx, y, ldy, dy, lddy,
                        gamma, mean, var, eps, train, relu, M, c, sums, sums + c, dx, lddx, 1.0f / (float)M);
     return dgnn_check_launch("bn_relu_bwd");
@@ -350,7 +373,7 @@ static int bn_relu_bwd_sums_f32(const float* x, int64_t ldx, const float* y, int
     const int64_t rpb = dgnn_cdiv(M, nblk);
     double* P = as_f64(scratch);
     launch_colreduce<1, float>(nblk, stream, x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, rpb, P);
-    hipLaunchKernelGGL(k_sum_finalize, dim3((c + 15) / 16), dim3(FIN_THREADS), 0, stream, P, nblk, c, sums, sums + c, 0, (float*)nullptr, (float*)nullptr);
+    launch_sum_finalize(stream, P, nblk, c, sums, sums + c, 0, (float*)nullptr, (float*)nullptr);
     return dgnn_check_launch("bn_relu_bwd_sums");
 }
 
@@ -361,8 +384,7 @@ static int colsum_t(const T* x, int64_t ldx, int64_t M, int c, float* out, int a
     const int64_t rpb = dgnn_cdiv(M, nblk);
     double* P = as_f64(scratch);
     launch_colreduce<2, T>(nblk, stream, x, ldx, (const T*)nullptr, (int64_t)0, (const T*)nullptr, (int64_t)0, nullptr, nullptr, 0.f, 0, M, c, rpb, P);
-    hipLaunchKernelGGL(k_sum_finalize, dim3((c + 15) / 16), dim3(FIN_THREADS), 0, stream, P, nblk, c, out, (float*)nullptr, accumulate,
-                       (float*)nullptr, (float*)nullptr);
+    launch_sum_finalize(stream, P, nblk, c, out, (float*)nullptr, accumulate, (float*)nullptr, (float*)nullptr);
     return dgnn_check_launch("colsum");
 }
 
@@ -384,8 +406,16 @@ extern "C" int dgnn_bn_stats_finalize_fold(const double* colstats, int64_t nblk,
                                            float* shift, void* stream) {
     DGNN_REQUIRE(colstats && nblk > 0 && M > 0 && c > 0 && mean && var, DGNN_E_INVALID, "bn_stats_finalize_fold: bad arguments");
     DGNN_REQUIRE((scale == nullptr) == (shift == nullptr), DGNN_E_INVALID, "bn_stats_finalize_fold: scale / shift must come together");
-    hipLaunchKernelGGL(k_stats_finalize, dim3((c + 15) / 16), dim3(FIN_THREADS), 0, (hipStream_t)stream, colstats, (int)nblk, M, c, mean, var, running_mean,
-                       running_var, momentum, gamma, beta, eps, scale, shift);
+    launch_stats_finalize((hipStream_t)stream, colstats, (int)nblk, M, c, mean, var, running_mean, running_var, momentum, gamma, beta, eps, scale, shift, nullptr);
+    return dgnn_check_launch("bn_stats_finalize_fold");
+}
+// ... that also counts the batch: *num_batches_tracked += 1 (NULL: no counter) -- library-internal (csrc/train.hip): the whole-model training forward
+// no longer launches a kernel of its own for the counters
+int dgnn_bn_stats_finalize_fold_nbt(const double* colstats, int64_t nblk, int64_t M, int c, float* mean, float* var, float* running_mean, float* running_var,
+                                    float momentum, const float* gamma, const float* beta, float eps, float* scale, float* shift, int64_t* nbt, void* stream) {
+    DGNN_REQUIRE(colstats && nblk > 0 && M > 0 && c > 0 && mean && var, DGNN_E_INVALID, "bn_stats_finalize_fold: bad arguments");
+    DGNN_REQUIRE((scale == nullptr) == (shift == nullptr), DGNN_E_INVALID, "bn_stats_finalize_fold: scale / shift must come together");
+    launch_stats_finalize((hipStream_t)stream, colstats, (int)nblk, M, c, mean, var, running_mean, running_var, momentum, gamma, beta, eps, scale, shift, nbt);
     return dgnn_check_launch("bn_stats_finalize_fold");
 }
 extern "C" int dgnn_bn_batch_stats_bf16(const uint16_t* x, int64_t ldx, int64_t M, int c, float* mean, float* var,

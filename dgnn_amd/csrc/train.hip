@@ -118,12 +118,34 @@ extern "C" int64_t dgnn_sage_layer_train_scratch_elems(int64_t n_src, int64_t n_
     return align4(n_dst * c_out) + 2 * align4(n_dst * c_in) + 2 * align4((int64_t)c_in * c_out) + align4(big) + align4(big > wc ? big : wc) + 64;
 }
 
+// library-internal (csrc/norm.hip): dgnn_bn_stats_finalize_fold that also counts the batch in *nbt
+int dgnn_bn_stats_finalize_fold_nbt(const double* colstats, int64_t nblk, int64_t M, int c, float* mean, float* var, float* running_mean, float* running_var,
+                                    float momentum, const float* gamma, const float* beta, float eps, float* scale, float* shift, int64_t* nbt, void* stream);
+
+// nbt / counted: the BatchNorm's num_batches_tracked and whether this call has counted the batch in it (the finalising launch of the statistics does
+// when they come out of the GEMM's epilogue -- round 6; otherwise the caller still has to)
+static int layer_train_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x, int64_t ldx, int c_in,
+                           const float* edge_attr, int64_t lde, int f_e, const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
+                           int c_out, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, int relu,
+                           float* a, float* z, float* mean, float* var, float* scale, float* shift, float* y, float* scratch, int gemm_mode, void* stream,
+                           int64_t* nbt, bool* counted);
+
 extern "C" int dgnn_sage_layer_train_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x,
                                          int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e, const float* We,
                                          const float* be, const float* Wj, const float* bj, const float* Wi, int c_out, const float* gamma,
                                          const float* beta, float* running_mean, float* running_var, float momentum, float eps, int relu,
                                          float* a, float* z, float* mean, float* var, float* scale, float* shift, float* y, float* scratch,
                                          int gemm_mode, void* stream) {
+    return layer_train_fwd(rowptr, src, eid, n_dst, x, ldx, c_in, edge_attr, lde, f_e, We, be, Wj, bj, Wi, c_out, gamma, beta, running_mean, running_var, momentum,
+                           eps, relu, a, z, mean, var, scale, shift, y, scratch, gemm_mode, stream, nullptr, nullptr);
+}
+
+static int layer_train_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x, int64_t ldx, int c_in,
+                           const float* edge_attr, int64_t lde, int f_e, const float* We, const float* be, const float* Wj, const float* bj, const float* Wi,
+                           int c_out, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, int relu,
+                           float* a, float* z, float* mean, float* var, float* scale, float* shift, float* y, float* scratch, int gemm_mode, void* stream,
+                           int64_t* nbt, bool* counted) {
+    if (counted) *counted = false;
     DGNN_REQUIRE(n_dst > 0 && c_in > 0 && c_out > 0, DGNN_E_INVALID, "sage_layer_train_fwd: bad sizes (BatchNorm needs at least one row)");
     DGNN_REQUIRE(x && Wj && z && mean && var && scale && shift && y && scratch, DGNN_E_INVALID, "sage_layer_train_fwd: null pointer");
     const float* A1 = x;
@@ -140,8 +162,9 @@ extern "C" int dgnn_sage_layer_train_fwd(const int32_t* rowptr, const int32_t* s
         double* cs = reinterpret_cast<double*>(((uintptr_t)scratch + 7) & ~(uintptr_t)7);
         const int rc = dgnn_linear_fwd_x3_stats(A1, lda1, c_in, Wj, c_in, A2, ldx, A2 ? c_in : 0, A2 ? Wi : nullptr, c_in, bj, n_dst, c_out, z, c_out, cs, stream);
         if (rc == DGNN_OK) {
-            TRY(dgnn_bn_stats_finalize_fold(cs, (n_dst + 31) / 32, n_dst, c_out, mean, var, running_mean, running_var, momentum, gamma, beta, eps, scale, shift,
-                                            stream));
+            TRY(dgnn_bn_stats_finalize_fold_nbt(cs, (n_dst + 31) / 32, n_dst, c_out, mean, var, running_mean, running_var, momentum, gamma, beta, eps, scale,
+                                                shift, nbt, stream));
+            if (counted) *counted = nbt != nullptr;
             TRY(dgnn_scale_shift_act(z, c_out, scale, shift, relu, n_dst, c_out, y, c_out, stream));
             return DGNN_OK;
         }
@@ -582,6 +605,7 @@ extern "C" int dgnn_static_train_fwd(int n_layers, const int32_t* const* rowptr,
                  DGNN_E_INVALID, "static_train_fwd: bad args (at most 8 layers)");
     const float* x = x0;
     int64_t ldx = ldx0;
+    unsigned counted_mask = 0;
     for (int l = 0; l < n_layers; ++l) {
         const int c_in = widths[l], c_out = widths[l + 1];
         float* st = stats[l];
@@ -595,16 +619,23 @@ extern "C" int dgnn_static_train_fwd(int n_layers, const int32_t* const* rowptr,
             ldx = c_out;
             continue;
         }
-        TRY(dgnn_sage_layer_train_fwd(rowptr[l], src[l], eid[l], n_dst[l], x, ldx, c_in, edge_attr[l], lde[l], We[l] ? f_e : 0, We[l], be[l], Wj[l], bj[l],
-                                      Wi[l], c_out, gamma[l], beta[l], running_mean[l], running_var[l], momentum[l], eps[l], 1, a[l], z[l], st, st + c_out,
-                                      st + 2 * c_out, st + 3 * c_out, y[l], scratch, gemm_mode, stream));
+        bool counted = false;
+        TRY(layer_train_fwd(rowptr[l], src[l], eid[l], n_dst[l], x, ldx, c_in, edge_attr[l], lde[l], We[l] ? f_e : 0, We[l], be[l], Wj[l], bj[l],
+                            Wi[l], c_out, gamma[l], beta[l], running_mean[l], running_var[l], momentum[l], eps[l], 1, a[l], z[l], st, st + c_out,
+                            st + 2 * c_out, st + 3 * c_out, y[l], scratch, gemm_mode, stream, num_batches_tracked ? num_batches_tracked[l] : nullptr, &counted));
+        if (counted) counted_mask |= 1u << l;
         x = y[l];
         ldx = c_out;
     }
     if (num_batches_tracked) {
+        // the counters the statistics' finalising launches have not already stepped (round 6: in the default arithmetic every BatchNorm's has been)
         Ptr8 ps;
-        for (int l = 0; l < 8; ++l) ps.p[l] = l < n_layers ? num_batches_tracked[l] : nullptr;
-        hipLaunchKernelGGL(k_inc_i64, dim3(1), dim3(64), 0, (hipStream_t)stream, ps, n_layers);
+        int left = 0;
+        for (int l = 0; l < 8; ++l) {
+            ps.p[l] = (l < n_layers && !((counted_mask >> l) & 1u)) ? num_batches_tracked[l] : nullptr;
+            left += ps.p[l] != nullptr;
+        }
+        if (left) hipLaunchKernelGGL(k_inc_i64, dim3(1), dim3(64), 0, (hipStream_t)stream, ps, n_layers);
     }
     return dgnn_check_launch("static_train_fwd");
 }

@@ -72,6 +72,17 @@ class Metrics:
             acc.add_(sums)
         self._host["samples_sum"] += samples
 
+    def packedAccumulator(self, device, samples):
+        """the device fp64 [cell_sum, weight_sum, OA_sum] accumulator itself, for a kernel that adds a batch's sums into it (ops.kl_cell_loss_step:
+        the loss launch does addPacked's add); `samples` rows are counted here"""
+        acc = self._dev.get("_packed")
+        if acc is None or acc.device != torch.device(device):
+            if acc is not None:
+                self._flush_packed()
+            acc = self._dev["_packed"] = torch.zeros(3, dtype=torch.float64, device=device)
+        self._host["samples_sum"] += samples
+        return acc
+
     _PACKED = ("cell_sum", "weight_sum", "OA_sum")
 
     def _flush_packed(self):
@@ -105,6 +116,7 @@ class Metrics:
 
 
 TRAIN_DIRECT = __import__("os").environ.get("DGNN_TRAIN_DIRECT", "1") != "0"
+KL_LOSS_ONE_LAUNCH = __import__("os").environ.get("DGNN_KL_LOSS_ONE_LAUNCH", "1") != "0"
 
 
 def make_adam(params, lr):
@@ -196,7 +208,10 @@ class Trainer:
     def _all_training(self):
         """model.train() (reference :266) writes the flag of ~40 modules through nn.Module.__setattr__ on every step; when every flag is
         already set it has nothing to do -- reading them costs a fifth of that."""
-        for m in self.model.modules():
+        mods = self.__dict__.get("_mods")
+        if mods is None or mods[0] is not self.model:
+            mods = self.__dict__["_mods"] = (self.model, list(self.model.modules()))      # (modules() walks the tree: 40 us a step)
+        for m in mods[1]:
             if not m.training:
                 return False
         return True
@@ -286,6 +301,12 @@ class Trainer:
             if logits.dim() != 2 or logits.size(1) != 2 or logits.size(0) != n_sup:
                 raise RuntimeError("train: the model returned %s logits for %d targets" % (tuple(logits.shape), n_sup))
             vol = data_train.batch_x[:, 0]
+            if KL_LOSS_ONE_LAUNCH and hasattr(metrics, "packedAccumulator"):
+                # forward, the metric sums' accumulation and the gradient in one launch (round 6; same bits as the calls below)
+                got = Fn.ops.kl_cell_loss_step(logits, data_train.batch_gt, vol, norm, running=metrics.packedAccumulator(logits.device, 0))
+                if got is not None:
+                    metrics.packedAccumulator(logits.device, n_sup)
+                    return got[0], got[2]
             loss, sums = Fn.ops.kl_cell_loss_fwd(logits, data_train.batch_gt, vol, norm)
             metrics.addPacked(sums, n_sup)
             return loss, Fn.ops.kl_cell_loss_bwd(logits, data_train.batch_gt, vol, norm, sums, one)

@@ -271,14 +271,20 @@ class SurfaceNet(nn.Module):
         from .. import ops
         if not (ops.TRAIN_COMPOSITE and ops.TRAIN_WHOLE_MODEL) or x.dtype != torch.float32 or self.num_layers + 2 > 8:
             return None
-        dec = self.decoder if self.clf.model.decoder else ()
+        # the module tree is read once per model (nn.Module.__getattr__ / Sequential.__getitem__ for every layer were a sixth of the step's host
+        # time, round 6); `invalidate_caches()` after replacing a sub-module
+        mods = self.__dict__.get("_train_mods")
+        if mods is None:
+            dec_ = tuple(self.decoder) if self.clf.model.decoder else ()
+            mods = self.__dict__["_train_mods"] = (dec_, [(self.convs[i][0], self.convs[i][1] if len(self.convs[i]) > 1 else None) for i in range(self.num_layers)])
+        dec, conv_mods = mods
         if len(dec) not in (0, 4) or (len(dec) == 4 and not isinstance(dec[1], BatchNorm)):
             return None
         ea_all = data.all.edge_attr
         spec, n_src = [], x.size(0)
         for i in range(self.num_layers):
             edge_index, e_id, size = data.batch_adjs[i]
-            conv, norm = self.convs[i][0], self.convs[i][1] if len(self.convs[i]) > 1 else None
+            conv, norm = conv_mods[i]
             if not isinstance(norm, BatchNorm) or not Fn.sage_train_layer_supported(x, conv.lin_e, norm.module) or size[0] != n_src:
                 return None
             plan = plan_for(edge_index.to(dev), size[0], size[1])
@@ -319,29 +325,46 @@ class SurfaceNet(nn.Module):
         if built is None or built[1] is not None or len(built[0]) <= self.num_layers:
             return None
         spec = built[0]
+        # what a layer's table holds of the MODEL (its parameters): read through the modules once, reused while the same modules come back
+        static = self.__dict__.get("_direct_static")
+        mods_now = tuple(id(sp[k]) for sp in spec for k in ("lin_e", "lin_j", "lin_i", "bn"))
+        if static is None or static[0] != mods_now:
+            tabs = []
+            for sp in spec:
+                le, lj, li, bn = sp["lin_e"], sp["lin_j"], sp["lin_i"], sp["bn"]
+                tabs.append(dict(We=le.weight if le is not None else None, be=le.bias if le is not None else None, Wj=lj.weight, bj=lj.bias,
+                                 Wi=li.weight if li is not None else None, gamma=bn.weight if bn is not None else None,
+                                 beta=bn.bias if bn is not None else None, bn=bn))
+            static = self.__dict__["_direct_static"] = (mods_now, tabs)
         layers = []
-        for sp in spec:
-            le, lj, li, bn, plan = sp["lin_e"], sp["lin_j"], sp["lin_i"], sp["bn"], sp["plan"]
-            layers.append(dict(plan_parts=plan.part_ptrs(bool(sp["scene_rows"])) if plan is not None else None,
-                               n_dst=plan.n_dst if plan is not None else sp["n_rows"], n_src=plan.n_src if plan is not None else sp["n_rows"],
-                               edge_attr=sp["edge_attr"] if le is not None else None, We=le.weight if le is not None else None,
-                               be=le.bias if le is not None else None, Wj=lj.weight, bj=lj.bias, Wi=li.weight if li is not None else None,
-                               gamma=bn.weight if bn is not None else None, beta=bn.bias if bn is not None else None, bn=bn))
+        for sp, st_ in zip(spec, static[1]):
+            plan = sp["plan"]
+            l = dict(st_)
+            if plan is not None:
+                l["plan_parts"], l["n_dst"], l["n_src"] = plan.part_ptrs(bool(sp["scene_rows"])), plan.n_dst, plan.n_src
+            else:
+                l["plan_parts"], l["n_dst"], l["n_src"] = None, sp["n_rows"], sp["n_rows"]
+            l["edge_attr"] = sp["edge_attr"] if st_["We"] is not None else None
+            layers.append(l)
         with torch.no_grad():
             logits, buf, meta = ops.static_train_fwd(x, layers)
             loss, dlogits = loss_fn(logits)
             for l, sp in zip(layers, spec):
                 if sp["plan"] is not None:
                     l["t_parts"] = sp["plan"].transposed_ptrs(bool(sp["scene_rows"]))
-            grads = ops.static_train_bwd(x, layers, buf, meta, dlogits)
+            grads = ops.static_train_bwd(x, layers, buf, meta, dlogits, keep=self.__dict__.setdefault("_grad_keep", {}) if ops.TRAIN_KEEP_GRADS else None)
         written = set()
         for l, g in zip(layers, grads):
             for name, gr in zip(("We", "be", "Wj", "bj", "Wi", "gamma", "beta"), g):
                 p_ = l[name]
                 if p_ is not None and p_.requires_grad:
-                    p_.grad = gr
+                    if p_.grad is not gr:       # (kept gradient tensors: assigned once, rewritten in place by every step)
+                        p_.grad = gr
                     written.add(id(p_))
-        for p_ in self.parameters():          # what zero_grad + backward leave: a trainable parameter this step did not reach has NO gradient
+        plist = self.__dict__.get("_param_list")      # (nn.Module.parameters() walks the module tree: 50 us a step)
+        if plist is None:
+            plist = self.__dict__["_param_list"] = list(self.parameters())
+        for p_ in plist:          # what zero_grad + backward leave: a trainable parameter this step did not reach has NO gradient
             if p_.requires_grad and p_.grad is not None and id(p_) not in written:       # (a stale one from an earlier autograd step would be applied by Adam)
                 p_.grad = None
         return loss.detach()
@@ -436,7 +459,7 @@ class SurfaceNet(nn.Module):
 
     def invalidate_caches(self):
         """Forget everything derived from the parameters (folded BatchNorm, prepared layer blocks, the one-call tables): after replacing a sub-module."""
-        for k in ("_oc_tables", "_fold_cache", "_prep_cache"):
+        for k in ("_oc_tables", "_fold_cache", "_prep_cache", "_train_mods", "_direct_static", "_param_list", "_grad_keep"):
             self.__dict__.pop(k, None)
 
     def _infer_one_call(self, x, xe, edge_index, plan):

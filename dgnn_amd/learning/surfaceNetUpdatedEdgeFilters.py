@@ -163,7 +163,7 @@ class SurfaceNet(nn.Module):
             x = Fn.linear2(x, self.out_net[3].weight, bias=self.out_net[3].bias, out_f32=True)
         return x.float() if x.dtype == torch.bfloat16 else x
 
-    def _conv_stack(self, x, edge_attr, adjs, dev, plus):
+    def _conv_stack(self, x, edge_attr, adjs, dev, plus, spec_only=False):
         """All conv layers and the edge chaining between them through ONE library call each way (Fn.updated_conv_stack) when every layer takes the
         composite form: sparse chaining, no output normalisation, lin_e with a bias, even widths in bf16 storage.  Returns the last layer's
         activations, or None (the per-layer path then runs)."""
@@ -195,7 +195,67 @@ class SurfaceNet(nn.Module):
                 and self.out_net[1].bias is not None and self.out_net[3].bias is not None and self.out_net[1].in_features == c:
             out_net = (self.out_net[1], self.out_net[3])       # :245-247 inside the same library-call pair; fp32 logits come back
             self._stack_did_tail = True
+        if spec_only:
+            return spec, out_net
         return Fn.updated_conv_stack(x, edge_attr, self._chain_table(edge_attr.size(0), dev), spec, out_net)
+
+    @torch.no_grad()
+    def train_step_direct(self, data_all, loss_fn):
+        """Forward, loss and backward of ONE training step without the autograd engine (round 6; reference learning/runModel.py:266-279 on this model's
+        forward :216-251): the conv stack's and the output network's library calls each way are issued directly around
+        `loss_fn(logits) -> (loss, dlogits)`, and every parameter's .grad is SET to its fresh gradient (what zero_grad + backward leave).  The same
+        kernels in the same order as the autograd node (functional._UpdatedConvStack): the same numbers (tests/test_gpu_train.py).  The engine --
+        its worker-thread hand-over, the node bookkeeping, three Function.apply calls -- was 0.15 ms of a 0.85 ms host-bound step.
+        Returns the detached loss, or None when the model does not take the one-call form with the output network inside (the caller then runs
+        forward() / backward())."""
+        from .. import ops
+        dev = self.clf.temp.device
+        if not str(dev).startswith("cuda") or self.clf.training.model_name[-1] != "+":
+            return None
+        f = self.clf.features
+        x_all = data_all.x
+        n_id = data_all.n_id.to(x_all.device)
+        from ..sampler import block_rows
+        col0 = 1 if (f.normalization_feature and not f.keep_normalization_feature) else 0
+        x = block_rows(n_id, x_all, col0, x_all.size(1) - col0, "all") if x_all.dim() == 2 else None
+        if x is None:
+            x = x_all[n_id, 1:] if col0 else x_all[n_id, :]
+        x = _dev_f32(x, dev)
+        if self.storage_dtype == torch.bfloat16 and x.dtype != torch.bfloat16:
+            x = ops.cast_to_bf16(x, x.size(1) if x.size(1) % 2 == 0 else None)[:, :x.size(1)]      # (= Fn.to_bf16's forward)
+        edge_attr = _dev_f32(data_all.edge_attr, dev)
+        self._stack_did_tail = False
+        built = self._conv_stack(x, edge_attr, data_all.adjs, dev, True, spec_only=True)
+        if built is None or built[1] is None:
+            return None
+        spec, (lin1, lin3) = built
+        layers = []
+        for sp in spec:
+            le, ll, lr = sp["lin_e"], sp["lin_l"], sp["lin_r"]
+            layers.append(dict(plan=sp["plan"], e_id=sp["e_id"], rows0=sp.get("rows0"), edge_in=sp["edge_in"], relu=sp["relu"], We=le.weight, be=le.bias,
+                               Wl=ll.weight, bl=ll.bias, Wr=lr.weight if lr is not None else None))
+        y, saved = ops.updated_stack_fwd(x, edge_attr, self._chain_table(edge_attr.size(0), dev), layers)
+        logits, h = ops.updated_tail_fwd(y, lin1.weight, lin1.bias, lin3.weight, lin3.bias)
+        loss, dlogits = loss_fn(logits)
+        dy, dW1, db1, dW3, db3 = ops.updated_tail_bwd(y, lin1.weight, lin3.weight, h, dlogits if dlogits.dtype == torch.float32 else dlogits.float())
+        grads = ops.updated_stack_bwd(x, layers, saved, dy)
+        written = set()
+
+        def put(p_, g_):
+            if p_ is not None and g_ is not None and p_.requires_grad:
+                p_.grad = g_
+                written.add(id(p_))
+        for l, g in zip(layers, grads):
+            for name, gr in zip(("We", "be", "Wl", "bl", "Wr"), g):
+                put(l[name], gr)
+        put(lin1.weight, dW1), put(lin1.bias, db1), put(lin3.weight, dW3), put(lin3.bias, db3)
+        plist = self.__dict__.get("_param_list")
+        if plist is None:
+            plist = self.__dict__["_param_list"] = list(self.parameters())
+        for p_ in plist:          # a trainable parameter this step did not reach has NO gradient (what zero_grad + backward leave)
+            if p_.requires_grad and p_.grad is not None and id(p_) not in written:
+                p_.grad = None
+        return loss.detach()
 
     def _unsupported(self, *a, **k):
         raise NotImplementedError("the reference's surfaceNetUpdatedEdgeFilters.inference_* methods call the conv without "

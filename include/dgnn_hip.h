@@ -565,6 +565,11 @@ int dgnn_kl_cell_loss_fwd(const float* logits, int64_t ldl, const float* gt, int
                           double* sums, float* loss, double* scratch, void* stream);
 int dgnn_kl_cell_loss_bwd(const float* logits, int64_t ldl, const float* gt, int64_t ldg, const float* vol, int64_t ldv, int norm, int64_t n,
                           const double* sums, const float* grad_loss, float* dlogits, int64_t ldd, void* stream);
+/* forward + (running += sums) + backward of one batch as ONE launch (round 6; the step around learning/runModel.py:171-209 and its gradient, with the
+ * metric sums of :48-80 accumulated on the device): the same bits as dgnn_kl_cell_loss_fwd followed by dgnn_kl_cell_loss_bwd.  grad_loss NULL = 1;
+ * running (fp64 [3]) and dlogits may be NULL.  DGNN_E_UNSUPPORTED (nothing launched) for n > 65536: use the two entry points above. */
+int dgnn_kl_cell_loss_step(const float* logits, int64_t ldl, const float* gt, int64_t ldg, const float* vol, int64_t ldv, int norm, int64_t n,
+                           const float* grad_loss, double* sums, float* loss, double* running, float* dlogits, int64_t ldd, void* stream);
 
 /* Fused decoder, eval mode (reference :180-187 applied at :350-351):
  *   logits = W3 . relu((W0 . y + b0) * scale + shift) + b3,   y [M,k] -> out [M,n_out]

@@ -651,6 +651,62 @@ def test_direct_training_step_equals_the_autograd_step():
         assert torch.equal(out[True][2][k], out[False][2][k]), k
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_updated_direct_training_step_equals_the_autograd_step(dtype):
+    """Round 6: the Updated model's step without the autograd engine (SurfaceNet.train_step_direct: the conv stack's and the output network's library
+    calls issued directly around the one-launch kl loss) against forward() + the fused loss + backward() on the same blocks (reference
+    learning/surfaceNetUpdatedEdgeFilters.py:216-251, learning/runModel.py:264-282): loss, every gradient and every parameter after three Adam steps,
+    bit for bit (same kernels in the same order), in fp32 and in bf16 storage; and the one-launch loss against its two-launch form."""
+    import dgnn_amd.learning.runModel as RM
+    from dgnn_amd import functional as Fn
+    from dgnn_amd import ops
+    from dgnn_amd.learning.surfaceNetUpdatedEdgeFilters import SurfaceNet as Updated
+    from dgnn_amd.sampler import NeighborSampler
+    from dgnn_amd.synthetic import delaunay_tet_graph, hashed_normal
+    adj, _, _ = delaunay_tet_graph(4000, seed=13)
+    n = adj.shape[0] // 4
+    ei = torch.from_numpy(adj.T.astype(np.int64)).to(DEV)
+    x = hashed_normal(np.arange(n), 29, seed=1, device=DEV)
+    x[:, 0] = x[:, 0].abs() + 0.05
+    ea = hashed_normal(np.arange(4 * n), 20, seed=2, device=DEV)
+    occ = torch.sigmoid(2 * x[:, 3:4] + x[:, 7:8])
+    y = torch.cat([occ, 1 - occ], 1)
+    ucfg = Config.wrap(dict(training=dict(model_params=[64, 128, 128, 128], model_name="sage+", loss="kl"),
+                            features=dict(normalization_feature=1, keep_normalization_feature=0), temp=dict(device=DEV)))
+    out = {}
+    for direct in (True, False):
+        torch.manual_seed(3)
+        net = Updated(28, ucfg).to(DEV).train().set_storage_dtype(dtype)
+        opt = RM.make_adam(net.parameters(), 0.005)
+        loader = NeighborSampler(ei, sizes=[-1] * 4, node_idx=torch.arange(0, 3 * 256, device=DEV), num_nodes=n, batch_size=256)
+        losses = []
+        for bs, n_id, adjs in loader:
+            ids = n_id[:bs]
+            by, vol = y[ids], x[ids, 0]
+            d = Config(x=x, edge_attr=ea, n_id=n_id, adjs=adjs)
+            if direct:
+                def loss_fn(logits):
+                    got = ops.kl_cell_loss_step(logits, by, vol, 0)
+                    l2, s2 = ops.kl_cell_loss_fwd(logits, by, vol, 0)               # the one-launch loss == the two-launch loss, bit for bit
+                    g2 = ops.kl_cell_loss_bwd(logits, by, vol, 0, s2, torch.ones((), device=DEV))
+                    assert torch.equal(got[0], l2) and torch.equal(got[1], s2) and torch.equal(got[2], g2)
+                    return got[0], got[2]
+                loss = net.train_step_direct(d, loss_fn)
+                assert loss is not None
+            else:
+                opt.zero_grad()
+                loss, _ = Fn.kl_cell_loss(net(d).float(), by, vol)
+                loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        out[direct] = (losses, {k: v.detach().clone() for k, v in net.state_dict().items()}, {k: p.grad.clone() for k, p in net.named_parameters()})
+    assert out[True][0] == out[False][0]
+    for k in out[False][1]:
+        assert torch.equal(out[True][1][k], out[False][1][k]), k
+    for k in out[False][2]:
+        assert torch.equal(out[True][2][k], out[False][2][k]), k
+
+
 @pytest.mark.parametrize("model", ["static", "updated"])
 def test_block_builder_gathers_the_step_rows_and_the_run_is_the_same(model):
     """NeighborSampler.attach_rows (Trainer.attach_block_rows): x[n_id, 1:], x[ids], y[ids] come out of the block builder -- equal to indexing, for every

@@ -83,9 +83,25 @@ if args.updated:
 
     class _Tr:   # the reference's loss (runModel.py:171-211) on the Updated model's (x, edge_attr, n_id, adjs) batch layout
         def train(self, data, opt, clf, group=None):
-            opt.zero_grad()
-            logits = net(Config(x=data.all.x, edge_attr=data.all.edge_attr, n_id=data.batch_n_id, adjs=data.batch_adjs)).float()
             from dgnn_amd import functional as Fn
+            d_u = Config(x=data.all.x, edge_attr=data.all.edge_attr, n_id=data.batch_n_id, adjs=data.batch_adjs)
+            if os.environ.get("DGNN_TRAIN_DIRECT", "1") != "0":
+                # the step without the autograd engine (round 6: SurfaceNet.train_step_direct of the Updated model; same kernels, same numbers)
+                bx, by = Trainer._batch_rows(data, data.batch_adjs[-1][2][1])
+
+                def loss_fn(logits):
+                    got = Fn.ops.kl_cell_loss_step(logits, by, bx[:, 0], 0)
+                    if got is None:
+                        loss_, sums_ = Fn.ops.kl_cell_loss_fwd(logits, by, bx[:, 0], 0)
+                        return loss_, Fn.ops.kl_cell_loss_bwd(logits, by, bx[:, 0], 0, sums_, torch.ones((), device=logits.device))
+                    return got[0], got[2]
+                loss = net.train_step_direct(d_u, loss_fn)
+                if loss is not None:
+                    allreduce_gradients(net, group)
+                    opt.step()
+                    return loss
+            opt.zero_grad()
+            logits = net(d_u).float()
             bx, by = Trainer._batch_rows(data, data.batch_adjs[-1][2][1])            # x[ids], y[ids]: from the block builder when it gathered them
             loss, _ = Fn.kl_cell_loss(logits, by, bx[:, 0])   # the Trainer's fused loss (runModel.py:171-209)
             loss.backward()

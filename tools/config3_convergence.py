@@ -54,13 +54,21 @@ def run(widths=(128, 256, 512, 1024), batch=1024, steps=300, points=10000, windo
         loader = NeighborSampler(ei, sizes=[-1] * 4, node_idx=idx, num_nodes=n, batch_size=batch, shuffle=False)
         losses = []
         for bs, n_id, adjs in loader:
-            opt.zero_grad()
-            logits = net(Config(x=x, edge_attr=ea, n_id=n_id, adjs=adjs)).float()
             ids = n_id[:bs]
-            loss, _ = Fn.kl_cell_loss(logits, y[ids], x[ids, 0])          # the Trainer's fused loss (runModel.py:171-209)
-            loss.backward()
+            by, vol = y[ids], x[ids, 0]
+
+            def loss_fn(logits):          # the Trainer's fused loss (runModel.py:171-209) and its gradient
+                got = Fn.ops.kl_cell_loss_step(logits, by, vol, 0)
+                return got[0], got[2]
+            loss = net.train_step_direct(Config(x=x, edge_attr=ea, n_id=n_id, adjs=adjs), loss_fn)
+            if loss is None:              # (a configuration the one-call form does not take: the autograd path)
+                opt.zero_grad()
+                logits = net(Config(x=x, edge_attr=ea, n_id=n_id, adjs=adjs)).float()
+                loss, _ = Fn.kl_cell_loss(logits, by, vol)
+                loss.backward()
+                loss = loss.detach()
             opt.step()
-            losses.append(loss.detach())
+            losses.append(loss)
         curves[name] = torch.stack(losses).double().cpu().numpy()
         del net, opt, loader
     k = (steps // window) * window
