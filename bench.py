@@ -555,7 +555,7 @@ def main():
 
         def step():
             return scene.inference_layer(net)
-        if backend == "nccl" and not rings:
+        if (backend == "nccl" or os.environ.get("DGNN_BENCH_SAFETY_NET") == "1") and not rings:
             # Safety net: if the device-to-device exchange cannot run on this node (P2P/IPC disabled ...), every rank sees the
             # error in its first step; all ranks then agree to stage the halo rows through host memory over gloo, and the
             # JSON line says so.  Compute is unchanged.
@@ -1058,7 +1058,7 @@ def main():
         def exchange_leg(points_x, label):
             sc_x = PartitionedScene.build_synthetic(points_x, 0, rank, world, dev, keep_global=True, halo="exchange", hops=net.num_layers)
             tr_x = "host-staged %s (validation run, not a benchmark)" % backend
-            if backend == "nccl":
+            if backend == "nccl" or os.environ.get("DGNN_BENCH_SAFETY_NET") == "1":
                 failed_x = 0
                 try:
                     sc_x.inference_layer(net)

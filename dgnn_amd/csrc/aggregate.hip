@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(256) k_agg_bwd_c(const int32_t* __restrict__ t
                                                    const float* __restrict__ We, const float* __restrict__ be, const T* __restrict__ phi,
                                                    int64_t ldphi, const T* __restrict__ da, int64_t ldda, T* __restrict__ dx, int64_t lddx,
                                                    T* __restrict__ dphi_out, int64_t lddphi, float* __restrict__ slabs, int rows_per_chunk,
-                                                   const T* __restrict__ add, int64_t ldadd, int64_t n_add, const T* __restrict__ dphi_ext) {
+                                                   const T* __restrict__ add, int64_t ldadd, int64_t n_add, const T* __restrict__ dphi_ext, int mask_dx) {
     constexpr int NW = FE > 0 ? FE : 1;
     // ADD: the addend rows of a chunk are parked in the wavefront's part of `red` (the slab region when the filter is fused, a region of its own
     // in the given-phi form, which has no slabs).  dphi_ext (given-phi form): dphi_out[e] = dphi_e + dphi_ext[e] -- the gradient the NEXT layer sent
@@ -388,6 +388,12 @@ __global__ void __launch_bounds__(256) k_agg_bwd_c(const int32_t* __restrict__ t
                     Vec<CPL, T> o;
 #pragma unroll
                     for (int j = 0; j < CPL; ++j) o.v[j] = (ADD && rb + cur < n_add) ? __fadd_rn(acc[j], park[cur * CPL + j]) : acc[j];
+                    if (mask_dx) {   // the ReLU behind the layer below (x = relu(y_below) is this layer's input): dx * [x > 0], see k_agg_bwd_g
+                        Vec<CPL, T> xm;
+                        xm.load(x + (rb + cur) * ldx + c0);
+#pragma unroll
+                        for (int j = 0; j < CPL; ++j) o.v[j] = xm.v[j] > 0.f ? o.v[j] : 0.f;
+                    }
                     o.store(dx + (rb + cur) * lddx + c0);
                 }
 #pragma unroll
@@ -526,7 +532,9 @@ __global__ void __launch_bounds__(256) k_agg_bwd_g(const int32_t* __restrict__ t
                                                    int64_t n_src, const int32_t* __restrict__ rowptr_dst, const T* __restrict__ x, int64_t ldx, int c_in,
                                                    const T* __restrict__ phi, int64_t ldphi, const T* __restrict__ da, int64_t ldda, T* __restrict__ dx,
                                                    int64_t lddx, T* __restrict__ dphi_out, int64_t lddphi, int rows_per_chunk, const T* __restrict__ add,
-                                                   int64_t ldadd, int64_t n_add) {
+                                                   int64_t ldadd, int64_t n_add, int mask_dx) {
+    // mask_dx (round 6): dx[row] *= [x[row] > 0] at the store -- the ReLU between the layer below and this one (this layer's input x IS relu(y_below),
+    // so the mask is in the row the kernel already holds): the Updated stack's k_relu_bwd launch per layer is gone.
     constexpr int R = 64 / G;
     const int lane = lane_id(), g = lane / G, c0 = 4 * (lane % G);
     const bool on = c0 < c_in;
@@ -554,7 +562,7 @@ __global__ void __launch_bounds__(256) k_agg_bwd_g(const int32_t* __restrict__ t
             V4<T> xs, av;
 #pragma unroll
             for (int j = 0; j < 4; ++j) xs.v[j] = av.v[j] = 0.f;
-            if (on && deg > 0) xs.load(x + row * ldx + c0);
+            if (on && (deg > 0 || (mask_dx && rv))) xs.load(x + row * ldx + c0);
             const bool has_add = ADD && rv && row < n_add;
             if (has_add && on) av.load(add + row * ldadd + c0);
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -606,6 +614,10 @@ __global__ void __launch_bounds__(256) k_agg_bwd_g(const int32_t* __restrict__ t
                 V4<T> o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o.v[j] = has_add ? __fadd_rn(acc[j], av.v[j]) : acc[j];
+                if (mask_dx) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o.v[j] = xs.v[j] > 0.f ? o.v[j] : 0.f;
+                }
                 o.store(dx + row * lddx + c0);
             }
         }
@@ -869,8 +881,9 @@ int agg_bwd_t(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
               const T* x_src, int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e, const float* We, const float* be,
               const T* phi, int64_t ldphi, const T* da, int64_t ldda, T* dx_src, int64_t lddx, float* dWe, float* dbe, T* dphi_out,
               int64_t lddphi, float* partials, hipStream_t stream, const T* add = nullptr, int64_t ldadd = 0, int64_t n_add = 0,
-              SlabReduceDesc* deferred = nullptr, const T* dphi_ext = nullptr) {
+              SlabReduceDesc* deferred = nullptr, const T* dphi_ext = nullptr, int mask_dx = 0) {
     DGNN_REQUIRE(n_src >= 0 && c_in > 0, DGNN_E_INVALID, "aggregate_bwd: bad sizes");
+    DGNN_REQUIRE(!mask_dx || (dx_src && agg_chunked()), DGNN_E_UNSUPPORTED, "aggregate_bwd: the masked dx store lives in the chunked kernels");
     if (n_src == 0) {   // nothing to sum: the parameter gradients are zero (they are written, not accumulated, otherwise)
         if (We && dWe && dbe) {
             (void)hipMemsetAsync(dWe, 0, sizeof(float) * (size_t)c_in * f_e, stream);
@@ -901,10 +914,10 @@ int agg_bwd_t(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
 #define LAUNCH_G(GG)                                                                                                                          \
         do { if (add)                                                                                                                         \
             hipLaunchKernelGGL((k_agg_bwd_g<GG, T, true>), ggrid, dim3(256), 0, stream, t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, ldx, c_in, phi, \
-                               ldphi, da, ldda, dx_src, lddx, dphi_out, lddphi, rw, add, ldadd, n_add);                                      \
+                               ldphi, da, ldda, dx_src, lddx, dphi_out, lddphi, rw, add, ldadd, n_add, mask_dx);                             \
         else                                                                                                                                  \
             hipLaunchKernelGGL((k_agg_bwd_g<GG, T, false>), ggrid, dim3(256), 0, stream, t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, ldx, c_in, phi, \
-                               ldphi, da, ldda, dx_src, lddx, dphi_out, lddphi, rw, (const T*)nullptr, (int64_t)0, (int64_t)0); } while (0)
+                               ldphi, da, ldda, dx_src, lddx, dphi_out, lddphi, rw, (const T*)nullptr, (int64_t)0, (int64_t)0, mask_dx); } while (0)
         if (c_in <= 32) LAUNCH_G(8);
         else if (c_in <= 64) LAUNCH_G(16);
         else LAUNCH_G(32);
@@ -918,15 +931,15 @@ int agg_bwd_t(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
     do { if (chunked && add && (FE == 20 || FE == 0))                                                                 \
         hipLaunchKernelGGL((k_agg_bwd_c<CPL, FE == 0 ? 0 : 20, T, (CPL == 2 && sizeof(T) == 4) ? 4 : 8, true>), grid, block, 0, stream, t_rowptr, t_dst, \
                            t_eid, n_src, rowptr_dst, x_src, ldx, c_in, edge_attr, lde, We, be, phi, ldphi, da, ldda, dx_src, lddx, dphi_out, lddphi, \
-                           partials, rw, add, ldadd, n_add, dphi_ext);                                                \
+                           partials, rw, add, ldadd, n_add, dphi_ext, mask_dx);                                       \
     else if (chunked && FE == 20 && !dx_src && no_dx_form())                                                          \
         hipLaunchKernelGGL((k_agg_bwd_c<CPL, FE == 20 ? 20 : 1, T, (CPL == 2 && sizeof(T) == 4) ? 4 : 8, false, false>), grid, block, 0, stream, t_rowptr, \
                            t_dst, t_eid, n_src, rowptr_dst, x_src, ldx, c_in, edge_attr, lde, We, be, phi, ldphi, da, ldda, dx_src, lddx, dphi_out, \
-                           lddphi, partials, rw, (const T*)nullptr, (int64_t)0, (int64_t)0, dphi_ext);                \
+                           lddphi, partials, rw, (const T*)nullptr, (int64_t)0, (int64_t)0, dphi_ext, mask_dx);       \
     else if (chunked)                                                                                                 \
         hipLaunchKernelGGL((k_agg_bwd_c<CPL, FE, T, (CPL == 2 && sizeof(T) == 4) ? 4 : 8>), grid, block, 0, stream, t_rowptr, t_dst, t_eid, n_src, \
                            rowptr_dst, x_src, ldx, c_in, edge_attr, lde, We, be, phi, ldphi, da, ldda, dx_src, lddx, dphi_out, lddphi, partials, rw, \
-                           (const T*)nullptr, (int64_t)0, (int64_t)0, dphi_ext);                                      \
+                           (const T*)nullptr, (int64_t)0, (int64_t)0, dphi_ext, mask_dx);                             \
     else                                                                                                              \
         hipLaunchKernelGGL((k_agg_bwd<CPL, FE, T>), grid, block, 0, stream, t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, ldx, \
                            c_in, edge_attr, lde, We, be, phi, ldphi, da, ldda, dx_src, lddx, dphi_out, lddphi, partials); } while (0)
@@ -1014,16 +1027,27 @@ int dgnn_sage_aggregate_bwd_add_deferred(const int32_t* t_rowptr, const int32_t*
 
 // given-phi form (Updated variant) with the two additions of a conv layer's backward folded into the stores: dx_src[row] += add[row] for
 // row < n_add (add may be NULL), dphi_out[e] = dphi_e + dphi_ext[e] (dphi_ext may be NULL).  bf16: storage 1, fp32: 0.
-extern "C" int dgnn_sage_aggregate_bwd_phi_add(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, int64_t n_src, const int32_t* rowptr_dst,
-                                               const void* x_src, int64_t ldx, int c_in, const void* phi, int64_t ldphi, const void* da, int64_t ldda,
-                                               void* dx_src, int64_t lddx, const void* add, int64_t ldadd, int64_t n_add, void* dphi_out, int64_t lddphi,
-                                               const void* dphi_ext, int bf16, void* stream) {
+// library-internal (csrc/train.hip): dgnn_sage_aggregate_bwd_phi_add whose dx store also applies the ReLU mask of the layer below, dx * [x_src > 0]
+// (mask_dx != 0; needs the chunked kernels: dgnn_agg_bwd_can_mask()).
+bool dgnn_agg_bwd_can_mask() { return agg_chunked(); }
+int dgnn_sage_aggregate_bwd_phi_add_masked(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, int64_t n_src, const int32_t* rowptr_dst,
+                                           const void* x_src, int64_t ldx, int c_in, const void* phi, int64_t ldphi, const void* da, int64_t ldda,
+                                           void* dx_src, int64_t lddx, const void* add, int64_t ldadd, int64_t n_add, void* dphi_out, int64_t lddphi,
+                                           const void* dphi_ext, int bf16, int mask_dx, void* stream) {
     DGNN_REQUIRE(n_add >= 0 && n_add <= n_src, DGNN_E_INVALID, "aggregate_bwd_phi_add: bad addend");
     if (bf16)
         return agg_bwd_t<uint16_t>(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, (const uint16_t*)x_src, ldx, c_in, nullptr, 0, 0, nullptr, nullptr,
                                    (const uint16_t*)phi, ldphi, (const uint16_t*)da, ldda, (uint16_t*)dx_src, lddx, nullptr, nullptr, (uint16_t*)dphi_out, lddphi,
-                                   nullptr, (hipStream_t)stream, (const uint16_t*)add, ldadd, n_add, nullptr, (const uint16_t*)dphi_ext);
+                                   nullptr, (hipStream_t)stream, (const uint16_t*)add, ldadd, n_add, nullptr, (const uint16_t*)dphi_ext, mask_dx);
     return agg_bwd_t<float>(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, (const float*)x_src, ldx, c_in, nullptr, 0, 0, nullptr, nullptr, (const float*)phi, ldphi,
                             (const float*)da, ldda, (float*)dx_src, lddx, nullptr, nullptr, (float*)dphi_out, lddphi, nullptr, (hipStream_t)stream,
-                            (const float*)add, ldadd, n_add, nullptr, (const float*)dphi_ext);
+                            (const float*)add, ldadd, n_add, nullptr, (const float*)dphi_ext, mask_dx);
+}
+
+extern "C" int dgnn_sage_aggregate_bwd_phi_add(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, int64_t n_src, const int32_t* rowptr_dst,
+                                               const void* x_src, int64_t ldx, int c_in, const void* phi, int64_t ldphi, const void* da, int64_t ldda,
+                                               void* dx_src, int64_t lddx, const void* add, int64_t ldadd, int64_t n_add, void* dphi_out, int64_t lddphi,
+                                               const void* dphi_ext, int bf16, void* stream) {
+    return dgnn_sage_aggregate_bwd_phi_add_masked(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x_src, ldx, c_in, phi, ldphi, da, ldda, dx_src, lddx, add, ldadd, n_add,
+                                                  dphi_out, lddphi, dphi_ext, bf16, 0, stream);
 }

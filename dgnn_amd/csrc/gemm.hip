@@ -313,17 +313,22 @@ __global__ void __launch_bounds__(256) k_linear_fwd_b(const uint16_t* __restrict
 // 0.3 ms in 22 such launches).  Like k_linear_fwd_x3_small, ONE WAVEFRONT owns a 32 x 32 output block and takes its fragments straight from
 // global memory in the MFMA's layout (A: 8 consecutive bf16 of a row = one 16-byte load; W: 8 fp32 rounded to bf16 in registers), four k-steps
 // of loads in flight, no LDS, no barrier.  k-steps in k_linear_fwd_b's order: bit-identical results.
-template <typename TO>
+// SPLITK (round 6; K = k1 + k2 >= 1024, the reference's training widths): the four wavefronts of a workgroup share ONE 32 x 32 output block, each walks a
+// quarter of every operand pair's k-steps, the three partial blocks cross LDS and wavefront 0 adds them in wavefront order and runs the epilogue.  One
+// wavefront walking 64+ k-steps behind four loads in flight was a 25-50 us dependent chain per launch at M <= 16k whatever the chip had free (the
+// modelnet-width step spent 280-350 us in these launches).  Another summation order than the tiled kernels' -- fp32 rounding level, used only for K >= 1024.
+template <typename TO, bool SPLITK = false>
 __global__ void __launch_bounds__(256) k_linear_fwd_b_small(const uint16_t* __restrict__ A1, int64_t lda1, int k1, const float* __restrict__ W1,
                                                             int64_t ldw1, bool va1, bool vw1, const uint16_t* __restrict__ A2, int64_t lda2, int k2,
                                                             const float* __restrict__ W2, int64_t ldw2, bool va2, bool vw2,
                                                             const float* __restrict__ bias, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int relu, int64_t M, int n_out, TO* __restrict__ out,
                                                             int64_t ldo) {
+    __shared__ float splitk_red[SPLITK ? 3 * 16 * 64 : 1];
     const int lane = lane_id(), w = wave_id_uniform();
     const int h = lane >> 5, l31 = lane & 31;
     const int nct = (n_out + 31) / 32;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + w;
+    const int64_t tile = SPLITK ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 4 + w;
     const int64_t rt = tile / nct;
     const int ct = (int)(tile - rt * nct);
     if (rt * 32 >= M) return;
@@ -340,7 +345,9 @@ __global__ void __launch_bounds__(256) k_linear_fwd_b_small(const uint16_t* __re
         const bool va = part == 0 ? va1 : va2, vw = part == 0 ? vw1 : vw2;
         const uint16_t* ap = A + rowc * (part == 0 ? lda1 : lda2) + 8 * h;
         const float* wp = W + (int64_t)colc * (part == 0 ? ldw1 : ldw2) + 8 * h;
-        const int nst = (kk + 15) / 16;
+        const int nst_all = (kk + 15) / 16;
+        const int q_ = (nst_all + 3) / 4;
+        const int st0 = SPLITK ? w * q_ : 0, nst = SPLITK ? (st0 + q_ < nst_all ? st0 + q_ : nst_all) : nst_all;
         struct Frag {
             uint4 a;
             f32x4 w0, w1;
@@ -373,7 +380,7 @@ __global__ void __launch_bounds__(256) k_linear_fwd_b_small(const uint16_t* __re
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
         };
         Frag r0, r1, r2, r3;
-        for (int st = 0; st < nst; st += 4) {
+        for (int st = st0; st < nst; st += 4) {
             load_step(r0, st);
             if (st + 1 < nst) load_step(r1, st + 1);
             if (st + 2 < nst) load_step(r2, st + 2);
@@ -383,6 +390,18 @@ __global__ void __launch_bounds__(256) k_linear_fwd_b_small(const uint16_t* __re
             if (st + 2 < nst) mul_step(r2);
             if (st + 3 < nst) mul_step(r3);
         }
+    }
+    if (SPLITK) {
+        if (w > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) splitk_red[((w - 1) * 16 + r) * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (w > 0) return;
+#pragma unroll
+        for (int ww = 0; ww < 3; ++ww)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += splitk_red[(ww * 16 + r) * 64 + lane];
     }
     if (col < n_out) {
         const float bb = bias ? bias[col] : 0.f;
@@ -903,16 +922,19 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_x3_n64(const float* __res
 // 32 x 32 output block and takes both operands straight from global memory in the MFMA's own layout (a lane's fragment is 8 consecutive
 // k of one row: two 16-byte loads), splitting them in registers: no LDS, no barrier, four k-steps of loads in flight, 4 x as many
 // independent workgroup slots.  k-steps and products in the order of k_linear_fwd_x3: bit-identical results.
+// SPLITK: as k_linear_fwd_b_small<., true> -- the workgroup's four wavefronts share one output block, a quarter of the k-steps each (K >= 1024 only)
+template <bool SPLITK>
 __global__ void __launch_bounds__(256) k_linear_fwd_x3_small(const float* __restrict__ A1, int64_t lda1, int k1, const float* __restrict__ W1,
                                                              int64_t ldw1, bool vec1, const float* __restrict__ A2, int64_t lda2, int k2,
                                                              const float* __restrict__ W2, int64_t ldw2, bool vec2,
                                                              const float* __restrict__ bias, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, int relu, int64_t M, int n_out,
                                                              float* __restrict__ out, int64_t ldo, double* __restrict__ colstats) {
+    __shared__ float splitk_red[SPLITK ? 3 * 16 * 64 : 1];
     const int lane = lane_id(), w = wave_id_uniform();
     const int h = lane >> 5, l31 = lane & 31;
     const int nct = (n_out + 31) / 32;                      // column tiles; a workgroup = 4 consecutive (row tile, column tile) pairs
-    const int64_t tile = (int64_t)blockIdx.x * 4 + w;
+    const int64_t tile = SPLITK ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 4 + w;
     const int64_t rt = tile / nct;
     const int ct = (int)(tile - rt * nct);
     if (rt * 32 >= M) return;
@@ -930,7 +952,9 @@ __global__ void __launch_bounds__(256) k_linear_fwd_x3_small(const float* __rest
         const bool vec = part == 0 ? vec1 : vec2;
         const float* ap = A + rowc * (part == 0 ? lda1 : lda2) + 8 * h;
         const float* wp = W + (int64_t)colc * (part == 0 ? ldw1 : ldw2) + 8 * h;
-        const int nst = (kk + 15) / 16;
+        const int nst_all = (kk + 15) / 16;
+        const int q_ = (nst_all + 3) / 4;
+        const int st0 = SPLITK ? w * q_ : 0, nst = SPLITK ? (st0 + q_ < nst_all ? st0 + q_ : nst_all) : nst_all;
         auto load_step = [&](f32x4 (&v)[4], int st) {      // v[0..1]: A k .. k+7, v[2..3]: W k .. k+7 (k = 16 st + 8 h)
             const int k0 = 16 * st;
             if (vec && k0 + 16 <= kk) {
@@ -976,7 +1000,7 @@ __global__ void __launch_bounds__(256) k_linear_fwd_x3_small(const float* __rest
         };
         // four k-steps of loads in flight
         f32x4 r0[4], r1[4], r2[4], r3[4];
-        for (int st = 0; st < nst; st += 4) {
+        for (int st = st0; st < nst; st += 4) {
             load_step(r0, st);
             if (st + 1 < nst) load_step(r1, st + 1);
             if (st + 2 < nst) load_step(r2, st + 2);
@@ -986,6 +1010,18 @@ __global__ void __launch_bounds__(256) k_linear_fwd_x3_small(const float* __rest
             if (st + 2 < nst) mul_step(r2);
             if (st + 3 < nst) mul_step(r3);
         }
+    }
+    if (SPLITK) {
+        if (w > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) splitk_red[((w - 1) * 16 + r) * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (w > 0) return;
+#pragma unroll
+        for (int ww = 0; ww < 3; ++ww)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += splitk_red[(ww * 16 + r) * 64 + lane];
     }
     {
         const float bb = bias ? bias[colc] : 0.f;
@@ -1776,6 +1812,17 @@ extern "C" int dgnn_linear_fwd_bf16(const uint16_t* A1, int64_t lda1, int k1, co
     const bool va1 = vec16(A1, lda1, 2), vw1 = vec16(W1, ldw1, 4);
     const bool va2 = A2 && vec16(A2, lda2, 2), vw2 = W2 && vec16(W2, ldw2, 4);
     static const bool small_ok = !(getenv("DGNN_BF16_SMALL") && getenv("DGNN_BF16_SMALL")[0] == '0');
+    static const bool splitk_ok = !(getenv("DGNN_SMALL_SPLITK") && getenv("DGNN_SMALL_SPLITK")[0] == '0');
+    if (small_ok && splitk_ok && M <= 16384 && k1 + (A2 ? k2 : 0) >= 1024) {   // four wavefronts per output block, a quarter of K each (see the kernel)
+        dim3 sgrid((unsigned)(dgnn_cdiv(M, 32) * dgnn_cdiv(n_out, 32)));
+        if (out_f32)
+            hipLaunchKernelGGL((k_linear_fwd_b_small<float, true>), sgrid, dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, va1, vw1, A2, lda2, k2, W2,
+                               ldw2, va2, vw2, bias, scale, shift, relu, M, n_out, (float*)out, ldo);
+        else
+            hipLaunchKernelGGL((k_linear_fwd_b_small<uint16_t, true>), sgrid, dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, va1, vw1, A2, lda2, k2,
+                               W2, ldw2, va2, vw2, bias, scale, shift, relu, M, n_out, (uint16_t*)out, ldo);
+        return dgnn_check_launch("linear_fwd_bf16");
+    }
     if (small_ok && M <= 16384) {   // same k order per output element: identical results
         dim3 sgrid((unsigned)dgnn_cdiv(dgnn_cdiv(M, 32) * dgnn_cdiv(n_out, 32), 4));
         if (out_f32)
@@ -1847,8 +1894,13 @@ int linear_fwd_x3_impl(const float* A1, int64_t lda1, int k1, const float* W1, i
     static const int64_t small_m = getenv("DGNN_X3_SMALL_M") ? atoll(getenv("DGNN_X3_SMALL_M")) : 16384;
     if (small_ok && M <= small_m) {
         const int64_t tiles = dgnn_cdiv(M, 32) * dgnn_cdiv(n_out, 32);
-        hipLaunchKernelGGL(k_linear_fwd_x3_small, dim3((unsigned)dgnn_cdiv(tiles, 4)), dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2, lda2,
-                           k2, W2, ldw2, v2, bias, scale, shift, relu, M, n_out, out, ldo, colstats);
+        static const bool splitk_ok = !(getenv("DGNN_SMALL_SPLITK") && getenv("DGNN_SMALL_SPLITK")[0] == '0');
+        if (splitk_ok && k1 + (A2 ? k2 : 0) >= 1024)
+            hipLaunchKernelGGL(k_linear_fwd_x3_small<true>, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2, lda2,
+                               k2, W2, ldw2, v2, bias, scale, shift, relu, M, n_out, out, ldo, colstats);
+        else
+            hipLaunchKernelGGL(k_linear_fwd_x3_small<false>, dim3((unsigned)dgnn_cdiv(tiles, 4)), dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2,
+                               lda2, k2, W2, ldw2, v2, bias, scale, shift, relu, M, n_out, out, ldo, colstats);
         return dgnn_check_launch("linear_fwd_x3");
     }
     static const bool n64_ok = !(getenv("DGNN_X3_N64") && getenv("DGNN_X3_N64")[0] == '0');

@@ -106,7 +106,22 @@ struct dgnn_halo_plan {
     size_t stage_bytes;
 };
 
-extern "C" int dgnn_rccl_available(void) { return rccl().handle != nullptr; }
+// Fault injection for the tests of the agreed fall-backs (tests/test_gpu_multi.py; VERDICT r5 item 8: the failure branches of communicator creation had
+// only ever seen their success side): DGNN_FAULT_<POINT> = "all" or a rank as in $RANK (torch.distributed.run sets it) makes that point fail there.
+//   DGNN_FAULT_RCCL_UNAVAILABLE   dgnn_rccl_available() says no
+//   DGNN_FAULT_COMM_CREATE        dgnn_comm_create fails BEFORE ncclCommInitRank (use "all": a lone rank that stays out leaves its peers in the collective)
+//   DGNN_FAULT_COMM_CREATE_AFTER  dgnn_comm_create joins ncclCommInitRank, destroys what it got and fails (a one-rank failure on a multi-GPU box)
+//   DGNN_FAULT_HALO_PLAN          dgnn_halo_plan_create fails
+// Never set outside tests.
+static bool fault_here(const char* name) {
+    const char* v = getenv(name);
+    if (!v || !*v) return false;
+    if (!strcmp(v, "all")) return true;
+    const char* r = getenv("RANK");
+    return r && !strcmp(v, r);
+}
+
+extern "C" int dgnn_rccl_available(void) { return rccl().handle != nullptr && !fault_here("DGNN_FAULT_RCCL_UNAVAILABLE"); }
 
 extern "C" int dgnn_comm_unique_id(void* id128) {
     DGNN_REQUIRE(id128, DGNN_E_INVALID, "comm_unique_id: null pointer");
@@ -121,11 +136,20 @@ extern "C" int dgnn_comm_create(const void* id128, int rank, int world, void** c
     DGNN_REQUIRE(id128 && comm_out && world >= 1 && rank >= 0 && rank < world, DGNN_E_INVALID, "comm_create: bad arguments");
     Rccl& r = rccl();
     DGNN_REQUIRE(r.handle, DGNN_E_UNSUPPORTED, "comm_create: RCCL unavailable: %s", r.why);
+    if (fault_here("DGNN_FAULT_COMM_CREATE")) {
+        dgnn_set_error("comm_create: injected fault (DGNN_FAULT_COMM_CREATE)");
+        return DGNN_E_LAUNCH;
+    }
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
     ncclComm_t comm = nullptr;
     const ncclResult_t rc = r.CommInitRank(&comm, world, id, rank);     // on the calling thread's current device
     if (rc != ncclSuccess) return rccl_fail("comm_create", rc);
+    if (fault_here("DGNN_FAULT_COMM_CREATE_AFTER")) {
+        (void)r.CommDestroy(comm);
+        dgnn_set_error("comm_create: injected fault (DGNN_FAULT_COMM_CREATE_AFTER)");
+        return DGNN_E_LAUNCH;
+    }
     *comm_out = comm;
     return DGNN_OK;
 }
@@ -150,6 +174,10 @@ extern "C" int dgnn_comm_count(void* comm) {
 extern "C" int dgnn_halo_plan_create(int rank, int world, int64_t n_own, const int32_t* send_idx, const int64_t* send_counts, const int64_t* recv_counts,
                                      dgnn_halo_plan** out) {
     DGNN_REQUIRE(out && world >= 1 && rank >= 0 && rank < world && n_own >= 0 && send_counts && recv_counts, DGNN_E_INVALID, "halo_plan_create: bad arguments");
+    if (fault_here("DGNN_FAULT_HALO_PLAN")) {
+        dgnn_set_error("halo_plan_create: injected fault (DGNN_FAULT_HALO_PLAN)");
+        return DGNN_E_LAUNCH;
+    }
     dgnn_halo_plan* p = new dgnn_halo_plan();
     p->rank = rank;
     p->world = world;

@@ -19,8 +19,19 @@ struct WgradReduceDesc {     // dW1 [na, nb1], dW2 [na, nb2] = sums over `splits
 
 constexpr int RS_SLICES = 64;   // reduce_slabs_block: 16 outputs x 64 slices = 1024 threads
 __host__ __device__ inline int slab_reduce_blocks(const SlabReduceDesc& d) { return (d.nchunks * d.per + 15) / 16; }
+// WIDE form of the matrix part (round 6): with few row splits and a large gradient (the reference's training widths: [1024, 1024 + 1024] elements,
+// 8-32 splits) the 16-outputs-per-256-threads form above launched 65 536 workgroups in which 16 x splits threads made one 4-byte load each (k_reduce_layer
+// 52 us for 33 MB).  Here a thread owns 4 consecutive outputs (one 16-byte load per split), 1024 outputs per 256 threads; the sum per output runs in
+// the SAME order (16 slices z = sl, sl + 16, ... each in ascending z from 0.f, the slice sums added in slice order from 0.f): bit-identical results.
+__host__ __device__ inline bool wgrad_reduce_wide(const WgradReduceDesc& d) {
+    return d.splits <= 64 && (int64_t)d.na * (d.nb1 + d.nb2) >= 32768 && d.nb1 % 4 == 0 && d.nb2 % 4 == 0 && (((uintptr_t)d.partials | (uintptr_t)d.dW1 | (uintptr_t)d.dW2) & 15) == 0;
+}
+__host__ __device__ inline int wgrad_reduce_mat_blocks(const WgradReduceDesc& d) {
+    const int nmat = d.na * (d.nb1 + d.nb2);
+    return wgrad_reduce_wide(d) ? (nmat + 1023) / 1024 : (nmat + 15) / 16;
+}
 __host__ __device__ inline int wgrad_reduce_blocks(const WgradReduceDesc& d) {   // blocks of 256 threads
-    return (d.na * (d.nb1 + d.nb2) + 15) / 16 + (d.dbias ? (d.na + 15) / 16 : 0);
+    return wgrad_reduce_mat_blocks(d) + (d.dbias ? (d.na + 15) / 16 : 0);
 }
 
 // one block of 1024 threads; `blk` = which 16 outputs.  Slice s adds slabs s, s + 64, ... in order, the 64 slice sums are added in slice order.
@@ -49,7 +60,23 @@ __device__ __forceinline__ void reduce_slabs_block(const SlabReduceDesc& d, int 
 // The caller synchronises: phase 0 fills the scratch, phase 1 (after a barrier) writes the results.
 __device__ __forceinline__ void wgrad_reduce_cat_phase(const WgradReduceDesc& d, int blk, int t, float (*redf)[17], double (*redd)[17], int phase) {
     const int o = t & 15, sl = t >> 4;
-    const int nbt = d.nb1 + d.nb2, nmat = d.na * nbt, nblk_mat = (nmat + 15) / 16;
+    const int nbt = d.nb1 + d.nb2, nmat = d.na * nbt, nblk_mat = wgrad_reduce_mat_blocks(d);
+    if (blk < nblk_mat && wgrad_reduce_wide(d)) {
+        if (phase == 0) return;
+        const int i = (blk * 256 + t) * 4;
+        if (i >= nmat) return;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int slc = 0; slc < 16 && slc < d.splits; ++slc) {
+            f4 p_ = {0.f, 0.f, 0.f, 0.f};
+            for (int z = slc; z < d.splits; z += 16) p_ += *reinterpret_cast<const f4*>(d.partials + (int64_t)z * nmat + i);
+            s += p_;
+        }
+        const int row = i / nbt, col = i - row * nbt;     // (nb1, nb2 multiples of 4: the four outputs sit in one matrix)
+        float* out = col < d.nb1 ? d.dW1 + (int64_t)row * d.nb1 + col : d.dW2 + (int64_t)row * d.nb2 + (col - d.nb1);
+        *reinterpret_cast<f4*>(out) = s;
+        return;
+    }
     if (blk < nblk_mat) {
         const int i = blk * 16 + o;
         const bool live = i < nmat;

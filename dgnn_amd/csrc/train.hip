@@ -436,13 +436,26 @@ int updated_fwd(const int32_t* rowptr, const int32_t* src, const int32_t* eid, i
     return DGNN_OK;
 }
 
+}  // namespace
+// library-internal (csrc/aggregate.hip)
+bool dgnn_agg_bwd_can_mask();
+int dgnn_sage_aggregate_bwd_phi_add_masked(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, int64_t n_src, const int32_t* rowptr_dst,
+                                           const void* x_src, int64_t ldx, int c_in, const void* phi, int64_t ldphi, const void* da, int64_t ldda,
+                                           void* dx_src, int64_t lddx, const void* add, int64_t ldadd, int64_t n_add, void* dphi_out, int64_t lddphi,
+                                           const void* dphi_ext, int bf16, int mask_dx, void* stream);
+namespace {
+
+// dy_is_dz: the caller's dy already carries this layer's ReLU mask (the layer above stored its dx masked): no k_relu_bwd launch.
+// want_mask / *masked: store dx with the mask of the layer BELOW (dx * [x > 0]; x is that layer's post-ReLU output) -- done in the fused chain only.
 template <typename K>
 int updated_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_eid, const int32_t* rowptr_dst, int64_t n_src, int64_t n_dst, int64_t E,
                 const void* x_, int64_t ldx, int c_in, const void* ea_, int64_t lde, int k_e, const float* We, const float* Wl, const float* Wr, int c_out,
                 int relu, const void* phi_, const void* a_, const void* y_, const void* dy_, const void* dphi_ext_, void* dx_, void* d_ea_, float* dWe,
-                float* dbe, float* dWl, float* dbl, float* dWr, void* dz_, void* da_, void* dphi_, float* scratch, int mode, void* st) {
+                float* dbe, float* dWl, float* dbl, float* dWr, void* dz_, void* da_, void* dphi_, float* scratch, int mode, void* st,
+                bool dy_is_dz = false, bool want_mask = false, bool* masked = nullptr) {
     typedef typename K::T T;
     hipStream_t stream = (hipStream_t)st;
+    if (masked) *masked = false;
     const T *x = (const T*)x_, *ea = (const T*)ea_, *phi = (const T*)phi_, *a = (const T*)a_, *y = (const T*)y_, *dy = (const T*)dy_,
             *dphi_ext = (const T*)dphi_ext_;
     T *dx = (T*)dx_, *d_ea = (T*)d_ea_, *dz = (T*)dz_, *da = (T*)da_, *dphi = (T*)dphi_;
@@ -461,11 +474,13 @@ int updated_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_
         (void)hipStreamWaitEvent(aux->stream, e, 0);
     };
     const T* g = dy;
-    if (relu) {
+    if (relu && !dy_is_dz) {
         TRY(K::relu_bwd(y, dy, n_dst * c_out, dz, st));
         g = dz;
     }
     if (!aux && fused_enabled() && K::can_fuse(mode)) {
+        const int mask_dx = (want_mask && dx && dgnn_agg_bwd_can_mask()) ? 1 : 0;
+        if (masked) *masked = mask_dx != 0;
         // The launch chain of the Static layer's fused backward (layer_bwd) for this variant: dWl / dWr / dbl from one launch pair, the three
         // transposes from one launch, [da | dz.Wr] from one GEMM against the stacked [Wl^T ; Wr^T] with the second half added where the
         // aggregate backward stores dx and dphi_ext added where it stores dphi, dWe / dbe from one launch pair.  `da` holds [n_dst, 2 c_in].
@@ -490,12 +505,12 @@ int updated_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_
         // it -- the fourth row load per edge cost the kernel 60 % (72 -> 115 us on the outermost block) against the 7-9 us of k_add_inplace)
         if (both) {
             TRY(K::linear(g, c_out, c_out, WlT, c_out, nullptr, 0, 0, nullptr, 0, nullptr, 0, n_dst, 2 * c_in, da, 2 * c_in, mode, st));
-            TRY(dgnn_sage_aggregate_bwd_phi_add(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x, ldx, c_in, phi, c_in, da, 2 * c_in, dx, c_in, da + c_in, 2 * c_in,
-                                                n_dst, dphi, c_in, nullptr, K::kBf16, st));
+            TRY(dgnn_sage_aggregate_bwd_phi_add_masked(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x, ldx, c_in, phi, c_in, da, 2 * c_in, dx, c_in, da + c_in,
+                                                       2 * c_in, n_dst, dphi, c_in, nullptr, K::kBf16, mask_dx, st));
         } else {
             TRY(K::linear(g, c_out, c_out, WlT, c_out, nullptr, 0, 0, nullptr, 0, nullptr, 0, n_dst, c_in, da, c_in, mode, st));
-            TRY(dgnn_sage_aggregate_bwd_phi_add(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x, ldx, c_in, phi, c_in, da, c_in, dx, c_in, nullptr, 0, 0, dphi, c_in,
-                                                nullptr, K::kBf16, st));
+            TRY(dgnn_sage_aggregate_bwd_phi_add_masked(t_rowptr, t_dst, t_eid, n_src, rowptr_dst, x, ldx, c_in, phi, c_in, da, c_in, dx, c_in, nullptr, 0, 0, dphi,
+                                                       c_in, nullptr, K::kBf16, mask_dx, st));
         }
         if (E > 0 && dphi_ext)
             hipLaunchKernelGGL((k_add_inplace<T>), dim3(dgnn_grid_cap(dgnn_cdiv(E * c_in, 256))), dim3(256), 0, stream, dphi, dphi_ext, E * c_in);
@@ -815,14 +830,26 @@ extern "C" int dgnn_updated_stack_bwd(int n_layers, const int32_t* const* t_rowp
                  DGNN_E_INVALID, "updated_stack_bwd: bad args");
     const void* g = dy;
     bool have_ext = false;
+    // round 6: a layer stores its dx already masked by the ReLU of the layer below (its own input x is that layer's post-ReLU output), so the layer below
+    // takes it as dz: one k_relu_bwd launch per inner layer less.  DGNN_UPDATED_MASK_DX=0: the launch chain of rounds 4-5.
+    static const bool mask_on = !(getenv("DGNN_UPDATED_MASK_DX") && getenv("DGNN_UPDATED_MASK_DX")[0] == '0');
+    bool g_masked = false;
     for (int l = n_layers - 1; l >= 0; --l) {
         const int c_in = widths[l], c_out = widths[l + 1], k = edge_in[l];
         const void* x = l == 0 ? x0 : y[l - 1];
         const int64_t ldx = l == 0 ? ldx0 : c_in;
         void* dx = l == 0 ? nullptr : dx_buf[l & 1];
-        TRY(dgnn_sage_updated_train_bwd(t_rowptr[l], t_dst[l], t_eid[l], rowptr_dst[l], n_src[l], n_dst[l], E[l], x, ldx, c_in, ea[l], ld_ea[l], k, We[l], Wl[l],
-                                        Wr[l], c_out, relu[l], phi[l], a[l], y[l], g, have_ext ? dphi_ext : nullptr, dx, l > 0 ? d_ea : nullptr, dWe[l], dbe[l],
-                                        dWl[l], dbl[l], dWr[l], dz, da, dphi, scratch, bf16, gemm_mode, stream));
+        DGNN_REQUIRE(n_dst[l] > 0 && n_src[l] >= n_dst[l] && E[l] >= 0 && c_in > 0 && c_out > 0 && k > 0, DGNN_E_INVALID, "updated_stack_bwd: bad sizes");
+        const bool want_mask = mask_on && l > 0 && relu[l - 1] != 0;
+        bool masked = false;
+        const int rc = bf16 ? updated_bwd<BF16>(t_rowptr[l], t_dst[l], t_eid[l], rowptr_dst[l], n_src[l], n_dst[l], E[l], x, ldx, c_in, ea[l], ld_ea[l], k, We[l], Wl[l],
+                                                Wr[l], c_out, relu[l], phi[l], a[l], y[l], g, have_ext ? dphi_ext : nullptr, dx, l > 0 ? d_ea : nullptr, dWe[l],
+                                                dbe[l], dWl[l], dbl[l], dWr[l], dz, da, dphi, scratch, gemm_mode, stream, g_masked, want_mask, &masked)
+                            : updated_bwd<F32>(t_rowptr[l], t_dst[l], t_eid[l], rowptr_dst[l], n_src[l], n_dst[l], E[l], x, ldx, c_in, ea[l], ld_ea[l], k, We[l], Wl[l],
+                                               Wr[l], c_out, relu[l], phi[l], a[l], y[l], g, have_ext ? dphi_ext : nullptr, dx, l > 0 ? d_ea : nullptr, dWe[l],
+                                               dbe[l], dWl[l], dbl[l], dWr[l], dz, da, dphi, scratch, gemm_mode, stream, g_masked, want_mask, &masked);
+        if (rc != DGNN_OK) return rc;
+        g_masked = masked;
         have_ext = false;
         if (l > 0 && E[l - 1] > 0) {   // layer l's edge rows came out of phi_{l-1}: their gradient is what layer l-1 adds to its dphi
             if (bf16)

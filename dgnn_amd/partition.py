@@ -158,6 +158,22 @@ def ring_dst(lp: LocalPart, num_layers: int) -> List[int]:
     return [lp.n_own + sum(lp.ring_counts[:num_layers - 1 - l]) for l in range(num_layers)]
 
 
+_FAULT_FIRED = [False]
+
+
+def _fault_first_exchange():
+    """Fault injection for tests (tests/test_gpu_multi.py): DGNN_FAULT_FIRST_EXCHANGE = "all" or a rank as in $RANK makes the FIRST exchange this process
+    starts raise before anything is posted -- what bench.py's agreed fall-back to host staging answers.  Use "all": a rank that alone stays out of an
+    exchange leaves its peers waiting for its rows (the fall-back agrees AFTER the failed step; it cannot recall posted receives)."""
+    import os
+    v = os.environ.get("DGNN_FAULT_FIRST_EXCHANGE")
+    if not v or _FAULT_FIRED[0]:
+        return
+    if v == "all" or v == os.environ.get("RANK"):
+        _FAULT_FIRED[0] = True
+        raise RuntimeError("injected fault (DGNN_FAULT_FIRST_EXCHANGE): the first halo exchange of this process")
+
+
 class HaloExchange:
     """Per-round exchange of boundary rows.  `pack(h, idx)` gathers rows (HIP gather kernel on GPU).
 
@@ -191,17 +207,23 @@ class HaloExchange:
         self._native = None
         self._native_bufs = {}
         import os
-        if self.device.type == "cuda" and not self.via_host and os.environ.get("DGNN_NATIVE_HALO", "1") != "0":
+        # DGNN_NATIVE_HALO=force (tests): the library's communicator is ATTEMPTED under any backend, also when this object was built for host staging -- the
+        # agreement protocol of _init_native then runs over that backend (gloo on a one-GPU box) and its failure branches can be exercised there.
+        force = os.environ.get("DGNN_NATIVE_HALO", "1") == "force"
+        self.native_attempt = None          # None: not attempted; else "ok" or the reason the group agreed to stay on torch.distributed
+        if self.device.type == "cuda" and (not self.via_host or force) and os.environ.get("DGNN_NATIVE_HALO", "1") != "0":
             import torch.distributed as dist
             # (ring parts -- build_ring_part -- never exchange: no communicator is made for them, on any rank)
-            if dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl" and lp.ring_counts is None \
+            if dist.is_available() and dist.is_initialized() and (dist.get_backend(group) == "nccl" or force) and lp.ring_counts is None \
                     and (self.active or dist.get_world_size(group) > 1):
                 try:
                     self._init_native(group)
+                    self.native_attempt = "ok"
                 except Exception as e:  # noqa: BLE001
                     import sys
                     sys.stderr.write("dgnn_amd: library halo exchange unavailable (%s); torch.distributed transport is used\n" % e)
                     self._native = None
+                    self.native_attempt = str(e)
 
     def _init_native(self, group):
         """Creates the library's communicator + halo plan.  COLLECTIVE over `group`, and every decision on the way is AGREED ON by all ranks
@@ -292,6 +314,7 @@ class HaloExchange:
         """h_full [n_own + n_halo, C] with the rows to send valid: begins filling the halo rows in place."""
         if not self.active:
             return
+        _fault_first_exchange()
         if self._native is not None:
             from ._lib import check, ptr, stream_ptr
             L, comm, plan = self._native

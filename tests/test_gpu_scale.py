@@ -498,3 +498,39 @@ def test_x3_gemm_small_problem_kernel_equals_the_tiled_kernels(monkeypatch, k1, 
     from dgnn_amd._lib import lib, ptr, stream_ptr, check
     check(lib().dgnn_linear_fwd_x3(ptr(A1), A1.stride(0), k1, ptr(W1), k1, None, 0, 0, None, 0, None, None, None, 2, M, n_out, ptr(out), n_out, stream_ptr()), "x3")
     assert torch.equal(out, acc + ops.linear_fwd(A1, W1))
+
+
+@pytest.mark.parametrize("k1,k2,n_out,M", [(512, 512, 1024, 1024), (1024, 0, 512, 2050), (1030, 77, 200, 333), (2048, 0, 64, 31)])
+def test_small_gemm_split_k_form(monkeypatch, k1, k2, n_out, M):
+    """Round 6: M <= 16384 rows and K = k1 + k2 >= 1024 (the reference's training widths, configs/modelnet.yaml:56: the 512 -> 1024 conv layer, the
+    1024 -> 512 decoder Linear and their input gradients at batch 1024) take the small-problem kernels in their split-K form -- four wavefronts per
+    32 x 32 output block, a quarter of the k-steps each, partial blocks added in wavefront order.  fp32-class arithmetic (x3) against fp64 within the
+    tiled kernels' tolerance, bf16 storage against fp64 on the bf16-rounded operands at fp32-accumulation level; the same bits on a second call; ragged
+    K / N / M; bias + BatchNorm + ReLU epilogue."""
+    from dgnn_amd import ops
+    monkeypatch.setattr(ops, "GEMM_MODE", ops.GEMM_BF16X3)
+    g = torch.Generator().manual_seed(k1 + 3 * n_out)
+    A1 = torch.randn(M, k1, generator=g).to(DEV)
+    W1 = (torch.randn(n_out, k1, generator=g) / (k1 + k2) ** 0.5).to(DEV)
+    A2 = torch.randn(M, k2, generator=g).to(DEV) if k2 else None
+    W2 = (torch.randn(n_out, k2, generator=g) / (k1 + k2) ** 0.5).to(DEV) if k2 else None
+    bias, scale, shift = torch.randn(n_out, generator=g).to(DEV), (torch.rand(n_out, generator=g) + 0.5).to(DEV), (torch.randn(n_out, generator=g) * 0.1).to(DEV)
+
+    def ref(a1, w1, a2, w2):
+        r = a1.double() @ w1.double().t() + bias.double()
+        m = a1.double().abs() @ w1.double().abs().t() + bias.double().abs()
+        if a2 is not None:
+            r = r + a2.double() @ w2.double().t()
+            m = m + a2.double().abs() @ w2.double().abs().t()
+        return (r * scale.double() + shift.double()).clamp_min(0), m * scale.double().abs() + shift.double().abs()
+    got = ops.linear_fwd(A1, W1, A2, W2, bias, scale, shift, relu=True)
+    want, mag = ref(A1, W1, A2, W2)
+    assert ((got.double() - want).abs() <= 2e-6 * mag + 1e-30).all(), ((got.double() - want).abs() / mag).max().item()
+    assert torch.equal(got, ops.linear_fwd(A1, W1, A2, W2, bias, scale, shift, relu=True))
+    # bf16 storage: operands as the kernel sees them (A bf16 as stored, W rounded to bf16 when staged), fp32 accumulate, fp32 out
+    bf = lambda t: t.to(torch.bfloat16)
+    A1b, A2b = bf(A1), (bf(A2) if k2 else None)
+    gotb = ops.linear_fwd(A1b, W1, A2b, W2, bias, scale, shift, relu=True, out_dtype=torch.float32)
+    wantb, magb = ref(A1b.float(), bf(W1).float(), A2b.float() if k2 else None, bf(W2).float() if k2 else None)
+    assert ((gotb.double() - wantb).abs() <= 4e-6 * magb + 1e-30).all(), ((gotb.double() - wantb).abs() / magb).max().item()
+    assert torch.equal(gotb, ops.linear_fwd(A1b, W1, A2b, W2, bias, scale, shift, relu=True, out_dtype=torch.float32))
