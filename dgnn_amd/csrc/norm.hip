@@ -159,11 +159,28 @@ __device__ __forceinline__ bool finalize_pair(const double* __restrict__ partial
     __shared__ double red[2][SLICES][COLS + 1];
     const int o = threadIdx.x % COLS, sl = threadIdx.x / COLS, col = blockIdx.x * COLS + o;
     double ps = 0.0, pq = 0.0;
-    if (col < c)
-        for (int b = sl; b < nblk; b += SLICES) {
+    if (col < c) {
+        // four partial rows requested at a time, added in ascending order (the sums' order is unchanged; a load -> add chain per row was ~600 ns
+        // a row: 13 us for the 4 400 partial rows of a 140k-cell layer)
+        int b = sl;
+        for (; b + 3 * SLICES < nblk; b += 4 * SLICES) {
+            double vs[4], vq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                vs[u] = partials[((int64_t)(b + u * SLICES) * 2 + 0) * c + col];
+                vq[u] = partials[((int64_t)(b + u * SLICES) * 2 + 1) * c + col];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ps += vs[u];
+                pq += vq[u];
+            }
+        }
+        for (; b < nblk; b += SLICES) {
             ps += partials[((int64_t)b * 2 + 0) * c + col];
             pq += partials[((int64_t)b * 2 + 1) * c + col];
         }
+    }
     red[0][sl][o] = ps;
     red[1][sl][o] = pq;
     __syncthreads();

@@ -41,8 +41,17 @@ __device__ __forceinline__ void reduce_slabs_block(const SlabReduceDesc& d, int 
     const bool live = i < d.nchunks * d.per;
     const int chunk = live ? i / d.per : 0, r = live ? i - chunk * d.per : 0;
     float p = 0.f;
-    if (live)
-        for (int b = sl; b < d.nblocks; b += RS_SLICES) p += d.slabs[((int64_t)b * d.nchunks + chunk) * d.per + r];
+    if (live) {      // four slabs requested at a time, added in ascending order (same sums; a load -> add chain per slab otherwise)
+        int b = sl;
+        for (; b + 3 * RS_SLICES < d.nblocks; b += 4 * RS_SLICES) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = d.slabs[((int64_t)(b + u * RS_SLICES) * d.nchunks + chunk) * d.per + r];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p += v[u];
+        }
+        for (; b < d.nblocks; b += RS_SLICES) p += d.slabs[((int64_t)b * d.nchunks + chunk) * d.per + r];
+    }
     red[sl][o] = p;
     __syncthreads();
     if (sl != 0 || !live) return;
@@ -82,8 +91,17 @@ __device__ __forceinline__ void wgrad_reduce_cat_phase(const WgradReduceDesc& d,
         const bool live = i < nmat;
         if (phase == 0) {
             float p = 0.f;
-            if (live)
-                for (int z = sl; z < d.splits; z += 16) p += d.partials[(int64_t)z * nmat + i];
+            if (live) {
+                int z = sl;
+                for (; z + 48 < d.splits; z += 64) {
+                    float v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = d.partials[(int64_t)(z + 16 * u) * nmat + i];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) p += v[u];
+                }
+                for (; z < d.splits; z += 16) p += d.partials[(int64_t)z * nmat + i];
+            }
             redf[sl][o] = p;
             return;
         }
