@@ -308,6 +308,109 @@ __global__ void __launch_bounds__(256) k_linear_fwd_b(const uint16_t* __restrict
     }
 }
 
+// 64 x 64 output tile with the next chunk's loads in flight under the products (round 6): for the problems between k_linear_fwd_b (128 x 64 tiles,
+// loads and products one after the other) and k_linear_fwd_b_small (no LDS: both operands re-read per 32 x 32 block) -- the reference's training widths
+// at batch 1024, see k_linear_fwd_x3_mid.  k-steps in k_linear_fwd_b's order: bit-identical results.
+template <typename TO>
+__global__ void __launch_bounds__(256, 2) k_linear_fwd_b_mid(const uint16_t* __restrict__ A1, int64_t lda1, int k1, const float* __restrict__ W1,
+                                                             int64_t ldw1, bool va1, bool vw1, const uint16_t* __restrict__ A2, int64_t lda2, int k2,
+                                                             const float* __restrict__ W2, int64_t ldw2, bool va2, bool vw2,
+                                                             const float* __restrict__ bias, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int relu, int64_t M, int n_out, TO* __restrict__ out,
+                                                             int64_t ldo) {
+    constexpr int TM = 64, TN = 64;
+    __shared__ __attribute__((aligned(16))) char As[TM * LDB];
+    __shared__ __attribute__((aligned(16))) char Ws[TN * LDB];
+    const int lane = lane_id(), w = wave_id_uniform();
+    const int wr = w >> 1, wc = w & 1, h = lane >> 5, l31 = lane & 31;
+    const int ncb = (n_out + TN - 1) / TN;
+    const int64_t row0 = (int64_t)(blockIdx.x / ncb) * TM;
+    const int col0 = (int)(blockIdx.x % ncb) * TN;
+    const int t = threadIdx.x, sr = t >> 3, scol = (t & 7) * 8;      // staging: 8 threads per row, 8 elements each, 32 rows per pass
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int nch1 = (k1 + BKB - 1) / BKB, nch2 = A2 ? (k2 + BKB - 1) / BKB : 0, nch = nch1 + nch2;
+    uint4 ra[2];
+    float rw[2][8];
+    auto load_chunk = [&](int ch) {
+        const bool first = ch < nch1;
+        const int kk = first ? k1 : k2, k0 = (first ? ch : ch - nch1) * BKB;
+        const uint16_t* A = first ? A1 : A2;
+        const float* W = first ? W1 : W2;
+        const int64_t lda = first ? lda1 : lda2, ldw = first ? ldw1 : ldw2;
+        const bool va = first ? va1 : va2, vw = first ? vw1 : vw2;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int rr = sr + p * 32;
+            const int64_t gr = row0 + rr;
+            ra[p] = make_uint4(0u, 0u, 0u, 0u);
+            if (gr < M && k0 + scol < kk) {
+                const uint16_t* g = A + gr * lda + k0 + scol;
+                if (va && k0 + scol + 8 <= kk) {
+                    ra[p] = *reinterpret_cast<const uint4*>(g);
+                } else {
+                    uint32_t e[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) e[j] = (k0 + scol + j < kk) ? (uint32_t)g[j] : 0u;
+                    ra[p] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+                }
+            }
+            const int64_t gc = col0 + rr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rw[p][j] = 0.f;
+            if (gc < n_out && k0 + scol < kk) {
+                const float* g = W + gc * ldw + k0 + scol;
+                if (vw && k0 + scol + 8 <= kk) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(g), b = *reinterpret_cast<const f32x4*>(g + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { rw[p][j] = a[j]; rw[p][4 + j] = b[j]; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (k0 + scol + j < kk) rw[p][j] = g[j];
+                }
+            }
+        }
+    };
+    load_chunk(0);
+    for (int ch = 0; ch < nch; ++ch) {
+        __syncthreads();                 // the previous chunk's fragments have been read
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int rr = sr + p * 32;
+            *reinterpret_cast<uint4*>(As + rr * LDB + scol * 2) = ra[p];
+            *reinterpret_cast<uint4*>(Ws + rr * LDB + scol * 2) = make_uint4(pk_bf16(rw[p][0], rw[p][1]), pk_bf16(rw[p][2], rw[p][3]), pk_bf16(rw[p][4], rw[p][5]),
+                                                                             pk_bf16(rw[p][6], rw[p][7]));
+        }
+        __syncthreads();
+        if (ch + 1 < nch) load_chunk(ch + 1);      // in flight under the products below
+        const char* ap = As + (wr * 32 + l31) * LDB + h * 16;
+        const char* bp = Ws + (wc * 32 + l31) * LDB + h * 16;
+#pragma unroll
+        for (int S = 0; S < BKB / 16; ++S) {
+            const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(ap + 32 * S);
+            const bf16x8_t bv = *reinterpret_cast<const bf16x8_t*>(bp + 32 * S);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+        }
+    }
+    const int col = col0 + wc * 32 + l31;
+    if (col < n_out) {
+        const float bb = bias ? bias[col] : 0.f;
+        const float sc = scale ? scale[col] : 1.f;
+        const float sh = scale ? shift[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row >= M) continue;
+            float v = acc[r] + bb;
+            if (scale) v = __fmaf_rn(v, sc, sh);
+            if (relu & 1) v = fmaxf(v, 0.f);
+            if (relu & DGNN_LINEAR_ACCUMULATE) v += dgnn_ld(out + row * ldo + col);
+            dgnn_st(out + row * ldo + col, v);
+        }
+    }
+}
+
 // Small problems (M <= 16384 rows: the inner blocks of a training step, the decoder) in bf16 storage: k_linear_fwd_b's 128-row tiles leave most
 // of the chip idle there and walk K behind two barriers per 64 columns (13-20 us per launch for 0.1 GFLOP; the bf16-storage training step spent
 // 0.3 ms in 22 such launches).  Like k_linear_fwd_x3_small, ONE WAVEFRONT owns a 32 x 32 output block and takes its fragments straight from
@@ -634,21 +737,22 @@ __device__ __forceinline__ void x3_split(float x0, float x1, uint32_t& hi, uint3
 // [128 x 32] fp32 tile -> 3 bf16 parts in LDS; 8 threads per row (4 floats each), 32 rows per pass.  Two steps, so that the next
 // chunk's global loads are in flight while the current chunk is multiplied (register staging, guide T14): x3_load issues the
 // loads into 4 x float4, x3_store splits them and writes the LDS image after the barrier.
-__device__ __forceinline__ void x3_load(f32x4 (&v)[4], const float* __restrict__ src, int64_t ld, int64_t row0, int64_t nrows, int k0, int kmax,
+template <int NP = 4>
+__device__ __forceinline__ void x3_load(f32x4 (&v)[NP], const float* __restrict__ src, int64_t ld, int64_t row0, int64_t nrows, int k0, int kmax,
                                         bool vec) {
     const int t = threadIdx.x, r = t >> 3, c = (t & 7) * 4;
     if (vec && k0 + XK <= kmax) {
         // whole chunk inside K and 16-byte aligned rows (uniform per chunk): four unconditional loads.  Rows past the end are
         // clamped to the last row -- they only feed output rows / columns that are never stored.
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const int64_t gr = row0 + r + p * 32;
             v[p] = *reinterpret_cast<const f32x4*>(src + (gr < nrows ? gr : nrows - 1) * ld + k0 + c);
         }
         return;
     }
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < NP; ++p) {
         const int64_t gr = row0 + r + p * 32;
         const float* g = src + (gr < nrows ? gr : nrows - 1) * ld;
 #pragma unroll
@@ -659,10 +763,11 @@ __device__ __forceinline__ void x3_load(f32x4 (&v)[4], const float* __restrict__
         }
     }
 }
-__device__ __forceinline__ void x3_store(char* __restrict__ dst, const f32x4 (&v)[4]) {
+template <int NP = 4>
+__device__ __forceinline__ void x3_store(char* __restrict__ dst, const f32x4 (&v)[NP]) {
     const int t = threadIdx.x, r = t >> 3, c = (t & 7) * 4;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < NP; ++p) {
         uint32_t h0, m0, l0, h1, m1, l1;
         x3_split(v[p][0], v[p][1], h0, m0, l0);
         x3_split(v[p][2], v[p][3], h1, m1, l1);
@@ -795,6 +900,89 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_x3(const float* __restric
             }
             if (colstats) stats_block_store(colstats, row0 + wr * 64 + a * 32, M, n_out, col, h, s, q);
         }
+    }
+}
+
+// 64 x 64 output tile (round 6): k_linear_fwd_x3's loop -- operands split while staged, the next chunk's loads in flight under the products -- with
+// the 2 x 2 wave grid on 32 x 32 blocks (one accumulator each).  For the problems between the two existing forms: the reference's training widths at
+// batch 1024 (M = 1 024 .. 6 000 rows, K and N 512 .. 1 024; configs/modelnet.yaml:44,56) give the 128 x 128 tiles a quarter of the chip (M = 1 024,
+// K = N = 1 024: 66 us) and make the LDS-free small-problem kernel re-read both operands once per 32 x 32 block (39 us, L2-bound: 268 MB for 8 MB of
+// operands); four times as many tiles as the former, half the operand traffic of the latter.  Same chunk and product order per output element as
+// k_linear_fwd_x3: bit-identical results.
+__global__ void __launch_bounds__(256, 2) k_linear_fwd_x3_mid(const float* __restrict__ A1, int64_t lda1, int k1, const float* __restrict__ W1,
+                                                              int64_t ldw1, bool vec1, const float* __restrict__ A2, int64_t lda2, int k2,
+                                                              const float* __restrict__ W2, int64_t ldw2, bool vec2,
+                                                              const float* __restrict__ bias, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int relu, int64_t M, int n_out,
+                                                              float* __restrict__ out, int64_t ldo, double* __restrict__ colstats) {
+    constexpr int TM = 64, TN = 64;
+    __shared__ __attribute__((aligned(16))) char As[TM * XLD];
+    __shared__ __attribute__((aligned(16))) char Ws[TN * XLD];
+    const int lane = lane_id(), w = wave_id_uniform();
+    const int wr = w >> 1, wc = w & 1, h = lane >> 5, l31 = lane & 31;
+    const int ncb = (n_out + TN - 1) / TN;
+    const int64_t rb = (int64_t)((blockIdx.x >> 3) / ncb) * 8 + (blockIdx.x & 7);      // XCD-aware tile map as in k_linear_fwd_x3
+    if (rb * TM >= M) return;
+    const int64_t row0 = rb * TM;
+    const int col0 = (int)((blockIdx.x >> 3) % ncb) * TN;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int nch1 = (k1 + XK - 1) / XK, nch2 = A2 ? (k2 + XK - 1) / XK : 0, nch = nch1 + nch2;
+    f32x4 ra[2], rw[2];
+    auto load_chunk = [&](int ch) {
+        const bool first = ch < nch1;
+        const int kk = first ? k1 : k2, k0 = (first ? ch : ch - nch1) * XK;
+        x3_load<2>(ra, first ? A1 : A2, first ? lda1 : lda2, row0, M, k0, kk, first ? vec1 : vec2);
+        x3_load<2>(rw, first ? W1 : W2, first ? ldw1 : ldw2, col0, n_out, k0, kk, first ? vec1 : vec2);
+    };
+    load_chunk(0);
+    for (int ch = 0; ch < nch; ++ch) {
+        __syncthreads();
+        x3_store<2>(As, ra);
+        x3_store<2>(Ws, rw);
+        __syncthreads();
+        if (ch + 1 < nch) load_chunk(ch + 1);
+        const char* ap = As + (wr * 32 + l31) * XLD + h * 16;
+        const char* bp = Ws + (wc * 32 + l31) * XLD + h * 16;
+#pragma unroll
+        for (int S = 0; S < XK / 16; ++S) {
+            bf16x8_t af[3], bf[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                af[p] = *reinterpret_cast<const bf16x8_t*>(ap + p * 64 + S * 32);
+                bf[p] = *reinterpret_cast<const bf16x8_t*>(bp + p * 64 + S * 32);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc, 0, 0, 0);   // small terms first
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc, 0, 0, 0);
+        }
+    }
+    {
+        const int col = col0 + wc * 32 + l31;
+        const int colc = col < n_out ? col : n_out - 1;
+        const float bb = bias ? bias[colc] : 0.f;
+        const float sc = scale ? scale[colc] : 1.f;
+        const float sh = scale ? shift[colc] : 0.f;
+        double s_ = 0.0, q_ = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row >= M || col >= n_out) continue;
+            float v = acc[r] + bb;
+            if (colstats) {
+                s_ += v;
+                q_ += (double)v * v;
+            }
+            if (scale) v = __fmaf_rn(v, sc, sh);
+            if (relu & 1) v = fmaxf(v, 0.f);
+            if (relu & DGNN_LINEAR_ACCUMULATE) v += out[row * ldo + col];
+            out[row * ldo + col] = v;
+        }
+        if (colstats) stats_block_store(colstats, row0 + wr * 32, M, n_out, col, h, s_, q_);
     }
 }
 
@@ -1813,7 +2001,23 @@ extern "C" int dgnn_linear_fwd_bf16(const uint16_t* A1, int64_t lda1, int k1, co
     const bool va2 = A2 && vec16(A2, lda2, 2), vw2 = W2 && vec16(W2, ldw2, 4);
     static const bool small_ok = !(getenv("DGNN_BF16_SMALL") && getenv("DGNN_BF16_SMALL")[0] == '0');
     static const bool splitk_ok = !(getenv("DGNN_SMALL_SPLITK") && getenv("DGNN_SMALL_SPLITK")[0] == '0');
-    if (small_ok && splitk_ok && M <= 16384 && k1 + (A2 ? k2 : 0) >= 1024) {   // four wavefronts per output block, a quarter of K each (see the kernel)
+    // Round 6: the small-problem kernel re-reads its operands once per 32 x 32 output block -- fine for the shipped widths' inner blocks, not for the
+    // reference's training widths (M = 6 000, K = N = 512: 38 us against the tiled kernel's 28; M = 12 000, K = N = 1024: 249 against 100,
+    // tools/bench_gemm_train_shapes.py).  It keeps the problems whose 128 x 64 tiles would leave most of the chip idle (fewer than 150 of them).
+    static const bool by_tiles = !(getenv("DGNN_SMALL_BY_TILES") && getenv("DGNN_SMALL_BY_TILES")[0] == '0');
+    const bool tiles_fill = by_tiles && k1 + (A2 ? k2 : 0) >= 128 && dgnn_cdiv(M, BM) * dgnn_cdiv(n_out, BN) >= 150;
+    static const bool mid_ok = !(getenv("DGNN_GEMM_MID") && getenv("DGNN_GEMM_MID")[0] == '0');
+    if (mid_ok && !tiles_fill && M <= 16384 && k1 + (A2 ? k2 : 0) >= 512 && dgnn_cdiv(M, 64) * dgnn_cdiv(n_out, 64) >= 128) {   // 64 x 64 tiles (see the kernel)
+        dim3 mgrid((unsigned)(dgnn_cdiv(M, 64) * dgnn_cdiv(n_out, 64)));
+        if (out_f32)
+            hipLaunchKernelGGL((k_linear_fwd_b_mid<float>), mgrid, dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, va1, vw1, A2, lda2, k2, W2, ldw2,
+                               va2, vw2, bias, scale, shift, relu, M, n_out, (float*)out, ldo);
+        else
+            hipLaunchKernelGGL((k_linear_fwd_b_mid<uint16_t>), mgrid, dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, va1, vw1, A2, lda2, k2, W2,
+                               ldw2, va2, vw2, bias, scale, shift, relu, M, n_out, (uint16_t*)out, ldo);
+        return dgnn_check_launch("linear_fwd_bf16");
+    }
+    if (small_ok && !tiles_fill && splitk_ok && M <= 16384 && k1 + (A2 ? k2 : 0) >= 1024) {   // four wavefronts per output block, a quarter of K each (see the kernel)
         dim3 sgrid((unsigned)(dgnn_cdiv(M, 32) * dgnn_cdiv(n_out, 32)));
         if (out_f32)
             hipLaunchKernelGGL((k_linear_fwd_b_small<float, true>), sgrid, dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, va1, vw1, A2, lda2, k2, W2,
@@ -1823,7 +2027,7 @@ extern "C" int dgnn_linear_fwd_bf16(const uint16_t* A1, int64_t lda1, int k1, co
                                W2, ldw2, va2, vw2, bias, scale, shift, relu, M, n_out, (uint16_t*)out, ldo);
         return dgnn_check_launch("linear_fwd_bf16");
     }
-    if (small_ok && M <= 16384) {   // same k order per output element: identical results
+    if (small_ok && !tiles_fill && M <= 16384) {   // same k order per output element: identical results
         dim3 sgrid((unsigned)dgnn_cdiv(dgnn_cdiv(M, 32) * dgnn_cdiv(n_out, 32), 4));
         if (out_f32)
             hipLaunchKernelGGL((k_linear_fwd_b_small<float>), sgrid, dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, va1, vw1, A2, lda2, k2, W2,
@@ -1892,7 +2096,20 @@ int linear_fwd_x3_impl(const float* A1, int64_t lda1, int k1, const float* W1, i
     }
     static const bool small_ok = !(getenv("DGNN_X3_SMALL") && getenv("DGNN_X3_SMALL")[0] == '0');
     static const int64_t small_m = getenv("DGNN_X3_SMALL_M") ? atoll(getenv("DGNN_X3_SMALL_M")) : 16384;
-    if (small_ok && M <= small_m) {
+    // (round 6: ... unless the 128 x 128 tiles of the tiled kernels would fill the chip anyway -- 150 of them -- where the small-problem kernel's operand
+    // re-reads cost more than its barrier-free walk saves: M = 6 000, K = N = 512 57 -> 44 us, M = 12 000, K = N = 1024 356 -> 172 us)
+    static const bool by_tiles = !(getenv("DGNN_SMALL_BY_TILES") && getenv("DGNN_SMALL_BY_TILES")[0] == '0');
+    const bool tiles_fill = by_tiles && k1 + (A2 ? k2 : 0) >= 128 && n_out > ZN && dgnn_cdiv(M, XM) * dgnn_cdiv(n_out, XN) >= 150;
+    // ... and between the two: 64 x 64 tiles when THEY fill the chip and the inner dimension is long enough for the operand re-reads of the
+    // small-problem kernel to matter (k_linear_fwd_x3_mid)
+    static const bool mid_ok = !(getenv("DGNN_GEMM_MID") && getenv("DGNN_GEMM_MID")[0] == '0');
+    if (mid_ok && !tiles_fill && M <= small_m && n_out > ZN && k1 + (A2 ? k2 : 0) >= 512 && dgnn_cdiv(M, 64) * dgnn_cdiv(n_out, 64) >= 128) {
+        dim3 grid((unsigned)(dgnn_cdiv(dgnn_cdiv(M, 64), 8) * 8 * dgnn_cdiv(n_out, 64)));
+        hipLaunchKernelGGL(k_linear_fwd_x3_mid, grid, dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2, lda2, k2, W2, ldw2, v2, bias, scale, shift,
+                           relu, M, n_out, out, ldo, colstats);
+        return dgnn_check_launch("linear_fwd_x3");
+    }
+    if (small_ok && !tiles_fill && M <= small_m) {
         const int64_t tiles = dgnn_cdiv(M, 32) * dgnn_cdiv(n_out, 32);
         static const bool splitk_ok = !(getenv("DGNN_SMALL_SPLITK") && getenv("DGNN_SMALL_SPLITK")[0] == '0');
         if (splitk_ok && k1 + (A2 ? k2 : 0) >= 1024)

@@ -32,6 +32,8 @@
 // inputs only (whole-scene, partitioned and differently tiled runs stay bit-identical).
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.h"
 #include "fused_common.h"
 
@@ -183,7 +185,7 @@ __global__ void __launch_bounds__(512, 2) k_agg_sr(const int32_t* __restrict__ r
                                                    int64_t n_dst, const void* __restrict__ x_, int64_t ldx, int64_t xrb, const float* __restrict__ xs, int ngx,
                                                    const float* __restrict__ ea, int64_t lde, const float* __restrict__ We, const float* __restrict__ be,
                                                    const char* __restrict__ prep, int pass, char* __restrict__ ao, int64_t arb, float* __restrict__ as, int nga,
-                                                   char* __restrict__ xo, float* __restrict__ xos, int nt_) {
+                                                   char* __restrict__ xo, float* __restrict__ xos, int nt_, int* __restrict__ tickets) {
     const bool nt = (nt_ & 1) != 0;
     const bool no_store = (nt_ & 2) != 0;       // DGNN_SR_NT=2 / 3: timing probe of the producer side alone (tools/probe_producer.py); never set by the product
     constexpr int NSB = NB / 8;                                        // sub-blocks of 8 positions per lane
@@ -226,22 +228,50 @@ __global__ void __launch_bounds__(512, 2) k_agg_sr(const int32_t* __restrict__ r
             }
         }
     };
-    const int64_t q_first = q_lo + slot * 8 + w;
+    // Which groups of 4 cells a wavefront takes.  Static (tickets == NULL): q_first, q_first + wpx, ... -- the XCD's wavefronts sweep its eighth side by
+    // side.  Tickets (round 6): every wavefront draws its next group from the XCD's counter (one returning atomic per step, requested a whole step before
+    // it is needed), so the groups in flight are always the most recently started ones however the wavefronts drift apart: with the static walk a
+    // wavefront that runs 10 % ahead after 60 steps works 6 x 2048 cells away from the slowest, and the rows the XCD's L2 has to hold are several
+    // times the 2 MB of one sweep line (tools/locality_model.py: an LRU cache of 4096 rows misses 30 % of the requests of an in-order walk; the
+    // launch measured 48 %).
+    int64_t qa, qb, qc;
+    int tk_next = 0;
+    auto draw = [&](int k) -> int {      // k tickets, the first one comes back (lane 0 draws, the wavefront shares)
+        int t = 0;
+        if (lane == 0) t = atomicAdd(tickets + xcd, k);
+        return __builtin_amdgcn_readfirstlane(t);
+    };
+    if (tickets) {
+        const int t0 = draw(3);
+        qa = q_lo + t0, qb = qa + 1, qc = qa + 2;
+        tk_next = draw(1);
+    } else {
+        qa = q_lo + slot * 8 + w, qb = qa + wpx, qc = qb + wpx;
+    }
     int vb1 = 0, vb2 = 0, vsrc1 = 0, veid1 = 0;
     bool reg1 = false;
-    load_rp(q_first, vb1);
-    load_rp(q_first + wpx, vb2);
-    load_idx(q_first, vb1, reg1, vsrc1, veid1);
+    load_rp(qa, vb1);
+    load_rp(qb, vb2);
+    load_idx(qa, vb1, reg1, vsrc1, veid1);
 
-    for (int64_t q = q_first; q < q_hi; q += wpx) {
+    for (int64_t q = qa; q < q_hi;) {
         const int64_t i0 = q * 4;
         const int nv = (int)(n_dst - i0 < 4 ? n_dst - i0 : 4);
         const bool regular = reg1;
         const int vsrc = vsrc1, veid = veid1;
         // the next step's sources / edge ids (its row starts arrived a step ago) and the row starts of the step behind it
         vb1 = vb2;
-        load_idx(q + wpx, vb1, reg1, vsrc1, veid1);
-        load_rp(q + 2 * (int64_t)wpx, vb2);
+        load_idx(qb, vb1, reg1, vsrc1, veid1);
+        load_rp(qc, vb2);
+        const int64_t q_now = q;
+        q = qb, qb = qc;
+        if (tickets) {
+            qc = q_lo + tk_next;
+            tk_next = draw(1);
+        } else {
+            qc = qb + wpx;
+        }
+        (void)q_now;
         const int tl = tq < nv ? tq : nv - 1;                          // a short group at the end of the graph: clamped (duplicated) cells
         const int64_t cell = i0 + tl;
         float aout[NB];
@@ -988,9 +1018,28 @@ extern "C" int dgnn_sage_aggregate_sr(const int32_t* rowptr, const int32_t* src,
     const dim3 grid((unsigned)nwg_), block(512);
     hipStream_t st = (hipStream_t)stream;
     static const int ilv = getenv("DGNN_AGG_SR_ILV") ? atoi(getenv("DGNN_AGG_SR_ILV")) : 2;   // measured: 1 / 2 / 4 interleaved chains within 1 % (the launch is bound by its gathers); 2 keeps four wavefronts per SIMD
+    // the XCDs' group counters of the ticket walk (see the kernel): 8 ints per device, zeroed in stream order before every launch
+    static const bool tickets_on = !(getenv("DGNN_AGG_SR_TICKETS") && getenv("DGNN_AGG_SR_TICKETS")[0] == '0');
+    int* tickets = nullptr;
+    if (tickets_on) {
+        static int* tk_dev[DGNN_MAX_DEVICES];
+        static std::mutex tk_m;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < DGNN_MAX_DEVICES) {
+            std::lock_guard<std::mutex> lock(tk_m);
+            if (!tk_dev[dev] && hipMalloc((void**)&tk_dev[dev], 16 * 64 * sizeof(int)) != hipSuccess) {
+                tk_dev[dev] = nullptr;
+                (void)hipGetLastError();
+            }
+            static unsigned tk_turn[DGNN_MAX_DEVICES];
+            if (tk_dev[dev]) tickets = tk_dev[dev] + 64 * (tk_turn[dev]++ & 15);      // a ring of 16 counter sets: launches in flight on other streams keep theirs
+        }
+    }
 #define DGNN_AGG_SR(NB_, SR_, IL_)                                                                                                                       \
     hipLaunchKernelGGL((k_agg_sr<NB_, SR_, IL_>), grid, block, lds, st, rowptr, src, eid, n_dst, x, ldx, rowb, xs, ng, edge_attr, lde, We, be,            \
-                       static_cast<const char*>(prep), pass, static_cast<char*>(a_out), rowb, a_scales, ng, static_cast<char*>(x_out), x_scales, sr_nt())
+                       static_cast<const char*>(prep), pass, static_cast<char*>(a_out), rowb, a_scales, ng, static_cast<char*>(x_out), x_scales, sr_nt(), \
+                       tickets ? tickets + 8 * (pass & 7) : nullptr)
+    if (tickets) (void)hipMemsetAsync(tickets, 0, 64 * sizeof(int), st);
     for (int pass = 0; pass < np; ++pass) {
         if (x_is_sr) {
             if (ilv == 1) DGNN_AGG_SR(16, true, 1);
