@@ -331,9 +331,14 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_b_mid(const uint16_t* __r
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const int nch1 = (k1 + BKB - 1) / BKB, nch2 = A2 ? (k2 + BKB - 1) / BKB : 0, nch = nch1 + nch2;
-    uint4 ra[2];
-    float rw[2][8];
-    auto load_chunk = [&](int ch) {
+    struct RS {
+        uint4 ra[2];
+        float rw[2][8];
+    };
+    RS s0, s1, s2;       // three register sets: two chunks of loads in flight (see k_linear_fwd_x3_mid)
+    auto load_chunk = [&](int ch, RS& R) {
+        uint4 (&ra)[2] = R.ra;
+        float (&rw)[2][8] = R.rw;
         const bool first = ch < nch1;
         const int kk = first ? k1 : k2, k0 = (first ? ch : ch - nch1) * BKB;
         const uint16_t* A = first ? A1 : A2;
@@ -372,18 +377,19 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_b_mid(const uint16_t* __r
             }
         }
     };
-    load_chunk(0);
-    for (int ch = 0; ch < nch; ++ch) {
+    load_chunk(0, s0);
+    if (nch > 1) load_chunk(1, s1);
+    auto step = [&](int ch, RS& R, RS& Rn) {
         __syncthreads();                 // the previous chunk's fragments have been read
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int rr = sr + p * 32;
-            *reinterpret_cast<uint4*>(As + rr * LDB + scol * 2) = ra[p];
-            *reinterpret_cast<uint4*>(Ws + rr * LDB + scol * 2) = make_uint4(pk_bf16(rw[p][0], rw[p][1]), pk_bf16(rw[p][2], rw[p][3]), pk_bf16(rw[p][4], rw[p][5]),
-                                                                             pk_bf16(rw[p][6], rw[p][7]));
+            *reinterpret_cast<uint4*>(As + rr * LDB + scol * 2) = R.ra[p];
+            *reinterpret_cast<uint4*>(Ws + rr * LDB + scol * 2) = make_uint4(pk_bf16(R.rw[p][0], R.rw[p][1]), pk_bf16(R.rw[p][2], R.rw[p][3]),
+                                                                             pk_bf16(R.rw[p][4], R.rw[p][5]), pk_bf16(R.rw[p][6], R.rw[p][7]));
         }
         __syncthreads();
-        if (ch + 1 < nch) load_chunk(ch + 1);      // in flight under the products below
+        if (ch + 2 < nch) load_chunk(ch + 2, Rn);      // two chunks ahead, in flight under the products below and the next chunk's
         const char* ap = As + (wr * 32 + l31) * LDB + h * 16;
         const char* bp = Ws + (wc * 32 + l31) * LDB + h * 16;
 #pragma unroll
@@ -392,6 +398,11 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_b_mid(const uint16_t* __r
             const bf16x8_t bv = *reinterpret_cast<const bf16x8_t*>(bp + 32 * S);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
         }
+    };
+    for (int ch0 = 0; ch0 < nch; ch0 += 3) {
+        step(ch0, s0, s2);
+        if (ch0 + 1 < nch) step(ch0 + 1, s1, s0);
+        if (ch0 + 2 < nch) step(ch0 + 2, s2, s1);
     }
     const int col = col0 + wc * 32 + l31;
     if (col < n_out) {
@@ -929,20 +940,23 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_x3_mid(const float* __res
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const int nch1 = (k1 + XK - 1) / XK, nch2 = A2 ? (k2 + XK - 1) / XK : 0, nch = nch1 + nch2;
-    f32x4 ra[2], rw[2];
-    auto load_chunk = [&](int ch) {
+    // three register sets: the loads of the next TWO chunks are in flight while a chunk is multiplied (with one tile per CU -- M = 1 024 -- nothing
+    // else hides a load's round trip: one chunk ahead left ~1 us per 32-wide chunk exposed)
+    f32x4 ra0[2], rw0[2], ra1[2], rw1[2], ra2[2], rw2[2];
+    auto load_chunk = [&](int ch, f32x4 (&ra)[2], f32x4 (&rw)[2]) {
         const bool first = ch < nch1;
         const int kk = first ? k1 : k2, k0 = (first ? ch : ch - nch1) * XK;
         x3_load<2>(ra, first ? A1 : A2, first ? lda1 : lda2, row0, M, k0, kk, first ? vec1 : vec2);
         x3_load<2>(rw, first ? W1 : W2, first ? ldw1 : ldw2, col0, n_out, k0, kk, first ? vec1 : vec2);
     };
-    load_chunk(0);
-    for (int ch = 0; ch < nch; ++ch) {
+    load_chunk(0, ra0, rw0);
+    if (nch > 1) load_chunk(1, ra1, rw1);
+    auto step = [&](int ch, f32x4 (&ra)[2], f32x4 (&rw)[2], f32x4 (&ran)[2], f32x4 (&rwn)[2]) {
         __syncthreads();
         x3_store<2>(As, ra);
         x3_store<2>(Ws, rw);
         __syncthreads();
-        if (ch + 1 < nch) load_chunk(ch + 1);
+        if (ch + 2 < nch) load_chunk(ch + 2, ran, rwn);
         const char* ap = As + (wr * 32 + l31) * XLD + h * 16;
         const char* bp = Ws + (wc * 32 + l31) * XLD + h * 16;
 #pragma unroll
@@ -960,6 +974,11 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_x3_mid(const float* __res
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc, 0, 0, 0);
         }
+    };
+    for (int ch0 = 0; ch0 < nch; ch0 += 3) {
+        step(ch0, ra0, rw0, ra2, rw2);
+        if (ch0 + 1 < nch) step(ch0 + 1, ra1, rw1, ra0, rw0);
+        if (ch0 + 2 < nch) step(ch0 + 2, ra2, rw2, ra1, rw1);
     }
     {
         const int col = col0 + wc * 32 + l31;

@@ -234,20 +234,36 @@ __global__ void __launch_bounds__(512, 2) k_agg_sr(const int32_t* __restrict__ r
     // wavefront that runs 10 % ahead after 60 steps works 6 x 2048 cells away from the slowest, and the rows the XCD's L2 has to hold are several
     // times the 2 MB of one sweep line (tools/locality_model.py: an LRU cache of 4096 rows misses 30 % of the requests of an in-order walk; the
     // launch measured 48 %).
-    int64_t qa, qb, qc;
-    int tk_next = 0;
-    auto draw = [&](int k) -> int {      // k tickets, the first one comes back (lane 0 draws, the wavefront shares)
-        int t = 0;
-        if (lane == 0) t = atomicAdd(tickets + xcd, k);
-        return __builtin_amdgcn_readfirstlane(t);
+    // A ticket is TK_G consecutive groups (16 cells); the counters of the 8 XCDs sit 256 bytes apart (one cache line each: eight counters in one line
+    // were served as one word, 88 draws / us for the whole chip, and a draw per group made the launch 3.7 x slower); a ticket is drawn when its
+    // predecessor is opened and read two groups before it is needed, so its latency is never waited for.
+    constexpr int TK_STRIDE = 64;
+    const int TK_G = nt_ >> 8;          // groups per ticket (launch parameter, bits 8.. of nt_)
+    int64_t it_base = 0;
+    int it_idx = 0, it_raw = 0;
+    auto draw = [&]() {                  // lane 0 draws; the value stays in its register until the ticket is opened
+        if (lane == 0) it_raw = atomicAdd(tickets + TK_STRIDE * xcd, 1);
+    };
+    auto next_q = [&]() -> int64_t {     // the next group this wavefront takes (static walk: + wpx)
+        if (!tickets) {
+            const int64_t q_ = it_base;
+            it_base += wpx;
+            return q_;
+        }
+        if (it_idx == TK_G) {
+            it_base = q_lo + (int64_t)__builtin_amdgcn_readfirstlane(it_raw) * TK_G;
+            it_idx = 0;
+            draw();
+        }
+        return it_base + it_idx++;
     };
     if (tickets) {
-        const int t0 = draw(3);
-        qa = q_lo + t0, qb = qa + 1, qc = qa + 2;
-        tk_next = draw(1);
+        draw();
+        it_idx = TK_G;                   // the first next_q() opens the ticket just drawn and draws the one after it
     } else {
-        qa = q_lo + slot * 8 + w, qb = qa + wpx, qc = qb + wpx;
+        it_base = q_lo + slot * 8 + w;
     }
+    int64_t qa = next_q(), qb = next_q(), qc = next_q();
     int vb1 = 0, vb2 = 0, vsrc1 = 0, veid1 = 0;
     bool reg1 = false;
     load_rp(qa, vb1);
@@ -263,15 +279,8 @@ __global__ void __launch_bounds__(512, 2) k_agg_sr(const int32_t* __restrict__ r
         vb1 = vb2;
         load_idx(qb, vb1, reg1, vsrc1, veid1);
         load_rp(qc, vb2);
-        const int64_t q_now = q;
         q = qb, qb = qc;
-        if (tickets) {
-            qc = q_lo + tk_next;
-            tk_next = draw(1);
-        } else {
-            qc = qb + wpx;
-        }
-        (void)q_now;
+        qc = next_q();
         const int tl = tq < nv ? tq : nv - 1;                          // a short group at the end of the graph: clamped (duplicated) cells
         const int64_t cell = i0 + tl;
         float aout[NB];
@@ -1020,6 +1029,7 @@ extern "C" int dgnn_sage_aggregate_sr(const int32_t* rowptr, const int32_t* src,
     static const int ilv = getenv("DGNN_AGG_SR_ILV") ? atoi(getenv("DGNN_AGG_SR_ILV")) : 2;   // measured: 1 / 2 / 4 interleaved chains within 1 % (the launch is bound by its gathers); 2 keeps four wavefronts per SIMD
     // the XCDs' group counters of the ticket walk (see the kernel): 8 ints per device, zeroed in stream order before every launch
     static const bool tickets_on = !(getenv("DGNN_AGG_SR_TICKETS") && getenv("DGNN_AGG_SR_TICKETS")[0] == '0');
+    static const int tk_g = getenv("DGNN_AGG_SR_TK_G") && atoi(getenv("DGNN_AGG_SR_TK_G")) > 0 ? atoi(getenv("DGNN_AGG_SR_TK_G")) : 1;   // groups of 4 cells per ticket
     int* tickets = nullptr;
     if (tickets_on) {
         static int* tk_dev[DGNN_MAX_DEVICES];
@@ -1027,19 +1037,19 @@ extern "C" int dgnn_sage_aggregate_sr(const int32_t* rowptr, const int32_t* src,
         int dev = 0;
         if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < DGNN_MAX_DEVICES) {
             std::lock_guard<std::mutex> lock(tk_m);
-            if (!tk_dev[dev] && hipMalloc((void**)&tk_dev[dev], 16 * 64 * sizeof(int)) != hipSuccess) {
+            if (!tk_dev[dev] && hipMalloc((void**)&tk_dev[dev], 16 * 2 * 512 * sizeof(int)) != hipSuccess) {
                 tk_dev[dev] = nullptr;
                 (void)hipGetLastError();
             }
             static unsigned tk_turn[DGNN_MAX_DEVICES];
-            if (tk_dev[dev]) tickets = tk_dev[dev] + 64 * (tk_turn[dev]++ & 15);      // a ring of 16 counter sets: launches in flight on other streams keep theirs
+            if (tk_dev[dev]) tickets = tk_dev[dev] + 2 * 512 * (tk_turn[dev]++ & 15);    // a ring of 16 counter sets (two passes each): launches in flight on other streams keep theirs
         }
     }
 #define DGNN_AGG_SR(NB_, SR_, IL_)                                                                                                                       \
     hipLaunchKernelGGL((k_agg_sr<NB_, SR_, IL_>), grid, block, lds, st, rowptr, src, eid, n_dst, x, ldx, rowb, xs, ng, edge_attr, lde, We, be,            \
-                       static_cast<const char*>(prep), pass, static_cast<char*>(a_out), rowb, a_scales, ng, static_cast<char*>(x_out), x_scales, sr_nt(), \
-                       tickets ? tickets + 8 * (pass & 7) : nullptr)
-    if (tickets) (void)hipMemsetAsync(tickets, 0, 64 * sizeof(int), st);
+                       static_cast<const char*>(prep), pass, static_cast<char*>(a_out), rowb, a_scales, ng, static_cast<char*>(x_out), x_scales, sr_nt() | (tk_g << 8), \
+                       tickets ? tickets + 512 * (pass & 1) : nullptr)
+    if (tickets) (void)hipMemsetAsync(tickets, 0, 2 * 512 * sizeof(int), st);
     for (int pass = 0; pass < np; ++pass) {
         if (x_is_sr) {
             if (ilv == 1) DGNN_AGG_SR(16, true, 1);
