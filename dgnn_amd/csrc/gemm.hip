@@ -311,34 +311,34 @@ __global__ void __launch_bounds__(256) k_linear_fwd_b(const uint16_t* __restrict
 // 64 x 64 output tile with the next chunk's loads in flight under the products (round 6): for the problems between k_linear_fwd_b (128 x 64 tiles,
 // loads and products one after the other) and k_linear_fwd_b_small (no LDS: both operands re-read per 32 x 32 block) -- the reference's training widths
 // at batch 1024, see k_linear_fwd_x3_mid.  k-steps in k_linear_fwd_b's order: bit-identical results.
-template <typename TO>
-__global__ void __launch_bounds__(256, 2) k_linear_fwd_b_mid(const uint16_t* __restrict__ A1, int64_t lda1, int k1, const float* __restrict__ W1,
-                                                             int64_t ldw1, bool va1, bool vw1, const uint16_t* __restrict__ A2, int64_t lda2, int k2,
-                                                             const float* __restrict__ W2, int64_t ldw2, bool va2, bool vw2,
-                                                             const float* __restrict__ bias, const float* __restrict__ scale,
-                                                             const float* __restrict__ shift, int relu, int64_t M, int n_out, TO* __restrict__ out,
-                                                             int64_t ldo) {
+// KS = 4: four groups of four wavefronts walk a quarter of the chunks each (see k_linear_fwd_x3_mid<4>).
+template <typename TO, int KS>
+__global__ void __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) k_linear_fwd_b_mid(const uint16_t* __restrict__ A1, int64_t lda1, int k1, const float* __restrict__ W1,
+                                                                            int64_t ldw1, bool va1, bool vw1, const uint16_t* __restrict__ A2, int64_t lda2, int k2,
+                                                                            const float* __restrict__ W2, int64_t ldw2, bool va2, bool vw2,
+                                                                            const float* __restrict__ bias, const float* __restrict__ scale,
+                                                                            const float* __restrict__ shift, int relu, int64_t M, int n_out, TO* __restrict__ out,
+                                                                            int64_t ldo) {
     constexpr int TM = 64, TN = 64;
-    __shared__ __attribute__((aligned(16))) char As[TM * LDB];
-    __shared__ __attribute__((aligned(16))) char Ws[TN * LDB];
+    extern __shared__ __attribute__((aligned(16))) char midb_smem[];     // per group: As [TM][LDB] | Ws [TN][LDB]
     const int lane = lane_id(), w = wave_id_uniform();
-    const int wr = w >> 1, wc = w & 1, h = lane >> 5, l31 = lane & 31;
+    const int g = w >> 2, wq = w & 3;
+    const int wr = wq >> 1, wc = wq & 1, h = lane >> 5, l31 = lane & 31;
+    char* const As = midb_smem + g * ((TM + TN) * LDB);
+    char* const Ws = As + TM * LDB;
     const int ncb = (n_out + TN - 1) / TN;
     const int64_t row0 = (int64_t)(blockIdx.x / ncb) * TM;
     const int col0 = (int)(blockIdx.x % ncb) * TN;
-    const int t = threadIdx.x, sr = t >> 3, scol = (t & 7) * 8;      // staging: 8 threads per row, 8 elements each, 32 rows per pass
+    const int t = (int)threadIdx.x & 255, sr = t >> 3, scol = (t & 7) * 8;      // staging: 8 threads per row, 8 elements each, 32 rows per pass
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const int nch1 = (k1 + BKB - 1) / BKB, nch2 = A2 ? (k2 + BKB - 1) / BKB : 0, nch = nch1 + nch2;
-    struct RS {
-        uint4 ra[2];
-        float rw[2][8];
-    };
-    RS s0, s1, s2;       // three register sets: two chunks of loads in flight (see k_linear_fwd_x3_mid)
-    auto load_chunk = [&](int ch, RS& R) {
-        uint4 (&ra)[2] = R.ra;
-        float (&rw)[2][8] = R.rw;
+    const int cpg = (nch + KS - 1) / KS;
+    const int ch_lo = g * cpg, ch_hi = ch_lo + cpg < nch ? ch_lo + cpg : nch;
+    uint4 ra[2];
+    float rw[2][8];
+    auto load_chunk = [&](int ch) {
         const bool first = ch < nch1;
         const int kk = first ? k1 : k2, k0 = (first ? ch : ch - nch1) * BKB;
         const uint16_t* A = first ? A1 : A2;
@@ -351,13 +351,13 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_b_mid(const uint16_t* __r
             const int64_t gr = row0 + rr;
             ra[p] = make_uint4(0u, 0u, 0u, 0u);
             if (gr < M && k0 + scol < kk) {
-                const uint16_t* g = A + gr * lda + k0 + scol;
+                const uint16_t* gp = A + gr * lda + k0 + scol;
                 if (va && k0 + scol + 8 <= kk) {
-                    ra[p] = *reinterpret_cast<const uint4*>(g);
+                    ra[p] = *reinterpret_cast<const uint4*>(gp);
                 } else {
                     uint32_t e[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) e[j] = (k0 + scol + j < kk) ? (uint32_t)g[j] : 0u;
+                    for (int j = 0; j < 8; ++j) e[j] = (k0 + scol + j < kk) ? (uint32_t)gp[j] : 0u;
                     ra[p] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
                 }
             }
@@ -365,31 +365,35 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_b_mid(const uint16_t* __r
 #pragma unroll
             for (int j = 0; j < 8; ++j) rw[p][j] = 0.f;
             if (gc < n_out && k0 + scol < kk) {
-                const float* g = W + gc * ldw + k0 + scol;
+                const float* gp = W + gc * ldw + k0 + scol;
                 if (vw && k0 + scol + 8 <= kk) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(g), b = *reinterpret_cast<const f32x4*>(g + 4);
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(gp), b = *reinterpret_cast<const f32x4*>(gp + 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { rw[p][j] = a[j]; rw[p][4 + j] = b[j]; }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) if (k0 + scol + j < kk) rw[p][j] = g[j];
+                    for (int j = 0; j < 8; ++j) if (k0 + scol + j < kk) rw[p][j] = gp[j];
                 }
             }
         }
     };
-    load_chunk(0, s0);
-    if (nch > 1) load_chunk(1, s1);
-    auto step = [&](int ch, RS& R, RS& Rn) {
+    if (ch_lo < ch_hi) load_chunk(ch_lo);
+    for (int i = 0; i < cpg; ++i) {
+        const int ch = ch_lo + i;
+        const bool live = ch < ch_hi;
         __syncthreads();                 // the previous chunk's fragments have been read
+        if (live) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int rr = sr + p * 32;
-            *reinterpret_cast<uint4*>(As + rr * LDB + scol * 2) = R.ra[p];
-            *reinterpret_cast<uint4*>(Ws + rr * LDB + scol * 2) = make_uint4(pk_bf16(R.rw[p][0], R.rw[p][1]), pk_bf16(R.rw[p][2], R.rw[p][3]),
-                                                                             pk_bf16(R.rw[p][4], R.rw[p][5]), pk_bf16(R.rw[p][6], R.rw[p][7]));
+            for (int p = 0; p < 2; ++p) {
+                const int rr = sr + p * 32;
+                *reinterpret_cast<uint4*>(As + rr * LDB + scol * 2) = ra[p];
+                *reinterpret_cast<uint4*>(Ws + rr * LDB + scol * 2) = make_uint4(pk_bf16(rw[p][0], rw[p][1]), pk_bf16(rw[p][2], rw[p][3]), pk_bf16(rw[p][4], rw[p][5]),
+                                                                                 pk_bf16(rw[p][6], rw[p][7]));
+            }
         }
         __syncthreads();
-        if (ch + 2 < nch) load_chunk(ch + 2, Rn);      // two chunks ahead, in flight under the products below and the next chunk's
+        if (ch + 1 < ch_hi) load_chunk(ch + 1);      // in flight under the products below
+        if (!live) continue;
         const char* ap = As + (wr * 32 + l31) * LDB + h * 16;
         const char* bp = Ws + (wc * 32 + l31) * LDB + h * 16;
 #pragma unroll
@@ -398,11 +402,20 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_b_mid(const uint16_t* __r
             const bf16x8_t bv = *reinterpret_cast<const bf16x8_t*>(bp + 32 * S);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
         }
-    };
-    for (int ch0 = 0; ch0 < nch; ch0 += 3) {
-        step(ch0, s0, s2);
-        if (ch0 + 1 < nch) step(ch0 + 1, s1, s0);
-        if (ch0 + 2 < nch) step(ch0 + 2, s2, s1);
+    }
+    if (KS > 1) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(midb_smem);
+        if (g > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(((g - 1) * 4 + wq) * 16 + r) * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (g > 0) return;
+#pragma unroll
+        for (int gg = 0; gg < KS - 1; ++gg)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += red[((gg * 4 + wq) * 16 + r) * 64 + lane];
     }
     const int col = col0 + wc * 32 + l31;
     if (col < n_out) {
@@ -750,8 +763,8 @@ __device__ __forceinline__ void x3_split(float x0, float x1, uint32_t& hi, uint3
 // loads into 4 x float4, x3_store splits them and writes the LDS image after the barrier.
 template <int NP = 4>
 __device__ __forceinline__ void x3_load(f32x4 (&v)[NP], const float* __restrict__ src, int64_t ld, int64_t row0, int64_t nrows, int k0, int kmax,
-                                        bool vec) {
-    const int t = threadIdx.x, r = t >> 3, c = (t & 7) * 4;
+                                        bool vec, int tid = -1) {
+    const int t = tid < 0 ? (int)threadIdx.x : tid, r = t >> 3, c = (t & 7) * 4;
     if (vec && k0 + XK <= kmax) {
         // whole chunk inside K and 16-byte aligned rows (uniform per chunk): four unconditional loads.  Rows past the end are
         // clamped to the last row -- they only feed output rows / columns that are never stored.
@@ -775,8 +788,8 @@ __device__ __forceinline__ void x3_load(f32x4 (&v)[NP], const float* __restrict_
     }
 }
 template <int NP = 4>
-__device__ __forceinline__ void x3_store(char* __restrict__ dst, const f32x4 (&v)[NP]) {
-    const int t = threadIdx.x, r = t >> 3, c = (t & 7) * 4;
+__device__ __forceinline__ void x3_store(char* __restrict__ dst, const f32x4 (&v)[NP], int tid = -1) {
+    const int t = tid < 0 ? (int)threadIdx.x : tid, r = t >> 3, c = (t & 7) * 4;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         uint32_t h0, m0, l0, h1, m1, l1;
@@ -920,17 +933,25 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_x3(const float* __restric
 // K = N = 1 024: 66 us) and make the LDS-free small-problem kernel re-read both operands once per 32 x 32 block (39 us, L2-bound: 268 MB for 8 MB of
 // operands); four times as many tiles as the former, half the operand traffic of the latter.  Same chunk and product order per output element as
 // k_linear_fwd_x3: bit-identical results.
-__global__ void __launch_bounds__(256, 2) k_linear_fwd_x3_mid(const float* __restrict__ A1, int64_t lda1, int k1, const float* __restrict__ W1,
-                                                              int64_t ldw1, bool vec1, const float* __restrict__ A2, int64_t lda2, int k2,
-                                                              const float* __restrict__ W2, int64_t ldw2, bool vec2,
-                                                              const float* __restrict__ bias, const float* __restrict__ scale,
-                                                              const float* __restrict__ shift, int relu, int64_t M, int n_out,
-                                                              float* __restrict__ out, int64_t ldo, double* __restrict__ colstats) {
+// KS = 4 (K >= 1 024 and fewer tiles than 2 per CU): the workgroup is 16 wavefronts, four groups of four, every group walks a quarter of the chunks
+// of the SAME tile through its own LDS buffers; the partial blocks are added in group order by group 0, which runs the epilogue.  With one 4-wavefront
+// tile per CU (M = 1 024, K = N = 1 024) every barrier, LDS round trip and load of the chunk loop was exposed -- one wavefront per SIMD: 34 us, and two
+// chunks of loads in flight instead of one changed nothing; four per SIMD hide them behind each other.  (Another summation order than the KS = 1
+// form: fp32 rounding level.)
+template <int KS>
+__global__ void __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) k_linear_fwd_x3_mid(const float* __restrict__ A1, int64_t lda1, int k1, const float* __restrict__ W1,
+                                                                             int64_t ldw1, bool vec1, const float* __restrict__ A2, int64_t lda2, int k2,
+                                                                             const float* __restrict__ W2, int64_t ldw2, bool vec2,
+                                                                             const float* __restrict__ bias, const float* __restrict__ scale,
+                                                                             const float* __restrict__ shift, int relu, int64_t M, int n_out,
+                                                                             float* __restrict__ out, int64_t ldo, double* __restrict__ colstats) {
     constexpr int TM = 64, TN = 64;
-    __shared__ __attribute__((aligned(16))) char As[TM * XLD];
-    __shared__ __attribute__((aligned(16))) char Ws[TN * XLD];
+    extern __shared__ __attribute__((aligned(16))) char mid_smem[];      // per group: As [TM][XLD] | Ws [TN][XLD]
     const int lane = lane_id(), w = wave_id_uniform();
-    const int wr = w >> 1, wc = w & 1, h = lane >> 5, l31 = lane & 31;
+    const int g = w >> 2, wq = w & 3, tid = (int)threadIdx.x & 255;
+    const int wr = wq >> 1, wc = wq & 1, h = lane >> 5, l31 = lane & 31;
+    char* const As = mid_smem + g * ((TM + TN) * XLD);
+    char* const Ws = As + TM * XLD;
     const int ncb = (n_out + TN - 1) / TN;
     const int64_t rb = (int64_t)((blockIdx.x >> 3) / ncb) * 8 + (blockIdx.x & 7);      // XCD-aware tile map as in k_linear_fwd_x3
     if (rb * TM >= M) return;
@@ -940,23 +961,27 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_x3_mid(const float* __res
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const int nch1 = (k1 + XK - 1) / XK, nch2 = A2 ? (k2 + XK - 1) / XK : 0, nch = nch1 + nch2;
-    // three register sets: the loads of the next TWO chunks are in flight while a chunk is multiplied (with one tile per CU -- M = 1 024 -- nothing
-    // else hides a load's round trip: one chunk ahead left ~1 us per 32-wide chunk exposed)
-    f32x4 ra0[2], rw0[2], ra1[2], rw1[2], ra2[2], rw2[2];
-    auto load_chunk = [&](int ch, f32x4 (&ra)[2], f32x4 (&rw)[2]) {
+    const int cpg = (nch + KS - 1) / KS;                       // chunks per group
+    const int ch_lo = g * cpg, ch_hi = ch_lo + cpg < nch ? ch_lo + cpg : nch;
+    f32x4 ra[2], rw[2];
+    auto load_chunk = [&](int ch) {
         const bool first = ch < nch1;
         const int kk = first ? k1 : k2, k0 = (first ? ch : ch - nch1) * XK;
-        x3_load<2>(ra, first ? A1 : A2, first ? lda1 : lda2, row0, M, k0, kk, first ? vec1 : vec2);
-        x3_load<2>(rw, first ? W1 : W2, first ? ldw1 : ldw2, col0, n_out, k0, kk, first ? vec1 : vec2);
+        x3_load<2>(ra, first ? A1 : A2, first ? lda1 : lda2, row0, M, k0, kk, first ? vec1 : vec2, tid);
+        x3_load<2>(rw, first ? W1 : W2, first ? ldw1 : ldw2, col0, n_out, k0, kk, first ? vec1 : vec2, tid);
     };
-    load_chunk(0, ra0, rw0);
-    if (nch > 1) load_chunk(1, ra1, rw1);
-    auto step = [&](int ch, f32x4 (&ra)[2], f32x4 (&rw)[2], f32x4 (&ran)[2], f32x4 (&rwn)[2]) {
+    if (ch_lo < ch_hi) load_chunk(ch_lo);
+    for (int i = 0; i < cpg; ++i) {
+        const int ch = ch_lo + i;
+        const bool live = ch < ch_hi;
         __syncthreads();
-        x3_store<2>(As, ra);
-        x3_store<2>(Ws, rw);
+        if (live) {
+            x3_store<2>(As, ra, tid);
+            x3_store<2>(Ws, rw, tid);
+        }
         __syncthreads();
-        if (ch + 2 < nch) load_chunk(ch + 2, ran, rwn);
+        if (ch + 1 < ch_hi) load_chunk(ch + 1);
+        if (!live) continue;
         const char* ap = As + (wr * 32 + l31) * XLD + h * 16;
         const char* bp = Ws + (wc * 32 + l31) * XLD + h * 16;
 #pragma unroll
@@ -974,11 +999,20 @@ __global__ void __launch_bounds__(256, 2) k_linear_fwd_x3_mid(const float* __res
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc, 0, 0, 0);
         }
-    };
-    for (int ch0 = 0; ch0 < nch; ch0 += 3) {
-        step(ch0, ra0, rw0, ra2, rw2);
-        if (ch0 + 1 < nch) step(ch0 + 1, ra1, rw1, ra0, rw0);
-        if (ch0 + 2 < nch) step(ch0 + 2, ra2, rw2, ra1, rw1);
+    }
+    if (KS > 1) {      // the groups' partial blocks -> group 0, in group order (16 KB per group: [wavefront][register][lane], over the chunk buffers)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(mid_smem);
+        if (g > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(((g - 1) * 4 + wq) * 16 + r) * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (g > 0) return;
+#pragma unroll
+        for (int gg = 0; gg < KS - 1; ++gg)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += red[((gg * 4 + wq) * 16 + r) * 64 + lane];
     }
     {
         const int col = col0 + wc * 32 + l31;
@@ -2028,12 +2062,26 @@ extern "C" int dgnn_linear_fwd_bf16(const uint16_t* A1, int64_t lda1, int k1, co
     static const bool mid_ok = !(getenv("DGNN_GEMM_MID") && getenv("DGNN_GEMM_MID")[0] == '0');
     if (mid_ok && !tiles_fill && M <= 16384 && k1 + (A2 ? k2 : 0) >= 512 && dgnn_cdiv(M, 64) * dgnn_cdiv(n_out, 64) >= 128) {   // 64 x 64 tiles (see the kernel)
         dim3 mgrid((unsigned)(dgnn_cdiv(M, 64) * dgnn_cdiv(n_out, 64)));
-        if (out_f32)
-            hipLaunchKernelGGL((k_linear_fwd_b_mid<float>), mgrid, dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, va1, vw1, A2, lda2, k2, W2, ldw2,
-                               va2, vw2, bias, scale, shift, relu, M, n_out, (float*)out, ldo);
-        else
-            hipLaunchKernelGGL((k_linear_fwd_b_mid<uint16_t>), mgrid, dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, va1, vw1, A2, lda2, k2, W2,
-                               ldw2, va2, vw2, bias, scale, shift, relu, M, n_out, (uint16_t*)out, ldo);
+        constexpr size_t lds1 = (size_t)(64 + 64) * LDB;
+        static const bool ks_ok = !(getenv("DGNN_GEMM_MID_KS") && getenv("DGNN_GEMM_MID_KS")[0] == '0');
+        const bool ks4 = ks_ok && k1 + (A2 ? k2 : 0) >= 1024 && dgnn_cdiv(M, 64) * dgnn_cdiv(n_out, 64) <= 2 * DGNN_NUM_CU;
+        static_assert(4 * lds1 >= 3 * 4 * 16 * 64 * sizeof(float), "the groups' partial blocks fit the chunk buffers");
+#define DGNN_MIDB(TO_, KS_)                                                                                                                                  \
+        hipLaunchKernelGGL((k_linear_fwd_b_mid<TO_, KS_>), mgrid, dim3(256 * KS_), KS_ * lds1, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, va1, vw1, A2, lda2, k2, \
+                           W2, ldw2, va2, vw2, bias, scale, shift, relu, M, n_out, (TO_*)out, ldo)
+        if (ks4) {
+            static bool attr_f[DGNN_MAX_DEVICES], attr_h[DGNN_MAX_DEVICES];
+            if (out_f32) {
+                dgnn_allow_dynamic_lds((const void*)k_linear_fwd_b_mid<float, 4>, 4 * lds1, attr_f);
+                DGNN_MIDB(float, 4);
+            } else {
+                dgnn_allow_dynamic_lds((const void*)k_linear_fwd_b_mid<uint16_t, 4>, 4 * lds1, attr_h);
+                DGNN_MIDB(uint16_t, 4);
+            }
+        } else {
+            if (out_f32) DGNN_MIDB(float, 1); else DGNN_MIDB(uint16_t, 1);
+        }
+#undef DGNN_MIDB
         return dgnn_check_launch("linear_fwd_bf16");
     }
     if (small_ok && !tiles_fill && splitk_ok && M <= 16384 && k1 + (A2 ? k2 : 0) >= 1024) {   // four wavefronts per output block, a quarter of K each (see the kernel)
@@ -2124,8 +2172,17 @@ int linear_fwd_x3_impl(const float* A1, int64_t lda1, int k1, const float* W1, i
     static const bool mid_ok = !(getenv("DGNN_GEMM_MID") && getenv("DGNN_GEMM_MID")[0] == '0');
     if (mid_ok && !tiles_fill && M <= small_m && n_out > ZN && k1 + (A2 ? k2 : 0) >= 512 && dgnn_cdiv(M, 64) * dgnn_cdiv(n_out, 64) >= 128) {
         dim3 grid((unsigned)(dgnn_cdiv(dgnn_cdiv(M, 64), 8) * 8 * dgnn_cdiv(n_out, 64)));
-        hipLaunchKernelGGL(k_linear_fwd_x3_mid, grid, dim3(256), 0, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2, lda2, k2, W2, ldw2, v2, bias, scale, shift,
-                           relu, M, n_out, out, ldo, colstats);
+        constexpr size_t lds1 = (size_t)(64 + 64) * XLD;
+        static const bool ks_ok = !(getenv("DGNN_GEMM_MID_KS") && getenv("DGNN_GEMM_MID_KS")[0] == '0');
+        if (ks_ok && k1 + (A2 ? k2 : 0) >= 1024 && dgnn_cdiv(M, 64) * dgnn_cdiv(n_out, 64) <= 2 * DGNN_NUM_CU) {
+            static bool attr_set[DGNN_MAX_DEVICES];
+            dgnn_allow_dynamic_lds((const void*)k_linear_fwd_x3_mid<4>, 4 * lds1, attr_set);
+            hipLaunchKernelGGL(k_linear_fwd_x3_mid<4>, grid, dim3(1024), 4 * lds1, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2, lda2, k2, W2, ldw2, v2, bias,
+                               scale, shift, relu, M, n_out, out, ldo, colstats);
+        } else {
+            hipLaunchKernelGGL(k_linear_fwd_x3_mid<1>, grid, dim3(256), lds1, (hipStream_t)stream, A1, lda1, k1, W1, ldw1, v1, A2, lda2, k2, W2, ldw2, v2, bias, scale,
+                               shift, relu, M, n_out, out, ldo, colstats);
+        }
         return dgnn_check_launch("linear_fwd_x3");
     }
     if (small_ok && !tiles_fill && M <= small_m) {

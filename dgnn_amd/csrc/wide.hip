@@ -1031,7 +1031,11 @@ extern "C" int dgnn_sage_aggregate_sr(const int32_t* rowptr, const int32_t* src,
     static const bool tickets_on = !(getenv("DGNN_AGG_SR_TICKETS") && getenv("DGNN_AGG_SR_TICKETS")[0] == '0');
     static const int tk_g = getenv("DGNN_AGG_SR_TK_G") && atoi(getenv("DGNN_AGG_SR_TK_G")) > 0 ? atoi(getenv("DGNN_AGG_SR_TK_G")) : 1;   // groups of 4 cells per ticket
     int* tickets = nullptr;
-    if (tickets_on) {
+    // ... for split-row input (C >= 256).  Measured (profiles/r06_wide.md): C = 256 pass FETCH_SIZE 1.53 M -> 0.85 M KiB, L2 hit rate 52 -> 68 %, 802 -> 805 us;
+    // the fp32-row form (C = 128, which also writes the own rows) 0.94 M -> 0.78 M KiB but 581 -> 695 us: it keeps the static walk unless
+    // DGNN_AGG_SR_TICKETS=2.
+    static const bool tickets_all = getenv("DGNN_AGG_SR_TICKETS") && getenv("DGNN_AGG_SR_TICKETS")[0] == '2';
+    if (tickets_on && (x_is_sr || tickets_all)) {
         static int* tk_dev[DGNN_MAX_DEVICES];
         static std::mutex tk_m;
         int dev = 0;

@@ -250,12 +250,19 @@ def test_x3_gemm_large_tile_equals_the_small_tile_and_fp64(monkeypatch, k1, k2, 
     bias = torch.randn(n_out, generator=g).to(DEV)
     big = ops.linear_fwd(A1, W1, A2, W2, bias, relu=True)
     small = torch.cat([ops.linear_fwd(A1[s:s + 4096], W1, A2[s:s + 4096] if k2 else None, W2, bias, relu=True) for s in range(0, M, 4096)])
-    assert torch.equal(big, small)
     ref = A1.double() @ W1.double().t() + bias.double()
     if k2:
         ref = ref + A2.double() @ W2.double().t()
     ref = ref.clamp_min(0)
+    if k1 + k2 >= 1024:
+        # round 6: the ragged last slice (589 rows, K = 1024) takes the 64 x 64 tiles with four K groups per workgroup (k_linear_fwd_x3_mid<4>):
+        # another summation order, fp32 rounding level; the 4096-row slices take the 128 x 128 tiles: the same bits as the large tile
+        assert torch.equal(big[:8192], small[:8192])
+        assert (big.double() - small.double()).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    else:
+        assert torch.equal(big, small)
     assert (big.double() - ref).abs().max().item() <= 4e-6 * ref.abs().max().item()
+    assert (small.double() - ref).abs().max().item() <= 4e-6 * ref.abs().max().item()
 
 
 @pytest.mark.parametrize("k1,k2,n_out", [(28, 28, 64), (128, 0, 64), (64, 64, 28), (64, 0, 2), (512, 0, 64), (70, 33, 37)])
