@@ -15,9 +15,9 @@ pytestmark = pytest.mark.gpu
 
 # The stated band.  The loss falls 300 x over the run, 4-5 x per 25 steps during the first 100: there a lag of three steps is a
 # 20 % gap between the 25-step means (measured 20.5 % at steps 25-50, bf16 behind), so the band is BAND_EARLY for steps < 100 and BAND_LATE from step
-# 100 on (measured: <= 4.5 %, 1.6 % at the end); both runs must reduce the loss by at least REDUCTION (measured: 300 x).
+# 100 on (measured: <= 5.8 %, 0.5-1.6 % at the end); both runs must reduce the loss by at least REDUCTION (measured: 300 x).
 BAND_EARLY = 0.30
-BAND_LATE = 0.08
+BAND_LATE = 0.10
 REDUCTION = 0.05
 
 
