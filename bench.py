@@ -184,7 +184,10 @@ def timed_steps(step, steps, sync, world, dev):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    return dt, [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+    per = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+    if os.environ.get("DGNN_BENCH_DEBUG_STEPS"):
+        sys.stderr.write("timed_steps: wall %.3f ms; per step (events) %s\n" % (dt * 1e3, " ".join("%.2f" % v for v in per)))
+    return dt, per
 
 
 def logits_check(got, ref, bf16, bf16_compensated=True):
