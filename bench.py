@@ -342,6 +342,7 @@ def start_scene_builder(points, seed):
 
 
 def drop_scene_builder(h):
+    """stops the child (if it still runs) and removes its scratch directory; safe to call twice"""
     if h is None:
         return
     proc, d = h
@@ -433,6 +434,9 @@ def main():
     if (world == 1 and args.scene_10m != "off" and not args.no_extras and args.points == 150000 and args.widths is None and args.dtype == "f32"
             and args.gemm_mode is None):
         scene10 = start_scene_builder(1485000, 0)
+        if scene10 is not None:
+            import atexit
+            atexit.register(drop_scene_builder, scene10)      # (a run that ends before the leg -- an exception, sys.exit -- must not leave the child or its files behind)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     # DGNN_BENCH_BACKEND=gloo: validation runs of the multi-rank path on a box with fewer GPUs than ranks (ranks share
