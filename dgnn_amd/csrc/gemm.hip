@@ -1991,7 +1991,8 @@ int wgrad_splits(int64_t M, int n_a = 0) {
     if (n_a > 0) {
         static const bool by_tiles = !(getenv("DGNN_WGRAD_SPLITS_BY_TILES") && getenv("DGNN_WGRAD_SPLITS_BY_TILES")[0] == '0');
         if (by_tiles) {
-            cap = WGRAD_SPLITS / dgnn_cdiv(n_a, WT);
+            static const int base = getenv("DGNN_WGRAD_SPLIT_CAP") && atoi(getenv("DGNN_WGRAD_SPLIT_CAP")) > 0 ? atoi(getenv("DGNN_WGRAD_SPLIT_CAP")) : WGRAD_SPLITS;
+            cap = base / dgnn_cdiv(n_a, WT);
             if (cap < 32) cap = 32;
         }
     }

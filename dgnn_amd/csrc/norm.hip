@@ -70,11 +70,14 @@ struct RowPiece {
     __device__ __forceinline__ float get(int j) const { return dgnn_ld(&v[j]); }
 };
 
+// zscale / zshift (MODE 1, round 6): the ReLU mask is taken from x itself -- [fma(x, zscale, zshift) > 0], the very expression scale_shift_act stored
+// y = max(., 0) of -- instead of from y: one row read less per pass (the training step's BatchNorm backward read dy, y AND z twice per layer).
 template <int MODE, typename T>
 __global__ void __launch_bounds__(256) k_colreduce4(const T* __restrict__ x, int64_t ldx, const T* __restrict__ y, int64_t ldy,
                                                     const T* __restrict__ dy, int64_t lddy, const float* __restrict__ mean,
                                                     const float* __restrict__ var, float eps, int relu, int64_t M, int c,
-                                                    int64_t rows_per_block, double* __restrict__ partials) {
+                                                    int64_t rows_per_block, double* __restrict__ partials,
+                                                    const float* __restrict__ zscale = nullptr, const float* __restrict__ zshift = nullptr) {
     constexpr int V = RowPiece<T>::V;
     constexpr int CW = 64 * V;            // widest column window: 64 column groups x 4 row lanes (fp32: 256 columns, bf16: 512)
     __shared__ double red[2][256 * V];   // [quantity][row lane][column of the window], nrl * cw = 256 V
@@ -88,15 +91,21 @@ __global__ void __launch_bounds__(256) k_colreduce4(const T* __restrict__ x, int
         const int cb = blockIdx.y * cw;      // one window per blockIdx.y: a [1024 x 1024] matrix (the last layers of a small batch) still fills the chip
         const int col = cb + V * tg;
         double s0[V], s1[V];
-        float mu[V], is[V];
+        float mu[V], is[V], zs[V], zh[V];
+        const bool zmask = MODE == 1 && relu && zscale != nullptr;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             s0[j] = s1[j] = 0.0;
             mu[j] = 0.f;
             is[j] = 1.f;
+            zs[j] = zh[j] = 0.f;
             if (MODE == 1) {
                 mu[j] = mean[col + j];
                 is[j] = 1.0f / sqrtf(var[col + j] + eps);
+                if (zmask) {
+                    zs[j] = zscale[col + j];
+                    zh[j] = zshift[col + j];
+                }
             }
         }
         for (int64_t r = r0 + ty; r < r1; r += nrl) {
@@ -112,11 +121,13 @@ __global__ void __launch_bounds__(256) k_colreduce4(const T* __restrict__ x, int
             } else if (MODE == 1) {
                 RowPiece<T> gv, yv;
                 gv.load(dy + r * lddy + col);
-                if (relu) yv.load(y + r * ldy + col);
+                if (relu && !zmask) yv.load(y + r * ldy + col);
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
                     float g = gv.get(j);
-                    if (relu && !(yv.get(j) > 0.f)) g = 0.f;
+                    if (zmask) {
+                        if (!(__fmaf_rn(xv.get(j), zs[j], zh[j]) > 0.f)) g = 0.f;
+                    } else if (relu && !(yv.get(j) > 0.f)) g = 0.f;
                     const float xh = (xv.get(j) - mu[j]) * is[j];
                     s0[j] += g;
                     s1[j] += (double)g * xh;
@@ -284,13 +295,17 @@ __global__ void k_bn_relu_bwd_apply(const T* __restrict__ x, int64_t ldx, const 
                                     const T* __restrict__ dy, int64_t lddy, const float* __restrict__ gamma,
                                     const float* __restrict__ mean, const float* __restrict__ var, float eps, int train,
                                     int relu, int64_t M, int c, const float* __restrict__ sum_g,
-                                    const float* __restrict__ sum_gx, T* __restrict__ dx, int64_t lddx, float invM) {
+                                    const float* __restrict__ sum_gx, T* __restrict__ dx, int64_t lddx, float invM,
+                                    const float* __restrict__ zscale = nullptr, const float* __restrict__ zshift = nullptr) {
     const int64_t total = M * c;      // invM = 1 / (rows the sums were taken over): M here, the whole scene's rows when the batch spans several ranks
+    const bool zmask = relu && zscale != nullptr;      // the mask from x (see k_colreduce4)
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = t / c;
         const int col = (int)(t - r * c);
         float g = dgnn_ld(dy + r * lddy + col);
-        if (relu && !(dgnn_ld(y + r * ldy + col) > 0.f)) g = 0.f;
+        if (zmask) {
+            if (!(__fmaf_rn(dgnn_ld(x + r * ldx + col), zscale[col], zshift[col]) > 0.f)) g = 0.f;
+        } else if (relu && !(dgnn_ld(y + r * ldy + col) > 0.f)) g = 0.f;
         const float is = 1.0f / sqrtf(var[col] + eps);
         const float gs = (gamma ? gamma[col] : 1.f) * is;
         float o;
@@ -330,15 +345,18 @@ extern "C" int dgnn_bn_fold(const float* gamma, const float* beta, const float* 
 
 // MODE-templated launch: the vectorised kernel for the rows it covers, the general one otherwise
 template <int MODE, typename T>
-static void launch_colreduce(int nblk, hipStream_t stream, const T* x, int64_t ldx, const T* y, int64_t ldy, const T* dy, int64_t lddy, const float* mean,
-                             const float* var, float eps, int relu, int64_t M, int c, int64_t rpb, double* P) {
+static bool launch_colreduce(int nblk, hipStream_t stream, const T* x, int64_t ldx, const T* y, int64_t ldy, const T* dy, int64_t lddy, const float* mean,
+                             const float* var, float eps, int relu, int64_t M, int c, int64_t rpb, double* P, const float* zscale = nullptr,
+                             const float* zshift = nullptr) {
     constexpr int V = 16 / sizeof(T);
     auto al = [](const void* p, int64_t ld) { return p == nullptr || ((((uintptr_t)p) & 15) == 0 && ld % V == 0); };
     if (colreduce4_ok<T>(c) && al(x, ldx) && al(y, ldy) && al(dy, lddy)) {
-        hipLaunchKernelGGL((k_colreduce4<MODE, T>), dim3(nblk, c > 64 * V ? c / (64 * V) : 1), dim3(256), 0, stream, x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, rpb, P);
-        return;
+        hipLaunchKernelGGL((k_colreduce4<MODE, T>), dim3(nblk, c > 64 * V ? c / (64 * V) : 1), dim3(256), 0, stream, x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, rpb, P,
+                           zscale, zshift);
+        return true;      // (took zscale / zshift: the caller's apply pass must use the same mask)
     }
     hipLaunchKernelGGL((k_colreduce<MODE, T>), dim3(nblk), dim3(256), 0, stream, x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, rpb, P);
+    return false;
 }
 
 template <typename T>
@@ -368,16 +386,16 @@ static int scale_shift_act_t(const T* x, int64_t ldx, const float* scale, const 
 template <typename T>
 static int bn_relu_bwd_t(const T* x, int64_t ldx, const T* y, int64_t ldy, const T* dy, int64_t lddy, const float* gamma, const float* mean,
                          const float* var, float eps, int train, int relu, int64_t M, int c, T* dx, int64_t lddx, float* dgamma, float* dbeta,
-                         float* scratch, hipStream_t stream) {
+                         float* scratch, hipStream_t stream, const float* zscale = nullptr, const float* zshift = nullptr) {
     DGNN_REQUIRE(M > 0 && c > 0 && x && dy && mean && var && dx && scratch && (!relu || y), DGNN_E_INVALID, "bn_relu_bwd: bad args");
     const int nblk = red_blocks(M);
     const int64_t rpb = dgnn_cdiv(M, nblk);
     double* P = as_f64(scratch);
     float* sums = reinterpret_cast<float*>(P + (int64_t)nblk * 2 * c);
-    launch_colreduce<1, T>(nblk, stream, x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, rpb, P);
+    const bool zm = launch_colreduce<1, T>(nblk, stream, x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, rpb, P, zscale, zshift) && zscale != nullptr;
     launch_sum_finalize(stream, P, nblk, c, sums, sums + c, 0, dbeta, dgamma);
     hipLaunchKernelGGL((k_bn_relu_bwd_apply<T>), dim3(dgnn_grid_cap(dgnn_cdiv(M * c, 256))), dim3(256), 0, stream, x, ldx, y, ldy, dy, lddy,
-                       gamma, mean, var, eps, train, relu, M, c, sums, sums + c, dx, lddx, 1.0f / (float)M);
+                       gamma, mean, var, eps, train, relu, M, c, sums, sums + c, dx, lddx, 1.0f / (float)M, zm ? zscale : nullptr, zm ? zshift : nullptr);
     return dgnn_check_launch("bn_relu_bwd");
 }
 
@@ -454,6 +472,14 @@ extern "C" int dgnn_bn_relu_bwd(const float* x, int64_t ldx, const float* y, int
     return bn_relu_bwd_t<float>(x, ldx, y, ldy, dy, lddy, gamma, mean, var, eps, train, relu, M, c, dx, lddx, dgamma, dbeta, scratch,
                                 (hipStream_t)stream);
 }
+// library-internal (csrc/train.hip): dgnn_bn_relu_bwd whose ReLU mask comes from x and the forward's (scale, shift) -- y is not read (see k_colreduce4)
+int dgnn_bn_relu_bwd_zmask(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* dy, int64_t lddy, const float* gamma, const float* mean,
+                           const float* var, float eps, int train, int relu, int64_t M, int c, float* dx, int64_t lddx, float* dgamma, float* dbeta,
+                           float* scratch, const float* zscale, const float* zshift, void* stream) {
+    return bn_relu_bwd_t<float>(x, ldx, y, ldy, dy, lddy, gamma, mean, var, eps, train, relu, M, c, dx, lddx, dgamma, dbeta, scratch, (hipStream_t)stream, zscale,
+                                zshift);
+}
+
 extern "C" int dgnn_bn_relu_bwd_sums(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* dy, int64_t lddy, const float* mean,
                                      const float* var, float eps, int relu, int64_t M, int c, float* sums, float* scratch, void* stream) {
     return bn_relu_bwd_sums_f32(x, ldx, y, ldy, dy, lddy, mean, var, eps, relu, M, c, sums, scratch, (hipStream_t)stream);

@@ -118,6 +118,10 @@ extern "C" int64_t dgnn_sage_layer_train_scratch_elems(int64_t n_src, int64_t n_
     return align4(n_dst * c_out) + 2 * align4(n_dst * c_in) + 2 * align4((int64_t)c_in * c_out) + align4(big) + align4(big > wc ? big : wc) + 64;
 }
 
+// library-internal (csrc/norm.hip): dgnn_bn_relu_bwd with the ReLU mask from x and the forward's (scale, shift)
+int dgnn_bn_relu_bwd_zmask(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* dy, int64_t lddy, const float* gamma, const float* mean,
+                           const float* var, float eps, int train, int relu, int64_t M, int c, float* dx, int64_t lddx, float* dgamma, float* dbeta,
+                           float* scratch, const float* zscale, const float* zshift, void* stream);
 // library-internal (csrc/norm.hip): dgnn_bn_stats_finalize_fold that also counts the batch in *nbt
 int dgnn_bn_stats_finalize_fold_nbt(const double* colstats, int64_t nblk, int64_t M, int c, float* mean, float* var, float* running_mean, float* running_var,
                                     float momentum, const float* gamma, const float* beta, float eps, float* scale, float* shift, int64_t* nbt, void* stream);
@@ -241,7 +245,8 @@ int layer_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
               int64_t ldx, int c_in, const float* edge_attr, int64_t lde, int f_e, const float* We, const float* be, const float* Wj, const float* Wi, int c_out,
               const float* gamma, const float* mean, const float* var, float eps, int relu, const float* a, const float* z, const float* y, const float* dy,
               float* dx, float* dWe, float* dbe, float* dWj, float* dbj, float* dWi, float* dgamma, float* dbeta, float* dz_buf, float* da, float* WjT, float* WiT,
-              float* tmp, float* tmp_w, int gemm_mode, hipStream_t stream, Aux* aux, hipEvent_t* done, bool pre_t = false, bool has_bn = true) {
+              float* tmp, float* tmp_w, int gemm_mode, hipStream_t stream, Aux* aux, hipEvent_t* done, bool pre_t = false, bool has_bn = true,
+              const float* bn_scale = nullptr) {
     void* stream_ = (void*)stream;
     const bool agg = t_rowptr != nullptr;
     const bool x3 = gemm_mode != DGNN_GEMM_F32;
@@ -259,7 +264,16 @@ int layer_bwd(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
     };
     // BatchNorm (batch statistics) + ReLU backward: dz, dgamma, dbeta
     // (has_bn == false: a plain Linear -- the decoder's output layer -- whose dz is dy itself)
-    if (has_bn) TRY(dgnn_bn_relu_bwd(z, c_out, y, c_out, dy, c_out, gamma, mean, var, eps, 1, relu, n_dst, c_out, dz_buf, c_out, dgamma, dbeta, tmp, stream_));
+    // (round 6: the whole-model call hands the forward's scale / shift on -- they sit behind mean / var in a layer's stats block -- and the ReLU mask is
+    // taken from z: y is not read by the two passes; DGNN_BN_ZMASK=0: the mask from y)
+    if (has_bn) {
+        static const bool zmask_on = !(getenv("DGNN_BN_ZMASK") && getenv("DGNN_BN_ZMASK")[0] == '0');
+        if (zmask_on && bn_scale && relu)
+            TRY(dgnn_bn_relu_bwd_zmask(z, c_out, y, c_out, dy, c_out, gamma, mean, var, eps, 1, relu, n_dst, c_out, dz_buf, c_out, dgamma, dbeta, tmp, bn_scale,
+                                       bn_scale + c_out, stream_));
+        else
+            TRY(dgnn_bn_relu_bwd(z, c_out, y, c_out, dy, c_out, gamma, mean, var, eps, 1, relu, n_dst, c_out, dz_buf, c_out, dgamma, dbeta, tmp, stream_));
+    }
     const float* const dz = has_bn ? dz_buf : dy;
     if (aux) {
         hipEvent_t e = next_event(aux);
@@ -755,7 +769,8 @@ extern "C" int dgnn_static_train_bwd(int n_layers, const int32_t* const* t_rowpt
         float* WjT = wt + (pre_t ? lay.wt_off[l] : 0);
         rc = layer_bwd(t_rowptr[l], t_dst[l], t_eid[l], rowptr_dst[l], n_src[l], n_dst[l], x, ldx, c_in, edge_attr[l], lde[l], We[l] ? f_e : 0, We[l], be[l], Wj[l],
                        Wi[l], c_out, gamma[l], st, st ? st + c_out : nullptr, eps[l], 1, a[l], z[l], y[l], g, dx, dWe[l], dbe[l], dWj[l], dbj[l], dWi[l], dgamma[l],
-                       dbeta[l], dzb[l & 1], da, WjT, WjT + (int64_t)c_in * c_out, tmp, tmp_w, gemm_mode, stream, aux, aux ? &done[l] : nullptr, pre_t, st != nullptr);
+                       dbeta[l], dzb[l & 1], da, WjT, WjT + (int64_t)c_in * c_out, tmp, tmp_w, gemm_mode, stream, aux, aux ? &done[l] : nullptr, pre_t, st != nullptr,
+                       st ? st + 2 * c_out : nullptr);
         g = dx;
     }
     if (aux)   // the gradients are consumed on `stream` (optimizer step): join.  In-order on the second stream: the last event covers all.
