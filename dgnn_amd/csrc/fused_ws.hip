@@ -104,6 +104,9 @@ __device__ __forceinline__ uint32_t ub16_enc(float v) {
 }
 __device__ __forceinline__ uint32_t bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 
+#ifndef DGNN_WS_LINE_OWN
+#define DGNN_WS_LINE_OWN 1      // 0: round 5's ownership (8 contiguous channels per lane) -- for A/B builds only
+#endif
 template <int CIN, int RING, bool FLAGS, bool DEC, bool IO16 = false>
 __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid,
                                                         int64_t n_dst, const float* __restrict__ x, const float* __restrict__ xdst, int64_t ldx,
@@ -192,10 +195,17 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
     __syncthreads();
     float sWe, inv_sWe;
     pow2_scales(scbuf[0], sWe, inv_sWe);
-    // entry (cb, part, g, j): channel c = NCH j + cb, k = 8 g .. 8 g + 7 (g < 3: attributes 0..19, the bias at k = 20, zeros)
+    // Which channels lane j of a cell's 16 lanes owns.  fp32 rows of 128 channels (two 16-byte loads per lane and row): channels 4 j .. 4 j + 3 and
+    // 64 + 4 j .. + 3, so that ONE load instruction covers whole 128-byte lines (16 lanes x 16 bytes = lines 0-1, then lines 2-3).  With 8 contiguous channels
+    // per lane (round 5) both instructions touched all four lines of a row, half of each: twice the tag look-ups in the vector L1, the second one a hit on
+    // a line still in flight.  Same bits (a channel's arithmetic does not depend on which lane owns it); measured on one box (profiles/r06_l1_probe.md):
+    // 128 -> 128 0.408 -> 0.406 ms, last layer + decoder 0.500 -> 0.490 ms.
+    constexpr bool LINE_OWN = !IO16 && NV == 2 && DGNN_WS_LINE_OWN;
+    auto chan = [](int j, int cb) { return LINE_OWN ? ((cb >> 2) * 64 + 4 * j + (cb & 3)) : NCH * j + cb; };
+    // entry (cb, part, g, j): channel c = chan(j, cb), k = 8 g .. 8 g + 7 (g < 3: attributes 0..19, the bias at k = 20, zeros)
     for (int e = threadIdx.x; e < NCH * 48; e += blockDim.x) {
         const int cb = e / 48, gj = e - cb * 48, g = gj >> 4, j = gj & 15;
-        const int c = NCH * j + cb;
+        const int c = chan(j, cb);
         uint32_t ph[4], pl[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -438,7 +448,8 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
     // ======================================================================= PRODUCER: group p of 4 cells of every tile
     __syncthreads();   // filter operand and constants in place
     const int p = w;
-    const int P0 = NCH * jcol;                     // the lane's NCH channels
+    const int P0 = NCH * jcol;                     // the lane's NCH channels (contiguous ownership)
+    const int Q0 = 4 * jcol;                       // LINE_OWN: its two quads start at Q0 and 64 + Q0
     auto load_rp = [&](int64_t it, int& vb) {
         if (it < my_n) {
             const int64_t i0 = tile_of(it) * WS_TILE + 4 * p;
@@ -488,9 +499,9 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                     xo16[0] = u.x, xo16[1] = u.y;
                 }
             } else {
-                const float* rp0 = xdst + cell * ldx + P0;
+                const float* rp0 = xdst + cell * ldx + (LINE_OWN ? Q0 : P0);
 #pragma unroll
-                for (int v = 0; v < NV; ++v) xo[v] = *reinterpret_cast<const f32x4_t*>(rp0 + 4 * v);
+                for (int v = 0; v < NV; ++v) xo[v] = *reinterpret_cast<const f32x4_t*>(rp0 + (LINE_OWN ? 64 : 4) * v);
             }
         };
         auto neighbour_rows = [&]() {
@@ -509,9 +520,9 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                         rr16[r][0] = u.x, rr16[r][1] = u.y;
                     }
                 } else {
-                    const float* rp = x + (int64_t)__shfl(vsrc, tl * 4 + r) * ldx + P0;
+                    const float* rp = x + (int64_t)__shfl(vsrc, tl * 4 + r) * ldx + (LINE_OWN ? Q0 : P0);
 #pragma unroll
-                    for (int v = 0; v < NV; ++v) rr[r][v] = *reinterpret_cast<const f32x4_t*>(rp + 4 * v);
+                    for (int v = 0; v < NV; ++v) rr[r][v] = *reinterpret_cast<const f32x4_t*>(rp + (LINE_OWN ? 64 : 4) * v);
                 }
             }
         };
@@ -613,7 +624,7 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                             const float* ar = ea + (int64_t)(eid ? eid[k] : k) * lde;
 #pragma unroll 1
                             for (int cb = 0; cb < NCH; ++cb) {
-                                const int c = P0 + cb;
+                                const int c = chan(jcol, cb);
                                 float pf = be[c];
                                 for (int f = 0; f < FE; ++f) pf = __fmaf_rn(We[(int64_t)c * FE + f], ar[f], pf);
                                 const float xs_ = IO16 ? __builtin_bit_cast(float, (uint32_t)x16[(int64_t)s_ * ldx + c] << 15) : x[(int64_t)s_ * ldx + c];
@@ -645,7 +656,18 @@ __global__ void __launch_bounds__(1024) k_sage_fused_ws(const int32_t* __restric
                 }
                 char* rowp = ring + sl * G::SLOT + T * G::ROWB;
                 const int key = T & 15;
-                if constexpr (NCH == 8) {
+                if constexpr (LINE_OWN) {
+                    // the lane's two quads of channels = half a piece each: quad q sits in piece 8 q + jcol / 2 of each quarter, half jcol & 1
+                    const int half = (jcol & 1) << 3;
+#pragma unroll
+                    for (int qd = 0; qd < 2; ++qd) {
+                        const int pc = 8 * qd + (jcol >> 1);
+                        *reinterpret_cast<uint2*>(rowp + ((pc ^ key) << 4) + half) = make_uint2(ah_[2 * qd], ah_[2 * qd + 1]);
+                        *reinterpret_cast<uint2*>(rowp + (((PP + pc) ^ key) << 4) + half) = make_uint2(xh_[2 * qd], xh_[2 * qd + 1]);
+                        *reinterpret_cast<uint2*>(rowp + (((2 * PP + pc) ^ key) << 4) + half) = make_uint2(al_[2 * qd], al_[2 * qd + 1]);
+                        *reinterpret_cast<uint2*>(rowp + (((3 * PP + pc) ^ key) << 4) + half) = make_uint2(xl_[2 * qd], xl_[2 * qd + 1]);
+                    }
+                } else if constexpr (NCH == 8) {
                     // the lane's 8 channels = one 16-byte piece of each quarter
                     *reinterpret_cast<uint4*>(rowp + ((jcol ^ key) << 4)) = make_uint4(ah_[0], ah_[1], ah_[2], ah_[3]);
                     *reinterpret_cast<uint4*>(rowp + (((PP + jcol) ^ key) << 4)) = make_uint4(xh_[0], xh_[1], xh_[2], xh_[3]);

@@ -1026,7 +1026,7 @@ extern "C" int dgnn_sage_aggregate_sr(const int32_t* rowptr, const int32_t* src,
     if (nwg_ < 8) nwg_ = 8;
     const dim3 grid((unsigned)nwg_), block(512);
     hipStream_t st = (hipStream_t)stream;
-    static const int ilv = getenv("DGNN_AGG_SR_ILV") ? atoi(getenv("DGNN_AGG_SR_ILV")) : 2;   // measured: 1 / 2 / 4 interleaved chains within 1 % (the launch is bound by its gathers); 2 keeps four wavefronts per SIMD
+    static const int ilv = getenv("DGNN_AGG_SR_ILV") ? atoi(getenv("DGNN_AGG_SR_ILV")) : 2;   // measured: 1 / 2 / 4 interleaved chains within 1 %.  (Round 6: with the ticket walk's registers the split-row form of ILV = 2 compiles to 137 VGPRs = ONE resident workgroup per CU, 2 wavefronts per SIMD; forced to 128 = two workgroups, 4 per SIMD, the launch is 3 % SLOWER -- profiles/r06_l1_probe.md)
     // the XCDs' group counters of the ticket walk (see the kernel): 8 ints per device, zeroed in stream order before every launch
     static const bool tickets_on = !(getenv("DGNN_AGG_SR_TICKETS") && getenv("DGNN_AGG_SR_TICKETS")[0] == '0');
     static const int tk_g = getenv("DGNN_AGG_SR_TK_G") && atoi(getenv("DGNN_AGG_SR_TK_G")) > 0 ? atoi(getenv("DGNN_AGG_SR_TK_G")) : 1;   // groups of 4 cells per ticket

@@ -5,6 +5,9 @@
 #   bash tools/gpu_round6.sh gemm   <tag>   the training step's GEMM shapes under the three kernel selections (tools/bench_gemm_train_shapes.py)
 #   bash tools/gpu_round6.sh wide   <tag>   the wide aggregate: static walk against the ticket walk(s): time, FETCH_SIZE, L2 hit rate -> profiles/r06_wide.md
 #   bash tools/gpu_round6.sh tests  <tag>   pytest -m gpu (whole suite)
+#   bash tools/gpu_round6.sh diag   <tag>   vector-memory path counters (L1 latency, L1->L2 latency, TLB, address / data stalls, wave states) of the
+#                                           wide aggregate and of the default line's launches, one counter family per pass (a TA_* pass was tried:
+#                                           rocprofv3 never returned from it, twice -- every pass stays under its own timeout)
 M=${1:-train}; T=${2:-r6}
 mkdir -p gpurun_out/$T
 cd /tmp && export TMPDIR=/tmp
@@ -57,6 +60,32 @@ for i in (3, 4):
     print("$CFG pmc%d" % i); print(t.round(0).to_string())
 PY
     rm -rf gpurun_out/$T/pmc3 gpurun_out/$T/pmc4
+  done;;
+diag)
+  for W in wide default; do
+    if [ $W = wide ]; then B="python3 bench.py --widths 64,128,256,512 --no-train --no-extras --no-cpu-baseline --no-breakdown --steps 3 --warmup 1"; PAT="k_agg_sr|k_gemm_sr";
+    else B="python3 bench.py --no-train --no-extras --no-cpu-baseline --no-breakdown --steps 3 --warmup 1"; PAT="k_sage_fused"; fi
+    i=0
+    for C in "TCP_TCP_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum" \
+             "TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum" \
+             "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_INST_LEVEL_VMEM SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+      i=$((i+1))
+      timeout 300 rocprofv3 --pmc $C --output-format csv -d gpurun_out/$T/d_${W}_$i -- $B > gpurun_out/$T/d_${W}_$i.log 2>&1; echo "$W pass $i rc=$?"
+      python3 - <<PY
+import glob, pandas as pd
+cs = glob.glob("gpurun_out/$T/d_${W}_$i/*/*counter_collection.csv")
+if not cs: print("$W pass $i: no csv")
+else:
+    d = pd.read_csv(cs[0])
+    d["K"] = d["Kernel_Name"].str.replace("(anonymous namespace)::", "").str.replace("void ", "").str.split("(").str[0].str[:44]
+    d["dur_us"] = (d["End_Timestamp"] - d["Start_Timestamp"]) / 1e3
+    k = d[d["K"].str.contains("$PAT")]
+    t = k.pivot_table(index="K", columns="Counter_Name", values="Counter_Value", aggfunc="mean")
+    t["dur_us"] = k.groupby("K")["dur_us"].mean(); t["n"] = k.groupby("K")["dur_us"].count() / max(1, k["Counter_Name"].nunique())
+    pd.set_option("display.width", 250); print(t.round(0).to_string())
+PY
+      rm -rf gpurun_out/$T/d_${W}_$i
+    done
   done;;
 tests)
   timeout 3000 python -m pytest tests -x -q -m gpu > gpurun_out/$T/tests.log 2>&1; echo "rc=$?" >> gpurun_out/$T/tests.log; tail -n 5 gpurun_out/$T/tests.log;;
