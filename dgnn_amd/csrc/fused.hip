@@ -79,9 +79,17 @@ struct FusedCfg {
     static constexpr int S_STEPS = CIN_PAD / 8;        // k-steps of 8 per K half
     static constexpr int RED_FLOATS = NWAVE * 8 * 64;  // one partial-sum exchange buffer
     static constexpr int SMEM_FLOATS = 2 * A_FLOATS + NWAVE * EA_PAD + 2 * RED_FLOATS;
+    static constexpr int FW_FLOATS = (CIN_PAD / 16) * 6 * 64;   // FM: the filter's matrix-core operand, [16-channel block][5 k-steps + bias][64 lanes]
 };
 
-template <int CIN_PAD, int COUT, int MODE>
+// FM (MODE 0 only; round 6): the filter product phi = We . A + be on the fp32 matrix cores too (v_mfma_f32_16x16x4_f32) instead of 20 FMAs per channel
+// and edge on the VALU.  fp32 MFMA and fp32 VALU time ADD on a SIMD (header), and the matrix pipe does 32 MACs per clock against the VALU's 16: the
+// wave's 16 edges (4 tets) x 16 channels x 4 attributes per instruction, C input = the bias, k ascending -- the same fmaf chain per (edge, channel) as the
+// VALU form (be, then attributes 0..19 in order).  The C/D layout puts the 4 in-edges of tet g = lane >> 4 into the 4 accumulator registers of the lanes
+// (., g): the in-order 4-term sum with the neighbour rows is in-lane, as in the fp16 kernels.  Lane (n = lane & 15, g) owns, of tet g's rows, the channels
+// chan(nb, n) = 64 (nb / VW) + VW n + nb % VW, nb < CIN_PAD / 16, VW = min(4, CIN_PAD / 16): contiguous pieces of 8 / 16 bytes per lane, so that the 16
+// lanes of a tet cover whole cache lines with one load instruction.
+template <int CIN_PAD, int COUT, int MODE, int FM = 0>
 __global__ void __launch_bounds__(512, 2)
 k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid, int64_t n_dst,
              const float* __restrict__ x, const float* __restrict__ xdst, int64_t ldx, int c_in, const float* __restrict__ ea, int64_t lde,
@@ -92,10 +100,16 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
     using C = FusedCfg<CIN_PAD, COUT, MODE>;
     constexpr int LDA = C::LDA, TILE = C::TILE, TPW = C::TPW, CPL = C::CPL, NQ = C::NQ, NEV = C::NEV, NV4 = C::NV4;
     constexpr int ROWB = C::ROWB;
+    static_assert(FM == 0 || (MODE == 0 && TPW % 4 == 0), "the matrix-core filter product: fp32 mode, whole blocks of 4 tets per wave");
+    constexpr int EB = FM ? TPW / 4 : 1;                  // blocks of 16 edges (4 tets) per wave and tile
+    constexpr int NBK = CIN_PAD / 16;                     // blocks of 16 channels
+    constexpr int VW = NBK < 4 ? NBK : 4;                 // contiguous channels per lane and segment
+    constexpr int NSEG = NBK / VW;                        // segments (64 channels apart)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const abuf = smem;                                  // [2][A_FLOATS]
     float* const eabuf = smem + 2 * C::A_FLOATS;               // [NWAVE][EA_PAD]
     float* const redbuf = eabuf + NWAVE * C::EA_PAD;           // [2][NWAVE][8][64]
+    float* const fwbuf = redbuf + 2 * C::RED_FLOATS;           // FM only: [NBK][6][64]
 
     const int lane = lane_id(), w = wave_id_uniform();
     const int h = lane >> 5, l31 = lane & 31;
@@ -157,21 +171,38 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
     const int c0 = lane * CPL;
     const bool on = c0 < c_in;    // c_in is a multiple of CPL (host-checked)
     const int c0l = on ? c0 : 0;  // clamped channel offset: loads stay in bounds for inactive lanes
-    float wl[CPL][FE], bl[CPL];
+    constexpr int NWL = FM ? 1 : CPL;
+    float wl[NWL][FE], bl[NWL];
+    if constexpr (!FM) {
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-        const float bv = be[c0l + j];
-        bl[j] = on ? bv : 0.f;
+        for (int j = 0; j < CPL; ++j) {
+            const float bv = be[c0l + j];
+            bl[j] = on ? bv : 0.f;
 #pragma unroll
-        for (int f = 0; f < FE; ++f) {
-            const float wv = We[(int64_t)(c0l + j) * FE + f];
-            wl[j][f] = on ? wv : 0.f;
+            for (int f = 0; f < FE; ++f) {
+                const float wv = We[(int64_t)(c0l + j) * FE + f];
+                wl[j][f] = on ? wv : 0.f;
+            }
         }
     }
     float* const myea = eabuf + w * C::EA_PAD;
+    // FM: lane (n, g): B operand We[chan(nb, n)][4 ks + g] of k-step ks, C input be[chan(nb, n)]
+    const int fn = lane & 15, fg = lane >> 4;
+    if constexpr (FM) {
+        // (in LDS, read where used: 40 + 8 registers per lane at 128 channels spilled beside the dense product's 64 resident weights)
+        for (int e = threadIdx.x; e < NBK * 6 * 64; e += blockDim.x) {
+            const int ln = e & 63, nk = e >> 6, nb = nk / 6, ks = nk - 6 * nb;
+            const int c = 64 * (nb / VW) + VW * (ln & 15) + nb % VW;
+            float v = 0.f;
+            if (c < c_in) v = ks < 5 ? We[(int64_t)c * FE + 4 * ks + (ln >> 4)] : be[c];
+            fwbuf[e] = v;
+        }
+        __syncthreads();
+    }
 
     // state of the tile in flight
-    float xd[TPW][CPL], xr[NQ][CPL];
+    float xd[FM ? 1 : TPW][CPL], xr[FM ? 1 : NQ][CPL];
+    float fxd[FM ? EB * NBK : 1], fxr[FM ? EB * 4 * NBK : 1];      // FM: [eb * NBK + nb], [(eb * 4 + r) * NBK + nb]: lane (n, g)'s channels of tet 4 eb + g
     bool regular = false;        // loads for the current tile are in flight (4-regular fast path)
     // Index prefetch runs two tiles deep so that no index round trip sits in front of the row loads.  The
     // indices live in VGPRs, one entry per lane (a single coalesced load each), and are turned into scalar row
@@ -205,11 +236,35 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
         if (regular) {
             const int i0 = (int)(tile_of(it) * TILE) + w * TPW;
             const float* eab = ea + (int64_t)__builtin_amdgcn_readfirstlane(vbeg1) * lde;
+            if constexpr (FM) {
+                // lane (n, g): VW contiguous channels per segment of tet 4 eb + g's own row and of its 4 neighbour rows (a segment past c_in: clamped, zeroed at use)
+                auto ld_seg = [&](float* dst, const float* rowp) {
 #pragma unroll
-            for (int r = 0; r < TPW; ++r) ld_row<CPL>(xd[r], xdst + (uint32_t)((i0 + r) * ldx32) + c0l);
+                    for (int sg = 0; sg < NSEG; ++sg) {
+                        const int cseg = 64 * sg + VW * fn;
+                        const float* pp = rowp + (cseg < c_in ? cseg : 0);
+                        if constexpr (VW == 4) {
+                            const f32x4 t = *reinterpret_cast<const f32x4*>(pp);
+                            dst[4 * sg] = t[0], dst[4 * sg + 1] = t[1], dst[4 * sg + 2] = t[2], dst[4 * sg + 3] = t[3];
+                        } else {
+                            const float2 t = *reinterpret_cast<const float2*>(pp);
+                            dst[2 * sg] = t.x, dst[2 * sg + 1] = t.y;
+                        }
+                    }
+                };
 #pragma unroll
-            for (int q = 0; q < NQ; ++q)
-                ld_row<CPL>(xr[q], x + (uint32_t)(__builtin_amdgcn_readlane(vsrc1, q) * ldx32) + c0l);
+                for (int eb = 0; eb < EB; ++eb) {
+                    ld_seg(fxd + eb * NBK, xdst + (uint32_t)((i0 + 4 * eb + fg) * ldx32));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ld_seg(fxr + (eb * 4 + r) * NBK, x + (uint32_t)(__shfl(vsrc1, 16 * eb + 4 * fg + r) * ldx32));
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < TPW; ++r) ld_row<CPL>(xd[r], xdst + (uint32_t)((i0 + r) * ldx32) + c0l);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    ld_row<CPL>(xr[q], x + (uint32_t)(__builtin_amdgcn_readlane(vsrc1, q) * ldx32) + c0l);
+            }
             // edge-attribute block of this wave's tets: async DMA straight into its private LDS strip (issued last:
             // hipcc answers any later wait on an ordinary load with vmcnt(0) while an LDS-DMA is in flight)
             // eid == nullptr: rows already in plan order (one contiguous block); otherwise row k comes from edge_attr[eid[k]]
@@ -296,7 +351,47 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             advance_idx(it + 1);  // index scalar loads fly under the VALU work below
             stamp(trace, trace_cap, it, w, 1);
-            if (was_regular) {
+            if constexpr (FM) {
+              if (was_regular) {
+#pragma unroll
+                for (int eb = 0; eb < EB; ++eb) {
+                    // A operand: lane (m = edge 16 eb + n of the wave, g) holds attribute 4 ks + g of its edge
+                    float fa[5];
+#pragma unroll
+                    for (int ks = 0; ks < 5; ++ks) fa[ks] = myea[(16 * eb + fn) * FE + 4 * ks + fg];
+                    float* dst = abuf + (int)(it & 1) * C::A_FLOATS + (w * TPW + 4 * eb + fg) * LDA;
+#pragma unroll
+                    for (int sg = 0; sg < NSEG; ++sg) {
+                        float av_[VW], xv_[VW];
+                        const bool con = 64 * sg + VW * fn < c_in;       // c_in is a multiple of VW's granule (host-checked): a lane's piece is all in or all out
+#pragma unroll
+                        for (int u = 0; u < VW; ++u) {
+                            const int nb = sg * VW + u;
+                            const float* fwp = fwbuf + nb * 6 * 64 + lane;
+                            const float fb_ = fwp[5 * 64];
+                            f32x4 d = {fb_, fb_, fb_, fb_};
+#pragma unroll
+                            for (int ks = 0; ks < 5; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks], fwp[ks * 64], d, 0, 0, 0);
+                            float a_ = 0.f;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) a_ = __fadd_rn(a_, __fmul_rn(con ? fxr[(eb * 4 + r) * NBK + nb] : 0.f, d[r]));
+                            av_[u] = a_ * 0.25f;
+                            xv_[u] = con ? fxd[eb * NBK + nb] : 0.f;
+                        }
+                        if (64 * sg + VW * fn < CIN_PAD) {
+                            if constexpr (VW == 4) {
+                                *reinterpret_cast<f32x4*>(dst + 64 * sg + 4 * fn) = f32x4{av_[0], av_[1], av_[2], av_[3]};
+                                *reinterpret_cast<f32x4*>(dst + CIN_PAD + 64 * sg + 4 * fn) = f32x4{xv_[0], xv_[1], xv_[2], xv_[3]};
+                            } else {
+                                *reinterpret_cast<float2*>(dst + 2 * fn) = make_float2(av_[0], av_[VW - 1]);
+                                *reinterpret_cast<float2*>(dst + CIN_PAD + 2 * fn) = make_float2(xv_[0], xv_[VW - 1]);
+                            }
+                        }
+                    }
+                }
+              }
+            }
+            if (!FM && was_regular) {
 #pragma unroll
                 for (int r = 0; r < TPW; ++r) {
                     float acc[CPL];
@@ -358,8 +453,10 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
                     }
                     put_row((int)(it & 1), w * TPW + r, acc, xv);
                 }
-            } else {
-                // generic path: any in-degree, tile tail; one edge at a time (rare)
+            }
+            if (!was_regular) {
+                // generic path: any in-degree, tile tail; one edge at a time (rare).  FM: the filter's weights come from memory here (they are not in this
+                // wave's registers in channel-per-lane order) -- the same chain, be then attributes 0..19
                 for (int r = 0; r < TPW; ++r) {
                     const int64_t i = i0 + r;
                     float acc[CPL], xdv[CPL];
@@ -375,9 +472,15 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
                             ld_row<CPL>(xv, x + (int64_t)s * ldx + c0l);
 #pragma unroll
                             for (int j = 0; j < CPL; ++j) {
-                                float p = bl[j];
+                                float p;
+                                if constexpr (FM) {
+                                    p = on ? be[c0l + j] : 0.f;
+                                    for (int f = 0; f < FE; ++f) p = __fmaf_rn(on ? We[(int64_t)(c0l + j) * FE + f] : 0.f, ar[f], p);
+                                } else {
+                                    p = bl[j];
 #pragma unroll
-                                for (int f = 0; f < FE; ++f) p = __fmaf_rn(wl[j][f], ar[f], p);
+                                    for (int f = 0; f < FE; ++f) p = __fmaf_rn(wl[j][f], ar[f], p);
+                                }
                                 acc[j] = __fadd_rn(acc[j], __fmul_rn(on ? xv[j] : 0.f, p));
                             }
                         }
@@ -469,7 +572,7 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
     }
 }
 
-template <int CIN_PAD, int COUT, int MODE>
+template <int CIN_PAD, int COUT, int MODE, int FM = 0>
 int launch_fused(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t n_dst, const float* x, const float* xdst,
                  int64_t ldx, int c_in,
                  const float* ea, int64_t lde, const float* We, const float* be, const float* Wj, const float* bj,
@@ -477,12 +580,12 @@ int launch_fused(const int32_t* rowptr, const int32_t* src, const int32_t* eid, 
                  hipStream_t stream) {
     using C = FusedCfg<CIN_PAD, COUT, MODE>;
     const int64_t ntiles = dgnn_cdiv(n_dst, C::TILE);
-    const size_t smem = sizeof(float) * C::SMEM_FLOATS;
+    const size_t smem = sizeof(float) * (C::SMEM_FLOATS + (FM ? C::FW_FLOATS : 0));
     static bool attr_set[DGNN_MAX_DEVICES] = {};
-    dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused<CIN_PAD, COUT, MODE>), smem, attr_set);
+    dgnn_allow_dynamic_lds(reinterpret_cast<const void*>(&k_sage_fused<CIN_PAD, COUT, MODE, FM>), smem, attr_set);
     int grid = (int)(ntiles < DGNN_NUM_CU ? ntiles : DGNN_NUM_CU);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((k_sage_fused<CIN_PAD, COUT, MODE>), dim3(grid), dim3(512), smem, stream, rowptr, src, eid, n_dst, x, xdst, ldx, c_in,
+    hipLaunchKernelGGL((k_sage_fused<CIN_PAD, COUT, MODE, FM>), dim3(grid), dim3(512), smem, stream, rowptr, src, eid, n_dst, x, xdst, ldx, c_in,
                        ea, lde, We, be, Wj, bj, Wi, scale, shift, relu, out, ldo, ntiles, g_dgnn_trace_buf, g_dgnn_trace_cap);
     return dgnn_check_launch("sage_layer_fused_fwd");
 }
@@ -522,8 +625,17 @@ extern "C" int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* s
         if (rc != DGNN_E_UNSUPPORTED) return rc;
         gemm_mode = DGNN_GEMM_BF16X3;  // shape not covered by the all-MFMA variant
     }
+    // the filter product on the fp32 matrix cores (FM, see the kernel): rows in pieces of VW = min(4, CP / 16) channels per lane.  DGNN_FILTER_MFMA=0: the VALU form
+    static const bool fm_on = !(getenv("DGNN_FILTER_MFMA") && getenv("DGNN_FILTER_MFMA")[0] == '0');
+    auto fm_ok = [&](int cp) {
+        const int vw = cp / 16 < 4 ? cp / 16 : 4;
+        return fm_on && gemm_mode == DGNN_GEMM_F32 && c_in % vw == 0 && ldx % vw == 0 && (((uintptr_t)x_src | (uintptr_t)x_dst) % (4 * vw)) == 0;
+    };
 #define GO(CP, CO)                                                                                                              \
     do {                                                                                                                        \
+        if (fm_ok(CP))                                                                                                          \
+            return launch_fused<CP, CO, 0, 1>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, \
+                                              shift, relu, out, ldo, stream);                                                   \
         if (gemm_mode == DGNN_GEMM_F32)                                                                                         \
             return launch_fused<CP, CO, 0>(rowptr, src, eid, n_dst, x_src, x_dst, ldx, c_in, edge_attr, lde, We, be, Wj, bj, Wi, scale, \
                                            shift, relu, out, ldo, stream);                                                      \

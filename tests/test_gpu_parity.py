@@ -738,6 +738,25 @@ def test_fused_layer_gemm_modes_vs_fp64(c_in, c_out):
     assert errs[ops.GEMM_F16X2] < 4 * errs[ops.GEMM_F32] + 2e-7, errs
 
 
+@pytest.mark.parametrize("c_in,c_out", [(28, 64), (64, 128), (128, 128), (64, 64), (32, 128)])
+def test_f32_filter_product_on_the_matrix_cores_is_the_fmaf_chain(c_in, c_out):
+    """gemm_mode f32 (round 6): the 4-regular fast path computes phi = We . A + be on v_mfma_f32_16x16x4_f32 (C input = the bias, attributes ascending);
+    the per-edge path of the same kernel (a wave whose group of tets crosses n_dst) runs the fmaf chain on the VALU from the same start in the same
+    order.  Cutting n_dst short by 1..7 rows moves the rows in front of the cut from the first path to the second: not a bit may change, in them or
+    anywhere else.  (DGNN_FILTER_MFMA=0 runs both on the VALU.)"""
+    from dgnn_amd import ops
+    n, ei, plan, t = _fused_case(900, c_in, c_out, seed=c_in + c_out)
+    d = {k: v.to(DEV) for k, v in t.items()}
+    def run(n_dst):
+        return ops.sage_layer_fused_fwd(plan.rowptr, plan.src, n_dst, d["x"], d["ea"], d["We"], d["be"], d["Wj"], d["bj"], d["Wi"], None, None, False,
+                                        gemm_mode=ops.GEMM_F32, eid=plan.eid)
+    whole = run(n)
+    assert rel_err(whole, _fused_ref(n, ei, t)) < 3e-6
+    for cut in range(1, 8):
+        part = run(n - cut)
+        assert part.shape[0] == n - cut and torch.equal(part, whole[:n - cut]), cut
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_fused_layers_row_level_on_larger_graph(mode):
     """Row-level check of every fused layer on a 134k-tet graph (thousands of tiles per launch, several launches) in every
