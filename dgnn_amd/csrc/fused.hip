@@ -41,6 +41,8 @@
 //
 // LDS A-tile row stride is K+4 floats: the 16-lane groups of ds_read_b128 then hit 16 distinct 16-byte
 // slots (conflict free) and rows stay 16-byte aligned.
+#include <type_traits>
+
 #include "fused_common.h"
 
 int64_t* g_dgnn_trace_buf = nullptr;
@@ -186,6 +188,7 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
         }
     }
     float* const myea = eabuf + w * C::EA_PAD;
+    const bool vec2 = c_in % 2 == 0 && ldx % 2 == 0 && (((uintptr_t)x | (uintptr_t)xdst) & 7) == 0;      // FM, VW == 2: a lane's pair of channels as one 8-byte load
     // FM: lane (n, g): B operand We[chan(nb, n)][4 ks + g] of k-step ks, C input be[chan(nb, n)]
     const int fn = lane & 15, fg = lane >> 4;
     if constexpr (FM) {
@@ -246,9 +249,12 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
                         if constexpr (VW == 4) {
                             const f32x4 t = *reinterpret_cast<const f32x4*>(pp);
                             dst[4 * sg] = t[0], dst[4 * sg + 1] = t[1], dst[4 * sg + 2] = t[2], dst[4 * sg + 3] = t[3];
-                        } else {
+                        } else if (vec2) {
                             const float2 t = *reinterpret_cast<const float2*>(pp);
                             dst[2 * sg] = t.x, dst[2 * sg + 1] = t.y;
+                        } else {      // rows that are not 8-byte aligned (the scene's feature rows behind a column slice) or an odd c_in: two dwords
+                            dst[2 * sg] = pp[0];
+                            dst[2 * sg + 1] = rowp[cseg + 1 < c_in ? cseg + 1 : 0];
                         }
                     }
                 };
@@ -352,7 +358,9 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
             advance_idx(it + 1);  // index scalar loads fly under the VALU work below
             stamp(trace, trace_cap, it, w, 1);
             if constexpr (FM) {
-              if (was_regular) {
+              // FULL: c_in == CIN_PAD (wave-uniform): no channel of a lane's piece is padding, no masks
+              auto fm_tile = [&](auto full_c) {
+                constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
                 for (int eb = 0; eb < EB; ++eb) {
                     // A operand: lane (m = edge 16 eb + n of the wave, g) holds attribute 4 ks + g of its edge
@@ -362,33 +370,45 @@ k_sage_fused(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
                     float* dst = abuf + (int)(it & 1) * C::A_FLOATS + (w * TPW + 4 * eb + fg) * LDA;
 #pragma unroll
                     for (int sg = 0; sg < NSEG; ++sg) {
+                        // the VW channel blocks of a segment advance together: independent chains of 5 dependent matrix instructions each
+                        f32x4 d[VW];
+                        float fwv[VW][5];
+#pragma unroll
+                        for (int u = 0; u < VW; ++u) {
+                            const float* fwp = fwbuf + (sg * VW + u) * 6 * 64 + lane;
+                            const float fb_ = fwp[5 * 64];
+                            d[u] = f32x4{fb_, fb_, fb_, fb_};
+#pragma unroll
+                            for (int ks = 0; ks < 5; ++ks) fwv[u][ks] = fwp[ks * 64];
+                        }
+#pragma unroll
+                        for (int ks = 0; ks < 5; ++ks)
+#pragma unroll
+                            for (int u = 0; u < VW; ++u) d[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks], fwv[u][ks], d[u], 0, 0, 0);
                         float av_[VW], xv_[VW];
-                        const bool con = 64 * sg + VW * fn < c_in;       // c_in is a multiple of VW's granule (host-checked): a lane's piece is all in or all out
 #pragma unroll
                         for (int u = 0; u < VW; ++u) {
                             const int nb = sg * VW + u;
-                            const float* fwp = fwbuf + nb * 6 * 64 + lane;
-                            const float fb_ = fwp[5 * 64];
-                            f32x4 d = {fb_, fb_, fb_, fb_};
-#pragma unroll
-                            for (int ks = 0; ks < 5; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks], fwp[ks * 64], d, 0, 0, 0);
+                            const bool con = FULL || 64 * sg + VW * fn + u < c_in;
                             float a_ = 0.f;
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) a_ = __fadd_rn(a_, __fmul_rn(con ? fxr[(eb * 4 + r) * NBK + nb] : 0.f, d[r]));
+                            for (int r = 0; r < 4; ++r) a_ = __fadd_rn(a_, __fmul_rn(con ? fxr[(eb * 4 + r) * NBK + nb] : 0.f, d[u][r]));
                             av_[u] = a_ * 0.25f;
                             xv_[u] = con ? fxd[eb * NBK + nb] : 0.f;
                         }
-                        if (64 * sg + VW * fn < CIN_PAD) {
-                            if constexpr (VW == 4) {
-                                *reinterpret_cast<f32x4*>(dst + 64 * sg + 4 * fn) = f32x4{av_[0], av_[1], av_[2], av_[3]};
-                                *reinterpret_cast<f32x4*>(dst + CIN_PAD + 64 * sg + 4 * fn) = f32x4{xv_[0], xv_[1], xv_[2], xv_[3]};
-                            } else {
-                                *reinterpret_cast<float2*>(dst + 2 * fn) = make_float2(av_[0], av_[VW - 1]);
-                                *reinterpret_cast<float2*>(dst + CIN_PAD + 2 * fn) = make_float2(xv_[0], xv_[VW - 1]);
-                            }
+                        if constexpr (VW == 4) {
+                            *reinterpret_cast<f32x4*>(dst + 64 * sg + 4 * fn) = f32x4{av_[0], av_[1], av_[2], av_[3]};
+                            *reinterpret_cast<f32x4*>(dst + CIN_PAD + 64 * sg + 4 * fn) = f32x4{xv_[0], xv_[1], xv_[2], xv_[3]};
+                        } else {
+                            *reinterpret_cast<float2*>(dst + 2 * fn) = make_float2(av_[0], av_[VW - 1]);
+                            *reinterpret_cast<float2*>(dst + CIN_PAD + 2 * fn) = make_float2(xv_[0], xv_[VW - 1]);
                         }
                     }
                 }
+              };
+              if (was_regular) {
+                  if (c_in == CIN_PAD) fm_tile(std::true_type{});
+                  else fm_tile(std::false_type{});
               }
             }
             if (!FM && was_regular) {
@@ -628,8 +648,8 @@ extern "C" int dgnn_sage_layer_fused_fwd(const int32_t* rowptr, const int32_t* s
     // the filter product on the fp32 matrix cores (FM, see the kernel): rows in pieces of VW = min(4, CP / 16) channels per lane.  DGNN_FILTER_MFMA=0: the VALU form
     static const bool fm_on = !(getenv("DGNN_FILTER_MFMA") && getenv("DGNN_FILTER_MFMA")[0] == '0');
     auto fm_ok = [&](int cp) {
-        const int vw = cp / 16 < 4 ? cp / 16 : 4;
-        return fm_on && gemm_mode == DGNN_GEMM_F32 && c_in % vw == 0 && ldx % vw == 0 && (((uintptr_t)x_src | (uintptr_t)x_dst) % (4 * vw)) == 0;
+        const int vw = cp / 16 < 4 ? cp / 16 : 4;      // (pairs: the kernel falls back to dword loads by itself; quads: only aligned rows)
+        return fm_on && gemm_mode == DGNN_GEMM_F32 && (vw < 4 || (c_in % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)x_src | (uintptr_t)x_dst) % 16) == 0));
     };
 #define GO(CP, CO)                                                                                                              \
     do {                                                                                                                        \

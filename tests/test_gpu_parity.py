@@ -738,8 +738,9 @@ def test_fused_layer_gemm_modes_vs_fp64(c_in, c_out):
     assert errs[ops.GEMM_F16X2] < 4 * errs[ops.GEMM_F32] + 2e-7, errs
 
 
-@pytest.mark.parametrize("c_in,c_out", [(28, 64), (64, 128), (128, 128), (64, 64), (32, 128)])
-def test_f32_filter_product_on_the_matrix_cores_is_the_fmaf_chain(c_in, c_out):
+@pytest.mark.parametrize("c_in,c_out,sliced", [(28, 64, False), (28, 64, True), (29, 64, False), (64, 128, False), (128, 128, False), (64, 64, False), (32, 128, True),
+                                               (64, 128, True)])
+def test_f32_filter_product_on_the_matrix_cores_is_the_fmaf_chain(c_in, c_out, sliced):
     """gemm_mode f32 (round 6): the 4-regular fast path computes phi = We . A + be on v_mfma_f32_16x16x4_f32 (C input = the bias, attributes ascending);
     the per-edge path of the same kernel (a wave whose group of tets crosses n_dst) runs the fmaf chain on the VALU from the same start in the same
     order.  Cutting n_dst short by 1..7 rows moves the rows in front of the cut from the first path to the second: not a bit may change, in them or
@@ -747,6 +748,8 @@ def test_f32_filter_product_on_the_matrix_cores_is_the_fmaf_chain(c_in, c_out):
     from dgnn_amd import ops
     n, ei, plan, t = _fused_case(900, c_in, c_out, seed=c_in + c_out)
     d = {k: v.to(DEV) for k, v in t.items()}
+    if sliced:      # rows behind a column slice, as the scene's feature rows are (x[:, 1:]): neither 8- nor 16-byte aligned (dword loads / the VALU form)
+        d["x"] = torch.cat([torch.zeros(n, 1), t["x"]], 1).to(DEV)[:, 1:]
     def run(n_dst):
         return ops.sage_layer_fused_fwd(plan.rowptr, plan.src, n_dst, d["x"], d["ea"], d["We"], d["be"], d["Wj"], d["bj"], d["Wi"], None, None, False,
                                         gemm_mode=ops.GEMM_F32, eid=plan.eid)
