@@ -797,6 +797,394 @@ __global__ void __launch_bounds__(256) k_agg_fwd_g20(const int32_t* __restrict__
     }
 }
 
+// =====================================================================================================================
+// Fused-filter aggregate, fp32 rows, 20 attributes, the filter product on the fp32 matrix cores (round 6).  phi = We . A + be as
+// v_mfma_f32_16x16x4_f32 with the bias as the C input and the attributes ascending is, per (edge, channel), the fmaf chain of k_agg_fwd -- the same bits
+// (tests/test_gpu_parity.py: ..._is_the_fmaf_chain, measured on the exact-fp32 fused layers first) -- at 32 multiply-adds per clock and SIMD against the
+// VALU's 16, with no 20 x 64 weights in registers.  A wavefront step takes 4 EB destination rows; every row gets 4 edge slots (a tetrahedron has 4
+// neighbours; a step with a row of more than 4 in-edges takes the per-edge path); lane (n = lane & 15, g = lane >> 4) owns, of row 4 eb + g and of that
+// row's 4 neighbour rows, the channels chan(nb, n) = 64 (nb / VW) + VW n + nb % VW (whole cache lines per load instruction), and the C/D layout hands it
+// phi of exactly those 4 edges x those channels: the in-order sum over the edges is in-lane.
+// =====================================================================================================================
+typedef float f32x4m_t __attribute__((ext_vector_type(4)));
+template <int NBK>   // blocks of 16 channels: c_in <= 16 NBK
+__global__ void __launch_bounds__(256) k_agg_fwd_m(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid,
+                                                   int64_t n_dst, const float* __restrict__ x, int64_t ldx, int c_in, const float* __restrict__ ea, int64_t lde,
+                                                   const float* __restrict__ We, const float* __restrict__ be, float* __restrict__ a, int64_t lda) {
+    constexpr int VW = NBK < 4 ? NBK : 4, NSEG = NBK / VW, EB = 8 / NBK, RS = 4 * EB, FE = 20;
+    __shared__ float fwbuf[NBK * 6 * 64];      // [16-channel block][5 k-steps + bias][lane]: B operand We[chan][4 ks + g], C input be[chan]
+    const int lane = lane_id(), fn = lane & 15, fg = lane >> 4;
+    for (int e = threadIdx.x; e < NBK * 6 * 64; e += 256) {
+        const int ln = e & 63, nk = e >> 6, nb = nk / 6, ks = nk - 6 * nb;
+        const int c = 64 * (nb / VW) + VW * (ln & 15) + nb % VW;
+        float v = 0.f;
+        if (c < c_in) v = ks < 5 ? We[(int64_t)c * FE + 4 * ks + (ln >> 4)] : be[c];
+        fwbuf[e] = v;
+    }
+    __syncthreads();
+    const int64_t ngrp = (n_dst + RS - 1) / RS, stride = (int64_t)gridDim.x * 4;
+    // index pipeline: a step's row pointers are requested two steps ahead, its slots' sources / edge ids one step ahead -- they arrive in the shadow of
+    // the step before's row gathers, so a step exposes ONE memory round trip (its gathers), not three
+    auto load_rp = [&](int64_t g_, int& rp_, int& nr_) {
+        rp_ = 0, nr_ = 0;
+        if (g_ < ngrp) {
+            const int64_t rb_ = g_ * RS;
+            nr_ = (int)(n_dst - rb_ < RS ? n_dst - rb_ : RS);
+            rp_ = rowptr[rb_ + (lane < nr_ ? lane : nr_)];
+        }
+    };
+    // lane l <-> slot l of the step: block l >> 4, row 4 (l >> 4) + ((l & 15) >> 2), edge l & 3 of that row
+    auto load_slots = [&](int rp_, int nr_, int& sv_, int& ev_, bool& slow_) {
+        sv_ = 0, ev_ = -1, slow_ = false;
+        if (nr_ > 0) {
+            const int rpn = __shfl(rp_, lane + 1 < 64 ? lane + 1 : 63);
+            slow_ = __any(lane < nr_ && rpn - rp_ > 4) != 0;
+            const int row = 4 * (lane >> 4) + ((lane & 15) >> 2), k_ = lane & 3;
+            const int rc = row < nr_ ? row : nr_;
+            const int b_ = __shfl(rp_, rc), d_ = row < nr_ ? __shfl(rp_, rc + 1) - b_ : 0;
+            if (!slow_ && row < RS && k_ < d_) {
+                sv_ = src[b_ + k_];
+                ev_ = eid ? eid[b_ + k_] : b_ + k_;
+            }
+        }
+    };
+    const int64_t g_first = (int64_t)blockIdx.x * 4 + wave_id_uniform();
+    int rp, nr, rp1, nr1, sv, ev;
+    bool slow;
+    load_rp(g_first, rp, nr);
+    load_rp(g_first + stride, rp1, nr1);
+    load_slots(rp, nr, sv, ev, slow);
+    for (int64_t grp = g_first; grp < ngrp; grp += stride) {
+        const int64_t rb = grp * RS;
+        int sv1, ev1, rp2, nr2;
+        bool slow1;
+        load_slots(rp1, nr1, sv1, ev1, slow1);
+        load_rp(grp + 2 * stride, rp2, nr2);
+        if (slow) {
+            // ---- per-edge path (never on a Delaunay scene): lane group g takes rows g, g + 4, ...; k_agg_fwd's arithmetic per (row, channel)
+            for (int r0 = 0; r0 < nr; r0 += 4) {      // (the shuffles with all lanes in; the groups' edge loops below may differ in length)
+                const int r = r0 + fg;
+                const bool rv = r < nr;
+                const int b_ = __shfl(rp, rv ? r : 0), e_ = rv ? __shfl(rp, rv ? r + 1 : 0) : b_;
+                for (int nb = 0; nb < NBK; ++nb) {
+                    const int c = 64 * (nb / VW) + VW * fn + nb % VW;
+                    if (c >= c_in || !rv) continue;
+                    float acc = 0.f;
+                    for (int k = b_; k < e_; ++k) {
+                        const float* ar = ea + (int64_t)(eid ? eid[k] : k) * lde;
+                        float p_ = be[c];
+                        for (int f = 0; f < FE; ++f) p_ = __fmaf_rn(We[(int64_t)c * FE + f], ar[f], p_);
+                        acc = __fadd_rn(acc, __fmul_rn(x[(int64_t)src[k] * ldx + c], p_));
+                    }
+                    a[(rb + r) * lda + c] = __fdiv_rn(acc, (float)max(e_ - b_, 1));
+                }
+            }
+        } else {
+#pragma unroll
+        for (int eb = 0; eb < EB; ++eb) {
+            if (4 * eb >= nr) break;
+            // A operand: lane (m = slot 16 eb + n, k = g) holds attribute 4 ks + g of its slot's edge (an empty slot: zeros).  (Parking the step's 64 attribute
+            // rows in LDS -- five 16-byte loads per slot instead of 4-byte loads per operand element -- measured no faster here and 30 % slower in the backward.)
+            const int ae = __shfl(ev, 16 * eb + fn);
+            float fa[5];
+#pragma unroll
+            for (int ks = 0; ks < 5; ++ks) fa[ks] = ae >= 0 ? ea[(int64_t)ae * lde + 4 * ks + fg] : 0.f;
+            // the 4 neighbour rows of row 4 eb + g: VW contiguous channels per segment
+            const int row = 4 * eb + fg;
+            int sj[4];
+            bool ok[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sj[r] = __shfl(sv, 16 * eb + 4 * fg + r);
+                ok[r] = __shfl(ev, 16 * eb + 4 * fg + r) >= 0;
+            }
+            float xr[4][NBK];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int sg = 0; sg < NSEG; ++sg) {
+                    const int cseg = 64 * sg + VW * fn;
+                    const float* pp = x + (int64_t)sj[r] * ldx + (cseg < c_in ? cseg : 0);
+                    if constexpr (VW == 4) {
+                        const f32x4m_t t = *reinterpret_cast<const f32x4m_t*>(pp);
+                        xr[r][4 * sg] = t[0], xr[r][4 * sg + 1] = t[1], xr[r][4 * sg + 2] = t[2], xr[r][4 * sg + 3] = t[3];
+                    } else {
+                        const float2 t = *reinterpret_cast<const float2*>(pp);
+                        xr[r][2 * sg] = t.x, xr[r][2 * sg + 1] = t.y;
+                    }
+                }
+            int deg = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) deg += ok[r] ? 1 : 0;
+            const float cnt = (float)max(deg, 1);
+#pragma unroll
+            for (int sg = 0; sg < NSEG; ++sg) {
+                f32x4m_t d[VW];
+                float fwv[VW][5];
+#pragma unroll
+                for (int u = 0; u < VW; ++u) {
+                    const float* fwp = fwbuf + (sg * VW + u) * 6 * 64 + lane;
+                    const float fb_ = fwp[5 * 64];
+                    d[u] = f32x4m_t{fb_, fb_, fb_, fb_};
+#pragma unroll
+                    for (int ks = 0; ks < 5; ++ks) fwv[u][ks] = fwp[ks * 64];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 5; ++ks)
+#pragma unroll
+                    for (int u = 0; u < VW; ++u) d[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks], fwv[u][ks], d[u], 0, 0, 0);
+                float o[VW];
+#pragma unroll
+                for (int u = 0; u < VW; ++u) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (ok[r]) acc = __fadd_rn(acc, __fmul_rn(xr[r][sg * VW + u], d[u][r]));
+                    o[u] = __fdiv_rn(acc, cnt);
+                }
+                const int cseg = 64 * sg + VW * fn;
+                if (row < nr && cseg < c_in) {
+                    float* op = a + (rb + row) * lda + cseg;
+                    if constexpr (VW == 4) *reinterpret_cast<f32x4m_t*>(op) = f32x4m_t{o[0], o[1], o[2], o[3]};
+                    else *reinterpret_cast<float2*>(op) = make_float2(o[0], o[1]);
+                }
+            }
+        }
+        }
+        rp = rp1, nr = nr1, sv = sv1, ev = ev1, slow = slow1, rp1 = rp2, nr1 = nr2;
+    }
+}
+
+// The backward of the same form (fp32 rows of up to 64 channels; wider rows keep k_agg_bwd_c, whose packed fused multiply-adds run at the matrix cores'
+// fp32 rate).  A step = 4 EB SOURCE rows x 4 out-edge slots.  Per 16 slots and 16 channels:
+//   phi (DX only) as in the forward: 5 matrix instructions, the bits of the VALU chain; lane (n, g) receives phi of row 4 eb + g's 4 out-edges x its channels
+//   dm = da[dst(slot)] / in-degree(dst) (a multiplication by the exact reciprocal when every in-degree of the step is a power of two, else the division),
+//   dx = sum over the row's slots of dm * phi in slot order (+ the addend row), dphi = dm * x[row] -- in-lane
+//   dWe^T [16 channels x 32] += dphi^T . [A | 1 | 0]: k-step r takes slot r of the four rows (k = g): the A operand IS the lane's dphi register r, the B
+//        operand attribute n (and 16 + n, 1.0 at column 20) of slot 4 g + r's edge -- 8 matrix instructions, nothing moves between lanes
+// The accumulators live for the whole launch; slab per workgroup in k_agg_bwd_c's layout (CPL = 1).  dWe / dbe are sums in ANOTHER order than
+// k_agg_bwd_c's (slot-major within a step, steps in the wavefront's walk): fp32-class, deterministic, not the old kernel's bits; dx is (same chains).
+template <int NBK, bool DX, bool ADD>
+__global__ void __launch_bounds__(256) k_agg_bwd_mm(const int32_t* __restrict__ t_rowptr, const int32_t* __restrict__ t_dst, const int32_t* __restrict__ t_eid,
+                                                    int64_t n_src, const int32_t* __restrict__ rowptr_dst, const float* __restrict__ x, int64_t ldx, int c_in,
+                                                    const float* __restrict__ ea, int64_t lde, const float* __restrict__ We, const float* __restrict__ be,
+                                                    const float* __restrict__ da, int64_t ldda, float* __restrict__ dx, int64_t lddx, float* __restrict__ slabs,
+                                                    const float* __restrict__ add, int64_t ldadd, int64_t n_add) {
+    static_assert(NBK == 2 || NBK == 4, "rows of up to 64 channels");
+    constexpr int VW = NBK, EB = 8 / NBK, RS = 4 * EB, FE = 20;      // one segment: lane n owns channels VW n .. VW n + VW - 1 (block nb <-> channel VW n + nb)
+    __shared__ float fwbuf[NBK * 6 * 64];       // the filter operand (DX)
+    __shared__ float smem_[4 * 64 * 21];        // the wavefronts' slabs: the per-edge path adds into its wavefront's directly, the accumulators are added at the end
+    const int lane = lane_id(), fn = lane & 15, fg = lane >> 4, wv = wave_id_uniform();
+    float* const mine = smem_ + wv * (64 * 21);
+    for (int i = lane; i < 64 * 21; i += 64) mine[i] = 0.f;
+    if (DX) {
+        for (int e = threadIdx.x; e < NBK * 6 * 64; e += 256) {
+            const int ln = e & 63, nk = e >> 6, nb = nk / 6, ks = nk - 6 * nb;
+            const int c = VW * (ln & 15) + nb;
+            float v = 0.f;
+            if (c < c_in) v = ks < 5 ? We[(int64_t)c * FE + 4 * ks + (ln >> 4)] : be[c];
+            fwbuf[e] = v;
+        }
+        __syncthreads();
+    }
+    f32x4m_t accW[NBK][2];
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) accW[nb][0] = accW[nb][1] = f32x4m_t{0.f, 0.f, 0.f, 0.f};
+    const int64_t ngrp = (n_src + RS - 1) / RS, stride = (int64_t)gridDim.x * 4;
+    const bool con = VW * fn < c_in;      // c_in is a multiple of VW (host-checked): a lane's channels are all in or all out
+    // index pipeline as in k_agg_fwd_m: row pointers two steps ahead, the slots' destinations / edge ids one step ahead; the destinations' in-degrees are
+    // requested with the step's gathers (they are needed behind them)
+    auto load_rp = [&](int64_t g_, int& rp_, int& nr_) {
+        rp_ = 0, nr_ = 0;
+        if (g_ < ngrp) {
+            const int64_t rb_ = g_ * RS;
+            nr_ = (int)(n_src - rb_ < RS ? n_src - rb_ : RS);
+            rp_ = t_rowptr[rb_ + (lane < nr_ ? lane : nr_)];
+        }
+    };
+    // lane l <-> slot l of the step: block l >> 4, row 4 (l >> 4) + ((l & 15) >> 2), out-edge l & 3 of that row
+    auto load_slots = [&](int rp_, int nr_, int& dv_, int& ev_, bool& slow_) {
+        dv_ = 0, ev_ = -1, slow_ = false;
+        if (nr_ > 0) {
+            const int rpn = __shfl(rp_, lane + 1 < 64 ? lane + 1 : 63);
+            slow_ = __any(lane < nr_ && rpn - rp_ > 4) != 0;
+            const int row = 4 * (lane >> 4) + ((lane & 15) >> 2), k_ = lane & 3;
+            const int rc = row < nr_ ? row : nr_;
+            const int b_ = __shfl(rp_, rc), d_ = row < nr_ ? __shfl(rp_, rc + 1) - b_ : 0;
+            if (!slow_ && row < RS && k_ < d_) {
+                dv_ = t_dst[b_ + k_];
+                ev_ = t_eid[b_ + k_];
+            }
+        }
+    };
+    const int64_t g_first = (int64_t)blockIdx.x * 4 + wv;
+    int rp, nr, rp1, nr1, dv, ev;
+    bool slow;
+    load_rp(g_first, rp, nr);
+    load_rp(g_first + stride, rp1, nr1);
+    load_slots(rp, nr, dv, ev, slow);
+    for (int64_t grp = g_first; grp < ngrp; grp += stride) {
+        const int64_t rb = grp * RS;
+        int dv1, ev1, rp2, nr2;
+        bool slow1;
+        load_slots(rp1, nr1, dv1, ev1, slow1);
+        load_rp(grp + 2 * stride, rp2, nr2);
+        if (slow) {
+            // ---- per-edge path (a source row with more than 4 out-edges: never on a Delaunay scene): lane group 0, one row and edge at a time
+            for (int r = 0; r < nr; ++r) {
+                const int b_ = rl(rp, r), e_ = rl(rp, r + 1);
+                if (fg == 0 && con) {
+#pragma unroll
+                    for (int nb = 0; nb < NBK; ++nb) {
+                        const int c = VW * fn + nb;
+                        const float xv = x[(rb + r) * ldx + c];
+                        float acc = 0.f;
+                        for (int k = b_; k < e_; ++k) {
+                            const int d_ = t_dst[k];
+                            const float* ar = ea + (int64_t)t_eid[k] * lde;
+                            const float dm = __fdiv_rn(da[(int64_t)d_ * ldda + c], (float)max(rowptr_dst[d_ + 1] - rowptr_dst[d_], 1));
+                            if (DX) {
+                                float p_ = be[c];
+                                for (int f = 0; f < FE; ++f) p_ = __fmaf_rn(We[(int64_t)c * FE + f], ar[f], p_);
+                                acc = __fadd_rn(acc, __fmul_rn(dm, p_));
+                            }
+                            const float dph = __fmul_rn(dm, xv);
+                            mine[c * 21 + 20] += dph;
+                            for (int f = 0; f < FE; ++f) mine[c * 21 + f] = __fmaf_rn(dph, ar[f], mine[c * 21 + f]);
+                        }
+                        if (DX) dx[(rb + r) * lddx + c] = (ADD && rb + r < n_add) ? __fadd_rn(acc, add[(rb + r) * ldadd + c]) : acc;
+                    }
+                }
+            }
+        } else {
+        int cn0 = 0, cn1 = 1;
+        if (ev >= 0) {
+            cn0 = rowptr_dst[dv];
+            cn1 = rowptr_dst[dv + 1];
+        }
+        float cf = 1.f, icf = 1.f;
+        bool pow2 = true;
+#pragma unroll
+        for (int eb = 0; eb < EB; ++eb) {
+            if (4 * eb >= nr) break;
+            const int row = 4 * eb + fg;
+            const bool rv = row < nr;
+            // phi's A operand: lane (m = slot 16 eb + n, k = g): attribute 4 ks + g of the slot's edge
+            float fa[5];
+            if (DX) {
+                const int ae = __shfl(ev, 16 * eb + fn);
+#pragma unroll
+                for (int ks = 0; ks < 5; ++ks) fa[ks] = ae >= 0 ? ea[(int64_t)ae * lde + 4 * ks + fg] : 0.f;
+            }
+            int dj[4], ej[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int sl = 16 * eb + 4 * fg + r;
+                dj[r] = __shfl(dv, sl);
+                ej[r] = __shfl(ev, sl);
+            }
+            // dWe's B operand: lane (column n, k = g), k-step r: attribute n -- and 16 + n (1.0 at column 20, zeros behind) -- of slot 4 g + r's edge
+            float b0[4], b1[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* ar = ea + (int64_t)(ej[r] >= 0 ? ej[r] : 0) * lde;
+                b0[r] = ej[r] >= 0 ? ar[fn] : 0.f;
+                b1[r] = (ej[r] >= 0 && fn < 4) ? ar[16 + fn] : (fn == 4 ? 1.f : 0.f);
+            }
+            float gq[4][VW], xq[VW], aq[VW];
+            auto ldv = [&](float* dst, const float* pp) {
+                if constexpr (VW == 4) {
+                    const f32x4m_t t = *reinterpret_cast<const f32x4m_t*>(pp);
+                    dst[0] = t[0], dst[1] = t[1], dst[2] = t[2], dst[3] = t[3];
+                } else {
+                    const float2 t = *reinterpret_cast<const float2*>(pp);
+                    dst[0] = t.x, dst[1] = t.y;
+                }
+            };
+            const int cs = con ? VW * fn : 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ldv(gq[r], da + (int64_t)dj[r] * ldda + cs);
+            ldv(xq, x + (rb + (rv ? row : 0)) * ldx + cs);
+            const bool addrow = ADD && rv && rb + row < n_add;
+            if (ADD) {
+                if (addrow) ldv(aq, add + (rb + row) * ldadd + cs);
+            }
+            if (eb == 0) {
+                // (behind the first block's gathers in program order: the in-degrees were requested in front of them)
+                cf = (float)max(cn1 - cn0, 1);
+                // every in-degree of the step a power of two (4 on a Delaunay scene): dm = da * (1 / cnt) is the division's result exactly
+                pow2 = __all((__builtin_bit_cast(uint32_t, cf) & 0x007FFFFFu) == 0u) != 0;
+                icf = 1.0f / cf;
+            }
+            float cj[4], ij[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int sl = 16 * eb + 4 * fg + r;
+                cj[r] = __shfl(cf, sl);
+                ij[r] = __shfl(icf, sl);
+            }
+            f32x4m_t d[VW];
+            if (DX) {
+                float fwv[VW][5];
+#pragma unroll
+                for (int u = 0; u < VW; ++u) {
+                    const float* fwp = fwbuf + u * 6 * 64 + lane;
+                    const float fb_ = fwp[5 * 64];
+                    d[u] = f32x4m_t{fb_, fb_, fb_, fb_};
+#pragma unroll
+                    for (int ks = 0; ks < 5; ++ks) fwv[u][ks] = fwp[ks * 64];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 5; ++ks)
+#pragma unroll
+                    for (int u = 0; u < VW; ++u) d[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks], fwv[u][ks], d[u], 0, 0, 0);
+            }
+            float dph[VW][4], o[VW];
+#pragma unroll
+            for (int u = 0; u < VW; ++u) {
+                float acc = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = ej[r] >= 0 && con && rv;
+                    const float dm = ok ? (pow2 ? __fmul_rn(gq[r][u], ij[r]) : __fdiv_rn(gq[r][u], cj[r])) : 0.f;
+                    if (DX && ok) acc = __fadd_rn(acc, __fmul_rn(dm, d[u][r]));
+                    dph[u][r] = __fmul_rn(dm, xq[u]);
+                }
+                o[u] = (ADD && addrow) ? __fadd_rn(acc, aq[u]) : acc;
+            }
+            if (DX && rv && con) {
+                float* op = dx + (rb + row) * lddx + cs;
+                if constexpr (VW == 4) *reinterpret_cast<f32x4m_t*>(op) = f32x4m_t{o[0], o[1], o[2], o[3]};
+                else *reinterpret_cast<float2*>(op) = make_float2(o[0], o[1]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int u = 0; u < VW; ++u) {
+                    accW[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(dph[u][r], b0[r], accW[u][0], 0, 0, 0);
+                    accW[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(dph[u][r], b1[r], accW[u][1], 0, 0, 0);
+                }
+        }
+        }
+        rp = rp1, nr = nr1, dv = dv1, ev = ev1, slow = slow1, rp1 = rp2, nr1 = nr2;
+    }
+    // ---- the workgroup's slab [64 channels][21]: accW[nb][blk][r] <-> channel VW (4 g + r) + nb, column n + 16 blk; the four wavefronts' sums in wavefront order
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = VW * (4 * fg + r) + nb;      // (every (c, column) of the slab belongs to exactly one lane and register)
+            mine[c * 21 + fn] += accW[nb][0][r];
+            if (fn < 5) mine[c * 21 + 16 + fn] += accW[nb][1][r];
+        }
+    __syncthreads();
+    constexpr int PER = 64 * 21;
+    float* slab = slabs + (int64_t)blockIdx.x * PER;
+    for (int i = threadIdx.x; i < PER; i += 256) slab[i] = ((smem_[i] + smem_[PER + i]) + smem_[2 * PER + i]) + smem_[3 * PER + i];
+}
+
 inline bool agg_grouped() {   // DGNN_AGG_GROUPED=0: the one-edge-per-instruction kernels for the given-phi backward too
     static const bool on = !(getenv("DGNN_AGG_GROUPED") && getenv("DGNN_AGG_GROUPED")[0] == '0');
     return on;
@@ -849,6 +1237,23 @@ int agg_fwd_t(const int32_t* rowptr, const int32_t* src, const int32_t* eid, int
         return dgnn_check_launch("aggregate_fwd");
     }
     if constexpr (sizeof(T) == 4) {
+        // the filter product on the fp32 matrix cores (k_agg_fwd_m; the bits of k_agg_fwd): rows in 8- / 16-byte pieces per lane.  DGNN_AGG_MFMA=0: the VALU forms
+        // (a training batch's blocks: 28 channels 35.9 -> 27.5 us, 64 channels 22.7 -> 14.0 us; 128 channels 10.1 -> 10.8 us: those keep k_agg_fwd unless DGNN_AGG_MFMA=2)
+        static const bool mfma_on = !(getenv("DGNN_AGG_MFMA") && getenv("DGNN_AGG_MFMA")[0] == '0');
+        static const int mfma_max = getenv("DGNN_AGG_MFMA") && getenv("DGNN_AGG_MFMA")[0] == '2' ? 128 : 64;
+        const int vw = c_in <= 32 ? 2 : 4;
+        if (mfma_on && fused && f_e == 20 && !phi_out && c_in <= mfma_max && c_in % vw == 0 && ldx % vw == 0 && lda % vw == 0 &&
+            (((uintptr_t)x_src | (uintptr_t)a) % (4 * vw)) == 0) {
+            const int rs = c_in <= 32 ? 16 : (c_in <= 64 ? 8 : 4);
+            dim3 mgrid((unsigned)dgnn_grid_cap(dgnn_cdiv(dgnn_cdiv(n_dst, rs), 4), 8));
+            if (c_in <= 32)
+                hipLaunchKernelGGL((k_agg_fwd_m<2>), mgrid, dim3(256), 0, stream, rowptr, src, eid, n_dst, (const float*)x_src, ldx, c_in, edge_attr, lde, We, be, (float*)a, lda);
+            else if (c_in <= 64)
+                hipLaunchKernelGGL((k_agg_fwd_m<4>), mgrid, dim3(256), 0, stream, rowptr, src, eid, n_dst, (const float*)x_src, ldx, c_in, edge_attr, lde, We, be, (float*)a, lda);
+            else
+                hipLaunchKernelGGL((k_agg_fwd_m<8>), mgrid, dim3(256), 0, stream, rowptr, src, eid, n_dst, (const float*)x_src, ldx, c_in, edge_attr, lde, We, be, (float*)a, lda);
+            return dgnn_check_launch("aggregate_fwd");
+        }
         // (measured on a training batch's blocks: 38 -> 31 us at 28 channels, 19 -> 23 us at 64 -- the five replicated attribute loads per lane
         // and 207 registers eat what the wider instructions save; only the narrow first layer takes this form)
         if (fused && f_e == 20 && !phi_out && agg_chunked() && agg_grouped() && c_in % 4 == 0 && c_in <= 32 && rows_of_4<T>(x_src, ldx) && rows_of_4<T>(a, lda) &&
@@ -923,6 +1328,40 @@ int agg_bwd_t(const int32_t* t_rowptr, const int32_t* t_dst, const int32_t* t_ei
         else LAUNCH_G(32);
 #undef LAUNCH_G
         return dgnn_check_launch("aggregate_bwd");
+    }
+    if constexpr (sizeof(T) == 4) {
+        // rows of up to 32 channels (the first conv layer; DGNN_AGG_MFMA=2: up to 64 -- measured 49 us against k_agg_bwd_c's 46.5 on a training batch's 64-wide
+        // layer): the filter's two products on the fp32 matrix cores (k_agg_bwd_mm).  DGNN_AGG_MFMA=0: the VALU form
+        static const bool mfma_on = !(getenv("DGNN_AGG_MFMA") && getenv("DGNN_AGG_MFMA")[0] == '0');
+        static const int mfma_max = getenv("DGNN_AGG_MFMA") && getenv("DGNN_AGG_MFMA")[0] == '2' ? 64 : 32;
+        const int vw = c_in <= 32 ? 2 : 4;
+        auto al = [&](const void* p_, int64_t ld_) { return p_ == nullptr || (((uintptr_t)p_ % (4 * vw)) == 0 && ld_ % vw == 0); };
+        if (mfma_on && fused && f_e == 20 && c_in <= mfma_max && c_in % vw == 0 && !mask_dx && !dphi_out && al(x_src, ldx) && al(da, ldda) && al(dx_src, lddx) &&
+            al(add, ldadd)) {
+            const int rs = c_in <= 32 ? 16 : 8;
+            const int64_t want_m = dgnn_cdiv(dgnn_cdiv(n_src, rs), 4);
+            const int nb_m = (int)(want_m < BWD_BLOCKS ? want_m : BWD_BLOCKS);
+#define LAUNCH_M(NBK_, DXV, ADDV)                                                                                                                     \
+            hipLaunchKernelGGL((k_agg_bwd_mm<NBK_, DXV, ADDV>), dim3(nb_m), dim3(256), 0, stream, t_rowptr, t_dst, t_eid, n_src, rowptr_dst, (const float*)x_src, \
+                               ldx, c_in, edge_attr, lde, We, be, (const float*)da, ldda, (float*)dx_src, lddx, partials, (const float*)add, ldadd, n_add)
+            if (c_in <= 32) {
+                if (!dx_src) LAUNCH_M(2, false, false);
+                else if (add) LAUNCH_M(2, true, true);
+                else LAUNCH_M(2, true, false);
+            } else {
+                if (!dx_src) LAUNCH_M(4, false, false);
+                else if (add) LAUNCH_M(4, true, true);
+                else LAUNCH_M(4, true, false);
+            }
+#undef LAUNCH_M
+            SlabReduceDesc d;
+            d.slabs = partials, d.nblocks = nb_m, d.nchunks = 1, d.per = 64 * 21, d.c_in = c_in, d.fe = 20, d.cpl = 1, d.dWe = dWe, d.dbe = dbe;
+            if (deferred)
+                *deferred = d;
+            else
+                hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)slab_reduce_blocks(d)), dim3(16 * RS_SLICES), 0, stream, d);
+            return dgnn_check_launch("aggregate_bwd");
+        }
     }
     const int64_t want = chunked ? dgnn_cdiv(dgnn_cdiv(n_src, rw), 4) : dgnn_cdiv(n_src, 4);
     const int nblocks = (int)(want < BWD_BLOCKS ? want : BWD_BLOCKS);

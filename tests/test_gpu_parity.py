@@ -157,8 +157,9 @@ def test_aggregate_fused_filter(c_in, f_e):
 
 @pytest.mark.parametrize("c_in,n_src,n_dst", [(28, 5000, 1777), (64, 900, 600), (32, 70, 70), (128, 800, 500)])
 def test_lane_group_fused_filter_forward_gives_the_bits_of_the_lane_per_channel_kernel(c_in, n_src, n_dst):
-    """k_agg_fwd_g20 (rows of up to 32 channels, 4 channels per lane, 8 destination rows per wavefront instruction) against k_agg_fwd (taken when
-    the row stride of x is no multiple of 4): the aggregate bit for bit, regular and ragged in-degrees; wider rows keep the old kernel either way"""
+    """k_agg_fwd_m (round 6: the filter product on the fp32 matrix cores, 4 edge slots per destination row; DGNN_AGG_MFMA=0: k_agg_fwd_g20 -- rows of up
+    to 32 channels, 4 channels per lane, 8 destination rows per wavefront instruction) against k_agg_fwd (taken when the row stride of x is no multiple
+    of 4): the aggregate bit for bit; regular, ragged (a row of more than 4 in-edges sends its step to the per-edge path) and thinned in-degrees"""
     from dgnn_amd import ops
     if os.environ.get("DGNN_AGG_CHUNKED") == "0" or os.environ.get("DGNN_AGG_GROUPED") == "0":
         pytest.skip("compares the two default kernels")
@@ -172,7 +173,8 @@ def test_lane_group_fused_filter_forward_gives_the_bits_of_the_lane_per_channel_
     ei = torch.stack([torch.randint(0, n_src, (E,), generator=g), torch.arange(n_dst).repeat_interleave(4)])
     ei2 = torch.stack([torch.randint(0, n_src, (E,), generator=g), torch.randint(0, n_dst, (E,), generator=g)])
     ei2[1, : E // 4] = ei2[1, : E // 4] % 11
-    for edges in (ei, ei2):
+    ei3 = ei[:, torch.rand(E, generator=g) < 0.7]        # in-degrees 0 .. 4: the matrix-core form's partly filled edge slots (k_agg_fwd_m, round 6)
+    for edges in (ei, ei2, ei3):
         rp, src, eid = ops.plan_build(edges.to(DEV), n_dst, 1)
         a_g = ops.aggregate_fwd(rp, src, eid, n_dst, x, ea, We, be)
         a_c = ops.aggregate_fwd(rp, src, eid, n_dst, xw[:, :c_in], ea, We, be)
@@ -289,6 +291,63 @@ def test_aggregate_backward_with_addend_matches_the_two_steps(c_in, n_src, n_dst
     want[:n_add] += add
     assert torch.equal(dx1, want)
     assert torch.equal(dWe1, dWe0) and torch.equal(dbe1, dbe0)
+
+
+@pytest.mark.parametrize("c_in", [28, 64, 32, 48, 20])
+@pytest.mark.parametrize("graph", ["tets", "thinned", "ragged"])
+def test_aggregate_backward_on_the_matrix_cores(c_in, graph):
+    """k_agg_bwd_mm (round 6: rows of up to 64 channels; the filter's recomputation and dWe = dphi^T . [A | 1] as v_mfma_f32_16x16x4_f32, 4 out-edge
+    slots per source row) against k_agg_bwd_c (taken when the row stride of x is no multiple of 2 / 4) and against fp64: dx bit for bit (the same
+    chains: phi's bias-then-attributes fmaf chain, da / in-degree, the slot-ordered sum), dWe / dbe at fp32 rounding level of their sums (another
+    order).  tets: every degree 4; thinned: degrees 0..4 (partly filled slots, in-degrees that are no power of two: the division); ragged: sources with
+    dozens of out-edges (the per-edge path).  With and without dx, with the addend.  (DGNN_AGG_MFMA=0: both sides run k_agg_bwd_c.)"""
+    from dgnn_amd import ops
+    from dgnn_amd.synthetic import delaunay_tet_graph
+    g = torch.Generator().manual_seed(c_in)
+    adj, _, _ = delaunay_tet_graph(700, seed=c_in)
+    n = adj.shape[0] // 4
+    ei = torch.from_numpy(adj.T.astype(np.int64))
+    if graph == "thinned":
+        ei = ei[:, torch.rand(ei.size(1), generator=g) < 0.7]
+    elif graph == "ragged":
+        ei = ei.clone()
+        ei[0, : ei.size(1) // 3] = ei[0, : ei.size(1) // 3] % 37
+    E = ei.size(1)
+    n_src = n_dst = n
+    x, da, ea = torch.randn(n_src, c_in, generator=g), torch.randn(n_dst, c_in, generator=g), torch.randn(E, 20, generator=g)
+    We, be = torch.randn(c_in, 20, generator=g) * 0.3, torch.randn(c_in, generator=g)
+    add = torch.randn(n_dst - 5, c_in, generator=g)
+    # fp64 reference through autograd
+    xd, Wd, bd = x.double().requires_grad_(), We.double().requires_grad_(), be.double().requires_grad_()
+    phi = ea.double() @ Wd.t() + bd
+    deg = torch.bincount(ei[1], minlength=n_dst).clamp_min(1).double()
+    a = torch.zeros(n_dst, c_in, dtype=torch.float64).index_add_(0, ei[1], xd[ei[0]] * phi) / deg[:, None]
+    (a * da.double()).sum().backward()
+    rowptr, _, _ = ops.plan_build(ei.to(DEV), n_dst, 1)
+    t_rowptr, t_dst, t_eid = ops.plan_build(ei.to(DEV), n_src, 0)
+    dev = lambda t: t.to(DEV)
+    x_d, da_d, ea_d, We_d, be_d, add_d = dev(x), dev(da), dev(ea), dev(We), dev(be), dev(add)
+    xw = torch.zeros(n_src, c_in + 1, device=DEV)
+    xw[:, :c_in] = x_d
+    dx_m, dWe_m, dbe_m, _ = ops.aggregate_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr, x_d, da_d, ea_d, We_d, be_d)
+    dx_c, dWe_c, dbe_c, _ = ops.aggregate_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr, xw[:, :c_in], da_d, ea_d, We_d, be_d)
+    assert torch.equal(dx_m, dx_c)
+    assert rel_err(dx_m, xd.grad) < 2e-6
+    for got, old, ref in ((dWe_m, dWe_c, Wd.grad), (dbe_m, dbe_c, bd.grad)):
+        scale = ref.abs().max().item()
+        assert (got.double().cpu() - ref).abs().max().item() <= 3e-6 * scale, graph
+        assert (got - old).abs().max().item() <= 3e-6 * scale
+    # no dx (the first layer's form): the same parameter gradients as with dx
+    none, dWe_n, dbe_n, _ = ops.aggregate_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr, x_d, da_d, ea_d, We_d, be_d, need_dx=False)
+    assert none is None and torch.equal(dWe_n, dWe_m) and torch.equal(dbe_n, dbe_m)
+    # the addend folded into the dx store
+    dx_a, dWe_a, dbe_a = ops.aggregate_bwd_add(t_rowptr, t_dst, t_eid, n_src, rowptr, x_d, da_d, ea_d, We_d, be_d, add_d)
+    want = dx_m.clone()
+    want[:add_d.size(0)] += add_d
+    assert torch.equal(dx_a, want) and torch.equal(dWe_a, dWe_m) and torch.equal(dbe_a, dbe_m)
+    # twice the same bits (accumulators and slabs in a fixed order)
+    dx_2, dWe_2, dbe_2, _ = ops.aggregate_bwd(t_rowptr, t_dst, t_eid, n_src, rowptr, x_d, da_d, ea_d, We_d, be_d)
+    assert torch.equal(dx_2, dx_m) and torch.equal(dWe_2, dWe_m) and torch.equal(dbe_2, dbe_m)
 
 
 def test_batchnorm_train_eval_and_backward():
