@@ -796,7 +796,7 @@ def main():
         try:
             settle(step)
             dt_x, ps_x = timed_steps(step, args.steps, sync, world, dev)
-            extras["exact_f32"] = {"gemm": "fp32 matrix cores (v_mfma_f32_32x32x2_f32), bit-faithful fmaf chains: --gemm-mode f32", "ms_per_step": round(dt_x / args.steps * 1e3, 4),
+            extras["exact_f32"] = {"gemm": "fp32 matrix cores (dense product v_mfma_f32_32x32x2_f32, filter product v_mfma_f32_16x16x4_f32), bit-faithful fmaf chains: --gemm-mode f32", "ms_per_step": round(dt_x / args.steps * 1e3, 4),
                                    "ms_per_step_median": round(float(np.median(ps_x)), 4), "value": round(n_total * args.steps / dt_x, 1), "_logits": (cell_order.to_file(step()) if cell_order is not None else step()).float().cpu()}
             # its own roofline: this leg is matrix-core work in the reference's own arithmetic -- algorithmic FLOPs of the whole path
             # (lin_e on 4 edges, the product-sum, lin_j + lin_i per conv layer; the decoder's two Linears) against the fp32-input MFMA peak
@@ -804,7 +804,7 @@ def main():
             fl_tet = sum(layer_flops(a_, b_) for a_, b_ in zip(cs_x[:-1], cs_x[1:])) + 2 * cs_x[-1] * 64 + 2 * 64 * 2
             tf_x = fl_tet * extras["exact_f32"]["value"] / 1e12
             extras["exact_f32"]["roofline"] = {"bound": "mfma", "achieved": round(tf_x, 1), "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf_x / FP32_MATRIX_PEAK_TF, 4),
-                                               "algorithmic_flops_per_tet": int(fl_tet), "kernel": "k_sage_fused_mfma<...> in --gemm-mode f32 (all four conv launches + decoder)",
+                                               "algorithmic_flops_per_tet": int(fl_tet), "kernel": "k_sage_fused<CIN,COUT,0,1> in --gemm-mode f32 (all four conv launches) + k_decoder_rows",
                                                "hbm_frac": round(extras["exact_f32"]["value"] * path_bytes(28, cs_x[1:], 4) / 1e9 / HBM_PEAK_GBS, 4)}
         finally:
             ops.GEMM_MODE = old_mode
