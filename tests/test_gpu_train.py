@@ -692,7 +692,9 @@ def test_updated_direct_training_step_equals_the_autograd_step(dtype):
                     assert torch.equal(got[0], l2) and torch.equal(got[1], s2) and torch.equal(got[2], g2)
                     return got[0], got[2]
                 loss = net.train_step_direct(d, loss_fn)
-                assert loss is not None
+                if loss is None:
+                    pytest.skip("this configuration does not take the one-call form (DGNN_TRAIN_COMPOSITE / DGNN_CHAIN_DENSE / DGNN_UPDATED_STACK / "
+                                "DGNN_UPDATED_TAIL_IN_CALL select the per-layer calls): train_step_direct steps aside, the Trainer runs forward() + backward()")
             else:
                 opt.zero_grad()
                 loss, _ = Fn.kl_cell_loss(net(d).float(), by, vol)
