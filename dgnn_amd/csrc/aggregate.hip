@@ -814,14 +814,6 @@ __global__ void __launch_bounds__(256) k_agg_fwd_m(const int32_t* __restrict__ r
     constexpr int VW = NBK < 4 ? NBK : 4, NSEG = NBK / VW, EB = 8 / NBK, RS = 4 * EB, FE = 20;
     __shared__ float fwbuf[NBK * 6 * 64];      // [16-channel block][5 k-steps + bias][lane]: B operand We[chan][4 ks + g], C input be[chan]
     const int lane = lane_id(), fn = lane & 15, fg = lane >> 4;
-    for (int e = threadIdx.x; e < NBK * 6 * 64; e += 256) {
-        const int ln = e & 63, nk = e >> 6, nb = nk / 6, ks = nk - 6 * nb;
-        const int c = 64 * (nb / VW) + VW * (ln & 15) + nb % VW;
-        float v = 0.f;
-        if (c < c_in) v = ks < 5 ? We[(int64_t)c * FE + 4 * ks + (ln >> 4)] : be[c];
-        fwbuf[e] = v;
-    }
-    __syncthreads();
     const int64_t ngrp = (n_dst + RS - 1) / RS, stride = (int64_t)gridDim.x * 4;
     // index pipeline: a step's row pointers are requested two steps ahead, its slots' sources / edge ids one step ahead -- they arrive in the shadow of
     // the step before's row gathers, so a step exposes ONE memory round trip (its gathers), not three
@@ -854,6 +846,15 @@ __global__ void __launch_bounds__(256) k_agg_fwd_m(const int32_t* __restrict__ r
     load_rp(g_first, rp, nr);
     load_rp(g_first + stride, rp1, nr1);
     load_slots(rp, nr, sv, ev, slow);
+    // the filter operand (filled behind the first index requests: its loads travel with theirs)
+    for (int e = threadIdx.x; e < NBK * 6 * 64; e += 256) {
+        const int ln = e & 63, nk = e >> 6, nb = nk / 6, ks = nk - 6 * nb;
+        const int c = 64 * (nb / VW) + VW * (ln & 15) + nb % VW;
+        float v = 0.f;
+        if (c < c_in) v = ks < 5 ? We[(int64_t)c * FE + 4 * ks + (ln >> 4)] : be[c];
+        fwbuf[e] = v;
+    }
+    __syncthreads();
     for (int64_t grp = g_first; grp < ngrp; grp += stride) {
         const int64_t rb = grp * RS;
         int sv1, ev1, rp2, nr2;
@@ -977,16 +978,6 @@ __global__ void __launch_bounds__(256) k_agg_bwd_mm(const int32_t* __restrict__ 
     const int lane = lane_id(), fn = lane & 15, fg = lane >> 4, wv = wave_id_uniform();
     float* const mine = smem_ + wv * (64 * 21);
     for (int i = lane; i < 64 * 21; i += 64) mine[i] = 0.f;
-    if (DX) {
-        for (int e = threadIdx.x; e < NBK * 6 * 64; e += 256) {
-            const int ln = e & 63, nk = e >> 6, nb = nk / 6, ks = nk - 6 * nb;
-            const int c = VW * (ln & 15) + nb;
-            float v = 0.f;
-            if (c < c_in) v = ks < 5 ? We[(int64_t)c * FE + 4 * ks + (ln >> 4)] : be[c];
-            fwbuf[e] = v;
-        }
-        __syncthreads();
-    }
     f32x4m_t accW[NBK][2];
 #pragma unroll
     for (int nb = 0; nb < NBK; ++nb) accW[nb][0] = accW[nb][1] = f32x4m_t{0.f, 0.f, 0.f, 0.f};
@@ -1023,6 +1014,17 @@ __global__ void __launch_bounds__(256) k_agg_bwd_mm(const int32_t* __restrict__ 
     load_rp(g_first, rp, nr);
     load_rp(g_first + stride, rp1, nr1);
     load_slots(rp, nr, dv, ev, slow);
+    // the filter operand (filled behind the first index requests: its loads travel with theirs)
+    if (DX) {
+        for (int e = threadIdx.x; e < NBK * 6 * 64; e += 256) {
+            const int ln = e & 63, nk = e >> 6, nb = nk / 6, ks = nk - 6 * nb;
+            const int c = VW * (ln & 15) + nb;
+            float v = 0.f;
+            if (c < c_in) v = ks < 5 ? We[(int64_t)c * FE + 4 * ks + (ln >> 4)] : be[c];
+            fwbuf[e] = v;
+        }
+        __syncthreads();
+    }
     for (int64_t grp = g_first; grp < ngrp; grp += stride) {
         const int64_t rb = grp * RS;
         int dv1, ev1, rp2, nr2;
