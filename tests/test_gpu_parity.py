@@ -155,7 +155,7 @@ def test_aggregate_fused_filter(c_in, f_e):
     assert rel_err(phi, phi64) < 2e-6
 
 
-@pytest.mark.parametrize("c_in,n_src,n_dst", [(28, 5000, 1777), (64, 900, 600), (32, 70, 70), (128, 800, 500)])
+@pytest.mark.parametrize("c_in,n_src,n_dst", [(28, 5000, 1777), (64, 900, 600), (32, 70, 70), (128, 800, 500), (48, 300, 203), (20, 64, 5), (64, 9, 1), (28, 40, 17)])
 def test_lane_group_fused_filter_forward_gives_the_bits_of_the_lane_per_channel_kernel(c_in, n_src, n_dst):
     """k_agg_fwd_m (round 6: the filter product on the fp32 matrix cores, 4 edge slots per destination row; DGNN_AGG_MFMA=0: k_agg_fwd_g20 -- rows of up
     to 32 channels, 4 channels per lane, 8 destination rows per wavefront instruction) against k_agg_fwd (taken when the row stride of x is no multiple
@@ -294,17 +294,17 @@ def test_aggregate_backward_with_addend_matches_the_two_steps(c_in, n_src, n_dst
 
 
 @pytest.mark.parametrize("c_in", [28, 64, 32, 48, 20])
-@pytest.mark.parametrize("graph", ["tets", "thinned", "ragged"])
+@pytest.mark.parametrize("graph", ["tets", "thinned", "ragged", "tiny"])
 def test_aggregate_backward_on_the_matrix_cores(c_in, graph):
     """k_agg_bwd_mm (round 6: rows of up to 64 channels; the filter's recomputation and dWe = dphi^T . [A | 1] as v_mfma_f32_16x16x4_f32, 4 out-edge
     slots per source row) against k_agg_bwd_c (taken when the row stride of x is no multiple of 2 / 4) and against fp64: dx bit for bit (the same
     chains: phi's bias-then-attributes fmaf chain, da / in-degree, the slot-ordered sum), dWe / dbe at fp32 rounding level of their sums (another
     order).  tets: every degree 4; thinned: degrees 0..4 (partly filled slots, in-degrees that are no power of two: the division); ragged: sources with
-    dozens of out-edges (the per-edge path).  With and without dx, with the addend.  (DGNN_AGG_MFMA=0: both sides run k_agg_bwd_c.)"""
+    dozens of out-edges (the per-edge path); tiny: a few dozen cells.  With and without dx, with the addend.  (DGNN_AGG_MFMA=0: both sides run k_agg_bwd_c.)"""
     from dgnn_amd import ops
     from dgnn_amd.synthetic import delaunay_tet_graph
     g = torch.Generator().manual_seed(c_in)
-    adj, _, _ = delaunay_tet_graph(700, seed=c_in)
+    adj, _, _ = delaunay_tet_graph(12 if graph == "tiny" else 700, seed=c_in)      # tiny: a few dozen cells -- one partly filled step
     n = adj.shape[0] // 4
     ei = torch.from_numpy(adj.T.astype(np.int64))
     if graph == "thinned":
