@@ -800,8 +800,8 @@ __global__ void __launch_bounds__(256) k_agg_fwd_g20(const int32_t* __restrict__
 // =====================================================================================================================
 // Fused-filter aggregate, fp32 rows, 20 attributes, the filter product on the fp32 matrix cores (round 6).  phi = We . A + be as
 // v_mfma_f32_16x16x4_f32 with the bias as the C input and the attributes ascending is, per (edge, channel), the fmaf chain of k_agg_fwd -- the same bits
-// (tests/test_gpu_parity.py: ..._is_the_fmaf_chain, measured on the exact-fp32 fused layers first) -- at 32 multiply-adds per clock and SIMD against the
-// VALU's 16, with no 20 x 64 weights in registers.  A wavefront step takes 4 EB destination rows; every row gets 4 edge slots (a tetrahedron has 4
+// (tests/test_gpu_parity.py: ..._is_the_fmaf_chain, measured on the exact-fp32 fused layers first) -- at the matrix pipe's 32 multiply-adds per clock and SIMD, a rate
+// the VALU form's dependent fmaf chains do not reach (nominally the same; fused.hip: 3.9 cycles per VALU instruction measured), with no 20 x 64 weights in registers.  A wavefront step takes 4 EB destination rows; every row gets 4 edge slots (a tetrahedron has 4
 // neighbours; a step with a row of more than 4 in-edges takes the per-edge path); lane (n = lane & 15, g = lane >> 4) owns, of row 4 eb + g and of that
 // row's 4 neighbour rows, the channels chan(nb, n) = 64 (nb / VW) + VW n + nb % VW (whole cache lines per load instruction), and the C/D layout hands it
 // phi of exactly those 4 edges x those channels: the in-order sum over the edges is in-lane.
@@ -956,7 +956,7 @@ __global__ void __launch_bounds__(256) k_agg_fwd_m(const int32_t* __restrict__ r
     }
 }
 
-// The backward of the same form (fp32 rows of up to 64 channels; wider rows keep k_agg_bwd_c, whose packed fused multiply-adds run at the matrix cores'
+// The backward of the same form (fp32 rows of up to 64 channels; wider rows keep k_agg_bwd_c, whose packed fused multiply-adds run at least at the matrix cores'
 // fp32 rate).  A step = 4 EB SOURCE rows x 4 out-edge slots.  Per 16 slots and 16 channels:
 //   phi (DX only) as in the forward: 5 matrix instructions, the bits of the VALU chain; lane (n, g) receives phi of row 4 eb + g's 4 out-edges x its channels
 //   dm = da[dst(slot)] / in-degree(dst) (a multiplication by the exact reciprocal when every in-degree of the step is a power of two, else the division),

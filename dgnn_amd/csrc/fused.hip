@@ -85,7 +85,9 @@ struct FusedCfg {
 };
 
 // FM (MODE 0 only; round 6): the filter product phi = We . A + be on the fp32 matrix cores too (v_mfma_f32_16x16x4_f32) instead of 20 FMAs per channel
-// and edge on the VALU.  fp32 MFMA and fp32 VALU time ADD on a SIMD (header), and the matrix pipe does 32 MACs per clock against the VALU's 16: the
+// and edge on the VALU.  fp32 MFMA and fp32 VALU time ADD on a SIMD (header); nominally both pipes do 32 multiply-adds per clock (SIMD-32), but measured on
+// the 128 -> 128 layer the 153 M VALU instructions per 1M tets this removes cost 3.9 SIMD cycles each (dependent fmaf chains at two wavefronts per SIMD
+// run at half the issue rate; SQ_ACTIVE_INST_VALU says the same) against 32 cycles for each of the 10 M matrix instructions that replace them: the
 // wave's 16 edges (4 tets) x 16 channels x 4 attributes per instruction, C input = the bias, k ascending -- the same fmaf chain per (edge, channel) as the
 // VALU form (be, then attributes 0..19 in order).  The C/D layout puts the 4 in-edges of tet g = lane >> 4 into the 4 accumulator registers of the lanes
 // (., g): the in-order 4-term sum with the neighbour rows is in-lane, as in the fp16 kernels.  Lane (n = lane & 15, g) owns, of tet g's rows, the channels
